@@ -1,0 +1,79 @@
+"""ctypes binding of libhulkhip.so (the C ABI declared in include/hulk_hip.h).
+
+The library is built in-tree (hulk_amd/csrc/Makefile).  There is NO fallback: if the shared
+object is missing or no gfx950 GPU is usable, importing/creating fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhulkhip.so")
+
+HULK_OK = 0
+HULK_CWS_GO_COMPAT = 0
+HULK_CWS_EXTERNAL = 1
+
+# every symbol include/hulk_hip.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = (
+    "hulk_abi_version", "hulk_strerror", "hulk_last_error", "hulk_create", "hulk_destroy",
+    "hulk_set_stream", "hulk_set_cws_tables", "hulk_add_reads", "hulk_add_reads_device",
+    "hulk_bin_reads_device", "hulk_histogram_device", "hulk_add_histogram", "hulk_flush",
+    "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
+    "hulk_get_cws_tables", "hulk_set_profiling", "hulk_get_profile",
+)
+
+
+class HulkParams(ctypes.Structure):
+    _fields_ = [
+        ("k", ctypes.c_uint32), ("w", ctypes.c_uint32), ("sketch_size", ctypes.c_uint32),
+        ("num_bins", ctypes.c_int32), ("decay_ratio", ctypes.c_double),
+        ("interval", ctypes.c_uint32), ("device", ctypes.c_int32),
+        ("slot_begin", ctypes.c_uint32), ("slot_count", ctypes.c_uint32),
+        ("cws_source", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 5),
+    ]
+
+
+class HulkError(RuntimeError):
+    """Carries the message the reference would have passed to log.Fatalf("ERROR---> %v")."""
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+        self.message = message
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C hulk_amd/csrc` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). hulk_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u64, u32, i32, dbl = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.c_double
+    L.hulk_abi_version.restype = ctypes.c_int
+    L.hulk_strerror.restype = ctypes.c_char_p; L.hulk_strerror.argtypes = [ctypes.c_int]
+    L.hulk_last_error.restype = ctypes.c_char_p; L.hulk_last_error.argtypes = [vp]
+    L.hulk_create.restype = ctypes.c_int; L.hulk_create.argtypes = [ctypes.POINTER(HulkParams), ctypes.POINTER(vp)]
+    L.hulk_destroy.restype = None; L.hulk_destroy.argtypes = [vp]
+    L.hulk_set_stream.restype = ctypes.c_int; L.hulk_set_stream.argtypes = [vp, vp]
+    L.hulk_set_cws_tables.restype = ctypes.c_int; L.hulk_set_cws_tables.argtypes = [vp, vp, vp, vp]
+    L.hulk_add_reads.restype = ctypes.c_int; L.hulk_add_reads.argtypes = [vp, vp, vp, u64]
+    L.hulk_add_reads_device.restype = ctypes.c_int; L.hulk_add_reads_device.argtypes = [vp, vp, vp, u64, u32, u64]
+    L.hulk_bin_reads_device.restype = ctypes.c_int; L.hulk_bin_reads_device.argtypes = [vp, vp, vp, u64, u32, u64]
+    L.hulk_histogram_device.restype = vp; L.hulk_histogram_device.argtypes = [vp]
+    L.hulk_add_histogram.restype = ctypes.c_int; L.hulk_add_histogram.argtypes = [vp, vp]
+    L.hulk_flush.restype = ctypes.c_int; L.hulk_flush.argtypes = [vp]
+    L.hulk_finish.restype = ctypes.c_int; L.hulk_finish.argtypes = [vp]
+    L.hulk_get_sketch.restype = ctypes.c_int; L.hulk_get_sketch.argtypes = [vp, vp, vp]
+    L.hulk_get_counters.restype = ctypes.c_int; L.hulk_get_counters.argtypes = [vp, vp, vp, vp]
+    L.hulk_get_histogram.restype = ctypes.c_int; L.hulk_get_histogram.argtypes = [vp, vp]
+    L.hulk_get_cms.restype = ctypes.c_int; L.hulk_get_cms.argtypes = [vp, vp]
+    L.hulk_get_cws_tables.restype = ctypes.c_int; L.hulk_get_cws_tables.argtypes = [vp, vp, vp, vp]
+    L.hulk_set_profiling.restype = ctypes.c_int; L.hulk_set_profiling.argtypes = [vp, ctypes.c_int]
+    L.hulk_get_profile.restype = ctypes.c_int; L.hulk_get_profile.argtypes = [vp, ctypes.c_char_p, vp, vp]
+    _lib = L
+    return L

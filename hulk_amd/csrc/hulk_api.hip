@@ -1,0 +1,501 @@
+// hulk_api.hip — the C ABI of libhulkhip.so (see include/hulk_hip.h for the reference seam each
+// entry point replaces).  Host-side orchestration only: every numeric step of the path runs in
+// the kernels of hulk_kernels.hip; there is no CPU fallback.
+#include "../../include/hulk_hip.h"
+#include "hulk_internal.h"
+#include "cws_gen.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hulk;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+const char *err_text(int status) {
+    switch (status) {
+        case HULK_OK: return "";
+        case HULK_ERR_W: return "w must be: 0 < w < 257";
+        case HULK_ERR_K: return "k size must be: 0 < k < 32";
+        case HULK_ERR_EMPTY_SEQ: return "sequence length must be > 0";
+        case HULK_ERR_SHORT_SEQ: return "sequence length must be >= w + k - 1";
+        case HULK_ERR_FEW_BINS: return "not used yet";
+        case HULK_ERR_HS_K: return "histosketching only supports k <= 31";
+        case HULK_ERR_DECAY: return "decay ratio must be between 0.0 and 1.0";
+        case HULK_ERR_BINS: return "histogram must have at least 2 bins";
+        case HULK_ERR_NEG_BINS: return "negative value used for number of k-mer spectrum bins";
+        case HULK_ERR_NO_SEQ: return "no sequences received";
+        case HULK_ERR_ARG: return "invalid argument";
+        case HULK_ERR_HIP: return "HIP runtime error";
+        case HULK_ERR_NO_DEVICE: return "no usable HIP device (libhulkhip needs an AMD gfx950 GPU)";
+        case HULK_ERR_READ_TOO_LONG: return "read longer than the per-read limit of this build";
+        case HULK_ERR_STATE: return "call not valid in this state";
+        default: return "unknown error";
+    }
+}
+
+// helpers.Pow (src/helpers/helpers.go:18-28)
+uint64_t ipow(uint64_t a, uint64_t b) {
+    uint64_t p = 1;
+    while (b > 0) { if (b & 1) p *= a; b >>= 1; a *= a; }
+    return p;
+}
+
+// go-jump on the host, only for building the static count-min chain tables
+int32_t jump_host(uint64_t key, int64_t n) {
+    int64_t b = -1, j = 0;
+    if (n <= 0) n = 1;
+    while (j < n) {
+        b = j;
+        key = key * 2862933555777941757ull + 1;
+        j = (int64_t)((double)(b + 1) * ((double)(1LL << 31) / (double)((key >> 33) + 1)));
+    }
+    return (int32_t)b;
+}
+
+struct ProfileRec { hipEvent_t a, b; };
+
+}  // namespace
+
+struct hulk_ctx {
+    hulk_params p{};
+    int32_t B = 0;
+    uint32_t S = 0, slot_begin = 0, slots = 0;
+    int cms_depth = 0, cms_width = 0;
+    int ntiles = 0; size_t row_stride = 0;
+    bool drift = false;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // device state
+    DevState *d_state = nullptr;
+    uint32_t *d_hist = nullptr, *d_hist_tmp = nullptr;
+    uint32_t *d_perm = nullptr, *d_chain_start = nullptr;
+    unsigned long long *d_ctr = nullptr, *d_est = nullptr, *d_mins = nullptr;
+    double *d_f64 = nullptr, *d_weights = nullptr, *d_rcb = nullptr;
+    float *d_rcp32 = nullptr, *d_k32 = nullptr, *d_tilemin = nullptr;
+    // staging for host reads
+    uint8_t *d_bases = nullptr; size_t d_bases_cap = 0;
+    uint64_t *d_offsets = nullptr; size_t d_offsets_cap = 0;
+    // host-side run state
+    uint64_t seq_count = 0, flush_index = 0;
+    bool tables_ready = false, finished = false, hist_hook_used = false;
+    int sticky = HULK_OK;
+    std::string last_error;
+    bool profiling = false;
+    std::vector<ProfileRec> prof;
+};
+
+namespace {
+
+int fail(hulk_ctx *c, int status, const std::string &extra = std::string()) {
+    std::string msg = err_text(status);
+    if (!extra.empty()) msg += ": " + extra;
+    if (c) c->last_error = msg; else g_create_error = msg;
+    return status;
+}
+int fail_hip(hulk_ctx *c, hipError_t e, const char *what) {
+    return fail(c, HULK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(c, call)                                             \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail_hip((c), e_, #call); } while (0)
+
+template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, n ? n * sizeof(T) : sizeof(T)); }
+
+// static chain tables for the count-min prefix sums: for row d, bins grouped by counter
+// position g = jump(bin*(d+1), width) (countmin.go:122-125), ascending bin inside a group.
+int build_chains(hulk_ctx *c) {
+    const int D = c->cms_depth, W = c->cms_width; const int32_t B = c->B;
+    std::vector<uint32_t> perm((size_t)D * B), start((size_t)D * (W + 1)), pos(B);
+    for (int d = 0; d < D; d++) {
+        std::vector<uint32_t> cnt(W + 1, 0);
+        for (int32_t b = 0; b < B; b++) {
+            uint64_t h = (uint64_t)b + (uint64_t)d * (uint64_t)b;
+            pos[b] = (uint32_t)jump_host(h, W);
+            cnt[pos[b] + 1]++;
+        }
+        for (int g = 0; g < W; g++) cnt[g + 1] += cnt[g];
+        for (int g = 0; g <= W; g++) start[(size_t)d * (W + 1) + g] = cnt[g];
+        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+        for (int32_t b = 0; b < B; b++) perm[(size_t)d * B + cur[pos[b]]++] = (uint32_t)b;
+    }
+    HIPCHK(c, dalloc(&c->d_perm, perm.size()));
+    HIPCHK(c, dalloc(&c->d_chain_start, start.size()));
+    HIPCHK(c, hipMemcpy(c->d_perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_chain_start, start.data(), start.size() * 4, hipMemcpyHostToDevice));
+    return HULK_OK;
+}
+
+// upload r,c,b rows owned by this context as interleaved {r,c,b} and derive the fp32 K table
+int install_tables(hulk_ctx *c, const double *r, const double *cc, const double *b) {
+    const size_t B = (size_t)c->B;
+    std::vector<double> row(B * 3);
+    for (uint32_t s = 0; s < c->slots; s++) {
+        const size_t src = (size_t)(c->slot_begin + s) * B;
+        for (size_t j = 0; j < B; j++) { row[j * 3] = r[src + j]; row[j * 3 + 1] = cc[src + j]; row[j * 3 + 2] = b[src + j]; }
+        HIPCHK(c, hipMemcpy(c->d_rcb + (size_t)s * B * 3, row.data(), B * 3 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIPCHK(c, launch_build_k32(c->stream, c->d_rcb, c->d_k32, (int)c->slots, c->B, c->row_stride));
+    c->tables_ready = true;
+    return HULK_OK;
+}
+
+// newCWS (histosketch.go:95-126) with the Go-compatible generators, streamed row by row
+int generate_tables(hulk_ctx *c) {
+    const size_t B = (size_t)c->B;
+    CwsGenerator gen;
+    std::vector<double> row(B * 3);
+    for (uint32_t s = 0; s < c->S; s++) {
+        gen.next_row(row.data(), B);
+        if (s >= c->slot_begin && s < c->slot_begin + c->slots)
+            HIPCHK(c, hipMemcpyAsync(c->d_rcb + (size_t)(s - c->slot_begin) * B * 3, row.data(),
+                                     B * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // row buffer is reused
+        if (s + 1 == c->slot_begin + c->slots) break; // later rows are not needed by this shard
+    }
+    HIPCHK(c, launch_build_k32(c->stream, c->d_rcb, c->d_k32, (int)c->slots, c->B, c->row_stride));
+    c->tables_ready = true;
+    return HULK_OK;
+}
+
+int ensure_tables(hulk_ctx *c) {
+    if (c->tables_ready) return HULK_OK;
+    if (c->p.cws_source == HULK_CWS_EXTERNAL)
+        return fail(c, HULK_ERR_STATE, "cws_source is EXTERNAL but hulk_set_cws_tables was not called");
+    return generate_tables(c);
+}
+
+// kernel configuration by read length: {xcap, table, block threads}
+bool pick_config(uint32_t k, uint32_t max_len, MinimizerParams &P, int &threads) {
+    const uint32_t npos = max_len >= k ? max_len - k + 1 : 1;
+    if (npos <= 192) { P.xcap = 192; P.tab_size = 256; threads = 256; return true; }
+    if (npos <= 1024) { P.xcap = 1024; P.tab_size = 2048; threads = 64; return true; }
+    if (npos <= 4096) { P.xcap = 4096; P.tab_size = 8192; threads = 64; return true; }
+    return false;
+}
+
+int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
+              uint32_t max_len, uint64_t bases_bytes) {
+    MinimizerParams P{};
+    P.k = c->p.k; P.w = c->p.w; P.num_bins = c->B; P.bases_bytes = bases_bytes;
+    int threads = 256;
+    if (!pick_config(c->p.k, max_len, P, threads)) return fail(c, HULK_ERR_READ_TOO_LONG);
+    HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, c->d_hist, c->d_state));
+    return HULK_OK;
+}
+
+int do_flush(hulk_ctx *c) {
+    int rc = ensure_tables(c);
+    if (rc != HULK_OK) return rc;
+    const int parity = (int)(c->flush_index & 1);
+    hipStream_t s = c->stream;
+    HIPCHK(c, launch_count_used(s, c->d_hist, c->B, c->d_state, parity));
+    HIPCHK(c, launch_cms_chains(s, c->d_hist, c->d_perm, c->d_chain_start, c->d_ctr, c->d_est, c->B,
+                                c->cms_depth, c->cms_width, c->d_state, parity));
+    HIPCHK(c, launch_freq(s, c->d_hist, c->d_est, c->d_f64, c->d_rcp32, c->B, c->cms_depth, c->d_state, parity));
+    if (c->slots) {
+        ProfileRec pr{};
+        if (c->profiling) {
+            HIPCHK(c, hipEventCreate(&pr.a)); HIPCHK(c, hipEventCreate(&pr.b));
+            HIPCHK(c, hipEventRecord(pr.a, s));
+        }
+        HIPCHK(c, launch_cws_scan(s, c->d_k32, c->d_rcp32, c->d_tilemin, (int)c->slots, c->ntiles,
+                                  c->row_stride, c->B, c->d_state, parity));
+        if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
+        HIPCHK(c, launch_cws_resolve(s, c->d_rcb, c->d_f64, c->d_tilemin, c->d_mins, c->d_weights,
+                                     (int)c->slots, (int)c->slot_begin, c->B, c->ntiles, c->d_state, parity));
+    }
+    c->flush_index++;
+    return HULK_OK;
+}
+
+int check_device_error(hulk_ctx *c) {
+    DevState st{};
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (st.err != 0) { c->sticky = st.err; return fail(c, st.err); }
+    return HULK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hulk_abi_version(void) { return HULK_ABI_VERSION; }
+const char *hulk_strerror(int status) { return err_text(status); }
+const char *hulk_last_error(const hulk_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+int hulk_create(const hulk_params *params, hulk_ctx **out) {
+    if (!out) return fail(nullptr, HULK_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!params) return fail(nullptr, HULK_ERR_ARG, "params is NULL");
+    hulk_params p = *params;
+    int64_t bins = p.num_bins;
+    if (bins == 0) bins = (int64_t)(int32_t)ipow(p.k, 4);           // cmd/sketch.go:118
+    // same order as the reference: NewKmerSpectrum (boss.go:57), then NewHistoSketch (sketch.go:277)
+    if (bins < 0) return fail(nullptr, HULK_ERR_NEG_BINS, std::to_string(bins));
+    if (p.w > 256) return fail(nullptr, HULK_ERR_W);
+    if (p.k > 31) return fail(nullptr, HULK_ERR_HS_K);
+    if (p.decay_ratio < 0.0 || p.decay_ratio > 1.0 || p.decay_ratio != p.decay_ratio) return fail(nullptr, HULK_ERR_DECAY);
+    if (bins < 2) return fail(nullptr, HULK_ERR_BINS);
+    if (p.k < 1) return fail(nullptr, HULK_ERR_K);
+    if (p.slot_count == 0) { p.slot_begin = 0; p.slot_count = p.sketch_size; }
+    if ((uint64_t)p.slot_begin + p.slot_count > p.sketch_size) return fail(nullptr, HULK_ERR_ARG, "slot shard outside sketch");
+    if (p.cws_source > HULK_CWS_EXTERNAL) return fail(nullptr, HULK_ERR_ARG, "cws_source");
+    if (p.decay_ratio != 1.0)
+        return fail(nullptr, HULK_ERR_ARG, "concept-drift (decay_ratio != 1.0) is not implemented in this build yet");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, HULK_ERR_NO_DEVICE);
+    if (p.device < 0 || p.device >= ndev) return fail(nullptr, HULK_ERR_ARG, "device ordinal");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p.device) != hipSuccess) return fail(nullptr, HULK_ERR_NO_DEVICE);
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(nullptr, HULK_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName);
+
+    hulk_ctx *c = new hulk_ctx();
+    c->p = p; c->B = (int32_t)bins; c->S = p.sketch_size; c->slot_begin = p.slot_begin; c->slots = p.slot_count;
+    c->drift = p.decay_ratio != 1.0;
+    c->cms_width = (int)std::ceil(2 / 0.001);                              // countmin.go:31
+    c->cms_depth = (int)std::ceil(std::log(1 - 0.99) / std::log(0.5));     // countmin.go:32
+    c->ntiles = (c->B + SCAN_TILE - 1) / SCAN_TILE;
+    c->row_stride = (size_t)c->ntiles * SCAN_TILE;
+
+#define CHK_CREATE(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int rc_ = fail_hip(nullptr, e_, #call); hulk_destroy(c); return rc_; } } while (0)
+    CHK_CREATE(hipSetDevice(p.device));
+    CHK_CREATE(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    const size_t B = (size_t)c->B, S = c->S, SL = c->slots;
+    CHK_CREATE(dalloc(&c->d_state, 1));
+    CHK_CREATE(dalloc(&c->d_hist, B));
+    CHK_CREATE(dalloc(&c->d_hist_tmp, B));
+    CHK_CREATE(dalloc(&c->d_ctr, (size_t)c->cms_depth * c->cms_width));
+    CHK_CREATE(dalloc(&c->d_est, B * CMS_DEPTH_MAX));
+    CHK_CREATE(dalloc(&c->d_f64, B));
+    CHK_CREATE(dalloc(&c->d_rcp32, c->row_stride));
+    CHK_CREATE(dalloc(&c->d_mins, S));
+    CHK_CREATE(dalloc(&c->d_weights, S));
+    CHK_CREATE(dalloc(&c->d_rcb, SL * B * 3));
+    CHK_CREATE(dalloc(&c->d_k32, SL * c->row_stride));
+    CHK_CREATE(dalloc(&c->d_tilemin, SL * (size_t)c->ntiles));
+    CHK_CREATE(hipMemsetAsync(c->d_state, 0, sizeof(DevState), c->stream));
+    CHK_CREATE(hipMemsetAsync(c->d_hist, 0, B * 4, c->stream));
+    CHK_CREATE(hipMemsetAsync(c->d_ctr, 0, (size_t)c->cms_depth * c->cms_width * 8, c->stream));
+    CHK_CREATE(hipMemsetAsync(c->d_mins, 0, (S ? S : 1) * 8, c->stream));
+    CHK_CREATE(launch_fill_f32(c->stream, c->d_rcp32, c->row_stride, std::nanf("")));
+    {   // weights start at MaxFloat64 (histosketch.go:84-87)
+        std::vector<double> w(S ? S : 1, 1.7976931348623157e308);
+        CHK_CREATE(hipMemcpy(c->d_weights, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+    }
+#undef CHK_CREATE
+    int rc = build_chains(c);
+    if (rc == HULK_OK && p.cws_source == HULK_CWS_GO_COMPAT) rc = generate_tables(c);
+    if (rc == HULK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = HULK_ERR_HIP;
+    if (rc != HULK_OK) { g_create_error = c->last_error.empty() ? err_text(rc) : c->last_error; hulk_destroy(c); return rc; }
+    *out = c;
+    return HULK_OK;
+}
+
+void hulk_destroy(hulk_ctx *c) {
+    if (!c) return;
+    if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    for (auto &pr : c->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
+    hipFree(c->d_state); hipFree(c->d_hist); hipFree(c->d_hist_tmp); hipFree(c->d_perm); hipFree(c->d_chain_start);
+    hipFree(c->d_ctr); hipFree(c->d_est); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
+    hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
+    hipFree(c->d_bases); hipFree(c->d_offsets);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int hulk_set_stream(hulk_ctx *c, void *hip_stream) {
+    if (!c) return HULK_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return HULK_OK;
+}
+
+int hulk_set_cws_tables(hulk_ctx *c, const double *r, const double *cc, const double *b) {
+    if (!c || !r || !cc || !b) return fail(c, HULK_ERR_ARG, "NULL table");
+    if (c->seq_count || c->flush_index) return fail(c, HULK_ERR_STATE, "tables must be set before the first read");
+    return install_tables(c, r, cc, b);
+}
+
+int hulk_add_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
+                          uint32_t max_read_len, uint64_t bases_bytes) {
+    if (!c) return HULK_ERR_ARG;
+    if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
+    if (c->sticky != HULK_OK) return fail(c, c->sticky);
+    if (n && (!d_bases || !d_offsets)) return fail(c, HULK_ERR_ARG, "NULL buffer");
+    const uint64_t I = c->p.interval;
+    uint64_t pos = 0;
+    while (pos < n) {
+        uint64_t chunk = n - pos;
+        if (I) { const uint64_t room = I - (c->seq_count % I); if (chunk > room) chunk = room; }
+        int rc = bin_reads(c, d_bases, d_offsets + pos, chunk, max_read_len, bases_bytes);
+        if (rc != HULK_OK) return rc;
+        c->seq_count += chunk; pos += chunk;
+        if (I && (c->seq_count % I) == 0) {            // pipeline/sketch.go:211-215
+            rc = do_flush(c);
+            if (rc != HULK_OK) return rc;
+        }
+    }
+    return HULK_OK;
+}
+
+int hulk_bin_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
+                          uint32_t max_read_len, uint64_t bases_bytes) {
+    if (!c) return HULK_ERR_ARG;
+    if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
+    if (n && (!d_bases || !d_offsets)) return fail(c, HULK_ERR_ARG, "NULL buffer");
+    int rc = bin_reads(c, d_bases, d_offsets, n, max_read_len, bases_bytes);
+    if (rc == HULK_OK) c->seq_count += n;
+    return rc;
+}
+
+uint32_t *hulk_histogram_device(hulk_ctx *c) { return c ? c->d_hist : nullptr; }
+
+int hulk_add_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n) {
+    if (!c) return HULK_ERR_ARG;
+    if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
+    if (n == 0) return HULK_OK;
+    if (!bases || !offsets) return fail(c, HULK_ERR_ARG, "NULL buffer");
+    // NewMinimizerSketch's checks run per read in the reference (minimizer.go:70-76)
+    uint64_t max_len = 0;
+    const uint64_t need = (uint64_t)c->p.w + c->p.k - 1;
+    for (uint64_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(c, HULK_ERR_ARG, "offsets not monotone");
+        const uint64_t L = offsets[i + 1] - offsets[i];
+        if (L < 1) return fail(c, HULK_ERR_EMPTY_SEQ);
+        if (L < need) return fail(c, HULK_ERR_SHORT_SEQ);
+        if (L > max_len) max_len = L;
+    }
+    if (max_len > 0xffffffffull) return fail(c, HULK_ERR_READ_TOO_LONG);
+    const uint64_t lo = offsets[0], hi = offsets[n];
+    const size_t nbytes = (size_t)(hi - lo), padded = (nbytes + 15) & ~(size_t)7;
+    if (padded > c->d_bases_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_bases); c->d_bases = nullptr; c->d_bases_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_bases, padded + padded / 4));
+        c->d_bases_cap = padded + padded / 4;
+    }
+    if (n + 1 > c->d_offsets_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_offsets); c->d_offsets = nullptr; c->d_offsets_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_offsets, (n + 1 + n / 4) * 8));
+        c->d_offsets_cap = n + 1 + n / 4;
+    }
+    // staging is reused batch to batch: wait for the kernels of the previous batch
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> rel(n + 1);
+    for (uint64_t i = 0; i <= n; i++) rel[i] = offsets[i] - lo;
+    HIPCHK(c, hipMemcpyAsync(c->d_bases, bases + lo, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_offsets, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return hulk_add_reads_device(c, c->d_bases, c->d_offsets, n, (uint32_t)max_len, c->d_bases_cap);
+}
+
+int hulk_add_histogram(hulk_ctx *c, const uint32_t *bins) {
+    if (!c || !bins) return fail(c, HULK_ERR_ARG, "NULL");
+    HIPCHK(c, hipMemcpyAsync(c->d_hist_tmp, bins, (size_t)c->B * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_add_hist(c->stream, c->d_hist, c->d_hist_tmp, c->B));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->hist_hook_used = true;
+    return HULK_OK;
+}
+
+int hulk_flush(hulk_ctx *c) {
+    if (!c) return HULK_ERR_ARG;
+    if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
+    return do_flush(c);
+}
+
+int hulk_finish(hulk_ctx *c) {
+    if (!c) return HULK_ERR_ARG;
+    if (!c->finished) {
+        int rc = do_flush(c);                          // pipeline/sketch.go:219-221
+        if (rc != HULK_OK) return rc;
+        c->finished = true;
+    }
+    int rc = check_device_error(c);
+    if (rc != HULK_OK) return rc;
+    // "no sequences received" (pipeline/sketch.go:237-239); the histogram test hook is exempt
+    if (c->seq_count == 0 && !c->hist_hook_used) return fail(c, HULK_ERR_NO_SEQ);
+    return HULK_OK;
+}
+
+int hulk_get_sketch(hulk_ctx *c, uint64_t *mins, double *weights) {
+    if (!c || !mins || !weights) return fail(c, HULK_ERR_ARG, "NULL");
+    HIPCHK(c, hipMemcpyAsync(mins, c->d_mins, (size_t)c->S * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(weights, c->d_weights, (size_t)c->S * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HULK_OK;
+}
+
+int hulk_get_counters(hulk_ctx *c, uint64_t *n_reads, uint64_t *n_minimizers, uint64_t *total_len) {
+    if (!c) return HULK_ERR_ARG;
+    DevState st{};
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_reads) *n_reads = c->seq_count;
+    if (n_minimizers) *n_minimizers = st.n_minimizers;
+    if (total_len) *total_len = st.total_len;
+    return HULK_OK;
+}
+
+int hulk_get_histogram(hulk_ctx *c, uint32_t *bins) {
+    if (!c || !bins) return fail(c, HULK_ERR_ARG, "NULL");
+    HIPCHK(c, hipMemcpyAsync(bins, c->d_hist, (size_t)c->B * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HULK_OK;
+}
+
+int hulk_get_cms(hulk_ctx *c, double *counters) {
+    if (!c || !counters) return fail(c, HULK_ERR_ARG, "NULL");
+    const size_t n = (size_t)c->cms_depth * c->cms_width;
+    std::vector<unsigned long long> tmp(n);
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_ctr, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) counters[i] = (double)tmp[i];
+    return HULK_OK;
+}
+
+int hulk_get_cws_tables(hulk_ctx *c, double *r, double *cc, double *b) {
+    if (!c || !r || !cc || !b) return fail(c, HULK_ERR_ARG, "NULL");
+    int rc = ensure_tables(c);
+    if (rc != HULK_OK) return rc;
+    const size_t B = (size_t)c->B;
+    std::vector<double> row(B * 3);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t s = 0; s < c->slots; s++) {
+        HIPCHK(c, hipMemcpy(row.data(), c->d_rcb + (size_t)s * B * 3, B * 3 * 8, hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < B; j++) { r[s * B + j] = row[j * 3]; cc[s * B + j] = row[j * 3 + 1]; b[s * B + j] = row[j * 3 + 2]; }
+    }
+    return HULK_OK;
+}
+
+int hulk_set_profiling(hulk_ctx *c, int enabled) {
+    if (!c) return HULK_ERR_ARG;
+    c->profiling = enabled != 0;
+    return HULK_OK;
+}
+
+int hulk_get_profile(hulk_ctx *c, const char *kernel, uint64_t *launches, double *total_ms) {
+    if (!c || !launches || !total_ms) return fail(c, HULK_ERR_ARG, "NULL");
+    if (kernel && strcmp(kernel, "k_cws_scan") != 0) return fail(c, HULK_ERR_ARG, "only k_cws_scan is instrumented");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double tot = 0; uint64_t n = 0;
+    for (auto &pr : c->prof) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) { tot += ms; n++; }
+        hipEventDestroy(pr.a); hipEventDestroy(pr.b);
+    }
+    c->prof.clear();
+    *launches = n; *total_ms = tot;
+    return HULK_OK;
+}
+
+}  // extern "C"

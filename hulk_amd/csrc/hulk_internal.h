@@ -1,0 +1,59 @@
+// Internal declarations shared by the kernel file and the C-ABI file of libhulkhip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hulk {
+
+constexpr int CMS_DEPTH_MAX = 8;      // est[] rows are padded to 8 per bin
+constexpr int SCAN_TILE = 1024;       // bins per CWS scan tile (256 threads x float4)
+constexpr int SCAN_ROWS = 8;          // sketch slots per CWS scan workgroup
+
+// Device-resident run state (one per context).
+struct DevState {
+    unsigned long long n_minimizers;  // boss.minimizerCounter            (boss.go:93)
+    unsigned long long total_len;     // SeqMinimizer.Run lengthTotal     (pipeline/sketch.go:208)
+    unsigned long long n_elements;    // AddElement calls (non-zero bins streamed)
+    unsigned int used[2];             // KmerSpectrum.Cardinality() of the flush in flight (ping-pong)
+    int err;                          // first deferred HULK_ERR_* (0 = none)
+    unsigned int pad;
+};
+
+struct MinimizerParams {
+    uint32_t k, w;
+    int32_t num_bins;
+    uint32_t xcap;       // max k-mer positions per read this launch supports
+    uint32_t tab_size;   // per-wave dedupe table entries (power of two, > xcap)
+    uint32_t lds_per_wave;  // filled by launch_minimizer_bin
+    uint64_t bases_bytes;
+};
+
+// bytes of dynamic LDS per wave / per workgroup for k_minimizer_bin
+size_t minimizer_lds_per_wave(uint32_t xcap, uint32_t tab_size);
+size_t minimizer_lds_per_block(uint32_t xcap, uint32_t tab_size, int waves);
+
+hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                uint64_t n_reads, MinimizerParams P, int block_threads,
+                                uint32_t *d_hist, DevState *d_state);
+hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hist, int32_t num_bins, DevState *st,
+                             int parity);
+hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hist, const uint32_t *d_perm,
+                             const uint32_t *d_chain_start, unsigned long long *d_ctr,
+                             unsigned long long *d_est, int32_t num_bins, int depth, int width,
+                             DevState *st, int parity);
+hipError_t launch_freq(hipStream_t s, uint32_t *d_hist, const unsigned long long *d_est,
+                       double *d_f64, float *d_rcp32, int32_t num_bins, int depth, DevState *st,
+                       int parity);
+hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
+                           int slots, int ntiles, size_t row_stride, int32_t num_bins, DevState *st,
+                           int parity);
+hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,
+                              const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
+                              int slots, int slot_begin, int32_t num_bins, int ntiles, DevState *st,
+                              int parity);
+hipError_t launch_build_k32(hipStream_t s, const double *d_rcb, float *d_k32, int slots,
+                            int32_t num_bins, size_t row_stride);
+hipError_t launch_fill_f32(hipStream_t s, float *p, size_t n, float v);
+hipError_t launch_add_hist(hipStream_t s, uint32_t *d_hist, const uint32_t *d_add, int32_t num_bins);
+
+}  // namespace hulk

@@ -1,0 +1,586 @@
+// hulk_kernels.hip — gfx950 kernels of the HULK `sketch` hot path.
+//
+//   K1  k_minimizer_bin   reads -> distinct minimizers per read -> jump hash -> histogram
+//                         (reference: src/minimizer/minimizer.go:96-204,
+//                          src/kmerspectrum/kmerspectrum.go:67-81)
+//   K2  k_count_used      KmerSpectrum.Cardinality()            (kmerspectrum.go:53-55)
+//   K3  k_cms_chains      count-min sketch Add() for a whole flush, as 7x2000 independent
+//       k_freq            ordered prefix sums (src/countmin/countmin.go:103-138)
+//   K4  k_cws_scan        fp32 streaming pass over K = c*exp(b-r): per (slot, tile) minimum
+//       k_cws_resolve     exact fp64 re-evaluation (literal formula of
+//                         src/histosketch/histosketch.go:30-33) of the candidate tiles and the
+//                         slot update (histosketch.go:135-153)
+//
+// All kernels are wave64 code for CDNA4; none of them has a CPU or library fallback.
+#include "hulk_internal.h"
+
+#include <math.h>
+
+namespace hulk {
+namespace {
+
+constexpr uint64_t TAB_EMPTY = 0x00000000000000FFull;   // never a minimizer value (see k_minimizer_bin)
+constexpr uint64_t X_NONE = ~0ull;
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_sync() {
+    // one wave owns its LDS region: program order is enough for the hardware, this stops the
+    // compiler from moving LDS accesses across the point.
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// minimap2 hash64 — src/minimizer/minimizer.go:33-42
+__device__ __forceinline__ uint64_t hash64(uint64_t key, uint64_t mask) {
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
+// Jump consistent hash (Lamping & Veach) == go-jump Hash(key, n); fp64 divide and multiply are
+// IEEE-exact on gfx950, so the result is bit-identical to the Go code.
+__device__ __forceinline__ int32_t jump_hash(uint64_t key, int32_t n) {
+    int64_t b = -1, j = 0;
+    while (j < (int64_t)n) {
+        b = j;
+        key = key * 2862933555777941757ull + 1;
+        j = (int64_t)((double)(b + 1) * (2147483648.0 / (double)((key >> 33) + 1)));
+    }
+    return (int32_t)b;
+}
+
+__device__ __forceinline__ void set_error(DevState *st, int code) { atomicCAS(&st->err, 0, code); }
+
+// Flush decision shared by all flush kernels: boss.go:118 (skip empty spectrum) and
+// kmerspectrum.go:88-96 (fatal below 1 % used bins).
+__device__ __forceinline__ bool flush_go(const DevState *st, int parity, int32_t num_bins) {
+    unsigned used = st->used[parity];
+    if (used == 0) return false;
+    double prop = (double)used / (double)num_bins;
+    return !(prop < 0.01);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: minimizers + binning.  One wave owns a read at a time.
+//
+// LDS per wave:  Xs[xcap] u64   hashed k-mer (or X_NONE) per k-mer position
+//                vm[xcap/64] u64 validity masks (position not skipped)
+//                tab[tab_size] u64  open-addressing set = the per-read golang-set
+//                q[128] u64     distinct minimizers waiting for a full-wave jump-hash pass
+//                pk[...] u8     2-bit packed bases, base p at bits 2(p%4) of byte p/4
+// LDS per block: lut[256]       seq_nt4_table (minimizer.go:13-30)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t nt4_of(unsigned c) {
+    unsigned u = c | 0x20u;
+    if (c < 4) return (uint8_t)c;
+    if (u == 'a') return 0;
+    if (u == 'c') return 1;
+    if (u == 'g') return 2;
+    if (u == 't' || u == 'u') return 3;
+    return 4;
+}
+
+__global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict__ bases,
+                                                       const uint64_t *__restrict__ offsets,
+                                                       uint64_t n_reads, MinimizerParams P,
+                                                       uint32_t *__restrict__ hist, DevState *st) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint8_t *lut = smem;
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) lut[t] = nt4_of((unsigned)t);
+    __syncthreads();
+
+    const int lane = lane_id();
+    const int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t xcap = P.xcap, tabn = P.tab_size, tabmask = P.tab_size - 1;
+    const size_t per_wave = P.lds_per_wave;
+    unsigned char *wbase = smem + 256 + (size_t)wid * per_wave;
+    uint64_t *Xs = (uint64_t *)wbase;
+    uint64_t *vm = Xs + xcap;
+    uint64_t *tab = vm + (xcap + 63) / 64;
+    uint64_t *q = tab + tabn;
+    uint8_t *pk8 = (uint8_t *)(q + 128);
+    const uint32_t *pk32 = (const uint32_t *)pk8;
+
+    const int32_t k = (int32_t)P.k, w = (int32_t)P.w;
+    const int32_t wwin = w > 0 ? w : 1;   // w == 0: the deque is emptied every step, same window as w == 1
+    const uint64_t mask = (1ull << (2 * k)) - 1;
+    const uint64_t shift = (uint64_t)(2 * (k - 1));
+
+    for (uint32_t s = lane; s < tabn; s += 64) tab[s] = TAB_EMPTY;
+    wave_sync();
+
+    uint32_t qn = 0;                 // wave-uniform
+    unsigned long long nmin = 0;     // wave-uniform
+
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_reads)
+        atomicAdd(&st->total_len, (unsigned long long)(offsets[n_reads] - offsets[0]));
+
+    const uint64_t gw = (uint64_t)blockIdx.x * nw + wid, stride = (uint64_t)gridDim.x * nw;
+    for (uint64_t rd = gw; rd < n_reads; rd += stride) {
+        const uint64_t o0 = offsets[rd], o1 = offsets[rd + 1];
+        const int64_t L = (int64_t)(o1 - o0);
+        // NewMinimizerSketch checks (minimizer.go:70-76); errors are deferred to hulk_finish
+        if (L < 1) { if (lane == 0) set_error(st, -3); continue; }
+        if (L < (int64_t)(w + k - 1)) { if (lane == 0) set_error(st, -4); continue; }
+        const int64_t npos64 = L - k + 1;
+        if (npos64 > (int64_t)xcap) { if (lane == 0) set_error(st, -33); continue; }
+        const int32_t npos = (int32_t)npos64;
+
+        // ---- stage: ASCII -> 2-bit packs in LDS (4 bases per lane per pass), detect code 4
+        bool sawN = false;
+        for (int64_t b0 = 0; b0 < L; b0 += 256) {
+            const int64_t p = b0 + 4 * lane;
+            const int64_t left = L - p;
+            if (left > 0) {
+                const uintptr_t addr = (uintptr_t)(bases + o0 + (uint64_t)p);
+                const uintptr_t al = addr & ~(uintptr_t)3;
+                const unsigned sh = (unsigned)(addr & 3) * 8;
+                const uint32_t lo = *(const uint32_t *)al;       // aligned dword holding base p
+                uint32_t hi = 0;
+                if (sh && al + 8 <= (uintptr_t)bases + P.bases_bytes) hi = *(const uint32_t *)(al + 4);
+                const uint32_t by = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+                const int nv = left < 4 ? (int)left : 4;
+                unsigned pack = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    unsigned c = lut[(by >> (8 * t)) & 0xff];
+                    if (t < nv) { sawN |= (c > 3); pack |= (c & 3u) << (2 * t); }
+                }
+                pk8[p >> 2] = (uint8_t)pack;
+            }
+        }
+        const bool hasN = __ballot(sawN) != 0ull;
+        wave_sync();
+
+        // ---- hashed canonical k-mer per position (minimizer.go:126-159)
+        for (int32_t j0 = 0; j0 < npos; j0 += 64) {
+            const int32_t j = j0 + lane;          // first base of the k-mer
+            const int32_t i = j + k - 1;          // its last base = the reference's loop index
+            uint64_t X = X_NONE;
+            bool valid = false;
+            if (j < npos) {
+                uint64_t f, r;
+                if (!hasN) {
+                    const uint32_t bo = 2u * (uint32_t)j, d = bo >> 5, o = bo & 31u;
+                    const uint64_t lo = (uint64_t)pk32[d] | ((uint64_t)pk32[d + 1] << 32);
+                    uint64_t W = o ? (lo >> o) | ((uint64_t)pk32[d + 2] << (64 - o)) : lo;
+                    W &= mask;                    // base j at bits 0..1, base i at bits 2(k-1)..
+                    uint64_t rev = __brevll(W) >> (64 - 2 * k);
+                    f = ((rev >> 1) & 0x5555555555555555ull) | ((rev & 0x5555555555555555ull) << 1);
+                    r = (~W) & mask;
+                } else {
+                    // literal recurrence; bases before i-k cannot reach bit positions that
+                    // survive (f is masked every step, r loses 2 bits per step)
+                    f = 0; r = 0;
+                    int32_t p0 = i - k; if (p0 < 0) p0 = 0;
+                    for (int32_t p = p0; p <= i; p++) {
+                        const uint64_t c = lut[bases[o0 + (uint64_t)p]];
+                        f = (f << 2 | c) & mask;
+                        r = (r >> 2) | ((3ull ^ c) << shift);
+                    }
+                }
+                if (f != r) {
+                    const uint64_t canon = f > r ? r : f;
+                    int32_t span = i - w + 2;     // windowIndex + 1
+                    if (span >= k) span = k;
+                    X = hash64(canon, mask) << 8 | (uint64_t)(int64_t)span;
+                    valid = true;
+                }
+                Xs[j] = X;
+            }
+            const uint64_t vmask = __ballot(valid);
+            if (lane == 0) vm[j0 >> 6] = vmask;
+        }
+        wave_sync();
+
+        // ---- windowed minimum, per-read set insert, queue new values (minimizer.go:162-199)
+        uint64_t carry_m = 0; bool carry_emit = false;     // wave-uniform: last lane of previous pass
+        for (int32_t j0 = 0; j0 < npos; j0 += 64) {
+            const int32_t j = j0 + lane;
+            const int32_t i = j + k - 1;
+            const uint64_t vmask = vm[j0 >> 6];
+            const bool emit = (j < npos) && ((vmask >> lane) & 1ull) && (i >= w - 1);
+            uint64_t m = X_NONE;
+            if (emit) {
+                int32_t lo = j - (wwin - 1); if (lo < 0) lo = 0;
+                for (int32_t p = lo; p <= j; p++) { const uint64_t x = Xs[p]; m = x < m ? x : m; }
+            }
+            uint64_t pm = __shfl_up(m, 1);
+            int pe = __shfl_up((int)emit, 1);
+            if (lane == 0) { pm = carry_m; pe = (int)carry_emit; }
+            carry_m = __shfl(m, 63); carry_emit = __shfl((int)emit, 63) != 0;
+            const bool start = emit && !(pe && pm == m);
+            bool isnew = false;
+            if (start) {
+                uint32_t slot = ((uint32_t)(m >> 8) ^ (uint32_t)(m >> 37)) & tabmask;
+                for (;;) {
+                    const unsigned long long old =
+                        atomicCAS((unsigned long long *)&tab[slot], (unsigned long long)TAB_EMPTY,
+                                  (unsigned long long)m);
+                    if (old == TAB_EMPTY) { isnew = true; break; }
+                    if (old == m) break;
+                    slot = (slot + 1) & tabmask;
+                }
+            }
+            const uint64_t nb = __ballot(isnew);
+            if (nb) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nb >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)nb, 0u));
+                if (isnew) q[qn + rank] = m;
+                qn += (uint32_t)__popcll(nb);
+                wave_sync();
+            }
+            if (qn >= 64) {
+                // full-wave jump-hash pass (kmerspectrum.go:70,78)
+                const uint64_t x = q[lane];
+                const uint64_t keep = (lane + 64u < qn) ? q[lane + 64] : 0;
+                atomicAdd(&hist[jump_hash(x, P.num_bins)], 1u);
+                wave_sync();
+                q[lane] = keep;
+                wave_sync();
+                qn -= 64; nmin += 64;
+            }
+        }
+        // clear the per-read set
+        for (uint32_t s = lane; s < tabn; s += 64) tab[s] = TAB_EMPTY;
+        wave_sync();
+    }
+    if (qn) {
+        if ((uint32_t)lane < qn) atomicAdd(&hist[jump_hash(q[lane], P.num_bins)], 1u);
+        nmin += qn;
+    }
+    if (lane == 0 && nmin) atomicAdd(&st->n_minimizers, nmin);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: number of used bins (bitvector PopCount in the reference)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count_used(const uint32_t *__restrict__ hist,
+                                                    int32_t num_bins, DevState *st, int parity) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->used[parity ^ 1] = 0;   // arm the next flush
+    unsigned cnt = 0;
+    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < num_bins; b += gridDim.x * blockDim.x)
+        cnt += hist[b] != 0;
+    for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane_id() == 0 && cnt) atomicAdd(&st->used[parity], cnt);
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: count-min.  Without decay every counter is an integer sum, and the stream order of a flush
+// is ascending bin id, so the value returned by Add() for bin x in row d is
+//     ctr_before[d][g] + sum{ v(y) : y <= x, pos_d(y) == g },   g = jump(x*(d+1), width)
+// i.e. an ordered prefix sum along the static chain of bins that share counter (d,g).
+// One wave per chain; perm/chain_start are built once on the host.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cms_chains(const uint32_t *__restrict__ hist,
+                                                    const uint32_t *__restrict__ perm,
+                                                    const uint32_t *__restrict__ chain_start,
+                                                    unsigned long long *__restrict__ ctr,
+                                                    unsigned long long *__restrict__ est,
+                                                    int32_t num_bins, int depth, int width,
+                                                    DevState *st, int parity) {
+    if (!flush_go(st, parity, num_bins)) return;
+    const int lane = lane_id();
+    const int chain = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (chain >= depth * width) return;
+    const int d = chain / width, g = chain - d * width;
+    const uint32_t s = chain_start[d * (width + 1) + g], e = chain_start[d * (width + 1) + g + 1];
+    unsigned long long total = ctr[chain];
+    const uint32_t *pd = perm + (size_t)d * num_bins;
+    for (uint32_t base = s; base < e; base += 64) {
+        const uint32_t idx = base + lane;
+        uint32_t bin = 0; unsigned long long v = 0;
+        if (idx < e) { bin = pd[idx]; v = hist[bin]; }
+        unsigned long long incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned long long t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (v) est[(size_t)bin * CMS_DEPTH_MAX + d] = total + incl;
+        total += __shfl(incl, 63);
+    }
+    if (lane == 0) ctr[chain] = total;
+}
+
+// estiFreq = min over rows; fp32 reciprocal for the streaming pass; wipe the spectrum
+// (kmerspectrum.go:58-64).  Excluded (zero) bins get rcp = NaN so that fminf() ignores them.
+__global__ __launch_bounds__(256) void k_freq(uint32_t *__restrict__ hist,
+                                              const unsigned long long *__restrict__ est,
+                                              double *__restrict__ f64, float *__restrict__ rcp32,
+                                              int32_t num_bins, int depth, DevState *st, int parity) {
+    const bool go = flush_go(st, parity, num_bins);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned used = st->used[parity];
+        if (used != 0 && !go) set_error(st, -5);
+        if (go) st->n_elements += used;
+    }
+    if (!go) return;      // reference: empty spectrum is skipped un-wiped (it is all zero); error is fatal
+    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < num_bins; b += gridDim.x * blockDim.x) {
+        const uint32_t h = hist[b];
+        if (h) {
+            unsigned long long m = ~0ull;
+            for (int d = 0; d < depth; d++) { unsigned long long e = est[(size_t)b * CMS_DEPTH_MAX + d]; m = e < m ? e : m; }
+            const double f = (double)m;
+            f64[b] = f;
+            rcp32[b] = (float)(1.0 / f);
+            hist[b] = 0;
+        } else {
+            f64[b] = 0.0;
+            rcp32[b] = __builtin_nanf("");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4a: the HBM-bound pass.  A[slot][bin] = K[slot][bin] * (1/f[bin]);  per (slot, tile) minimum.
+// Each workgroup streams SCAN_ROWS rows x SCAN_TILE bins of K (16 B per lane per row, all rows'
+// loads independent => SCAN_ROWS x 16 B in flight per lane) against one register-resident
+// float4 of reciprocals.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
+                                                  const float *__restrict__ rcp32,
+                                                  float *__restrict__ tilemin, int slots, int ntiles,
+                                                  size_t row_stride, const DevState *st, int parity,
+                                                  int32_t num_bins) {
+    if (!flush_go(st, parity, num_bins)) return;
+    __shared__ float red[4][SCAN_ROWS];
+    const int tile = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
+    const int tid = threadIdx.x;
+    const size_t col = (size_t)tile * SCAN_TILE + (size_t)tid * 4;
+    const floatx4 rc = *(const floatx4 *)(rcp32 + col);
+    floatx4 kv[SCAN_ROWS];
+#pragma unroll
+    for (int r = 0; r < SCAN_ROWS; r++) {
+        const int slot = grp * SCAN_ROWS + r;
+        if (slot < slots)
+            kv[r] = __builtin_nontemporal_load((const floatx4 *)(k32 + (size_t)slot * row_stride + col));
+        else
+            kv[r] = (floatx4)(0.f);
+    }
+    float m[SCAN_ROWS];
+#pragma unroll
+    for (int r = 0; r < SCAN_ROWS; r++) {
+        float a = fminf(kv[r].x * rc.x, kv[r].y * rc.y);
+        float b = fminf(kv[r].z * rc.z, kv[r].w * rc.w);
+        m[r] = fminf(INFINITY, fminf(a, b));
+    }
+#pragma unroll
+    for (int r = 0; r < SCAN_ROWS; r++)
+        for (int off = 32; off; off >>= 1) m[r] = fminf(m[r], __shfl_xor(m[r], off));
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int r = 0; r < SCAN_ROWS; r++) red[tid >> 6][r] = m[r];
+    }
+    __syncthreads();
+    if (tid < SCAN_ROWS) {
+        const int slot = grp * SCAN_ROWS + tid;
+        if (slot < slots) {
+            float v = fminf(fminf(red[0][tid], red[1][tid]), fminf(red[2][tid], red[3][tid]));
+            tilemin[(size_t)slot * ntiles + tile] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4b: per slot, re-evaluate in fp64 — with the literal getSample formula — every tile whose fp32
+// minimum is within a relative band of the slot's fp32 minimum, then apply AddElement's update
+// rule.  The band (1e-5 rel + 1e-37 abs) is >30x the worst fp32 error of K4a, so the true fp64
+// argmin (and every exact tie, for earliest-wins) is always inside a re-evaluated tile.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ rcb,
+                                                     const double *__restrict__ f64,
+                                                     const float *__restrict__ tilemin,
+                                                     unsigned long long *__restrict__ mins,
+                                                     double *__restrict__ weights, int slot_begin,
+                                                     int32_t num_bins, int ntiles, const DevState *st,
+                                                     int parity) {
+    if (!flush_go(st, parity, num_bins)) return;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *tm = (float *)smem;                       // [ntiles]
+    __shared__ float redf[4];
+    __shared__ double redA[4];
+    __shared__ int32_t redB[4];
+    const int slot = blockIdx.x;                     // local slot
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+    float g = INFINITY;
+    for (int t = tid; t < ntiles; t += blockDim.x) {
+        const float v = tilemin[(size_t)slot * ntiles + t];
+        tm[t] = v;
+        g = fminf(g, v);
+    }
+    for (int off = 32; off; off >>= 1) g = fminf(g, __shfl_xor(g, off));
+    if (lane == 0) redf[wid] = g;
+    __syncthreads();
+    g = fminf(fminf(redf[0], redf[1]), fminf(redf[2], redf[3]));
+    if (!(g < INFINITY)) return;                     // no element reached this slot's rows
+    const float thr = g + 1e-5f * fabsf(g) + 1e-37f;
+
+    double bestA = INFINITY; int32_t bestB = 0x7fffffff;
+    const double *row = rcb + (size_t)slot * (size_t)num_bins * 3;
+    for (int t = 0; t < ntiles; t++) {
+        if (!(tm[t] <= thr)) continue;               // block-uniform
+#pragma unroll
+        for (int qd = 0; qd < SCAN_TILE / 256; qd++) {
+            const int32_t bin = t * SCAN_TILE + qd * 256 + tid;
+            if (bin < num_bins) {
+                const double f = f64[bin];
+                if (f != 0.0) {
+                    const double r = row[(size_t)bin * 3 + 0];
+                    const double c = row[(size_t)bin * 3 + 1];
+                    const double b = row[(size_t)bin * 3 + 2];
+                    const double Yka = exp(log(f) - b);
+                    const double A = c / (Yka * exp(r));
+                    if (A < bestA) { bestA = A; bestB = bin; }   // bins ascend per thread: earliest wins
+                }
+            }
+        }
+    }
+    for (int off = 32; off; off >>= 1) {
+        const double oA = __shfl_xor(bestA, off);
+        const int32_t oB = __shfl_xor(bestB, off);
+        if (oA < bestA || (oA == bestA && oB < bestB)) { bestA = oA; bestB = oB; }
+    }
+    if (lane == 0) { redA[wid] = bestA; redB[wid] = bestB; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int x = 1; x < 4; x++)
+            if (redA[x] < bestA || (redA[x] == bestA && redB[x] < bestB)) { bestA = redA[x]; bestB = redB[x]; }
+        const int gs = slot_begin + slot;
+        if (bestB != 0x7fffffff && bestA < weights[gs]) {        // histosketch.go:150-153, no drift
+            weights[gs] = bestA;
+            mins[gs] = (unsigned long long)bestB;
+        }
+    }
+}
+
+// K = c * exp(b - r) in fp64, rounded once to fp32 (pad columns stay 0: 0 * NaN = NaN, ignored)
+__global__ __launch_bounds__(256) void k_build_k32(const double *__restrict__ rcb,
+                                                   float *__restrict__ k32, int32_t num_bins,
+                                                   size_t row_stride) {
+    const int slot = blockIdx.y;
+    const double *row = rcb + (size_t)slot * (size_t)num_bins * 3;
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < row_stride;
+         b += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (b < (size_t)num_bins) {
+            const double r = row[b * 3 + 0], c = row[b * 3 + 1], bb = row[b * 3 + 2];
+            v = (float)(c * exp(bb - r));
+        }
+        k32[(size_t)slot * row_stride + b] = v;
+    }
+}
+
+__global__ void k_fill_f32(float *p, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void k_add_hist(uint32_t *hist, const uint32_t *add, int32_t n) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) hist[i] += add[i];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- host wrappers
+size_t minimizer_lds_per_wave(uint32_t xcap, uint32_t tab_size) {
+    size_t words = (size_t)xcap + (xcap + 63) / 64 + tab_size + 128;
+    size_t pk = ((size_t)xcap + 32 + 3) / 4 + 16;          // packed bases + slack for 3-dword reads
+    pk = (pk + 7) & ~(size_t)7;
+    return words * 8 + pk;
+}
+size_t minimizer_lds_per_block(uint32_t xcap, uint32_t tab_size, int waves) {
+    return 256 + (size_t)waves * minimizer_lds_per_wave(xcap, tab_size);
+}
+
+hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                uint64_t n_reads, MinimizerParams P, int block_threads,
+                                uint32_t *d_hist, DevState *d_state) {
+    if (n_reads == 0) return hipSuccess;
+    const int waves = block_threads / 64;
+    P.lds_per_wave = (uint32_t)minimizer_lds_per_wave(P.xcap, P.tab_size);
+    const size_t lds = minimizer_lds_per_block(P.xcap, P.tab_size, waves);
+    uint64_t blocks = (n_reads + (uint64_t)waves * 4 - 1) / ((uint64_t)waves * 4);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_minimizer_bin,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_minimizer_bin, dim3((unsigned)blocks), dim3(block_threads), lds, s, d_bases,
+                       d_offsets, n_reads, P, d_hist, d_state);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hist, int32_t num_bins, DevState *st,
+                             int parity) {
+    int blocks = (num_bins + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_count_used, dim3(blocks), dim3(256), 0, s, d_hist, num_bins, st, parity);
+    return hipGetLastError();
+}
+
+hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hist, const uint32_t *d_perm,
+                             const uint32_t *d_chain_start, unsigned long long *d_ctr,
+                             unsigned long long *d_est, int32_t num_bins, int depth, int width,
+                             DevState *st, int parity) {
+    const int chains = depth * width;
+    const int blocks = (chains + 3) / 4;
+    hipLaunchKernelGGL(k_cms_chains, dim3(blocks), dim3(256), 0, s, d_hist, d_perm, d_chain_start,
+                       d_ctr, d_est, num_bins, depth, width, st, parity);
+    return hipGetLastError();
+}
+
+hipError_t launch_freq(hipStream_t s, uint32_t *d_hist, const unsigned long long *d_est,
+                       double *d_f64, float *d_rcp32, int32_t num_bins, int depth, DevState *st,
+                       int parity) {
+    int blocks = (num_bins + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_freq, dim3(blocks), dim3(256), 0, s, d_hist, d_est, d_f64, d_rcp32, num_bins,
+                       depth, st, parity);
+    return hipGetLastError();
+}
+
+hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
+                           int slots, int ntiles, size_t row_stride, int32_t num_bins, DevState *st,
+                           int parity) {
+    const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    hipLaunchKernelGGL(k_cws_scan, dim3((unsigned)(groups * ntiles)), dim3(256), 0, s, d_k32, d_rcp32,
+                       d_tilemin, slots, ntiles, row_stride, st, parity, num_bins);
+    return hipGetLastError();
+}
+
+hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,
+                              const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
+                              int slots, int slot_begin, int32_t num_bins, int ntiles, DevState *st,
+                              int parity) {
+    hipLaunchKernelGGL(k_cws_resolve, dim3(slots), dim3(256), (size_t)ntiles * sizeof(float), s, d_rcb,
+                       d_f64, d_tilemin, d_mins, d_weights, slot_begin, num_bins, ntiles, st, parity);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_k32(hipStream_t s, const double *d_rcb, float *d_k32, int slots,
+                            int32_t num_bins, size_t row_stride) {
+    if (slots == 0) return hipSuccess;
+    int bx = (int)((row_stride + 255) / 256); if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_build_k32, dim3(bx, slots), dim3(256), 0, s, d_rcb, d_k32, num_bins, row_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_f32(hipStream_t s, float *p, size_t n, float v) {
+    hipLaunchKernelGGL(k_fill_f32, dim3(256), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_hist(hipStream_t s, uint32_t *d_hist, const uint32_t *d_add, int32_t num_bins) {
+    int blocks = (num_bins + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_add_hist, dim3(blocks), dim3(256), 0, s, d_hist, d_add, num_bins);
+    return hipGetLastError();
+}
+
+}  // namespace hulk

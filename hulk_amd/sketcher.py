@@ -1,0 +1,176 @@
+"""Host-side mirror of the reference's sketching seam, over the libhulkhip C ABI.
+
+Reference objects mirrored here (will-rowe/hulk v1.0.0):
+  * `theBoss` (src/pipeline/boss.go:10-41): AddSeq / Flush / StopWork / GetMinimizerCount
+  * `histosketch.HistoSketch` (src/histosketch/histosketch.go:36-47): the exported fields
+    Sketch (`mins`), SketchWeights (`weights`), KmerSize, SketchSize, Dimensions,
+    ApplyConceptDrift — consumed by sketchio.HULKdata.Add / WriteJSON
+  * the interval rule of SeqMinimizer.Run (src/pipeline/sketch.go:196-224)
+
+Every numeric step runs on the GPU inside libhulkhip.so; this module only marshals buffers.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import HulkError, HulkParams
+
+
+def spectrum_size(k: int) -> int:
+    """int32(helpers.Pow(k, 4)) — cmd/sketch.go:118."""
+    v = (k ** 4) & 0xFFFFFFFF
+    return v - (1 << 32) if v & 0x80000000 else v
+
+
+class HistoSketch:
+    """The result object: field names follow histosketch.HistoSketch's JSON tags."""
+    algorithm = "histosketch"
+
+    def __init__(self, ksize, mins, weights, num_histogram_bins, concept_drift):
+        self.ksize = int(ksize)
+        self.mins = np.asarray(mins, dtype=np.uint64)
+        self.weights = np.asarray(weights, dtype=np.float64)
+        self.num = len(self.mins)
+        self.num_histogram_bins = int(num_histogram_bins)
+        self.concept_drift = bool(concept_drift)
+        self.md5sum = ""
+
+    def get_sketch(self):
+        return self.mins
+
+
+class GpuSketcher:
+    """boss + sketcher for one `hulk sketch` run on one GPU (or one rank's shard of it)."""
+
+    def __init__(self, k=21, w=9, sketch_size=50, interval=0, decay_ratio=1.0, num_bins=0,
+                 device=0, slot_begin=0, slot_count=0, cws_source=_lib.HULK_CWS_GO_COMPAT,
+                 stream=None):
+        self._L = _lib.load()
+        self._ctx = ctypes.c_void_p()
+        p = HulkParams(k=k, w=w, sketch_size=sketch_size, num_bins=num_bins,
+                       decay_ratio=decay_ratio, interval=interval, device=device,
+                       slot_begin=slot_begin, slot_count=slot_count, cws_source=cws_source)
+        rc = self._L.hulk_create(ctypes.byref(p), ctypes.byref(self._ctx))
+        if rc != 0:
+            self._ctx = None
+            raise HulkError(rc, self._L.hulk_last_error(None).decode())
+        self.k, self.w, self.sketch_size = k, w, sketch_size
+        self.interval, self.decay_ratio = interval, decay_ratio
+        self.num_bins = num_bins if num_bins else spectrum_size(k)
+        self.slot_begin = slot_begin
+        self.slot_count = slot_count if slot_count else sketch_size
+        if stream is not None:
+            self.set_stream(stream)
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.hulk_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HulkError(rc, self._L.hulk_last_error(self._ctx).decode())
+
+    def set_stream(self, stream_handle):
+        self._chk(self._L.hulk_set_stream(self._ctx, ctypes.c_void_p(stream_handle or 0)))
+
+    # ---- theBoss
+    def add_seq(self, seq: bytes):
+        """theBoss.AddSeq (boss.go:24-26) for a single sequence."""
+        arr = np.frombuffer(seq, dtype=np.uint8)
+        self.add_reads(arr, np.array([0, len(arr)], dtype=np.uint64))
+
+    def add_reads(self, bases, offsets):
+        """AddSeq for a batch held in host memory: read i = bases[offsets[i]:offsets[i+1]]."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._chk(self._L.hulk_add_reads(self._ctx, bases.ctypes.data, offsets.ctypes.data,
+                                         len(offsets) - 1))
+
+    def add_reads_device(self, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes):
+        """AddSeq for a batch already resident in HBM (raw device pointers)."""
+        self._chk(self._L.hulk_add_reads_device(self._ctx, bases_ptr, offsets_ptr, n_reads,
+                                                max_read_len, bases_bytes))
+
+    def bin_reads_device(self, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes):
+        """Multi-GPU step 1: bin this rank's reads, no interval rule (see hulk_hip.h)."""
+        self._chk(self._L.hulk_bin_reads_device(self._ctx, bases_ptr, offsets_ptr, n_reads,
+                                                max_read_len, bases_bytes))
+
+    def histogram_device_ptr(self):
+        return self._L.hulk_histogram_device(self._ctx)
+
+    def add_histogram(self, hist):
+        hist = np.ascontiguousarray(hist, dtype=np.uint32)
+        if len(hist) != self.num_bins:
+            raise ValueError("histogram length != num_bins")
+        self._chk(self._L.hulk_add_histogram(self._ctx, hist.ctypes.data))
+
+    def set_cws_tables(self, r, c, b):
+        r, c, b = (np.ascontiguousarray(x, dtype=np.float64) for x in (r, c, b))
+        self._chk(self._L.hulk_set_cws_tables(self._ctx, r.ctypes.data, c.ctypes.data, b.ctypes.data))
+
+    def flush(self):
+        """theBoss.Flush (boss.go:34-36)."""
+        self._chk(self._L.hulk_flush(self._ctx))
+
+    def stop_work(self):
+        """Final flush + theBoss.StopWork (pipeline/sketch.go:219-224)."""
+        self._chk(self._L.hulk_finish(self._ctx))
+
+    finish = stop_work
+
+    def get_minimizer_count(self):
+        return self.counters()["n_minimizers"]
+
+    # ---- outputs
+    def counters(self):
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._chk(self._L.hulk_get_counters(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"n_reads": a.value, "n_minimizers": b.value, "total_len": c.value}
+
+    def sketch(self):
+        mins = np.zeros(self.sketch_size, dtype=np.uint64)
+        weights = np.zeros(self.sketch_size, dtype=np.float64)
+        self._chk(self._L.hulk_get_sketch(self._ctx, mins.ctypes.data, weights.ctypes.data))
+        return mins, weights
+
+    def histosketch(self) -> HistoSketch:
+        mins, weights = self.sketch()
+        return HistoSketch(self.k, mins, weights, self.num_bins, self.decay_ratio != 1.0)
+
+    def histogram(self):
+        h = np.zeros(self.num_bins, dtype=np.uint32)
+        self._chk(self._L.hulk_get_histogram(self._ctx, h.ctypes.data))
+        return h
+
+    def cms(self):
+        a = np.zeros(7 * 2000, dtype=np.float64)
+        self._chk(self._L.hulk_get_cms(self._ctx, a.ctypes.data))
+        return a.reshape(7, 2000)
+
+    def cws_tables(self):
+        n = self.slot_count * self.num_bins
+        r, c, b = np.empty(n), np.empty(n), np.empty(n)
+        self._chk(self._L.hulk_get_cws_tables(self._ctx, r.ctypes.data, c.ctypes.data, b.ctypes.data))
+        shp = (self.slot_count, self.num_bins)
+        return r.reshape(shp), c.reshape(shp), b.reshape(shp)
+
+    def set_profiling(self, on=True):
+        self._chk(self._L.hulk_set_profiling(self._ctx, int(on)))
+
+    def get_profile(self, kernel="k_cws_scan"):
+        n, ms = ctypes.c_uint64(), ctypes.c_double()
+        self._chk(self._L.hulk_get_profile(self._ctx, kernel.encode(), ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value

@@ -1,0 +1,148 @@
+/*
+ * hulk_hip.h — C ABI of libhulkhip.so: the MI355X (gfx950) implementation of HULK's
+ * `sketch` hot path (minimizers -> jump-hash k-mer spectrum -> count-min + CWS histosketch).
+ *
+ * The reference (will-rowe/hulk v1.0.0) has no FFI layer; the seam this library replaces is
+ * the Go package API that `SeqMinimizer.Run` / `Sketcher.Run` drive:
+ *
+ *   reference interface (file:line)                               this ABI
+ *   -----------------------------------------------------------   -------------------------
+ *   pipeline.findMinimizers(chan, *Info) (*theBoss, error)        hulk_create
+ *       src/pipeline/boss.go:54
+ *   histosketch.NewHistoSketch(k, s, bins, decay)                 hulk_create (same checks,
+ *       src/histosketch/histosketch.go:50-92                        same error strings)
+ *   theBoss.AddSeq(seq []byte)        src/pipeline/boss.go:24-26  hulk_add_reads[_device]
+ *   theBoss.Flush()                   src/pipeline/boss.go:34-36  hulk_flush
+ *   theBoss.StopWork() + final flush  src/pipeline/boss.go:29-31, hulk_finish
+ *       src/pipeline/sketch.go:219-224
+ *   theBoss.GetMinimizerCount()       src/pipeline/boss.go:39-41  hulk_get_counters
+ *   HistoSketch.AddElement(bin, v)    src/histosketch/histosketch.go:129-155
+ *                                       (driven internally by hulk_flush; exposed for
+ *                                        tests as hulk_add_histogram)
+ *   HistoSketch.Sketch / .SketchWeights (exported fields)         hulk_get_sketch
+ *       src/histosketch/histosketch.go:40-41
+ *   KmerSpectrum bins                 src/kmerspectrum/kmerspectrum.go:25
+ *                                                                 hulk_get_histogram
+ *   interval rule `seqCount % Interval == 0`                      params.interval
+ *       src/pipeline/sketch.go:211-215
+ *
+ * Conventions: every call returns HULK_OK (0) or a negative HULK_ERR_*; the message the
+ * reference would have passed to log.Fatalf("ERROR---> %v") is available from
+ * hulk_last_error()/hulk_strerror().  The library never aborts the process.  A context is
+ * single-caller (the reference's SeqMinimizer.Run is one goroutine).  Caller owns every
+ * buffer it passes; host buffers may be released as soon as the call returns.  Work is
+ * asynchronous on one HIP stream; hulk_finish / hulk_get_* are the synchronisation points and
+ * the place where device-side errors (short read, <1% bins used) surface.
+ */
+#ifndef HULK_HIP_H
+#define HULK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HULK_ABI_VERSION 1
+
+#define HULK_OK 0
+#define HULK_ERR_W (-1)          /* "w must be: 0 < w < 257"                  minimizer.go:63 */
+#define HULK_ERR_K (-2)          /* "k size must be: 0 < k < 32"              minimizer.go:66 */
+#define HULK_ERR_EMPTY_SEQ (-3)  /* "sequence length must be > 0"             minimizer.go:72 */
+#define HULK_ERR_SHORT_SEQ (-4)  /* "sequence length must be >= w + k - 1"    minimizer.go:75 */
+#define HULK_ERR_FEW_BINS (-5)   /* "not used yet"                            kmerspectrum.go:95 */
+#define HULK_ERR_HS_K (-6)       /* "histosketching only supports k <= 31"    histosketch.go:54 */
+#define HULK_ERR_DECAY (-7)      /* "decay ratio must be between 0.0 and 1.0" histosketch.go:63 */
+#define HULK_ERR_BINS (-8)       /* "histogram must have at least 2 bins"     histosketch.go:66 */
+#define HULK_ERR_NEG_BINS (-9)   /* "negative value used for number of k-mer spectrum bins: %d" kmerspectrum.go:34 */
+#define HULK_ERR_NO_SEQ (-10)    /* "no sequences received"                   pipeline/sketch.go:238 */
+#define HULK_ERR_ARG (-30)       /* bad argument to this ABI (NULL pointer, bad shard, ...) */
+#define HULK_ERR_HIP (-31)       /* HIP runtime failure; hulk_last_error has the hipError string */
+#define HULK_ERR_NO_DEVICE (-32) /* no usable gfx950 device */
+#define HULK_ERR_READ_TOO_LONG (-33) /* read longer than this build's per-read limit */
+#define HULK_ERR_STATE (-34)     /* call not valid in this state (e.g. add after finish) */
+
+/* How the CWS parameter matrices r, c, b (histosketch.go:95-126) are produced. */
+#define HULK_CWS_GO_COMPAT 0     /* go_rng Gamma/Uniform over Go math/rand, seed 1 (default) */
+#define HULK_CWS_EXTERNAL 1      /* caller supplies them with hulk_set_cws_tables (e.g. dumped by a Go program) */
+
+typedef struct hulk_ctx hulk_ctx;
+
+typedef struct hulk_params {
+    uint32_t k;            /* -k/--kmerSize   (cmd/root.go:62)   */
+    uint32_t w;            /* -w/--windowSize (cmd/sketch.go:52) */
+    uint32_t sketch_size;  /* -s/--sketchSize (cmd/sketch.go:54) */
+    int32_t  num_bins;     /* 0 => Pow(k,4) as cmd/sketch.go:118 */
+    double   decay_ratio;  /* -x/--decayRatio (cmd/sketch.go:55); 1.0 = concept drift off */
+    uint32_t interval;     /* -i/--interval   (cmd/sketch.go:53); 0 = none */
+    int32_t  device;       /* HIP device ordinal */
+    uint32_t slot_begin;   /* this context owns sketch slots [slot_begin, slot_begin+slot_count) */
+    uint32_t slot_count;   /* 0 => all slots (single-GPU) */
+    uint32_t cws_source;   /* HULK_CWS_* */
+    uint32_t reserved[5];
+} hulk_params;
+
+/* Version of this ABI (HULK_ABI_VERSION). */
+int hulk_abi_version(void);
+/* Reference error text for a status code. */
+const char *hulk_strerror(int status);
+/* Message of the last failure on this context ("" if none). NULL ctx => last hulk_create failure. */
+const char *hulk_last_error(const hulk_ctx *ctx);
+
+/* findMinimizers + NewHistoSketch.  Allocates device state, generates/uploads the CWS tables. */
+int hulk_create(const hulk_params *params, hulk_ctx **out);
+void hulk_destroy(hulk_ctx *ctx);
+
+/* Run all work on the caller's hipStream_t (e.g. torch's current stream) instead of the
+ * context's own stream.  NULL restores the private stream. */
+int hulk_set_stream(hulk_ctx *ctx, void *hip_stream);
+
+/* Supply r, c, b ([sketch_size][num_bins] row-major fp64, full matrices, host memory) when
+ * cws_source == HULK_CWS_EXTERNAL.  Must be called before the first read. */
+int hulk_set_cws_tables(hulk_ctx *ctx, const double *r, const double *c, const double *b);
+
+/* AddSeq for a batch.  Read i is bases[offsets[i] .. offsets[i+1]) (ASCII, any case).
+ * The interval rule is applied inside: a flush is queued whenever the global read count hits a
+ * multiple of params.interval.  Host variant validates lengths and copies before returning. */
+int hulk_add_reads(hulk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads);
+/* Same, buffers already resident in this device's memory (offsets too).  `max_read_len` is an
+ * upper bound on the read lengths in the batch (selects the kernel configuration);
+ * `bases_bytes` is the size of the bases allocation.  Length validation happens on device. */
+int hulk_add_reads_device(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets,
+                          uint64_t n_reads, uint32_t max_read_len, uint64_t bases_bytes);
+
+/* Multi-GPU split of one interval: (1) bin this rank's reads into the context's histogram
+ * WITHOUT applying the interval rule, (2) caller all-reduces hulk_histogram_device() across
+ * ranks (RCCL, uint32 sum, num_bins elements), (3) hulk_flush() on every rank. */
+int hulk_bin_reads_device(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets,
+                          uint64_t n_reads, uint32_t max_read_len, uint64_t bases_bytes);
+uint32_t *hulk_histogram_device(hulk_ctx *ctx);
+
+/* Test hook: add counts to the current k-mer spectrum directly (host uint32[num_bins]). */
+int hulk_add_histogram(hulk_ctx *ctx, const uint32_t *bins);
+
+/* theBoss.Flush(): histosketch the current k-mer spectrum, then wipe it. */
+int hulk_flush(hulk_ctx *ctx);
+/* Final flush + StopWork; synchronises and reports any deferred device-side error. */
+int hulk_finish(hulk_ctx *ctx);
+
+/* Outputs (each synchronises the stream).  mins/weights are full length sketch_size; slots not
+ * owned by this context keep their initial values (0 / MaxFloat64). */
+int hulk_get_sketch(hulk_ctx *ctx, uint64_t *mins, double *weights);
+int hulk_get_counters(hulk_ctx *ctx, uint64_t *n_reads, uint64_t *n_minimizers, uint64_t *total_len);
+int hulk_get_histogram(hulk_ctx *ctx, uint32_t *bins);
+/* Count-min counters as fp64 [7][2000] (test hook). */
+int hulk_get_cms(hulk_ctx *ctx, double *counters);
+/* Copy rows of the CWS tables owned by this context to host: each [slot_count][num_bins] (test hook). */
+int hulk_get_cws_tables(hulk_ctx *ctx, double *r, double *c, double *b);
+
+/* Per-kernel timing for bench.py: when enabled, hipEvents bracket every launch of the CWS
+ * table-scan kernel on the work stream. */
+int hulk_set_profiling(hulk_ctx *ctx, int enabled);
+/* Returns number of timed launches; *total_ms = summed duration (synchronises). Resets the log. */
+int hulk_get_profile(hulk_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HULK_HIP_H */
