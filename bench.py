@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — reads/sec of the HULK `sketch` hot path on MI355X (BASELINE.json metric).
+
+Workload at N=1 (BASELINE configs[1], "C2"): synthetic 150 bp reads, k=21, w=9, sketchSize=512,
+interval=100k reads; reads are resident in HBM before the timed region.  One *step* = one
+interval: bin 100k reads (minimizers -> jump hash -> k^4-bin spectrum) and flush it through the
+count-min + CWS histosketch update.  K=100 steps = the 10 M reads of C2.
+
+N>1 (one process per GPU, launched by torch.distributed.run): every interval's reads are split
+into N contiguous slices, histograms are merged with ONE RCCL all-reduce per interval, the CWS
+update is slot-sharded (hulk_amd/distributed.py).  Per-rank work per step is kept fixed as N
+grows (each rank bins 100k reads per step => the global interval is N x 100k): "weak" scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K, W, S, READ_LEN, INTERVAL = 21, 9, 512, 150, 100_000
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(sample_intervals=2):
+    """The CPU oracle (oracle/hulk_oracle.c, a literal port of the Go algorithm) timed on this
+    box's host cores on a bounded sample of the same workload.  Single thread."""
+    from oracle import pyorc
+    from hulk_amd import synth
+    o = pyorc.Sketcher(K, W, S, 0, 1.0, INTERVAL)          # CWS table generation: not timed
+    bases, offsets = synth.reads_numpy(0, sample_intervals * INTERVAL, READ_LEN)
+    t0 = time.perf_counter()
+    o.add_reads(bases, offsets)
+    dt = time.perf_counter() - t0
+    n = sample_intervals * INTERVAL
+    o.close()
+    return {"value": n / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": f"{n} reads = {sample_intervals} intervals of {INTERVAL} "
+                      f"(k={K}, sketchSize={S}), single-threaded C port of the Go path, "
+                      f"CWS table generation excluded; {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the all-reduce path even at world size 1 (test aid)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import hulk_amd
+    from hulk_amd import synth
+    from hulk_amd.distributed import GpuEngine, ShardedSketcher, slot_shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(device))
+
+    steps, warmup = args.steps, args.warmup
+    total_steps = steps + warmup
+    # global interval = world * INTERVAL; this rank bins its contiguous INTERVAL-read slice
+    reads_per_rank_step = INTERVAL
+    sb, sc = slot_shard(S, rank, world)
+
+    stream = torch.cuda.current_stream()
+    sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=local_rank,
+                              slot_begin=sb, slot_count=sc, stream=stream.cuda_stream)
+    eng = GpuEngine(sk, device)
+    sh = ShardedSketcher(eng, S, rank, world if use_dist else 1, dist if use_dist else None)
+
+    # synthetic reads for all steps of this rank, resident in HBM (global read index keeps
+    # the N-rank run identical to a 1-rank run over the same global stream)
+    step_bases, offsets = [], None
+    for t in range(total_steps):
+        first = (t * world + rank) * reads_per_rank_step
+        b, o = synth.reads_torch(first, reads_per_rank_step, READ_LEN, device=device)
+        step_bases.append(b)
+        offsets = o
+    torch.cuda.synchronize()
+
+    def one_step(t):
+        b = step_bases[t]
+        sk.bin_reads_device(b.data_ptr(), offsets.data_ptr(), reads_per_rank_step, READ_LEN, b.numel())
+        if use_dist:
+            dist.all_reduce(eng.histogram_tensor(), op=dist.ReduceOp.SUM)
+        sk.flush()
+
+    for t in range(warmup):
+        one_step(t)
+    torch.cuda.synchronize()
+    sk.set_profiling(True)
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(warmup, total_steps):
+        one_step(t)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_launch, scan_ms = sk.get_profile("k_cws_scan")
+    sk.set_profiling(False)
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    sk.finish()
+    counters = sk.counters()
+    mins, weights = sh.gather_sketch() if (use_dist and world > 1) else sk.sketch()
+
+    if rank == 0:
+        total_reads = steps * reads_per_rank_step * world
+        value = total_reads / elapsed
+        # roofline of the dominant kernel (k_cws_scan): algorithmic bytes per launch = one fp32
+        # pass over this rank's slice of K = 4 * slots * k^4, over the average
+        # launch duration measured with HIP events on the work stream during the timed region
+        alg_bytes = 4.0 * sc * (K ** 4)
+        avg_s = (scan_ms / 1e3) / max(n_launch, 1)
+        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        out = {
+            "metric": "reads/sec (150bp, k=21, sketch=512)", "value": value, "unit": "reads/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C2: synthetic 150bp reads, k=21, w=9, sketchSize=512, "
+                                   "interval=100k reads per rank-step, HBM-resident input",
+                       "reads_per_step": reads_per_rank_step * world, "total_reads": total_reads,
+                       "parallelism": f"read-shard x{world}, slot-sharded CWS"},
+            "roofline": {"bound": "hbm", "kernel": "k_cws_scan", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "launches": int(n_launch),
+                         "avg_launch_us": avg_s * 1e6, "alg_bytes_per_launch": alg_bytes},
+            "path_bytes_per_read": READ_LEN + 4.0 * S * (K ** 4) / (INTERVAL * world),
+            "sketch_md5": __import__("hashlib").md5(mins.astype("<u8").tobytes()).hexdigest(),
+            "n_minimizers_rank0": counters["n_minimizers"],
+        }
+        out["path_hbm_frac"] = value * out["path_bytes_per_read"] / 1e9 / (HBM_PEAK_GBS * world)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    sk.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
