@@ -16,7 +16,7 @@ HULK_CWS_EXTERNAL = 1
 # every symbol include/hulk_hip.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = (
     "hulk_abi_version", "hulk_strerror", "hulk_last_error", "hulk_create", "hulk_destroy",
-    "hulk_set_stream", "hulk_set_cws_tables", "hulk_add_reads", "hulk_add_reads_device",
+    "hulk_set_stream", "hulk_set_private_stream", "hulk_set_cws_tables", "hulk_add_reads", "hulk_add_reads_device",
     "hulk_bin_reads_device", "hulk_histogram_device", "hulk_add_histogram", "hulk_flush",
     "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
     "hulk_get_cws_tables", "hulk_set_profiling", "hulk_get_profile",
@@ -60,6 +60,7 @@ def load():
     L.hulk_create.restype = ctypes.c_int; L.hulk_create.argtypes = [ctypes.POINTER(HulkParams), ctypes.POINTER(vp)]
     L.hulk_destroy.restype = None; L.hulk_destroy.argtypes = [vp]
     L.hulk_set_stream.restype = ctypes.c_int; L.hulk_set_stream.argtypes = [vp, vp]
+    L.hulk_set_private_stream.restype = ctypes.c_int; L.hulk_set_private_stream.argtypes = [vp]
     L.hulk_set_cws_tables.restype = ctypes.c_int; L.hulk_set_cws_tables.argtypes = [vp, vp, vp, vp]
     L.hulk_add_reads.restype = ctypes.c_int; L.hulk_add_reads.argtypes = [vp, vp, vp, u64]
     L.hulk_add_reads_device.restype = ctypes.c_int; L.hulk_add_reads_device.argtypes = [vp, vp, vp, u64, u32, u64]

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -74,7 +75,7 @@ struct hulk_ctx {
     DevState *d_state = nullptr;
     uint32_t *d_hist = nullptr, *d_hist_tmp = nullptr;
     uint32_t *d_perm = nullptr, *d_chain_start = nullptr;
-    unsigned long long *d_ctr = nullptr, *d_est = nullptr, *d_mins = nullptr;
+    unsigned long long *d_ctr = nullptr, *d_est = nullptr, *d_mins = nullptr, *d_min_slots = nullptr;
     double *d_f64 = nullptr, *d_weights = nullptr, *d_rcb = nullptr;
     float *d_rcp32 = nullptr, *d_k32 = nullptr, *d_tilemin = nullptr;
     // staging for host reads
@@ -181,9 +182,10 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
               uint32_t max_len, uint64_t bases_bytes) {
     MinimizerParams P{};
     P.k = c->p.k; P.w = c->p.w; P.num_bins = c->B; P.bases_bytes = bases_bytes;
+    if (const char *e = getenv("HULK_K1_DEBUG")) P.debug = (uint32_t)atoi(e);
     int threads = 256;
     if (!pick_config(c->p.k, max_len, P, threads)) return fail(c, HULK_ERR_READ_TOO_LONG);
-    HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, c->d_hist, c->d_state));
+    HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, c->d_hist, c->d_state, c->d_min_slots));
     return HULK_OK;
 }
 
@@ -272,6 +274,8 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_state, 1));
     CHK_CREATE(dalloc(&c->d_hist, B));
     CHK_CREATE(dalloc(&c->d_hist_tmp, B));
+    CHK_CREATE(dalloc(&c->d_min_slots, (size_t)MIN_SLOTS));
+    CHK_CREATE(hipMemsetAsync(c->d_min_slots, 0, (size_t)MIN_SLOTS * 8, c->stream));
     CHK_CREATE(dalloc(&c->d_ctr, (size_t)c->cms_depth * c->cms_width));
     CHK_CREATE(dalloc(&c->d_est, B * CMS_DEPTH_MAX));
     CHK_CREATE(dalloc(&c->d_f64, B));
@@ -306,7 +310,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_state); hipFree(c->d_hist); hipFree(c->d_hist_tmp); hipFree(c->d_perm); hipFree(c->d_chain_start);
     hipFree(c->d_ctr); hipFree(c->d_est); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
     hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
-    hipFree(c->d_bases); hipFree(c->d_offsets);
+    hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -314,7 +318,14 @@ void hulk_destroy(hulk_ctx *c) {
 int hulk_set_stream(hulk_ctx *c, void *hip_stream) {
     if (!c) return HULK_ERR_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;          // NULL = the HIP null stream
+    return HULK_OK;
+}
+
+int hulk_set_private_stream(hulk_ctx *c) {
+    if (!c) return HULK_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = c->own_stream;
     return HULK_OK;
 }
 
@@ -438,10 +449,14 @@ int hulk_get_sketch(hulk_ctx *c, uint64_t *mins, double *weights) {
 int hulk_get_counters(hulk_ctx *c, uint64_t *n_reads, uint64_t *n_minimizers, uint64_t *total_len) {
     if (!c) return HULK_ERR_ARG;
     DevState st{};
+    std::vector<unsigned long long> slots(MIN_SLOTS);
     HIPCHK(c, hipMemcpyAsync(&st, c->d_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(slots.data(), c->d_min_slots, (size_t)MIN_SLOTS * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long nm = 0;
+    for (auto v : slots) nm += v;                       // boss.minimizerCounter (boss.go:93)
     if (n_reads) *n_reads = c->seq_count;
-    if (n_minimizers) *n_minimizers = st.n_minimizers;
+    if (n_minimizers) *n_minimizers = nm;
     if (total_len) *total_len = st.total_len;
     return HULK_OK;
 }

@@ -8,10 +8,10 @@ namespace hulk {
 constexpr int CMS_DEPTH_MAX = 8;      // est[] rows are padded to 8 per bin
 constexpr int SCAN_TILE = 1024;       // bins per CWS scan tile (256 threads x float4)
 constexpr int SCAN_ROWS = 8;          // sketch slots per CWS scan workgroup
+constexpr int MIN_SLOTS = 8192;       // max blocks of k_minimizer_bin = per-block minimizer-count slots
 
 // Device-resident run state (one per context).
 struct DevState {
-    unsigned long long n_minimizers;  // boss.minimizerCounter            (boss.go:93)
     unsigned long long total_len;     // SeqMinimizer.Run lengthTotal     (pipeline/sketch.go:208)
     unsigned long long n_elements;    // AddElement calls (non-zero bins streamed)
     unsigned int used[2];             // KmerSpectrum.Cardinality() of the flush in flight (ping-pong)
@@ -25,6 +25,7 @@ struct MinimizerParams {
     uint32_t xcap;       // max k-mer positions per read this launch supports
     uint32_t tab_size;   // per-wave dedupe table entries (power of two, > xcap)
     uint32_t lds_per_wave;  // filled by launch_minimizer_bin
+    uint32_t debug;         // ablation switches (env HULK_K1_DEBUG), 0 in production
     uint64_t bases_bytes;
 };
 
@@ -34,7 +35,7 @@ size_t minimizer_lds_per_block(uint32_t xcap, uint32_t tab_size, int waves);
 
 hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
                                 uint64_t n_reads, MinimizerParams P, int block_threads,
-                                uint32_t *d_hist, DevState *d_state);
+                                uint32_t *d_hist, DevState *d_state, unsigned long long *d_min_slots);
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hist, int32_t num_bins, DevState *st,
                              int parity);
 hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hist, const uint32_t *d_perm,

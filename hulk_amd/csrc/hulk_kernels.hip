@@ -90,7 +90,8 @@ __device__ __forceinline__ uint8_t nt4_of(unsigned c) {
 __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offsets,
                                                        uint64_t n_reads, MinimizerParams P,
-                                                       uint32_t *__restrict__ hist, DevState *st) {
+                                                       uint32_t *__restrict__ hist, DevState *st,
+                                                       unsigned long long *__restrict__ min_slots) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint8_t *lut = smem;
     for (int t = threadIdx.x; t < 256; t += blockDim.x) lut[t] = nt4_of((unsigned)t);
@@ -118,6 +119,8 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
 
     uint32_t qn = 0;                 // wave-uniform
     unsigned long long nmin = 0;     // wave-uniform
+    const uint32_t dbg = P.debug;    // ablation switches for tools/k1_ablate.py (0 in production)
+    uint32_t sink = 0;
 
     if (blockIdx.x == 0 && threadIdx.x == 0 && n_reads)
         atomicAdd(&st->total_len, (unsigned long long)(offsets[n_reads] - offsets[0]));
@@ -218,6 +221,8 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
             carry_m = __shfl(m, 63); carry_emit = __shfl((int)emit, 63) != 0;
             const bool start = emit && !(pe && pm == m);
             bool isnew = false;
+            if (dbg & 8u) { sink += (uint32_t)m; } else
+            if (dbg & 4u) { isnew = start; } else
             if (start) {
                 uint32_t slot = ((uint32_t)(m >> 8) ^ (uint32_t)(m >> 37)) & tabmask;
                 for (;;) {
@@ -241,7 +246,9 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
                 // full-wave jump-hash pass (kmerspectrum.go:70,78)
                 const uint64_t x = q[lane];
                 const uint64_t keep = (lane + 64u < qn) ? q[lane + 64] : 0;
-                atomicAdd(&hist[jump_hash(x, P.num_bins)], 1u);
+                const int32_t bin = (dbg & 2u) ? (int32_t)((uint32_t)(x >> 20) & 0xffffu) : jump_hash(x, P.num_bins);
+                if (dbg & 1u) sink += (uint32_t)bin; else
+                atomicAdd(&hist[bin], 1u);
                 wave_sync();
                 q[lane] = keep;
                 wave_sync();
@@ -256,7 +263,17 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
         if ((uint32_t)lane < qn) atomicAdd(&hist[jump_hash(q[lane], P.num_bins)], 1u);
         nmin += qn;
     }
-    if (lane == 0 && nmin) atomicAdd(&st->n_minimizers, nmin);
+    // same-address atomics serialise at ~12 ns each on this chip: every block owns one slot of
+    // min_slots[] instead (launches are stream-ordered, so a plain read-modify-write is safe)
+    __shared__ unsigned long long blk_nmin[4];
+    if (lane == 0) blk_nmin[wid] = nmin;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int x = 0; x < nw; x++) t += blk_nmin[x];
+        if (t) min_slots[blockIdx.x] += t;
+    }
+    if (dbg && sink == 0xdeadbeefu) hist[0] = sink;     // keep ablated work alive
 }
 
 // ------------------------------------------------------------------------------------------
@@ -264,12 +281,18 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_count_used(const uint32_t *__restrict__ hist,
                                                     int32_t num_bins, DevState *st, int parity) {
+    __shared__ unsigned red[4];
     if (blockIdx.x == 0 && threadIdx.x == 0) st->used[parity ^ 1] = 0;   // arm the next flush
     unsigned cnt = 0;
     for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < num_bins; b += gridDim.x * blockDim.x)
         cnt += hist[b] != 0;
     for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
-    if (lane_id() == 0 && cnt) atomicAdd(&st->used[parity], cnt);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt = red[0] + red[1] + red[2] + red[3];
+        if (cnt) atomicAdd(&st->used[parity], cnt);      // one per block; the grid is small
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -501,13 +524,13 @@ size_t minimizer_lds_per_block(uint32_t xcap, uint32_t tab_size, int waves) {
 
 hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
                                 uint64_t n_reads, MinimizerParams P, int block_threads,
-                                uint32_t *d_hist, DevState *d_state) {
+                                uint32_t *d_hist, DevState *d_state, unsigned long long *d_min_slots) {
     if (n_reads == 0) return hipSuccess;
     const int waves = block_threads / 64;
     P.lds_per_wave = (uint32_t)minimizer_lds_per_wave(P.xcap, P.tab_size);
     const size_t lds = minimizer_lds_per_block(P.xcap, P.tab_size, waves);
     uint64_t blocks = (n_reads + (uint64_t)waves * 4 - 1) / ((uint64_t)waves * 4);
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > MIN_SLOTS) blocks = MIN_SLOTS;
     if (blocks < 1) blocks = 1;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k_minimizer_bin,
@@ -515,13 +538,13 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_minimizer_bin, dim3((unsigned)blocks), dim3(block_threads), lds, s, d_bases,
-                       d_offsets, n_reads, P, d_hist, d_state);
+                       d_offsets, n_reads, P, d_hist, d_state, d_min_slots);
     return hipGetLastError();
 }
 
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hist, int32_t num_bins, DevState *st,
                              int parity) {
-    int blocks = (num_bins + 255) / 256; if (blocks > 1024) blocks = 1024;
+    int blocks = (num_bins + 2047) / 2048; if (blocks > 128) blocks = 128;
     hipLaunchKernelGGL(k_count_used, dim3(blocks), dim3(256), 0, s, d_hist, num_bins, st, parity);
     return hipGetLastError();
 }

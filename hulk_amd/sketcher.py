@@ -83,7 +83,11 @@ class GpuSketcher:
             raise HulkError(rc, self._L.hulk_last_error(self._ctx).decode())
 
     def set_stream(self, stream_handle):
+        """Run on the caller's hipStream_t (0/None = the HIP null stream, torch's default)."""
         self._chk(self._L.hulk_set_stream(self._ctx, ctypes.c_void_p(stream_handle or 0)))
+
+    def set_private_stream(self):
+        self._chk(self._L.hulk_set_private_stream(self._ctx))
 
     # ---- theBoss
     def add_seq(self, seq: bytes):

@@ -94,8 +94,10 @@ int hulk_create(const hulk_params *params, hulk_ctx **out);
 void hulk_destroy(hulk_ctx *ctx);
 
 /* Run all work on the caller's hipStream_t (e.g. torch's current stream) instead of the
- * context's own stream.  NULL restores the private stream. */
+ * context's own stream.  NULL is the HIP null (default) stream. */
 int hulk_set_stream(hulk_ctx *ctx, void *hip_stream);
+/* Go back to the context's private non-blocking stream (the default after hulk_create). */
+int hulk_set_private_stream(hulk_ctx *ctx);
 
 /* Supply r, c, b ([sketch_size][num_bins] row-major fp64, full matrices, host memory) when
  * cws_source == HULK_CWS_EXTERNAL.  Must be called before the first read. */

@@ -1,0 +1,119 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/hulk_hip.h declares
+(no compute calls — there is no GPU here), host-side JSON writer/loader, synthetic reads."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "hulk_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hulk_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hulk_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build libhulkhip.so first (make -C hulk_amd/csrc)"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/hulk_hip.h but not exported"
+    assert sorted(_lib.ABI_SYMBOLS) == syms, "hulk_amd/_lib.py binding list out of sync with the header"
+    L.hulk_abi_version.restype = ctypes.c_int
+    assert L.hulk_abi_version() == 1
+    L.hulk_strerror.restype = ctypes.c_char_p
+    assert L.hulk_strerror(-4) == b"sequence length must be >= w + k - 1"
+    assert L.hulk_strerror(-5) == b"not used yet"
+
+
+def test_params_struct_layout_matches_header():
+    from hulk_amd._lib import HulkParams
+    assert ctypes.sizeof(HulkParams) == 64
+    assert HulkParams.decay_ratio.offset == 16 and HulkParams.interval.offset == 24
+    assert HulkParams.cws_source.offset == 40
+
+
+def test_create_without_gpu_fails_loudly():
+    """No CPU fallback: on a box without a gfx950 GPU hulk_create must return an error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import hulk_amd
+    with pytest.raises(hulk_amd.HulkError):
+        hulk_amd.GpuSketcher(21, 9, 8)
+
+
+def test_parameter_errors_before_device_probe():
+    import hulk_amd
+    with pytest.raises(hulk_amd.HulkError, match="histosketching only supports k <= 31"):
+        hulk_amd.GpuSketcher(32, 9, 8)
+    with pytest.raises(hulk_amd.HulkError, match="decay ratio must be between 0.0 and 1.0"):
+        hulk_amd.GpuSketcher(21, 9, 8, decay_ratio=1.5)
+    with pytest.raises(hulk_amd.HulkError, match="histogram must have at least 2 bins"):
+        hulk_amd.GpuSketcher(1, 9, 8)
+    with pytest.raises(hulk_amd.HulkError, match="negative value used for number of k-mer spectrum bins"):
+        hulk_amd.GpuSketcher(21, 9, 8, num_bins=-3)
+
+
+def test_go_float_formatting():
+    from hulk_amd.sketchio import go_float
+    cases = [(1.7976931348623157e308, "1.7976931348623157e+308"), (0.5, "0.5"), (1e-7, "1e-7"),
+             (1.5e-7, "1.5e-7"), (1e21, "1e+21"), (123456789.0, "123456789"), (1e-6, "0.000001"),
+             (-0.000001234, "-0.000001234"), (9.999e20, "999900000000000000000"), (100.0, "100"),
+             (-3.25e-12, "-3.25e-12"), (0.0, "0"), (-0.1234567890123, "-0.1234567890123"),
+             (2.5e-10, "2.5e-10"), (1.2e22, "1.2e+22")]
+    for v, want in cases:
+        assert go_float(v) == want, (v, go_float(v), want)
+    rng = np.random.default_rng(1)
+    for v in np.concatenate([rng.standard_normal(200) * 10.0 ** rng.integers(-12, 12, 200)]):
+        assert float(go_float(v)) == v            # shortest round-trip digits
+
+
+def test_json_writer_layout_and_loader(tmp_path):
+    from hulk_amd import HistoSketch
+    from hulk_amd.sketchio import HULKdata, load_hulk_data, md5sum
+    mins = np.array([5, 0, 194480], dtype=np.uint64)
+    w = np.array([-0.25, 1.7976931348623157e308, 3e-9])
+    hs = HistoSketch(21, mins, w, 194481, False)
+    d = HULKdata(); d.add(hs); d.filename = "a.fq,b<c>.fq,"; d.banner_label = "blank"
+    txt = d.dumps()
+    assert txt.splitlines()[:6] == ['{', '    "class": "hulk_sketch",', '    "filename": "a.fq,b\\u003cc\\u003e.fq,",',
+                                    '    "hash_function": "ntHash",', '    "license": "CC0",', '    "signatures": [']
+    assert '                "mins": [\n                    5,\n                    0,\n                    194480\n                ],' in txt
+    assert '                    1.7976931348623157e+308,\n                    3e-9\n' in txt
+    obj = json.loads(txt)
+    assert list(obj) == ["class", "filename", "hash_function", "license", "signatures", "version", "banner_label"]
+    sk = obj["signatures"][0]
+    assert list(sk) == ["Algorithm", "Sketch"]
+    assert list(sk["Sketch"]) == ["ksize", "md5sum", "mins", "weights", "num", "num_histogram_bins", "concept_drift"]
+    assert sk["Sketch"]["md5sum"] == hashlib.md5(mins.astype("<u8").tobytes()).hexdigest() == md5sum(mins)
+    p = tmp_path / "x.json"; d.write_json(p)
+    back = load_hulk_data(p)
+    assert np.array_equal(back.signatures[0][1].mins, mins)
+    bad = txt.replace('"md5sum": "' + sk["Sketch"]["md5sum"], '"md5sum": "' + "0" * 32)
+    p.write_text(bad)
+    with pytest.raises(ValueError, match="md5sum mismatch"):
+        load_hulk_data(p)
+
+
+def test_synthetic_reads_are_shardable():
+    from hulk_amd import synth
+    b, o = synth.reads_numpy(0, 40, 150)
+    assert set(np.unique(b).tolist()) <= set(b"ACGT") and len(b) == 6000 and o[-1] == 6000
+    b2, _ = synth.reads_numpy(17, 5, 150)
+    assert np.array_equal(b[17 * 150:22 * 150], b2)
+    assert hashlib.sha256(bytes(b[:300])).hexdigest() == hashlib.sha256(bytes(synth.reads_numpy(0, 2, 150)[0])).hexdigest()
+
+
+def test_spectrum_size_is_int32_pow():
+    from hulk_amd import spectrum_size
+    assert spectrum_size(21) == 194481 and spectrum_size(31) == 923521
+    assert spectrum_size(216) < 0          # int32 wrap, as int32(helpers.Pow(k,4))

@@ -1,0 +1,102 @@
+"""World-size-2 test of the multi-GPU host logic (hulk_amd/distributed.py) on CPU over gloo.
+The GPU engine is replaced by a test double built on the CPU oracle — tests are the only place
+where that is allowed; the product engine (GpuEngine over libhulkhip) has no such fallback."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hulk_amd import synth
+from hulk_amd.distributed import ShardedSketcher, read_shard, slot_shard
+
+K, W, S, I, NI, L = 9, 4, 10, 600, 3, 80
+
+
+class OracleEngine:
+    """Test double: same duck type as GpuEngine."""
+    def __init__(self, rank, world):
+        from oracle import pyorc
+        self.pyorc = pyorc
+        self.o = pyorc.Sketcher(K, W, S)
+        self.hist = torch.zeros(K ** 4, dtype=torch.int32)
+        self.lo, self.n = slot_shard(S, rank, world)
+
+    def bin_reads(self, bases, offsets):
+        for i in range(len(offsets) - 1):
+            seq = bytes(bases[int(offsets[i]):int(offsets[i + 1])])
+            for x in self.pyorc.minimizers(seq, K, W):
+                self.hist[self.pyorc.jump(int(x), K ** 4)] += 1
+
+    def histogram_tensor(self): return self.hist
+
+    def flush(self):
+        self.o.add_histogram(self.hist.numpy().astype(np.uint32))
+        self.o.flush()
+        self.hist.zero_()
+
+    def finish(self):
+        self.flush()
+
+    def sketch(self):
+        m, w = self.o.sketch()
+        mm = np.zeros(S, dtype=np.uint64); ww = np.full(S, np.finfo(np.float64).max)
+        mm[self.lo:self.lo + self.n] = m[self.lo:self.lo + self.n]      # only the owned slots
+        ww[self.lo:self.lo + self.n] = w[self.lo:self.lo + self.n]
+        return mm, ww
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = OracleEngine(rank, world)
+    sh = ShardedSketcher(eng, S, rank, world, dist)
+    for t in range(NI):
+        lo, hi = read_shard(I, rank, world)
+        bases, offsets = synth.reads_numpy(t * I + lo, hi - lo, L)
+        eng.bin_reads(bases, offsets)
+        sh.end_interval()
+    sh.finish()
+    mins, weights = sh.gather_sketch()
+    q.put((rank, mins, weights))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_shard_helpers():
+    for world in (1, 2, 3, 8):
+        cov = []
+        for r in range(world):
+            b, c = slot_shard(512, r, world); cov += list(range(b, b + c))
+        assert cov == list(range(512))
+        cov = []
+        for r in range(world):
+            lo, hi = read_shard(100000, r, world); cov += [(lo, hi)]
+        assert cov[0][0] == 0 and cov[-1][1] == 100000 and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_single_process():
+    from oracle import pyorc
+    ref = pyorc.Sketcher(K, W, S, 0, 1.0, I)
+    bases, offsets = synth.reads_numpy(0, NI * I, L)
+    ref.add_reads(bases, offsets); ref.finish()
+    rm, rw = ref.sketch()
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    outs = [q.get(timeout=240) for _ in range(world)]
+    for p in procs: p.join(60)
+    for rank, mins, weights in outs:
+        assert np.array_equal(mins, rm), f"rank {rank}"
+        assert np.array_equal(weights, rw), f"rank {rank}"

@@ -1,0 +1,21 @@
+"""Time k_minimizer_bin alone under ablation switches (HULK_K1_DEBUG)."""
+import os, sys, subprocess, json
+if len(sys.argv) > 1:
+    sys.path.insert(0, os.getcwd())
+    import torch, hulk_amd
+    from hulk_amd import synth
+    n = 100000
+    sk = hulk_amd.GpuSketcher(21, 9, 8, stream=torch.cuda.current_stream().cuda_stream)
+    b, o = synth.reads_torch(0, n, 150)
+    torch.cuda.synchronize()
+    for _ in range(3): sk.bin_reads_device(b.data_ptr(), o.data_ptr(), n, 150, b.numel())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): sk.bin_reads_device(b.data_ptr(), o.data_ptr(), n, 150, b.numel())
+    e1.record(); torch.cuda.synchronize()
+    print(f"dbg={os.environ.get('HULK_K1_DEBUG','0'):>3}  {e0.elapsed_time(e1)/20*1000:8.1f} us per 100k reads")
+else:
+    for d in (0, 1, 2, 4, 8):
+        env = dict(os.environ, HULK_K1_DEBUG=str(d))
+        subprocess.run([sys.executable, __file__, "child"], env=env)
