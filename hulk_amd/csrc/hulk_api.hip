@@ -5,6 +5,7 @@
 #include "hulk_internal.h"
 #include "cws_gen.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -81,6 +82,7 @@ struct hulk_ctx {
     // staging for host reads
     uint8_t *d_bases = nullptr; size_t d_bases_cap = 0;
     uint64_t *d_offsets = nullptr; size_t d_offsets_cap = 0;
+    uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;
     // host-side run state
     uint64_t seq_count = 0, flush_index = 0;
     bool tables_ready = false, finished = false, hist_hook_used = false;
@@ -184,8 +186,31 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
     P.k = c->p.k; P.w = c->p.w; P.num_bins = c->B; P.bases_bytes = bases_bytes;
     if (const char *e = getenv("HULK_K1_DEBUG")) P.debug = (uint32_t)atoi(e);
     int threads = 256;
+    // the short-read kernel takes reads of <= 16*w k-mer positions and <= 256 bases; when the batch's
+    // length bound already exceeds that, go straight to the generic kernel
+    const bool fast_ok = c->p.w >= 1 && c->p.w <= 16 && !getenv("HULK_NO_FAST_K1") && n < 0xffffffffull &&
+                         max_len <= 256 && (uint64_t)max_len < (uint64_t)c->p.k + 16ull * c->p.w;
+    if (fast_ok) {
+        // short-read kernel first; reads it cannot take (N bases, too long for 16 blocks of w
+        // positions) are queued on the device and binned by the generic kernel right after
+        if (n > c->d_slow_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->d_slow_list); c->d_slow_list = nullptr; c->d_slow_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_slow_list, (size_t)(n + n / 4 + 1024) * 4));
+            c->d_slow_cap = n + n / 4 + 1024;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_slow_count, 0, 4, c->stream));
+        HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->d_hist, c->d_state,
+                                        c->d_min_slots, c->d_slow_list, c->d_slow_count));
+        if (!pick_config(c->p.k, max_len, P, threads)) return fail(c, HULK_ERR_READ_TOO_LONG);
+        const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(1024, (n + 3) / 4);
+        HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, c->d_hist, c->d_state,
+                                       c->d_min_slots, c->d_slow_list, c->d_slow_count, list_blocks));
+        return HULK_OK;
+    }
     if (!pick_config(c->p.k, max_len, P, threads)) return fail(c, HULK_ERR_READ_TOO_LONG);
-    HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, c->d_hist, c->d_state, c->d_min_slots));
+    HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, c->d_hist, c->d_state,
+                                   c->d_min_slots, nullptr, nullptr, 0));
     return HULK_OK;
 }
 
@@ -274,6 +299,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_state, 1));
     CHK_CREATE(dalloc(&c->d_hist, B));
     CHK_CREATE(dalloc(&c->d_hist_tmp, B));
+    CHK_CREATE(dalloc(&c->d_slow_count, 1));
     CHK_CREATE(dalloc(&c->d_min_slots, (size_t)MIN_SLOTS));
     CHK_CREATE(hipMemsetAsync(c->d_min_slots, 0, (size_t)MIN_SLOTS * 8, c->stream));
     CHK_CREATE(dalloc(&c->d_ctr, (size_t)c->cms_depth * c->cms_width));
@@ -310,7 +336,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_state); hipFree(c->d_hist); hipFree(c->d_hist_tmp); hipFree(c->d_perm); hipFree(c->d_chain_start);
     hipFree(c->d_ctr); hipFree(c->d_est); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
     hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
-    hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots);
+    hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -489,6 +515,20 @@ int hulk_get_cws_tables(hulk_ctx *c, double *r, double *cc, double *b) {
         HIPCHK(c, hipMemcpy(row.data(), c->d_rcb + (size_t)s * B * 3, B * 3 * 8, hipMemcpyDeviceToHost));
         for (size_t j = 0; j < B; j++) { r[s * B + j] = row[j * 3]; cc[s * B + j] = row[j * 3 + 1]; b[s * B + j] = row[j * 3 + 2]; }
     }
+    return HULK_OK;
+}
+
+int hulk_selftest_reciprocal(hulk_ctx *c, uint64_t *mismatches) {
+    if (!c || !mismatches) return fail(c, HULK_ERR_ARG, "NULL");
+    unsigned long long *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, 8));
+    HIPCHK(c, hipMemsetAsync(d, 0, 8, c->stream));
+    HIPCHK(c, launch_selftest_rcp(c->stream, d));
+    unsigned long long h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d);
+    *mismatches = h;
     return HULK_OK;
 }
 

@@ -35,7 +35,13 @@ size_t minimizer_lds_per_block(uint32_t xcap, uint32_t tab_size, int waves);
 
 hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
                                 uint64_t n_reads, MinimizerParams P, int block_threads,
-                                uint32_t *d_hist, DevState *d_state, unsigned long long *d_min_slots);
+                                uint32_t *d_hist, DevState *d_state, unsigned long long *d_min_slots,
+                                const uint32_t *d_read_list, const uint32_t *d_read_list_count,
+                                uint32_t list_blocks);
+hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                 uint64_t n_reads, MinimizerParams P, uint32_t *d_hist, DevState *d_state,
+                                 unsigned long long *d_min_slots, uint32_t *d_slow_list,
+                                 uint32_t *d_slow_count);
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hist, int32_t num_bins, DevState *st,
                              int parity);
 hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hist, const uint32_t *d_perm,
@@ -54,6 +60,7 @@ hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *
                               int parity);
 hipError_t launch_build_k32(hipStream_t s, const double *d_rcb, float *d_k32, int slots,
                             int32_t num_bins, size_t row_stride);
+hipError_t launch_selftest_rcp(hipStream_t s, unsigned long long *d_mismatches);
 hipError_t launch_fill_f32(hipStream_t s, float *p, size_t n, float v);
 hipError_t launch_add_hist(hipStream_t s, uint32_t *d_hist, const uint32_t *d_add, int32_t num_bins);
 

@@ -46,14 +46,54 @@ __device__ __forceinline__ uint64_t hash64(uint64_t key, uint64_t mask) {
 
 // Jump consistent hash (Lamping & Veach) == go-jump Hash(key, n); fp64 divide and multiply are
 // IEEE-exact on gfx950, so the result is bit-identical to the Go code.
+// RN(1/r) for an integer 1 <= r <= 2^31 without the full IEEE division sequence: hardware
+// reciprocal estimate + two FMA Newton steps.  With an exact residual e = 1 - r*y (FMA) the second
+// step rounds correctly (Markstein); tests/test_gpu_parity.py::test_reciprocal_exhaustive checks
+// every r in [1, 2^31] against IEEE division on the device.  2^31/r = 2^31 * RN(1/r) exactly.
+__device__ __forceinline__ double rcp_exact_u31(uint32_t r) {
+    const double d = (double)r;
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+
 __device__ __forceinline__ int32_t jump_hash(uint64_t key, int32_t n) {
-    int64_t b = -1, j = 0;
-    while (j < (int64_t)n) {
-        b = j;
+    // b+1 <= n < 2^31 and (key>>33)+1 <= 2^31 convert exactly from uint32; the product is only
+    // needed (a) to decide j >= n and (b), when j < n, as a value below 2^31 — so the int64
+    // conversion of the Go code is replaced by a double compare + an exact int32 truncation.
+    // float64(b+1) * (2^31 / r) == 2^31 * fl(float64(b+1) * RN(1/r))  (power-of-two scaling is exact)
+    const double dn = (double)n * 0x1p-31;
+    int32_t res = 0;
+    uint32_t j = 0;
+    for (;;) {
+        res = (int32_t)j;                 // b = j
         key = key * 2862933555777941757ull + 1;
-        j = (int64_t)((double)(b + 1) * (2147483648.0 / (double)((key >> 33) + 1)));
+        const double p = (double)(j + 1u) * rcp_exact_u31((uint32_t)(key >> 33) + 1u);
+        if (p >= dn) break;               // j >= n
+        j = (uint32_t)(int32_t)(p * 0x1p31);   // trunc, exact (< n < 2^31)
     }
-    return (int32_t)b;
+    return res;
+}
+
+// two keys at once (independent chains; the loop runs until both are done)
+__device__ __forceinline__ void jump_hash2(uint64_t k0, uint64_t k1, int32_t n, int32_t &r0, int32_t &r1) {
+    const double dn = (double)n * 0x1p-31;
+    uint32_t j0 = 0, j1 = 0;
+    bool d0 = false, d1 = false;
+    r0 = 0; r1 = 0;
+    while (!(d0 && d1)) {
+        if (!d0) r0 = (int32_t)j0;
+        if (!d1) r1 = (int32_t)j1;
+        k0 = k0 * 2862933555777941757ull + 1;
+        k1 = k1 * 2862933555777941757ull + 1;
+        const double p0 = (double)(j0 + 1u) * rcp_exact_u31((uint32_t)(k0 >> 33) + 1u);
+        const double p1 = (double)(j1 + 1u) * rcp_exact_u31((uint32_t)(k1 >> 33) + 1u);
+        if (!d0) { if (p0 >= dn) d0 = true; else j0 = (uint32_t)(int32_t)(p0 * 0x1p31); }
+        if (!d1) { if (p1 >= dn) d1 = true; else j1 = (uint32_t)(int32_t)(p1 * 0x1p31); }
+    }
 }
 
 __device__ __forceinline__ void set_error(DevState *st, int code) { atomicCAS(&st->err, 0, code); }
@@ -91,9 +131,12 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
                                                        const uint64_t *__restrict__ offsets,
                                                        uint64_t n_reads, MinimizerParams P,
                                                        uint32_t *__restrict__ hist, DevState *st,
-                                                       unsigned long long *__restrict__ min_slots) {
+                                                       unsigned long long *__restrict__ min_slots,
+                                                       const uint32_t *__restrict__ read_list,
+                                                       const uint32_t *__restrict__ read_list_count) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint8_t *lut = smem;
+    if (read_list) n_reads = *read_list_count;      // second pass over the reads the fast kernel deferred
     for (int t = threadIdx.x; t < 256; t += blockDim.x) lut[t] = nt4_of((unsigned)t);
     __syncthreads();
 
@@ -122,11 +165,12 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
     const uint32_t dbg = P.debug;    // ablation switches for tools/k1_ablate.py (0 in production)
     uint32_t sink = 0;
 
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n_reads)
+    if (!read_list && blockIdx.x == 0 && threadIdx.x == 0 && n_reads)
         atomicAdd(&st->total_len, (unsigned long long)(offsets[n_reads] - offsets[0]));
 
     const uint64_t gw = (uint64_t)blockIdx.x * nw + wid, stride = (uint64_t)gridDim.x * nw;
-    for (uint64_t rd = gw; rd < n_reads; rd += stride) {
+    for (uint64_t ri = gw; ri < n_reads; ri += stride) {
+        const uint64_t rd = read_list ? (uint64_t)read_list[ri] : ri;
         const uint64_t o0 = offsets[rd], o1 = offsets[rd + 1];
         const int64_t L = (int64_t)(o1 - o0);
         // NewMinimizerSketch checks (minimizer.go:70-76); errors are deferred to hulk_finish
@@ -274,6 +318,285 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
         if (t) min_slots[blockIdx.x] += t;
     }
     if (dbg && sink == 0xdeadbeefu) hist[0] = sink;     // keep ablated work alive
+}
+
+
+// ------------------------------------------------------------------------------------------
+// K1-fast: the short-read form of K1.  A 16-lane group (one DPP row) owns a read; lane g of the
+// group owns the block of w consecutive k-mer positions [g*w, (g+1)*w) and walks it with the
+// rolling 2-bit k-mers of the reference (one extraction from the packed read, then shift-in per
+// base), so the minimap2 hash is the only per-position cost; the block is fully unrolled (WM >= w
+// register slots) so the w independent hash chains interleave.  With blocks of exactly w
+// positions the windowed minimum is the van Herk/Gil-Werman form: min(suffix-min of the previous
+// block — fetched from the neighbouring lane with DPP row_shr:1 —, prefix-min of the own block).
+// Per-read set semantics: a 128-entry open-addressing set per group; all run-start values of a
+// lane are inserted with back-to-back LDS compare-and-swaps (one round trip), collisions probe on.
+// Eligible reads: no code-4 base, 1 <= w <= WM <= 16, k-mer positions <= 16*w, length <= 256,
+// <= 96 run starts.  Anything else is appended to slow_list and handled by k_minimizer_bin.
+//
+// LDS per group: tab[128] u64 | pk[20] u32      per wave: q[192] u64      per block: lut[256]
+// ------------------------------------------------------------------------------------------
+constexpr int FAST_Q = 192;
+constexpr int FAST_TAB = 128;
+
+__device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint64_t dpp_row_shr1_u64(uint64_t v) {
+    return (uint64_t)dpp_row_shr1((uint32_t)v) | ((uint64_t)dpp_row_shr1((uint32_t)(v >> 32)) << 32);
+}
+
+template <int WM>
+__global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__restrict__ bases,
+                                                        const uint64_t *__restrict__ offsets,
+                                                        uint64_t n_reads, MinimizerParams P,
+                                                        uint32_t *__restrict__ hist, DevState *st,
+                                                        unsigned long long *__restrict__ min_slots,
+                                                        uint32_t *__restrict__ slow_list,
+                                                        uint32_t *__restrict__ slow_count) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint8_t *lut = smem;
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) lut[t] = nt4_of((unsigned)t);
+
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, gsh = lane & 48;
+    const int32_t k = (int32_t)P.k, w = (int32_t)P.w;
+    const uint64_t mask = (1ull << (2 * k)) - 1;
+    const uint64_t shift = (uint64_t)(2 * (k - 1));
+    uint64_t *q = (uint64_t *)(smem + 256) + (size_t)wid * FAST_Q;
+    uint64_t *tab = (uint64_t *)(smem + 256 + 4 * FAST_Q * 8) + (size_t)grp * FAST_TAB;
+    uint32_t *pk32 = (uint32_t *)(smem + 256 + 4 * FAST_Q * 8 + 16 * FAST_TAB * 8) + grp * 20;
+#pragma unroll
+    for (int x = 0; x < FAST_TAB / 16; x++) tab[gl + 16 * x] = TAB_EMPTY;
+    __syncthreads();
+
+    uint32_t qn = 0;
+    unsigned long long nmin = 0;
+    const uint32_t dbg = P.debug;     // ablation switches (tools/k1_ablate.py); 0 in production
+    uint32_t sink = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_reads)
+        atomicAdd(&st->total_len, (unsigned long long)(offsets[n_reads] - offsets[0]));
+
+    for (uint64_t base = (uint64_t)blockIdx.x * 16 + (uint64_t)wid * 4; base < n_reads;
+         base += (uint64_t)gridDim.x * 16) {
+        const uint64_t rd = base + (uint64_t)(grp & 3);
+        bool act = rd < n_reads;                               // group-uniform
+        uint64_t o0 = 0; int64_t L = 0; int32_t npos = 0;
+        if (act) {
+            o0 = offsets[rd];
+            L = (int64_t)(offsets[rd + 1] - o0);
+            if (L < 1) { if (gl == 0) set_error(st, -3); act = false; }
+            else if (L < (int64_t)(w + k - 1)) { if (gl == 0) set_error(st, -4); act = false; }
+        }
+        bool defer = false;
+        if (act) {
+            npos = (int32_t)(L - k + 1 > 0x7fffffff ? 0x7fffffff : L - k + 1);
+            if (npos > 16 * w || L > 256) defer = true;
+        }
+        // ---- stage 16 bases per lane: ASCII -> 2-bit pack (one dword per lane), detect code 4
+        bool sawN = false;
+        if (act && !defer) {
+            const int64_t p = 16 * gl;
+            uint32_t pack = 0;
+            if (p < L) {
+                const uintptr_t addr = (uintptr_t)(bases + o0 + (uint64_t)p);
+                const uintptr_t al = addr & ~(uintptr_t)3, end = (uintptr_t)bases + P.bases_bytes;
+                const unsigned sh = (unsigned)(addr & 3) * 8;
+                uint32_t d[5];
+#pragma unroll
+                for (int x = 0; x < 5; x++) d[x] = (al + 4 * (x + 1) <= end) ? *(const uint32_t *)(al + 4 * x) : 0u;
+                const int nv = L - p < 16 ? (int)(L - p) : 16;
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const uint32_t by = sh ? (d[x] >> sh) | (d[x + 1] << (32 - sh)) : d[x];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const unsigned c = lut[(by >> (8 * t)) & 0xff];
+                        if (4 * x + t < nv) { sawN |= (c > 3); pack |= (c & 3u) << (2 * (4 * x + t)); }
+                    }
+                }
+            }
+            pk32[gl] = pack;
+            if (gl < 4) pk32[16 + gl] = 0;                     // slack for 3-dword window reads
+        }
+        {
+            const uint32_t gN = (uint32_t)(__ballot(sawN) >> gsh) & 0xffffu;
+            if (gN) defer = true;
+        }
+        wave_sync();
+
+        // ---- phase A: rolling k-mers over the own block (registers)
+        const int32_t p0 = gl * w;
+        const bool mine = act && !defer && p0 < npos;
+        uint32_t validbits = 0;
+        uint64_t X[WM];
+#pragma unroll
+        for (int t = 0; t < WM; t++) X[t] = X_NONE;
+        if (mine) {
+            uint64_t f, r;
+            {
+                const uint32_t bo = 2u * (uint32_t)p0, d = bo >> 5, o = bo & 31u;
+                const uint64_t lo = (uint64_t)pk32[d] | ((uint64_t)pk32[d + 1] << 32);
+                uint64_t W = o ? (lo >> o) | ((uint64_t)pk32[d + 2] << (64 - o)) : lo;
+                W &= mask;
+                const uint64_t rev = __brevll(W) >> (64 - 2 * k);
+                f = ((rev >> 1) & 0x5555555555555555ull) | ((rev & 0x5555555555555555ull) << 1);
+                r = (~W) & mask;
+            }
+            uint32_t nb;                                        // next <=15 bases, 2 bits each
+            {
+                const uint32_t bo = 2u * (uint32_t)(p0 + k), d = bo >> 5, o = bo & 31u;
+                const uint64_t lo = (uint64_t)pk32[d] | ((uint64_t)pk32[d + 1] << 32);
+                nb = (uint32_t)(lo >> o);
+            }
+            const int32_t span0 = p0 + k - 1 - w + 2;
+#pragma unroll
+            for (int t = 0; t < WM; t++) {
+                if (t) {
+                    const uint64_t c = nb & 3u; nb >>= 2;
+                    f = (f << 2 | c) & mask;
+                    r = (r >> 2) | ((3ull ^ c) << shift);
+                }
+                if (t < w && p0 + t < npos && f != r) {
+                    const uint64_t canon = f > r ? r : f;
+                    int32_t span = span0 + t;
+                    if (span >= k) span = k;
+                    X[t] = ((dbg & 16u) ? canon * 0x9E3779B97F4A7C15ull : hash64(canon, mask)) << 8 | (uint64_t)(int64_t)span;
+                    validbits |= 1u << t;
+                }
+            }
+        }
+        if (dbg & 8u) {
+#pragma unroll
+            for (int t = 0; t < WM; t++) sink += (uint32_t)X[t];
+            wave_sync();
+            continue;
+        }
+
+        // ---- phase B: windowed minimum m(pos) = min(prev block's suffix-min, own prefix-min)
+        uint32_t startbits = 0;
+        {
+            // own suffix minima h[t] = min(X[t..w-1]); the next lane needs h[t+1] as hp[t]
+            uint64_t hp[WM];
+            {
+                uint64_t h = X_NONE;
+#pragma unroll
+                for (int t = WM - 1; t >= 0; t--) {
+                    if (t < w) h = X[t] < h ? X[t] : h;
+                    hp[t] = h;                                 // h[t]
+                }
+            }
+            const uint64_t whole = dpp_row_shr1_u64(hp[0]);    // min of the whole previous block
+#pragma unroll
+            for (int t = 0; t < WM - 1; t++) hp[t] = dpp_row_shr1_u64(hp[t + 1]);
+            hp[WM - 1] = X_NONE;
+            const uint32_t pv = dpp_row_shr1(validbits);
+            bool pe = false; uint64_t pm = 0;
+            if (gl > 0) { pe = ((pv >> (w - 1)) & 1u) && (p0 - 1 + k - 1 >= w - 1); pm = whole; }
+            uint64_t g = X_NONE;
+#pragma unroll
+            for (int t = 0; t < WM; t++) {
+                const uint64_t x = X[t];
+                g = x < g ? x : g;
+                const uint64_t hpt = (gl > 0 && t + 1 < w) ? hp[t] : X_NONE;
+                const uint64_t m = hpt < g ? hpt : g;
+                const bool emit = ((validbits >> t) & 1u) && (p0 + t + k - 1 >= w - 1);
+                if (emit && !(pe && pm == m)) startbits |= 1u << t;
+                X[t] = m;
+                if (t < w) { pe = emit; pm = m; }
+            }
+        }
+        // too many run starts for the 128-entry set (cannot happen for w >= 2): defer the read
+        {
+            uint32_t cnt = (uint32_t)__popc(startbits);
+            cnt += dpp_row_shr1(cnt);
+            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x112, 0xf, 0xf, true);
+            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x114, 0xf, 0xf, true);
+            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x118, 0xf, 0xf, true);
+            const uint32_t over = (uint32_t)(__ballot(gl == 15 && cnt > 96u) >> gsh) & 0xffffu;
+            if (over) { defer = true; startbits = 0; }
+        }
+        if (act && defer) {
+            if (gl == 0) { const uint32_t at = atomicAdd(slow_count, 1u); slow_list[at] = (uint32_t)rd; }
+            act = false;
+        }
+
+        // ---- per-read set: one compare-and-swap per run start, all issued back to back
+        uint32_t newbits = 0;
+        {
+            unsigned long long old[WM];
+            uint32_t slot[WM];
+#pragma unroll
+            for (int t = 0; t < WM; t++) {
+                slot[t] = ((uint32_t)(X[t] >> 8) ^ (uint32_t)(X[t] >> 37)) & (FAST_TAB - 1);
+                old[t] = 0;
+                if ((startbits >> t) & 1u) {
+                    if (dbg & 4u) old[t] = TAB_EMPTY; else
+                    old[t] = atomicCAS((unsigned long long *)&tab[slot[t]], (unsigned long long)TAB_EMPTY,
+                                       (unsigned long long)X[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < WM; t++) {
+                if ((startbits >> t) & 1u) {
+                    unsigned long long o = old[t];
+                    uint32_t sl = slot[t];
+                    while (o != TAB_EMPTY && o != X[t]) {      // rare: occupied by another value
+                        sl = (sl + 1) & (FAST_TAB - 1);
+                        o = atomicCAS((unsigned long long *)&tab[sl], (unsigned long long)TAB_EMPTY,
+                                      (unsigned long long)X[t]);
+                    }
+                    if (o == TAB_EMPTY) newbits |= 1u << t;
+                }
+            }
+        }
+        // ---- queue the new values of the wave; jump-hash them 128 at a time
+        // (runtime loop + select chain keeps ONE copy of the drain code in the instruction stream)
+        for (int t = 0; t < w; t++) {
+            uint64_t xt = X[0];
+#pragma unroll
+            for (int u = 1; u < WM; u++) xt = (t == u) ? X[u] : xt;
+            const bool nw = (newbits >> t) & 1u;
+            const uint64_t nbal = __ballot(nw);
+            if (nbal) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nbal >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)nbal, 0u));
+                if (nw) q[qn + rank] = xt;
+                qn += (uint32_t)__popcll(nbal);
+            }
+            if (qn >= 128) {
+                wave_sync();
+                const uint64_t y0 = q[lane], y1 = q[lane + 64];
+                const uint64_t keep = (lane + 128u < qn) ? q[lane + 128] : 0;
+                int32_t b0, b1;
+                if (dbg & 2u) { b0 = (int32_t)((uint32_t)(y0 >> 20) & 0xffffu); b1 = (int32_t)((uint32_t)(y1 >> 20) & 0xffffu); }
+                else jump_hash2(y0, y1, P.num_bins, b0, b1);
+                if (dbg & 1u) sink += (uint32_t)(b0 + b1); else {
+                atomicAdd(&hist[b0], 1u);
+                atomicAdd(&hist[b1], 1u); }
+                wave_sync();
+                q[lane] = keep;
+                wave_sync();
+                qn -= 128; nmin += 128;
+            }
+        }
+        // clear the group's set (16 lanes x 8 entries)
+#pragma unroll
+        for (int x = 0; x < FAST_TAB / 16; x++) tab[gl + 16 * x] = TAB_EMPTY;
+        wave_sync();
+    }
+    wave_sync();
+    for (uint32_t at = 0; at < qn; at += 64)
+        if (at + (uint32_t)lane < qn) atomicAdd(&hist[jump_hash(q[at + lane], P.num_bins)], 1u);
+    nmin += qn;
+    if (dbg && sink == 0xdeadbeefu) hist[0] = sink;
+    __shared__ unsigned long long blk_nmin[4];
+    if (lane == 0) blk_nmin[wid] = nmin;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = blk_nmin[0] + blk_nmin[1] + blk_nmin[2] + blk_nmin[3];
+        if (t) min_slots[blockIdx.x] += t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -501,6 +824,19 @@ __global__ __launch_bounds__(256) void k_build_k32(const double *__restrict__ rc
     }
 }
 
+// self-test: RN(1/r) by Newton == IEEE division for every r in [1, 2^31]
+__global__ __launch_bounds__(256) void k_selftest_rcp(unsigned long long *mismatches) {
+    unsigned bad = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; r <= 0x80000000ull;
+         r += (uint64_t)gridDim.x * blockDim.x) {
+        const double a = rcp_exact_u31((uint32_t)r);
+        const double b = 1.0 / (double)(uint32_t)r;
+        bad += (a != b);
+    }
+    for (int off = 32; off; off >>= 1) bad += __shfl_xor(bad, off);
+    if (lane_id() == 0 && bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 __global__ void k_fill_f32(float *p, size_t n, float v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -524,7 +860,9 @@ size_t minimizer_lds_per_block(uint32_t xcap, uint32_t tab_size, int waves) {
 
 hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
                                 uint64_t n_reads, MinimizerParams P, int block_threads,
-                                uint32_t *d_hist, DevState *d_state, unsigned long long *d_min_slots) {
+                                uint32_t *d_hist, DevState *d_state, unsigned long long *d_min_slots,
+                                const uint32_t *d_read_list, const uint32_t *d_read_list_count,
+                                uint32_t list_blocks) {
     if (n_reads == 0) return hipSuccess;
     const int waves = block_threads / 64;
     P.lds_per_wave = (uint32_t)minimizer_lds_per_wave(P.xcap, P.tab_size);
@@ -532,13 +870,40 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
     uint64_t blocks = (n_reads + (uint64_t)waves * 4 - 1) / ((uint64_t)waves * 4);
     if (blocks > MIN_SLOTS) blocks = MIN_SLOTS;
     if (blocks < 1) blocks = 1;
+    if (d_read_list) blocks = list_blocks;            // size unknown on the host: small fixed grid
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k_minimizer_bin,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_minimizer_bin, dim3((unsigned)blocks), dim3(block_threads), lds, s, d_bases,
-                       d_offsets, n_reads, P, d_hist, d_state, d_min_slots);
+                       d_offsets, n_reads, P, d_hist, d_state, d_min_slots, d_read_list, d_read_list_count);
+    return hipGetLastError();
+}
+
+size_t minimizer_fast_lds(uint32_t) {
+    return 256 + 4 * (size_t)FAST_Q * 8 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4;
+}
+
+hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                 uint64_t n_reads, MinimizerParams P, uint32_t *d_hist, DevState *d_state,
+                                 unsigned long long *d_min_slots, uint32_t *d_slow_list,
+                                 uint32_t *d_slow_count) {
+    if (n_reads == 0) return hipSuccess;
+    const size_t lds = minimizer_fast_lds(P.w);
+    uint64_t blocks = (n_reads + 63) / 64;            // >= 4 reads per group
+    if (blocks > MIN_SLOTS) blocks = MIN_SLOTS;
+    if (blocks < 1) blocks = 1;
+    const dim3 g((unsigned)blocks), b(256);
+    if (P.w <= 4)
+        hipLaunchKernelGGL(k_minimizer_fast<4>, g, b, lds, s, d_bases, d_offsets, n_reads, P, d_hist,
+                           d_state, d_min_slots, d_slow_list, d_slow_count);
+    else if (P.w <= 9)
+        hipLaunchKernelGGL(k_minimizer_fast<9>, g, b, lds, s, d_bases, d_offsets, n_reads, P, d_hist,
+                           d_state, d_min_slots, d_slow_list, d_slow_count);
+    else
+        hipLaunchKernelGGL(k_minimizer_fast<16>, g, b, lds, s, d_bases, d_offsets, n_reads, P, d_hist,
+                           d_state, d_min_slots, d_slow_list, d_slow_count);
     return hipGetLastError();
 }
 
@@ -592,6 +957,11 @@ hipError_t launch_build_k32(hipStream_t s, const double *d_rcb, float *d_k32, in
     if (slots == 0) return hipSuccess;
     int bx = (int)((row_stride + 255) / 256); if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(k_build_k32, dim3(bx, slots), dim3(256), 0, s, d_rcb, d_k32, num_bins, row_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_rcp(hipStream_t s, unsigned long long *d_mismatches) {
+    hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(256), 0, s, d_mismatches);
     return hipGetLastError();
 }
 

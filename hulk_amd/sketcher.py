@@ -171,6 +171,11 @@ class GpuSketcher:
         shp = (self.slot_count, self.num_bins)
         return r.reshape(shp), c.reshape(shp), b.reshape(shp)
 
+    def selftest_reciprocal(self):
+        n = ctypes.c_uint64()
+        self._chk(self._L.hulk_selftest_reciprocal(self._ctx, ctypes.byref(n)))
+        return n.value
+
     def set_profiling(self, on=True):
         self._chk(self._L.hulk_set_profiling(self._ctx, int(on)))
 

@@ -138,6 +138,10 @@ int hulk_get_cms(hulk_ctx *ctx, double *counters);
 /* Copy rows of the CWS tables owned by this context to host: each [slot_count][num_bins] (test hook). */
 int hulk_get_cws_tables(hulk_ctx *ctx, double *r, double *c, double *b);
 
+/* Device self-test: the jump hash replaces the fp64 division 2^31/r by a Newton reciprocal; this
+ * checks RN(1/r) against IEEE division for EVERY r in [1, 2^31] and returns the mismatch count. */
+int hulk_selftest_reciprocal(hulk_ctx *ctx, uint64_t *mismatches);
+
 /* Per-kernel timing for bench.py: when enabled, hipEvents bracket every launch of the CWS
  * table-scan kernel on the work stream. */
 int hulk_set_profiling(hulk_ctx *ctx, int enabled);

@@ -173,3 +173,20 @@ def test_histogram_hook_sparse_and_dense():
         o.flush(); g.flush()
         assert_same_sketch(o, g)
     g.close(); o.close()
+
+
+def test_reciprocal_exhaustive():
+    """The jump hash's 2^31/r uses a Newton reciprocal instead of the IEEE division sequence:
+    checked on the device against IEEE division for every r in [1, 2^31]."""
+    g = gpu().GpuSketcher(9, 4, 4)
+    assert g.selftest_reciprocal() == 0
+    g.close()
+
+
+def test_jump_hash_many_keys_large_bins():
+    """k=31 has 923,521 bins (20 jump iterations): spectrum of 30k random reads bit-exact."""
+    rng = np.random.default_rng(99)
+    seqs = random_reads(rng, 30000, 150)
+    o, g = run_both(seqs, 31, 9, 2)
+    assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32))
+    g.close(); o.close()

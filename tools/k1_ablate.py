@@ -1,7 +1,7 @@
 """Time k_minimizer_bin alone under ablation switches (HULK_K1_DEBUG)."""
 import os, sys, subprocess, json
 if len(sys.argv) > 1:
-    sys.path.insert(0, os.getcwd())
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch, hulk_amd
     from hulk_amd import synth
     n = 100000
@@ -16,6 +16,6 @@ if len(sys.argv) > 1:
     e1.record(); torch.cuda.synchronize()
     print(f"dbg={os.environ.get('HULK_K1_DEBUG','0'):>3}  {e0.elapsed_time(e1)/20*1000:8.1f} us per 100k reads")
 else:
-    for d in (0, 1, 2, 4, 8):
+    for d in (0, 3, 7, 8, 24):
         env = dict(os.environ, HULK_K1_DEBUG=str(d))
         subprocess.run([sys.executable, __file__, "child"], env=env)
