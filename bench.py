@@ -2,14 +2,16 @@
 """bench.py — reads/sec of the HULK `sketch` hot path on MI355X (BASELINE.json metric).
 
 Workload at N=1 (BASELINE configs[1], "C2"): synthetic 150 bp reads, k=21, w=9, sketchSize=512,
-interval=100k reads; reads are resident in HBM before the timed region.  One *step* = one
-interval: bin 100k reads (minimizers -> jump hash -> k^4-bin spectrum) and flush it through the
-count-min + CWS histosketch update.  K=100 steps = the 10 M reads of C2.
+interval=100k reads; reads are resident in HBM before the timed region.  One *step* = one batch of
+T=10 sketching intervals (1 M reads): one launch bins the reads of the 10 intervals into 10 k-mer
+spectra (minimizers -> jump hash), the spectra go through the count-min update, and ONE pass over
+the CWS table applies all 10 histosketch updates in interval order — bit-identical to flushing
+after every 100k reads.  K=10 steps = the 10 M reads of C2; the default is K=20.
 
 N>1 (one process per GPU, launched by torch.distributed.run): every interval's reads are split
-into N contiguous slices, histograms are merged with ONE RCCL all-reduce per interval, the CWS
+into N contiguous slices, the 10 spectra of a step are merged with ONE RCCL all-reduce, the CWS
 update is slot-sharded (hulk_amd/distributed.py).  Per-rank work per step is kept fixed as N
-grows (each rank bins 100k reads per step => the global interval is N x 100k): "weak" scaling.
+grows (each rank bins 100k reads per interval => the global interval is N x 100k): "weak" scaling.
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 K, W, S, READ_LEN, INTERVAL = 21, 9, 512, 150, 100_000
+BATCH = 10                   # sketching intervals per step (one pass over the CWS table)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -50,8 +53,8 @@ def cpu_baseline(sample_intervals=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-reduce path even at world size 1 (test aid)")
@@ -81,32 +84,41 @@ def main():
 
     steps, warmup = args.steps, args.warmup
     total_steps = steps + warmup
-    # global interval = world * INTERVAL; this rank bins its contiguous INTERVAL-read slice
-    reads_per_rank_step = INTERVAL
+    # global interval = world * INTERVAL; this rank bins its contiguous INTERVAL-read slice of each
+    reads_per_rank_step = INTERVAL * BATCH
     sb, sc = slot_shard(S, rank, world)
 
+    os.environ["HULK_BATCH"] = str(BATCH)
     stream = torch.cuda.current_stream()
     sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=local_rank,
                               slot_begin=sb, slot_count=sc, stream=stream.cuda_stream)
-    eng = GpuEngine(sk, device)
+    assert sk.batch_size == BATCH
+    eng = GpuEngine(sk, device, n_spectra=BATCH)
     sh = ShardedSketcher(eng, S, rank, world if use_dist else 1, dist if use_dist else None)
 
-    # synthetic reads for all steps of this rank, resident in HBM (global read index keeps
-    # the N-rank run identical to a 1-rank run over the same global stream)
+    # synthetic reads, resident in HBM.  Interval t of step s = global reads
+    # [(s*BATCH+t)*world*INTERVAL, +world*INTERVAL); this rank owns the slice [rank*INTERVAL, +INTERVAL)
+    # of it, so an N-rank run sketches the same global stream as a 1-rank run with interval N*100k.
+    n_buf = min(total_steps, 24)          # distinct steps kept in HBM (reused cyclically beyond that)
     step_bases, offsets = [], None
-    for t in range(total_steps):
-        first = (t * world + rank) * reads_per_rank_step
-        b, o = synth.reads_torch(first, reads_per_rank_step, READ_LEN, device=device)
-        step_bases.append(b)
-        offsets = o
+    for s_ in range(n_buf):
+        parts = []
+        for t in range(BATCH):
+            first = ((s_ * BATCH + t) * world + rank) * INTERVAL
+            b, _ = synth.reads_torch(first, INTERVAL, READ_LEN, device=device)
+            parts.append(b[:INTERVAL * READ_LEN])
+        pad = torch.zeros(16, dtype=torch.uint8, device=device)
+        step_bases.append(torch.cat(parts + [pad]))
+    offsets = torch.arange(reads_per_rank_step + 1, dtype=torch.int64, device=device) * READ_LEN
     torch.cuda.synchronize()
 
     def one_step(t):
-        b = step_bases[t]
-        sk.bin_reads_device(b.data_ptr(), offsets.data_ptr(), reads_per_rank_step, READ_LEN, b.numel())
+        b = step_bases[t % n_buf]
+        sk.bin_reads_device(b.data_ptr(), offsets.data_ptr(), reads_per_rank_step, READ_LEN, b.numel(),
+                            reads_per_spectrum=INTERVAL)
         if use_dist:
             dist.all_reduce(eng.histogram_tensor(), op=dist.ReduceOp.SUM)
-        sk.flush()
+        sk.flush_batch(BATCH)
 
     for t in range(warmup):
         one_step(t)
@@ -140,7 +152,7 @@ def main():
         # roofline of the dominant kernel (k_cws_scan): algorithmic bytes per launch = one fp32
         # pass over this rank's slice of K = 4 * slots * k^4, over the average
         # launch duration measured with HIP events on the work stream during the timed region
-        alg_bytes = 4.0 * sc * (K ** 4)
+        alg_bytes = 4.0 * sc * (K ** 4) + 4.0 * BATCH * (K ** 4)   # K once + the BATCH reciprocal vectors
         avg_s = (scan_ms / 1e3) / max(n_launch, 1)
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         out = {
@@ -150,7 +162,7 @@ def main():
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "C2: synthetic 150bp reads, k=21, w=9, sketchSize=512, "
-                                   "interval=100k reads per rank-step, HBM-resident input",
+                                   "interval=100k reads per rank, 10 intervals per step, HBM-resident input",
                        "reads_per_step": reads_per_rank_step * world, "total_reads": total_reads,
                        "parallelism": f"read-shard x{world}, slot-sharded CWS"},
             "roofline": {"bound": "hbm", "kernel": "k_cws_scan", "achieved": achieved,
@@ -158,6 +170,7 @@ def main():
                          "traffic": None, "launches": int(n_launch),
                          "avg_launch_us": avg_s * 1e6, "alg_bytes_per_launch": alg_bytes},
             "path_bytes_per_read": READ_LEN + 4.0 * S * (K ** 4) / (INTERVAL * world),
+            "intervals_per_step": BATCH,
             "sketch_md5": __import__("hashlib").md5(mins.astype("<u8").tobytes()).hexdigest(),
             "n_minimizers_rank0": counters["n_minimizers"],
         }

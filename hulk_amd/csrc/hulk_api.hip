@@ -76,15 +76,18 @@ struct hulk_ctx {
     DevState *d_state = nullptr;
     uint32_t *d_hist = nullptr, *d_hist_tmp = nullptr;
     uint32_t *d_perm = nullptr, *d_chain_start = nullptr;
-    unsigned long long *d_ctr = nullptr, *d_est = nullptr, *d_mins = nullptr, *d_min_slots = nullptr;
+    unsigned long long *d_ctr = nullptr, *d_basearr = nullptr, *d_mins = nullptr, *d_min_slots = nullptr;
+    uint32_t *d_estl = nullptr, *d_invperm = nullptr; uint16_t *d_pos16 = nullptr;
     double *d_f64 = nullptr, *d_weights = nullptr, *d_rcb = nullptr;
     float *d_rcp32 = nullptr, *d_k32 = nullptr, *d_tilemin = nullptr;
+    double *d_candA = nullptr; int32_t *d_candB = nullptr;
     // staging for host reads
     uint8_t *d_bases = nullptr; size_t d_bases_cap = 0;
     uint64_t *d_offsets = nullptr; size_t d_offsets_cap = 0;
     uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;
     // host-side run state
     uint64_t seq_count = 0, flush_index = 0;
+    uint32_t T = 8, ring_n = 9, ring_base = 0;   // interval batch size and spectrum ring
     bool tables_ready = false, finished = false, hist_hook_used = false;
     int sticky = HULK_OK;
     std::string last_error;
@@ -112,7 +115,8 @@ template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((voi
 // position g = jump(bin*(d+1), width) (countmin.go:122-125), ascending bin inside a group.
 int build_chains(hulk_ctx *c) {
     const int D = c->cms_depth, W = c->cms_width; const int32_t B = c->B;
-    std::vector<uint32_t> perm((size_t)D * B), start((size_t)D * (W + 1)), pos(B);
+    std::vector<uint32_t> perm((size_t)D * B), start((size_t)D * (W + 1)), pos(B), invperm((size_t)D * B);
+    std::vector<uint16_t> pos16((size_t)D * B);
     for (int d = 0; d < D; d++) {
         std::vector<uint32_t> cnt(W + 1, 0);
         for (int32_t b = 0; b < B; b++) {
@@ -123,8 +127,17 @@ int build_chains(hulk_ctx *c) {
         for (int g = 0; g < W; g++) cnt[g + 1] += cnt[g];
         for (int g = 0; g <= W; g++) start[(size_t)d * (W + 1) + g] = cnt[g];
         std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
-        for (int32_t b = 0; b < B; b++) perm[(size_t)d * B + cur[pos[b]]++] = (uint32_t)b;
+        for (int32_t b = 0; b < B; b++) {
+            const uint32_t at = cur[pos[b]]++;
+            perm[(size_t)d * B + at] = (uint32_t)b;
+            invperm[(size_t)d * B + b] = at;
+            pos16[(size_t)d * B + b] = (uint16_t)pos[b];
+        }
     }
+    HIPCHK(c, dalloc(&c->d_invperm, invperm.size()));
+    HIPCHK(c, dalloc(&c->d_pos16, pos16.size()));
+    HIPCHK(c, hipMemcpy(c->d_invperm, invperm.data(), invperm.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_pos16, pos16.data(), pos16.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(c, dalloc(&c->d_perm, perm.size()));
     HIPCHK(c, dalloc(&c->d_chain_start, start.size()));
     HIPCHK(c, hipMemcpy(c->d_perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
@@ -181,9 +194,10 @@ bool pick_config(uint32_t k, uint32_t max_len, MinimizerParams &P, int &threads)
 }
 
 int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
-              uint32_t max_len, uint64_t bases_bytes) {
+              uint32_t max_len, uint64_t bases_bytes, uint64_t interval, uint64_t fill) {
     MinimizerParams P{};
     P.k = c->p.k; P.w = c->p.w; P.num_bins = c->B; P.bases_bytes = bases_bytes;
+    P.interval = interval; P.fill = fill; P.ring_base = c->ring_base; P.ring_n = c->ring_n;
     if (const char *e = getenv("HULK_K1_DEBUG")) P.debug = (uint32_t)atoi(e);
     int threads = 256;
     // the short-read kernel takes reads of <= 16*w k-mer positions and <= 256 bases; when the batch's
@@ -214,15 +228,20 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
     return HULK_OK;
 }
 
-int do_flush(hulk_ctx *c) {
+// Flush `count` consecutive spectra of the ring (starting at ring_base) through count-min + CWS.
+int flush_batch(hulk_ctx *c, uint32_t count) {
+    if (count == 0) return HULK_OK;
     int rc = ensure_tables(c);
     if (rc != HULK_OK) return rc;
-    const int parity = (int)(c->flush_index & 1);
+    FlushBatch fb{};
+    fb.ring_base = c->ring_base; fb.ring_n = c->ring_n; fb.count = count;
+    fb.parity = (int)(c->flush_index & 1); fb.num_bins = c->B;
     hipStream_t s = c->stream;
-    HIPCHK(c, launch_count_used(s, c->d_hist, c->B, c->d_state, parity));
-    HIPCHK(c, launch_cms_chains(s, c->d_hist, c->d_perm, c->d_chain_start, c->d_ctr, c->d_est, c->B,
-                                c->cms_depth, c->cms_width, c->d_state, parity));
-    HIPCHK(c, launch_freq(s, c->d_hist, c->d_est, c->d_f64, c->d_rcp32, c->B, c->cms_depth, c->d_state, parity));
+    HIPCHK(c, launch_count_used(s, c->d_hist, c->d_state, fb));
+    HIPCHK(c, launch_cms_chains(s, c->d_hist, c->d_perm, c->d_chain_start, c->d_ctr, c->d_estl, c->d_basearr,
+                                c->cms_depth, c->cms_width, c->d_state, fb));
+    HIPCHK(c, launch_freq(s, c->d_hist, c->d_estl, c->d_basearr, c->d_invperm, c->d_pos16, c->d_f64, c->d_rcp32,
+                          c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
     if (c->slots) {
         ProfileRec pr{};
         if (c->profiling) {
@@ -230,14 +249,16 @@ int do_flush(hulk_ctx *c) {
             HIPCHK(c, hipEventRecord(pr.a, s));
         }
         HIPCHK(c, launch_cws_scan(s, c->d_k32, c->d_rcp32, c->d_tilemin, (int)c->slots, c->ntiles,
-                                  c->row_stride, c->B, c->d_state, parity));
+                                  c->row_stride, c->d_state, fb));
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
-        HIPCHK(c, launch_cws_resolve(s, c->d_rcb, c->d_f64, c->d_tilemin, c->d_mins, c->d_weights,
-                                     (int)c->slots, (int)c->slot_begin, c->B, c->ntiles, c->d_state, parity));
+        HIPCHK(c, launch_cws_resolve(s, c->d_rcb, c->d_f64, c->d_tilemin, c->d_candA, c->d_candB, c->d_mins, c->d_weights,
+                                     (int)c->slots, (int)c->slot_begin, c->ntiles, c->d_state, fb));
     }
     c->flush_index++;
     return HULK_OK;
 }
+
+int do_flush(hulk_ctx *c) { return flush_batch(c, 1); }
 
 int check_device_error(hulk_ctx *c) {
     DevState st{};
@@ -297,25 +318,31 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     c->stream = c->own_stream;
     const size_t B = (size_t)c->B, S = c->S, SL = c->slots;
     CHK_CREATE(dalloc(&c->d_state, 1));
-    CHK_CREATE(dalloc(&c->d_hist, B));
+    if (const char *e = getenv("HULK_BATCH")) { int v = atoi(e); if (v >= 1 && v <= SCAN_BATCH_MAX) c->T = (uint32_t)v; }
+    c->ring_n = c->T + 1;
+    const size_t T = c->T, RN = c->ring_n;
+    CHK_CREATE(dalloc(&c->d_hist, RN * B));
     CHK_CREATE(dalloc(&c->d_hist_tmp, B));
     CHK_CREATE(dalloc(&c->d_slow_count, 1));
     CHK_CREATE(dalloc(&c->d_min_slots, (size_t)MIN_SLOTS));
     CHK_CREATE(hipMemsetAsync(c->d_min_slots, 0, (size_t)MIN_SLOTS * 8, c->stream));
     CHK_CREATE(dalloc(&c->d_ctr, (size_t)c->cms_depth * c->cms_width));
-    CHK_CREATE(dalloc(&c->d_est, B * CMS_DEPTH_MAX));
-    CHK_CREATE(dalloc(&c->d_f64, B));
-    CHK_CREATE(dalloc(&c->d_rcp32, c->row_stride));
+    CHK_CREATE(dalloc(&c->d_estl, T * B * (size_t)c->cms_depth));
+    CHK_CREATE(dalloc(&c->d_basearr, T * (size_t)c->cms_depth * c->cms_width));
+    CHK_CREATE(dalloc(&c->d_f64, T * B));
+    CHK_CREATE(dalloc(&c->d_rcp32, T * c->row_stride));
     CHK_CREATE(dalloc(&c->d_mins, S));
     CHK_CREATE(dalloc(&c->d_weights, S));
     CHK_CREATE(dalloc(&c->d_rcb, SL * B * 3));
     CHK_CREATE(dalloc(&c->d_k32, SL * c->row_stride));
-    CHK_CREATE(dalloc(&c->d_tilemin, SL * (size_t)c->ntiles));
+    CHK_CREATE(dalloc(&c->d_tilemin, T * SL * (size_t)c->ntiles * 4));
+    CHK_CREATE(dalloc(&c->d_candA, T * SL));
+    CHK_CREATE(dalloc(&c->d_candB, T * SL));
     CHK_CREATE(hipMemsetAsync(c->d_state, 0, sizeof(DevState), c->stream));
-    CHK_CREATE(hipMemsetAsync(c->d_hist, 0, B * 4, c->stream));
+    CHK_CREATE(hipMemsetAsync(c->d_hist, 0, RN * B * 4, c->stream));
     CHK_CREATE(hipMemsetAsync(c->d_ctr, 0, (size_t)c->cms_depth * c->cms_width * 8, c->stream));
     CHK_CREATE(hipMemsetAsync(c->d_mins, 0, (S ? S : 1) * 8, c->stream));
-    CHK_CREATE(launch_fill_f32(c->stream, c->d_rcp32, c->row_stride, std::nanf("")));
+    CHK_CREATE(launch_fill_f32(c->stream, c->d_rcp32, T * c->row_stride, std::nanf("")));
     {   // weights start at MaxFloat64 (histosketch.go:84-87)
         std::vector<double> w(S ? S : 1, 1.7976931348623157e308);
         CHK_CREATE(hipMemcpy(c->d_weights, w.data(), w.size() * 8, hipMemcpyHostToDevice));
@@ -334,8 +361,8 @@ void hulk_destroy(hulk_ctx *c) {
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (auto &pr : c->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
     hipFree(c->d_state); hipFree(c->d_hist); hipFree(c->d_hist_tmp); hipFree(c->d_perm); hipFree(c->d_chain_start);
-    hipFree(c->d_ctr); hipFree(c->d_est); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
-    hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
+    hipFree(c->d_ctr); hipFree(c->d_estl); hipFree(c->d_basearr); hipFree(c->d_invperm); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
+    hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
     hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -370,30 +397,47 @@ int hulk_add_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d
     const uint64_t I = c->p.interval;
     uint64_t pos = 0;
     while (pos < n) {
+        // one K1 launch covers up to T complete intervals; they are then flushed with ONE pass over K
+        const uint64_t fill = I ? c->seq_count % I : 0;
         uint64_t chunk = n - pos;
-        if (I) { const uint64_t room = I - (c->seq_count % I); if (chunk > room) chunk = room; }
-        int rc = bin_reads(c, d_bases, d_offsets + pos, chunk, max_read_len, bases_bytes);
+        if (I) { const uint64_t room = (uint64_t)c->T * I - fill; if (chunk > room) chunk = room; }
+        int rc = bin_reads(c, d_bases, d_offsets + pos, chunk, max_read_len, bases_bytes, I, fill);
         if (rc != HULK_OK) return rc;
         c->seq_count += chunk; pos += chunk;
-        if (I && (c->seq_count % I) == 0) {            // pipeline/sketch.go:211-215
-            rc = do_flush(c);
+        if (I) {                                            // pipeline/sketch.go:211-215
+            const uint32_t done = (uint32_t)((fill + chunk) / I);
+            rc = flush_batch(c, done);
             if (rc != HULK_OK) return rc;
+            c->ring_base = (c->ring_base + done) % c->ring_n;
+            if ((fill + chunk) % I == 0) c->ring_base = 0;  // every spectrum is empty again
         }
     }
     return HULK_OK;
 }
 
 int hulk_bin_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
-                          uint32_t max_read_len, uint64_t bases_bytes) {
+                          uint32_t max_read_len, uint64_t bases_bytes, uint64_t reads_per_spectrum) {
     if (!c) return HULK_ERR_ARG;
     if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
     if (n && (!d_bases || !d_offsets)) return fail(c, HULK_ERR_ARG, "NULL buffer");
-    int rc = bin_reads(c, d_bases, d_offsets, n, max_read_len, bases_bytes);
+    if (c->ring_base != 0) return fail(c, HULK_ERR_STATE, "a partial interval is pending");
+    if (reads_per_spectrum && (n + reads_per_spectrum - 1) / reads_per_spectrum > c->T)
+        return fail(c, HULK_ERR_ARG, "more spectra than the batch size");
+    int rc = bin_reads(c, d_bases, d_offsets, n, max_read_len, bases_bytes, reads_per_spectrum, 0);
     if (rc == HULK_OK) c->seq_count += n;
     return rc;
 }
 
-uint32_t *hulk_histogram_device(hulk_ctx *c) { return c ? c->d_hist : nullptr; }
+int hulk_flush_batch(hulk_ctx *c, uint32_t count) {
+    if (!c) return HULK_ERR_ARG;
+    if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
+    if (count > c->T || c->ring_base != 0) return fail(c, HULK_ERR_ARG, "batch count");
+    return flush_batch(c, count);
+}
+
+uint32_t hulk_batch_size(const hulk_ctx *c) { return c ? c->T : 0; }
+
+uint32_t *hulk_histogram_device(hulk_ctx *c) { return c ? c->d_hist + (size_t)c->ring_base * (size_t)c->B : nullptr; }
 
 int hulk_add_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n) {
     if (!c) return HULK_ERR_ARG;
@@ -438,7 +482,7 @@ int hulk_add_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, u
 int hulk_add_histogram(hulk_ctx *c, const uint32_t *bins) {
     if (!c || !bins) return fail(c, HULK_ERR_ARG, "NULL");
     HIPCHK(c, hipMemcpyAsync(c->d_hist_tmp, bins, (size_t)c->B * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_add_hist(c->stream, c->d_hist, c->d_hist_tmp, c->B));
+    HIPCHK(c, launch_add_hist(c->stream, c->d_hist + (size_t)c->ring_base * (size_t)c->B, c->d_hist_tmp, c->B));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->hist_hook_used = true;
     return HULK_OK;
@@ -489,7 +533,7 @@ int hulk_get_counters(hulk_ctx *c, uint64_t *n_reads, uint64_t *n_minimizers, ui
 
 int hulk_get_histogram(hulk_ctx *c, uint32_t *bins) {
     if (!c || !bins) return fail(c, HULK_ERR_ARG, "NULL");
-    HIPCHK(c, hipMemcpyAsync(bins, c->d_hist, (size_t)c->B * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(bins, c->d_hist + (size_t)c->ring_base * (size_t)c->B, (size_t)c->B * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HULK_OK;
 }

@@ -8,15 +8,24 @@ namespace hulk {
 constexpr int CMS_DEPTH_MAX = 8;      // est[] rows are padded to 8 per bin
 constexpr int SCAN_TILE = 1024;       // bins per CWS scan tile (256 threads x float4)
 constexpr int SCAN_ROWS = 8;          // sketch slots per CWS scan workgroup
+constexpr int SCAN_BATCH_MAX = 16;     // max sketching intervals flushed by one pass over the K table
+constexpr int RING_MAX = SCAN_BATCH_MAX + 1;  // spectra in the ring (one may be a partial interval)
 constexpr int MIN_SLOTS = 8192;       // max blocks of k_minimizer_bin = per-block minimizer-count slots
 
 // Device-resident run state (one per context).
 struct DevState {
     unsigned long long total_len;     // SeqMinimizer.Run lengthTotal     (pipeline/sketch.go:208)
     unsigned long long n_elements;    // AddElement calls (non-zero bins streamed)
-    unsigned int used[2];             // KmerSpectrum.Cardinality() of the flush in flight (ping-pong)
+    unsigned int used[2][RING_MAX];   // KmerSpectrum.Cardinality() per ring spectrum (ping-pong by flush parity)
     int err;                          // first deferred HULK_ERR_* (0 = none)
     unsigned int pad;
+};
+
+// One flush = `count` consecutive spectra of the ring starting at ring_base.
+struct FlushBatch {
+    uint32_t ring_base, ring_n, count;
+    int parity;
+    int32_t num_bins;
 };
 
 struct MinimizerParams {
@@ -27,6 +36,9 @@ struct MinimizerParams {
     uint32_t lds_per_wave;  // filled by launch_minimizer_bin
     uint32_t debug;         // ablation switches (env HULK_K1_DEBUG), 0 in production
     uint64_t bases_bytes;
+    uint64_t interval;   // reads per k-mer spectrum (0 = everything into ring_base)
+    uint64_t fill;       // reads already counted into the first spectrum of this launch
+    uint32_t ring_base, ring_n;   // spectra live in a ring of ring_n histograms
 };
 
 // bytes of dynamic LDS per wave / per workgroup for k_minimizer_bin
@@ -42,22 +54,21 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
                                  uint64_t n_reads, MinimizerParams P, uint32_t *d_hist, DevState *d_state,
                                  unsigned long long *d_min_slots, uint32_t *d_slow_list,
                                  uint32_t *d_slow_count);
-hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hist, int32_t num_bins, DevState *st,
-                             int parity);
-hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hist, const uint32_t *d_perm,
+hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb);
+hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,
                              const uint32_t *d_chain_start, unsigned long long *d_ctr,
-                             unsigned long long *d_est, int32_t num_bins, int depth, int width,
-                             DevState *st, int parity);
-hipError_t launch_freq(hipStream_t s, uint32_t *d_hist, const unsigned long long *d_est,
-                       double *d_f64, float *d_rcp32, int32_t num_bins, int depth, DevState *st,
-                       int parity);
+                             uint32_t *d_estl, unsigned long long *d_basearr, int depth, int width,
+                             DevState *st, const FlushBatch &fb);
+hipError_t launch_freq(hipStream_t s, uint32_t *d_hists, const uint32_t *d_estl,
+                       const unsigned long long *d_basearr, const uint32_t *d_invperm,
+                       const uint16_t *d_pos16, double *d_f64, float *d_rcp32, int depth, int width,
+                       size_t row_stride, DevState *st, const FlushBatch &fb);
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
-                           int slots, int ntiles, size_t row_stride, int32_t num_bins, DevState *st,
-                           int parity);
+                           int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb);
 hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,
-                              const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
-                              int slots, int slot_begin, int32_t num_bins, int ntiles, DevState *st,
-                              int parity);
+                              const float *d_tilemin, double *d_candA, int32_t *d_candB,
+                              unsigned long long *d_mins, double *d_weights,
+                              int slots, int slot_begin, int ntiles, DevState *st, const FlushBatch &fb);
 hipError_t launch_build_k32(hipStream_t s, const double *d_rcb, float *d_k32, int slots,
                             int32_t num_bins, size_t row_stride);
 hipError_t launch_selftest_rcp(hipStream_t s, unsigned long long *d_mismatches);

@@ -96,16 +96,13 @@ __device__ __forceinline__ void jump_hash2(uint64_t k0, uint64_t k1, int32_t n, 
     }
 }
 
-__device__ __forceinline__ void set_error(DevState *st, int code) { atomicCAS(&st->err, 0, code); }
-
-// Flush decision shared by all flush kernels: boss.go:118 (skip empty spectrum) and
-// kmerspectrum.go:88-96 (fatal below 1 % used bins).
-__device__ __forceinline__ bool flush_go(const DevState *st, int parity, int32_t num_bins) {
-    unsigned used = st->used[parity];
-    if (used == 0) return false;
-    double prop = (double)used / (double)num_bins;
-    return !(prop < 0.01);
+// spectrum (ring slot) a read is binned into: interval rule of pipeline/sketch.go:211
+__device__ __forceinline__ uint32_t hist_slot(const MinimizerParams &P, uint64_t rd) {
+    if (P.interval == 0) return P.ring_base;
+    return (uint32_t)(((P.fill + rd) / P.interval + P.ring_base) % P.ring_n);
 }
+
+__device__ __forceinline__ void set_error(DevState *st, int code) { atomicCAS(&st->err, 0, code); }
 
 // ------------------------------------------------------------------------------------------
 // K1: minimizers + binning.  One wave owns a read at a time.
@@ -149,7 +146,8 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
     uint64_t *vm = Xs + xcap;
     uint64_t *tab = vm + (xcap + 63) / 64;
     uint64_t *q = tab + tabn;
-    uint8_t *pk8 = (uint8_t *)(q + 128);
+    uint32_t *qs = (uint32_t *)(q + 128);                      // spectrum slot of each queued value
+    uint8_t *pk8 = (uint8_t *)(q + 128 + 64);
     const uint32_t *pk32 = (const uint32_t *)pk8;
 
     const int32_t k = (int32_t)P.k, w = (int32_t)P.w;
@@ -171,6 +169,7 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
     const uint64_t gw = (uint64_t)blockIdx.x * nw + wid, stride = (uint64_t)gridDim.x * nw;
     for (uint64_t ri = gw; ri < n_reads; ri += stride) {
         const uint64_t rd = read_list ? (uint64_t)read_list[ri] : ri;
+        const uint32_t hslot = hist_slot(P, rd);             // which k-mer spectrum of the ring
         const uint64_t o0 = offsets[rd], o1 = offsets[rd + 1];
         const int64_t L = (int64_t)(o1 - o0);
         // NewMinimizerSketch checks (minimizer.go:70-76); errors are deferred to hulk_finish
@@ -282,19 +281,21 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
             if (nb) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nb >> 32),
                                           __builtin_amdgcn_mbcnt_lo((uint32_t)nb, 0u));
-                if (isnew) q[qn + rank] = m;
+                if (isnew) { q[qn + rank] = m; qs[qn + rank] = hslot; }
                 qn += (uint32_t)__popcll(nb);
                 wave_sync();
             }
             if (qn >= 64) {
                 // full-wave jump-hash pass (kmerspectrum.go:70,78)
                 const uint64_t x = q[lane];
+                const uint32_t xs = qs[lane];
                 const uint64_t keep = (lane + 64u < qn) ? q[lane + 64] : 0;
+                const uint32_t keeps = (lane + 64u < qn) ? qs[lane + 64] : 0;
                 const int32_t bin = (dbg & 2u) ? (int32_t)((uint32_t)(x >> 20) & 0xffffu) : jump_hash(x, P.num_bins);
                 if (dbg & 1u) sink += (uint32_t)bin; else
-                atomicAdd(&hist[bin], 1u);
+                atomicAdd(&hist[(size_t)xs * (size_t)P.num_bins + bin], 1u);
                 wave_sync();
-                q[lane] = keep;
+                q[lane] = keep; qs[lane] = keeps;
                 wave_sync();
                 qn -= 64; nmin += 64;
             }
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
         wave_sync();
     }
     if (qn) {
-        if ((uint32_t)lane < qn) atomicAdd(&hist[jump_hash(q[lane], P.num_bins)], 1u);
+        if ((uint32_t)lane < qn)
+            atomicAdd(&hist[(size_t)qs[lane] * (size_t)P.num_bins + jump_hash(q[lane], P.num_bins)], 1u);
         nmin += qn;
     }
     // same-address atomics serialise at ~12 ns each on this chip: every block owns one slot of
@@ -366,6 +368,7 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
     uint64_t *q = (uint64_t *)(smem + 256) + (size_t)wid * FAST_Q;
     uint64_t *tab = (uint64_t *)(smem + 256 + 4 * FAST_Q * 8) + (size_t)grp * FAST_TAB;
     uint32_t *pk32 = (uint32_t *)(smem + 256 + 4 * FAST_Q * 8 + 16 * FAST_TAB * 8) + grp * 20;
+    uint32_t *qs = (uint32_t *)(smem + 256 + 4 * FAST_Q * 8 + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * FAST_Q;
 #pragma unroll
     for (int x = 0; x < FAST_TAB / 16; x++) tab[gl + 16 * x] = TAB_EMPTY;
     __syncthreads();
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
          base += (uint64_t)gridDim.x * 16) {
         const uint64_t rd = base + (uint64_t)(grp & 3);
         bool act = rd < n_reads;                               // group-uniform
+        const uint32_t hslot = hist_slot(P, rd);
         uint64_t o0 = 0; int64_t L = 0; int32_t npos = 0;
         if (act) {
             o0 = offsets[rd];
@@ -561,21 +565,23 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
             if (nbal) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nbal >> 32),
                                           __builtin_amdgcn_mbcnt_lo((uint32_t)nbal, 0u));
-                if (nw) q[qn + rank] = xt;
+                if (nw) { q[qn + rank] = xt; qs[qn + rank] = hslot; }
                 qn += (uint32_t)__popcll(nbal);
             }
             if (qn >= 128) {
                 wave_sync();
                 const uint64_t y0 = q[lane], y1 = q[lane + 64];
+                const size_t s0 = (size_t)qs[lane] * (size_t)P.num_bins, s1 = (size_t)qs[lane + 64] * (size_t)P.num_bins;
                 const uint64_t keep = (lane + 128u < qn) ? q[lane + 128] : 0;
+                const uint32_t keeps = (lane + 128u < qn) ? qs[lane + 128] : 0;
                 int32_t b0, b1;
                 if (dbg & 2u) { b0 = (int32_t)((uint32_t)(y0 >> 20) & 0xffffu); b1 = (int32_t)((uint32_t)(y1 >> 20) & 0xffffu); }
                 else jump_hash2(y0, y1, P.num_bins, b0, b1);
                 if (dbg & 1u) sink += (uint32_t)(b0 + b1); else {
-                atomicAdd(&hist[b0], 1u);
-                atomicAdd(&hist[b1], 1u); }
+                atomicAdd(&hist[s0 + b0], 1u);
+                atomicAdd(&hist[s1 + b1], 1u); }
                 wave_sync();
-                q[lane] = keep;
+                q[lane] = keep; qs[lane] = keeps;
                 wave_sync();
                 qn -= 128; nmin += 128;
             }
@@ -587,7 +593,8 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
     }
     wave_sync();
     for (uint32_t at = 0; at < qn; at += 64)
-        if (at + (uint32_t)lane < qn) atomicAdd(&hist[jump_hash(q[at + lane], P.num_bins)], 1u);
+        if (at + (uint32_t)lane < qn)
+            atomicAdd(&hist[(size_t)qs[at + lane] * (size_t)P.num_bins + jump_hash(q[at + lane], P.num_bins)], 1u);
     nmin += qn;
     if (dbg && sink == 0xdeadbeefu) hist[0] = sink;
     __shared__ unsigned long long blk_nmin[4];
@@ -600,21 +607,39 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: number of used bins (bitvector PopCount in the reference)
+// Flush kernels.  A flush covers `count` consecutive spectra of the ring (FlushBatch), i.e. up to
+// SCAN_BATCH sketching intervals at once: K2/K3 run per spectrum, K4a streams the K table ONCE
+// for all of them, K4b applies the updates in interval order.  The result is identical to
+// flushing the intervals one by one (per slot a running arg-min in stream order).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_count_used(const uint32_t *__restrict__ hist,
-                                                    int32_t num_bins, DevState *st, int parity) {
+__device__ __forceinline__ uint32_t ring_slot(const FlushBatch &fb, int t) { return (fb.ring_base + (uint32_t)t) % fb.ring_n; }
+
+// Flush decision per spectrum: boss.go:118 (skip empty spectrum) and kmerspectrum.go:88-96
+// (fatal below 1 % used bins).
+__device__ __forceinline__ bool flush_go(const DevState *st, const FlushBatch &fb, int t) {
+    const unsigned used = st->used[fb.parity][ring_slot(fb, t)];
+    if (used == 0) return false;
+    const double prop = (double)used / (double)fb.num_bins;
+    return !(prop < 0.01);
+}
+
+// K2: number of used bins (bitvector PopCount in the reference).  grid = (blocks, count)
+__global__ __launch_bounds__(256) void k_count_used(const uint32_t *__restrict__ hists, DevState *st,
+                                                    FlushBatch fb) {
     __shared__ unsigned red[4];
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->used[parity ^ 1] = 0;   // arm the next flush
+    const int t = blockIdx.y;
+    const uint32_t slot = ring_slot(fb, t);
+    if (blockIdx.x == 0 && t == 0 && threadIdx.x < RING_MAX) st->used[fb.parity ^ 1][threadIdx.x] = 0;  // arm the next flush
+    const uint32_t *hist = hists + (size_t)slot * (size_t)fb.num_bins;
     unsigned cnt = 0;
-    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < num_bins; b += gridDim.x * blockDim.x)
+    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < fb.num_bins; b += gridDim.x * blockDim.x)
         cnt += hist[b] != 0;
     for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
     if (lane_id() == 0) red[threadIdx.x >> 6] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) {
         cnt = red[0] + red[1] + red[2] + red[3];
-        if (cnt) atomicAdd(&st->used[parity], cnt);      // one per block; the grid is small
+        if (cnt) atomicAdd(&st->used[fb.parity][slot], cnt);   // one per block; the grid is small
     }
 }
 
@@ -623,84 +648,148 @@ __global__ __launch_bounds__(256) void k_count_used(const uint32_t *__restrict__
 // is ascending bin id, so the value returned by Add() for bin x in row d is
 //     ctr_before[d][g] + sum{ v(y) : y <= x, pos_d(y) == g },   g = jump(x*(d+1), width)
 // i.e. an ordered prefix sum along the static chain of bins that share counter (d,g).
-// One wave per chain; perm/chain_start are built once on the host.
+// One wave per chain, spectra of the batch in order; perm/chain_start are built once on the host.
+// est[t][bin][d] receives the estimate of row d.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cms_chains(const uint32_t *__restrict__ hist,
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u_zero(uint32_t v) {    // 0 where the source lane is invalid / row masked
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+// wave-wide inclusive prefix sum with DPP only (6 VALU instructions); lane 63 ends with the total
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+    x += dpp_u_zero<0x111, 0xf>(x);      // row_shr:1
+    x += dpp_u_zero<0x112, 0xf>(x);      // row_shr:2
+    x += dpp_u_zero<0x114, 0xf>(x);      // row_shr:4
+    x += dpp_u_zero<0x118, 0xf>(x);      // row_shr:8      -> scan inside each row of 16
+    x += dpp_u_zero<0x142, 0xa>(x);      // row_bcast15 -> rows 1,3
+    x += dpp_u_zero<0x143, 0xc>(x);      // row_bcast31 -> rows 2,3
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_cms_chains(const uint32_t *__restrict__ hists,
                                                     const uint32_t *__restrict__ perm,
                                                     const uint32_t *__restrict__ chain_start,
                                                     unsigned long long *__restrict__ ctr,
-                                                    unsigned long long *__restrict__ est,
-                                                    int32_t num_bins, int depth, int width,
-                                                    DevState *st, int parity) {
-    if (!flush_go(st, parity, num_bins)) return;
+                                                    uint32_t *__restrict__ estl,
+                                                    unsigned long long *__restrict__ basearr,
+                                                    int depth, int width, const DevState *st,
+                                                    FlushBatch fb) {
+    // estl[t][d][idx]  : prefix sum inside the chain, stored in CHAIN order (coalesced)
+    // basearr[t][chain]: counter value in front of spectrum t
     const int lane = lane_id();
     const int chain = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (chain >= depth * width) return;
     const int d = chain / width, g = chain - d * width;
     const uint32_t s = chain_start[d * (width + 1) + g], e = chain_start[d * (width + 1) + g + 1];
-    unsigned long long total = ctr[chain];
-    const uint32_t *pd = perm + (size_t)d * num_bins;
+    const uint32_t *pd = perm + (size_t)d * fb.num_bins;
+    const size_t B = (size_t)fb.num_bins;
+    const int count = (int)fb.count;
+    uint32_t gomask = 0;
+    for (int t = 0; t < count; t++) gomask |= flush_go(st, fb, t) ? (1u << t) : 0u;
+
+    uint32_t carry[SCAN_BATCH_MAX];
+#pragma unroll
+    for (int t = 0; t < SCAN_BATCH_MAX; t++) carry[t] = 0;
     for (uint32_t base = s; base < e; base += 64) {
         const uint32_t idx = base + lane;
-        uint32_t bin = 0; unsigned long long v = 0;
-        if (idx < e) { bin = pd[idx]; v = hist[bin]; }
-        unsigned long long incl = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            unsigned long long t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
+        const uint32_t bin = idx < e ? pd[idx] : 0u;
+        uint32_t v[SCAN_BATCH_MAX];
+#pragma unroll
+        for (int t = 0; t < SCAN_BATCH_MAX; t++)
+            v[t] = (t < count && idx < e && ((gomask >> t) & 1u)) ? hists[(size_t)ring_slot(fb, t) * B + bin] : 0u;
+#pragma unroll
+        for (int t = 0; t < SCAN_BATCH_MAX; t++) {
+            if (t < count && ((gomask >> t) & 1u)) {
+                const uint32_t incl = wave_scan_incl(v[t]);
+                if (idx < e) estl[((size_t)t * depth + d) * B + idx] = carry[t] + incl;
+                carry[t] += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
         }
-        if (v) est[(size_t)bin * CMS_DEPTH_MAX + d] = total + incl;
-        total += __shfl(incl, 63);
     }
-    if (lane == 0) ctr[chain] = total;
+    if (lane == 0) {
+        unsigned long long run = ctr[chain];
+#pragma unroll
+        for (int t = 0; t < SCAN_BATCH_MAX; t++)
+            if (t < count) { basearr[(size_t)t * (depth * width) + chain] = run; run += carry[t]; }
+        ctr[chain] = run;
+    }
 }
 
-// estiFreq = min over rows; fp32 reciprocal for the streaming pass; wipe the spectrum
-// (kmerspectrum.go:58-64).  Excluded (zero) bins get rcp = NaN so that fminf() ignores them.
-__global__ __launch_bounds__(256) void k_freq(uint32_t *__restrict__ hist,
-                                              const unsigned long long *__restrict__ est,
+// estiFreq = min over rows of (counter in front of the spectrum + prefix inside the chain);
+// fp32 reciprocal for the streaming pass; wipe the spectrum (kmerspectrum.go:58-64).
+// Excluded (zero) bins get rcp = NaN so that fminf() ignores them.   grid = (blocks, count)
+__global__ __launch_bounds__(256) void k_freq(uint32_t *__restrict__ hists,
+                                              const uint32_t *__restrict__ estl,
+                                              const unsigned long long *__restrict__ basearr,
+                                              const uint32_t *__restrict__ invperm,
+                                              const uint16_t *__restrict__ pos16,
                                               double *__restrict__ f64, float *__restrict__ rcp32,
-                                              int32_t num_bins, int depth, DevState *st, int parity) {
-    const bool go = flush_go(st, parity, num_bins);
+                                              int depth, int width, size_t row_stride, DevState *st,
+                                              FlushBatch fb) {
+    const int t = blockIdx.y;
+    const bool go = flush_go(st, fb, t);
+    const uint32_t slot = ring_slot(fb, t);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const unsigned used = st->used[parity];
+        const unsigned used = st->used[fb.parity][slot];
         if (used != 0 && !go) set_error(st, -5);
-        if (go) st->n_elements += used;
+        if (go) atomicAdd(&st->n_elements, (unsigned long long)used);
     }
     if (!go) return;      // reference: empty spectrum is skipped un-wiped (it is all zero); error is fatal
-    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < num_bins; b += gridDim.x * blockDim.x) {
+    const size_t B = (size_t)fb.num_bins;
+    uint32_t *hist = hists + (size_t)slot * B;
+    double *ft = f64 + (size_t)t * B;
+    float *rt = rcp32 + (size_t)t * row_stride;
+    const unsigned long long *bt = basearr + (size_t)t * (depth * width);
+    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < fb.num_bins; b += gridDim.x * blockDim.x) {
         const uint32_t h = hist[b];
         if (h) {
             unsigned long long m = ~0ull;
-            for (int d = 0; d < depth; d++) { unsigned long long e = est[(size_t)b * CMS_DEPTH_MAX + d]; m = e < m ? e : m; }
+            for (int d = 0; d < depth; d++) {
+                const unsigned long long e = bt[d * width + pos16[(size_t)d * B + b]] +
+                                             estl[((size_t)t * depth + d) * B + invperm[(size_t)d * B + b]];
+                m = e < m ? e : m;
+            }
             const double f = (double)m;
-            f64[b] = f;
-            rcp32[b] = (float)(1.0 / f);
+            ft[b] = f;
+            rt[b] = (float)(1.0 / f);
             hist[b] = 0;
         } else {
-            f64[b] = 0.0;
-            rcp32[b] = __builtin_nanf("");
+            ft[b] = 0.0;
+            rt[b] = __builtin_nanf("");
         }
     }
 }
 
+// wave-wide minimum with DPP (result valid in lane 63): 6 VALU instructions, no LDS traffic
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_min_to_lane63(float v) {
+    v = fminf(v, dpp_f<0xB1, 0xf>(v));     // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_f<0x4E, 0xf>(v));     // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_f<0x141, 0xf>(v));    // row_half_mirror
+    v = fminf(v, dpp_f<0x140, 0xf>(v));    // row_mirror            -> every row uniform
+    v = fminf(v, dpp_f<0x142, 0xa>(v));    // row_bcast15 into rows 1,3
+    v = fminf(v, dpp_f<0x143, 0xc>(v));    // row_bcast31 into rows 2,3 -> lane 63 holds the wave minimum
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------
-// K4a: the HBM-bound pass.  A[slot][bin] = K[slot][bin] * (1/f[bin]);  per (slot, tile) minimum.
-// Each workgroup streams SCAN_ROWS rows x SCAN_TILE bins of K (16 B per lane per row, all rows'
-// loads independent => SCAN_ROWS x 16 B in flight per lane) against one register-resident
-// float4 of reciprocals.
+// K4a: the HBM-bound pass.  A[t][slot][bin] = K[slot][bin] * (1/f_t[bin]); minimum per
+// (interval t, slot, 256-bin wave tile).  A workgroup streams SCAN_ROWS rows x SCAN_TILE bins of K
+// exactly once (16 B per lane per row, SCAN_ROWS independent loads in flight) and re-uses the
+// registers for every interval of the batch, so the table is read once per BATCH, not per interval.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
                                                   const float *__restrict__ rcp32,
                                                   float *__restrict__ tilemin, int slots, int ntiles,
-                                                  size_t row_stride, const DevState *st, int parity,
-                                                  int32_t num_bins) {
-    if (!flush_go(st, parity, num_bins)) return;
-    __shared__ float red[4][SCAN_ROWS];
+                                                  size_t row_stride, const DevState *st, FlushBatch fb) {
     const int tile = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wid = tid >> 6;
     const size_t col = (size_t)tile * SCAN_TILE + (size_t)tid * 4;
-    const floatx4 rc = *(const floatx4 *)(rcp32 + col);
+    const int wtiles = ntiles * 4;                               // 256-bin wave tiles per row
     floatx4 kv[SCAN_ROWS];
 #pragma unroll
     for (int r = 0; r < SCAN_ROWS; r++) {
@@ -710,101 +799,147 @@ __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
         else
             kv[r] = (floatx4)(0.f);
     }
-    float m[SCAN_ROWS];
+    uint32_t gomask = 0;
+    for (int t = 0; t < (int)fb.count; t++) gomask |= flush_go(st, fb, t) ? (1u << t) : 0u;
+    floatx4 rc_next = *(const floatx4 *)(rcp32 + col);
+    for (int t = 0; t < (int)fb.count; t++) {
+        const floatx4 rc = rc_next;
+        if (t + 1 < (int)fb.count) rc_next = *(const floatx4 *)(rcp32 + (size_t)(t + 1) * row_stride + col);
+        if (!((gomask >> t) & 1u)) continue;
+        float m[SCAN_ROWS];
 #pragma unroll
-    for (int r = 0; r < SCAN_ROWS; r++) {
-        float a = fminf(kv[r].x * rc.x, kv[r].y * rc.y);
-        float b = fminf(kv[r].z * rc.z, kv[r].w * rc.w);
-        m[r] = fminf(INFINITY, fminf(a, b));
-    }
+        for (int r = 0; r < SCAN_ROWS; r++) {
+            const float a = fminf(kv[r].x * rc.x, kv[r].y * rc.y);
+            const float b = fminf(kv[r].z * rc.z, kv[r].w * rc.w);
+            m[r] = fminf(INFINITY, fminf(a, b));
+        }
 #pragma unroll
-    for (int r = 0; r < SCAN_ROWS; r++)
-        for (int off = 32; off; off >>= 1) m[r] = fminf(m[r], __shfl_xor(m[r], off));
-    if ((tid & 63) == 0) {
+        for (int r = 0; r < SCAN_ROWS; r++) m[r] = wave_min_to_lane63(m[r]);
+        if ((tid & 63) == 63) {
+            float *out = tilemin + ((size_t)t * slots) * wtiles + (size_t)(tile * 4 + wid);
 #pragma unroll
-        for (int r = 0; r < SCAN_ROWS; r++) red[tid >> 6][r] = m[r];
-    }
-    __syncthreads();
-    if (tid < SCAN_ROWS) {
-        const int slot = grp * SCAN_ROWS + tid;
-        if (slot < slots) {
-            float v = fminf(fminf(red[0][tid], red[1][tid]), fminf(red[2][tid], red[3][tid]));
-            tilemin[(size_t)slot * ntiles + tile] = v;
+            for (int r = 0; r < SCAN_ROWS; r++) {
+                const int slot = grp * SCAN_ROWS + r;
+                if (slot < slots) out[(size_t)slot * wtiles] = m[r];
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K4b: per slot, re-evaluate in fp64 — with the literal getSample formula — every tile whose fp32
-// minimum is within a relative band of the slot's fp32 minimum, then apply AddElement's update
-// rule.  The band (1e-5 rel + 1e-37 abs) is >30x the worst fp32 error of K4a, so the true fp64
-// argmin (and every exact tie, for earliest-wins) is always inside a re-evaluated tile.
+// K4b: per slot, interval by interval: re-evaluate in fp64 — with the literal getSample formula —
+// every wave tile whose fp32 minimum is within a relative band of the slot's fp32 minimum, then
+// apply AddElement's update rule.  The band (1e-5 rel + 1e-37 abs) is >30x the worst fp32 error
+// of K4a, so the true fp64 argmin (and every exact tie, for earliest-wins) is always inside a
+// re-evaluated tile.
 // ------------------------------------------------------------------------------------------
+constexpr int WTILE = SCAN_TILE / 4;
 __global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ rcb,
                                                      const double *__restrict__ f64,
                                                      const float *__restrict__ tilemin,
-                                                     unsigned long long *__restrict__ mins,
-                                                     double *__restrict__ weights, int slot_begin,
-                                                     int32_t num_bins, int ntiles, const DevState *st,
-                                                     int parity) {
-    if (!flush_go(st, parity, num_bins)) return;
+                                                     double *__restrict__ candA, int32_t *__restrict__ candB,
+                                                     int slots, int ntiles, const DevState *st,
+                                                     FlushBatch fb) {
     extern __shared__ __align__(16) unsigned char smem[];
-    float *tm = (float *)smem;                       // [ntiles]
+    float *tm = (float *)smem;                       // [wtiles]
     __shared__ float redf[4];
     __shared__ double redA[4];
     __shared__ int32_t redB[4];
-    const int slot = blockIdx.x;                     // local slot
+    __shared__ int ncand;
+    __shared__ int cand[64];
+    const int slot = blockIdx.x, t = blockIdx.y;     // local slot, interval of the batch
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-
-    float g = INFINITY;
-    for (int t = tid; t < ntiles; t += blockDim.x) {
-        const float v = tilemin[(size_t)slot * ntiles + t];
-        tm[t] = v;
-        g = fminf(g, v);
-    }
-    for (int off = 32; off; off >>= 1) g = fminf(g, __shfl_xor(g, off));
-    if (lane == 0) redf[wid] = g;
-    __syncthreads();
-    g = fminf(fminf(redf[0], redf[1]), fminf(redf[2], redf[3]));
-    if (!(g < INFINITY)) return;                     // no element reached this slot's rows
-    const float thr = g + 1e-5f * fabsf(g) + 1e-37f;
-
+    const int wtiles = ntiles * 4;
+    const int32_t num_bins = fb.num_bins;
     double bestA = INFINITY; int32_t bestB = 0x7fffffff;
-    const double *row = rcb + (size_t)slot * (size_t)num_bins * 3;
-    for (int t = 0; t < ntiles; t++) {
-        if (!(tm[t] <= thr)) continue;               // block-uniform
-#pragma unroll
-        for (int qd = 0; qd < SCAN_TILE / 256; qd++) {
-            const int32_t bin = t * SCAN_TILE + qd * 256 + tid;
-            if (bin < num_bins) {
-                const double f = f64[bin];
-                if (f != 0.0) {
-                    const double r = row[(size_t)bin * 3 + 0];
-                    const double c = row[(size_t)bin * 3 + 1];
-                    const double b = row[(size_t)bin * 3 + 2];
-                    const double Yka = exp(log(f) - b);
-                    const double A = c / (Yka * exp(r));
-                    if (A < bestA) { bestA = A; bestB = bin; }   // bins ascend per thread: earliest wins
+    if (flush_go(st, fb, t)) {                        // block-uniform
+        const double *row = rcb + (size_t)slot * (size_t)num_bins * 3;
+        const float *tmin_t = tilemin + ((size_t)t * slots + slot) * wtiles;
+        const double *ft = f64 + (size_t)t * (size_t)num_bins;
+        if (tid == 0) ncand = 0;
+        float g = INFINITY;
+        for (int x = tid; x < wtiles; x += blockDim.x) {
+            const float v = tmin_t[x];
+            tm[x] = v;
+            g = fminf(g, v);
+        }
+        for (int off = 32; off; off >>= 1) g = fminf(g, __shfl_xor(g, off));
+        if (lane == 0) redf[wid] = g;
+        __syncthreads();
+        g = fminf(fminf(redf[0], redf[1]), fminf(redf[2], redf[3]));
+        if (g < INFINITY) {                           // some element reached this slot's row
+            const float thr = g + 1e-5f * fabsf(g) + 1e-37f;
+            // candidate wave tiles (normally one): every tile whose fp32 minimum is inside the band
+            bool overflow = false;
+            for (int x = tid; x < wtiles; x += blockDim.x)
+                if (tm[x] <= thr) { const int at = atomicAdd(&ncand, 1); if (at < 64) cand[at] = x; else overflow = true; }
+            __syncthreads();
+            const int nc = ncand;                     // block-uniform
+            if (nc <= 64) {
+                for (int ci = 0; ci < nc; ci++) {
+                    const int32_t bin = cand[ci] * WTILE + tid;      // WTILE == blockDim.x
+                    if (bin < num_bins) {
+                        const double f = ft[bin];
+                        if (f != 0.0) {
+                            const double r = row[(size_t)bin * 3 + 0];
+                            const double c = row[(size_t)bin * 3 + 1];
+                            const double b = row[(size_t)bin * 3 + 2];
+                            const double Yka = exp(log(f) - b);
+                            const double A = c / (Yka * exp(r));
+                            if (A < bestA || (A == bestA && bin < bestB)) { bestA = A; bestB = bin; }
+                        }
+                    }
+                }
+            } else {
+                // degenerate spectrum (many equal minima): evaluate every tile inside the band
+                for (int x = 0; x < wtiles; x++) {
+                    if (!(tm[x] <= thr)) continue;
+                    const int32_t bin = x * WTILE + tid;
+                    if (bin < num_bins) {
+                        const double f = ft[bin];
+                        if (f != 0.0) {
+                            const double r = row[(size_t)bin * 3 + 0];
+                            const double c = row[(size_t)bin * 3 + 1];
+                            const double b = row[(size_t)bin * 3 + 2];
+                            const double Yka = exp(log(f) - b);
+                            const double A = c / (Yka * exp(r));
+                            if (A < bestA || (A == bestA && bin < bestB)) { bestA = A; bestB = bin; }
+                        }
+                    }
                 }
             }
+            (void)overflow;
+            for (int off = 32; off; off >>= 1) {
+                const double oA = __shfl_xor(bestA, off);
+                const int32_t oB = __shfl_xor(bestB, off);
+                if (oA < bestA || (oA == bestA && oB < bestB)) { bestA = oA; bestB = oB; }
+            }
+            if (lane == 0) { redA[wid] = bestA; redB[wid] = bestB; }
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                if (redA[x] < bestA || (redA[x] == bestA && redB[x] < bestB)) { bestA = redA[x]; bestB = redB[x]; }
         }
     }
-    for (int off = 32; off; off >>= 1) {
-        const double oA = __shfl_xor(bestA, off);
-        const int32_t oB = __shfl_xor(bestB, off);
-        if (oA < bestA || (oA == bestA && oB < bestB)) { bestA = oA; bestB = oB; }
+    if (tid == 0) { candA[(size_t)t * slots + slot] = bestA; candB[(size_t)t * slots + slot] = bestB; }
+}
+
+// AddElement's slot update (histosketch.go:150-153, no drift) in interval order: the element with
+// the smallest A of interval t replaces the slot iff it is strictly below the running weight.
+__global__ void k_cws_apply(const double *__restrict__ candA, const int32_t *__restrict__ candB,
+                            unsigned long long *__restrict__ mins, double *__restrict__ weights,
+                            int slots, int slot_begin, const DevState *st, FlushBatch fb) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= slots) return;
+    const int gs = slot_begin + slot;
+    double w = weights[gs]; unsigned long long m = mins[gs];
+    for (int t = 0; t < (int)fb.count; t++) {
+        if (!flush_go(st, fb, t)) continue;
+        const double A = candA[(size_t)t * slots + slot];
+        const int32_t b = candB[(size_t)t * slots + slot];
+        if (b != 0x7fffffff && A < w) { w = A; m = (unsigned long long)b; }
     }
-    if (lane == 0) { redA[wid] = bestA; redB[wid] = bestB; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int x = 1; x < 4; x++)
-            if (redA[x] < bestA || (redA[x] == bestA && redB[x] < bestB)) { bestA = redA[x]; bestB = redB[x]; }
-        const int gs = slot_begin + slot;
-        if (bestB != 0x7fffffff && bestA < weights[gs]) {        // histosketch.go:150-153, no drift
-            weights[gs] = bestA;
-            mins[gs] = (unsigned long long)bestB;
-        }
-    }
+    weights[gs] = w; mins[gs] = m;
 }
 
 // K = c * exp(b - r) in fp64, rounded once to fp32 (pad columns stay 0: 0 * NaN = NaN, ignored)
@@ -849,7 +984,7 @@ __global__ void k_add_hist(uint32_t *hist, const uint32_t *add, int32_t n) {
 
 // ---------------------------------------------------------------------------- host wrappers
 size_t minimizer_lds_per_wave(uint32_t xcap, uint32_t tab_size) {
-    size_t words = (size_t)xcap + (xcap + 63) / 64 + tab_size + 128;
+    size_t words = (size_t)xcap + (xcap + 63) / 64 + tab_size + 128 + 64;
     size_t pk = ((size_t)xcap + 32 + 3) / 4 + 16;          // packed bases + slack for 3-dword reads
     pk = (pk + 7) & ~(size_t)7;
     return words * 8 + pk;
@@ -882,7 +1017,7 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
 }
 
 size_t minimizer_fast_lds(uint32_t) {
-    return 256 + 4 * (size_t)FAST_Q * 8 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4;
+    return 256 + 4 * (size_t)FAST_Q * 8 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)FAST_Q * 4;
 }
 
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
@@ -907,48 +1042,49 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
     return hipGetLastError();
 }
 
-hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hist, int32_t num_bins, DevState *st,
-                             int parity) {
-    int blocks = (num_bins + 2047) / 2048; if (blocks > 128) blocks = 128;
-    hipLaunchKernelGGL(k_count_used, dim3(blocks), dim3(256), 0, s, d_hist, num_bins, st, parity);
+hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb) {
+    int blocks = (fb.num_bins + 2047) / 2048; if (blocks > 128) blocks = 128;
+    hipLaunchKernelGGL(k_count_used, dim3(blocks, fb.count), dim3(256), 0, s, d_hists, st, fb);
     return hipGetLastError();
 }
 
-hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hist, const uint32_t *d_perm,
+hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,
                              const uint32_t *d_chain_start, unsigned long long *d_ctr,
-                             unsigned long long *d_est, int32_t num_bins, int depth, int width,
-                             DevState *st, int parity) {
+                             uint32_t *d_estl, unsigned long long *d_basearr, int depth, int width,
+                             DevState *st, const FlushBatch &fb) {
     const int chains = depth * width;
     const int blocks = (chains + 3) / 4;
-    hipLaunchKernelGGL(k_cms_chains, dim3(blocks), dim3(256), 0, s, d_hist, d_perm, d_chain_start,
-                       d_ctr, d_est, num_bins, depth, width, st, parity);
+    hipLaunchKernelGGL(k_cms_chains, dim3(blocks), dim3(256), 0, s, d_hists, d_perm, d_chain_start,
+                       d_ctr, d_estl, d_basearr, depth, width, st, fb);
     return hipGetLastError();
 }
 
-hipError_t launch_freq(hipStream_t s, uint32_t *d_hist, const unsigned long long *d_est,
-                       double *d_f64, float *d_rcp32, int32_t num_bins, int depth, DevState *st,
-                       int parity) {
-    int blocks = (num_bins + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_freq, dim3(blocks), dim3(256), 0, s, d_hist, d_est, d_f64, d_rcp32, num_bins,
-                       depth, st, parity);
+hipError_t launch_freq(hipStream_t s, uint32_t *d_hists, const uint32_t *d_estl,
+                       const unsigned long long *d_basearr, const uint32_t *d_invperm,
+                       const uint16_t *d_pos16, double *d_f64, float *d_rcp32, int depth, int width,
+                       size_t row_stride, DevState *st, const FlushBatch &fb) {
+    int blocks = (fb.num_bins + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_freq, dim3(blocks, fb.count), dim3(256), 0, s, d_hists, d_estl, d_basearr,
+                       d_invperm, d_pos16, d_f64, d_rcp32, depth, width, row_stride, st, fb);
     return hipGetLastError();
 }
 
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
-                           int slots, int ntiles, size_t row_stride, int32_t num_bins, DevState *st,
-                           int parity) {
+                           int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb) {
     const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
     hipLaunchKernelGGL(k_cws_scan, dim3((unsigned)(groups * ntiles)), dim3(256), 0, s, d_k32, d_rcp32,
-                       d_tilemin, slots, ntiles, row_stride, st, parity, num_bins);
+                       d_tilemin, slots, ntiles, row_stride, st, fb);
     return hipGetLastError();
 }
 
 hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,
-                              const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
-                              int slots, int slot_begin, int32_t num_bins, int ntiles, DevState *st,
-                              int parity) {
-    hipLaunchKernelGGL(k_cws_resolve, dim3(slots), dim3(256), (size_t)ntiles * sizeof(float), s, d_rcb,
-                       d_f64, d_tilemin, d_mins, d_weights, slot_begin, num_bins, ntiles, st, parity);
+                              const float *d_tilemin, double *d_candA, int32_t *d_candB,
+                              unsigned long long *d_mins, double *d_weights,
+                              int slots, int slot_begin, int ntiles, DevState *st, const FlushBatch &fb) {
+    hipLaunchKernelGGL(k_cws_resolve, dim3(slots, fb.count), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
+                       d_rcb, d_f64, d_tilemin, d_candA, d_candB, slots, ntiles, st, fb);
+    hipLaunchKernelGGL(k_cws_apply, dim3((slots + 255) / 256), dim3(256), 0, s, d_candA, d_candB, d_mins,
+                       d_weights, slots, slot_begin, st, fb);
     return hipGetLastError();
 }
 

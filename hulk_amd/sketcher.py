@@ -107,10 +107,18 @@ class GpuSketcher:
         self._chk(self._L.hulk_add_reads_device(self._ctx, bases_ptr, offsets_ptr, n_reads,
                                                 max_read_len, bases_bytes))
 
-    def bin_reads_device(self, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes):
+    def bin_reads_device(self, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes,
+                         reads_per_spectrum=0):
         """Multi-GPU step 1: bin this rank's reads, no interval rule (see hulk_hip.h)."""
         self._chk(self._L.hulk_bin_reads_device(self._ctx, bases_ptr, offsets_ptr, n_reads,
-                                                max_read_len, bases_bytes))
+                                                max_read_len, bases_bytes, reads_per_spectrum))
+
+    def flush_batch(self, n_spectra):
+        self._chk(self._L.hulk_flush_batch(self._ctx, n_spectra))
+
+    @property
+    def batch_size(self):
+        return self._L.hulk_batch_size(self._ctx)
 
     def histogram_device_ptr(self):
         return self._L.hulk_histogram_device(self._ctx)

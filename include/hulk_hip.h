@@ -113,12 +113,20 @@ int hulk_add_reads(hulk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets,
 int hulk_add_reads_device(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets,
                           uint64_t n_reads, uint32_t max_read_len, uint64_t bases_bytes);
 
-/* Multi-GPU split of one interval: (1) bin this rank's reads into the context's histogram
- * WITHOUT applying the interval rule, (2) caller all-reduces hulk_histogram_device() across
- * ranks (RCCL, uint32 sum, num_bins elements), (3) hulk_flush() on every rank. */
+/* Intervals are flushed in batches: up to hulk_batch_size() consecutive sketching intervals are
+ * binned into separate k-mer spectra by one kernel launch and then pushed through count-min + CWS
+ * with ONE pass over the CWS table.  The result is identical to flushing them one at a time. */
+uint32_t hulk_batch_size(const hulk_ctx *ctx);
+
+/* Multi-GPU split: (1) bin this rank's reads WITHOUT applying the interval rule: read i goes to
+ * spectrum i / reads_per_spectrum (0 => all into spectrum 0; at most hulk_batch_size() spectra),
+ * (2) the caller all-reduces hulk_histogram_device() across ranks (RCCL, uint32 sum,
+ * n_spectra * num_bins contiguous elements), (3) hulk_flush_batch(n_spectra) on every rank. */
 int hulk_bin_reads_device(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets,
-                          uint64_t n_reads, uint32_t max_read_len, uint64_t bases_bytes);
+                          uint64_t n_reads, uint32_t max_read_len, uint64_t bases_bytes,
+                          uint64_t reads_per_spectrum);
 uint32_t *hulk_histogram_device(hulk_ctx *ctx);
+int hulk_flush_batch(hulk_ctx *ctx, uint32_t n_spectra);
 
 /* Test hook: add counts to the current k-mer spectrum directly (host uint32[num_bins]). */
 int hulk_add_histogram(hulk_ctx *ctx, const uint32_t *bins);
