@@ -335,7 +335,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_weights, S));
     CHK_CREATE(dalloc(&c->d_rcb, SL * B * 3));
     CHK_CREATE(dalloc(&c->d_k32, SL * c->row_stride));
-    CHK_CREATE(dalloc(&c->d_tilemin, T * SL * (size_t)c->ntiles * 4));
+    CHK_CREATE(dalloc(&c->d_tilemin, T * ((SL + SCAN_ROWS - 1) / SCAN_ROWS) * SCAN_ROWS * (size_t)c->ntiles * 4));
     CHK_CREATE(dalloc(&c->d_candA, T * SL));
     CHK_CREATE(dalloc(&c->d_candB, T * SL));
     CHK_CREATE(hipMemsetAsync(c->d_state, 0, sizeof(DevState), c->stream));

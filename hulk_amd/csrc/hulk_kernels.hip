@@ -623,6 +623,14 @@ __device__ __forceinline__ bool flush_go(const DevState *st, const FlushBatch &f
     return !(prop < 0.01);
 }
 
+// all flush decisions of the batch with ONE memory round trip (call with the whole wave active)
+__device__ __forceinline__ uint32_t batch_gomask(const DevState *st, const FlushBatch &fb) {
+    const int lane = lane_id();
+    bool go = false;
+    if (lane < (int)fb.count) go = flush_go(st, fb, lane);
+    return (uint32_t)__ballot(go);
+}
+
 // K2: number of used bins (bitvector PopCount in the reference).  grid = (blocks, count)
 __global__ __launch_bounds__(256) void k_count_used(const uint32_t *__restrict__ hists, DevState *st,
                                                     FlushBatch fb) {
@@ -678,14 +686,13 @@ __global__ __launch_bounds__(256) void k_cms_chains(const uint32_t *__restrict__
     // basearr[t][chain]: counter value in front of spectrum t
     const int lane = lane_id();
     const int chain = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t gomask = batch_gomask(st, fb);
     if (chain >= depth * width) return;
     const int d = chain / width, g = chain - d * width;
     const uint32_t s = chain_start[d * (width + 1) + g], e = chain_start[d * (width + 1) + g + 1];
     const uint32_t *pd = perm + (size_t)d * fb.num_bins;
     const size_t B = (size_t)fb.num_bins;
     const int count = (int)fb.count;
-    uint32_t gomask = 0;
-    for (int t = 0; t < count; t++) gomask |= flush_go(st, fb, t) ? (1u << t) : 0u;
 
     uint32_t carry[SCAN_BATCH_MAX];
 #pragma unroll
@@ -760,20 +767,26 @@ __global__ __launch_bounds__(256) void k_freq(uint32_t *__restrict__ hists,
     }
 }
 
-// wave-wide minimum with DPP (result valid in lane 63): 6 VALU instructions, no LDS traffic
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
-                                                                 CTRL, ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ float wave_min_to_lane63(float v) {
-    v = fminf(v, dpp_f<0xB1, 0xf>(v));     // quad_perm [1,0,3,2]
-    v = fminf(v, dpp_f<0x4E, 0xf>(v));     // quad_perm [2,3,0,1]
-    v = fminf(v, dpp_f<0x141, 0xf>(v));    // row_half_mirror
-    v = fminf(v, dpp_f<0x140, 0xf>(v));    // row_mirror            -> every row uniform
-    v = fminf(v, dpp_f<0x142, 0xa>(v));    // row_bcast15 into rows 1,3
-    v = fminf(v, dpp_f<0x143, 0xc>(v));    // row_bcast31 into rows 2,3 -> lane 63 holds the wave minimum
-    return v;
+// Wave-wide minimum of 8 independent (non-NaN) values with DPP-modified v_min_f32: 6 instructions per
+// value, no LDS traffic; lane 63 ends with the wave minimum.  Written as ONE asm block with the 8
+// values interleaved per step so that no DPP source was written by the two preceding instructions
+// (the VALU->DPP read hazard needs 2 wait states; hipcc emits mov+mov_dpp+canonicalise+min per step
+// for the equivalent builtin sequence, 4x the instructions).
+__device__ __forceinline__ void wave_min8_to_lane63(float (&m)[8]) {
+#define HULK_DPP_STEP(ctrl)                                                   \
+    "v_min_f32_dpp %0, %0, %0 " ctrl "\n\t" "v_min_f32_dpp %1, %1, %1 " ctrl "\n\t"   \
+    "v_min_f32_dpp %2, %2, %2 " ctrl "\n\t" "v_min_f32_dpp %3, %3, %3 " ctrl "\n\t"   \
+    "v_min_f32_dpp %4, %4, %4 " ctrl "\n\t" "v_min_f32_dpp %5, %5, %5 " ctrl "\n\t"   \
+    "v_min_f32_dpp %6, %6, %6 " ctrl "\n\t" "v_min_f32_dpp %7, %7, %7 " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 HULK_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 HULK_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 HULK_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 HULK_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+                 HULK_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 HULK_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]));
+#undef HULK_DPP_STEP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -799,8 +812,8 @@ __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
         else
             kv[r] = (floatx4)(0.f);
     }
-    uint32_t gomask = 0;
-    for (int t = 0; t < (int)fb.count; t++) gomask |= flush_go(st, fb, t) ? (1u << t) : 0u;
+    const uint32_t gomask = batch_gomask(st, fb);
+    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
     floatx4 rc_next = *(const floatx4 *)(rcp32 + col);
     for (int t = 0; t < (int)fb.count; t++) {
         const floatx4 rc = rc_next;
@@ -813,15 +826,15 @@ __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
             const float b = fminf(kv[r].z * rc.z, kv[r].w * rc.w);
             m[r] = fminf(INFINITY, fminf(a, b));
         }
-#pragma unroll
-        for (int r = 0; r < SCAN_ROWS; r++) m[r] = wave_min_to_lane63(m[r]);
+        static_assert(SCAN_ROWS == 8, "wave_min8_to_lane63 reduces exactly 8 rows");
+        wave_min8_to_lane63(m);
         if ((tid & 63) == 63) {
-            float *out = tilemin + ((size_t)t * slots) * wtiles + (size_t)(tile * 4 + wid);
-#pragma unroll
-            for (int r = 0; r < SCAN_ROWS; r++) {
-                const int slot = grp * SCAN_ROWS + r;
-                if (slot < slots) out[(size_t)slot * wtiles] = m[r];
-            }
+            // tilemin[t][slot group][wave tile][row]: the 8 rows of a wave tile are one 32-byte store
+            floatx4 *out = (floatx4 *)(tilemin + (((size_t)t * ngroups + grp) * wtiles + (size_t)(tile * 4 + wid)) * SCAN_ROWS);
+            floatx4 a, b;
+            a.x = m[0]; a.y = m[1]; a.z = m[2]; a.w = m[3];
+            b.x = m[4]; b.y = m[5]; b.z = m[6]; b.w = m[7];
+            out[0] = a; out[1] = b;
         }
     }
 }
@@ -854,12 +867,13 @@ __global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ 
     double bestA = INFINITY; int32_t bestB = 0x7fffffff;
     if (flush_go(st, fb, t)) {                        // block-uniform
         const double *row = rcb + (size_t)slot * (size_t)num_bins * 3;
-        const float *tmin_t = tilemin + ((size_t)t * slots + slot) * wtiles;
+        const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+        const float *tmin_t = tilemin + (((size_t)t * ngroups + slot / SCAN_ROWS) * wtiles) * SCAN_ROWS + (slot % SCAN_ROWS);
         const double *ft = f64 + (size_t)t * (size_t)num_bins;
         if (tid == 0) ncand = 0;
         float g = INFINITY;
         for (int x = tid; x < wtiles; x += blockDim.x) {
-            const float v = tmin_t[x];
+            const float v = tmin_t[(size_t)x * SCAN_ROWS];
             tm[x] = v;
             g = fminf(g, v);
         }
