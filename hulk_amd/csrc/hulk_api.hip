@@ -60,7 +60,7 @@ int32_t jump_host(uint64_t key, int64_t n) {
     return (int32_t)b;
 }
 
-struct ProfileRec { hipEvent_t a, b; };
+struct ProfileRec { hipEvent_t a, b; int which; };   // which: 0 = k_cws_scan, 1 = k_minimizer_fast
 
 }  // namespace
 
@@ -214,8 +214,14 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             c->d_slow_cap = n + n / 4 + 1024;
         }
         HIPCHK(c, hipMemsetAsync(c->d_slow_count, 0, 4, c->stream));
+        ProfileRec pr{}; pr.which = 1;
+        if (c->profiling) {
+            HIPCHK(c, hipEventCreate(&pr.a)); HIPCHK(c, hipEventCreate(&pr.b));
+            HIPCHK(c, hipEventRecord(pr.a, c->stream));
+        }
         HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->d_hist, c->d_state,
                                         c->d_min_slots, c->d_slow_list, c->d_slow_count));
+        if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
         if (!pick_config(c->p.k, max_len, P, threads)) return fail(c, HULK_ERR_READ_TOO_LONG);
         const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(1024, (n + 3) / 4);
         HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, c->d_hist, c->d_state,
@@ -584,15 +590,20 @@ int hulk_set_profiling(hulk_ctx *c, int enabled) {
 
 int hulk_get_profile(hulk_ctx *c, const char *kernel, uint64_t *launches, double *total_ms) {
     if (!c || !launches || !total_ms) return fail(c, HULK_ERR_ARG, "NULL");
-    if (kernel && strcmp(kernel, "k_cws_scan") != 0) return fail(c, HULK_ERR_ARG, "only k_cws_scan is instrumented");
+    int which = 0;
+    if (kernel && strcmp(kernel, "k_minimizer_fast") == 0) which = 1;
+    else if (kernel && strcmp(kernel, "k_cws_scan") != 0)
+        return fail(c, HULK_ERR_ARG, "instrumented kernels: k_cws_scan, k_minimizer_fast");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double tot = 0; uint64_t n = 0;
+    std::vector<ProfileRec> keep;
     for (auto &pr : c->prof) {
+        if (pr.which != which) { keep.push_back(pr); continue; }
         float ms = 0;
         if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) { tot += ms; n++; }
         hipEventDestroy(pr.a); hipEventDestroy(pr.b);
     }
-    c->prof.clear();
+    c->prof.swap(keep);
     *launches = n; *total_ms = tot;
     return HULK_OK;
 }

@@ -150,10 +150,10 @@ int hulk_get_cws_tables(hulk_ctx *ctx, double *r, double *c, double *b);
  * checks RN(1/r) against IEEE division for EVERY r in [1, 2^31] and returns the mismatch count. */
 int hulk_selftest_reciprocal(hulk_ctx *ctx, uint64_t *mismatches);
 
-/* Per-kernel timing for bench.py: when enabled, hipEvents bracket every launch of the CWS
- * table-scan kernel on the work stream. */
+/* Per-kernel timing for bench.py: when enabled, hipEvents bracket every launch of the two heavy
+ * kernels ("k_minimizer_fast", "k_cws_scan") on the work stream. */
 int hulk_set_profiling(hulk_ctx *ctx, int enabled);
-/* Returns number of timed launches; *total_ms = summed duration (synchronises). Resets the log. */
+/* Number of timed launches of `kernel` and their summed duration (synchronises; clears that log). */
 int hulk_get_profile(hulk_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);
 
 #ifdef __cplusplus

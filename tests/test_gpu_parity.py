@@ -190,3 +190,53 @@ def test_jump_hash_many_keys_large_bins():
     o, g = run_both(seqs, 31, 9, 2)
     assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32))
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("batch", [1, 3, 16])
+def test_interval_batches_ring_wraparound(batch, monkeypatch):
+    """Intervals are flushed in batches of HULK_BATCH spectra held in a ring; uneven host calls leave
+    partial intervals pending across calls and wrap the ring many times.  Must equal the oracle's
+    flush-every-interval result bit for bit."""
+    monkeypatch.setenv("HULK_BATCH", str(batch))
+    rng = np.random.default_rng(batch)
+    k, w, S, interval = 11, 5, 16, 50
+    seqs = random_reads(rng, 2113, (60, 150), b"ACGTN" if batch == 3 else b"ACGT")
+    o = pyorc.Sketcher(k, w, S, 0, 1.0, interval)
+    g = gpu().GpuSketcher(k, w, S, interval)
+    assert g.batch_size == batch
+    bases, offsets = pack_reads(seqs)
+    o.add_reads(bases, offsets)
+    cuts = [0, 7, 50, 51, 420, 1000, 1777, 2113]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        g.add_reads(bases, offsets[a:b + 1])
+    assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32))   # the pending partial interval
+    o.finish(); g.finish()
+    assert o.counters()["n_minimizers"] == g.counters()["n_minimizers"]
+    assert np.array_equal(g.cms(), o.cms())
+    assert_same_sketch(o, g)
+    g.close(); o.close()
+
+
+def test_bin_then_flush_batch_equals_interval_rule():
+    """The multi-GPU entry points (bin_reads_device + flush_batch) on one GPU = the interval rule."""
+    import torch
+    from hulk_amd import synth
+    k, w, S, interval, T = 13, 7, 12, 300, 5
+    os_env = __import__("os").environ
+    os_env["HULK_BATCH"] = str(T)
+    try:
+        g = gpu().GpuSketcher(k, w, S, 0)
+        o = pyorc.Sketcher(k, w, S, 0, 1.0, interval)
+        for step in range(3):
+            b, off = synth.reads_torch(step * interval * T, interval * T, 120)
+            g.bin_reads_device(b.data_ptr(), off.data_ptr(), interval * T, 120, b.numel(), interval)
+            g.flush_batch(T)
+            hb, ho = synth.reads_numpy(step * interval * T, interval * T, 120)
+            o.add_reads(hb, ho)
+        torch.cuda.synchronize()
+        o.finish(); g.finish()
+        assert_same_sketch(o, g)
+        assert np.array_equal(g.cms(), o.cms())
+        g.close(); o.close()
+    finally:
+        os_env.pop("HULK_BATCH", None)
