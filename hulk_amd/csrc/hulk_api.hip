@@ -70,7 +70,9 @@ struct hulk_ctx {
     uint32_t S = 0, slot_begin = 0, slots = 0;
     int cms_depth = 0, cms_width = 0;
     int ntiles = 0; size_t row_stride = 0;
-    bool drift = false;
+    bool drift = false, scaling = false;   // ApplyConceptDrift (histosketch.go:79-81), applyScaling (countmin.go:50-55)
+    double decay_weight = 0.0;
+    uint32_t *d_blkcnt = nullptr, *d_eidx = nullptr, *d_etot = nullptr; double *d_ctrd = nullptr, *d_estd = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // device state
     DevState *d_state = nullptr;
@@ -244,10 +246,18 @@ int flush_batch(hulk_ctx *c, uint32_t count) {
     fb.parity = (int)(c->flush_index & 1); fb.num_bins = c->B;
     hipStream_t s = c->stream;
     HIPCHK(c, launch_count_used(s, c->d_hist, c->d_state, fb));
-    HIPCHK(c, launch_cms_chains(s, c->d_hist, c->d_perm, c->d_chain_start, c->d_ctr, c->d_estl, c->d_basearr,
-                                c->cms_depth, c->cms_width, c->d_state, fb));
-    HIPCHK(c, launch_freq(s, c->d_hist, c->d_estl, c->d_basearr, c->d_invperm, c->d_pos16, c->d_f64, c->d_rcp32,
-                          c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
+    if (c->scaling) {
+        HIPCHK(c, launch_elem_index(s, c->d_hist, c->d_blkcnt, c->d_eidx, c->d_etot, fb));
+        HIPCHK(c, launch_cms_chains_decay(s, c->d_hist, c->d_perm, c->d_chain_start, c->d_eidx, c->d_etot, c->d_ctrd,
+                                          c->d_estd, c->cms_depth, c->cms_width, c->decay_weight, c->d_state, fb));
+        HIPCHK(c, launch_freq_decay(s, c->d_hist, c->d_estd, c->d_invperm, c->d_f64, c->d_rcp32, c->cms_depth,
+                                    c->row_stride, c->d_state, fb));
+    } else {
+        HIPCHK(c, launch_cms_chains(s, c->d_hist, c->d_perm, c->d_chain_start, c->d_ctr, c->d_estl, c->d_basearr,
+                                    c->cms_depth, c->cms_width, c->d_state, fb));
+        HIPCHK(c, launch_freq(s, c->d_hist, c->d_estl, c->d_basearr, c->d_invperm, c->d_pos16, c->d_f64, c->d_rcp32,
+                              c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
+    }
     if (c->slots) {
         ProfileRec pr{};
         if (c->profiling) {
@@ -257,6 +267,10 @@ int flush_batch(hulk_ctx *c, uint32_t count) {
         HIPCHK(c, launch_cws_scan(s, c->d_k32, c->d_rcp32, c->d_tilemin, (int)c->slots, c->ntiles,
                                   c->row_stride, c->d_state, fb));
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
+        if (c->drift)
+            HIPCHK(c, launch_cws_resolve_drift(s, c->d_rcb, c->d_f64, c->d_tilemin, c->d_mins, c->d_weights, (int)c->slots,
+                                               (int)c->slot_begin, c->ntiles, c->decay_weight, c->d_state, fb));
+        else
         HIPCHK(c, launch_cws_resolve(s, c->d_rcb, c->d_f64, c->d_tilemin, c->d_candA, c->d_candB, c->d_mins, c->d_weights,
                                      (int)c->slots, (int)c->slot_begin, c->ntiles, c->d_state, fb));
     }
@@ -299,8 +313,6 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     if (p.slot_count == 0) { p.slot_begin = 0; p.slot_count = p.sketch_size; }
     if ((uint64_t)p.slot_begin + p.slot_count > p.sketch_size) return fail(nullptr, HULK_ERR_ARG, "slot shard outside sketch");
     if (p.cws_source > HULK_CWS_EXTERNAL) return fail(nullptr, HULK_ERR_ARG, "cws_source");
-    if (p.decay_ratio != 1.0)
-        return fail(nullptr, HULK_ERR_ARG, "concept-drift (decay_ratio != 1.0) is not implemented in this build yet");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, HULK_ERR_NO_DEVICE);
@@ -313,6 +325,8 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     hulk_ctx *c = new hulk_ctx();
     c->p = p; c->B = (int32_t)bins; c->S = p.sketch_size; c->slot_begin = p.slot_begin; c->slots = p.slot_count;
     c->drift = p.decay_ratio != 1.0;
+    c->scaling = p.decay_ratio > 0.0 && p.decay_ratio < 1.0;
+    c->decay_weight = c->scaling ? std::exp(-p.decay_ratio) : 0.0;   // countmin.go:50-52 (0 otherwise: Go zero value)
     c->cms_width = (int)std::ceil(2 / 0.001);                              // countmin.go:31
     c->cms_depth = (int)std::ceil(std::log(1 - 0.99) / std::log(0.5));     // countmin.go:32
     c->ntiles = (c->B + SCAN_TILE - 1) / SCAN_TILE;
@@ -342,6 +356,15 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_rcb, SL * B * 3));
     CHK_CREATE(dalloc(&c->d_k32, SL * c->row_stride));
     CHK_CREATE(dalloc(&c->d_tilemin, T * ((SL + SCAN_ROWS - 1) / SCAN_ROWS) * SCAN_ROWS * (size_t)c->ntiles * 4));
+    if (c->scaling) {
+        const size_t NC = (size_t)c->cms_depth * c->cms_width;
+        CHK_CREATE(dalloc(&c->d_blkcnt, T * (size_t)elem_index_blocks(c->B)));
+        CHK_CREATE(dalloc(&c->d_eidx, T * B));
+        CHK_CREATE(dalloc(&c->d_etot, T));
+        CHK_CREATE(dalloc(&c->d_ctrd, NC));
+        CHK_CREATE(dalloc(&c->d_estd, T * B * (size_t)c->cms_depth));
+        CHK_CREATE(hipMemsetAsync(c->d_ctrd, 0, NC * 8, c->stream));
+    }
     CHK_CREATE(dalloc(&c->d_candA, T * SL));
     CHK_CREATE(dalloc(&c->d_candB, T * SL));
     CHK_CREATE(hipMemsetAsync(c->d_state, 0, sizeof(DevState), c->stream));
@@ -368,6 +391,7 @@ void hulk_destroy(hulk_ctx *c) {
     for (auto &pr : c->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
     hipFree(c->d_state); hipFree(c->d_hist); hipFree(c->d_hist_tmp); hipFree(c->d_perm); hipFree(c->d_chain_start);
     hipFree(c->d_ctr); hipFree(c->d_estl); hipFree(c->d_basearr); hipFree(c->d_invperm); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
+    hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd); hipFree(c->d_estd);
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
     hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -547,6 +571,11 @@ int hulk_get_histogram(hulk_ctx *c, uint32_t *bins) {
 int hulk_get_cms(hulk_ctx *c, double *counters) {
     if (!c || !counters) return fail(c, HULK_ERR_ARG, "NULL");
     const size_t n = (size_t)c->cms_depth * c->cms_width;
+    if (c->scaling) {
+        HIPCHK(c, hipMemcpyAsync(counters, c->d_ctrd, n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return HULK_OK;
+    }
     std::vector<unsigned long long> tmp(n);
     HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_ctr, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

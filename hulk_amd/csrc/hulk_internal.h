@@ -69,6 +69,20 @@ hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *
                               const float *d_tilemin, double *d_candA, int32_t *d_candB,
                               unsigned long long *d_mins, double *d_weights,
                               int slots, int slot_begin, int ntiles, DevState *st, const FlushBatch &fb);
+hipError_t launch_elem_index(hipStream_t s, const uint32_t *d_hists, uint32_t *d_blkcnt, uint32_t *d_eidx,
+                             uint32_t *d_etot, const FlushBatch &fb);
+int elem_index_blocks(int32_t num_bins);
+hipError_t launch_cms_chains_decay(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,
+                                   const uint32_t *d_chain_start, const uint32_t *d_eidx,
+                                   const uint32_t *d_etot, double *d_ctrd, double *d_estd, int depth,
+                                   int width, double omega, DevState *st, const FlushBatch &fb);
+hipError_t launch_freq_decay(hipStream_t s, uint32_t *d_hists, const double *d_estd,
+                             const uint32_t *d_invperm, double *d_f64, float *d_rcp32, int depth,
+                             size_t row_stride, DevState *st, const FlushBatch &fb);
+hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const double *d_f64,
+                                    const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
+                                    int slots, int slot_begin, int ntiles, double decay_weight,
+                                    DevState *st, const FlushBatch &fb);
 hipError_t launch_build_k32(hipStream_t s, const double *d_rcb, float *d_k32, int slots,
                             int32_t num_bins, size_t row_stride);
 hipError_t launch_selftest_rcp(hipStream_t s, unsigned long long *d_mismatches);

@@ -956,6 +956,245 @@ __global__ void k_cws_apply(const double *__restrict__ candA, const int32_t *__r
     weights[gs] = w; mins[gs] = m;
 }
 
+// ==========================================================================================
+// Concept drift (decay_ratio != 1): reference src/countmin/countmin.go:49-56,103-110,141-147 and
+// src/histosketch/histosketch.go:79-81,139-153.
+//
+// Count-min with uniform scaling (0 < decay < 1): every Add() first multiplies ALL counters by
+// w = exp(-decay).  With i = index of an element inside its flush (ascending non-zero bins), the
+// counter (d,g) right after element i is  C0*w^(i+1) + sum{ v_j * w^(i-j) : j <= i, pos_d(b_j)=g },
+// i.e. along a chain the first-order recurrence  S_m = w^(gap_m) * S_{m-1} + v_m  — an affine scan.
+// (The reference multiplies step by step; the closed form differs by accumulated rounding of
+// ~gap*2^-53 relative, far inside the 1e-5 tolerance the north star states for CWS values.)
+// ==========================================================================================
+
+// element index of every bin = number of non-zero bins in front of it.  grid = (blocks, count)
+constexpr int EIDX_BLOCK = 2048;
+__global__ __launch_bounds__(256) void k_elem_count(const uint32_t *__restrict__ hists,
+                                                    uint32_t *__restrict__ blkcnt, int nblk, FlushBatch fb) {
+    __shared__ unsigned red[4];
+    const int t = blockIdx.y, blk = blockIdx.x;
+    const uint32_t *hist = hists + (size_t)ring_slot(fb, t) * (size_t)fb.num_bins;
+    unsigned cnt = 0;
+    for (int x = 0; x < EIDX_BLOCK / 256; x++) {
+        const int32_t b = blk * EIDX_BLOCK + x * 256 + threadIdx.x;
+        if (b < fb.num_bins) cnt += hist[b] != 0;
+    }
+    for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) blkcnt[(size_t)t * nblk + blk] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_elem_index(const uint32_t *__restrict__ hists,
+                                                    const uint32_t *__restrict__ blkcnt,
+                                                    uint32_t *__restrict__ eidx, uint32_t *__restrict__ etot,
+                                                    int nblk, FlushBatch fb) {
+    __shared__ unsigned red[4];
+    __shared__ unsigned wsum[4];
+    const int t = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const size_t B = (size_t)fb.num_bins;
+    const uint32_t *hist = hists + (size_t)ring_slot(fb, t) * B;
+    // offset of this block = sum of the counts of the blocks in front of it
+    unsigned off = 0, all = 0;
+    for (int x = tid; x < nblk; x += 256) { const unsigned c = blkcnt[(size_t)t * nblk + x]; all += c; if (x < blk) off += c; }
+    for (int o = 32; o; o >>= 1) { off += __shfl_xor(off, o); all += __shfl_xor(all, o); }
+    if (lane == 0) { red[wid] = off; wsum[wid] = all; }
+    __syncthreads();
+    off = red[0] + red[1] + red[2] + red[3];
+    if (blk == 0 && tid == 0) etot[t] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    // 8 consecutive bins per thread
+    const int32_t b0 = blk * EIDX_BLOCK + tid * 8;
+    unsigned nz[8]; unsigned mine = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++) { nz[x] = (b0 + x < fb.num_bins) ? (hist[b0 + x] != 0) : 0u; mine += nz[x]; }
+    unsigned incl = wave_scan_incl(mine);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    unsigned before = off + incl - mine;
+    for (int x = 0; x < wid; x++) before += wsum[x];
+#pragma unroll
+    for (int x = 0; x < 8; x++) { if (b0 + x < fb.num_bins) eidx[(size_t)t * B + b0 + x] = before; before += nz[x]; }
+}
+
+// affine map composition for the chain recurrence: apply (a1,b1) first, then (a2,b2)
+struct Affine { double a, b; };
+__device__ __forceinline__ Affine affine_then(const Affine &first, const Affine &second) {
+    Affine r; r.a = first.a * second.a; r.b = second.a * first.b + second.b; return r;
+}
+
+// One wave per chain, spectra of the batch in order (the counter state flows through them).
+// estd[t][d][idx] (chain order) = value returned for row d.   ctrd = fp64 counters.
+__global__ __launch_bounds__(256) void k_cms_chains_decay(const uint32_t *__restrict__ hists,
+                                                          const uint32_t *__restrict__ perm,
+                                                          const uint32_t *__restrict__ chain_start,
+                                                          const uint32_t *__restrict__ eidx,
+                                                          const uint32_t *__restrict__ etot,
+                                                          double *__restrict__ ctrd, double *__restrict__ estd,
+                                                          int depth, int width, double omega,
+                                                          const DevState *st, FlushBatch fb) {
+    const int lane = lane_id();
+    const int chain = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t gomask = batch_gomask(st, fb);
+    if (chain >= depth * width) return;
+    const int d = chain / width, g = chain - d * width;
+    const uint32_t s = chain_start[d * (width + 1) + g], e = chain_start[d * (width + 1) + g + 1];
+    const uint32_t *pd = perm + (size_t)d * fb.num_bins;
+    const size_t B = (size_t)fb.num_bins;
+    double cval = ctrd[chain];
+    for (int t = 0; t < (int)fb.count; t++) {
+        if (!((gomask >> t) & 1u)) continue;
+        const uint32_t *hist = hists + (size_t)ring_slot(fb, t) * B;
+        const uint32_t *ei = eidx + (size_t)t * B;
+        long long lastj = -1;                           // element index of the previous chain element
+        for (uint32_t base = s; base < e; base += 64) {
+            const uint32_t idx = base + lane;
+            uint32_t bin = 0, v = 0; long long j = -1;
+            if (idx < e) { bin = pd[idx]; v = hist[bin]; if (v) j = (long long)ei[bin]; }
+            // previous element index: running max over the lanes in front (j ascends along the chain)
+            long long pj = j;
+            for (int off = 1; off < 64; off <<= 1) {
+                const long long x = __shfl_up(pj, off);
+                if (lane >= off && x > pj) pj = x;
+            }
+            long long prevj = __shfl_up(pj, 1);
+            if (lane == 0 || prevj < 0) prevj = lastj;
+            Affine m; m.a = 1.0; m.b = 0.0;             // identity for lanes that are not stream elements
+            if (v) { m.a = pow(omega, (double)(j - prevj)); m.b = (double)v; }
+            for (int off = 1; off < 64; off <<= 1) {
+                Affine o; o.a = __shfl_up(m.a, off); o.b = __shfl_up(m.b, off);
+                if (lane >= off) m = affine_then(o, m);
+            }
+            const double val = m.a * cval + m.b;       // counter right after this lane's element
+            if (v) estd[((size_t)t * depth + d) * B + idx] = val;
+            cval = __shfl(val, 63);
+            const long long lj = __shfl(pj, 63);
+            if (lj >= 0) lastj = lj;
+        }
+        cval *= pow(omega, (double)((long long)etot[t] - 1 - lastj));   // scalings by the rest of the flush
+    }
+    if (lane == 0) ctrd[chain] = cval;
+}
+
+__global__ __launch_bounds__(256) void k_freq_decay(uint32_t *__restrict__ hists,
+                                                    const double *__restrict__ estd,
+                                                    const uint32_t *__restrict__ invperm,
+                                                    double *__restrict__ f64, float *__restrict__ rcp32,
+                                                    int depth, size_t row_stride, DevState *st, FlushBatch fb) {
+    const int t = blockIdx.y;
+    const bool go = flush_go(st, fb, t);
+    const uint32_t slot = ring_slot(fb, t);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned used = st->used[fb.parity][slot];
+        if (used != 0 && !go) set_error(st, -5);
+        if (go) atomicAdd(&st->n_elements, (unsigned long long)used);
+    }
+    if (!go) return;
+    const size_t B = (size_t)fb.num_bins;
+    uint32_t *hist = hists + (size_t)slot * B;
+    double *ft = f64 + (size_t)t * B;
+    float *rt = rcp32 + (size_t)t * row_stride;
+    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < fb.num_bins; b += gridDim.x * blockDim.x) {
+        if (hist[b]) {
+            double m = INFINITY;                       // currentMinimum starts at MaxFloat64 (countmin.go:116)
+            for (int d = 0; d < depth; d++) {
+                const double e = estd[((size_t)t * depth + d) * B + invperm[(size_t)d * B + b]];
+                m = e < m ? e : m;
+            }
+            ft[b] = m;
+            rt[b] = (float)(1.0 / m);
+            hist[b] = 0;
+        } else {
+            ft[b] = 0.0;
+            rt[b] = __builtin_nanf("");
+        }
+    }
+}
+
+// AddElement with concept drift, per slot, in stream order:  if A < w/decayWeight { w = A; min = bin }
+// (histosketch.go:139-153).  Not a minimum: w may move either way, so elements are taken in order,
+// but a wave tile whose fp32 minimum is not below the current threshold (with the fp32 band) cannot
+// contain a trigger and is skipped; tiles that may are evaluated in fp64 and replayed exactly.
+__global__ __launch_bounds__(256) void k_cws_resolve_drift(const double *__restrict__ rcb,
+                                                           const double *__restrict__ f64,
+                                                           const float *__restrict__ tilemin,
+                                                           unsigned long long *__restrict__ mins,
+                                                           double *__restrict__ weights, int slots,
+                                                           int slot_begin, int ntiles, double decay_weight,
+                                                           const DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *tm = (float *)smem;                       // [wtiles]
+    __shared__ int redi[4];
+    __shared__ double s_w;
+    __shared__ int s_first;
+    const int slot = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wtiles = ntiles * 4, ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    const int32_t num_bins = fb.num_bins;
+    const int gs = slot_begin + slot;
+    const double *row = rcb + (size_t)slot * (size_t)num_bins * 3;
+    double w = weights[gs];
+    unsigned long long wm = mins[gs];
+    const uint32_t gomask = batch_gomask(st, fb);
+
+    for (int t = 0; t < (int)fb.count; t++) {
+        if (!((gomask >> t) & 1u)) continue;
+        __syncthreads();
+        const float *tmin_t = tilemin + (((size_t)t * ngroups + slot / SCAN_ROWS) * wtiles) * SCAN_ROWS + (slot % SCAN_ROWS);
+        const double *ft = f64 + (size_t)t * (size_t)num_bins;
+        for (int x = tid; x < wtiles; x += blockDim.x) tm[x] = tmin_t[(size_t)x * SCAN_ROWS];
+        __syncthreads();
+        int from = 0;                                 // first tile not yet passed
+        for (;;) {
+            // first tile >= from that may hold a trigger for the current threshold
+            const double thr = w / decay_weight;      // curMin of the reference (IEEE: +-Inf / NaN when weight is 0)
+            int first = 0x7fffffff;
+            if (!(thr != thr)) {                       // NaN threshold: nothing compares below it
+                // fp32 screen; the band keeps it conservative (fp32 error of K*rcp is ~2e-7 relative)
+                const double lim = thr + 1e-5 * fabs(thr) + 1e-37;
+                for (int x = from + tid; x < wtiles; x += blockDim.x)
+                    if ((double)tm[x] <= lim || !(lim < INFINITY)) { first = x; break; }
+            }
+            for (int off = 32; off; off >>= 1) { const int o = __shfl_xor(first, off); first = o < first ? o : first; }
+            if (lane == 0) redi[wid] = first;
+            __syncthreads();
+            first = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+            __syncthreads();
+            if (first == 0x7fffffff) break;           // block-uniform
+            // exact replay of tile `first`: one element per thread, in bin order
+            const int32_t bin = first * WTILE + tid;
+            double A = INFINITY; bool elem = false;
+            if (bin < num_bins) {
+                const double f = ft[bin];
+                if (f != 0.0) {
+                    const double r = row[(size_t)bin * 3 + 0], c = row[(size_t)bin * 3 + 1], b = row[(size_t)bin * 3 + 2];
+                    const double Yka = exp(log(f) - b);
+                    A = c / (Yka * exp(r));
+                    elem = true;
+                }
+            }
+            int pos = 0;                              // next position of the tile to look at
+            for (;;) {
+                const double th = w / decay_weight;
+                int hit = 0x7fffffff;
+                if (elem && tid >= pos && A < th) hit = tid;
+                for (int off = 32; off; off >>= 1) { const int o = __shfl_xor(hit, off); hit = o < hit ? o : hit; }
+                if (lane == 0) redi[wid] = hit;
+                __syncthreads();
+                hit = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+                if (hit != 0x7fffffff && tid == hit) { s_w = A; s_first = bin; }
+                __syncthreads();
+                if (hit == 0x7fffffff) break;
+                w = s_w; wm = (unsigned long long)s_first;
+                pos = hit + 1;
+            }
+            from = first + 1;
+        }
+    }
+    if (tid == 0) { weights[gs] = w; mins[gs] = wm; }
+}
+
 // K = c * exp(b - r) in fp64, rounded once to fp32 (pad columns stay 0: 0 * NaN = NaN, ignored)
 __global__ __launch_bounds__(256) void k_build_k32(const double *__restrict__ rcb,
                                                    float *__restrict__ k32, int32_t num_bins,
@@ -1099,6 +1338,43 @@ hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *
                        d_rcb, d_f64, d_tilemin, d_candA, d_candB, slots, ntiles, st, fb);
     hipLaunchKernelGGL(k_cws_apply, dim3((slots + 255) / 256), dim3(256), 0, s, d_candA, d_candB, d_mins,
                        d_weights, slots, slot_begin, st, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_elem_index(hipStream_t s, const uint32_t *d_hists, uint32_t *d_blkcnt, uint32_t *d_eidx,
+                             uint32_t *d_etot, const FlushBatch &fb) {
+    const int nblk = (fb.num_bins + EIDX_BLOCK - 1) / EIDX_BLOCK;
+    hipLaunchKernelGGL(k_elem_count, dim3(nblk, fb.count), dim3(256), 0, s, d_hists, d_blkcnt, nblk, fb);
+    hipLaunchKernelGGL(k_elem_index, dim3(nblk, fb.count), dim3(256), 0, s, d_hists, d_blkcnt, d_eidx, d_etot, nblk, fb);
+    return hipGetLastError();
+}
+int elem_index_blocks(int32_t num_bins) { return (num_bins + EIDX_BLOCK - 1) / EIDX_BLOCK; }
+
+hipError_t launch_cms_chains_decay(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,
+                                   const uint32_t *d_chain_start, const uint32_t *d_eidx,
+                                   const uint32_t *d_etot, double *d_ctrd, double *d_estd, int depth,
+                                   int width, double omega, DevState *st, const FlushBatch &fb) {
+    const int chains = depth * width;
+    hipLaunchKernelGGL(k_cms_chains_decay, dim3((chains + 3) / 4), dim3(256), 0, s, d_hists, d_perm,
+                       d_chain_start, d_eidx, d_etot, d_ctrd, d_estd, depth, width, omega, st, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_freq_decay(hipStream_t s, uint32_t *d_hists, const double *d_estd,
+                             const uint32_t *d_invperm, double *d_f64, float *d_rcp32, int depth,
+                             size_t row_stride, DevState *st, const FlushBatch &fb) {
+    int blocks = (fb.num_bins + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_freq_decay, dim3(blocks, fb.count), dim3(256), 0, s, d_hists, d_estd, d_invperm,
+                       d_f64, d_rcp32, depth, row_stride, st, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const double *d_f64,
+                                    const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
+                                    int slots, int slot_begin, int ntiles, double decay_weight,
+                                    DevState *st, const FlushBatch &fb) {
+    hipLaunchKernelGGL(k_cws_resolve_drift, dim3(slots), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
+                       d_rcb, d_f64, d_tilemin, d_mins, d_weights, slots, slot_begin, ntiles, decay_weight, st, fb);
     return hipGetLastError();
 }
 

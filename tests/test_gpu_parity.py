@@ -28,9 +28,9 @@ def random_reads(rng, n, length, alphabet=b"ACGT"):
     return [bytes(a[rng.integers(0, len(a), size=l)]) for l in lens]
 
 
-def run_both(seqs, k, w, S, interval=0, num_bins=0, batches=1):
-    o = pyorc.Sketcher(k, w, S, num_bins, 1.0, interval)
-    g = gpu().GpuSketcher(k, w, S, interval, 1.0, num_bins)
+def run_both(seqs, k, w, S, interval=0, num_bins=0, batches=1, decay=1.0):
+    o = pyorc.Sketcher(k, w, S, num_bins, decay, interval)
+    g = gpu().GpuSketcher(k, w, S, interval, decay, num_bins)
     bases, offsets = pack_reads(seqs)
     o.add_reads(bases, offsets)
     # feed the GPU in several host batches to exercise interval splitting across calls
@@ -240,3 +240,28 @@ def test_bin_then_flush_batch_equals_interval_rule():
         g.close(); o.close()
     finally:
         os_env.pop("HULK_BATCH", None)
+
+
+DRIFT_RTOL = 1e-7   # the count-min decay is evaluated in closed form (w^gap) instead of step by step
+
+
+@pytest.mark.parametrize("decay,k,w,S,n,L,interval", [
+    (0.02, 9, 4, 24, 3000, 120, 500),
+    (0.5, 9, 4, 24, 3000, 120, 500),
+    (0.002, 11, 5, 16, 4000, 150, 1000),
+    (0.0, 9, 4, 16, 2000, 120, 500),      # drift on, scaling off, decayWeight == 0 (w/0 semantics)
+    (0.9999, 7, 3, 8, 1500, 100, 0),
+])
+def test_concept_drift(decay, k, w, S, n, L, interval):
+    """decay_ratio != 1: uniform scaling of the count-min counters (countmin.go:141-147) and the
+    `A < w/decayWeight` update (histosketch.go:139-153), BASELINE config C3's mode."""
+    rng = np.random.default_rng(int(decay * 1e4) + k)
+    seqs = random_reads(rng, n, L)
+    o, g = run_both(seqs, k, w, S, interval, batches=2, decay=decay)
+    o.finish(); g.finish()
+    om, ow = o.sketch(); gm, gw = g.sketch()
+    assert np.array_equal(om, gm), f"{(om != gm).sum()} of {len(om)} mins differ"
+    assert np.allclose(gw, ow, rtol=DRIFT_RTOL, atol=0)
+    oc, gc = o.cms(), g.cms()
+    assert np.allclose(gc, oc, rtol=1e-9, atol=1e-300)
+    g.close(); o.close()
