@@ -187,6 +187,17 @@ def main():
             "sketch_md5": __import__("hashlib").md5(mins.astype("<u8").tobytes()).hexdigest(),
             "n_minimizers_rank0": counters["n_minimizers"],
         }
+        # HBM traffic per launch from rocprofv3 PMC (FETCH_SIZE/WRITE_SIZE, separate passes of this same
+        # command, gfx950 correction applied — see profiles/r01_pmc.json); cannot be collected live.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            if world == 1:
+                out["roofline"]["traffic"] = pmc["k_minimizer_fast"]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = ("spectrum atomics: ~32 B written per atomicAdd at the memory "
+                                                   "side; reads = bases + offsets")
+                out["roofline_cws_scan"]["traffic"] = pmc["k_cws_scan"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out["path_hbm_frac"] = value * out["path_bytes_per_read"] / 1e9 / (HBM_PEAK_GBS * world)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -803,6 +803,8 @@ __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
     const int tid = threadIdx.x, wid = tid >> 6;
     const size_t col = (size_t)tile * SCAN_TILE + (size_t)tid * 4;
     const int wtiles = ntiles * 4;                               // 256-bin wave tiles per row
+    // (consecutive workgroups stream consecutive 4 KB pieces of the same 8 rows; mapping them to
+    //  share the column tile instead — better L2 reuse of the reciprocals — measured 5 % slower)
     floatx4 kv[SCAN_ROWS];
 #pragma unroll
     for (int r = 0; r < SCAN_ROWS; r++) {

@@ -14,7 +14,7 @@ with open(out, "w") as f:
             "torch's synthetic-read generator / collectives plumbing, outside the timed region.\n\n")
     f.write("| kernel | calls | total_us | avg_us | % |\n|---|---|---|---|---|\n")
     for n, cl, t, a, p in rows:
-        m = re.search(r"(k_\w+)\(", n)
+        m = re.search(r"(k_\w+)[<(]", n)
         short = m.group(1) if m else re.sub(r"[|<].*", "", n.replace("void ", ""))[:70]
         f.write(f"| {short} | {cl} | {t:.1f} | {a:.2f} | {p:.2f} |\n")
 print(open(out).read())
