@@ -60,6 +60,11 @@ def main():
                     help="run the all-reduce path even at world size 1 (test aid)")
     args = ap.parse_args()
 
+    # RCCL / the HIP runtime print banners on stdout; the contract is ONE JSON line there.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import hulk_amd
@@ -202,7 +207,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     sk.close()
     if use_dist:
         dist.destroy_process_group()

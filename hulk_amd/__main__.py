@@ -1,0 +1,157 @@
+"""`python -m hulk_amd sketch ...` — the `hulk sketch` flag surface (cmd/root.go:62-66,
+cmd/sketch.go:50-59) over the GPU path, writing the reference's JSON sketch.
+
+Host-side plumbing only (FASTQ/FASTA line handling follows src/pipeline/sketch.go:40-161); every
+numeric step runs in libhulkhip.  `smash`, --khf/--kmv and --profiling are not provided.
+"""
+import argparse
+import gzip
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import GpuSketcher, HulkError, spectrum_size
+from .sketchio import HULKdata, VERSION
+
+
+def log(msg):
+    print(time.strftime("%Y/%m/%d %H:%M:%S ") + msg, flush=True)
+
+
+def read_lines(paths):
+    """DataStreamer.Run: one item per line, gzip when the name ends in .gz, STDIN when no file."""
+    if not paths:
+        for line in sys.stdin.buffer:
+            yield line.rstrip(b"\n")
+        return
+    for p in paths:
+        op = gzip.open if p.split(".")[-1] == "gz" else open
+        with op(p, "rb") as fh:
+            for line in fh:
+                yield line.rstrip(b"\n")
+
+
+def sequences(lines, fasta):
+    """FastqHandler.Run: FASTQ = groups of 4 non-empty lines (empty lines are skipped because an
+    empty line stays nil in the reference); FASTA = sequence lines concatenated per '>' record."""
+    if fasta:
+        seq, have = [], False
+        for line in lines:
+            if len(line) == 0:
+                break
+            if line[0:1] == b">":
+                if have:
+                    yield b"".join(seq)
+                seq, have = [], True
+            else:
+                seq.append(line)
+        if have:
+            yield b"".join(seq)
+        return
+    slot = []
+    for line in lines:
+        if len(line) == 0:
+            continue
+        slot.append(line)
+        if len(slot) == 4:
+            if slot[0][0:1] != b"@":
+                raise HulkError(-30, "read ID in fastq file does not begin with @")   # seqio.go:38-40
+            yield slot[1]
+            slot = []
+
+
+def run_sketch(a):
+    start = time.time()
+    log(f"this is hulk (version {VERSION})")
+    log("please cite Rowe et al. 2019, doi: https://doi.org/10.1186/s40168-019-0653-2")
+    log("starting the sketch subcommand")
+    log("checking parameters...")
+    for f in a.fastq:
+        if not os.path.exists(f):
+            raise HulkError(-30, f"file does not exist: {f}")
+    log("\tmode: FASTA" if a.fasta else "\tmode: FASTQ")
+    log(f"\tminimizer k-mer size: {a.kmerSize}")
+    log(f"\tminimizer window size: {a.windowSize}")
+    log(f"\tsketch size: {a.sketchSize}")
+    if a.decayRatio == 1:
+        log("\tconcept drift: disabled")
+    else:
+        log("\tconcept drift: enabled")
+        log(f"\tdecay ratio: {a.decayRatio:.2f}")
+    bins = spectrum_size(a.kmerSize)
+    log(f"\tnumber of bins in k-mer spectrum: {bins}")
+    log("initialising sketching pipeline...")
+    g = GpuSketcher(a.kmerSize, a.windowSize, a.sketchSize, a.interval, a.decayRatio, device=a.device)
+    log("finding minimizers...")
+    batch, n_in_batch, seq_count, length_total = [], 0, 0, 0
+
+    def push():
+        nonlocal batch
+        if batch:
+            offsets = np.zeros(len(batch) + 1, dtype=np.uint64)
+            offsets[1:] = np.cumsum([len(s) for s in batch])
+            g.add_reads(np.frombuffer(b"".join(batch), dtype=np.uint8), offsets)
+            batch = []
+
+    for seq in sequences(read_lines(a.fastq), a.fasta):
+        batch.append(seq)
+        seq_count += 1
+        length_total += len(seq)
+        if seq_count % 100000 == 0:
+            log(f"\tprocessed {seq_count} sequences")
+        if len(batch) >= 1 << 16:
+            push()
+    push()
+    log("generating final histosketch of k-mer spectra...")
+    if seq_count == 0:
+        raise HulkError(-10, "no sequences received")
+    g.stop_work()
+    log(f"\tprocessed {seq_count} sequences in total")
+    log(f"\tmean sequence length: {int(length_total / seq_count)}")
+    log(f"\tfound {g.get_minimizer_count()} minimizers")
+    log(f"\thistosketching across {bins} bins")
+    log("cleaning up...")
+    d = HULKdata()
+    d.add(g.histosketch())
+    d.filename = "".join(f + "," for f in a.fastq) if a.fastq else "STDIN"   # cmd/sketch.go:147-155
+    d.banner_label = a.bannerLabel
+    out = a.outFile + ".json"
+    od = os.path.dirname(a.outFile)
+    if od and od != "." and not os.path.exists(od):
+        os.makedirs(od, mode=0o700)
+    d.write_json(out)
+    log(f"\twritten sketch to disk: {out}")
+    g.close()
+    log(f"finished in {time.time() - start:.3f}s")
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="hulk", description="Histosketching Using Little Kmers (MI355X path)")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    sk = sub.add_parser("sketch", help="Create a sketch from a set of reads")
+    sk.add_argument("-k", "--kmerSize", type=int, default=21)
+    sk.add_argument("-o", "--outFile", default="./hulk-" + time.strftime("%Y%m%d%H%M%S"))
+    sk.add_argument("-p", "--processors", type=int, default=1)
+    sk.add_argument("-f", "--fastq", action="append", default=[],
+                    type=lambda s: s.split(","), help="FASTQ file(s) to sketch (comma separated or repeated)")
+    sk.add_argument("--fasta", action="store_true")
+    sk.add_argument("-w", "--windowSize", type=int, default=9)
+    sk.add_argument("-i", "--interval", type=int, default=0)
+    sk.add_argument("-s", "--sketchSize", type=int, default=50)
+    sk.add_argument("-x", "--decayRatio", type=float, default=1.0)
+    sk.add_argument("-b", "--bannerLabel", default="blank")
+    sk.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    a.fastq = [f for grp in a.fastq for f in grp if f]
+    try:
+        run_sketch(a)
+    except HulkError as e:
+        log(f"ERROR---> {e.message}")        # helpers.ErrorCheck -> log.Fatalf (helpers.go:31-35)
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -265,3 +265,32 @@ def test_concept_drift(decay, k, w, S, n, L, interval):
     oc, gc = o.cms(), g.cms()
     assert np.allclose(gc, oc, rtol=1e-9, atol=1e-300)
     g.close(); o.close()
+
+
+def test_cli_c1_fixture(tmp_path, fq_reads):
+    """BASELINE config C1 end to end: `hulk sketch -f test-reads-small.fq.gz -k 21 --sketchSize 256`
+    through the flag-compatible front-end; JSON fields vs the oracle."""
+    import json, os
+    from conftest import GOLDEN
+    from hulk_amd.__main__ import main
+    from hulk_amd.sketchio import load_hulk_data
+    out = str(tmp_path / "sk")
+    fq = os.path.join(GOLDEN, "test-reads-small.fq.gz")
+    assert main(["sketch", "-f", fq, "-k", "21", "--sketchSize", "256", "-o", out]) == 0
+    doc = json.load(open(out + ".json"))
+    assert doc["filename"] == fq + "," and doc["class"] == "hulk_sketch" and doc["version"] == "1.0.0"
+    sk = doc["signatures"][0]["Sketch"]
+    assert sk["ksize"] == 21 and sk["num"] == 256 and sk["num_histogram_bins"] == 194481 and sk["concept_drift"] is False
+    o = pyorc.Sketcher(21, 9, 256)
+    for r in fq_reads:
+        o.add_read(r)
+    o.finish()
+    om, ow = o.sketch()
+    assert sk["mins"] == om.tolist()
+    assert np.allclose(np.array(sk["weights"]), ow, rtol=1e-5, atol=0)          # north-star tolerance on the JSON
+    assert np.allclose(np.array(sk["weights"]), ow, rtol=WEIGHT_RTOL, atol=0)
+    load_hulk_data(out + ".json")                                              # class/version/MD5 checks
+    # error path: a read shorter than w+k-1 is fatal with the reference's message
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@r\nACGTACGT\n+\nIIIIIIII\n")
+    assert main(["sketch", "-f", str(bad), "-o", out]) == 1
