@@ -60,6 +60,8 @@ int32_t jump_host(uint64_t key, int64_t n) {
     return (int32_t)b;
 }
 
+constexpr uint64_t MAX_READS_PER_LAUNCH = 4u << 20;   // 4 Mi reads -> <= ~7 GB of minimizer list at w = 9
+
 struct ProfileRec { hipEvent_t a, b; int which; };   // which: 0 = k_cws_scan, 1 = k_minimizer_fast
 
 }  // namespace
@@ -87,6 +89,7 @@ struct hulk_ctx {
     uint8_t *d_bases = nullptr; size_t d_bases_cap = 0;
     uint64_t *d_offsets = nullptr; size_t d_offsets_cap = 0;
     uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;
+    MinimizerList ml{}; uint64_t ml_regions = 0;   // minimizer list of the short-read kernel (grow-only)
     // host-side run state
     uint64_t seq_count = 0, flush_index = 0;
     uint32_t T = 8, ring_n = 9, ring_base = 0;   // interval batch size and spectrum ring
@@ -216,12 +219,33 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             c->d_slow_cap = n + n / 4 + 1024;
         }
         HIPCHK(c, hipMemsetAsync(c->d_slow_count, 0, 4, c->stream));
+        const uint64_t regions = (n + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE;
+        const uint64_t rcap = minimizer_list_rcap(c->p.w);
+        if (regions > c->ml_regions || c->ml.rcap != rcap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum);
+            uint32_t *keep_partial = c->ml.partial; const uint32_t keep_parts = c->ml.max_parts;
+            c->ml = MinimizerList{}; c->ml_regions = 0;
+            c->ml.partial = keep_partial; c->ml.max_parts = keep_parts;
+            const uint64_t cap = regions + regions / 8 + 64;
+            HIPCHK(c, hipMalloc((void **)&c->ml.x, cap * rcap * 8));
+            HIPCHK(c, hipMalloc((void **)&c->ml.slot, cap * rcap));
+            HIPCHK(c, hipMalloc((void **)&c->ml.key, cap * rcap * 4));
+            HIPCHK(c, hipMalloc((void **)&c->ml.cnt, cap * 4));
+            HIPCHK(c, hipMalloc((void **)&c->ml.off, (cap + 1) * 4));
+            HIPCHK(c, hipMalloc((void **)&c->ml.bsum, (cap / 1024 + 2) * 4));
+            if (!c->ml.partial) {
+                c->ml.max_parts = 8;
+                HIPCHK(c, hipMalloc((void **)&c->ml.partial, (size_t)c->ml.max_parts * c->ring_n * (size_t)c->B * 4));
+            }
+            c->ml.rcap = rcap; c->ml_regions = cap;
+        }
         ProfileRec pr{}; pr.which = 1;
         if (c->profiling) {
             HIPCHK(c, hipEventCreate(&pr.a)); HIPCHK(c, hipEventCreate(&pr.b));
             HIPCHK(c, hipEventRecord(pr.a, c->stream));
         }
-        HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->d_hist, c->d_state,
+        HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->ml, c->d_hist, c->d_state,
                                         c->d_min_slots, c->d_slow_list, c->d_slow_count));
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
         if (!pick_config(c->p.k, max_len, P, threads)) return fail(c, HULK_ERR_READ_TOO_LONG);
@@ -394,6 +418,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd); hipFree(c->d_estd);
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
     hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
+    hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -431,6 +456,7 @@ int hulk_add_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d
         const uint64_t fill = I ? c->seq_count % I : 0;
         uint64_t chunk = n - pos;
         if (I) { const uint64_t room = (uint64_t)c->T * I - fill; if (chunk > room) chunk = room; }
+        if (chunk > MAX_READS_PER_LAUNCH) chunk = MAX_READS_PER_LAUNCH;   // bounds the minimizer list (HBM)
         int rc = bin_reads(c, d_bases, d_offsets + pos, chunk, max_read_len, bases_bytes, I, fill);
         if (rc != HULK_OK) return rc;
         c->seq_count += chunk; pos += chunk;
@@ -453,9 +479,13 @@ int hulk_bin_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d
     if (c->ring_base != 0) return fail(c, HULK_ERR_STATE, "a partial interval is pending");
     if (reads_per_spectrum && (n + reads_per_spectrum - 1) / reads_per_spectrum > c->T)
         return fail(c, HULK_ERR_ARG, "more spectra than the batch size");
-    int rc = bin_reads(c, d_bases, d_offsets, n, max_read_len, bases_bytes, reads_per_spectrum, 0);
-    if (rc == HULK_OK) c->seq_count += n;
-    return rc;
+    for (uint64_t pos = 0; pos < n; pos += MAX_READS_PER_LAUNCH) {
+        const uint64_t chunk = std::min<uint64_t>(MAX_READS_PER_LAUNCH, n - pos);
+        int rc = bin_reads(c, d_bases, d_offsets + pos, chunk, max_read_len, bases_bytes, reads_per_spectrum, pos);
+        if (rc != HULK_OK) return rc;
+    }
+    c->seq_count += n;
+    return HULK_OK;
 }
 
 int hulk_flush_batch(hulk_ctx *c, uint32_t count) {

@@ -28,6 +28,20 @@ struct FlushBatch {
     int32_t num_bins;
 };
 
+// Minimizer list written by k_minimizer_fast: one region of `rcap` entries per wave (16 reads).
+constexpr int FAST_READS_PER_WAVE = 16;
+struct MinimizerList {
+    uint64_t *x;        // [regions][rcap] distinct minimizer values
+    uint8_t *slot;      // [regions][rcap] spectrum (ring slot) of the read each value came from
+    uint32_t *key;      // dense (regions back to back): slot << 20 | bin, written by k_jump_bin
+    uint32_t *cnt;      // [regions]
+    uint32_t *off;      // [regions + 1] exclusive prefix of cnt
+    uint32_t *bsum;     // [regions / 1024 + 1] per-block sums for the prefix
+    uint32_t *partial;  // [max_parts][ring_n][num_bins] per-part spectra of k_range_hist
+    uint32_t max_parts;
+    uint64_t rcap;
+};
+
 struct MinimizerParams {
     uint32_t k, w;
     int32_t num_bins;
@@ -51,9 +65,10 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
                                 const uint32_t *d_read_list, const uint32_t *d_read_list_count,
                                 uint32_t list_blocks);
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
-                                 uint64_t n_reads, MinimizerParams P, uint32_t *d_hist, DevState *d_state,
-                                 unsigned long long *d_min_slots, uint32_t *d_slow_list,
+                                 uint64_t n_reads, MinimizerParams P, const MinimizerList &ml, uint32_t *d_hists,
+                                 DevState *d_state, unsigned long long *d_min_slots, uint32_t *d_slow_list,
                                  uint32_t *d_slow_count);
+uint32_t minimizer_list_rcap(uint32_t w);
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb);
 hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,
                              const uint32_t *d_chain_start, unsigned long long *d_ctr,

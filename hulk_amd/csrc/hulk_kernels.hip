@@ -32,6 +32,23 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u_zero(uint32_t v) {    // 0 where the source lane is invalid / row masked
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+// wave-wide inclusive prefix sum with DPP only (6 VALU instructions); lane 63 ends with the total
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+    x += dpp_u_zero<0x111, 0xf>(x);      // row_shr:1
+    x += dpp_u_zero<0x112, 0xf>(x);      // row_shr:2
+    x += dpp_u_zero<0x114, 0xf>(x);      // row_shr:4
+    x += dpp_u_zero<0x118, 0xf>(x);      // row_shr:8      -> scan inside each row of 16
+    x += dpp_u_zero<0x142, 0xa>(x);      // row_bcast15 -> rows 1,3
+    x += dpp_u_zero<0x143, 0xc>(x);      // row_bcast31 -> rows 2,3
+    return x;
+}
+
+
+
 // minimap2 hash64 — src/minimizer/minimizer.go:33-42
 __device__ __forceinline__ uint64_t hash64(uint64_t key, uint64_t mask) {
     key = (~key + (key << 21)) & mask;
@@ -338,8 +355,8 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
 //
 // LDS per group: tab[128] u64 | pk[20] u32      per wave: q[192] u64      per block: lut[256]
 // ------------------------------------------------------------------------------------------
-constexpr int FAST_Q = 192;
 constexpr int FAST_TAB = 128;
+constexpr int FAST_RAW = 3072 + 64;    // raw ASCII of the wave's 16 reads, staged once (bytes per wave)
 
 __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
@@ -352,7 +369,7 @@ template <int WM>
 __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__restrict__ bases,
                                                         const uint64_t *__restrict__ offsets,
                                                         uint64_t n_reads, MinimizerParams P,
-                                                        uint32_t *__restrict__ hist, DevState *st,
+                                                        MinimizerList ml, DevState *st,
                                                         unsigned long long *__restrict__ min_slots,
                                                         uint32_t *__restrict__ slow_list,
                                                         uint32_t *__restrict__ slow_count) {
@@ -365,30 +382,62 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
     const int32_t k = (int32_t)P.k, w = (int32_t)P.w;
     const uint64_t mask = (1ull << (2 * k)) - 1;
     const uint64_t shift = (uint64_t)(2 * (k - 1));
-    uint64_t *q = (uint64_t *)(smem + 256) + (size_t)wid * FAST_Q;
-    uint64_t *tab = (uint64_t *)(smem + 256 + 4 * FAST_Q * 8) + (size_t)grp * FAST_TAB;
-    uint32_t *pk32 = (uint32_t *)(smem + 256 + 4 * FAST_Q * 8 + 16 * FAST_TAB * 8) + grp * 20;
-    uint32_t *qs = (uint32_t *)(smem + 256 + 4 * FAST_Q * 8 + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * FAST_Q;
+    uint64_t *tab = (uint64_t *)(smem + 256) + (size_t)grp * FAST_TAB;
+    uint32_t *pk32 = (uint32_t *)(smem + 256 + 16 * FAST_TAB * 8) + grp * 20;
+    uint32_t *raw32 = (uint32_t *)(smem + 256 + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * (FAST_RAW / 4);
 #pragma unroll
     for (int x = 0; x < FAST_TAB / 16; x++) tab[gl + 16 * x] = TAB_EMPTY;
     __syncthreads();
 
-    uint32_t qn = 0;
-    unsigned long long nmin = 0;
+    // this wave owns FAST_READS_PER_WAVE consecutive reads and one region of the minimizer list
+    const uint64_t region = (uint64_t)blockIdx.x * 4 + (uint64_t)wid;
+    const uint64_t wave_first = region * FAST_READS_PER_WAVE;
+    uint64_t *xl = ml.x + region * ml.rcap;
+    uint8_t *sl = ml.slot + region * ml.rcap;
+    uint32_t wcount = 0;              // wave-uniform: values written to the region so far
     const uint32_t dbg = P.debug;     // ablation switches (tools/k1_ablate.py); 0 in production
     uint32_t sink = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0 && n_reads)
         atomicAdd(&st->total_len, (unsigned long long)(offsets[n_reads] - offsets[0]));
 
-    for (uint64_t base = (uint64_t)blockIdx.x * 16 + (uint64_t)wid * 4; base < n_reads;
-         base += (uint64_t)gridDim.x * 16) {
+    // ---- wave prologue: the 17 offsets of the wave's reads in ONE round trip, then (when the reads
+    // fit) all their bases in ONE more: 16-byte chunks straight into LDS.  The per-iteration code then
+    // never waits on global memory (it used to cost 3 dependent round trips per iteration).
+    const uint32_t nrd = wave_first < n_reads ? (uint32_t)((n_reads - wave_first < FAST_READS_PER_WAVE) ? n_reads - wave_first : FAST_READS_PER_WAVE) : 0u;
+    uint64_t myoff = 0;
+    if ((uint32_t)lane <= nrd && nrd) myoff = offsets[wave_first + (uint32_t)lane];
+    const uint64_t span_lo = __shfl(myoff, 0), span_hi = __shfl(myoff, (int)nrd);
+    const uintptr_t raw_a0 = ((uintptr_t)bases + span_lo) & ~(uintptr_t)15;
+    const uintptr_t raw_end = (uintptr_t)bases + span_hi;
+    const bool bulk = nrd && (raw_end - raw_a0) <= (uintptr_t)(FAST_RAW - 64);
+    if (bulk) {
+        const uintptr_t lim = (uintptr_t)bases + P.bases_bytes;
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            const uintptr_t a = raw_a0 + 16u * (uint32_t)(lane + 64 * x);
+            if (a < raw_end + 16 && a + 16 <= lim) {
+                const uint4 v = *(const uint4 *)a;
+                *(uint4 *)(raw32 + 4 * (lane + 64 * x)) = v;
+            } else if (a < raw_end + 16) {
+                for (int y = 0; y < 4; y++) raw32[4 * (lane + 64 * x) + y] = (a + 4 * y + 4 <= lim) ? *(const uint32_t *)(a + 4 * y) : 0u;
+            }
+        }
+    }
+    wave_sync();
+
+    for (int it = 0; it < FAST_READS_PER_WAVE / 4; it++) {
+        const uint64_t base = wave_first + 4u * (uint32_t)it;
+        if (base >= n_reads) break;
         const uint64_t rd = base + (uint64_t)(grp & 3);
         bool act = rd < n_reads;                               // group-uniform
         const uint32_t hslot = hist_slot(P, rd);
         uint64_t o0 = 0; int64_t L = 0; int32_t npos = 0;
+        {
+            const int oi = 4 * it + (grp & 3);
+            const uint64_t a = __shfl(myoff, oi), b = __shfl(myoff, oi + 1);
+            if (act) { o0 = a; L = (int64_t)(b - a); }
+        }
         if (act) {
-            o0 = offsets[rd];
-            L = (int64_t)(offsets[rd + 1] - o0);
             if (L < 1) { if (gl == 0) set_error(st, -3); act = false; }
             else if (L < (int64_t)(w + k - 1)) { if (gl == 0) set_error(st, -4); act = false; }
         }
@@ -407,8 +456,14 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
                 const uintptr_t al = addr & ~(uintptr_t)3, end = (uintptr_t)bases + P.bases_bytes;
                 const unsigned sh = (unsigned)(addr & 3) * 8;
                 uint32_t d[5];
+                if (bulk) {
+                    const uint32_t *src = raw32 + ((al - raw_a0) >> 2);
 #pragma unroll
-                for (int x = 0; x < 5; x++) d[x] = (al + 4 * (x + 1) <= end) ? *(const uint32_t *)(al + 4 * x) : 0u;
+                    for (int x = 0; x < 5; x++) d[x] = src[x];
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 5; x++) d[x] = (al + 4 * (x + 1) <= end) ? *(const uint32_t *)(al + 4 * x) : 0u;
+                }
                 const int nv = L - p < 16 ? (int)(L - p) : 16;
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
@@ -554,8 +609,8 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
                 }
             }
         }
-        // ---- queue the new values of the wave; jump-hash them 128 at a time
-        // (runtime loop + select chain keeps ONE copy of the drain code in the instruction stream)
+        // ---- append the new values of the wave to its region of the minimizer list (coalesced: the
+        // ranks of the writing lanes are consecutive addresses); k_jump_bin hashes them afterwards
         for (int t = 0; t < w; t++) {
             uint64_t xt = X[0];
 #pragma unroll
@@ -565,25 +620,11 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
             if (nbal) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nbal >> 32),
                                           __builtin_amdgcn_mbcnt_lo((uint32_t)nbal, 0u));
-                if (nw) { q[qn + rank] = xt; qs[qn + rank] = hslot; }
-                qn += (uint32_t)__popcll(nbal);
-            }
-            if (qn >= 128) {
-                wave_sync();
-                const uint64_t y0 = q[lane], y1 = q[lane + 64];
-                const size_t s0 = (size_t)qs[lane] * (size_t)P.num_bins, s1 = (size_t)qs[lane + 64] * (size_t)P.num_bins;
-                const uint64_t keep = (lane + 128u < qn) ? q[lane + 128] : 0;
-                const uint32_t keeps = (lane + 128u < qn) ? qs[lane + 128] : 0;
-                int32_t b0, b1;
-                if (dbg & 2u) { b0 = (int32_t)((uint32_t)(y0 >> 20) & 0xffffu); b1 = (int32_t)((uint32_t)(y1 >> 20) & 0xffffu); }
-                else jump_hash2(y0, y1, P.num_bins, b0, b1);
-                if (dbg & 1u) sink += (uint32_t)(b0 + b1); else {
-                atomicAdd(&hist[s0 + b0], 1u);
-                atomicAdd(&hist[s1 + b1], 1u); }
-                wave_sync();
-                q[lane] = keep; qs[lane] = keeps;
-                wave_sync();
-                qn -= 128; nmin += 128;
+                if (nw) {
+                    if (dbg & 1u) sink += (uint32_t)xt; else {
+                    xl[wcount + rank] = xt; sl[wcount + rank] = (uint8_t)hslot; }
+                }
+                wcount += (uint32_t)__popcll(nbal);
             }
         }
         // clear the group's set (16 lanes x 8 entries)
@@ -591,18 +632,153 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
         for (int x = 0; x < FAST_TAB / 16; x++) tab[gl + 16 * x] = TAB_EMPTY;
         wave_sync();
     }
-    wave_sync();
-    for (uint32_t at = 0; at < qn; at += 64)
-        if (at + (uint32_t)lane < qn)
-            atomicAdd(&hist[(size_t)qs[at + lane] * (size_t)P.num_bins + jump_hash(q[at + lane], P.num_bins)], 1u);
-    nmin += qn;
-    if (dbg && sink == 0xdeadbeefu) hist[0] = sink;
+    if (lane == 0 && wave_first < n_reads) ml.cnt[region] = wcount;
+    if (dbg && sink == 0xdeadbeefu) xl[0] = sink;
     __shared__ unsigned long long blk_nmin[4];
-    if (lane == 0) blk_nmin[wid] = nmin;
+    if (lane == 0) blk_nmin[wid] = wcount;
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long t = blk_nmin[0] + blk_nmin[1] + blk_nmin[2] + blk_nmin[3];
-        if (t) min_slots[blockIdx.x] += t;
+        if (t) atomicAdd(&min_slots[blockIdx.x & (MIN_SLOTS - 1)], t);   // boss.minimizerCounter, spread over slots
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1b: jump hash of the minimizer list.  One wave per region; lanes take the region's values
+// round-robin (lane l: l, l+64, ...) with the next value prefetched, so every lane stays busy
+// with its own chain of ~ln(k^4) fp64 steps (no lock-step tail per 64 values); 8 waves/SIMD.
+// Output: key = spectrum slot << 20 | bin  (k^4 < 2^20 for k <= 31).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_regions, int32_t num_bins) {
+    const int lane = lane_id();
+    const uint32_t region = (uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (region >= n_regions) return;
+    const uint32_t cnt = ml.cnt[region];
+    const uint64_t *xl = ml.x + (size_t)region * ml.rcap;
+    const uint8_t *sl = ml.slot + (size_t)region * ml.rcap;
+    uint32_t *kl = ml.key + ml.off[region];                   // dense: regions back to back
+    const double dn = (double)num_bins * 0x1p-31;
+    uint32_t idx = (uint32_t)lane;
+    uint64_t nx = 0; uint32_t ns = 0;
+    if (idx < cnt) { nx = xl[idx]; ns = sl[idx]; }
+    while (idx < cnt) {
+        uint64_t key = nx; const uint32_t slot = ns;
+        const uint32_t nidx = idx + 64;
+        if (nidx < cnt) { nx = xl[nidx]; ns = sl[nidx]; }      // prefetch the lane's next value
+        uint32_t j = 0; int32_t res;
+        for (;;) {
+            res = (int32_t)j;
+            key = key * 2862933555777941757ull + 1;
+            const double p = (double)(j + 1u) * rcp_exact_u31((uint32_t)(key >> 33) + 1u);
+            if (p >= dn) break;
+            j = (uint32_t)(int32_t)(p * 0x1p31);
+        }
+        kl[idx] = (slot << 20) | (uint32_t)res;
+        idx = nidx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1c: k-mer spectrum from the key list WITHOUT global atomics.  Random global atomicAdd runs at
+// ~27 G lane-ops/s on this chip whatever the scope or footprint (tools/ubench/atomics*.hip) — 1 ms
+// per 10^6 reads here — while LDS atomics and coalesced traffic are an order of magnitude cheaper:
+// workgroup (r, t) owns bins [r*RANGE, (r+1)*RANGE) of spectrum t, counts them in LDS over the
+// (L2/Infinity-Cache resident) keys of that interval's reads and adds the range to the spectrum
+// with plain coalesced read-modify-writes — it is the only writer of those bins in this launch.
+// ------------------------------------------------------------------------------------------
+constexpr int HIST_RANGE = 32768;     // bins per workgroup (128 KB of LDS)
+
+// exclusive prefix sum of the region counts: per-block sums, then one block per 1024 regions
+__global__ __launch_bounds__(1024) void k_region_bsum(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ bsum,
+                                                      uint32_t n_regions) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    uint32_t v = i < n_regions ? cnt[i] : 0u;
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int x = 0; x < 16; x++) t += wsum[x]; bsum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ bsum,
+                                                         uint32_t *__restrict__ off, uint32_t n_regions) {
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t i = blockIdx.x * 1024u + (uint32_t)tid;
+    uint32_t before = 0;
+    for (uint32_t b = 0; b < blockIdx.x; b++) before += bsum[b];       // same address for the whole block: broadcast
+    const uint32_t v = i < n_regions ? cnt[i] : 0u;
+    const uint32_t incl = wave_scan_incl(v);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    for (int x = 0; x < wid; x++) before += wsum[x];
+    if (i < n_regions) off[i] = before + incl - v;
+    if (i + 1 == n_regions) off[n_regions] = before + incl;
+}
+
+// workgroup (r, t, part): LDS spectrum of bins [r*RANGE, (r+1)*RANGE) over part `part` of interval t's keys
+__global__ __launch_bounds__(1024) void k_range_hist(MinimizerList ml, uint32_t n_regions,
+                                                     uint32_t *__restrict__ partial, MinimizerParams P,
+                                                     uint32_t n_spectra, uint32_t n_parts, uint64_t n_reads) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *lh = (uint32_t *)smem;
+    const int r = blockIdx.x, t = blockIdx.y, part = blockIdx.z;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HIST_RANGE; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    // reads of spectrum t: local read index rd with (fill + rd) / interval == t   (all reads if interval == 0)
+    uint64_t rd0 = 0, rd1 = n_reads;
+    if (P.interval) {
+        const uint64_t lo = (uint64_t)t * P.interval, hi = lo + P.interval;
+        rd0 = lo > P.fill ? lo - P.fill : 0;
+        rd1 = hi > P.fill ? hi - P.fill : 0;
+        if (rd1 > n_reads) rd1 = n_reads;
+    }
+    const uint32_t slot = P.interval ? (uint32_t)(((uint64_t)t + P.ring_base) % P.ring_n) : P.ring_base;
+    if (rd0 < rd1) {
+        const uint32_t g0 = (uint32_t)(rd0 / FAST_READS_PER_WAVE), g1 = (uint32_t)((rd1 - 1) / FAST_READS_PER_WAVE);
+        const uint32_t a = ml.off[g0], b = ml.off[(g1 + 1 < n_regions ? g1 + 1 : n_regions)];
+        const uint32_t len = b - a, per = (len + n_parts - 1) / n_parts;
+        const uint32_t lo = a + (uint32_t)part * per, hi = (lo + per < b) ? lo + per : b;
+        const uint32_t want = (slot << 5) | (uint32_t)r;           // key >> 15
+        const uint32_t *kl = ml.key;
+        // head up to 16-byte alignment, then 4 keys per lane per load with 4 loads in flight, then the tail
+        uint32_t i = lo;
+        const uint32_t head_end = ((lo + 3u) & ~3u) < hi ? ((lo + 3u) & ~3u) : hi;
+        if (i + (uint32_t)tid < head_end) { const uint32_t k = kl[i + tid]; if ((k >> 15) == want) atomicAdd(&lh[k & (HIST_RANGE - 1)], 1u); }
+        i = head_end;
+        const uint4 *k4 = (const uint4 *)(kl + i);
+        const uint32_t n4 = (hi - i) / 4u;
+        uint32_t j = (uint32_t)tid;
+#define HULK_COUNT4(q)                                                                         \
+        { if ((q.x >> 15) == want) atomicAdd(&lh[q.x & (HIST_RANGE - 1)], 1u);                 \
+          if ((q.y >> 15) == want) atomicAdd(&lh[q.y & (HIST_RANGE - 1)], 1u);                 \
+          if ((q.z >> 15) == want) atomicAdd(&lh[q.z & (HIST_RANGE - 1)], 1u);                 \
+          if ((q.w >> 15) == want) atomicAdd(&lh[q.w & (HIST_RANGE - 1)], 1u); }
+        for (; j + 3u * 1024u < n4; j += 4u * 1024u) {
+            const uint4 q0 = k4[j], q1 = k4[j + 1024u], q2 = k4[j + 2048u], q3 = k4[j + 3072u];
+            HULK_COUNT4(q0) HULK_COUNT4(q1) HULK_COUNT4(q2) HULK_COUNT4(q3)
+        }
+        for (; j < n4; j += 1024u) { const uint4 q0 = k4[j]; HULK_COUNT4(q0) }
+#undef HULK_COUNT4
+        const uint32_t tail = i + n4 * 4u + (uint32_t)tid;
+        if (tail < hi) { const uint32_t k = kl[tail]; if ((k >> 15) == want) atomicAdd(&lh[k & (HIST_RANGE - 1)], 1u); }
+    }
+    __syncthreads();
+    uint32_t *out = partial + ((size_t)part * n_spectra + t) * (size_t)P.num_bins + (size_t)r * HIST_RANGE;
+    const int32_t nb = P.num_bins - r * HIST_RANGE;
+    for (int i = tid; i < HIST_RANGE && i < nb; i += blockDim.x) out[i] = lh[i];
+}
+
+// spectrum[slot_t][bin] += sum over parts    grid = (blocks, n_spectra)
+__global__ __launch_bounds__(256) void k_merge_hist(const uint32_t *__restrict__ partial, uint32_t *__restrict__ hists,
+                                                    MinimizerParams P, uint32_t n_spectra, uint32_t n_parts) {
+    const int t = blockIdx.y;
+    const uint32_t slot = P.interval ? (uint32_t)(((uint64_t)t + P.ring_base) % P.ring_n) : P.ring_base;
+    uint32_t *hist = hists + (size_t)slot * (size_t)P.num_bins;
+    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < P.num_bins; b += gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        for (uint32_t p = 0; p < n_parts; p++) v += partial[((size_t)p * n_spectra + t) * (size_t)P.num_bins + b];
+        if (v) hist[b] += v;
     }
 }
 
@@ -659,21 +835,6 @@ __global__ __launch_bounds__(256) void k_count_used(const uint32_t *__restrict__
 // One wave per chain, spectra of the batch in order; perm/chain_start are built once on the host.
 // est[t][bin][d] receives the estimate of row d.
 // ------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_u_zero(uint32_t v) {    // 0 where the source lane is invalid / row masked
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
-}
-// wave-wide inclusive prefix sum with DPP only (6 VALU instructions); lane 63 ends with the total
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
-    x += dpp_u_zero<0x111, 0xf>(x);      // row_shr:1
-    x += dpp_u_zero<0x112, 0xf>(x);      // row_shr:2
-    x += dpp_u_zero<0x114, 0xf>(x);      // row_shr:4
-    x += dpp_u_zero<0x118, 0xf>(x);      // row_shr:8      -> scan inside each row of 16
-    x += dpp_u_zero<0x142, 0xa>(x);      // row_bcast15 -> rows 1,3
-    x += dpp_u_zero<0x143, 0xc>(x);      // row_bcast31 -> rows 2,3
-    return x;
-}
-
 __global__ __launch_bounds__(256) void k_cms_chains(const uint32_t *__restrict__ hists,
                                                     const uint32_t *__restrict__ perm,
                                                     const uint32_t *__restrict__ chain_start,
@@ -1272,30 +1433,54 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
 }
 
 size_t minimizer_fast_lds(uint32_t) {
-    return 256 + 4 * (size_t)FAST_Q * 8 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)FAST_Q * 4;
+    return 256 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)FAST_RAW;
 }
 
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
-                                 uint64_t n_reads, MinimizerParams P, uint32_t *d_hist, DevState *d_state,
-                                 unsigned long long *d_min_slots, uint32_t *d_slow_list,
+                                 uint64_t n_reads, MinimizerParams P, const MinimizerList &ml, uint32_t *d_hists,
+                                 DevState *d_state, unsigned long long *d_min_slots, uint32_t *d_slow_list,
                                  uint32_t *d_slow_count) {
     if (n_reads == 0) return hipSuccess;
     const size_t lds = minimizer_fast_lds(P.w);
-    uint64_t blocks = (n_reads + 63) / 64;            // >= 4 reads per group
-    if (blocks > MIN_SLOTS) blocks = MIN_SLOTS;
-    if (blocks < 1) blocks = 1;
+    const uint64_t blocks = (n_reads + 4 * FAST_READS_PER_WAVE - 1) / (4 * FAST_READS_PER_WAVE);
+    const uint32_t n_regions = (uint32_t)((n_reads + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE);
     const dim3 g((unsigned)blocks), b(256);
     if (P.w <= 4)
-        hipLaunchKernelGGL(k_minimizer_fast<4>, g, b, lds, s, d_bases, d_offsets, n_reads, P, d_hist,
+        hipLaunchKernelGGL(k_minimizer_fast<4>, g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,
                            d_state, d_min_slots, d_slow_list, d_slow_count);
     else if (P.w <= 9)
-        hipLaunchKernelGGL(k_minimizer_fast<9>, g, b, lds, s, d_bases, d_offsets, n_reads, P, d_hist,
+        hipLaunchKernelGGL(k_minimizer_fast<9>, g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,
                            d_state, d_min_slots, d_slow_list, d_slow_count);
     else
-        hipLaunchKernelGGL(k_minimizer_fast<16>, g, b, lds, s, d_bases, d_offsets, n_reads, P, d_hist,
+        hipLaunchKernelGGL(k_minimizer_fast<16>, g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,
                            d_state, d_min_slots, d_slow_list, d_slow_count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // K1b: jump hash of the list (dense key array); K1c: spectrum ranges in LDS, merged without atomics
+    const uint32_t nblk = (n_regions + 1023) / 1024;
+    hipLaunchKernelGGL(k_region_bsum, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, n_regions);
+    hipLaunchKernelGGL(k_region_offsets, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.off, n_regions);
+    hipLaunchKernelGGL(k_jump_bin, dim3((n_regions + 3) / 4), dim3(256), 0, s, ml, n_regions, P.num_bins);
+    const uint32_t n_spectra = P.interval ? (uint32_t)((P.fill + n_reads + P.interval - 1) / P.interval) : 1u;
+    const int nranges = (P.num_bins + HIST_RANGE - 1) / HIST_RANGE;
+    uint32_t n_parts = 384u / (uint32_t)(nranges * n_spectra);
+    if (n_parts < 1) n_parts = 1;
+    if (n_parts > ml.max_parts) n_parts = ml.max_parts;
+    if (n_reads < 65536) n_parts = 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute((const void *)k_range_hist, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_RANGE * 4);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_range_hist, dim3(nranges, n_spectra, n_parts), dim3(1024), HIST_RANGE * 4, s, ml, n_regions,
+                       ml.partial, P, n_spectra, n_parts, n_reads);
+    int mb = (P.num_bins + 255) / 256; if (mb > 512) mb = 512;
+    hipLaunchKernelGGL(k_merge_hist, dim3(mb, n_spectra), dim3(256), 0, s, ml.partial, d_hists, P, n_spectra, n_parts);
     return hipGetLastError();
 }
+
+uint32_t minimizer_list_rcap(uint32_t w) { return FAST_READS_PER_WAVE * 16u * w; }
 
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb) {
     int blocks = (fb.num_bins + 2047) / 2048; if (blocks > 128) blocks = 128;
