@@ -351,11 +351,12 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
 // Per-read set semantics: a 128-entry open-addressing set per group; all run-start values of a
 // lane are inserted with back-to-back LDS compare-and-swaps (one round trip), collisions probe on.
 // Eligible reads: no code-4 base, 1 <= w <= WM <= 16, k-mer positions <= 16*w, length <= 256,
-// <= 96 run starts.  Anything else is appended to slow_list and handled by k_minimizer_bin.
+// <= 64 run starts.  Anything else is appended to slow_list and handled by k_minimizer_bin.
 //
 // LDS per group: tab[128] u64 | pk[20] u32      per wave: q[192] u64      per block: lut[256]
 // ------------------------------------------------------------------------------------------
 constexpr int FAST_TAB = 128;
+constexpr int FAST_CAND = 64;          // max run starts per read on the fast path
 constexpr int FAST_RAW = 3072 + 64;    // raw ASCII of the wave's 16 reads, staged once (bytes per wave)
 
 __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) {
@@ -366,7 +367,7 @@ __device__ __forceinline__ uint64_t dpp_row_shr1_u64(uint64_t v) {
 }
 
 template <int WM>
-__global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__restrict__ bases,
+__global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__restrict__ bases,
                                                         const uint64_t *__restrict__ offsets,
                                                         uint64_t n_reads, MinimizerParams P,
                                                         MinimizerList ml, DevState *st,
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
     uint64_t *tab = (uint64_t *)(smem + 256) + (size_t)grp * FAST_TAB;
     uint32_t *pk32 = (uint32_t *)(smem + 256 + 16 * FAST_TAB * 8) + grp * 20;
     uint32_t *raw32 = (uint32_t *)(smem + 256 + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * (FAST_RAW / 4);
+    uint64_t *cs = (uint64_t *)(smem + 256 + 16 * FAST_TAB * 8 + 16 * 20 * 4 + 4 * FAST_RAW) + (size_t)grp * FAST_CAND;
 #pragma unroll
     for (int x = 0; x < FAST_TAB / 16; x++) tab[gl + 16 * x] = TAB_EMPTY;
     __syncthreads();
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
     const uint64_t region = (uint64_t)blockIdx.x * 4 + (uint64_t)wid;
     const uint64_t wave_first = region * FAST_READS_PER_WAVE;
     uint64_t *xl = ml.x + region * ml.rcap;
-    uint8_t *sl = ml.slot + region * ml.rcap;
+    uint8_t *sl8 = ml.slot + region * ml.rcap;
     uint32_t wcount = 0;              // wave-uniform: values written to the region so far
     const uint32_t dbg = P.debug;     // ablation switches (tools/k1_ablate.py); 0 in production
     uint32_t sink = 0;
@@ -565,71 +567,69 @@ __global__ __launch_bounds__(256, 5) void k_minimizer_fast(const uint8_t *__rest
                 if (t < w) { pe = emit; pm = m; }
             }
         }
-        // too many run starts for the 128-entry set (cannot happen for w >= 2): defer the read
+        // ---- compact the run-start values of the read into the group's candidate list (LDS)
+        uint32_t total;
         {
-            uint32_t cnt = (uint32_t)__popc(startbits);
-            cnt += dpp_row_shr1(cnt);
-            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x112, 0xf, 0xf, true);
-            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x114, 0xf, 0xf, true);
-            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x118, 0xf, 0xf, true);
-            const uint32_t over = (uint32_t)(__ballot(gl == 15 && cnt > 96u) >> gsh) & 0xffffu;
-            if (over) { defer = true; startbits = 0; }
+            const uint32_t cnt = (uint32_t)__popc(startbits);
+            uint32_t incl = cnt;
+            incl += dpp_row_shr1(incl);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);
+            total = (uint32_t)__shfl((int)incl, (lane & 48) | 15);
+            if (total > (uint32_t)FAST_CAND) { defer = true; total = 0; }    // very repetitive read: generic kernel
+            else {
+                uint32_t at = incl - cnt;
+#pragma unroll
+                for (int t = 0; t < WM; t++)
+                    if ((startbits >> t) & 1u) cs[at++] = X[t];
+            }
         }
         if (act && defer) {
             if (gl == 0) { const uint32_t at = atomicAdd(slow_count, 1u); slow_list[at] = (uint32_t)rd; }
             act = false;
         }
+        wave_sync();
 
-        // ---- per-read set: one compare-and-swap per run start, all issued back to back
-        uint32_t newbits = 0;
-        {
-            unsigned long long old[WM];
-            uint32_t slot[WM];
+        // ---- per-read set + list append: one candidate per lane per round (<= 4 rounds).  A
+        // candidate is new iff its compare-and-swap finds the slot empty; new values go straight to
+        // the wave's region of the minimizer list (consecutive ranks = consecutive addresses).
+        uint32_t myslot[FAST_CAND / 16];
+        uint32_t newmask = 0;
 #pragma unroll
-            for (int t = 0; t < WM; t++) {
-                slot[t] = ((uint32_t)(X[t] >> 8) ^ (uint32_t)(X[t] >> 37)) & (FAST_TAB - 1);
-                old[t] = 0;
-                if ((startbits >> t) & 1u) {
-                    if (dbg & 4u) old[t] = TAB_EMPTY; else
-                    old[t] = atomicCAS((unsigned long long *)&tab[slot[t]], (unsigned long long)TAB_EMPTY,
-                                       (unsigned long long)X[t]);
+        for (int rnd = 0; rnd < FAST_CAND / 16; rnd++) {
+            const uint32_t c = (uint32_t)gl + 16u * (uint32_t)rnd;
+            myslot[rnd] = 0;
+            if (!__any((int)(c < total))) break;
+            bool isnew = false; uint64_t x = 0;
+            if (c < total) {
+                x = cs[c];
+                uint32_t sl = ((uint32_t)(x >> 8) ^ (uint32_t)(x >> 37)) & (FAST_TAB - 1);
+                unsigned long long o = (dbg & 4u) ? (unsigned long long)TAB_EMPTY
+                                                  : atomicCAS((unsigned long long *)&tab[sl], (unsigned long long)TAB_EMPTY, (unsigned long long)x);
+                while (o != TAB_EMPTY && o != x) {                 // occupied by another value: probe on
+                    sl = (sl + 1) & (FAST_TAB - 1);
+                    o = atomicCAS((unsigned long long *)&tab[sl], (unsigned long long)TAB_EMPTY, (unsigned long long)x);
                 }
+                isnew = (o == TAB_EMPTY);
+                myslot[rnd] = sl;
             }
-#pragma unroll
-            for (int t = 0; t < WM; t++) {
-                if ((startbits >> t) & 1u) {
-                    unsigned long long o = old[t];
-                    uint32_t sl = slot[t];
-                    while (o != TAB_EMPTY && o != X[t]) {      // rare: occupied by another value
-                        sl = (sl + 1) & (FAST_TAB - 1);
-                        o = atomicCAS((unsigned long long *)&tab[sl], (unsigned long long)TAB_EMPTY,
-                                      (unsigned long long)X[t]);
-                    }
-                    if (o == TAB_EMPTY) newbits |= 1u << t;
-                }
-            }
-        }
-        // ---- append the new values of the wave to its region of the minimizer list (coalesced: the
-        // ranks of the writing lanes are consecutive addresses); k_jump_bin hashes them afterwards
-        for (int t = 0; t < w; t++) {
-            uint64_t xt = X[0];
-#pragma unroll
-            for (int u = 1; u < WM; u++) xt = (t == u) ? X[u] : xt;
-            const bool nw = (newbits >> t) & 1u;
-            const uint64_t nbal = __ballot(nw);
+            const uint64_t nbal = __ballot(isnew);
             if (nbal) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nbal >> 32),
                                           __builtin_amdgcn_mbcnt_lo((uint32_t)nbal, 0u));
-                if (nw) {
-                    if (dbg & 1u) sink += (uint32_t)xt; else {
-                    xl[wcount + rank] = xt; sl[wcount + rank] = (uint8_t)hslot; }
+                if (isnew) {
+                    newmask |= 1u << rnd;
+                    if (dbg & 1u) sink += (uint32_t)x; else { xl[wcount + rank] = x; sl8[wcount + rank] = (uint8_t)hslot; }
                 }
                 wcount += (uint32_t)__popcll(nbal);
             }
         }
-        // clear the group's set (16 lanes x 8 entries)
+        wave_sync();
+        // empty the set again: only the slots this lane filled
 #pragma unroll
-        for (int x = 0; x < FAST_TAB / 16; x++) tab[gl + 16 * x] = TAB_EMPTY;
+        for (int rnd = 0; rnd < FAST_CAND / 16; rnd++)
+            if ((newmask >> rnd) & 1u) tab[myslot[rnd]] = TAB_EMPTY;
         wave_sync();
     }
     if (lane == 0 && wave_first < n_reads) ml.cnt[region] = wcount;
@@ -665,14 +665,16 @@ __global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_r
         uint64_t key = nx; const uint32_t slot = ns;
         const uint32_t nidx = idx + 64;
         if (nidx < cnt) { nx = xl[nidx]; ns = sl[nidx]; }      // prefetch the lane's next value
-        uint32_t j = 0; int32_t res;
+        // b+1 and the candidate j stay in fp64 (exact integers < 2^31): no int<->double round trip per step
+        double fj1 = 1.0, fres = 0.0;                           // float64(b+1) with b = -1+1.. ; result b
         for (;;) {
-            res = (int32_t)j;
             key = key * 2862933555777941757ull + 1;
-            const double p = (double)(j + 1u) * rcp_exact_u31((uint32_t)(key >> 33) + 1u);
-            if (p >= dn) break;
-            j = (uint32_t)(int32_t)(p * 0x1p31);
+            const double p = fj1 * rcp_exact_u31((uint32_t)(key >> 33) + 1u);
+            if (p >= dn) break;                                 // j >= n: b (= fj1 - 1) is the bucket
+            fres = __builtin_trunc(p * 0x1p31);                 // j = int64(p * 2^31), exact
+            fj1 = fres + 1.0;
         }
+        const int32_t res = (int32_t)fres;
         kl[idx] = (slot << 20) | (uint32_t)res;
         idx = nidx;
     }
@@ -1433,7 +1435,7 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
 }
 
 size_t minimizer_fast_lds(uint32_t) {
-    return 256 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)FAST_RAW;
+    return 256 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)FAST_RAW + 16 * (size_t)FAST_CAND * 8;
 }
 
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
