@@ -375,18 +375,23 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                                                         uint32_t *__restrict__ slow_list,
                                                         uint32_t *__restrict__ slow_count) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint8_t *lut = smem;
-    for (int t = threadIdx.x; t < 256; t += blockDim.x) lut[t] = nt4_of((unsigned)t);
+    // positional nt4 tables: lut16[t][byte] = (code & 3) << 2t | (code > 3) << (8 + t), so the four
+    // lookups of a dword OR straight into an 8-bit pack plus 4 "is code 4" flags
+    uint16_t *lut16 = (uint16_t *)smem;
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+        const unsigned c = nt4_of((unsigned)(i & 255)), t = (unsigned)i >> 8;
+        lut16[i] = (uint16_t)(((c & 3u) << (2 * t)) | ((c > 3 ? 1u : 0u) << (8 + t)));
+    }
 
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, gsh = lane & 48;
     const int32_t k = (int32_t)P.k, w = (int32_t)P.w;
     const uint64_t mask = (1ull << (2 * k)) - 1;
     const uint64_t shift = (uint64_t)(2 * (k - 1));
-    uint64_t *tab = (uint64_t *)(smem + 256) + (size_t)grp * FAST_TAB;
-    uint32_t *pk32 = (uint32_t *)(smem + 256 + 16 * FAST_TAB * 8) + grp * 20;
-    uint32_t *raw32 = (uint32_t *)(smem + 256 + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * (FAST_RAW / 4);
-    uint64_t *cs = (uint64_t *)(smem + 256 + 16 * FAST_TAB * 8 + 16 * 20 * 4 + 4 * FAST_RAW) + (size_t)grp * FAST_CAND;
+    uint64_t *tab = (uint64_t *)(smem + 2048) + (size_t)grp * FAST_TAB;
+    uint32_t *pk32 = (uint32_t *)(smem + 2048 + 16 * FAST_TAB * 8) + grp * 20;
+    uint32_t *raw32 = (uint32_t *)(smem + 2048 + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * (FAST_RAW / 4);
+    uint64_t *cs = (uint64_t *)(smem + 2048 + 16 * FAST_TAB * 8 + 16 * 20 * 4 + 4 * FAST_RAW) + (size_t)grp * FAST_CAND;
 #pragma unroll
     for (int x = 0; x < FAST_TAB / 16; x++) tab[gl + 16 * x] = TAB_EMPTY;
     __syncthreads();
@@ -467,15 +472,17 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     for (int x = 0; x < 5; x++) d[x] = (al + 4 * (x + 1) <= end) ? *(const uint32_t *)(al + 4 * x) : 0u;
                 }
                 const int nv = L - p < 16 ? (int)(L - p) : 16;
+                uint32_t nflags = 0;
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
                     const uint32_t by = sh ? (d[x] >> sh) | (d[x + 1] << (32 - sh)) : d[x];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const unsigned c = lut[(by >> (8 * t)) & 0xff];
-                        if (4 * x + t < nv) { sawN |= (c > 3); pack |= (c & 3u) << (2 * (4 * x + t)); }
-                    }
+                    const uint32_t v = (uint32_t)lut16[by & 0xff] | (uint32_t)lut16[256 + ((by >> 8) & 0xff)] |
+                                       (uint32_t)lut16[512 + ((by >> 16) & 0xff)] | (uint32_t)lut16[768 + (by >> 24)];
+                    pack |= (v & 0xffu) << (8 * x);
+                    nflags |= (v >> 8) << (4 * x);
                 }
+                if (nv < 16) { pack &= (1u << (2 * nv)) - 1u; nflags &= (1u << nv) - 1u; }   // bytes past the read's end
+                sawN = nflags != 0;
             }
             pk32[gl] = pack;
             if (gl < 4) pk32[16 + gl] = 0;                     // slack for 3-dword window reads
@@ -1435,7 +1442,7 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
 }
 
 size_t minimizer_fast_lds(uint32_t) {
-    return 256 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)FAST_RAW + 16 * (size_t)FAST_CAND * 8;
+    return 2048 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)FAST_RAW + 16 * (size_t)FAST_CAND * 8;
 }
 
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
