@@ -1,4 +1,4 @@
-// cws_gen.h — host generator of the CWS parameter stream of HistoSketch.newCWS
+// cws_gen.h — host half of the generator of the CWS parameter stream of HistoSketch.newCWS
 // (reference src/histosketch/histosketch.go:95-126):
 //     for slot { for bin { r = G.Gamma(2,1); c = ln(G.Gamma(2,1)); b = U.Float64Range(0,1) * r } }
 // G = go_rng.NewGammaGenerator(1), U = go_rng.NewUniformGenerator(1); both wrap Go's math/rand
@@ -56,40 +56,63 @@ class GoRandSource {
     int tap_, feed_;
 };
 
-// go_rng GammaGenerator.Gamma(alpha>1, beta): Cheng (1977) rejection sampler as in CPython's
-// random.gammavariate, with go_rng's squeeze constant 4*exp(-0.5)/sqrt(2).
-class CwsGenerator {
+// go_rng GammaGenerator.Gamma(alpha > 1, beta): Cheng (1977) rejection sampler as in CPython's
+// random.gammavariate, with go_rng's squeeze constant 4*exp(-0.5)/sqrt(2):
+//     loop { u1 = U();  if !(1e-7 < u1 < .9999999) continue;  u2 = 1 - U();  ...accept/reject... }
+// The uniform stream is sequential, the transcendental math is not: the host only walks the raw
+// stream and pairs every attempt's (u1, u2) — integer compares, ~1 ns per value — and the GPU
+// evaluates all attempts of a chunk in parallel and compacts the accepted values in order
+// (k_cws_eval / k_cws_scatter in hulk_kernels.hip).
+struct CwsConstants {
+    double ainv, bbb, ccc, magic;            // alpha = 2, beta = 1 (histosketch.go:112-113)
+    CwsConstants() {
+        const double alpha = 2.0;
+        magic = 4 * std::exp(-0.5) / std::sqrt(2.0);
+        ainv = std::sqrt(2.0 * alpha - 1.0);
+        bbb = alpha - std::log(4.0);
+        ccc = alpha + ainv;
+    }
+};
+
+class AttemptStream {
   public:
-    CwsGenerator() : g_(1), u_(1) {}          // DISTRIBUTION_SEED = 1 (histosketch.go:20)
-    // one sketch slot: out[3*j + {0,1,2}] = {r, c, b} for bin j
-    void next_row(double *out, size_t num_bins) {
-        for (size_t j = 0; j < num_bins; j++) {
-            const double r = gamma2();
-            const double c = std::log(gamma2());
-            const double b = (0.0 + u_.next_f64() * (1.0 - 0.0)) * r;
-            out[3 * j] = r; out[3 * j + 1] = c; out[3 * j + 2] = b;
+    AttemptStream() : g_(1) {}                // gamma generator's own uniform source, seed 1
+    // fills `pairs` with the raw int63 values (u1, u2) of the next `n` attempts that pass the
+    // u1 range test; Float64()'s "== 1, resample" rule is applied here too
+    void fill(uint64_t *pairs, size_t n) {
+        for (size_t i = 0; i < n; i++) {
+            uint64_t a;
+            for (;;) { a = next63(); const double u1 = (double)(int64_t)a * 0x1p-63; if (1e-7 < u1 && u1 < .9999999) break; }
+            pairs[2 * i] = a;
+            pairs[2 * i + 1] = next63();
         }
     }
 
   private:
-    double gamma2() {
-        const double alpha = 2.0, beta = 1.0;
-        static const double magic = 4 * std::exp(-0.5) / std::sqrt(2.0);
-        static const double ainv = std::sqrt(2.0 * alpha - 1.0);
-        static const double bbb = alpha - std::log(4.0);
-        static const double ccc = alpha + ainv;
+    uint64_t next63() {                       // Rand.Float64's input, skipping values that round to 1.0
         for (;;) {
-            const double u1 = g_.next_f64();
-            if (!(1e-7 < u1 && u1 < .9999999)) continue;
-            const double u2 = 1.0 - g_.next_f64();
-            const double v = std::log(u1 / (1.0 - u1)) / ainv;
-            const double x = alpha * std::exp(v);
-            const double z = u1 * u1 * u2;
-            const double rr = bbb + ccc * v - x;
-            if (rr + magic - 4.5 * z >= 0.0 || rr >= std::log(z)) return x * beta;
+            const uint64_t x = g_.next_u64() & 0x7fffffffffffffffull;
+            if ((double)(int64_t)x * 0x1p-63 != 1.0) return x;
         }
     }
-    GoRandSource g_, u_;
+    GoRandSource g_;
+};
+
+// the separate uniform generator (seed 1) of newCWS: one Float64 per table entry
+class UniformStream {
+  public:
+    UniformStream() : u_(1) {}
+    void fill(uint64_t *raw, size_t n) {
+        for (size_t i = 0; i < n; i++) {
+            for (;;) {
+                const uint64_t x = u_.next_u64() & 0x7fffffffffffffffull;
+                if ((double)(int64_t)x * 0x1p-63 != 1.0) { raw[i] = x; break; }
+            }
+        }
+    }
+
+  private:
+    GoRandSource u_;
 };
 
 }  // namespace hulk

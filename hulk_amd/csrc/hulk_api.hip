@@ -164,20 +164,76 @@ int install_tables(hulk_ctx *c, const double *r, const double *cc, const double 
     return HULK_OK;
 }
 
-// newCWS (histosketch.go:95-126) with the Go-compatible generators, streamed row by row
+// newCWS (histosketch.go:95-126): the host walks Go's math/rand streams (cws_gen.h), the device does
+// the gamma math and the in-order compaction, chunk by chunk (double-buffered pinned staging).
 int generate_tables(hulk_ctx *c) {
-    const size_t B = (size_t)c->B;
-    CwsGenerator gen;
-    std::vector<double> row(B * 3);
-    for (uint32_t s = 0; s < c->S; s++) {
-        gen.next_row(row.data(), B);
-        if (s >= c->slot_begin && s < c->slot_begin + c->slots)
-            HIPCHK(c, hipMemcpyAsync(c->d_rcb + (size_t)(s - c->slot_begin) * B * 3, row.data(),
-                                     B * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));   // row buffer is reused
-        if (s + 1 == c->slot_begin + c->slots) break; // later rows are not needed by this shard
+    const uint64_t B = (uint64_t)c->B;
+    const uint64_t need_entries = (uint64_t)(c->slot_begin + c->slots) * B;     // rows of later slots are not needed
+    if (need_entries == 0) { c->tables_ready = true; return HULK_OK; }
+    const uint64_t need_gammas = 2 * need_entries;
+    const size_t CH = (size_t)1 << 22;                                        // attempts (or uniforms) per chunk
+    const CwsConstants K;
+    uint64_t *h_buf[2] = {nullptr, nullptr}; uint64_t *d_pairs[2] = {nullptr, nullptr};
+    double *d_val = nullptr; uint32_t *d_blkcnt = nullptr; unsigned long long *d_tot = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int rc = HULK_OK;
+    auto cleanup = [&]() {
+        for (int i = 0; i < 2; i++) { if (h_buf[i]) hipHostFree(h_buf[i]); hipFree(d_pairs[i]); if (done[i]) hipEventDestroy(done[i]); }
+        hipFree(d_val); hipFree(d_blkcnt); hipFree(d_tot);
+    };
+#define GEN_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = fail_hip(c, e_, #call); cleanup(); return rc; } } while (0)
+    for (int i = 0; i < 2; i++) {
+        GEN_CHK(hipHostMalloc((void **)&h_buf[i], CH * 16, hipHostMallocDefault));
+        GEN_CHK(hipMalloc((void **)&d_pairs[i], CH * 16));
+        GEN_CHK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
     }
-    HIPCHK(c, launch_build_k32(c->stream, c->d_rcb, c->d_k32, (int)c->slots, c->B, c->row_stride));
+    GEN_CHK(hipMalloc((void **)&d_val, CH * 8));
+    GEN_CHK(hipMalloc((void **)&d_blkcnt, (CH / 1024 + 1) * 4));
+    GEN_CHK(hipMalloc((void **)&d_tot, 16));
+    GEN_CHK(hipMemsetAsync(d_tot, 0, 16, c->stream));
+    // ---- r and c: gamma variates
+    {
+        AttemptStream attempts;
+        unsigned long long got = 0; int cur = 0; uint64_t inflight[2] = {0, 0};
+        // acceptance of Cheng's sampler at alpha = 2 is ~0.8; the tail chunk is sized from the estimate
+        while (got < need_gammas) {
+            uint64_t want = (uint64_t)((double)(need_gammas - got) / 0.78) + 4096;
+            if (want > CH) want = CH;
+            if (inflight[cur]) GEN_CHK(hipEventSynchronize(done[cur]));         // staging buffer free again
+            attempts.fill(h_buf[cur], (size_t)want);
+            GEN_CHK(hipMemcpyAsync(d_pairs[cur], h_buf[cur], want * 16, hipMemcpyHostToDevice, c->stream));
+            GEN_CHK(launch_cws_chunk(c->stream, d_pairs[cur], want, d_val, d_blkcnt, d_tot, d_tot + 1, c->d_rcb, B,
+                                     c->slot_begin, c->slots, c->S, K.ainv, K.bbb, K.ccc, K.magic));
+            GEN_CHK(hipEventRecord(done[cur], c->stream));
+            inflight[cur] = want;
+            cur ^= 1;
+            // progress is only needed near the end; until then overlap host generation with the device
+            if ((double)(got + (unsigned long long)(0.70 * (double)want)) >= (double)need_gammas || want < CH) {
+                GEN_CHK(hipMemcpyAsync(&got, d_tot, 8, hipMemcpyDeviceToHost, c->stream));
+                GEN_CHK(hipStreamSynchronize(c->stream));
+            } else {
+                got += (unsigned long long)(0.70 * (double)want);                // safe under-estimate
+            }
+        }
+    }
+    // ---- b = U(0,1) * r
+    {
+        UniformStream uni;
+        int cur = 0; bool used[2] = {false, false};
+        for (uint64_t first = 0; first < need_entries; first += CH) {
+            const uint64_t n = std::min<uint64_t>(CH, need_entries - first);
+            if (used[cur]) GEN_CHK(hipEventSynchronize(done[cur]));
+            uni.fill(h_buf[cur], (size_t)n);
+            GEN_CHK(hipMemcpyAsync(d_pairs[cur], h_buf[cur], n * 8, hipMemcpyHostToDevice, c->stream));
+            GEN_CHK(launch_cws_beta(c->stream, d_pairs[cur], first, n, c->d_rcb, B, c->slot_begin, c->slots));
+            GEN_CHK(hipEventRecord(done[cur], c->stream));
+            used[cur] = true; cur ^= 1;
+        }
+    }
+    GEN_CHK(launch_build_k32(c->stream, c->d_rcb, c->d_k32, (int)c->slots, c->B, c->row_stride));
+    GEN_CHK(hipStreamSynchronize(c->stream));
+#undef GEN_CHK
+    cleanup();
     c->tables_ready = true;
     return HULK_OK;
 }

@@ -98,6 +98,12 @@ hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const do
                                     const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
                                     int slots, int slot_begin, int ntiles, double decay_weight,
                                     DevState *st, const FlushBatch &fb);
+hipError_t launch_cws_chunk(hipStream_t s, const uint64_t *d_pairs, uint64_t n_attempts, double *d_val,
+                            uint32_t *d_blkcnt, unsigned long long *d_gamma_total, unsigned long long *d_chunk_base,
+                            double *d_rcb, uint64_t num_bins, uint64_t slot_begin, uint64_t slots,
+                            uint64_t sketch_size, double ainv, double bbb, double ccc, double magic);
+hipError_t launch_cws_beta(hipStream_t s, const uint64_t *d_uraw, uint64_t first_entry, uint64_t n, double *d_rcb,
+                           uint64_t num_bins, uint64_t slot_begin, uint64_t slots);
 hipError_t launch_build_k32(hipStream_t s, const double *d_rcb, float *d_k32, int slots,
                             int32_t num_bins, size_t row_stride);
 hipError_t launch_selftest_rcp(hipStream_t s, unsigned long long *d_mismatches);

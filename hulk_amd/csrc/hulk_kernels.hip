@@ -1367,6 +1367,103 @@ __global__ __launch_bounds__(256) void k_cws_resolve_drift(const double *__restr
     if (tid == 0) { weights[gs] = w; mins[gs] = wm; }
 }
 
+// ==========================================================================================
+// newCWS on the device (histosketch.go:95-126).  The host walks Go's math/rand stream and hands
+// over the (u1, u2) raw values of every Cheng attempt (cws_gen.h); here all attempts of a chunk are
+// evaluated in parallel and the accepted gamma variates are compacted IN ORDER into the table:
+// gamma #n -> entry n/2 = slot*B + bin, r if n is even, c = ln(gamma) if n is odd.
+// ==========================================================================================
+constexpr int CWS_BLOCK = 1024;     // attempts per block (256 threads x 4)
+
+__global__ __launch_bounds__(256) void k_cws_eval(const uint64_t *__restrict__ pairs, uint64_t n_attempts,
+                                                  double *__restrict__ val, uint32_t *__restrict__ blkcnt,
+                                                  double ainv, double bbb, double ccc, double magic) {
+    __shared__ unsigned red[4];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int x = 0; x < CWS_BLOCK / 256; x++) {
+        const uint64_t i = (uint64_t)blockIdx.x * CWS_BLOCK + (uint64_t)x * 256 + threadIdx.x;
+        double out = -1.0;                                       // < 0 marks a rejected attempt
+        if (i < n_attempts) {
+            const double u1 = (double)(long long)pairs[2 * i] * 0x1p-63;
+            const double u2 = 1.0 - (double)(long long)pairs[2 * i + 1] * 0x1p-63;
+            const double v = log(u1 / (1.0 - u1)) / ainv;
+            const double xx = 2.0 * exp(v);
+            const double z = u1 * u1 * u2;
+            const double r = bbb + ccc * v - xx;
+            if (r + magic - 4.5 * z >= 0.0 || r >= log(z)) { out = xx * 1.0; cnt++; }
+            val[i] = out;
+        }
+    }
+    for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) blkcnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of the block counts (single workgroup), advancing the running gamma count
+__global__ __launch_bounds__(1024) void k_cws_scan_blocks(uint32_t *__restrict__ blkcnt, uint32_t nblk,
+                                                          unsigned long long *__restrict__ gamma_total,
+                                                          unsigned long long *__restrict__ chunk_base) {
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t per = (nblk + 1023) / 1024;
+    const uint32_t lo = (uint32_t)tid * per, hi = lo + per < nblk ? lo + per : nblk;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += blkcnt[i];
+    const uint32_t incl = wave_scan_incl(sum);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    uint32_t before = incl - sum;
+    for (int x = 0; x < wid; x++) before += wsum[x];
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t c = blkcnt[i]; blkcnt[i] = before; before += c; }
+    if (tid == 1023) { *chunk_base = *gamma_total; *gamma_total += before; }
+}
+
+__global__ __launch_bounds__(256) void k_cws_scatter(const double *__restrict__ val, uint64_t n_attempts,
+                                                     const uint32_t *__restrict__ blkoff,
+                                                     const unsigned long long *__restrict__ chunk_base,
+                                                     double *__restrict__ rcb, uint64_t num_bins,
+                                                     uint64_t slot_begin, uint64_t slots, uint64_t sketch_size) {
+    __shared__ unsigned wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint64_t i0 = (uint64_t)blockIdx.x * CWS_BLOCK + (uint64_t)tid * 4;   // 4 consecutive attempts per thread
+    double v[4]; unsigned mine = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) { v[x] = (i0 + x < n_attempts) ? val[i0 + x] : -1.0; mine += v[x] >= 0.0; }
+    const unsigned incl = wave_scan_incl(mine);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    unsigned long long n = *chunk_base + blkoff[blockIdx.x] + (incl - mine);
+    for (int x = 0; x < wid; x++) n += wsum[x];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        if (v[x] >= 0.0) {
+            const unsigned long long entry = n >> 1;                  // slot * B + bin
+            const unsigned long long slot = entry / num_bins;
+            if (slot >= slot_begin && slot < slot_begin + slots && slot < sketch_size) {
+                const unsigned long long at = (entry - slot_begin * num_bins) * 3 + (n & 1ull);
+                rcb[at] = (n & 1ull) ? log(v[x]) : v[x];              // r = Gamma(2,1); c = ln(Gamma(2,1))
+            }
+            n++;
+        }
+    }
+}
+
+// b = U(0,1) * r with the separate uniform generator: entry i uses its i-th Float64
+__global__ __launch_bounds__(256) void k_cws_beta(const uint64_t *__restrict__ uraw, uint64_t first_entry,
+                                                  uint64_t n, double *__restrict__ rcb, uint64_t num_bins,
+                                                  uint64_t slot_begin, uint64_t slots) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t entry = first_entry + i, slot = entry / num_bins;
+        if (slot >= slot_begin && slot < slot_begin + slots) {
+            const uint64_t at = (entry - slot_begin * num_bins) * 3;
+            const double u = 0.0 + (double)(long long)uraw[i] * 0x1p-63 * (1.0 - 0.0);   // Float64Range(0, 1)
+            rcb[at + 2] = u * rcb[at];
+        }
+    }
+}
+
 // K = c * exp(b - r) in fp64, rounded once to fp32 (pad columns stay 0: 0 * NaN = NaN, ignored)
 __global__ __launch_bounds__(256) void k_build_k32(const double *__restrict__ rcb,
                                                    float *__restrict__ k32, int32_t num_bins,
@@ -1571,6 +1668,24 @@ hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const do
                                     DevState *st, const FlushBatch &fb) {
     hipLaunchKernelGGL(k_cws_resolve_drift, dim3(slots), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
                        d_rcb, d_f64, d_tilemin, d_mins, d_weights, slots, slot_begin, ntiles, decay_weight, st, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_cws_chunk(hipStream_t s, const uint64_t *d_pairs, uint64_t n_attempts, double *d_val,
+                            uint32_t *d_blkcnt, unsigned long long *d_gamma_total, unsigned long long *d_chunk_base,
+                            double *d_rcb, uint64_t num_bins, uint64_t slot_begin, uint64_t slots,
+                            uint64_t sketch_size, double ainv, double bbb, double ccc, double magic) {
+    const uint32_t nblk = (uint32_t)((n_attempts + CWS_BLOCK - 1) / CWS_BLOCK);
+    hipLaunchKernelGGL(k_cws_eval, dim3(nblk), dim3(256), 0, s, d_pairs, n_attempts, d_val, d_blkcnt, ainv, bbb, ccc, magic);
+    hipLaunchKernelGGL(k_cws_scan_blocks, dim3(1), dim3(1024), 0, s, d_blkcnt, nblk, d_gamma_total, d_chunk_base);
+    hipLaunchKernelGGL(k_cws_scatter, dim3(nblk), dim3(256), 0, s, d_val, n_attempts, d_blkcnt, d_chunk_base, d_rcb,
+                       num_bins, slot_begin, slots, sketch_size);
+    return hipGetLastError();
+}
+
+hipError_t launch_cws_beta(hipStream_t s, const uint64_t *d_uraw, uint64_t first_entry, uint64_t n, double *d_rcb,
+                           uint64_t num_bins, uint64_t slot_begin, uint64_t slots) {
+    hipLaunchKernelGGL(k_cws_beta, dim3(2048), dim3(256), 0, s, d_uraw, first_entry, n, d_rcb, num_bins, slot_begin, slots);
     return hipGetLastError();
 }
 
