@@ -161,7 +161,10 @@ def main():
         # VALU issue (integer hashing, fp64 jump hash), not by HBM — frac is reported against the HBM
         # peak as the contract asks, the VALU-busy fraction from rocprofv3 PMC is in profiles/.
         k1_avg_s = (k1_ms / 1e3) / max(n_k1, 1)
-        k1_bytes = float(reads_per_rank_step * (READ_LEN + 8))
+        # algorithmic bytes of k_minimizer_fast: bases + offsets in, (value u64 + slot u8) per distinct
+        # minimizer out (the list k_jump_bin consumes)
+        per_read_min = counters["n_minimizers"] / float(counters["n_reads"])
+        k1_bytes = float(reads_per_rank_step) * (READ_LEN + 8 + 9.0 * per_read_min)
         k1_ach = k1_bytes / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
         # The HBM-streaming kernel of the path = k_cws_scan: algorithmic bytes per launch = ONE fp32
         # pass over this rank's slice of K (4*slots*k^4) + the BATCH reciprocal vectors.
@@ -182,7 +185,8 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_ach / HBM_PEAK_GBS,
                          "traffic": None, "launches": int(n_k1), "avg_launch_us": k1_avg_s * 1e6,
                          "alg_bytes_per_launch": k1_bytes,
-                         "note": "dominant by time; VALU-issue bound (see profiles/), not HBM bound"},
+                         "note": "dominant by time; VALU-issue bound (SQ_ACTIVE_INST_VALU = 100% of SIMD cycles, "
+                                 "profiles/r01_pmc.json), not HBM bound"},
             "roofline_cws_scan": {"bound": "hbm", "kernel": "k_cws_scan", "achieved": achieved,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                   "traffic": None, "launches": int(n_launch),
@@ -198,8 +202,6 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
             if world == 1:
                 out["roofline"]["traffic"] = pmc["k_minimizer_fast"]["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_note"] = ("spectrum atomics: ~32 B written per atomicAdd at the memory "
-                                                   "side; reads = bases + offsets")
                 out["roofline_cws_scan"]["traffic"] = pmc["k_cws_scan"]["hbm_bytes_per_launch"]
         except Exception:
             pass

@@ -1,0 +1,38 @@
+"""Run one BASELINE config on the GPU path with synthetic HBM-resident reads and report timing.
+usage: run_config.py --k 31 --S 1024 --decay 0.02 --reads 5000000 --interval 100000 [--batch 10]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--k", type=int, default=31); ap.add_argument("--w", type=int, default=9)
+ap.add_argument("--S", type=int, default=1024); ap.add_argument("--decay", type=float, default=0.02)
+ap.add_argument("--reads", type=int, default=5_000_000); ap.add_argument("--interval", type=int, default=100_000)
+ap.add_argument("--batch", type=int, default=10); ap.add_argument("--len", type=int, default=150)
+a = ap.parse_args()
+os.environ["HULK_BATCH"] = str(a.batch)
+import torch, hulk_amd
+from hulk_amd import synth
+t0 = time.time()
+sk = hulk_amd.GpuSketcher(a.k, a.w, a.S, interval=a.interval, decay_ratio=a.decay,
+                          stream=torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize(); t_create = time.time() - t0
+step = a.interval * a.batch
+bufs = []
+for s in range(min(4, (a.reads + step - 1) // step)):
+    b, o = synth.reads_torch(s * step, step, a.len); bufs.append((b, o))
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+done = 0; i = 0
+sk.add_reads_device(bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), step, a.len, bufs[0][0].numel()); done += step; i += 1   # warm
+torch.cuda.synchronize(); e0.record()
+t1 = time.time()
+while done < a.reads:
+    b, o = bufs[i % len(bufs)]
+    sk.add_reads_device(b.data_ptr(), o.data_ptr(), step, a.len, b.numel()); done += step; i += 1
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+sk.finish()
+mins, w = sk.sketch()
+print(json.dumps({"k": a.k, "S": a.S, "decay": a.decay, "interval": a.interval, "batch": a.batch,
+                  "reads_timed": done - step, "ms": ms, "reads_per_s": (done - step) / ms * 1e3,
+                  "create_s": t_create, "mem_GB": torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9,
+                  "distinct_mins": int(len(set(mins.tolist()))), "neg_weights": int((w < 0).sum())}))
