@@ -301,9 +301,10 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             HIPCHK(c, hipEventCreate(&pr.a)); HIPCHK(c, hipEventCreate(&pr.b));
             HIPCHK(c, hipEventRecord(pr.a, c->stream));
         }
-        HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->ml, c->d_hist, c->d_state,
+        HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->ml, c->d_state,
                                         c->d_min_slots, c->d_slow_list, c->d_slow_count));
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
+        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, c->d_hist));
         if (!pick_config(c->p.k, max_len, P, threads)) return fail(c, HULK_ERR_READ_TOO_LONG);
         const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(1024, (n + 3) / 4);
         HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, c->d_hist, c->d_state,

@@ -65,9 +65,11 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
                                 const uint32_t *d_read_list, const uint32_t *d_read_list_count,
                                 uint32_t list_blocks);
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
-                                 uint64_t n_reads, MinimizerParams P, const MinimizerList &ml, uint32_t *d_hists,
+                                 uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
                                  DevState *d_state, unsigned long long *d_min_slots, uint32_t *d_slow_list,
                                  uint32_t *d_slow_count);
+hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
+                                 uint32_t *d_hists);
 uint32_t minimizer_list_rcap(uint32_t w);
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb);
 hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,

@@ -1543,13 +1543,12 @@ size_t minimizer_fast_lds(uint32_t) {
 }
 
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
-                                 uint64_t n_reads, MinimizerParams P, const MinimizerList &ml, uint32_t *d_hists,
+                                 uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
                                  DevState *d_state, unsigned long long *d_min_slots, uint32_t *d_slow_list,
                                  uint32_t *d_slow_count) {
     if (n_reads == 0) return hipSuccess;
     const size_t lds = minimizer_fast_lds(P.w);
     const uint64_t blocks = (n_reads + 4 * FAST_READS_PER_WAVE - 1) / (4 * FAST_READS_PER_WAVE);
-    const uint32_t n_regions = (uint32_t)((n_reads + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE);
     const dim3 g((unsigned)blocks), b(256);
     if (P.w <= 4)
         hipLaunchKernelGGL(k_minimizer_fast<4>, g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,
@@ -1560,9 +1559,15 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
     else
         hipLaunchKernelGGL(k_minimizer_fast<16>, g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,
                            d_state, d_min_slots, d_slow_list, d_slow_count);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    // K1b: jump hash of the list (dense key array); K1c: spectrum ranges in LDS, merged without atomics
+    return hipGetLastError();
+}
+
+// K1b: jump hash of the list (dense key array); K1c: spectrum ranges in LDS, merged without atomics
+hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
+                                 uint32_t *d_hists) {
+    if (n_reads == 0) return hipSuccess;
+    hipError_t e = hipSuccess;
+    const uint32_t n_regions = (uint32_t)((n_reads + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE);
     const uint32_t nblk = (n_regions + 1023) / 1024;
     hipLaunchKernelGGL(k_region_bsum, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, n_regions);
     hipLaunchKernelGGL(k_region_offsets, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.off, n_regions);
