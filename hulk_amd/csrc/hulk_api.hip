@@ -76,6 +76,12 @@ struct hulk_ctx {
     double decay_weight = 0.0;
     uint32_t *d_blkcnt = nullptr, *d_eidx = nullptr, *d_etot = nullptr; double *d_ctrd = nullptr, *d_estd = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // Flushes run on their own stream so that the (memory/latency-bound) count-min + CWS kernels of
+    // batch n overlap the (VALU-bound) minimizer kernels of batch n+1.  Two spectrum rings alternate.
+    hipStream_t flush_stream = nullptr;
+    hipEvent_t ev_binned = nullptr, ev_flushed[2] = {nullptr, nullptr};
+    bool pending_flush[2] = {false, false};
+    int cur_ring = 0;
     // device state
     DevState *d_state = nullptr;
     uint32_t *d_hist = nullptr, *d_hist_tmp = nullptr;
@@ -245,6 +251,23 @@ int ensure_tables(hulk_ctx *c) {
     return generate_tables(c);
 }
 
+uint32_t *ring_hist(hulk_ctx *c) { return c->d_hist + (size_t)c->cur_ring * (size_t)c->ring_n * (size_t)c->B; }
+
+// the work stream may only write spectra of the current ring once the flush that last read them is done
+int ring_ready_for_writes(hulk_ctx *c) {
+    if (c->pending_flush[c->cur_ring]) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_flushed[c->cur_ring], 0));
+        c->pending_flush[c->cur_ring] = false;
+    }
+    return HULK_OK;
+}
+
+int sync_all(hulk_ctx *c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->flush_stream));
+    return HULK_OK;
+}
+
 // kernel configuration by read length: {xcap, table, block threads}
 bool pick_config(uint32_t k, uint32_t max_len, MinimizerParams &P, int &threads) {
     const uint32_t npos = max_len >= k ? max_len - k + 1 : 1;
@@ -260,6 +283,8 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
     P.k = c->p.k; P.w = c->p.w; P.num_bins = c->B; P.bases_bytes = bases_bytes;
     P.interval = interval; P.fill = fill; P.ring_base = c->ring_base; P.ring_n = c->ring_n;
     if (const char *e = getenv("HULK_K1_DEBUG")) P.debug = (uint32_t)atoi(e);
+    { int rcw = ring_ready_for_writes(c); if (rcw != HULK_OK) return rcw; }
+    uint32_t *hist = ring_hist(c);
     int threads = 256;
     // the short-read kernel takes reads of <= 16*w k-mer positions and <= 256 bases; when the batch's
     // length bound already exceeds that, go straight to the generic kernel
@@ -304,15 +329,15 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
         HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->ml, c->d_state,
                                         c->d_min_slots, c->d_slow_list, c->d_slow_count));
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
-        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, c->d_hist));
+        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist));
         if (!pick_config(c->p.k, max_len, P, threads)) return fail(c, HULK_ERR_READ_TOO_LONG);
         const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(1024, (n + 3) / 4);
-        HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, c->d_hist, c->d_state,
+        HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, hist, c->d_state,
                                        c->d_min_slots, c->d_slow_list, c->d_slow_count, list_blocks));
         return HULK_OK;
     }
     if (!pick_config(c->p.k, max_len, P, threads)) return fail(c, HULK_ERR_READ_TOO_LONG);
-    HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, c->d_hist, c->d_state,
+    HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, hist, c->d_state,
                                    c->d_min_slots, nullptr, nullptr, 0));
     return HULK_OK;
 }
@@ -325,18 +350,23 @@ int flush_batch(hulk_ctx *c, uint32_t count) {
     FlushBatch fb{};
     fb.ring_base = c->ring_base; fb.ring_n = c->ring_n; fb.count = count;
     fb.parity = (int)(c->flush_index & 1); fb.num_bins = c->B;
-    hipStream_t s = c->stream;
-    HIPCHK(c, launch_count_used(s, c->d_hist, c->d_state, fb));
+    // everything binned so far (and e.g. the caller's all-reduce) is on the work stream: the flush
+    // stream waits for it, then runs on its own
+    HIPCHK(c, hipEventRecord(c->ev_binned, c->stream));
+    hipStream_t s = c->flush_stream;
+    HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
+    uint32_t *hist = ring_hist(c);
+    HIPCHK(c, launch_count_used(s, hist, c->d_state, fb));
     if (c->scaling) {
-        HIPCHK(c, launch_elem_index(s, c->d_hist, c->d_blkcnt, c->d_eidx, c->d_etot, fb));
-        HIPCHK(c, launch_cms_chains_decay(s, c->d_hist, c->d_perm, c->d_chain_start, c->d_eidx, c->d_etot, c->d_ctrd,
+        HIPCHK(c, launch_elem_index(s, hist, c->d_blkcnt, c->d_eidx, c->d_etot, fb));
+        HIPCHK(c, launch_cms_chains_decay(s, hist, c->d_perm, c->d_chain_start, c->d_eidx, c->d_etot, c->d_ctrd,
                                           c->d_estd, c->cms_depth, c->cms_width, c->decay_weight, c->d_state, fb));
-        HIPCHK(c, launch_freq_decay(s, c->d_hist, c->d_estd, c->d_invperm, c->d_f64, c->d_rcp32, c->cms_depth,
+        HIPCHK(c, launch_freq_decay(s, hist, c->d_estd, c->d_invperm, c->d_f64, c->d_rcp32, c->cms_depth,
                                     c->row_stride, c->d_state, fb));
     } else {
-        HIPCHK(c, launch_cms_chains(s, c->d_hist, c->d_perm, c->d_chain_start, c->d_ctr, c->d_estl, c->d_basearr,
+        HIPCHK(c, launch_cms_chains(s, hist, c->d_perm, c->d_chain_start, c->d_ctr, c->d_estl, c->d_basearr,
                                     c->cms_depth, c->cms_width, c->d_state, fb));
-        HIPCHK(c, launch_freq(s, c->d_hist, c->d_estl, c->d_basearr, c->d_invperm, c->d_pos16, c->d_f64, c->d_rcp32,
+        HIPCHK(c, launch_freq(s, hist, c->d_estl, c->d_basearr, c->d_invperm, c->d_pos16, c->d_f64, c->d_rcp32,
                               c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
     }
     if (c->slots) {
@@ -355,6 +385,8 @@ int flush_batch(hulk_ctx *c, uint32_t count) {
         HIPCHK(c, launch_cws_resolve(s, c->d_rcb, c->d_f64, c->d_tilemin, c->d_candA, c->d_candB, c->d_mins, c->d_weights,
                                      (int)c->slots, (int)c->slot_begin, c->ntiles, c->d_state, fb));
     }
+    HIPCHK(c, hipEventRecord(c->ev_flushed[c->cur_ring], s));
+    c->pending_flush[c->cur_ring] = true;
     c->flush_index++;
     return HULK_OK;
 }
@@ -362,6 +394,7 @@ int flush_batch(hulk_ctx *c, uint32_t count) {
 int do_flush(hulk_ctx *c) { return flush_batch(c, 1); }
 
 int check_device_error(hulk_ctx *c) {
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
     DevState st{};
     HIPCHK(c, hipMemcpyAsync(&st, c->d_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -422,7 +455,19 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     if (const char *e = getenv("HULK_BATCH")) { int v = atoi(e); if (v >= 1 && v <= SCAN_BATCH_MAX) c->T = (uint32_t)v; }
     c->ring_n = c->T + 1;
     const size_t T = c->T, RN = c->ring_n;
-    CHK_CREATE(dalloc(&c->d_hist, RN * B));
+    CHK_CREATE(dalloc(&c->d_hist, 2 * RN * B));
+    {   // the flush kernels fill the gaps the VALU-bound minimizer kernels leave: lowest queue priority
+        // measured best (7.66e8 reads/s vs 7.59e8 default vs 7.37e8 highest) — the minimizer chain is the
+        // critical path
+        int lo = 0, hi = 0;
+        CHK_CREATE(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const char *pe = getenv("HULK_FLUSH_PRIORITY");
+        const int prio = pe ? atoi(pe) : lo;   // `lo` = least priority (numerically greatest)
+        CHK_CREATE(hipStreamCreateWithPriority(&c->flush_stream, hipStreamNonBlocking, prio));
+    }
+    CHK_CREATE(hipEventCreateWithFlags(&c->ev_binned, hipEventDisableTiming));
+    CHK_CREATE(hipEventCreateWithFlags(&c->ev_flushed[0], hipEventDisableTiming));
+    CHK_CREATE(hipEventCreateWithFlags(&c->ev_flushed[1], hipEventDisableTiming));
     CHK_CREATE(dalloc(&c->d_hist_tmp, B));
     CHK_CREATE(dalloc(&c->d_slow_count, 1));
     CHK_CREATE(dalloc(&c->d_min_slots, (size_t)MIN_SLOTS));
@@ -449,7 +494,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_candA, T * SL));
     CHK_CREATE(dalloc(&c->d_candB, T * SL));
     CHK_CREATE(hipMemsetAsync(c->d_state, 0, sizeof(DevState), c->stream));
-    CHK_CREATE(hipMemsetAsync(c->d_hist, 0, RN * B * 4, c->stream));
+    CHK_CREATE(hipMemsetAsync(c->d_hist, 0, 2 * RN * B * 4, c->stream));
     CHK_CREATE(hipMemsetAsync(c->d_ctr, 0, (size_t)c->cms_depth * c->cms_width * 8, c->stream));
     CHK_CREATE(hipMemsetAsync(c->d_mins, 0, (S ? S : 1) * 8, c->stream));
     CHK_CREATE(launch_fill_f32(c->stream, c->d_rcp32, T * c->row_stride, std::nanf("")));
@@ -469,6 +514,9 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
 void hulk_destroy(hulk_ctx *c) {
     if (!c) return;
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    if (c->flush_stream) { hipStreamSynchronize(c->flush_stream); hipStreamDestroy(c->flush_stream); }
+    if (c->ev_binned) hipEventDestroy(c->ev_binned);
+    for (int i = 0; i < 2; i++) if (c->ev_flushed[i]) hipEventDestroy(c->ev_flushed[i]);
     for (auto &pr : c->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
     hipFree(c->d_state); hipFree(c->d_hist); hipFree(c->d_hist_tmp); hipFree(c->d_perm); hipFree(c->d_chain_start);
     hipFree(c->d_ctr); hipFree(c->d_estl); hipFree(c->d_basearr); hipFree(c->d_invperm); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
@@ -482,14 +530,14 @@ void hulk_destroy(hulk_ctx *c) {
 
 int hulk_set_stream(hulk_ctx *c, void *hip_stream) {
     if (!c) return HULK_ERR_ARG;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
     c->stream = (hipStream_t)hip_stream;          // NULL = the HIP null stream
     return HULK_OK;
 }
 
 int hulk_set_private_stream(hulk_ctx *c) {
     if (!c) return HULK_ERR_ARG;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
     c->stream = c->own_stream;
     return HULK_OK;
 }
@@ -522,7 +570,7 @@ int hulk_add_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d
             rc = flush_batch(c, done);
             if (rc != HULK_OK) return rc;
             c->ring_base = (c->ring_base + done) % c->ring_n;
-            if ((fill + chunk) % I == 0) c->ring_base = 0;  // every spectrum is empty again
+            if ((fill + chunk) % I == 0) { c->ring_base = 0; if (done) c->cur_ring ^= 1; }  // clean: next batch uses the other ring
         }
     }
     return HULK_OK;
@@ -549,12 +597,14 @@ int hulk_flush_batch(hulk_ctx *c, uint32_t count) {
     if (!c) return HULK_ERR_ARG;
     if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
     if (count > c->T || c->ring_base != 0) return fail(c, HULK_ERR_ARG, "batch count");
-    return flush_batch(c, count);
+    int rc = flush_batch(c, count);
+    if (rc == HULK_OK && count) c->cur_ring ^= 1;      // the next batch is binned into the other ring meanwhile
+    return rc;
 }
 
 uint32_t hulk_batch_size(const hulk_ctx *c) { return c ? c->T : 0; }
 
-uint32_t *hulk_histogram_device(hulk_ctx *c) { return c ? c->d_hist + (size_t)c->ring_base * (size_t)c->B : nullptr; }
+uint32_t *hulk_histogram_device(hulk_ctx *c) { return c ? ring_hist(c) + (size_t)c->ring_base * (size_t)c->B : nullptr; }
 
 int hulk_add_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n) {
     if (!c) return HULK_ERR_ARG;
@@ -599,7 +649,8 @@ int hulk_add_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, u
 int hulk_add_histogram(hulk_ctx *c, const uint32_t *bins) {
     if (!c || !bins) return fail(c, HULK_ERR_ARG, "NULL");
     HIPCHK(c, hipMemcpyAsync(c->d_hist_tmp, bins, (size_t)c->B * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_add_hist(c->stream, c->d_hist + (size_t)c->ring_base * (size_t)c->B, c->d_hist_tmp, c->B));
+    { int rcw = ring_ready_for_writes(c); if (rcw != HULK_OK) return rcw; }
+    HIPCHK(c, launch_add_hist(c->stream, ring_hist(c) + (size_t)c->ring_base * (size_t)c->B, c->d_hist_tmp, c->B));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->hist_hook_used = true;
     return HULK_OK;
@@ -627,6 +678,7 @@ int hulk_finish(hulk_ctx *c) {
 
 int hulk_get_sketch(hulk_ctx *c, uint64_t *mins, double *weights) {
     if (!c || !mins || !weights) return fail(c, HULK_ERR_ARG, "NULL");
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
     HIPCHK(c, hipMemcpyAsync(mins, c->d_mins, (size_t)c->S * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(weights, c->d_weights, (size_t)c->S * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -637,6 +689,7 @@ int hulk_get_counters(hulk_ctx *c, uint64_t *n_reads, uint64_t *n_minimizers, ui
     if (!c) return HULK_ERR_ARG;
     DevState st{};
     std::vector<unsigned long long> slots(MIN_SLOTS);
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
     HIPCHK(c, hipMemcpyAsync(&st, c->d_state, sizeof st, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(slots.data(), c->d_min_slots, (size_t)MIN_SLOTS * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -650,7 +703,8 @@ int hulk_get_counters(hulk_ctx *c, uint64_t *n_reads, uint64_t *n_minimizers, ui
 
 int hulk_get_histogram(hulk_ctx *c, uint32_t *bins) {
     if (!c || !bins) return fail(c, HULK_ERR_ARG, "NULL");
-    HIPCHK(c, hipMemcpyAsync(bins, c->d_hist + (size_t)c->ring_base * (size_t)c->B, (size_t)c->B * 4, hipMemcpyDeviceToHost, c->stream));
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
+    HIPCHK(c, hipMemcpyAsync(bins, ring_hist(c) + (size_t)c->ring_base * (size_t)c->B, (size_t)c->B * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HULK_OK;
 }
@@ -658,6 +712,7 @@ int hulk_get_histogram(hulk_ctx *c, uint32_t *bins) {
 int hulk_get_cms(hulk_ctx *c, double *counters) {
     if (!c || !counters) return fail(c, HULK_ERR_ARG, "NULL");
     const size_t n = (size_t)c->cms_depth * c->cms_width;
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
     if (c->scaling) {
         HIPCHK(c, hipMemcpyAsync(counters, c->d_ctrd, n * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -710,7 +765,7 @@ int hulk_get_profile(hulk_ctx *c, const char *kernel, uint64_t *launches, double
     if (kernel && strcmp(kernel, "k_minimizer_fast") == 0) which = 1;
     else if (kernel && strcmp(kernel, "k_cws_scan") != 0)
         return fail(c, HULK_ERR_ARG, "instrumented kernels: k_cws_scan, k_minimizer_fast");
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
     double tot = 0; uint64_t n = 0;
     std::vector<ProfileRec> keep;
     for (auto &pr : c->prof) {

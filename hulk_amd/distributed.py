@@ -94,16 +94,22 @@ class GpuEngine:
         self.sk = sketcher
         self.collective_device = torch.device(device)
         self.n_spectra = n_spectra          # spectra (intervals) merged per collective
-        ptr = sketcher.histogram_device_ptr()
-        nb = sketcher.num_bins * n_spectra
-
-        class _View:  # __cuda_array_interface__ v2: int32 view (counts < 2^31, sum is bit-identical)
-            __cuda_array_interface__ = {"shape": (nb,), "typestr": "<i4", "data": (ptr, False),
-                                        "version": 2, "strides": None}
-        self._hist = torch.as_tensor(_View(), device=self.collective_device)
+        self._views = {}                    # the library alternates between two spectrum rings
 
     def histogram_tensor(self):
-        return self._hist
+        """torch view of the spectra the NEXT flush will consume (int32: counts < 2^31, sum bit-identical)."""
+        import torch
+        ptr = self.sk.histogram_device_ptr()
+        t = self._views.get(ptr)
+        if t is None:
+            nb = self.sk.num_bins * self.n_spectra
+
+            class _View:  # __cuda_array_interface__ v2
+                __cuda_array_interface__ = {"shape": (nb,), "typestr": "<i4", "data": (ptr, False),
+                                            "version": 2, "strides": None}
+            t = torch.as_tensor(_View(), device=self.collective_device)
+            self._views[ptr] = t
+        return t
 
     def flush(self): self.sk.flush_batch(self.n_spectra)
     def finish(self): self.sk.finish()
