@@ -294,3 +294,39 @@ def test_cli_c1_fixture(tmp_path, fq_reads):
     bad = tmp_path / "bad.fq"
     bad.write_bytes(b"@r\nACGTACGT\n+\nIIIIIIII\n")
     assert main(["sketch", "-f", str(bad), "-o", out]) == 1
+
+
+@pytest.mark.parametrize("k,w,lens,n", [
+    (15, 9, (300, 900), 600),        # generic kernel, 1024-position configuration
+    (15, 9, (1500, 4000), 200),      # generic kernel, 4096-position configuration
+    (21, 16, (150, 150), 2000),      # fast kernel, widest block (WM = 16)
+    (21, 1, (30, 36), 3000),         # w = 1: every k-mer is its own minimizer; <= 16 positions on the fast path
+    (21, 20, (150, 250), 1500),      # w > 16: generic kernel only
+    (12, 4, (40, 300), 2500),        # mixed: short reads on the fast path, long ones deferred to the generic kernel
+    (9, 0, (20, 60), 1000),          # w = 0 is accepted by the reference (windowIndex = i + 1)
+])
+def test_read_length_and_window_configurations(k, w, lens, n):
+    rng = np.random.default_rng(k * 100 + w)
+    seqs = random_reads(rng, n, lens)
+    o, g = run_both(seqs, k, w, 4, num_bins=200003)
+    assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32))
+    assert o.counters()["n_minimizers"] == g.counters()["n_minimizers"]
+    g.close(); o.close()
+
+
+def test_read_too_long_is_reported():
+    g = gpu().GpuSketcher(15, 9, 4)
+    with pytest.raises(gpu().HulkError, match="read longer than"):
+        g.add_seq(b"ACGT" * 2000)
+    g.close()
+
+
+def test_repetitive_reads_fall_back_to_generic_kernel():
+    """> 64 run starts in one read (low-complexity / tandem repeats) leave the fast path."""
+    rng = np.random.default_rng(4)
+    unit = bytes(rng.choice(list(b"ACGT"), size=7))
+    seqs = [unit * 21] * 40 + random_reads(rng, 500, 147) + [b"AC" * 70, b"A" * 150, b"ACG" * 50]
+    o, g = run_both(seqs, 5, 2, 4, num_bins=997)
+    assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32))
+    assert o.counters()["n_minimizers"] == g.counters()["n_minimizers"]
+    g.close(); o.close()
