@@ -95,7 +95,9 @@ struct hulk_ctx {
     uint8_t *d_bases = nullptr; size_t d_bases_cap = 0;
     uint64_t *d_offsets = nullptr; size_t d_offsets_cap = 0;
     uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;
-    MinimizerList ml{}; uint64_t ml_regions = 0;   // minimizer list of the short-read kernel (grow-only)
+    MinimizerList ml{}; uint64_t ml_regions = 0;
+    uint64_t *d_long_xs = nullptr, *d_long_table = nullptr; uint8_t *d_long_valid = nullptr;   // long-sequence scratch
+    uint64_t long_cap = 0, long_table_cap = 0;   // minimizer list of the short-read kernel (grow-only)
     // host-side run state
     uint64_t seq_count = 0, flush_index = 0;
     uint32_t T = 8, ring_n = 9, ring_base = 0;   // interval batch size and spectrum ring
@@ -269,12 +271,46 @@ int sync_all(hulk_ctx *c) {
 }
 
 // kernel configuration by read length: {xcap, table, block threads}
+constexpr uint32_t GENERIC_XCAP_MAX = 4096;
+// returns false when some reads may exceed the largest configuration (they take the long-read path)
 bool pick_config(uint32_t k, uint32_t max_len, MinimizerParams &P, int &threads) {
     const uint32_t npos = max_len >= k ? max_len - k + 1 : 1;
     if (npos <= 192) { P.xcap = 192; P.tab_size = 256; threads = 256; return true; }
     if (npos <= 1024) { P.xcap = 1024; P.tab_size = 2048; threads = 64; return true; }
-    if (npos <= 4096) { P.xcap = 4096; P.tab_size = 8192; threads = 64; return true; }
-    return false;
+    P.xcap = GENERIC_XCAP_MAX; P.tab_size = 8192; threads = 64;
+    return npos <= GENERIC_XCAP_MAX;
+}
+
+// sequences with more than GENERIC_XCAP_MAX k-mer positions: one at a time over the whole grid
+int bin_long_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, MinimizerParams P,
+                   uint32_t *hist) {
+    std::vector<uint64_t> off(n + 1);
+    HIPCHK(c, hipMemcpyAsync(off.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint64_t rd = 0; rd < n; rd++) {
+        const uint64_t L = off[rd + 1] - off[rd];
+        if (L < (uint64_t)P.k || L - P.k + 1 <= GENERIC_XCAP_MAX) continue;
+        const uint64_t npos = L - P.k + 1;
+        uint64_t tsize = 1; while (tsize < 2 * npos) tsize <<= 1;
+        if (npos > c->long_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->d_long_xs); hipFree(c->d_long_valid); c->d_long_xs = nullptr; c->d_long_valid = nullptr; c->long_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_long_xs, npos * 8));
+            HIPCHK(c, hipMalloc((void **)&c->d_long_valid, npos));
+            c->long_cap = npos;
+        }
+        if (tsize > c->long_table_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->d_long_table); c->d_long_table = nullptr; c->long_table_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_long_table, tsize * 8));
+            c->long_table_cap = tsize;
+        }
+        uint32_t slot = P.ring_base;
+        if (P.interval) slot = (uint32_t)(((P.fill + rd) / P.interval + P.ring_base) % P.ring_n);
+        HIPCHK(c, launch_long_read(c->stream, d_bases + off[rd], L, P, c->d_long_xs, c->d_long_valid, c->d_long_table,
+                                   tsize, hist + (size_t)slot * (size_t)c->B, c->d_min_slots));
+    }
+    return HULK_OK;
 }
 
 int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
@@ -304,7 +340,8 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
         const uint64_t rcap = minimizer_list_rcap(c->p.w);
         if (regions > c->ml_regions || c->ml.rcap != rcap) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum);
+            hipFree(c->d_long_xs); hipFree(c->d_long_table); hipFree(c->d_long_valid);
+    hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum);
             uint32_t *keep_partial = c->ml.partial; const uint32_t keep_parts = c->ml.max_parts;
             c->ml = MinimizerList{}; c->ml_regions = 0;
             c->ml.partial = keep_partial; c->ml.max_parts = keep_parts;
@@ -330,15 +367,17 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
                                         c->d_min_slots, c->d_slow_list, c->d_slow_count));
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
         HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist));
-        if (!pick_config(c->p.k, max_len, P, threads)) return fail(c, HULK_ERR_READ_TOO_LONG);
+        pick_config(c->p.k, max_len, P, threads);      // (fast_ok implies max_len <= 256: always fits)
         const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(1024, (n + 3) / 4);
         HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, hist, c->d_state,
                                        c->d_min_slots, c->d_slow_list, c->d_slow_count, list_blocks));
         return HULK_OK;
     }
-    if (!pick_config(c->p.k, max_len, P, threads)) return fail(c, HULK_ERR_READ_TOO_LONG);
+    const bool fits = pick_config(c->p.k, max_len, P, threads);
+    P.skip_long = fits ? 0u : 1u;
     HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, hist, c->d_state,
                                    c->d_min_slots, nullptr, nullptr, 0));
+    if (!fits) return bin_long_reads(c, d_bases, d_offsets, n, P, hist);
     return HULK_OK;
 }
 

@@ -49,6 +49,7 @@ struct MinimizerParams {
     uint32_t tab_size;   // per-wave dedupe table entries (power of two, > xcap)
     uint32_t lds_per_wave;  // filled by launch_minimizer_bin
     uint32_t debug;         // ablation switches (env HULK_K1_DEBUG), 0 in production
+    uint32_t skip_long;     // reads beyond xcap are handled by the long-read path, not an error
     uint64_t bases_bytes;
     uint64_t interval;   // reads per k-mer spectrum (0 = everything into ring_base)
     uint64_t fill;       // reads already counted into the first spectrum of this launch
@@ -71,6 +72,9 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
 hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
                                  uint32_t *d_hists);
 uint32_t minimizer_list_rcap(uint32_t w);
+hipError_t launch_long_read(hipStream_t s, const uint8_t *d_seq, uint64_t L, MinimizerParams P, uint64_t *d_xs,
+                            uint8_t *d_valid, uint64_t *d_table, uint64_t table_size, uint32_t *d_hist_slot,
+                            unsigned long long *d_min_slots);
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb);
 hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,
                              const uint32_t *d_chain_start, unsigned long long *d_ctr,

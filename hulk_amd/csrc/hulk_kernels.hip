@@ -15,6 +15,7 @@
 #include "hulk_internal.h"
 
 #include <math.h>
+#include <algorithm>
 
 namespace hulk {
 namespace {
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
         if (L < 1) { if (lane == 0) set_error(st, -3); continue; }
         if (L < (int64_t)(w + k - 1)) { if (lane == 0) set_error(st, -4); continue; }
         const int64_t npos64 = L - k + 1;
-        if (npos64 > (int64_t)xcap) { if (lane == 0) set_error(st, -33); continue; }
+        if (npos64 > (int64_t)xcap) { if (lane == 0 && !P.skip_long) set_error(st, -33); continue; }
         const int32_t npos = (int32_t)npos64;
 
         // ---- stage: ASCII -> 2-bit packs in LDS (4 bases per lane per pass), detect code 4
@@ -789,6 +790,78 @@ __global__ __launch_bounds__(256) void k_merge_hist(const uint32_t *__restrict__
         for (uint32_t p = 0; p < n_parts; p++) v += partial[((size_t)p * n_spectra + t) * (size_t)P.num_bins + b];
         if (v) hist[b] += v;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Long sequences (FASTA contigs, anything beyond the generic kernel's 4096 k-mer positions): one
+// sequence at a time over the whole grid.  k_long_hash: hashed canonical k-mer per position with
+// the literal recurrence (N-safe); k_long_emit: windowed minimum per position, per-read set =
+// open-addressing table in HBM (64-bit compare-and-swap), new values are jump-hashed and counted.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_long_hash(const uint8_t *__restrict__ seq, uint64_t L, MinimizerParams P,
+                                                   uint64_t *__restrict__ Xs, uint8_t *__restrict__ valid) {
+    __shared__ uint8_t lut[256];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) lut[t] = nt4_of((unsigned)t);
+    __syncthreads();
+    const int64_t k = (int64_t)P.k, w = (int64_t)P.w;
+    const uint64_t mask = (1ull << (2 * k)) - 1, shift = (uint64_t)(2 * (k - 1));
+    const uint64_t npos = L - (uint64_t)k + 1;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < npos; j += (uint64_t)gridDim.x * blockDim.x) {
+        const int64_t i = (int64_t)j + k - 1;
+        uint64_t f = 0, r = 0;
+        int64_t p0 = i - k; if (p0 < 0) p0 = 0;
+        for (int64_t p = p0; p <= i; p++) {                     // bases before i-k cannot survive (see k_minimizer_bin)
+            const uint64_t c = lut[seq[p]];
+            f = (f << 2 | c) & mask;
+            r = (r >> 2) | ((3ull ^ c) << shift);
+        }
+        uint64_t X = X_NONE; uint8_t ok = 0;
+        if (f != r) {
+            const uint64_t canon = f > r ? r : f;
+            int64_t span = i - w + 2;
+            if (span >= k) span = k;
+            X = hash64(canon, mask) << 8 | (uint64_t)(int64_t)(int32_t)span;
+            ok = 1;
+        }
+        Xs[j] = X; valid[j] = ok;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_long_emit(const uint64_t *__restrict__ Xs, const uint8_t *__restrict__ valid,
+                                                   uint64_t L, MinimizerParams P, uint64_t *__restrict__ table,
+                                                   uint64_t table_mask, uint32_t *__restrict__ hist,
+                                                   unsigned long long *__restrict__ min_slots) {
+    __shared__ unsigned red[4];
+    const int64_t k = (int64_t)P.k, w = (int64_t)P.w, wwin = w > 0 ? w : 1;
+    const uint64_t npos = L - (uint64_t)k + 1;
+    unsigned fresh = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < npos; j += (uint64_t)gridDim.x * blockDim.x) {
+        const int64_t i = (int64_t)j + k - 1;
+        if (!valid[j] || i < w - 1) continue;
+        uint64_t lo = j >= (uint64_t)(wwin - 1) ? j - (uint64_t)(wwin - 1) : 0;
+        uint64_t m = X_NONE;
+        for (uint64_t p = lo; p <= j; p++) { const uint64_t x = Xs[p]; m = x < m ? x : m; }
+        // per-read set: only the thread whose compare-and-swap claims the slot counts the value
+        uint64_t slot = (m ^ (m >> 29)) * 0x9E3779B97F4A7C15ull >> 20 & table_mask;
+        for (;;) {
+            const unsigned long long old = atomicCAS((unsigned long long *)&table[slot], (unsigned long long)TAB_EMPTY,
+                                                     (unsigned long long)m);
+            if (old == TAB_EMPTY) { atomicAdd(&hist[jump_hash(m, P.num_bins)], 1u); fresh++; break; }
+            if (old == m) break;
+            slot = (slot + 1) & table_mask;
+        }
+    }
+    for (int off = 32; off; off >>= 1) fresh += __shfl_xor(fresh, off);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = fresh;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = red[0] + red[1] + red[2] + red[3];
+        if (t) atomicAdd(&min_slots[blockIdx.x & (MIN_SLOTS - 1)], (unsigned long long)t);
+    }
+}
+
+__global__ void k_fill_u64(uint64_t *p, uint64_t n, uint64_t v) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1592,6 +1665,18 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
 }
 
 uint32_t minimizer_list_rcap(uint32_t w) { return FAST_READS_PER_WAVE * 16u * w; }
+
+hipError_t launch_long_read(hipStream_t s, const uint8_t *d_seq, uint64_t L, MinimizerParams P, uint64_t *d_xs,
+                            uint8_t *d_valid, uint64_t *d_table, uint64_t table_size, uint32_t *d_hist_slot,
+                            unsigned long long *d_min_slots) {
+    const uint64_t npos = L - P.k + 1;
+    unsigned blocks = (unsigned)std::min<uint64_t>((npos + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_fill_u64, dim3(2048), dim3(256), 0, s, d_table, table_size, TAB_EMPTY);
+    hipLaunchKernelGGL(k_long_hash, dim3(blocks), dim3(256), 0, s, d_seq, L, P, d_xs, d_valid);
+    hipLaunchKernelGGL(k_long_emit, dim3(blocks), dim3(256), 0, s, d_xs, d_valid, L, P, d_table, table_size - 1,
+                       d_hist_slot, d_min_slots);
+    return hipGetLastError();
+}
 
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb) {
     int blocks = (fb.num_bins + 2047) / 2048; if (blocks > 128) blocks = 128;

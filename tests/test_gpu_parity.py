@@ -314,11 +314,18 @@ def test_read_length_and_window_configurations(k, w, lens, n):
     g.close(); o.close()
 
 
-def test_read_too_long_is_reported():
-    g = gpu().GpuSketcher(15, 9, 4)
-    with pytest.raises(gpu().HulkError, match="read longer than"):
-        g.add_seq(b"ACGT" * 2000)
-    g.close()
+def test_long_sequences_fasta_style():
+    """Sequences beyond the generic kernel's 4096 positions (FASTA contigs) take the long-sequence
+    path: per-sequence set in an HBM hash table.  Mixed with short and medium reads, with N."""
+    rng = np.random.default_rng(12)
+    seqs = random_reads(rng, 3, (20000, 40000), b"ACGTN" * 40 + b"N")[0:3]
+    seqs += random_reads(rng, 300, (60, 150)) + random_reads(rng, 20, (2000, 4000))
+    seqs += [seqs[0][:9000] * 3]                         # a long repetitive one: duplicates inside one sequence
+    rng.shuffle(seqs)
+    o, g = run_both(seqs, 15, 9, 4, num_bins=300007, batches=2)
+    assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32))
+    assert o.counters()["n_minimizers"] == g.counters()["n_minimizers"]
+    g.close(); o.close()
 
 
 def test_repetitive_reads_fall_back_to_generic_kernel():
