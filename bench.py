@@ -3,13 +3,15 @@
 
 Workload at N=1 (BASELINE configs[1], "C2"): synthetic 150 bp reads, k=21, w=9, sketchSize=512,
 interval=100k reads; reads are resident in HBM before the timed region.  One *step* = one batch of
-T=10 sketching intervals (1 M reads): one launch bins the reads of the 10 intervals into 10 k-mer
-spectra (minimizers -> jump hash), the spectra go through the count-min update, and ONE pass over
-the CWS table applies all 10 histosketch updates in interval order — bit-identical to flushing
-after every 100k reads.  K=10 steps = the 10 M reads of C2; the default is K=20.
+T=16 sketching intervals (1.6 M reads): one launch chain bins the reads of the 16 intervals into 16
+k-mer spectra (minimizers -> jump hash -> spectrum), the spectra go through the count-min update,
+and ONE pass over the CWS table applies all 16 histosketch updates in interval order —
+bit-identical to flushing after every 100k reads (tests/test_gpu_parity.py).  The flush of step n
+runs on a second stream under the minimizer kernels of step n+1.  Default K=20 steps = 32 M reads
+(C2's 10 M reads = 6.25 steps).
 
 N>1 (one process per GPU, launched by torch.distributed.run): every interval's reads are split
-into N contiguous slices, the 10 spectra of a step are merged with ONE RCCL all-reduce, the CWS
+into N contiguous slices, the 16 spectra of a step are merged with ONE RCCL all-reduce, the CWS
 update is slot-sharded (hulk_amd/distributed.py).  Per-rank work per step is kept fixed as N
 grows (each rank bins 100k reads per interval => the global interval is N x 100k): "weak" scaling.
 
@@ -28,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 K, W, S, READ_LEN, INTERVAL = 21, 9, 512, 150, 100_000
-BATCH = 10                   # sketching intervals per step (one pass over the CWS table)
+BATCH = int(os.environ.get("HULK_BENCH_BATCH", "16"))   # sketching intervals per step (one pass over the CWS table)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -177,7 +179,7 @@ def main():
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "C2: synthetic 150bp reads, k=21, w=9, sketchSize=512, "
-                                   "interval=100k reads per rank, 10 intervals per step, HBM-resident input",
+                                   f"interval=100k reads per rank, {BATCH} intervals per step, HBM-resident input",
                        "reads_per_step": reads_per_rank_step * world, "total_reads": total_reads,
                        "intervals_per_step": BATCH,
                        "parallelism": f"read-shard x{world}, slot-sharded CWS"},

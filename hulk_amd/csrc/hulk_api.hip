@@ -391,9 +391,12 @@ int flush_batch(hulk_ctx *c, uint32_t count) {
     fb.parity = (int)(c->flush_index & 1); fb.num_bins = c->B;
     // everything binned so far (and e.g. the caller's all-reduce) is on the work stream: the flush
     // stream waits for it, then runs on its own
-    HIPCHK(c, hipEventRecord(c->ev_binned, c->stream));
-    hipStream_t s = c->flush_stream;
-    HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
+    static const bool no_overlap = getenv("HULK_NO_OVERLAP") != nullptr;   // profiling aid: one stream, kernels back to back
+    hipStream_t s = no_overlap ? c->stream : c->flush_stream;
+    if (!no_overlap) {
+        HIPCHK(c, hipEventRecord(c->ev_binned, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
+    }
     uint32_t *hist = ring_hist(c);
     HIPCHK(c, launch_count_used(s, hist, c->d_state, fb));
     if (c->scaling) {

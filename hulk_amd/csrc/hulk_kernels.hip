@@ -15,6 +15,7 @@
 #include "hulk_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 
 namespace hulk {
@@ -1042,12 +1043,17 @@ __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
                                                   const float *__restrict__ rcp32,
                                                   float *__restrict__ tilemin, int slots, int ntiles,
                                                   size_t row_stride, const DevState *st, FlushBatch fb) {
-    const int tile = blockIdx.x % ntiles, grp = blockIdx.x / ntiles;
+    // XCD-aware order (workgroup b lands on XCD b % 8): XCD x works through column tile 8*chunk + x for
+    // ALL slot groups before moving on, so a column's reciprocal vectors (T x 4 KB) are fetched into
+    // that XCD's L2 once and re-used by the other groups; the 8 XCDs stream 8 adjacent 4 KB pieces of
+    // the same K rows at the same time (32 KB contiguous per row).
+    const int ngrp = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    const int chunk = blockIdx.x / (8 * ngrp), rem = blockIdx.x % (8 * ngrp);
+    const int grp = rem / 8, tile = chunk * 8 + (rem % 8);
+    if (tile >= ntiles) return;
     const int tid = threadIdx.x, wid = tid >> 6;
     const size_t col = (size_t)tile * SCAN_TILE + (size_t)tid * 4;
     const int wtiles = ntiles * 4;                               // 256-bin wave tiles per row
-    // (consecutive workgroups stream consecutive 4 KB pieces of the same 8 rows; mapping them to
-    //  share the column tile instead — better L2 reuse of the reciprocals — measured 5 % slower)
     floatx4 kv[SCAN_ROWS];
 #pragma unroll
     for (int r = 0; r < SCAN_ROWS; r++) {
@@ -1644,7 +1650,11 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     const uint32_t nblk = (n_regions + 1023) / 1024;
     hipLaunchKernelGGL(k_region_bsum, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, n_regions);
     hipLaunchKernelGGL(k_region_offsets, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.off, n_regions);
-    hipLaunchKernelGGL(k_jump_bin, dim3((n_regions + 3) / 4), dim3(256), 0, s, ml, n_regions, P.num_bins);
+    // k_jump_bin needs no LDS; a dummy allocation caps its occupancy so that the flush kernels of the
+    // previous batch (other stream) find free wave slots next to it
+    static int jump_lds = -1;
+    if (jump_lds < 0) { const char *e = getenv("HULK_JUMP_LDS"); jump_lds = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(k_jump_bin, dim3((n_regions + 3) / 4), dim3(256), (size_t)jump_lds, s, ml, n_regions, P.num_bins);
     const uint32_t n_spectra = P.interval ? (uint32_t)((P.fill + n_reads + P.interval - 1) / P.interval) : 1u;
     const int nranges = (P.num_bins + HIST_RANGE - 1) / HIST_RANGE;
     uint32_t n_parts = 384u / (uint32_t)(nranges * n_spectra);
@@ -1708,7 +1718,8 @@ hipError_t launch_freq(hipStream_t s, uint32_t *d_hists, const uint32_t *d_estl,
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb) {
     const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
-    hipLaunchKernelGGL(k_cws_scan, dim3((unsigned)(groups * ntiles)), dim3(256), 0, s, d_k32, d_rcp32,
+    const int chunks = (ntiles + 7) / 8;
+    hipLaunchKernelGGL(k_cws_scan, dim3((unsigned)(chunks * 8 * groups)), dim3(256), 0, s, d_k32, d_rcp32,
                        d_tilemin, slots, ntiles, row_stride, st, fb);
     return hipGetLastError();
 }
