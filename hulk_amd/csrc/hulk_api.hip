@@ -88,6 +88,7 @@ struct hulk_ctx {
     uint32_t *d_perm = nullptr, *d_chain_start = nullptr;
     unsigned long long *d_ctr = nullptr, *d_basearr = nullptr, *d_mins = nullptr, *d_min_slots = nullptr;
     uint32_t *d_estl = nullptr, *d_invperm = nullptr; uint16_t *d_pos16 = nullptr;
+    uint8_t *d_meta8 = nullptr; uint32_t *d_segsum = nullptr; unsigned long long *d_cbase = nullptr;   // bin-order count-min
     double *d_f64 = nullptr, *d_weights = nullptr, *d_rcb = nullptr;
     float *d_rcp32 = nullptr, *d_k32 = nullptr, *d_tilemin = nullptr;
     double *d_candA = nullptr; int32_t *d_candB = nullptr;
@@ -130,6 +131,7 @@ int build_chains(hulk_ctx *c) {
     const int D = c->cms_depth, W = c->cms_width; const int32_t B = c->B;
     std::vector<uint32_t> perm((size_t)D * B), start((size_t)D * (W + 1)), pos(B), invperm((size_t)D * B);
     std::vector<uint16_t> pos16((size_t)D * B);
+    std::vector<uint8_t> meta8((size_t)D * B);       // bits 0-6: previous lane of the 64-bin chunk on the same counter (64 = none); bit 7: last one
     for (int d = 0; d < D; d++) {
         std::vector<uint32_t> cnt(W + 1, 0);
         for (int32_t b = 0; b < B; b++) {
@@ -146,7 +148,20 @@ int build_chains(hulk_ctx *c) {
             invperm[(size_t)d * B + b] = at;
             pos16[(size_t)d * B + b] = (uint16_t)pos[b];
         }
+        std::vector<int32_t> last_bin(W, -1);
+        for (int32_t c0 = 0; c0 < B; c0 += 64) {
+            const int32_t c1 = std::min<int32_t>(B, c0 + 64);
+            for (int32_t b = c0; b < c1; b++) {
+                const int32_t prev = last_bin[pos[b]];
+                uint8_t m = 64;
+                if (prev >= c0) { m = (uint8_t)(prev - c0); meta8[(size_t)d * B + prev] &= 0x7f; }   // prev is no longer the last
+                meta8[(size_t)d * B + b] = m | 0x80;
+                last_bin[pos[b]] = b;
+            }
+        }
     }
+    HIPCHK(c, dalloc(&c->d_meta8, meta8.size()));
+    HIPCHK(c, hipMemcpy(c->d_meta8, meta8.data(), meta8.size(), hipMemcpyHostToDevice));
     HIPCHK(c, dalloc(&c->d_invperm, invperm.size()));
     HIPCHK(c, dalloc(&c->d_pos16, pos16.size()));
     HIPCHK(c, hipMemcpy(c->d_invperm, invperm.data(), invperm.size() * 4, hipMemcpyHostToDevice));
@@ -406,10 +421,16 @@ int flush_batch(hulk_ctx *c, uint32_t count) {
         HIPCHK(c, launch_freq_decay(s, hist, c->d_estd, c->d_invperm, c->d_f64, c->d_rcp32, c->cms_depth,
                                     c->row_stride, c->d_state, fb));
     } else {
-        HIPCHK(c, launch_cms_chains(s, hist, c->d_perm, c->d_chain_start, c->d_ctr, c->d_estl, c->d_basearr,
-                                    c->cms_depth, c->cms_width, c->d_state, fb));
-        HIPCHK(c, launch_freq(s, hist, c->d_estl, c->d_basearr, c->d_invperm, c->d_pos16, c->d_f64, c->d_rcp32,
-                              c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
+        static const bool chain_order = getenv("HULK_CMS_CHAINS") != nullptr;   // the earlier chain-order kernels (A/B aid)
+        if (chain_order) {
+            HIPCHK(c, launch_cms_chains(s, hist, c->d_perm, c->d_chain_start, c->d_ctr, c->d_estl, c->d_basearr,
+                                        c->cms_depth, c->cms_width, c->d_state, fb));
+            HIPCHK(c, launch_freq(s, hist, c->d_estl, c->d_basearr, c->d_invperm, c->d_pos16, c->d_f64, c->d_rcp32,
+                                  c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
+        } else {
+            HIPCHK(c, launch_cms_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_ctr, c->d_segsum, c->d_cbase, c->d_f64,
+                                          c->d_rcp32, c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
+        }
     }
     if (c->slots) {
         ProfileRec pr{};
@@ -516,6 +537,8 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(hipMemsetAsync(c->d_min_slots, 0, (size_t)MIN_SLOTS * 8, c->stream));
     CHK_CREATE(dalloc(&c->d_ctr, (size_t)c->cms_depth * c->cms_width));
     CHK_CREATE(dalloc(&c->d_estl, T * B * (size_t)c->cms_depth));
+    CHK_CREATE(dalloc(&c->d_segsum, T * cms_binorder_entries(c->cms_depth, c->cms_width)));
+    CHK_CREATE(dalloc(&c->d_cbase, T * cms_binorder_entries(c->cms_depth, c->cms_width)));
     CHK_CREATE(dalloc(&c->d_basearr, T * (size_t)c->cms_depth * c->cms_width));
     CHK_CREATE(dalloc(&c->d_f64, T * B));
     CHK_CREATE(dalloc(&c->d_rcp32, T * c->row_stride));
@@ -561,6 +584,7 @@ void hulk_destroy(hulk_ctx *c) {
     for (int i = 0; i < 2; i++) if (c->ev_flushed[i]) hipEventDestroy(c->ev_flushed[i]);
     for (auto &pr : c->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
     hipFree(c->d_state); hipFree(c->d_hist); hipFree(c->d_hist_tmp); hipFree(c->d_perm); hipFree(c->d_chain_start);
+    hipFree(c->d_meta8); hipFree(c->d_segsum); hipFree(c->d_cbase);
     hipFree(c->d_ctr); hipFree(c->d_estl); hipFree(c->d_basearr); hipFree(c->d_invperm); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
     hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd); hipFree(c->d_estd);
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);

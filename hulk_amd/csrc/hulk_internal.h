@@ -84,6 +84,11 @@ hipError_t launch_freq(hipStream_t s, uint32_t *d_hists, const uint32_t *d_estl,
                        const unsigned long long *d_basearr, const uint32_t *d_invperm,
                        const uint16_t *d_pos16, double *d_f64, float *d_rcp32, int depth, int width,
                        size_t row_stride, DevState *st, const FlushBatch &fb);
+hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
+                               unsigned long long *d_ctr, uint32_t *d_segsum, unsigned long long *d_base,
+                               double *d_f64, float *d_rcp32, int depth, int width, size_t row_stride,
+                               DevState *st, const FlushBatch &fb);
+size_t cms_binorder_entries(int depth, int width);   // entries of segsum / base per spectrum
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb);
 hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,

@@ -1011,6 +1011,152 @@ __global__ __launch_bounds__(256) void k_freq(uint32_t *__restrict__ hists,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K3 (no decay), bin-order form.  The chain-order kernels above gather 4-byte values along chains
+// whose bins are ~2000 apart: rocprofv3 showed 13x more HBM traffic than the algorithmic bytes.
+// Here every array is read in BIN order (coalesced) and the 7 x 2000 running counters live in LDS:
+//   k_cms_segsum : per (spectrum, row, bin segment) sums per counter            (LDS atomics)
+//   k_cms_base   : counter value in front of every (spectrum, segment)          (tiny prefix kernel)
+//   k_cms_freq   : one workgroup per (segment, spectrum): waves 0..6 replay their row in bin order —
+//                  est = ctr[pos] + (own + earlier same-counter bins of the 64-bin chunk, followed
+//                  through a static "previous lane with the same counter" table) — wave 7 takes the
+//                  minimum over the rows, writes f / 1/f and wipes the spectrum.  No est arrays at all.
+// ------------------------------------------------------------------------------------------
+constexpr int CMS_SEGS = 16;          // bin segments per spectrum
+constexpr int CMS_GROUP = 4;          // 64-bin chunks staged per barrier
+
+__global__ __launch_bounds__(512) void k_cms_segsum(const uint32_t *__restrict__ hists,
+                                                    const uint16_t *__restrict__ pos16,
+                                                    uint32_t *__restrict__ segsum, int depth, int width,
+                                                    int seg_chunks, const DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *lctr = (uint32_t *)smem;                           // [depth][width]
+    const int seg = blockIdx.x, t = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;  // wave d = row d (depth waves + 1 idle)
+    const uint32_t gomask = batch_gomask(st, fb);
+    if (!((gomask >> t) & 1u)) return;
+    for (int i = tid; i < depth * width; i += blockDim.x) lctr[i] = 0;
+    __syncthreads();
+    const size_t B = (size_t)fb.num_bins;
+    const uint32_t *hist = hists + (size_t)ring_slot(fb, t) * B;
+    if (d < depth) {
+        const uint16_t *pd = pos16 + (size_t)d * B;
+        const int64_t b0 = (int64_t)seg * seg_chunks * 64;
+        for (int c = 0; c < seg_chunks; c++) {
+            const int64_t b = b0 + (int64_t)c * 64 + lane;
+            if (b < (int64_t)B) { const uint32_t h = hist[b]; if (h) atomicAdd(&lctr[d * width + pd[b]], h); }
+        }
+    }
+    __syncthreads();
+    uint32_t *out = segsum + (((size_t)t * depth) * CMS_SEGS + 0) * width;
+    for (int i = tid; i < depth * width; i += blockDim.x) {
+        const int dd = i / width, p = i - dd * width;
+        out[((size_t)dd * CMS_SEGS + seg) * width + p] = lctr[i];
+    }
+}
+
+// base[t][d][seg][p] = counter (d,p) in front of segment seg of spectrum t; advances the persistent counters
+__global__ __launch_bounds__(256) void k_cms_base(const uint32_t *__restrict__ segsum,
+                                                  unsigned long long *__restrict__ ctr,
+                                                  unsigned long long *__restrict__ base, int depth, int width,
+                                                  const DevState *st, FlushBatch fb) {
+    const uint32_t gomask = batch_gomask(st, fb);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= depth * width) return;
+    const int d = i / width, p = i - d * width;
+    unsigned long long run = ctr[i];
+    for (int t = 0; t < (int)fb.count; t++) {
+        if (!((gomask >> t) & 1u)) continue;
+        for (int seg = 0; seg < CMS_SEGS; seg++) {
+            const size_t at = ((((size_t)t * depth + d) * CMS_SEGS) + seg) * width + p;
+            base[at] = run;
+            run += segsum[at];
+        }
+    }
+    ctr[i] = run;
+}
+
+__global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
+                                                  const uint8_t *__restrict__ meta8,
+                                                  const unsigned long long *__restrict__ base,
+                                                  double *__restrict__ f64, float *__restrict__ rcp32,
+                                                  int depth, int width, int seg_chunks, size_t row_stride,
+                                                  DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long *lctr = (unsigned long long *)smem;                       // [depth][width]
+    unsigned long long *stage = lctr + (size_t)depth * width;                    // [2][depth][CMS_GROUP*64]
+    const int seg = blockIdx.x, t = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;                  // waves 0..depth-1: rows; wave depth: combiner
+    const uint32_t gomask = batch_gomask(st, fb);
+    const bool go = (gomask >> t) & 1u;
+    const uint32_t slot = ring_slot(fb, t);
+    if (seg == 0 && tid == 0) {
+        const unsigned used = st->used[fb.parity][slot];
+        if (used != 0 && !go) set_error(st, -5);                                 // "not used yet" (kmerspectrum.go:94-96)
+        if (go) atomicAdd(&st->n_elements, (unsigned long long)used);
+    }
+    if (!go) return;
+    const size_t B = (size_t)fb.num_bins;
+    {
+        const unsigned long long *bt = base + (((size_t)t * depth) * CMS_SEGS) * width;
+        for (int i = tid; i < depth * width; i += blockDim.x) {
+            const int dd = i / width, p = i - dd * width;
+            lctr[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];
+        }
+    }
+    __syncthreads();
+    uint32_t *hist = hists + (size_t)slot * B;
+    double *ft = f64 + (size_t)t * B;
+    float *rt = rcp32 + (size_t)t * row_stride;
+    const int64_t b0 = (int64_t)seg * seg_chunks * 64;
+    const int ngroups = (seg_chunks + CMS_GROUP - 1) / CMS_GROUP;
+    constexpr int GB = CMS_GROUP * 64;
+    for (int g = 0; g <= ngroups; g++) {
+        // rows: stage group g        combiner: finish group g-1
+        if (d < depth && g < ngroups) {
+            unsigned long long *my = stage + ((size_t)(g & 1) * depth + d) * GB;
+            const uint16_t *pd = pos16 + (size_t)d * B;
+            const uint8_t *md = meta8 + (size_t)d * B;
+            unsigned long long *rc = lctr + (size_t)d * width;
+            for (int c = 0; c < CMS_GROUP; c++) {
+                const int ch = g * CMS_GROUP + c;
+                if (ch >= seg_chunks) break;
+                const int64_t b = b0 + (int64_t)ch * 64 + lane;
+                uint32_t h = 0, p = 0, m = 64u | 0x80u;
+                if (b < (int64_t)B) { h = hist[b]; p = pd[b]; m = md[b]; }
+                // own count + the counts of the earlier lanes of this chunk that share the counter
+                uint32_t acc = h, cur = m & 0x7fu;
+                while (__any((int)(cur < 64u))) {
+                    const uint32_t oh = (uint32_t)__shfl((int)h, (int)(cur & 63u));
+                    const uint32_t oc = (uint32_t)__shfl((int)m, (int)(cur & 63u)) & 0x7fu;
+                    if (cur < 64u) { acc += oh; cur = oc; }
+                }
+                const unsigned long long est = rc[p] + acc;          // every lane reads before any lane writes
+                my[c * 64 + lane] = est;
+                if ((m & 0x80u) && b < (int64_t)B) rc[p] = est;      // last lane of the chunk for this counter
+            }
+        }
+        if (d == depth && g > 0) {
+            const unsigned long long *src = stage + ((size_t)((g - 1) & 1) * depth) * GB;
+            for (int c = 0; c < CMS_GROUP; c++) {
+                const int ch = (g - 1) * CMS_GROUP + c;
+                if (ch >= seg_chunks) break;
+                const int64_t b = b0 + (int64_t)ch * 64 + lane;
+                if (b < (int64_t)B) {
+                    if (hist[b]) {
+                        unsigned long long mn = ~0ull;
+                        for (int dd = 0; dd < depth; dd++) { const unsigned long long e = src[(size_t)dd * GB + c * 64 + lane]; mn = e < mn ? e : mn; }
+                        const double f = (double)mn;
+                        ft[b] = f; rt[b] = (float)(1.0 / f);
+                        hist[b] = 0;                                 // Wipe (kmerspectrum.go:58-64)
+                    } else { ft[b] = 0.0; rt[b] = __builtin_nanf(""); }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Wave-wide minimum of 8 independent (non-NaN) values with DPP-modified v_min_f32: 6 instructions per
 // value, no LDS traffic; lane 63 ends with the wave minimum.  Written as ONE asm block with the 8
 // values interleaved per step so that no DPP source was written by the two preceding instructions
@@ -1714,6 +1860,29 @@ hipError_t launch_freq(hipStream_t s, uint32_t *d_hists, const uint32_t *d_estl,
                        d_invperm, d_pos16, d_f64, d_rcp32, depth, width, row_stride, st, fb);
     return hipGetLastError();
 }
+
+hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
+                               unsigned long long *d_ctr, uint32_t *d_segsum, unsigned long long *d_base,
+                               double *d_f64, float *d_rcp32, int depth, int width, size_t row_stride,
+                               DevState *st, const FlushBatch &fb) {
+    const int chunks = (fb.num_bins + 63) / 64;
+    const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
+    const size_t lds1 = (size_t)depth * width * 4;
+    const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * depth * CMS_GROUP * 64 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_cms_freq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_cms_segsum, dim3(CMS_SEGS, fb.count), dim3(512), lds1, s, d_hists, d_pos16, d_segsum, depth, width,
+                       seg_chunks, st, fb);
+    hipLaunchKernelGGL(k_cms_base, dim3((depth * width + 255) / 256), dim3(256), 0, s, d_segsum, d_ctr, d_base, depth, width, st, fb);
+    hipLaunchKernelGGL(k_cms_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_meta8, d_base, d_f64,
+                       d_rcp32, depth, width, seg_chunks, row_stride, st, fb);
+    return hipGetLastError();
+}
+size_t cms_binorder_entries(int depth, int width) { return (size_t)depth * CMS_SEGS * width; }
 
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb) {
