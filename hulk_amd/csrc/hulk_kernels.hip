@@ -1042,9 +1042,16 @@ __global__ __launch_bounds__(512) void k_cms_segsum(const uint32_t *__restrict__
     if (d < depth) {
         const uint16_t *pd = pos16 + (size_t)d * B;
         const int64_t b0 = (int64_t)seg * seg_chunks * 64;
-        for (int c = 0; c < seg_chunks; c++) {
-            const int64_t b = b0 + (int64_t)c * 64 + lane;
-            if (b < (int64_t)B) { const uint32_t h = hist[b]; if (h) atomicAdd(&lctr[d * width + pd[b]], h); }
+        for (int c0 = 0; c0 < seg_chunks; c0 += 8) {              // 8 chunks of loads in flight
+            uint32_t h[8]; uint32_t p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int64_t b = b0 + (int64_t)(c0 + u) * 64 + lane;
+                const bool ok = (c0 + u < seg_chunks) && b < (int64_t)B;
+                h[u] = ok ? hist[b] : 0u; p[u] = ok ? pd[b] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (h[u]) atomicAdd(&lctr[d * width + p[u]], h[u]);
         }
     }
     __syncthreads();
@@ -1067,11 +1074,12 @@ __global__ __launch_bounds__(256) void k_cms_base(const uint32_t *__restrict__ s
     unsigned long long run = ctr[i];
     for (int t = 0; t < (int)fb.count; t++) {
         if (!((gomask >> t) & 1u)) continue;
-        for (int seg = 0; seg < CMS_SEGS; seg++) {
-            const size_t at = ((((size_t)t * depth + d) * CMS_SEGS) + seg) * width + p;
-            base[at] = run;
-            run += segsum[at];
-        }
+        uint32_t sv[CMS_SEGS];
+        const size_t at0 = (((size_t)t * depth + d) * CMS_SEGS) * width + p;
+#pragma unroll
+        for (int seg = 0; seg < CMS_SEGS; seg++) sv[seg] = segsum[at0 + (size_t)seg * width];   // independent loads
+#pragma unroll
+        for (int seg = 0; seg < CMS_SEGS; seg++) { base[at0 + (size_t)seg * width] = run; run += sv[seg]; }
     }
     ctr[i] = run;
 }
@@ -1111,19 +1119,39 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
     const int64_t b0 = (int64_t)seg * seg_chunks * 64;
     const int ngroups = (seg_chunks + CMS_GROUP - 1) / CMS_GROUP;
     constexpr int GB = CMS_GROUP * 64;
+    // software pipeline: the loads of group g+1 are issued before group g is processed
+    const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
+    const uint8_t *md = meta8 + (size_t)(d < depth ? d : 0) * B;
+    uint32_t nh[CMS_GROUP], np_[CMS_GROUP], nm[CMS_GROUP];
+    auto load_group = [&](int g) {
+#pragma unroll
+        for (int c = 0; c < CMS_GROUP; c++) {
+            const int ch = g * CMS_GROUP + c;
+            const int64_t b = b0 + (int64_t)ch * 64 + lane;
+            const bool ok = g < ngroups && ch < seg_chunks && b < (int64_t)B;
+            nh[c] = ok ? hist[b] : 0u;
+            if (d < depth) { np_[c] = ok ? pd[b] : 0u; nm[c] = ok ? md[b] : (64u | 0x80u); }
+        }
+    };
+    load_group(0);
+    uint32_t ph[CMS_GROUP];                                      // combiner: spectrum values of the group it finishes next
+#pragma unroll
+    for (int c = 0; c < CMS_GROUP; c++) ph[c] = 0;
     for (int g = 0; g <= ngroups; g++) {
         // rows: stage group g        combiner: finish group g-1
+        uint32_t hh[CMS_GROUP], pp[CMS_GROUP], mm[CMS_GROUP];
+#pragma unroll
+        for (int c = 0; c < CMS_GROUP; c++) { hh[c] = nh[c]; pp[c] = np_[c]; mm[c] = nm[c]; }
+        load_group(g + 1);
         if (d < depth && g < ngroups) {
             unsigned long long *my = stage + ((size_t)(g & 1) * depth + d) * GB;
-            const uint16_t *pd = pos16 + (size_t)d * B;
-            const uint8_t *md = meta8 + (size_t)d * B;
             unsigned long long *rc = lctr + (size_t)d * width;
+#pragma unroll
             for (int c = 0; c < CMS_GROUP; c++) {
                 const int ch = g * CMS_GROUP + c;
                 if (ch >= seg_chunks) break;
                 const int64_t b = b0 + (int64_t)ch * 64 + lane;
-                uint32_t h = 0, p = 0, m = 64u | 0x80u;
-                if (b < (int64_t)B) { h = hist[b]; p = pd[b]; m = md[b]; }
+                const uint32_t h = hh[c], p = pp[c], m = mm[c];
                 // own count + the counts of the earlier lanes of this chunk that share the counter
                 uint32_t acc = h, cur = m & 0x7fu;
                 while (__any((int)(cur < 64u))) {
@@ -1138,12 +1166,13 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
         }
         if (d == depth && g > 0) {
             const unsigned long long *src = stage + ((size_t)((g - 1) & 1) * depth) * GB;
+#pragma unroll
             for (int c = 0; c < CMS_GROUP; c++) {
                 const int ch = (g - 1) * CMS_GROUP + c;
                 if (ch >= seg_chunks) break;
                 const int64_t b = b0 + (int64_t)ch * 64 + lane;
                 if (b < (int64_t)B) {
-                    if (hist[b]) {
+                    if (ph[c]) {
                         unsigned long long mn = ~0ull;
                         for (int dd = 0; dd < depth; dd++) { const unsigned long long e = src[(size_t)dd * GB + c * 64 + lane]; mn = e < mn ? e : mn; }
                         const double f = (double)mn;
@@ -1153,6 +1182,8 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
                 }
             }
         }
+#pragma unroll
+        for (int c = 0; c < CMS_GROUP; c++) ph[c] = hh[c];          // group g is finished by the combiner at g+1
         __syncthreads();
     }
 }
