@@ -89,6 +89,7 @@ struct hulk_ctx {
     unsigned long long *d_ctr = nullptr, *d_basearr = nullptr, *d_mins = nullptr, *d_min_slots = nullptr;
     uint32_t *d_estl = nullptr, *d_invperm = nullptr; uint16_t *d_pos16 = nullptr;
     uint8_t *d_meta8 = nullptr; uint32_t *d_segsum = nullptr; unsigned long long *d_cbase = nullptr;   // bin-order count-min
+    double *d_segadd = nullptr, *d_segfac = nullptr, *d_cstart = nullptr; uint32_t *d_sege0 = nullptr; // ... with decay
     double *d_f64 = nullptr, *d_weights = nullptr, *d_rcb = nullptr;
     float *d_rcp32 = nullptr, *d_k32 = nullptr, *d_tilemin = nullptr;
     double *d_candA = nullptr; int32_t *d_candB = nullptr;
@@ -416,10 +417,17 @@ int flush_batch(hulk_ctx *c, uint32_t count) {
     HIPCHK(c, launch_count_used(s, hist, c->d_state, fb));
     if (c->scaling) {
         HIPCHK(c, launch_elem_index(s, hist, c->d_blkcnt, c->d_eidx, c->d_etot, fb));
-        HIPCHK(c, launch_cms_chains_decay(s, hist, c->d_perm, c->d_chain_start, c->d_eidx, c->d_etot, c->d_ctrd,
-                                          c->d_estd, c->cms_depth, c->cms_width, c->decay_weight, c->d_state, fb));
-        HIPCHK(c, launch_freq_decay(s, hist, c->d_estd, c->d_invperm, c->d_f64, c->d_rcp32, c->cms_depth,
-                                    c->row_stride, c->d_state, fb));
+        static const bool chain_order_d = getenv("HULK_CMS_CHAINS") != nullptr;
+        if (chain_order_d) {
+            HIPCHK(c, launch_cms_chains_decay(s, hist, c->d_perm, c->d_chain_start, c->d_eidx, c->d_etot, c->d_ctrd,
+                                              c->d_estd, c->cms_depth, c->cms_width, c->decay_weight, c->d_state, fb));
+            HIPCHK(c, launch_freq_decay(s, hist, c->d_estd, c->d_invperm, c->d_f64, c->d_rcp32, c->cms_depth,
+                                        c->row_stride, c->d_state, fb));
+        } else {
+            HIPCHK(c, launch_cmsd_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_eidx, c->d_etot, c->d_ctrd, c->d_segadd,
+                                           c->d_segfac, c->d_sege0, c->d_cstart, c->d_f64, c->d_rcp32, c->cms_depth,
+                                           c->cms_width, c->row_stride, c->decay_weight, c->d_state, fb));
+        }
     } else {
         static const bool chain_order = getenv("HULK_CMS_CHAINS") != nullptr;   // the earlier chain-order kernels (A/B aid)
         if (chain_order) {
@@ -554,6 +562,10 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
         CHK_CREATE(dalloc(&c->d_etot, T));
         CHK_CREATE(dalloc(&c->d_ctrd, NC));
         CHK_CREATE(dalloc(&c->d_estd, T * B * (size_t)c->cms_depth));
+        CHK_CREATE(dalloc(&c->d_segadd, T * cms_binorder_entries(c->cms_depth, c->cms_width)));
+        CHK_CREATE(dalloc(&c->d_cstart, T * cms_binorder_entries(c->cms_depth, c->cms_width)));
+        CHK_CREATE(dalloc(&c->d_segfac, T * 64));
+        CHK_CREATE(dalloc(&c->d_sege0, T * 64));
         CHK_CREATE(hipMemsetAsync(c->d_ctrd, 0, NC * 8, c->stream));
     }
     CHK_CREATE(dalloc(&c->d_candA, T * SL));
@@ -585,6 +597,7 @@ void hulk_destroy(hulk_ctx *c) {
     for (auto &pr : c->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
     hipFree(c->d_state); hipFree(c->d_hist); hipFree(c->d_hist_tmp); hipFree(c->d_perm); hipFree(c->d_chain_start);
     hipFree(c->d_meta8); hipFree(c->d_segsum); hipFree(c->d_cbase);
+    hipFree(c->d_segadd); hipFree(c->d_segfac); hipFree(c->d_cstart); hipFree(c->d_sege0);
     hipFree(c->d_ctr); hipFree(c->d_estl); hipFree(c->d_basearr); hipFree(c->d_invperm); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
     hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd); hipFree(c->d_estd);
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);

@@ -1202,6 +1202,169 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K3 with uniform scaling (0 < decay < 1), bin-order form.  Counter (d,p) right after stream element j
+// is C(j) = w*C(j-1) + (v_j if element j hits it).  Over a bin segment holding elements [e0,e1):
+//     C(e1-1) = w^(e1-e0) * C(e0-1) + sum{ v_j * w^(e1-1-j) : hits }
+//   k_cmsd_segsum : the sum (one w^x per element, LDS fp64 atomics) and the factor per segment
+//   k_cmsd_base   : C in front of every (spectrum, segment), advancing the persistent fp64 counters
+//   k_cmsd_freq   : replay in bin order with lazily decayed LDS counters {value, time}; zero bins are
+//                   transparent; same-counter lanes of a 64-bin chunk resolve in lane order
+// (fp64 sums are re-associated w.r.t. the reference's step-by-step scaling: ~1e-13 relative)
+// ------------------------------------------------------------------------------------------
+constexpr int CMSD_GROUP = 2;         // chunks staged per barrier (LDS: 112 KB values + 28 KB times + 14 KB stage)
+
+__global__ __launch_bounds__(512) void k_cmsd_segsum(const uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
+                                                     const uint32_t *__restrict__ eidx, const uint32_t *__restrict__ etot,
+                                                     double *__restrict__ segadd, double *__restrict__ segfac,
+                                                     uint32_t *__restrict__ sege0, int depth, int width, int seg_chunks,
+                                                     double omega, const DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *ladd = (double *)smem;                                // [depth][width]
+    const int seg = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const uint32_t gomask = batch_gomask(st, fb);
+    if (!((gomask >> t) & 1u)) return;
+    for (int i = tid; i < depth * width; i += blockDim.x) ladd[i] = 0.0;
+    __syncthreads();
+    const size_t B = (size_t)fb.num_bins;
+    const uint32_t *hist = hists + (size_t)ring_slot(fb, t) * B;
+    const uint32_t *ei = eidx + (size_t)t * B;
+    const int64_t b0 = (int64_t)seg * seg_chunks * 64, b1 = b0 + (int64_t)seg_chunks * 64;
+    const uint32_t e0 = b0 < (int64_t)B ? ei[b0] : etot[t];
+    const uint32_t e1 = b1 < (int64_t)B ? ei[b1] : etot[t];
+    const double lnw = log(omega);                                // w^x = exp(x ln w): |x ln w| * 2^-53 relative, far below the tolerance
+    if (tid == 0) { segfac[(size_t)t * CMS_SEGS + seg] = exp((double)(e1 - e0) * lnw); sege0[(size_t)t * CMS_SEGS + seg] = e0; }
+    for (int64_t b = b0 + tid; b < b1 && b < (int64_t)B; b += blockDim.x) {
+        const uint32_t h = hist[b];
+        if (h) {
+            const double wgt = (double)h * exp((double)(e1 - 1u - ei[b]) * lnw);
+            for (int d = 0; d < depth; d++) atomicAdd(&ladd[d * width + pos16[(size_t)d * B + b]], wgt);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < depth * width; i += blockDim.x) {
+        const int dd = i / width, p = i - dd * width;
+        segadd[((((size_t)t * depth) + dd) * CMS_SEGS + seg) * width + p] = ladd[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cmsd_base(const double *__restrict__ segadd, const double *__restrict__ segfac,
+                                                   double *__restrict__ ctrd, double *__restrict__ cstart, int depth,
+                                                   int width, const DevState *st, FlushBatch fb) {
+    const uint32_t gomask = batch_gomask(st, fb);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= depth * width) return;
+    const int d = i / width, p = i - d * width;
+    double C = ctrd[i];
+    for (int t = 0; t < (int)fb.count; t++) {
+        if (!((gomask >> t) & 1u)) continue;
+        double sv[CMS_SEGS], fv[CMS_SEGS];
+        const size_t at0 = (((size_t)t * depth + d) * CMS_SEGS) * width + p;
+#pragma unroll
+        for (int seg = 0; seg < CMS_SEGS; seg++) { sv[seg] = segadd[at0 + (size_t)seg * width]; fv[seg] = segfac[(size_t)t * CMS_SEGS + seg]; }
+#pragma unroll
+        for (int seg = 0; seg < CMS_SEGS; seg++) { cstart[at0 + (size_t)seg * width] = C; C = C * fv[seg] + sv[seg]; }
+    }
+    ctrd[i] = C;
+}
+
+__global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
+                                                   const uint8_t *__restrict__ meta8, const uint32_t *__restrict__ eidx,
+                                                   const uint32_t *__restrict__ sege0, const double *__restrict__ cstart,
+                                                   double *__restrict__ f64, float *__restrict__ rcp32, int depth,
+                                                   int width, int seg_chunks, size_t row_stride, double omega,
+                                                   DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *lval = (double *)smem;                                               // [depth][width] counter value ...
+    double *stage = lval + (size_t)depth * width;                                // [2][depth][CMSD_GROUP*64]
+    uint16_t *ltime = (uint16_t *)(stage + (size_t)2 * depth * CMSD_GROUP * 64); // ... as of element e0 - 1 + ltime
+    const int seg = blockIdx.x, t = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;
+    const uint32_t gomask = batch_gomask(st, fb);
+    const bool go = (gomask >> t) & 1u;
+    const uint32_t slot = ring_slot(fb, t);
+    if (seg == 0 && tid == 0) {
+        const unsigned used = st->used[fb.parity][slot];
+        if (used != 0 && !go) set_error(st, -5);
+        if (go) atomicAdd(&st->n_elements, (unsigned long long)used);
+    }
+    if (!go) return;
+    const size_t B = (size_t)fb.num_bins;
+    {
+        const double *bt = cstart + (((size_t)t * depth) * CMS_SEGS) * width;
+        for (int i = tid; i < depth * width; i += blockDim.x) {
+            const int dd = i / width, p = i - dd * width;
+            lval[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];
+            ltime[i] = 0;
+        }
+    }
+    __syncthreads();
+    uint32_t *hist = hists + (size_t)slot * B;
+    const uint32_t *ei = eidx + (size_t)t * B;
+    double *ft = f64 + (size_t)t * B;
+    float *rt = rcp32 + (size_t)t * row_stride;
+    const int64_t b0 = (int64_t)seg * seg_chunks * 64;
+    const long long tref = (long long)sege0[(size_t)t * CMS_SEGS + seg] - 1;     // time of ltime == 0
+    const int ngroups = (seg_chunks + CMSD_GROUP - 1) / CMSD_GROUP;
+    constexpr int GB = CMSD_GROUP * 64;
+    const double lnw = log(omega);
+    __shared__ double pw[64];                                     // w^x for the gaps inside one 64-bin chunk
+    if (tid < 64) pw[tid] = exp((double)tid * lnw);
+    __syncthreads();
+    const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
+    const uint8_t *md = meta8 + (size_t)(d < depth ? d : 0) * B;
+    for (int g = 0; g <= ngroups; g++) {
+        if (d < depth && g < ngroups) {
+            double *my = stage + ((size_t)(g & 1) * depth + d) * GB;
+            double *rv = lval + (size_t)d * width;
+            uint16_t *rtm = ltime + (size_t)d * width;
+            for (int c = 0; c < CMSD_GROUP; c++) {
+                const int ch = g * CMSD_GROUP + c;
+                if (ch >= seg_chunks) break;
+                const int64_t b = b0 + (int64_t)ch * 64 + lane;
+                uint32_t h = 0, p = 0, m = 64u | 0x80u; long long j = 0;
+                if (b < (int64_t)B) { h = hist[b]; p = pd[b]; m = md[b]; j = (long long)ei[b]; }
+                // resolve the lanes in same-counter order: a lane is computed once its predecessor is
+                const uint32_t prev = m & 0x7fu;
+                bool ready = false; double C = 0.0; long long tj = 0;
+                if (prev >= 64u) {                                  // first lane of the chunk on this counter: LDS state
+                    const double C0 = rv[p]; const long long t0 = tref + (long long)rtm[p];
+                    if (h) { C = C0 * exp((double)(j - t0) * lnw) + (double)h; tj = j; } else { C = C0; tj = t0; }
+                    ready = true;
+                }
+                while (__any((int)!ready)) {
+                    const double pc = __shfl(C, (int)(prev & 63u));
+                    const long long pt = __shfl(tj, (int)(prev & 63u));
+                    const int pr = __shfl((int)ready, (int)(prev & 63u));
+                    if (!ready && pr) {
+                        if (h) { C = pc * pw[(int)(j - pt) & 63] + (double)h; tj = j; } else { C = pc; tj = pt; }   // gap < 64 inside a chunk
+                        ready = true;
+                    }
+                }
+                my[c * 64 + lane] = C;
+                if ((m & 0x80u) && b < (int64_t)B) { rv[p] = C; rtm[p] = (uint16_t)(tj - tref); }
+            }
+        }
+        if (d == depth && g > 0) {
+            const double *src = stage + ((size_t)((g - 1) & 1) * depth) * GB;
+            for (int c = 0; c < CMSD_GROUP; c++) {
+                const int ch = (g - 1) * CMSD_GROUP + c;
+                if (ch >= seg_chunks) break;
+                const int64_t b = b0 + (int64_t)ch * 64 + lane;
+                if (b < (int64_t)B) {
+                    if (hist[b]) {
+                        double mn = INFINITY;
+                        for (int dd = 0; dd < depth; dd++) { const double e = src[(size_t)dd * GB + c * 64 + lane]; mn = e < mn ? e : mn; }
+                        ft[b] = mn; rt[b] = (float)(1.0 / mn);
+                        hist[b] = 0;
+                    } else { ft[b] = 0.0; rt[b] = __builtin_nanf(""); }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Wave-wide minimum of 8 independent (non-NaN) values with DPP-modified v_min_f32: 6 instructions per
 // value, no LDS traffic; lane 63 ends with the wave minimum.  Written as ONE asm block with the 8
 // values interleaved per step so that no DPP source was written by the two preceding instructions
@@ -1928,6 +2091,30 @@ hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t 
     return hipGetLastError();
 }
 size_t cms_binorder_entries(int depth, int width) { return (size_t)depth * CMS_SEGS * width; }
+
+hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
+                                const uint32_t *d_eidx, const uint32_t *d_etot, double *d_ctrd, double *d_segadd,
+                                double *d_segfac, uint32_t *d_sege0, double *d_cstart, double *d_f64, float *d_rcp32,
+                                int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb) {
+    const int chunks = (fb.num_bins + 63) / 64;
+    const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
+    const size_t lds1 = (size_t)depth * width * 8;
+    const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * depth * CMSD_GROUP * 64 * 8 + (size_t)depth * width * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_cmsd_segsum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cmsd_freq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_cmsd_segsum, dim3(CMS_SEGS, fb.count), dim3(512), lds1, s, d_hists, d_pos16, d_eidx, d_etot, d_segadd,
+                       d_segfac, d_sege0, depth, width, seg_chunks, omega, st, fb);
+    hipLaunchKernelGGL(k_cmsd_base, dim3((depth * width + 255) / 256), dim3(256), 0, s, d_segadd, d_segfac, d_ctrd, d_cstart,
+                       depth, width, st, fb);
+    hipLaunchKernelGGL(k_cmsd_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_meta8, d_eidx, d_sege0,
+                       d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
+    return hipGetLastError();
+}
 
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb) {
