@@ -96,7 +96,11 @@ def main():
     sb, sc = slot_shard(S, rank, world)
 
     os.environ["HULK_BATCH"] = str(BATCH)
-    stream = torch.cuda.current_stream()
+    # work stream (minimizer kernels) and, for N > 1, a second stream for the collective: the all-reduce
+    # of step n and the flush behind it run under the minimizer kernels of step n+1
+    stream = torch.cuda.Stream(device=device)
+    coll_stream = torch.cuda.Stream(device=device) if use_dist else None
+    torch.cuda.set_stream(stream)
     sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=local_rank,
                               slot_begin=sb, slot_count=sc, stream=stream.cuda_stream)
     assert sk.batch_size == BATCH
@@ -124,8 +128,13 @@ def main():
         sk.bin_reads_device(b.data_ptr(), offsets.data_ptr(), reads_per_rank_step, READ_LEN, b.numel(),
                             reads_per_spectrum=INTERVAL)
         if use_dist:
-            dist.all_reduce(eng.histogram_tensor(), op=dist.ReduceOp.SUM)
-        sk.flush_batch(BATCH)
+            h = eng.histogram_tensor()                 # view of the ring the reads were just binned into
+            coll_stream.wait_stream(stream)
+            with torch.cuda.stream(coll_stream):
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            sk.flush_batch(BATCH, after_stream=coll_stream.cuda_stream)
+        else:
+            sk.flush_batch(BATCH)
 
     for t in range(warmup):
         one_step(t)

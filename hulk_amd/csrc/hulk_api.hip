@@ -398,7 +398,7 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
 }
 
 // Flush `count` consecutive spectra of the ring (starting at ring_base) through count-min + CWS.
-int flush_batch(hulk_ctx *c, uint32_t count) {
+int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, bool use_dep = false) {
     if (count == 0) return HULK_OK;
     int rc = ensure_tables(c);
     if (rc != HULK_OK) return rc;
@@ -409,7 +409,10 @@ int flush_batch(hulk_ctx *c, uint32_t count) {
     // stream waits for it, then runs on its own
     static const bool no_overlap = getenv("HULK_NO_OVERLAP") != nullptr;   // profiling aid: one stream, kernels back to back
     hipStream_t s = no_overlap ? c->stream : c->flush_stream;
-    if (!no_overlap) {
+    if (use_dep) {            // e.g. the stream the caller's all-reduce of the spectra was issued on
+        HIPCHK(c, hipEventRecord(c->ev_binned, dep_stream));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
+    } else if (!no_overlap) {
         HIPCHK(c, hipEventRecord(c->ev_binned, c->stream));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
     }
@@ -678,6 +681,15 @@ int hulk_flush_batch(hulk_ctx *c, uint32_t count) {
     if (count > c->T || c->ring_base != 0) return fail(c, HULK_ERR_ARG, "batch count");
     int rc = flush_batch(c, count);
     if (rc == HULK_OK && count) c->cur_ring ^= 1;      // the next batch is binned into the other ring meanwhile
+    return rc;
+}
+
+int hulk_flush_batch_after(hulk_ctx *c, uint32_t count, void *dep_stream) {
+    if (!c) return HULK_ERR_ARG;
+    if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
+    if (count > c->T || c->ring_base != 0) return fail(c, HULK_ERR_ARG, "batch count");
+    int rc = flush_batch(c, count, (hipStream_t)dep_stream, true);
+    if (rc == HULK_OK && count) c->cur_ring ^= 1;
     return rc;
 }
 

@@ -113,8 +113,13 @@ class GpuSketcher:
         self._chk(self._L.hulk_bin_reads_device(self._ctx, bases_ptr, offsets_ptr, n_reads,
                                                 max_read_len, bases_bytes, reads_per_spectrum))
 
-    def flush_batch(self, n_spectra):
-        self._chk(self._L.hulk_flush_batch(self._ctx, n_spectra))
+    def flush_batch(self, n_spectra, after_stream=None):
+        """Flush n_spectra spectra; with after_stream (a hipStream_t handle) the flush waits for that
+        stream (the collective's) instead of the work stream."""
+        if after_stream is None:
+            self._chk(self._L.hulk_flush_batch(self._ctx, n_spectra))
+        else:
+            self._chk(self._L.hulk_flush_batch_after(self._ctx, n_spectra, ctypes.c_void_p(after_stream)))
 
     @property
     def batch_size(self):

@@ -127,6 +127,11 @@ int hulk_bin_reads_device(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t 
                           uint64_t reads_per_spectrum);
 uint32_t *hulk_histogram_device(hulk_ctx *ctx);
 int hulk_flush_batch(hulk_ctx *ctx, uint32_t n_spectra);
+/* Same, but the flush waits for the work queued so far on `dep_stream` (the stream the all-reduce
+ * was issued on) instead of the context's work stream, so the next hulk_bin_reads_device on the
+ * work stream runs UNDER the collective.  The caller must have made dep_stream wait for the binning
+ * (event / wait_stream) before the collective. */
+int hulk_flush_batch_after(hulk_ctx *ctx, uint32_t n_spectra, void *dep_stream);
 
 /* Test hook: add counts to the current k-mer spectrum directly (host uint32[num_bins]). */
 int hulk_add_histogram(hulk_ctx *ctx, const uint32_t *bins);
