@@ -593,6 +593,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
 
 void hulk_destroy(hulk_ctx *c) {
     if (!c) return;
+    if (c->stream) hipStreamSynchronize(c->stream);       // the caller's stream may still run our kernels
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     if (c->flush_stream) { hipStreamSynchronize(c->flush_stream); hipStreamDestroy(c->flush_stream); }
     if (c->ev_binned) hipEventDestroy(c->ev_binned);
