@@ -143,9 +143,31 @@ def main(argv=None):
     sk.add_argument("-x", "--decayRatio", type=float, default=1.0)
     sk.add_argument("-b", "--bannerLabel", default="blank")
     sk.add_argument("--device", type=int, default=0)
+    sm = sub.add_parser("smash", help="Smash a bunch of sketches and return a similarity matrix")
+    sm.add_argument("-k", "--kmerSize", type=int, default=21)
+    sm.add_argument("-o", "--outFile", default="./hulk-" + time.strftime("%Y%m%d%H%M%S"))
+    sm.add_argument("-p", "--processors", type=int, default=1)
+    sm.add_argument("-d", "--sketchDir", default="./")
+    sm.add_argument("--recursive", action="store_true")
+    sm.add_argument("-a", "--algorithm", default="histosketch")
+    sm.add_argument("-m", "--metric", default="jaccard")
+    sm.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
-    a.fastq = [f for grp in a.fastq for f in grp if f]
     try:
+        if a.cmd == "smash":
+            from .smash import smash
+            log(f"this is hulk (version {VERSION})")
+            log("starting the smash subcommand")
+            log("checking parameters and collecting sketches...")
+            log(f"\talgorithm: {a.algorithm}")
+            log(f"\tk-mer size: {a.kmerSize}")
+            order, _ = smash(a.sketchDir, a.outFile, a.kmerSize, a.algorithm, a.metric, a.recursive, a.device)
+            log(f"\tnumber of sketch objects: {len(order)}")
+            log("HULK SMASH!")
+            log(f"\twritten similarity matrix to disk: {a.outFile}.hulk-matrix.csv")
+            log("finished")
+            return 0
+        a.fastq = [f for grp in a.fastq for f in grp if f]
         run_sketch(a)
     except HulkError as e:
         log(f"ERROR---> {e.message}")        # helpers.ErrorCheck -> log.Fatalf (helpers.go:31-35)

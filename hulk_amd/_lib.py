@@ -19,7 +19,7 @@ ABI_SYMBOLS = (
     "hulk_set_stream", "hulk_set_private_stream", "hulk_set_cws_tables", "hulk_add_reads", "hulk_add_reads_device",
     "hulk_batch_size", "hulk_bin_reads_device", "hulk_histogram_device", "hulk_flush_batch", "hulk_flush_batch_after", "hulk_add_histogram", "hulk_flush",
     "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
-    "hulk_get_cws_tables", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
+    "hulk_get_cws_tables", "hulk_smash", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
 )
 
 
@@ -77,6 +77,7 @@ def load():
     L.hulk_get_histogram.restype = ctypes.c_int; L.hulk_get_histogram.argtypes = [vp, vp]
     L.hulk_get_cms.restype = ctypes.c_int; L.hulk_get_cms.argtypes = [vp, vp]
     L.hulk_get_cws_tables.restype = ctypes.c_int; L.hulk_get_cws_tables.argtypes = [vp, vp, vp, vp]
+    L.hulk_smash.restype = ctypes.c_int; L.hulk_smash.argtypes = [ctypes.c_int, vp, vp, u32, u32, ctypes.c_int, vp]
     L.hulk_selftest_reciprocal.restype = ctypes.c_int; L.hulk_selftest_reciprocal.argtypes = [vp, vp]
     L.hulk_set_profiling.restype = ctypes.c_int; L.hulk_set_profiling.argtypes = [vp, ctypes.c_int]
     L.hulk_get_profile.restype = ctypes.c_int; L.hulk_get_profile.argtypes = [vp, ctypes.c_char_p, vp, vp]

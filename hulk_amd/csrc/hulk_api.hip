@@ -845,6 +845,29 @@ int hulk_selftest_reciprocal(hulk_ctx *c, uint64_t *mismatches) {
     return HULK_OK;
 }
 
+int hulk_smash(int device, const uint64_t *mins, const double *weights, uint32_t n_sketches, uint32_t sketch_size,
+               int metric, double *distances) {
+    if (!mins || !weights || !distances) return fail(nullptr, HULK_ERR_ARG, "NULL");
+    if (metric != HULK_METRIC_JACCARD && metric != HULK_METRIC_WEIGHTED_JACCARD) return fail(nullptr, HULK_ERR_ARG, "metric");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, HULK_ERR_NO_DEVICE);
+    if (device < 0 || device >= ndev) return fail(nullptr, HULK_ERR_ARG, "device ordinal");
+#define SM_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipFree(d_m); hipFree(d_w); hipFree(d_o); return fail_hip(nullptr, e_, #call); } } while (0)
+    unsigned long long *d_m = nullptr; double *d_w = nullptr, *d_o = nullptr;
+    const size_t NS = (size_t)n_sketches * sketch_size, NN = (size_t)n_sketches * n_sketches;
+    SM_CHK(hipSetDevice(device));
+    SM_CHK(hipMalloc((void **)&d_m, (NS ? NS : 1) * 8));
+    SM_CHK(hipMalloc((void **)&d_w, (NS ? NS : 1) * 8));
+    SM_CHK(hipMalloc((void **)&d_o, (NN ? NN : 1) * 8));
+    SM_CHK(hipMemcpy(d_m, mins, NS * 8, hipMemcpyHostToDevice));
+    SM_CHK(hipMemcpy(d_w, weights, NS * 8, hipMemcpyHostToDevice));
+    SM_CHK(launch_smash(nullptr, d_m, d_w, n_sketches, sketch_size, metric, d_o));
+    SM_CHK(hipMemcpy(distances, d_o, NN * 8, hipMemcpyDeviceToHost));
+#undef SM_CHK
+    hipFree(d_m); hipFree(d_w); hipFree(d_o);
+    return HULK_OK;
+}
+
 int hulk_set_profiling(hulk_ctx *c, int enabled) {
     if (!c) return HULK_ERR_ARG;
     c->profiling = enabled != 0;

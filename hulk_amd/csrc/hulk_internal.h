@@ -119,6 +119,8 @@ hipError_t launch_cws_chunk(hipStream_t s, const uint64_t *d_pairs, uint64_t n_a
                             uint64_t sketch_size, double ainv, double bbb, double ccc, double magic);
 hipError_t launch_cws_beta(hipStream_t s, const uint64_t *d_uraw, uint64_t first_entry, uint64_t n, double *d_rcb,
                            uint64_t num_bins, uint64_t slot_begin, uint64_t slots);
+hipError_t launch_smash(hipStream_t s, const unsigned long long *d_mins, const double *d_weights, uint32_t N, uint32_t S,
+                        int metric, double *d_out);
 hipError_t launch_build_k32(hipStream_t s, const double *d_rcb, float *d_k32, int slots,
                             int32_t num_bins, size_t row_stride);
 hipError_t launch_selftest_rcp(hipStream_t s, unsigned long long *d_mismatches);

@@ -1897,6 +1897,49 @@ __global__ __launch_bounds__(256) void k_cws_beta(const uint64_t *__restrict__ u
     }
 }
 
+// ==========================================================================================
+// hulk smash: pairwise distance matrix over N sketches of S slots.
+// distances.GetDistance "jaccard" (distances.go:19-26) and GetWJD (distances.go:44-72) with the
+// reference's quirk that BOTH weight vectors come from the subject sketch (sketchio.go:293-301).
+// Thread (s, q) accumulates over the slots IN ORDER, so the fp64 sums are bit-identical to the Go
+// loops; a 16x16 tile of pairs shares the slot chunks of its 16 subjects / 16 queries through LDS.
+// ==========================================================================================
+constexpr int SMASH_T = 16, SMASH_CH = 64;
+__global__ __launch_bounds__(256) void k_smash(const unsigned long long *__restrict__ mins,
+                                               const double *__restrict__ weights, uint32_t N, uint32_t S,
+                                               int metric, double *__restrict__ out) {
+    __shared__ unsigned long long ma[SMASH_T][SMASH_CH + 1], mb[SMASH_T][SMASH_CH + 1];
+    __shared__ double wa[SMASH_T][SMASH_CH + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;        // query, subject inside the tile
+    const uint32_t s = blockIdx.y * SMASH_T + ty, q = blockIdx.x * SMASH_T + tx;
+    double intersect = 0.0, uni = 0.0;
+    for (uint32_t c0 = 0; c0 < S; c0 += SMASH_CH) {
+        for (int i = threadIdx.x; i < SMASH_T * SMASH_CH; i += 256) {
+            const int r = i / SMASH_CH, c = i % SMASH_CH;
+            const uint32_t sa = blockIdx.y * SMASH_T + r, qb = blockIdx.x * SMASH_T + r, col = c0 + c;
+            const bool okc = col < S;
+            ma[r][c] = (okc && sa < N) ? mins[(size_t)sa * S + col] : 0ull;
+            wa[r][c] = (okc && sa < N) ? weights[(size_t)sa * S + col] : 0.0;
+            mb[r][c] = (okc && qb < N) ? mins[(size_t)qb * S + col] : 0ull;
+        }
+        __syncthreads();
+        const uint32_t lim = S - c0 < (uint32_t)SMASH_CH ? S - c0 : (uint32_t)SMASH_CH;
+        if (metric == 1) {
+            for (uint32_t c = 0; c < lim; c++) {
+                // math.Max(math.Max(w,0), math.Max(-w,0)) == |w| (NaN stays NaN); weightB == weightA
+                const double wgt = fabs(wa[ty][c]);
+                if ((double)ma[ty][c] == (double)mb[tx][c]) { intersect += wgt; uni += wgt; }
+                else uni += wgt;
+            }
+        } else {
+            for (uint32_t c = 0; c < lim; c++) if ((double)ma[ty][c] == (double)mb[tx][c]) intersect += 1.0;
+        }
+        __syncthreads();
+    }
+    if (s < N && q < N)
+        out[(size_t)s * N + q] = metric == 1 ? 1 - (intersect / uni) : 1.0 - (intersect / (double)S);
+}
+
 // K = c * exp(b - r) in fp64, rounded once to fp32 (pad columns stay 0: 0 * NaN = NaN, ignored)
 __global__ __launch_bounds__(256) void k_build_k32(const double *__restrict__ rcb,
                                                    float *__restrict__ k32, int32_t num_bins,
@@ -2188,6 +2231,14 @@ hipError_t launch_cws_chunk(hipStream_t s, const uint64_t *d_pairs, uint64_t n_a
 hipError_t launch_cws_beta(hipStream_t s, const uint64_t *d_uraw, uint64_t first_entry, uint64_t n, double *d_rcb,
                            uint64_t num_bins, uint64_t slot_begin, uint64_t slots) {
     hipLaunchKernelGGL(k_cws_beta, dim3(2048), dim3(256), 0, s, d_uraw, first_entry, n, d_rcb, num_bins, slot_begin, slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_smash(hipStream_t s, const unsigned long long *d_mins, const double *d_weights, uint32_t N, uint32_t S,
+                        int metric, double *d_out) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_smash, dim3((N + SMASH_T - 1) / SMASH_T, (N + SMASH_T - 1) / SMASH_T), dim3(256), 0, s, d_mins,
+                       d_weights, N, S, metric, d_out);
     return hipGetLastError();
 }
 

@@ -1,0 +1,114 @@
+"""`hulk smash` on the GPU: pairwise similarity matrix of a directory of HULK sketches.
+
+Reference: cmd/smash.go:60-226 (parameter checks, CollectJSONs, makeMatrix), HULKdata.GetDistance
+(src/sketchio/sketchio.go:259-306), distances.GetDistance/GetWJD (src/distances/distances.go).
+The N x N x S comparison runs in libhulkhip (hulk_smash); this module only loads, orders and writes.
+"""
+import ctypes
+import fnmatch
+import glob
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import HulkError
+from .sketchio import load_hulk_data
+
+AVAIL_METRICS = ["jaccard", "weightedjaccard"]          # cmd/smash.go:30 (the others are unreachable from the CLI)
+AVAIL_ALGORITHMS = ["histosketch", "kmv", "khf"]        # sketchio.go:17
+
+
+def collect_jsons(sketch_dir, recursive=False):
+    """helpers.CollectJSONs (src/helpers/helpers.go:168-208)."""
+    if not sketch_dir.endswith("/"):
+        sketch_dir += "/"
+    if recursive:
+        found = []
+        for root, _, files in os.walk(sketch_dir):
+            found += [os.path.join(root, f) for f in sorted(files) if fnmatch.fnmatch(f, "*.json")]
+    else:
+        found = glob.glob(sketch_dir + "*.json")
+    if not found:
+        raise HulkError(-30, f"no JSON files found in supplied directory: {sketch_dir}\n")
+    return found
+
+
+def distance_matrix(mins, weights, metric="jaccard", device=0):
+    """distances[s, q] = GetDistance(subject s, query q) for all pairs, computed on the GPU."""
+    mins = np.ascontiguousarray(mins, dtype=np.uint64)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    if mins.shape != weights.shape or mins.ndim != 2:
+        raise ValueError("mins/weights must be [n_sketches][sketch_size]")
+    n, s = mins.shape
+    out = np.zeros((n, n), dtype=np.float64)
+    L = _lib.load()
+    rc = L.hulk_smash(device, mins.ctypes.data, weights.ctypes.data, n, s,
+                      1 if metric == "weightedjaccard" else 0, out.ctypes.data)
+    if rc != 0:
+        raise HulkError(rc, L.hulk_last_error(None).decode())
+    return out
+
+
+def go_format_f2(v: float) -> str:
+    """strconv.FormatFloat(v, 'f', 2, 64)"""
+    if v != v:
+        return "NaN"
+    if v in (float("inf"), float("-inf")):
+        return "+Inf" if v > 0 else "-Inf"
+    return f"{v:.2f}"
+
+
+def go_csv_field(f: str) -> str:
+    """encoding/csv Writer: quote a field only when it needs it (fieldNeedsQuotes)."""
+    need = f == "\\." or any(ch in f for ch in ',"\r\n') or (f != "" and f[0] in " \t")
+    return '"' + f.replace('"', '""') + '"' if need else f
+
+
+def find_sketch(data, ksize, algo, path):
+    """HULKdata.FindSketch (sketchio.go:198-257) for histosketch signatures."""
+    if algo not in AVAIL_ALGORITHMS:
+        raise HulkError(-30, f"specified algorithm ({algo}) not found in the supplied sketch: {data.filename}\n")
+    sigs = [hs for a, hs in data.signatures if a == algo]
+    if not sigs:
+        raise HulkError(-30, f"no sketches were produced using the {algo} algorithm in file: {data.filename}\n")
+    hit = [hs for hs in sigs if hs.ksize == ksize]
+    if len(hit) > 1:
+        raise HulkError(-30, f"found {len(hit)} possible duplicate sketches in the supplied sketch file: {data.filename}\n")
+    if not hit:
+        raise HulkError(-30, f"specified k-mer size ({ksize}) not found in the supplied sketch file: {data.filename}\n")
+    return hit[0]
+
+
+def smash(sketch_dir, out_file, ksize=21, algo="histosketch", metric="jaccard", recursive=False, device=0):
+    """runSmash + makeMatrix: writes <out_file>.hulk-matrix.csv and returns (ordering, distances)."""
+    if metric not in AVAIL_METRICS:
+        raise HulkError(-30, f"supplied distance metric is not available: {metric}\nplease select one of the following: {AVAIL_METRICS}")
+    if algo not in AVAIL_ALGORITHMS:
+        raise HulkError(-30, f"supplied algorithm not available: {algo}\nplease select one of the following: {AVAIL_ALGORITHMS}")
+    files = collect_jsons(sketch_dir, recursive)
+    loaded = {}
+    for f in files:
+        try:
+            loaded[f] = load_hulk_data(f)
+        except ValueError as e:
+            raise HulkError(-30, str(e))
+    if len(loaded) < 2:
+        raise HulkError(-30, f"{len(loaded)} sketches found in the supplied directory, HULK needs at least 2 to smash!\n")
+    ordering = sorted(loaded)                                   # sort.Strings (byte order)
+    sk = [find_sketch(loaded[f], ksize, algo, f) for f in ordering]
+    size = len(sk[0].mins)
+    for a in sk:
+        if len(a.mins) != size:
+            raise HulkError(-30, f"sketch length mismatch: {size} vs {len(a.mins)}\n")
+    mins = np.stack([a.mins for a in sk])
+    weights = np.stack([a.weights for a in sk])
+    dist = distance_matrix(mins, weights, metric, device)
+    od = os.path.dirname(out_file)
+    if od and od != "." and not os.path.exists(od):
+        os.makedirs(od, mode=0o700)
+    with open(out_file + ".hulk-matrix.csv", "w", encoding="utf-8", newline="") as fh:
+        fh.write(",".join(go_csv_field(f) for f in ordering) + "\n")
+        for row in dist:
+            fh.write(",".join(go_format_f2(100 - (d * 100)) for d in row) + "\n")
+    return ordering, dist

@@ -151,6 +151,15 @@ int hulk_get_cms(hulk_ctx *ctx, double *counters);
 /* Copy rows of the CWS tables owned by this context to host: each [slot_count][num_bins] (test hook). */
 int hulk_get_cws_tables(hulk_ctx *ctx, double *r, double *c, double *b);
 
+/* `hulk smash` (cmd/smash.go:183-226): pairwise distance matrix of n_sketches histosketches of
+ * sketch_size slots (host arrays, row-major).  distances[s * n + q] = HULKdata.GetDistance(subject s,
+ * query q) (src/sketchio/sketchio.go:259-306): jaccard = distances.go:19-26, weighted jaccard =
+ * distances.GetWJD (distances.go:44-72) with the subject's weights on both sides, as the reference does. */
+#define HULK_METRIC_JACCARD 0
+#define HULK_METRIC_WEIGHTED_JACCARD 1
+int hulk_smash(int device, const uint64_t *mins, const double *weights, uint32_t n_sketches,
+               uint32_t sketch_size, int metric, double *distances);
+
 /* Device self-test: the jump hash replaces the fp64 division 2^31/r by a Newton reciprocal; this
  * checks RN(1/r) against IEEE division for EVERY r in [1, 2^31] and returns the mismatch count. */
 int hulk_selftest_reciprocal(hulk_ctx *ctx, uint64_t *mismatches);

@@ -480,3 +480,45 @@ int orc_add_histogram(orc_sketcher *o, const uint32_t *hist) {
     }
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------ smash (next-tier row)
+ * distances.GetDistance "jaccard" — src/distances/distances.go:19-26;
+ * distances.GetWJD — src/distances/distances.go:44-72;
+ * HULKdata.GetDistance — src/sketchio/sketchio.go:259-306 (note :293-301: BOTH weight vectors of the
+ * weighted Jaccard are taken from the SUBJECT sketch);  makeMatrix loop — cmd/smash.go:208-224. */
+double orc_jaccard_distance(const uint64_t *a, const uint64_t *b, uint32_t n) {
+    double intersect = 0.0;
+    for (uint32_t i = 0; i < n; i++) if ((double)a[i] == (double)b[i]) intersect++;
+    return 1.0 - (intersect / (double)n);
+}
+static double go_max(double x, double y) {            /* math.Max: NaN if either is NaN, +0 > -0 */
+    if (isinf(x) && x > 0) return x;
+    if (isinf(y) && y > 0) return y;
+    if (x != x || y != y) return NAN;
+    if (x == 0 && x == y) return signbit(x) ? y : x;
+    return x > y ? x : y;
+}
+double orc_wjd(const uint64_t *setA, const uint64_t *setB, const double *weightsA, const double *weightsB, uint32_t n) {
+    double intersect = 0.0, uni = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+        double weightA = go_max(go_max(weightsA[i], 0), go_max(-weightsA[i], 0));
+        double weightB = go_max(go_max(weightsB[i], 0), go_max(-weightsB[i], 0));
+        if ((double)setA[i] == (double)setB[i]) {
+            if (weightA < weightB) { intersect += weightA; uni += weightB; }
+            else { intersect += weightB; uni += weightA; }
+        } else {
+            if (weightA > weightB) uni += weightA; else uni += weightB;
+        }
+    }
+    return 1 - (intersect / uni);
+}
+/* out[s*N + q] = distance(subject s, query q); metric 0 = jaccard, 1 = weightedjaccard */
+void orc_smash_matrix(const uint64_t *mins, const double *weights, uint32_t N, uint32_t S, int metric, double *out) {
+    for (uint32_t s = 0; s < N; s++)
+        for (uint32_t q = 0; q < N; q++) {
+            const uint64_t *a = mins + (size_t)s * S, *b = mins + (size_t)q * S;
+            const double *wa = weights + (size_t)s * S;
+            out[(size_t)s * N + q] = metric == 1 ? orc_wjd(a, b, wa, wa, S)      /* sketchio.go:296: hsB = subject */
+                                                 : orc_jaccard_distance(a, b, S);
+        }
+}

@@ -70,6 +70,7 @@ def lib():
         L.orc_get_counters.argtypes = [vp] * 6
         for n in ("orc_cws_r", "orc_cws_c", "orc_cws_b"):
             getattr(L, n).restype = ctypes.POINTER(ctypes.c_double); getattr(L, n).argtypes = [vp]
+        L.orc_smash_matrix.argtypes = [vp, vp, u32, u32, ctypes.c_int, vp]
         _lib = L
     return _lib
 
@@ -184,3 +185,12 @@ class Sketcher:
         n = self.S * self.B
         return tuple(np.ctypeslib.as_array(getattr(lib(), f)(self._p), shape=(n,)).reshape(self.S, self.B).copy()
                      for f in ("orc_cws_r", "orc_cws_c", "orc_cws_b"))
+
+
+def smash_matrix(mins, weights, metric="jaccard"):
+    """Pairwise distance matrix out[subject, query] (reference: cmd/smash.go:208-224)."""
+    mins = np.ascontiguousarray(mins, dtype=np.uint64); weights = np.ascontiguousarray(weights, dtype=np.float64)
+    N, S = mins.shape
+    out = np.zeros((N, N))
+    lib().orc_smash_matrix(mins.ctypes.data, weights.ctypes.data, N, S, 1 if metric == "weightedjaccard" else 0, out.ctypes.data)
+    return out

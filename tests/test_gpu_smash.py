@@ -1,0 +1,79 @@
+"""`hulk smash` on the GPU vs the literal CPU restatement: distances must be
+bit-identical (the kernel accumulates over the slots in the reference's order)."""
+import numpy as np
+import pytest
+
+from oracle import pyorc
+
+pytestmark = pytest.mark.gpu
+
+
+def make_sketches(rng, n, s, bins=194481, related=True):
+    base = rng.integers(0, bins, size=s).astype(np.uint64)
+    mins = np.empty((n, s), dtype=np.uint64)
+    for i in range(n):
+        keep = rng.random(s) < (0.2 + 0.6 * rng.random()) if related else np.zeros(s, bool)
+        mins[i] = np.where(keep, base, rng.integers(0, bins, size=s).astype(np.uint64))
+    weights = -rng.gamma(2.0, 1e-3, size=(n, s))            # histosketch weights are mostly negative
+    weights[rng.random((n, s)) < 0.05] *= -1                # ... some positive
+    return mins, weights
+
+
+@pytest.mark.parametrize("n,s", [(2, 50), (17, 512), (65, 2048), (33, 100)])
+def test_distance_matrix_bit_exact(n, s):
+    from hulk_amd.smash import distance_matrix
+    rng = np.random.default_rng(n * 7 + s)
+    mins, weights = make_sketches(rng, n, s)
+    for metric in ("jaccard", "weightedjaccard"):
+        got = distance_matrix(mins, weights, metric)
+        want = pyorc.smash_matrix(mins, weights, metric)
+        assert np.array_equal(got, want), metric
+    # the subject-weights quirk (sketchio.go:296) makes the weighted matrix asymmetric; jaccard is symmetric
+    j = distance_matrix(mins, weights, "jaccard")
+    assert np.array_equal(j, j.T) and np.all(np.diag(j) == 0)
+
+
+def test_untouched_slots_and_special_values():
+    """MaxFloat64 weights (slots never updated) overflow the union: Inf/Inf = NaN, as in Go."""
+    from hulk_amd.smash import distance_matrix, go_format_f2
+    mins = np.array([[1, 2, 3, 4], [1, 2, 9, 4], [0, 0, 0, 0]], dtype=np.uint64)
+    w = np.array([[-1.0, 2.0, -3.0, 4.0], [np.finfo(np.float64).max] * 4, [0.0, -0.0, 0.0, 0.0]])
+    got = distance_matrix(mins, w, "weightedjaccard")
+    want = pyorc.smash_matrix(mins, w, "weightedjaccard")
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.isnan(got[1, 0]) and np.isnan(got[2, 2])
+    assert go_format_f2(float("nan")) == "NaN" and go_format_f2(100 - 0.125 * 100) == "87.50"
+
+
+def test_smash_cli_end_to_end(tmp_path):
+    """sketch three read sets with the GPU path, smash them, compare the CSV with the oracle's matrix."""
+    import hulk_amd
+    from hulk_amd import synth
+    from hulk_amd.__main__ import main
+    from hulk_amd.sketchio import HULKdata
+    from hulk_amd.smash import go_format_f2
+    d = tmp_path / "sk"
+    d.mkdir()
+    mins, weights, names = [], [], []
+    for i, (first, n) in enumerate(((0, 3000), (1000, 3000), (50000, 2500))):
+        g = hulk_amd.GpuSketcher(15, 9, 64, interval=1000)
+        g.add_reads(*synth.reads_numpy(first, n, 120))
+        g.finish()
+        hs = g.histosketch()
+        doc = HULKdata(); doc.add(hs); doc.filename = f"r{i}.fq,"; doc.banner_label = "blank"
+        p = d / f"s{2 - i}.json"          # file order != creation order: the header must be sorted
+        doc.write_json(p)
+        names.append(str(p)); mins.append(hs.mins); weights.append(hs.weights)
+        g.close()
+    out = str(tmp_path / "res")
+    for metric in ("jaccard", "weightedjaccard"):
+        assert main(["smash", "-d", str(d), "-k", "15", "-m", metric, "-o", out]) == 0
+        rows = open(out + ".hulk-matrix.csv").read().splitlines()
+        order = sorted(names)
+        assert rows[0] == ",".join(order)
+        idx = [names.index(f) for f in order]
+        want = pyorc.smash_matrix(np.stack(mins)[idx], np.stack(weights)[idx], metric)
+        for r, line in enumerate(rows[1:]):
+            assert line == ",".join(go_format_f2(100 - v * 100) for v in want[r])
+    assert main(["smash", "-d", str(d), "-m", "euclidean", "-o", out]) == 1     # not in availMetrics
+    assert main(["smash", "-d", str(d), "-k", "21", "-o", out]) == 1            # no sketch with that k
