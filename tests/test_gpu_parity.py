@@ -337,3 +337,22 @@ def test_repetitive_reads_fall_back_to_generic_kernel():
     assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32))
     assert o.counters()["n_minimizers"] == g.counters()["n_minimizers"]
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("name,k,S,interval,decay", [("c1_fixture_k21_s256", 21, 256, 0, 1.0),
+                                                     ("c1_fixture_k15_s64_drift", 15, 64, 250, 0.05)])
+def test_against_committed_golden_sketches(name, k, S, interval, decay, fq_reads):
+    """GPU sketch of the reference's fixture vs the committed golden JSON (tests/golden, produced by
+    tools/make_golden.py from the CPU restatement): mins + MD5 exact, weights within the north-star 1e-5."""
+    import os
+    from conftest import GOLDEN
+    from hulk_amd.sketchio import load_hulk_data, md5sum
+    gold = load_hulk_data(os.path.join(GOLDEN, name + ".json")).signatures[0][1]
+    g = gpu().GpuSketcher(k, 9, S, interval, decay)
+    g.add_reads(*pack_reads(fq_reads))
+    g.finish()
+    hs = g.histosketch()
+    assert np.array_equal(hs.mins, gold.mins) and md5sum(hs.mins) == gold.md5sum
+    assert np.allclose(hs.weights, gold.weights, rtol=1e-5, atol=0)
+    assert np.allclose(hs.weights, gold.weights, rtol=1e-7, atol=0)
+    g.close()

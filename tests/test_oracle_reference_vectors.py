@@ -188,3 +188,19 @@ def test_addelement_literal_small_case():
         wm[upd] = A[upd]; mm[upd] = bin_
     assert np.array_equal(mm, mins) and np.allclose(wm, weights, rtol=1e-12)
     assert np.array_equal(ctr, s.cms())
+
+
+def test_golden_sketch_reproduced_by_oracle(fq_reads):
+    """tests/golden/c1_fixture_k15_s64_drift.json (tools/make_golden.py): the oracle still produces the
+    committed sketch — guards the checker itself against silent changes (k=15 keeps the tables small)."""
+    import os
+    from conftest import GOLDEN
+    from hulk_amd.sketchio import load_hulk_data
+    g = load_hulk_data(os.path.join(GOLDEN, "c1_fixture_k15_s64_drift.json")).signatures[0][1]
+    o = pyorc.Sketcher(15, 9, 64, 0, 0.05, 250)
+    for r in fq_reads:
+        o.add_read(r)
+    o.finish()
+    m, w = o.sketch()
+    assert np.array_equal(m, g.mins) and np.array_equal(w, g.weights)     # JSON floats round-trip exactly
+    assert g.concept_drift is True and g.num_histogram_bins == 50625
