@@ -1,0 +1,111 @@
+"""Two ranks of the PRODUCT multi-GPU path (GpuSketcher + GpuEngine + ShardedSketcher, the protocol of
+bench.py) on ONE MI355X: both processes use cuda:0 and exchange over gloo (RCCL refuses two ranks on
+one device; the collective is the only thing swapped).  The gathered sketch must equal a single-rank
+GPU run over the same global read stream with interval = 2 x the per-rank interval, and the oracle.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K, W, S, I, BATCH, STEPS, L = 15, 9, 64, 3000, 4, 3, 150
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q, overlap):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["HULK_BATCH"] = str(BATCH)
+    import hulk_amd
+    from hulk_amd import synth
+    from hulk_amd.distributed import GpuEngine, ShardedSketcher, slot_shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    stream = torch.cuda.Stream()
+    coll = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    sb, sc = slot_shard(S, rank, world)
+    sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=0, slot_begin=sb, slot_count=sc,
+                              stream=stream.cuda_stream)
+    assert sk.batch_size == BATCH
+    eng = GpuEngine(sk, "cuda:0", n_spectra=BATCH)
+    sh = ShardedSketcher(eng, S, rank, world, dist)
+    n = I * BATCH
+    offsets = torch.arange(n + 1, dtype=torch.int64, device="cuda:0") * L
+    keep = []
+    for s_ in range(STEPS):
+        parts = []
+        for t in range(BATCH):
+            first = ((s_ * BATCH + t) * world + rank) * I
+            b, _ = synth.reads_torch(first, I, L, device="cuda:0")
+            parts.append(b[:I * L])
+        bases = torch.cat(parts + [torch.zeros(16, dtype=torch.uint8, device="cuda:0")])
+        keep.append(bases)
+        sk.bin_reads_device(bases.data_ptr(), offsets.data_ptr(), n, L, bases.numel(), reads_per_spectrum=I)
+        h = eng.histogram_tensor()
+        if overlap:                                     # bench.py's shape: collective + flush on a second stream
+            coll.wait_stream(stream)
+            with torch.cuda.stream(coll):
+                hc = h.cpu()                            # gloo: host-staged all-reduce of the int32 spectra
+                dist.all_reduce(hc, op=dist.ReduceOp.SUM)
+                h.copy_(hc)
+            sk.flush_batch(BATCH, after_stream=coll.cuda_stream)
+        else:
+            hc = h.cpu()
+            dist.all_reduce(hc, op=dist.ReduceOp.SUM)
+            h.copy_(hc)
+            sk.flush_batch(BATCH)
+    sk.finish()
+    eng.collective_device = None                        # gloo gather on host tensors
+    mins, weights = sh.gather_sketch()
+    if rank == 0:
+        q.put((mins, weights, sk.counters()))
+    sk.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_ranks_one_gpu_match_single_rank(overlap):
+    import torch
+    import torch.multiprocessing as mp
+    import hulk_amd
+    from hulk_amd import synth
+    from oracle import pyorc
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, overlap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    mins, weights, _ = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single rank, same global stream: interval = world * I
+    total = STEPS * BATCH * world * I
+    bases, offsets = synth.reads_numpy(0, total, L)
+    g = hulk_amd.GpuSketcher(K, W, S, interval=world * I)
+    g.add_reads(bases, offsets)
+    g.finish()
+    m1, w1 = g.sketch()
+    g.close()
+    assert np.array_equal(mins, m1)
+    assert np.array_equal(weights, w1)                  # same kernels, same order: bit-identical
+    o = pyorc.Sketcher(K, W, S, 0, 1.0, world * I)
+    o.add_reads(bases, offsets)
+    o.finish()
+    mo, wo = o.sketch()
+    o.close()
+    assert np.array_equal(mins, mo)
+    assert np.allclose(weights, wo, rtol=1e-12, atol=0)
