@@ -20,6 +20,7 @@ ABI_SYMBOLS = (
     "hulk_batch_size", "hulk_bin_reads_device", "hulk_histogram_device", "hulk_flush_batch", "hulk_flush_batch_after", "hulk_add_histogram", "hulk_flush",
     "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
     "hulk_get_cws_tables", "hulk_smash", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
+    "hulk_parse_files", "hulk_sketch_files",
 )
 
 
@@ -31,6 +32,15 @@ class HulkParams(ctypes.Structure):
         ("slot_begin", ctypes.c_uint32), ("slot_count", ctypes.c_uint32),
         ("cws_source", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 5),
     ]
+
+
+class IngestStats(ctypes.Structure):
+    _fields_ = [("n_seqs", ctypes.c_uint64), ("total_len", ctypes.c_uint64), ("n_lines", ctypes.c_uint64),
+                ("bytes_in", ctypes.c_uint64), ("seconds", ctypes.c_double)]
+
+
+BATCH_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8),
+                            ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64)
 
 
 class HulkError(RuntimeError):
@@ -81,5 +91,11 @@ def load():
     L.hulk_selftest_reciprocal.restype = ctypes.c_int; L.hulk_selftest_reciprocal.argtypes = [vp, vp]
     L.hulk_set_profiling.restype = ctypes.c_int; L.hulk_set_profiling.argtypes = [vp, ctypes.c_int]
     L.hulk_get_profile.restype = ctypes.c_int; L.hulk_get_profile.argtypes = [vp, ctypes.c_char_p, vp, vp]
+    L.hulk_parse_files.restype = ctypes.c_int
+    L.hulk_parse_files.argtypes = [ctypes.POINTER(ctypes.c_char_p), u32, ctypes.c_int, u32, BATCH_FN, vp,
+                                   ctypes.POINTER(IngestStats), ctypes.c_char_p, u64]
+    L.hulk_sketch_files.restype = ctypes.c_int
+    L.hulk_sketch_files.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), u32, ctypes.c_int, u32,
+                                    ctypes.POINTER(IngestStats)]
     _lib = L
     return L

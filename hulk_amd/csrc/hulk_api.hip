@@ -32,6 +32,10 @@ const char *err_text(int status) {
         case HULK_ERR_BINS: return "histogram must have at least 2 bins";
         case HULK_ERR_NEG_BINS: return "negative value used for number of k-mer spectrum bins";
         case HULK_ERR_NO_SEQ: return "no sequences received";
+        case HULK_ERR_FASTQ_ID: return "read ID in fastq file does not begin with @";
+        case HULK_ERR_LINE_TOO_LONG: return "bufio.Scanner: token too long";
+        case HULK_ERR_IO: return "input/output error";
+        case HULK_ERR_FASTA_HEADER: return "fasta input holds no header line";
         case HULK_ERR_ARG: return "invalid argument";
         case HULK_ERR_HIP: return "HIP runtime error";
         case HULK_ERR_NO_DEVICE: return "no usable HIP device (libhulkhip needs an AMD gfx950 GPU)";
@@ -631,6 +635,19 @@ int hulk_set_cws_tables(hulk_ctx *c, const double *r, const double *cc, const do
     return install_tables(c, r, cc, b);
 }
 
+}  // extern "C"
+
+// internal accessors for hulk_ingest.hip (not part of the ABI)
+namespace hulk {
+hipStream_t ctx_stream(hulk_ctx *c) { return c->stream; }
+uint64_t ctx_min_read_len(const hulk_ctx *c) { return (uint64_t)c->p.w + c->p.k - 1; }
+int ctx_fail(hulk_ctx *c, int code, const char *full_message) {
+    c->last_error = (full_message && *full_message) ? full_message : err_text(code);
+    return code;
+}
+}  // namespace hulk
+
+extern "C" {
 int hulk_add_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
                           uint32_t max_read_len, uint64_t bases_bytes) {
     if (!c) return HULK_ERR_ARG;

@@ -1,0 +1,585 @@
+// Host ingest of libhulkhip: files / STDIN -> lines -> sequences -> pinned staging -> HBM.
+//
+// Replaces, with the same observable semantics, the reference's
+//   DataStreamer.Run   src/pipeline/sketch.go:40-79   (bufio.Scanner lines; gzip when the name ends
+//                                                       in ".gz"; STDIN when no file is given)
+//   FastqHandler.Run   src/pipeline/sketch.go:99-161  (four nil-tested line slots; FASTA branch)
+//   seqio.NewFASTQread src/seqio/seqio.go:38-40       ('@' check when the 4th line arrives)
+// and the AddSeq loop of SeqMinimizer.Run (sketch.go:196-217) when a context is attached.
+//
+// Shape: a reader thread turns the inputs into 32 MB blocks that end on a line boundary (gzip
+// inflation runs there, ahead of the parser); a block is parsed by P threads in two passes — pass 1
+// runs the 4-state line machine for all four possible start states of every piece (state,
+// sequences, bytes), a serial prefix fixes each piece's real start state and its output offsets,
+// pass 2 copies the sequence lines straight into pinned staging — and is handed to the GPU with
+// asynchronous copies on the context's stream while the next block is read and parsed.
+#include <errno.h>
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/hulk_hip.h"
+#include "hulk_internal.h"
+
+namespace {
+
+constexpr size_t MAX_TOKEN = 64 * 1024;      // bufio.MaxScanTokenSize
+// block size: 32 MB; HULK_INGEST_BLOCK (bytes, >= 128 KiB) shrinks it so that tests cross many block borders
+static size_t block_bytes() {
+    static const size_t v = [] {
+        const char *e = getenv("HULK_INGEST_BLOCK");
+        size_t b = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(32u << 20);
+        return b < 2 * MAX_TOKEN ? 2 * MAX_TOKEN : b;
+    }();
+    return v;
+}
+#define BLOCK_BYTES (block_bytes())
+constexpr size_t FASTA_BATCH_BYTES = 64u << 20;
+
+struct IngestError {
+    int code = HULK_OK;
+    std::string msg;
+    bool set(int c, const std::string &m) { if (code == HULK_OK) { code = c; msg = m; } return false; }
+};
+
+// ------------------------------------------------------------------------------------------
+// Sequential byte source over the inputs.  bufio.Scanner is per input: an unterminated last line is
+// a token of THAT input, so a '\n' is supplied at the end of an input that does not end in one.
+// ------------------------------------------------------------------------------------------
+class ByteSource {
+ public:
+    ByteSource(const char *const *paths, uint32_t n) {
+        for (uint32_t i = 0; i < n; i++) paths_.push_back(paths[i] ? paths[i] : "");
+        stdin_mode_ = paths_.empty();
+    }
+    ~ByteSource() { close_current(); }
+
+    // up to cap bytes into dst; 0 = all inputs exhausted; -1 = error
+    long read(uint8_t *dst, size_t cap, IngestError &err) {
+        for (;;) {
+            if (!open_) {
+                if (stdin_mode_) { if (stdin_done_) return 0; fd_ = 0; open_ = true; is_gz_ = false; }
+                else {
+                    if (idx_ >= paths_.size()) return 0;
+                    if (!open_path(paths_[idx_], err)) return -1;
+                }
+                last_ = '\n'; got_any_ = false;
+            }
+            long n;
+            if (is_gz_) {
+                n = gzread(gz_, dst, (unsigned)std::min<size_t>(cap, 1u << 30));
+                if (n < 0) { int e = 0; const char *m = gzerror(gz_, &e); err.set(HULK_ERR_IO, std::string("gzip: ") + (m ? m : "read error")); return -1; }
+            } else {
+                do { n = ::read(fd_, dst, cap); } while (n < 0 && errno == EINTR);
+                if (n < 0) { err.set(HULK_ERR_IO, std::string("read ") + current_name() + ": " + strerror(errno)); return -1; }
+            }
+            if (n > 0) { last_ = dst[n - 1]; got_any_ = true; return n; }
+            // end of this input
+            const bool need_nl = got_any_ && last_ != '\n';
+            close_current();
+            if (stdin_mode_) stdin_done_ = true; else idx_++;
+            if (need_nl) { dst[0] = '\n'; return 1; }
+        }
+    }
+
+ private:
+    std::string current_name() const { return stdin_mode_ ? "STDIN" : paths_[idx_]; }
+    bool open_path(const std::string &p, IngestError &err) {
+        fd_ = ::open(p.c_str(), O_RDONLY);
+        if (fd_ < 0) return err.set(HULK_ERR_IO, "open " + p + ": " + strerror(errno));   // os.Open's *PathError text
+        open_ = true;
+        // sketch.go:64-65: strings.Split(name, ".") last element == "gz"
+        const size_t dot = p.rfind('.');
+        is_gz_ = dot != std::string::npos && p.compare(dot + 1, std::string::npos, "gz") == 0;
+        if (is_gz_) {
+            uint8_t magic[2] = {0, 0};
+            const ssize_t m = ::pread(fd_, magic, 2, 0);
+            if (m == 0) { close_current(); return err.set(HULK_ERR_IO, "EOF"); }                    // gzip.NewReader on an empty file
+            if (m < 2 || magic[0] != 0x1f || magic[1] != 0x8b) { close_current(); return err.set(HULK_ERR_IO, "gzip: invalid header"); }
+            gz_ = gzdopen(fd_, "rb");
+            if (!gz_) { close_current(); return err.set(HULK_ERR_IO, "gzip: cannot open stream"); }
+            gzbuffer(gz_, 1u << 20);
+        }
+        return true;
+    }
+    void close_current() {
+        if (gz_) { gzclose(gz_); gz_ = nullptr; fd_ = -1; }       // gzclose closes the descriptor
+        else if (fd_ > 0) ::close(fd_);
+        fd_ = -1; open_ = false;
+    }
+    std::vector<std::string> paths_;
+    size_t idx_ = 0;
+    bool stdin_mode_ = false, stdin_done_ = false, open_ = false, is_gz_ = false, got_any_ = false;
+    int fd_ = -1;
+    gzFile gz_ = nullptr;
+    uint8_t last_ = '\n';
+};
+
+// ------------------------------------------------------------------------------------------
+// Reader thread: blocks that end on '\n' (the unterminated tail is carried into the next block).
+// ------------------------------------------------------------------------------------------
+struct Block {
+    std::vector<uint8_t> buf;
+    size_t len = 0;
+    bool tail_too_long = false;   // the line after this block's last '\n' already has >= MAX_TOKEN bytes
+};
+
+class BlockReader {
+ public:
+    BlockReader(const char *const *paths, uint32_t n) : src_(paths, n) { th_ = std::thread([this] { run(); }); }
+    ~BlockReader() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    // next block, or nullptr at the end / on error (err filled)
+    std::unique_ptr<Block> next(IngestError &err) {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return !q_.empty() || done_; });
+        if (!q_.empty()) { auto b = std::move(q_.front()); q_.pop_front(); cv_.notify_all(); return b; }
+        if (err_.code != HULK_OK) err = err_;
+        return nullptr;
+    }
+    void recycle(std::unique_ptr<Block> b) { std::lock_guard<std::mutex> g(m_); if (pool_.size() < 3) pool_.push_back(std::move(b)); }
+    uint64_t bytes_in() const { return bytes_in_; }
+
+ private:
+    void run() {
+        std::vector<uint8_t> carry;
+        bool eof = false;
+        while (!eof) {
+            std::unique_ptr<Block> b;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return q_.size() < 2 || stop_; });
+                if (stop_) break;
+                if (!pool_.empty()) { b = std::move(pool_.back()); pool_.pop_back(); }
+            }
+            if (!b) b.reset(new Block);
+            if (b->buf.size() < BLOCK_BYTES + MAX_TOKEN + 16) b->buf.resize(BLOCK_BYTES + MAX_TOKEN + 16);
+            size_t have = carry.size();
+            if (have > b->buf.size() - BLOCK_BYTES) b->buf.resize(have + BLOCK_BYTES + 16);
+            if (have) memcpy(b->buf.data(), carry.data(), have);
+            carry.clear();
+            IngestError e;
+            while (have < BLOCK_BYTES) {
+                const long n = src_.read(b->buf.data() + have, BLOCK_BYTES - have, e);
+                if (n < 0) { finish(e); return; }
+                if (n == 0) { eof = true; break; }
+                have += (size_t)n; bytes_in_ += (uint64_t)n;
+            }
+            // cut at the last '\n'
+            size_t cut = have;
+            while (cut > 0 && b->buf[cut - 1] != '\n') cut--;
+            b->tail_too_long = false;
+            if (!eof) {
+                carry.assign(b->buf.begin() + cut, b->buf.begin() + have);
+                if (carry.size() >= MAX_TOKEN) b->tail_too_long = true;
+            }   // at EOF every input ended in '\n' (ByteSource), so cut == have
+            b->len = eof ? have : cut;
+            const bool fatal_tail = b->tail_too_long;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                q_.push_back(std::move(b));
+            }
+            cv_.notify_all();
+            if (fatal_tail) break;       // the parser reports "token too long" after this block
+        }
+        IngestError none;
+        finish(none);
+    }
+    void finish(const IngestError &e) {
+        { std::lock_guard<std::mutex> g(m_); err_ = e; done_ = true; }
+        cv_.notify_all();
+    }
+    ByteSource src_;
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::unique_ptr<Block>> q_, pool_;
+    bool done_ = false, stop_ = false;
+    IngestError err_;
+    uint64_t bytes_in_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// Sinks: where parsed sequences go.  prepare() hands out room for n sequences / nbytes bases
+// (lens[i] receives the length of sequence i); commit() takes the first n_commit of them.
+// ------------------------------------------------------------------------------------------
+struct Sink {
+    virtual ~Sink() {}
+    virtual bool prepare(uint64_t n, uint64_t nbytes, uint8_t **bases, uint64_t **lens, IngestError &err) = 0;
+    virtual bool commit(uint64_t n_commit, IngestError &err) = 0;     // lens -> offsets happens here
+    virtual bool finish(IngestError &err) { (void)err; return true; }
+    uint64_t n_seqs = 0, total_len = 0;
+};
+
+// lens[0..n) -> exclusive offsets in place (array has n+1 entries); returns total, min, max
+static uint64_t lens_to_offsets(uint64_t *a, uint64_t n, uint64_t &mn, uint64_t &mx) {
+    uint64_t run = 0; mn = ~0ull; mx = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t L = a[i];
+        if (L < mn) mn = L;
+        if (L > mx) mx = L;
+        a[i] = run; run += L;
+    }
+    a[n] = run;
+    return run;
+}
+
+struct CallbackSink : Sink {
+    hulk_batch_fn fn; void *user;
+    std::vector<uint8_t> bases; std::vector<uint64_t> lens;
+    CallbackSink(hulk_batch_fn f, void *u) : fn(f), user(u) {}
+    bool prepare(uint64_t n, uint64_t nbytes, uint8_t **b, uint64_t **l, IngestError &) override {
+        if (bases.size() < nbytes + 16) bases.resize(nbytes + 16);
+        if (lens.size() < n + 2) lens.resize(n + 2);
+        *b = bases.data(); *l = lens.data();
+        return true;
+    }
+    bool commit(uint64_t n, IngestError &err) override {
+        if (n == 0) return true;
+        uint64_t mn, mx;
+        const uint64_t tot = lens_to_offsets(lens.data(), n, mn, mx);
+        n_seqs += n; total_len += tot;
+        if (fn) { const int rc = fn(user, bases.data(), lens.data(), n); if (rc != 0) return err.set(rc < 0 ? rc : HULK_ERR_ARG, "batch callback failed"); }
+        return true;
+    }
+};
+
+#define ING_HIP(call)                                                                               \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) return err.set(HULK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+// pinned double-buffered staging in front of hulk_add_reads_device
+struct GpuSink : Sink {
+    struct Stage {
+        uint8_t *h_bases = nullptr, *d_bases = nullptr; uint64_t *h_off = nullptr, *d_off = nullptr;
+        size_t cap_bases = 0, cap_off = 0; hipEvent_t ev = nullptr; bool busy = false;
+    };
+    hulk_ctx *ctx; Stage st[2]; int cur = 0; uint64_t min_len;
+    explicit GpuSink(hulk_ctx *c) : ctx(c), min_len(hulk::ctx_min_read_len(c)) {}
+    ~GpuSink() override {
+        for (auto &s : st) {
+            if (s.busy && s.ev) hipEventSynchronize(s.ev);
+            if (s.ev) hipEventDestroy(s.ev);
+            if (s.h_bases) hipHostFree(s.h_bases);
+            if (s.h_off) hipHostFree(s.h_off);
+            if (s.d_bases) hipFree(s.d_bases);
+            if (s.d_off) hipFree(s.d_off);
+        }
+    }
+    bool prepare(uint64_t n, uint64_t nbytes, uint8_t **b, uint64_t **l, IngestError &err) override {
+        Stage &s = st[cur];
+        if (!s.ev) ING_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+        if (s.busy) { ING_HIP(hipEventSynchronize(s.ev)); s.busy = false; }      // its copies + kernels are done
+        if (nbytes + 32 > s.cap_bases) {
+            if (s.h_bases) hipHostFree(s.h_bases);
+            if (s.d_bases) hipFree(s.d_bases);
+            s.h_bases = s.d_bases = nullptr;
+            s.cap_bases = (nbytes + 32) + (nbytes + 32) / 4;
+            ING_HIP(hipHostMalloc((void **)&s.h_bases, s.cap_bases, hipHostMallocDefault));
+            ING_HIP(hipMalloc((void **)&s.d_bases, s.cap_bases));
+        }
+        if (n + 2 > s.cap_off) {
+            if (s.h_off) hipHostFree(s.h_off);
+            if (s.d_off) hipFree(s.d_off);
+            s.h_off = s.d_off = nullptr;
+            s.cap_off = (n + 2) + (n + 2) / 4;
+            ING_HIP(hipHostMalloc((void **)&s.h_off, s.cap_off * 8, hipHostMallocDefault));
+            ING_HIP(hipMalloc((void **)&s.d_off, s.cap_off * 8));
+        }
+        *b = s.h_bases; *l = s.h_off;
+        return true;
+    }
+    bool commit(uint64_t n, IngestError &err) override {
+        if (n == 0) return true;
+        Stage &s = st[cur];
+        uint64_t mn, mx;
+        const uint64_t tot = lens_to_offsets(s.h_off, n, mn, mx);
+        // NewMinimizerSketch's checks (minimizer.go:70-76), as hulk_add_reads makes them
+        if (mn < 1) return err.set(HULK_ERR_EMPTY_SEQ, hulk_strerror(HULK_ERR_EMPTY_SEQ));
+        if (mn < min_len) return err.set(HULK_ERR_SHORT_SEQ, hulk_strerror(HULK_ERR_SHORT_SEQ));
+        if (mx > 0xffffffffull) return err.set(HULK_ERR_READ_TOO_LONG, hulk_strerror(HULK_ERR_READ_TOO_LONG));
+        hipStream_t stream = hulk::ctx_stream(ctx);
+        ING_HIP(hipMemcpyAsync(s.d_bases, s.h_bases, tot, hipMemcpyHostToDevice, stream));
+        ING_HIP(hipMemcpyAsync(s.d_off, s.h_off, (n + 1) * 8, hipMemcpyHostToDevice, stream));
+        const int rc = hulk_add_reads_device(ctx, s.d_bases, s.d_off, n, (uint32_t)mx, s.cap_bases);
+        if (rc != HULK_OK) return err.set(rc, hulk_last_error(ctx));
+        ING_HIP(hipEventRecord(s.ev, stream));
+        s.busy = true;
+        cur ^= 1;
+        n_seqs += n; total_len += tot;
+        return true;
+    }
+    bool finish(IngestError &err) override {
+        for (auto &s : st) if (s.busy) { ING_HIP(hipEventSynchronize(s.ev)); s.busy = false; }
+        return true;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// FASTQ: the line machine of FastqHandler.Run.  state = number of filled slots (0..3).
+//   state 0..2: an EMPTY line leaves the slot nil (skipped); a non-empty line fills it
+//   state 3   : ANY line (empty too) is l4 and completes the record
+// ------------------------------------------------------------------------------------------
+static inline size_t line_len(const uint8_t *p, const uint8_t *nl) {     // ScanLines' dropCR
+    size_t L = (size_t)(nl - p);
+    if (L && p[L - 1] == '\r') L--;
+    return L;
+}
+
+struct Scan1 {
+    uint8_t end_state[4]; uint64_t nseq[4], nbytes[4]; uint64_t n_lines = 0; bool too_long = false;
+};
+
+static void fastq_pass1(const uint8_t *a, const uint8_t *b, Scan1 &r) {
+    uint8_t st[4] = {0, 1, 2, 3};
+    uint64_t ns[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0};
+    const uint8_t *p = a;
+    while (p < b) {
+        const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(b - p));
+        if (!nl) nl = b;                                   // cannot happen: pieces end in '\n'
+        if ((size_t)(nl - p) >= MAX_TOKEN) { r.too_long = true; break; }
+        const size_t L = line_len(p, nl);
+        r.n_lines++;
+        for (int h = 0; h < 4; h++) {
+            const uint8_t s = st[h];
+            if (s == 3) st[h] = 0;
+            else if (L) { if (s == 1) { ns[h]++; nb[h] += L; } st[h] = (uint8_t)(s + 1); }
+        }
+        p = nl + 1;
+    }
+    for (int h = 0; h < 4; h++) { r.end_state[h] = st[h]; r.nseq[h] = ns[h]; r.nbytes[h] = nb[h]; }
+}
+
+struct Scan2 {
+    uint64_t completed = 0;          // records completed in this piece
+    bool bad_done = false;           // a record that STARTED here with a bad header completed here
+    std::string bad_done_hdr;
+    bool bad_pending = false;        // the record in progress at the end started here with a bad header
+    std::string bad_pending_hdr;
+    bool started = false;            // a header line was seen in this piece
+};
+
+static void fastq_pass2(const uint8_t *a, const uint8_t *b, uint8_t state, uint8_t *out, uint64_t *lens, Scan2 &r) {
+    const uint8_t *p = a;
+    bool cur_bad = false; std::string cur_hdr;
+    while (p < b) {
+        const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(b - p));
+        if (!nl) nl = b;
+        if ((size_t)(nl - p) >= MAX_TOKEN) break;          // reported from pass 1
+        const size_t L = line_len(p, nl);
+        if (state == 3) {
+            r.completed++;
+            if (cur_bad && !r.bad_done) { r.bad_done = true; r.bad_done_hdr = cur_hdr; }
+            cur_bad = false; state = 0;
+        } else if (L) {
+            if (state == 0) {
+                r.started = true;
+                cur_bad = p[0] != '@';
+                if (cur_bad) cur_hdr.assign((const char *)p, std::min<size_t>(L, 512));
+            } else if (state == 1) {
+                memcpy(out, p, L); out += L; *lens++ = (uint64_t)L;
+            }
+            state++;
+        }
+        p = nl + 1;
+    }
+    if (cur_bad && state != 0) { r.bad_pending = true; r.bad_pending_hdr = cur_hdr; }
+}
+
+struct Parser {
+    Sink &sink; uint32_t threads; IngestError &err;
+    uint64_t n_lines = 0;
+    Parser(Sink &s, uint32_t t, IngestError &e) : sink(s), threads(t ? t : 1), err(e) {}
+
+    // ---- FASTQ ----
+    uint8_t fq_state = 0;
+    std::vector<uint8_t> pending;      // sequence of the record in progress (l2 set, l4 not yet seen)
+    bool have_pending = false;
+    bool carry_bad = false; std::string carry_hdr;
+
+    bool fastq_block(const Block &blk) {
+        const uint8_t *base = blk.buf.data(), *end = base + blk.len;
+        uint32_t P = (uint32_t)std::min<size_t>(threads, std::max<size_t>(1, blk.len / 16384));
+        std::vector<const uint8_t *> cutp(P + 1);
+        cutp[0] = base; cutp[P] = end;
+        for (uint32_t i = 1; i < P; i++) {
+            const uint8_t *q = base + blk.len * i / P;
+            if (q < cutp[i - 1]) q = cutp[i - 1];
+            const uint8_t *nl = q < end ? (const uint8_t *)memchr(q, '\n', (size_t)(end - q)) : nullptr;
+            cutp[i] = nl ? nl + 1 : end;
+        }
+        std::vector<Scan1> s1(P);
+        run_parallel(P, [&](uint32_t i) { fastq_pass1(cutp[i], cutp[i + 1], s1[i]); });
+        // serial prefix: real start state and output offsets of every piece
+        std::vector<uint8_t> st(P + 1);
+        std::vector<uint64_t> seq0(P + 1), byte0(P + 1);
+        st[0] = fq_state; seq0[0] = have_pending ? 1 : 0; byte0[0] = have_pending ? pending.size() : 0;
+        for (uint32_t i = 0; i < P; i++) {
+            st[i + 1] = s1[i].end_state[st[i]];
+            seq0[i + 1] = seq0[i] + s1[i].nseq[st[i]];
+            byte0[i + 1] = byte0[i] + s1[i].nbytes[st[i]];
+            n_lines += s1[i].n_lines;
+        }
+        uint8_t *ob = nullptr; uint64_t *ol = nullptr;
+        if (!sink.prepare(seq0[P], byte0[P], &ob, &ol, err)) return false;
+        if (have_pending) { memcpy(ob, pending.data(), pending.size()); ol[0] = pending.size(); }
+        std::vector<Scan2> s2(P);
+        run_parallel(P, [&](uint32_t i) { fastq_pass2(cutp[i], cutp[i + 1], st[i], ob + byte0[i], ol + seq0[i], s2[i]); });
+        // errors in stream order (seqio.go:38-40 fires when the record's 4th line arrives)
+        for (uint32_t i = 0; i < P; i++) {
+            if (carry_bad && s2[i].completed) return bad_id(carry_hdr);
+            if (s2[i].bad_done) return bad_id(s2[i].bad_done_hdr);
+            if (s2[i].started || s2[i].completed) { carry_bad = s2[i].bad_pending; carry_hdr = s2[i].bad_pending_hdr; }
+            if (s1[i].too_long) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
+        }
+        if (blk.tail_too_long) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
+        fq_state = st[P];
+        // a record whose sequence line has been seen but not its 4th line is not a read yet
+        uint64_t n = seq0[P];
+        if (fq_state >= 2 && n > 0) {
+            const uint64_t L = ol[n - 1];
+            uint64_t off = byte0[P] - L;
+            pending.assign(ob + off, ob + off + L);
+            have_pending = true; n--;
+        } else if (fq_state < 2) {
+            have_pending = false;
+        }
+        return sink.commit(n, err);
+    }
+    bool bad_id(const std::string &hdr) {
+        return err.set(HULK_ERR_FASTQ_ID, std::string("read ID in fastq file does not begin with @: ") + hdr);
+    }
+
+    // ---- FASTA (sequential: records are unbounded, lines are not) ----
+    bool fa_have_hdr = false, fa_stopped = false, fa_any_line = false;
+    std::vector<uint8_t> fa_bases; std::vector<uint64_t> fa_lens; uint64_t fa_cur = 0;
+
+    bool fasta_flush_batch(bool final_record) {
+        // everything but the record still being accumulated
+        uint64_t n = fa_lens.size(), nbytes = fa_bases.size() - (final_record ? 0 : fa_cur);
+        if (n == 0) return true;
+        uint8_t *ob; uint64_t *ol;
+        if (!sink.prepare(n, nbytes, &ob, &ol, err)) return false;
+        memcpy(ob, fa_bases.data(), nbytes);
+        memcpy(ol, fa_lens.data(), n * 8);
+        if (!sink.commit(n, err)) return false;
+        fa_bases.erase(fa_bases.begin(), fa_bases.begin() + nbytes);
+        fa_lens.clear();
+        return true;
+    }
+    bool fasta_block(const Block &blk) {
+        if (fa_stopped) return true;
+        const uint8_t *p = blk.buf.data(), *end = p + blk.len;
+        while (p < end) {
+            const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+            if (!nl) nl = end;
+            if ((size_t)(nl - p) >= MAX_TOKEN) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
+            const size_t L = line_len(p, nl);
+            n_lines++;
+            if (L == 0) { fa_stopped = true; return true; }            // sketch.go:103-105: break
+            fa_any_line = true;
+            if (p[0] == '>') {
+                if (fa_have_hdr) {                                      // store the current entry
+                    fa_lens.push_back(fa_cur);
+                    if (fa_bases.size() >= FASTA_BATCH_BYTES && !fasta_flush_batch(true)) return false;
+                } else {
+                    fa_bases.clear();                                   // sequence lines before any header are dropped (l2 = nil)
+                }
+                fa_have_hdr = true; fa_cur = 0;
+            } else {
+                fa_bases.insert(fa_bases.end(), p, p + L); fa_cur += L;
+            }
+            p = nl + 1;
+        }
+        if (blk.tail_too_long) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
+        return true;
+    }
+    bool fasta_end() {
+        // sketch.go:126-135 flushes the final entry unconditionally; with no header line at all the
+        // reference dies on l1[0] = 64 (nil slice) — reported as an error here
+        if (!fa_have_hdr) return err.set(HULK_ERR_FASTA_HEADER, hulk_strerror(HULK_ERR_FASTA_HEADER));
+        fa_lens.push_back(fa_cur);
+        return fasta_flush_batch(true);
+    }
+
+    template <class F> void run_parallel(uint32_t P, F f) {
+        if (P == 1) { f(0); return; }
+        std::vector<std::thread> th;
+        th.reserve(P - 1);
+        for (uint32_t i = 1; i < P; i++) th.emplace_back([&f, i] { f(i); });
+        f(0);
+        for (auto &t : th) t.join();
+    }
+};
+
+int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads, Sink &sink,
+               hulk_ingest_stats *stats, IngestError &err) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n_paths && !paths) { err.set(HULK_ERR_ARG, "NULL path list"); return err.code; }
+    if (threads == 0) { threads = std::thread::hardware_concurrency(); if (threads == 0) threads = 1; if (threads > 16) threads = 16; }
+    BlockReader reader(paths, n_paths);
+    Parser ps(sink, threads, err);
+    bool ok = true;
+    for (;;) {
+        std::unique_ptr<Block> b = reader.next(err);
+        if (!b) { ok = err.code == HULK_OK; break; }
+        ok = fasta ? ps.fasta_block(*b) : ps.fastq_block(*b);
+        reader.recycle(std::move(b));
+        if (!ok || (fasta && ps.fa_stopped)) break;
+    }
+    if (ok && fasta) ok = ps.fasta_end();
+    if (ok) ok = sink.finish(err);
+    if (stats) {
+        stats->n_seqs = sink.n_seqs; stats->total_len = sink.total_len; stats->n_lines = ps.n_lines;
+        stats->bytes_in = reader.bytes_in();
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return ok ? HULK_OK : err.code;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hulk_parse_files(const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads, hulk_batch_fn fn,
+                     void *user, hulk_ingest_stats *stats, char *errbuf, uint64_t errbuf_len) {
+    IngestError err;
+    CallbackSink sink(fn, user);
+    const int rc = run_ingest(paths, n_paths, fasta, threads, sink, stats, err);
+    if (errbuf && errbuf_len) {
+        const std::string &m = rc == HULK_OK ? std::string() : err.msg;
+        const size_t n = std::min<size_t>(m.size(), (size_t)errbuf_len - 1);
+        memcpy(errbuf, m.data(), n); errbuf[n] = 0;
+    }
+    return rc;
+}
+
+int hulk_sketch_files(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads,
+                      hulk_ingest_stats *stats) {
+    if (!ctx) return HULK_ERR_ARG;
+    IngestError err;
+    int rc;
+    {
+        GpuSink sink(ctx);
+        rc = run_ingest(paths, n_paths, fasta, threads, sink, stats, err);
+    }
+    if (rc != HULK_OK) return hulk::ctx_fail(ctx, rc, err.msg.c_str());
+    return HULK_OK;
+}
+
+}  // extern "C"

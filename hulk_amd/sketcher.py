@@ -102,6 +102,17 @@ class GpuSketcher:
         self._chk(self._L.hulk_add_reads(self._ctx, bases.ctypes.data, offsets.ctypes.data,
                                          len(offsets) - 1))
 
+    def sketch_files(self, paths, fasta=False, threads=0):
+        """DataStreamer + FastqHandler + the AddSeq loop (pipeline/sketch.go:40-217) in native code:
+        parse the inputs ([] = STDIN, *.gz gunzipped) and add every read.  Returns the ingest stats."""
+        import ctypes
+        from ._lib import IngestStats
+        from .ingest import _path_array, stats_dict
+        arr, n = _path_array(paths)
+        st = IngestStats()
+        self._chk(self._L.hulk_sketch_files(self._ctx, arr, n, 1 if fasta else 0, threads, ctypes.byref(st)))
+        return stats_dict(st)
+
     def add_reads_device(self, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes):
         """AddSeq for a batch already resident in HBM (raw device pointers)."""
         self._chk(self._L.hulk_add_reads_device(self._ctx, bases_ptr, offsets_ptr, n_reads,

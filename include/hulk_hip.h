@@ -25,6 +25,9 @@
  *                                                                 hulk_get_histogram
  *   interval rule `seqCount % Interval == 0`                      params.interval
  *       src/pipeline/sketch.go:211-215
+ *   DataStreamer.Run + FastqHandler.Run (lines -> reads)          hulk_parse_files (host only),
+ *       src/pipeline/sketch.go:40-79, 99-161; seqio.go:38-40        hulk_sketch_files (+ the AddSeq
+ *                                                                   loop of sketch.go:196-217)
  *
  * Conventions: every call returns HULK_OK (0) or a negative HULK_ERR_*; the message the
  * reference would have passed to log.Fatalf("ERROR---> %v") is available from
@@ -56,11 +59,15 @@ extern "C" {
 #define HULK_ERR_BINS (-8)       /* "histogram must have at least 2 bins"     histosketch.go:66 */
 #define HULK_ERR_NEG_BINS (-9)   /* "negative value used for number of k-mer spectrum bins: %d" kmerspectrum.go:34 */
 #define HULK_ERR_NO_SEQ (-10)    /* "no sequences received"                   pipeline/sketch.go:238 */
+#define HULK_ERR_FASTQ_ID (-11)  /* "read ID in fastq file does not begin with @: %v"  seqio.go:39 */
+#define HULK_ERR_LINE_TOO_LONG (-12) /* "bufio.Scanner: token too long" (a line of >= 64 KiB; sketch.go:53,76 log.Fatal(scanner.Err())) */
 #define HULK_ERR_ARG (-30)       /* bad argument to this ABI (NULL pointer, bad shard, ...) */
 #define HULK_ERR_HIP (-31)       /* HIP runtime failure; hulk_last_error has the hipError string */
 #define HULK_ERR_NO_DEVICE (-32) /* no usable gfx950 device */
 #define HULK_ERR_READ_TOO_LONG (-33) /* read longer than this build's per-read limit */
 #define HULK_ERR_STATE (-34)     /* call not valid in this state (e.g. add after finish) */
+#define HULK_ERR_IO (-35)        /* open/read/gzip failure; the message is the one Go's os/gzip error carries */
+#define HULK_ERR_FASTA_HEADER (-36) /* --fasta input without any '>' line (the reference panics on l1[0] = 64, sketch.go:127) */
 
 /* How the CWS parameter matrices r, c, b (histosketch.go:95-126) are produced. */
 #define HULK_CWS_GO_COMPAT 0     /* go_rng Gamma/Uniform over Go math/rand, seed 1 (default) */
@@ -112,6 +119,32 @@ int hulk_add_reads(hulk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets,
  * `bases_bytes` is the size of the bases allocation.  Length validation happens on device. */
 int hulk_add_reads_device(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets,
                           uint64_t n_reads, uint32_t max_read_len, uint64_t bases_bytes);
+
+/* ---- host ingest: DataStreamer.Run + FastqHandler.Run ------------------------
+ * Inputs are read in order (n_paths == 0: STDIN; a name whose last '.'-separated element is "gz" is
+ * gunzipped), cut into lines the way bufio.Scanner/ScanLines does ('\n', one trailing '\r' dropped,
+ * unterminated last line kept, a line of >= 65536 bytes is HULK_ERR_LINE_TOO_LONG) and grouped into
+ * reads by the reference's slot machine: FASTQ = l1..l3 take the next NON-EMPTY line, l4 takes the
+ * next line whatever it is, the read is l2 and its l1 must start with '@' (checked when l4 arrives,
+ * so a truncated last record is dropped silently); --fasta = lines of a '>' record concatenated,
+ * parsing stops at the first empty line.  `threads` parser threads (0 = one per core, at most 16). */
+typedef struct hulk_ingest_stats {
+    uint64_t n_seqs;      /* seqCount of SeqMinimizer.Run */
+    uint64_t total_len;   /* lengthTotal */
+    uint64_t n_lines;
+    uint64_t bytes_in;    /* bytes read (after gunzip) */
+    double   seconds;
+} hulk_ingest_stats;
+/* Called once per parsed batch, in input order; buffers are only valid during the call. */
+typedef int (*hulk_batch_fn)(void *user, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads);
+/* Parse only (no GPU, no context): every batch goes to `fn`.  Error text -> errbuf. */
+int hulk_parse_files(const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads,
+                     hulk_batch_fn fn, void *user, hulk_ingest_stats *stats, char *errbuf, uint64_t errbuf_len);
+/* Parse and AddSeq every read (pinned double-buffered staging, copies and kernels asynchronous on
+ * the context's stream while the next block is read and parsed).  The interval rule applies as in
+ * hulk_add_reads; the caller still ends the run with hulk_finish (Flush + StopWork). */
+int hulk_sketch_files(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads,
+                      hulk_ingest_stats *stats);
 
 /* Intervals are flushed in batches: up to hulk_batch_size() consecutive sketching intervals are
  * binned into separate k-mer spectra by one kernel launch and then pushed through count-min + CWS

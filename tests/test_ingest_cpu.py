@@ -1,0 +1,211 @@
+"""Native host ingest (hulk_parse_files: no GPU needed) against the literal restatement of the
+reference's DataStreamer/FastqHandler (oracle/linepump.py, src/pipeline/sketch.go:40-161)."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from hulk_amd import ingest
+from hulk_amd._lib import HulkError
+from oracle import linepump
+from conftest import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def native(paths, fasta=False, threads=0):
+    b, o, st = ingest.parse_files(paths, fasta=fasta, threads=threads)
+    seqs = [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(len(o) - 1)]
+    assert st["n_seqs"] == len(seqs) and st["total_len"] == sum(map(len, seqs))
+    return seqs
+
+
+def restated(paths, fasta=False):
+    return [s if s is not None else b"" for s in linepump.sequences(paths, fasta)]
+
+
+def write(tmp_path, name, data):
+    p = str(tmp_path / name)
+    if name.endswith(".gz"):
+        with gzip.open(p, "wb") as fh:
+            fh.write(data)
+    else:
+        with open(p, "wb") as fh:
+            fh.write(data)
+    return p
+
+
+def test_reference_fixture():
+    p = os.path.join(GOLDEN, "test-reads-small.fq.gz")
+    got = native([p])
+    assert got == restated([p]) and len(got) == 1000 and all(len(s) == 100 for s in got)
+
+
+FASTQ_CASES = {
+    "plain": b"@r1\nACGT\n+\nIIII\n@r2\nGGCC\n+\nIIII\n",
+    "no_final_newline": b"@r1\nACGT\n+\nIIII\n@r2\nGGCC\n+\nIIII",
+    "crlf": b"@r1\r\nACGT\r\n+\r\nIIII\r\n@r2\r\nGGCC\r\n+\r\nIIII\r\n",
+    "empty_lines_skipped": b"\n\n@r1\n\nACGT\n\n\n+\nIIII\n\n@r2\nGGCC\n+\nIIII\n",
+    "empty_fourth_line_completes": b"@r1\nACGT\n+\n\n@r2\nGGCC\n+\nIIII\n",
+    "truncated_last_record": b"@r1\nACGT\n+\nIIII\n@r2\nGGCC\n+\n",
+    "truncated_after_seq": b"@r1\nACGT\n+\nIIII\n@r2\nGGCC\n",
+    "truncated_after_header": b"@r1\nACGT\n+\nIIII\n@r2\n",
+    "bad_header_in_truncated_record": b"@r1\nACGT\n+\nIIII\nr2\nGGCC\n+\n",
+    "cr_only_line_is_empty": b"@r1\nACGT\n+\nIIII\n\r\n@r2\nGGCC\n+\nIIII\n",
+    "lowercase_and_n": b"@r1\nacgtNNnn\n+\nIIIIIIII\n",
+    "empty": b"",
+    "only_newlines": b"\n\n\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(FASTQ_CASES))
+@pytest.mark.parametrize("gz", [False, True])
+def test_fastq_cases(tmp_path, name, gz):
+    p = write(tmp_path, "x.fq.gz" if gz else "x.fq", FASTQ_CASES[name])
+    assert native([p]) == restated([p])
+
+
+def test_fastq_bad_id_message(tmp_path):
+    p = write(tmp_path, "bad.fq", b"@r1\nACGT\n+\nIIII\nr2 oops\nGGCC\n+\nIIII\n@r3\nAAAA\n+\nIIII\n")
+    with pytest.raises(linepump.PumpError) as e0:
+        restated([p])
+    with pytest.raises(HulkError) as e1:
+        native([p])
+    assert e1.value.message == str(e0.value) == "read ID in fastq file does not begin with @: r2 oops"
+    assert e1.value.code == -11
+
+
+def test_token_too_long(tmp_path):
+    ok = b"@r\n" + b"A" * 65535 + b"\n+\n" + b"I" * 65535 + b"\n"
+    p = write(tmp_path, "ok.fq", ok)
+    assert native([p]) == restated([p]) and len(native([p])[0]) == 65535
+    bad = b"@r\n" + b"A" * 65536 + b"\n+\nI\n"
+    p2 = write(tmp_path, "bad.fq", bad)
+    with pytest.raises(linepump.PumpError):
+        restated([p2])
+    with pytest.raises(HulkError) as e:
+        native([p2])
+    assert e.value.message == "bufio.Scanner: token too long" and e.value.code == -12
+    p3 = write(tmp_path, "nonl.fq", b"A" * 300000)          # no newline at all
+    with pytest.raises(HulkError) as e:
+        native([p3])
+    assert e.value.code == -12
+
+
+def test_multiple_files_are_one_line_stream(tmp_path):
+    # a record may straddle inputs; an unterminated last line is a line of ITS input
+    a = write(tmp_path, "a.fq", b"@r1\nACGT\n+\nIIII\n@r2\nGG")
+    b = write(tmp_path, "b.fq.gz", b"+\nIIII\n@r3\nTTTT\n+\nIIII\n")
+    got = native([a, b])
+    assert got == restated([a, b]) == [b"ACGT", b"GG", b"TTTT"]   # "GG" ends a.fq as its own line
+    c = write(tmp_path, "c.fq", b"@r4\nCCCC\n+\nIIII\n")
+    assert native([a, b, c]) == restated([a, b, c])
+
+
+def test_open_and_gzip_errors(tmp_path):
+    with pytest.raises(HulkError) as e:
+        native([str(tmp_path / "missing.fq")])
+    assert e.value.code == -35 and "no such file" in e.value.message.lower()
+    p = write(tmp_path, "notgz.fq", b"@r\nACGT\n+\nIIII\n")
+    fake = str(tmp_path / "fake.fq.gz")
+    os.rename(p, fake)
+    with pytest.raises(HulkError) as e:
+        native([fake])
+    assert e.value.message == "gzip: invalid header"
+
+
+FASTA_CASES = {
+    "two_records": b">a desc\nACGT\nGGCC\n>b\nTTTT\n",
+    "no_final_newline": b">a\nACGT\nGG",
+    "stops_at_empty_line": b">a\nACGT\n\n>b\nTTTT\n",
+    "lines_before_first_header_dropped": b"ACGT\n>a\nGGGG\n",
+    "empty_record": b">a\n>b\nACGT\n",
+    "crlf": b">a\r\nAC\r\nGT\r\n",
+    "header_only": b">a\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(FASTA_CASES))
+def test_fasta_cases(tmp_path, name):
+    p = write(tmp_path, "x.fa", FASTA_CASES[name])
+    assert native([p], fasta=True) == restated([p], fasta=True)
+
+
+def test_fasta_without_header_is_an_error(tmp_path):
+    p = write(tmp_path, "x.fa", b"ACGT\nGGCC\n")
+    with pytest.raises(linepump.PumpError):
+        restated([p], fasta=True)
+    with pytest.raises(HulkError) as e:
+        native([p], fasta=True)
+    assert e.value.code == -36
+
+
+def _random_fastq(rng, n, quirks):
+    out = []
+    for i in range(n):
+        L = int(rng.integers(30, 300))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), size=L))
+        rec = [b"@read%d" % i, seq, b"+", b"I" * L]
+        if quirks:
+            r = rng.random()
+            if r < 0.02:
+                rec.insert(int(rng.integers(0, 3)), b"")       # empty line before l1, l2 or l3: skipped
+            elif r < 0.03:
+                rec[3] = b""                                     # empty quality line: completes the record
+            elif r < 0.04:
+                rec = [x + b"\r" for x in rec]
+        out.append(b"\n".join(rec) + b"\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_many_blocks_and_pieces(tmp_path, threads):
+    """~6 MB of FASTQ with line-level quirks, parsed with 128 KiB blocks so that records, empty lines
+    and the 4-state machine cross hundreds of block and piece borders."""
+    rng = np.random.default_rng(7)
+    data = _random_fastq(rng, 18000, quirks=True)
+    p = write(tmp_path, "big.fq", data)
+    want = restated([p])
+    code = ("import sys; sys.path.insert(0, %r); from hulk_amd import ingest; import hashlib;"
+            "b, o, st = ingest.parse_files([%r], threads=%d);"
+            "print(st['n_seqs'], hashlib.sha256(b.tobytes()).hexdigest(), hashlib.sha256(o.tobytes()).hexdigest())"
+            % (ROOT, p, threads))
+    env = dict(os.environ, HULK_INGEST_BLOCK="131072")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import hashlib
+    n, hb, ho = out.stdout.split()
+    offs = np.zeros(len(want) + 1, dtype=np.uint64)
+    np.cumsum([len(s) for s in want], out=offs[1:])
+    assert int(n) == len(want)
+    assert hb == hashlib.sha256(b"".join(want)).hexdigest()
+    assert ho == hashlib.sha256(offs.tobytes()).hexdigest()
+
+
+def test_misframed_stream_reports_the_same_first_error(tmp_path):
+    """An empty line between '+' and the qualities is taken as l4, so the quality line becomes the next
+    header: both sides must stop at the same record with the same message, whatever the piece borders."""
+    rng = np.random.default_rng(11)
+    good = _random_fastq(rng, 3000, quirks=False)
+    bad = b"@x\nACGT\n+\n\nIIII\n" + _random_fastq(rng, 3000, quirks=False)
+    p = write(tmp_path, "mis.fq", good + bad)
+    with pytest.raises(linepump.PumpError) as e0:
+        restated([p])
+    code = ("import sys; sys.path.insert(0, %r); from hulk_amd import ingest\n"
+            "try:\n    ingest.parse_files([%r], threads=4)\nexcept Exception as e:\n    print(e.message)" % (ROOT, p))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         env=dict(os.environ, HULK_INGEST_BLOCK="131072"), timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip() == str(e0.value) == "read ID in fastq file does not begin with @: IIII"
+
+
+def test_stdin(tmp_path):
+    data = FASTQ_CASES["empty_lines_skipped"]
+    code = ("import sys; sys.path.insert(0, %r); from hulk_amd import ingest;"
+            "b, o, st = ingest.parse_files([]); print(bytes(b).decode(), list(map(int, o)))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], input=data, capture_output=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.decode().strip() == "ACGTGGCC [0, 4, 8]"
