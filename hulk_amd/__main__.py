@@ -1,16 +1,13 @@
 """`python -m hulk_amd sketch ...` — the `hulk sketch` flag surface (cmd/root.go:62-66,
 cmd/sketch.go:50-59) over the GPU path, writing the reference's JSON sketch.
 
-Host-side plumbing only (FASTQ/FASTA line handling follows src/pipeline/sketch.go:40-161); every
-numeric step runs in libhulkhip.  `smash`, --khf/--kmv and --profiling are not provided.
+Flag handling, log lines and the JSON writer only: the line pump (src/pipeline/sketch.go:40-161) and
+every numeric step run in libhulkhip.  `smash`, --khf/--kmv and --profiling are not provided.
 """
 import argparse
-import gzip
 import os
 import sys
 import time
-
-import numpy as np
 
 from . import GpuSketcher, HulkError, spectrum_size
 from .sketchio import HULKdata, VERSION
@@ -18,48 +15,6 @@ from .sketchio import HULKdata, VERSION
 
 def log(msg):
     print(time.strftime("%Y/%m/%d %H:%M:%S ") + msg, flush=True)
-
-
-def read_lines(paths):
-    """DataStreamer.Run: one item per line, gzip when the name ends in .gz, STDIN when no file."""
-    if not paths:
-        for line in sys.stdin.buffer:
-            yield line.rstrip(b"\n")
-        return
-    for p in paths:
-        op = gzip.open if p.split(".")[-1] == "gz" else open
-        with op(p, "rb") as fh:
-            for line in fh:
-                yield line.rstrip(b"\n")
-
-
-def sequences(lines, fasta):
-    """FastqHandler.Run: FASTQ = groups of 4 non-empty lines (empty lines are skipped because an
-    empty line stays nil in the reference); FASTA = sequence lines concatenated per '>' record."""
-    if fasta:
-        seq, have = [], False
-        for line in lines:
-            if len(line) == 0:
-                break
-            if line[0:1] == b">":
-                if have:
-                    yield b"".join(seq)
-                seq, have = [], True
-            else:
-                seq.append(line)
-        if have:
-            yield b"".join(seq)
-        return
-    slot = []
-    for line in lines:
-        if len(line) == 0:
-            continue
-        slot.append(line)
-        if len(slot) == 4:
-            if slot[0][0:1] != b"@":
-                raise HulkError(-30, "read ID in fastq file does not begin with @")   # seqio.go:38-40
-            yield slot[1]
-            slot = []
 
 
 def run_sketch(a):
@@ -85,25 +40,12 @@ def run_sketch(a):
     log("initialising sketching pipeline...")
     g = GpuSketcher(a.kmerSize, a.windowSize, a.sketchSize, a.interval, a.decayRatio, device=a.device)
     log("finding minimizers...")
-    batch, n_in_batch, seq_count, length_total = [], 0, 0, 0
-
-    def push():
-        nonlocal batch
-        if batch:
-            offsets = np.zeros(len(batch) + 1, dtype=np.uint64)
-            offsets[1:] = np.cumsum([len(s) for s in batch])
-            g.add_reads(np.frombuffer(b"".join(batch), dtype=np.uint8), offsets)
-            batch = []
-
-    for seq in sequences(read_lines(a.fastq), a.fasta):
-        batch.append(seq)
-        seq_count += 1
-        length_total += len(seq)
-        if seq_count % 100000 == 0:
-            log(f"\tprocessed {seq_count} sequences")
-        if len(batch) >= 1 << 16:
-            push()
-    push()
+    # DataStreamer + FastqHandler + the AddSeq loop run in libhulkhip (hulk_sketch_files); the
+    # per-100k progress lines of sketch.go:204-207 are printed once the input has been consumed
+    st = g.sketch_files(a.fastq, fasta=a.fasta, threads=a.processors if a.processors > 1 else 0)
+    seq_count, length_total = st["n_seqs"], st["total_len"]
+    for done in range(100000, seq_count + 1, 100000):
+        log(f"\tprocessed {done} sequences")
     log("generating final histosketch of k-mer spectra...")
     if seq_count == 0:
         raise HulkError(-10, "no sequences received")

@@ -1,0 +1,103 @@
+"""hulk_sketch_files on the GPU: the native ingest feeding the HIP path must give the sketch that
+hulk_add_reads gives for the same reads, and the oracle's."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, pack_reads
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gpu():
+    import hulk_amd
+    return hulk_amd
+
+
+def test_fixture_file_matches_add_reads_and_oracle(fq_reads):
+    from oracle import pyorc
+    p = os.path.join(GOLDEN, "test-reads-small.fq.gz")
+    a = gpu().GpuSketcher(21, 9, 128)
+    st = a.sketch_files([p])
+    a.finish()
+    assert st["n_seqs"] == 1000 and st["total_len"] == 100000
+    b = gpu().GpuSketcher(21, 9, 128)
+    b.add_reads(*pack_reads(fq_reads))
+    b.finish()
+    ma, wa = a.sketch(); mb, wb = b.sketch()
+    assert np.array_equal(ma, mb) and np.array_equal(wa, wb)
+    assert a.counters() == b.counters()
+    o = pyorc.Sketcher(21, 9, 128)
+    for r in fq_reads:
+        o.add_read(r)
+    o.finish()
+    mo, wo = o.sketch()
+    assert np.array_equal(ma, mo) and np.allclose(wa, wo, rtol=1e-12, atol=0)
+    a.close(); b.close(); o.close()
+
+
+def test_intervals_across_many_blocks(tmp_path):
+    """60k reads with an interval of 7000, parsed in 128 KiB blocks: batches, intervals and the two
+    staging buffers interleave; result = one hulk_add_reads call over the same reads."""
+    from hulk_amd import synth
+    n, L = 60000, 150
+    bases, offsets = synth.reads_numpy(0, n, L)
+    raw = bases[:n * L].tobytes()
+    p = str(tmp_path / "r.fq")
+    with open(p, "wb") as fh:
+        fh.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, raw[i * L:(i + 1) * L], b"I" * L) for i in range(n)))
+    code = ("import sys; sys.path.insert(0, %r); import hulk_amd, hashlib\n"
+            "g = hulk_amd.GpuSketcher(15, 9, 64, interval=7000)\n"
+            "st = g.sketch_files([%r], threads=4); g.finish(); m, w = g.sketch()\n"
+            "print(st['n_seqs'], hashlib.sha256(m.tobytes() + w.tobytes()).hexdigest())" % (ROOT, p))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         env=dict(os.environ, HULK_INGEST_BLOCK="131072"), timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import hashlib
+    g = gpu().GpuSketcher(15, 9, 64, interval=7000)
+    g.add_reads(bases, offsets)
+    g.finish()
+    m, w = g.sketch()
+    g.close()
+    cnt, h = out.stdout.split()
+    assert int(cnt) == n and h == hashlib.sha256(m.tobytes() + w.tobytes()).hexdigest()
+
+
+def test_fasta_and_errors(tmp_path):
+    from hulk_amd import synth
+    from hulk_amd._lib import HulkError
+    bases, _ = synth.reads_numpy(5, 3, 5000)
+    seqs = [bases[i * 5000:(i + 1) * 5000].tobytes() for i in range(3)]
+    p = str(tmp_path / "g.fa.gz")
+    with gzip.open(p, "wb") as fh:
+        for i, s in enumerate(seqs):
+            fh.write(b">c%d\n" % i + b"\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + b"\n")
+    a = gpu().GpuSketcher(11, 9, 32)
+    st = a.sketch_files([p], fasta=True)
+    a.finish()
+    assert st["n_seqs"] == 3 and st["total_len"] == 15000
+    b = gpu().GpuSketcher(11, 9, 32)
+    b.add_reads(*pack_reads(seqs))
+    b.finish()
+    assert np.array_equal(a.sketch()[0], b.sketch()[0]) and np.array_equal(a.sketch()[1], b.sketch()[1])
+    a.close(); b.close()
+    # a read shorter than w + k - 1 is the reference's fatal error (minimizer.go:75)
+    q = str(tmp_path / "short.fq")
+    open(q, "wb").write(b"@r\nACGTACGT\n+\nIIIIIIII\n")
+    c = gpu().GpuSketcher(21, 9, 32)
+    with pytest.raises(HulkError) as e:
+        c.sketch_files([q])
+    assert e.value.message == "sequence length must be >= w + k - 1"
+    c.close()
+    d = gpu().GpuSketcher(21, 9, 32)
+    bad = str(tmp_path / "bad.fq")
+    open(bad, "wb").write(b"r1\nACGT\n+\nIIII\n")
+    with pytest.raises(HulkError) as e:
+        d.sketch_files([bad])
+    assert e.value.message == "read ID in fastq file does not begin with @: r1"
+    d.close()
