@@ -93,6 +93,7 @@ def main(argv=None):
     sm.add_argument("--recursive", action="store_true")
     sm.add_argument("-a", "--algorithm", default="histosketch")
     sm.add_argument("-m", "--metric", default="jaccard")
+    sm.add_argument("--bannerMatrix", action="store_true")
     sm.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
     try:
@@ -103,10 +104,14 @@ def main(argv=None):
             log("checking parameters and collecting sketches...")
             log(f"\talgorithm: {a.algorithm}")
             log(f"\tk-mer size: {a.kmerSize}")
-            order, _ = smash(a.sketchDir, a.outFile, a.kmerSize, a.algorithm, a.metric, a.recursive, a.device)
+            log(f"\tcreate matrix for banner: {'true' if a.bannerMatrix else 'false'}")
+            order, _ = smash(a.sketchDir, a.outFile, a.kmerSize, a.algorithm, a.metric, a.recursive, a.device,
+                             banner_matrix=a.bannerMatrix)
             log(f"\tnumber of sketch objects: {len(order)}")
             log("HULK SMASH!")
             log(f"\twritten similarity matrix to disk: {a.outFile}.hulk-matrix.csv")
+            if a.bannerMatrix:
+                log(f"\twritten banner matrix to disk: {a.outFile}.banner-matrix.csv")
             log("finished")
             return 0
         a.fastq = [f for grp in a.fastq for f in grp if f]

@@ -80,8 +80,12 @@ def find_sketch(data, ksize, algo, path):
     return hit[0]
 
 
-def smash(sketch_dir, out_file, ksize=21, algo="histosketch", metric="jaccard", recursive=False, device=0):
-    """runSmash + makeMatrix: writes <out_file>.hulk-matrix.csv and returns (ordering, distances)."""
+def smash(sketch_dir, out_file, ksize=21, algo="histosketch", metric="jaccard", recursive=False, device=0,
+          banner_matrix=False):
+    """runSmash + makeMatrix: writes <out_file>.hulk-matrix.csv and returns (ordering, distances).
+    banner_matrix: also <out_file>.banner-matrix.csv (makeBannerMatrix, cmd/smash.go:229-261): one line
+    per sketch = its mins + the banner label; the reference iterates a Go map (random order), here the
+    sorted file order is used."""
     if metric not in AVAIL_METRICS:
         raise HulkError(-30, f"supplied distance metric is not available: {metric}\nplease select one of the following: {AVAIL_METRICS}")
     if algo not in AVAIL_ALGORITHMS:
@@ -111,4 +115,8 @@ def smash(sketch_dir, out_file, ksize=21, algo="histosketch", metric="jaccard", 
         fh.write(",".join(go_csv_field(f) for f in ordering) + "\n")
         for row in dist:
             fh.write(",".join(go_format_f2(100 - (d * 100)) for d in row) + "\n")
+    if banner_matrix:
+        with open(out_file + ".banner-matrix.csv", "w", encoding="utf-8", newline="") as fh:
+            for f, a in zip(ordering, sk):
+                fh.write(",".join([str(int(v)) for v in a.mins] + [go_csv_field(loaded[f].banner_label)]) + "\n")
     return ordering, dist

@@ -1,0 +1,117 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through size-independent properties
+(the oracle needs hours at these sizes): invariance of the sketch under the interval-batch size and
+under the way reads are cut into calls, linearity of the k-mer spectrum, counters, determinism, and a
+prefix of the stream against the oracle.
+
+C2: 10^7 reads x 150 bp, k=21, w=9, sketchSize=512, interval=100k.
+C3-shaped: k=31, sketchSize=1024, decay on (22.7 GB of tables) on 5*10^6 reads.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+L = 150
+
+
+def gpu():
+    import hulk_amd
+    return hulk_amd
+
+
+def _run_stream(k, S, interval, decay, n_reads, chunk, batch):
+    """Sketch synthetic reads [0, n_reads) fed as device-resident chunks of `chunk` reads."""
+    import torch
+    from hulk_amd import synth
+    old = os.environ.get("HULK_BATCH")
+    os.environ["HULK_BATCH"] = str(batch)
+    try:
+        g = gpu().GpuSketcher(k, 9, S, interval, decay)
+    finally:
+        if old is None:
+            os.environ.pop("HULK_BATCH", None)
+        else:
+            os.environ["HULK_BATCH"] = old
+    assert g.batch_size == batch
+    first = 0
+    while first < n_reads:
+        n = min(chunk, n_reads - first)
+        b, off = synth.reads_torch(first, n, L)
+        torch.cuda.synchronize()            # generated on torch's stream; the context runs on its own
+        g.add_reads_device(b.data_ptr(), off.data_ptr(), n, L, b.numel())
+        torch.cuda.synchronize()            # b/off are released when they go out of scope
+        first += n
+    g.finish()
+    m, w = g.sketch()
+    c = g.counters()
+    g.close()
+    return m, w, c
+
+
+def test_c2_full_size_invariances():
+    n = 10_000_000
+    m1, w1, c1 = _run_stream(21, 512, 100_000, 1.0, n, 1_600_000, 16)
+    assert c1["n_reads"] == n and c1["total_len"] == n * L
+    assert 26.5 * n < c1["n_minimizers"] < 27.5 * n           # ~27.0 distinct minimizers per random 150 bp read
+    assert m1.max() < 21 ** 4
+    assert np.all(np.isfinite(w1)) and np.all(w1 < np.finfo(np.float64).max)
+    # other batch size, other call boundaries (not multiples of the interval): bit-identical sketch
+    m2, w2, c2 = _run_stream(21, 512, 100_000, 1.0, n, 1_234_567, 5)
+    assert np.array_equal(m1, m2) and np.array_equal(w1, w2) and c1 == c2
+    # determinism of the two-stream pipeline
+    m3, w3, _ = _run_stream(21, 512, 100_000, 1.0, n, 1_600_000, 16)
+    assert np.array_equal(m1, m3) and np.array_equal(w1, w3)
+
+
+def test_c2_prefix_against_oracle():
+    """The first 3 intervals of the C2 stream (300k reads) against the CPU oracle, C2 parameters."""
+    from oracle import pyorc
+    from hulk_amd import synth
+    n = 300_000
+    m, w, c = _run_stream(21, 512, 100_000, 1.0, n, 170_000, 16)
+    bases, offsets = synth.reads_numpy(0, n, L)
+    o = pyorc.Sketcher(21, 9, 512, 0, 1.0, 100_000)
+    o.add_reads(bases, offsets)
+    o.finish()
+    mo, wo = o.sketch()
+    assert o.counters()["n_minimizers"] == c["n_minimizers"]
+    assert np.array_equal(m, mo)
+    assert np.allclose(w, wo, rtol=1e-9, atol=0)
+    o.close()
+
+
+def test_spectrum_linearity_full_interval():
+    """hist(A u B) = hist(A) + hist(B) on two full 100k-read intervals, and sum(hist) = #minimizers."""
+    import torch
+    from hulk_amd import synth
+    g = gpu().GpuSketcher(21, 9, 8)                    # no interval: everything stays in one spectrum
+    parts = []
+    for first, n in ((0, 100_000), (100_000, 100_000)):
+        h = gpu().GpuSketcher(21, 9, 8)
+        b, off = synth.reads_torch(first, n, L)
+        torch.cuda.synchronize()
+        h.add_reads_device(b.data_ptr(), off.data_ptr(), n, L, b.numel())
+        g.add_reads_device(b.data_ptr(), off.data_ptr(), n, L, b.numel())
+        torch.cuda.synchronize()
+        parts.append(h.histogram().astype(np.uint64))
+        assert int(parts[-1].sum()) == h.counters()["n_minimizers"]
+        h.close()
+    both = g.histogram().astype(np.uint64)
+    assert np.array_equal(both, parts[0] + parts[1])
+    assert int(both.sum()) == g.counters()["n_minimizers"]
+    assert (both > 0).mean() > 0.99                    # ~all 194,481 bins used per interval
+    g.close()
+
+
+def test_c3_shape_drift_batch_invariance():
+    """k=31, sketchSize=1024, concept drift on (decay 0.02): 22.7 GB of CWS tables resident; the sketch
+    must not depend on how many intervals are flushed per pass over the table."""
+    n = 5_000_000
+    m1, w1, c1 = _run_stream(31, 1024, 100_000, 0.02, n, 1_600_000, 16)
+    m2, w2, c2 = _run_stream(31, 1024, 100_000, 0.02, n, 900_001, 3)
+    assert c1 == c2 and c1["n_reads"] == n
+    assert np.array_equal(m1, m2) and np.array_equal(w1, w2)
+    assert m1.max() < 31 ** 4 and np.all(np.isfinite(w1))

@@ -229,6 +229,7 @@ def test_bin_then_flush_batch_equals_interval_rule():
         o = pyorc.Sketcher(k, w, S, 0, 1.0, interval)
         for step in range(3):
             b, off = synth.reads_torch(step * interval * T, interval * T, 120)
+            torch.cuda.synchronize()        # generated on torch's stream; the context runs on its own
             g.bin_reads_device(b.data_ptr(), off.data_ptr(), interval * T, 120, b.numel(), interval)
             g.flush_batch(T)
             hb, ho = synth.reads_numpy(step * interval * T, interval * T, 120)

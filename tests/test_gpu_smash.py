@@ -75,5 +75,11 @@ def test_smash_cli_end_to_end(tmp_path):
         want = pyorc.smash_matrix(np.stack(mins)[idx], np.stack(weights)[idx], metric)
         for r, line in enumerate(rows[1:]):
             assert line == ",".join(go_format_f2(100 - v * 100) for v in want[r])
+    # --bannerMatrix (cmd/smash.go:229-261): mins of every sketch + its banner label
+    assert main(["smash", "-d", str(d), "-k", "15", "-o", out, "--bannerMatrix"]) == 0
+    brow = open(out + ".banner-matrix.csv").read().splitlines()
+    assert len(brow) == 3
+    for line, f in zip(brow, sorted(names)):
+        assert line == ",".join(str(int(v)) for v in mins[names.index(f)]) + ",blank"
     assert main(["smash", "-d", str(d), "-m", "euclidean", "-o", out]) == 1     # not in availMetrics
     assert main(["smash", "-d", str(d), "-k", "21", "-o", out]) == 1            # no sketch with that k
