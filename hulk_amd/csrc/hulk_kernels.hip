@@ -24,6 +24,7 @@ namespace {
 constexpr uint64_t TAB_EMPTY = 0x00000000000000FFull;   // never a minimizer value (see k_minimizer_bin)
 constexpr uint64_t X_NONE = ~0ull;
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void wave_sync() {
     // one wave owns its LDS region: program order is enough for the hardware, this stops the
@@ -1365,26 +1366,43 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
     }
 }
 
-// Wave-wide minimum of 8 independent (non-NaN) values with DPP-modified v_min_f32: 6 instructions per
-// value, no LDS traffic; lane 63 ends with the wave minimum.  Written as ONE asm block with the 8
-// values interleaved per step so that no DPP source was written by the two preceding instructions
-// (the VALU->DPP read hazard needs 2 wait states; hipcc emits mov+mov_dpp+canonicalise+min per step
-// for the equivalent builtin sequence, 4x the instructions).
-__device__ __forceinline__ void wave_min8_to_lane63(float (&m)[8]) {
-#define HULK_DPP_STEP(ctrl)                                                   \
-    "v_min_f32_dpp %0, %0, %0 " ctrl "\n\t" "v_min_f32_dpp %1, %1, %1 " ctrl "\n\t"   \
-    "v_min_f32_dpp %2, %2, %2 " ctrl "\n\t" "v_min_f32_dpp %3, %3, %3 " ctrl "\n\t"   \
-    "v_min_f32_dpp %4, %4, %4 " ctrl "\n\t" "v_min_f32_dpp %5, %5, %5 " ctrl "\n\t"   \
-    "v_min_f32_dpp %6, %6, %6 " ctrl "\n\t" "v_min_f32_dpp %7, %7, %7 " ctrl "\n\t"
+// Wave-wide minima of 8 independent (non-NaN) values, transposed: 19 instructions instead of the 48
+// of six DPP butterfly steps per value (and hipcc emits mov+mov_dpp+canonicalise+min per step for the
+// equivalent builtins, 4x that again — hence one asm block).
+// v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / 16-lane rows between two
+// registers, so one swap + one v_min folds two rows' partial minima at once and halves the number of
+// live registers: 8 -> 4 (halves) -> 2 (rows); the two survivors are folded over 8-lane halves with
+// row_ror:8, merged into one register (lanes 8..15 of every row take the second) and finished with
+// three DPP steps inside groups of 8 lanes.  Lane l returns the wave minimum of value l / 8.
+__device__ __forceinline__ float wave_min8_by_row(float (&m)[8]) {
+    // one block: the swaps need 2 wait states after a VALU write of either operand (s_nop), DPP sources too
     asm volatile("s_nop 1\n\t"
-                 HULK_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 HULK_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 HULK_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
-                 HULK_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
-                 HULK_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 HULK_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "v_permlane32_swap_b32 %0, %4\n\t"        // lanes 0..31: value j, lanes 32..63: value j+4
+                 "v_permlane32_swap_b32 %1, %5\n\t"
+                 "v_permlane32_swap_b32 %2, %6\n\t"
+                 "v_permlane32_swap_b32 %3, %7\n\t"
+                 "v_min_f32 %0, %0, %4\n\t"
+                 "v_min_f32 %2, %2, %6\n\t"
+                 "v_min_f32 %1, %1, %5\n\t"
+                 "v_min_f32 %3, %3, %7\n\t"
+                 "v_permlane16_swap_b32 %0, %2\n\t"        // 16-lane row q: value 2q
+                 "s_nop 0\n\t"
+                 "v_permlane16_swap_b32 %1, %3\n\t"        // 16-lane row q: value 2q+1
+                 "v_min_f32 %0, %0, %2\n\t"
+                 "v_min_f32 %1, %1, %3\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %1 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xc\n\t"   // lanes 8..15 of each row
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                  : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]));
-#undef HULK_DPP_STEP
+    return m[0];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1419,28 +1437,24 @@ __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
     }
     const uint32_t gomask = batch_gomask(st, fb);
     const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    const int lane = tid & 63;
     floatx4 rc_next = *(const floatx4 *)(rcp32 + col);
     for (int t = 0; t < (int)fb.count; t++) {
         const floatx4 rc = rc_next;
         if (t + 1 < (int)fb.count) rc_next = *(const floatx4 *)(rcp32 + (size_t)(t + 1) * row_stride + col);
         if (!((gomask >> t) & 1u)) continue;
         float m[SCAN_ROWS];
+        // v_mul_f32 x4 + v_min3_f32 x2 per row.  (v_pk_mul_f32 halves the multiplies but runs this loop 2x
+        // SLOWER on MI355X — measured 304 vs 150 us — so the products stay scalar.)  NaN (bin not in the
+        // stream) loses every v_min; INFINITY keeps an all-NaN lane out of the reduction.
 #pragma unroll
-        for (int r = 0; r < SCAN_ROWS; r++) {
-            const float a = fminf(kv[r].x * rc.x, kv[r].y * rc.y);
-            const float b = fminf(kv[r].z * rc.z, kv[r].w * rc.w);
-            m[r] = fminf(INFINITY, fminf(a, b));
-        }
-        static_assert(SCAN_ROWS == 8, "wave_min8_to_lane63 reduces exactly 8 rows");
-        wave_min8_to_lane63(m);
-        if ((tid & 63) == 63) {
-            // tilemin[t][slot group][wave tile][row]: the 8 rows of a wave tile are one 32-byte store
-            floatx4 *out = (floatx4 *)(tilemin + (((size_t)t * ngroups + grp) * wtiles + (size_t)(tile * 4 + wid)) * SCAN_ROWS);
-            floatx4 a, b;
-            a.x = m[0]; a.y = m[1]; a.z = m[2]; a.w = m[3];
-            b.x = m[4]; b.y = m[5]; b.z = m[6]; b.w = m[7];
-            out[0] = a; out[1] = b;
-        }
+        for (int r = 0; r < SCAN_ROWS; r++)
+            m[r] = fminf(fminf(fminf(fminf(kv[r].x * rc.x, kv[r].y * rc.y), kv[r].z * rc.z), kv[r].w * rc.w), INFINITY);
+        static_assert(SCAN_ROWS == 8, "wave_min8_by_row reduces exactly 8 rows");
+        const float mine = wave_min8_by_row(m);                    // lane l: minimum of row l / 8 over the wave
+        // tilemin[t][slot group][wave tile][row]: 8 lanes write the 8 rows of a wave tile (32 contiguous bytes)
+        if ((lane & 7) == 0)
+            tilemin[(((size_t)t * ngroups + grp) * wtiles + (size_t)(tile * 4 + wid)) * SCAN_ROWS + (lane >> 3)] = mine;
     }
 }
 
