@@ -2,6 +2,9 @@
 
 The library is built in-tree (hulk_amd/csrc/Makefile).  There is NO fallback: if the shared
 object is missing or no gfx950 GPU is usable, importing/creating fails loudly.
+
+A process that also uses torch must `import torch` BEFORE the first hulk_amd call: torch bundles its
+own libamdhip64, and two HIP runtimes in one process leave the second without devices.
 """
 import ctypes
 import os

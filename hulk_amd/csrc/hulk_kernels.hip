@@ -744,10 +744,16 @@ __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *__restr
 // workgroup (r, t, part): LDS spectrum of bins [r*RANGE, (r+1)*RANGE) over part `part` of interval t's keys
 __global__ __launch_bounds__(1024) void k_range_hist(MinimizerList ml, uint32_t n_regions,
                                                      uint32_t *__restrict__ partial, MinimizerParams P,
-                                                     uint32_t n_spectra, uint32_t n_parts, uint64_t n_reads) {
+                                                     uint32_t n_spectra, uint32_t n_parts, uint64_t n_reads, int nranges) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *lh = (uint32_t *)smem;
-    const int r = blockIdx.x, t = blockIdx.y, part = blockIdx.z;
+    // XCD-aware order (workgroup b lands on XCD b % 8): the nranges workgroups that stream the SAME keys
+    // (one (spectrum, part) pair, different bin ranges) get consecutive slots of ONE XCD, so its L2 serves
+    // all but the first of them — otherwise every range re-fetches the keys over the fabric (nranges x)
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int pr = (seq / nranges) * 8 + xcd, r = seq % nranges;
+    if (pr >= (int)(n_spectra * n_parts)) return;
+    const int t = pr % (int)n_spectra, part = pr / (int)n_spectra;
     const int tid = threadIdx.x;
     for (int i = tid; i < HIST_RANGE; i += blockDim.x) lh[i] = 0;
     __syncthreads();
@@ -2078,8 +2084,9 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_range_hist, dim3(nranges, n_spectra, n_parts), dim3(1024), HIST_RANGE * 4, s, ml, n_regions,
-                       ml.partial, P, n_spectra, n_parts, n_reads);
+    const unsigned pair_groups = (n_spectra * n_parts + 7) / 8;
+    hipLaunchKernelGGL(k_range_hist, dim3(8u * (unsigned)nranges * pair_groups), dim3(1024), HIST_RANGE * 4, s, ml, n_regions,
+                       ml.partial, P, n_spectra, n_parts, n_reads, nranges);
     int mb = (P.num_bins + 255) / 256; if (mb > 512) mb = 512;
     hipLaunchKernelGGL(k_merge_hist, dim3(mb, n_spectra), dim3(256), 0, s, ml.partial, d_hists, P, n_spectra, n_parts);
     return hipGetLastError();

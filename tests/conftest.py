@@ -11,6 +11,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# torch ships its own HIP runtime: it has to be loaded before libhulkhip.so pulls in /opt/rocm's, or
+# torch.cuda finds no device later in the same process (some GPU tests use torch for device buffers)
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
