@@ -439,10 +439,17 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     // all instructions when done per read); the following 15 reads step from it
     uint32_t slot0 = P.ring_base; uint64_t rem0 = 0;
     if (P.interval) {
+        // a launch covers at most ring_n - 1 intervals (hulk_api.hip), so the quotient is found by a short
+        // scalar loop; the two 64-bit divisions that stood here were ~3 % of the kernel's VALU instructions
         const uint64_t x = P.fill + wave_first;
-        const uint64_t t0 = x / P.interval;
-        rem0 = x - t0 * P.interval;
-        slot0 = (uint32_t)((t0 + P.ring_base) % P.ring_n);
+        uint32_t xl = __builtin_amdgcn_readfirstlane((uint32_t)x), xh = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+        uint64_t xs = ((uint64_t)xh << 32) | xl;
+        uint32_t t0 = 0;
+        while (xs >= P.interval && t0 < P.ring_n) { xs -= P.interval; t0++; }
+        if (xs >= P.interval) { t0 += (uint32_t)((xs / P.interval) % P.ring_n); xs %= P.interval; }   // not reached by libhulkhip's own launches
+        rem0 = xs;
+        slot0 = t0 + P.ring_base;
+        while (slot0 >= P.ring_n) slot0 -= P.ring_n;
     }
 
     for (int it = 0; it < FAST_READS_PER_WAVE / 4; it++) {
@@ -470,6 +477,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             npos = (int32_t)(L - k + 1 > 0x7fffffff ? 0x7fffffff : L - k + 1);
             if (npos > 16 * w || L > 256) defer = true;
         }
+        if (dbg & 64u) { sink += (uint32_t)o0 + (uint32_t)npos + hslot; continue; }   // ablation: per-iteration bookkeeping only
         // ---- stage 16 bases per lane: ASCII -> 2-bit pack (one dword per lane), detect code 4
         bool sawN = false;
         if (act && !defer) {
@@ -509,6 +517,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             if (gN) defer = true;
         }
         wave_sync();
+        if (dbg & 32u) { sink += pk32[gl]; wave_sync(); continue; }      // ablation: staging only
 
         // ---- phase A: rolling k-mers over the own block (registers)
         const int32_t p0 = gl * w;

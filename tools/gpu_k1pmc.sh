@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-for d in 24 0; do
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA" "SQ_INSTS_SMEM SQ_IFETCH SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM"; do
+for d in 64 32 24 8 0; do
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"; do
 OUT=/tmp/k1p; rm -rf $OUT
 cd /tmp && HULK_K1_DEBUG=$d rocprofv3 --kernel-trace --pmc $set -d $OUT -o k --output-format csv -- python $GRAFT_REPO_ROOT/tools/k1_ablate.py child > /dev/null 2>&1
 python - <<PY
