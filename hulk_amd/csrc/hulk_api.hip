@@ -103,6 +103,7 @@ struct hulk_ctx {
     uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;
     MinimizerList ml{}; uint64_t ml_regions = 0;
     uint64_t *d_long_xs = nullptr, *d_long_table = nullptr; uint8_t *d_long_valid = nullptr;   // long-sequence scratch
+    void *d_long_desc = nullptr; uint64_t long_desc_cap = 0;
     uint64_t long_cap = 0, long_table_cap = 0;   // minimizer list of the short-read kernel (grow-only)
     // host-side run state
     uint64_t seq_count = 0, flush_index = 0;
@@ -291,46 +292,76 @@ int sync_all(hulk_ctx *c) {
 }
 
 // kernel configuration by read length: {xcap, table, block threads}
-constexpr uint32_t GENERIC_XCAP_MAX = 4096;
+// the one-wave-per-read kernel takes reads of up to 1024 k-mer positions; its 4096-position configuration
+// ran at 10 Gbases/s (32 KB of LDS per wave), the grouped long-sequence path does 21 — so longer reads go there
+constexpr uint32_t GENERIC_XCAP_MAX = 1024;
 // returns false when some reads may exceed the largest configuration (they take the long-read path)
 bool pick_config(uint32_t k, uint32_t max_len, MinimizerParams &P, int &threads) {
     const uint32_t npos = max_len >= k ? max_len - k + 1 : 1;
     if (npos <= 192) { P.xcap = 192; P.tab_size = 256; threads = 256; return true; }
-    if (npos <= 1024) { P.xcap = 1024; P.tab_size = 2048; threads = 64; return true; }
-    P.xcap = GENERIC_XCAP_MAX; P.tab_size = 8192; threads = 64;
+    P.xcap = GENERIC_XCAP_MAX; P.tab_size = 2048; threads = 64;
     return npos <= GENERIC_XCAP_MAX;
 }
 
-// sequences with more than GENERIC_XCAP_MAX k-mer positions: one at a time over the whole grid
+// sequences with more than GENERIC_XCAP_MAX k-mer positions: grouped launches of the long-sequence kernels
 int bin_long_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, MinimizerParams P,
                    uint32_t *hist) {
     std::vector<uint64_t> off(n + 1);
     HIPCHK(c, hipMemcpyAsync(off.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // groups of long sequences, one launch set per group: bounded scratch (positions) and grid.y
+    constexpr uint64_t GROUP_POS = 128ull << 20;        // positions per group (8 B + 1 B scratch, <= 16 B of table each)
+    constexpr uint32_t GROUP_SEQS = 32768;
+    std::vector<hulk::LongSeqDesc> descs;
+    uint64_t pos_total = 0, tab_total = 0, max_npos = 0;
+    auto launch_group = [&]() -> int {
+        if (descs.empty()) return HULK_OK;
+        if (pos_total > c->long_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->d_long_xs); hipFree(c->d_long_valid); c->d_long_xs = nullptr; c->d_long_valid = nullptr; c->long_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_long_xs, pos_total * 8));
+            HIPCHK(c, hipMalloc((void **)&c->d_long_valid, pos_total));
+            c->long_cap = pos_total;
+        }
+        if (tab_total > c->long_table_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->d_long_table); c->d_long_table = nullptr; c->long_table_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_long_table, tab_total * 8));
+            c->long_table_cap = tab_total;
+        }
+        if (descs.size() > c->long_desc_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->d_long_desc); c->d_long_desc = nullptr; c->long_desc_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->d_long_desc, (descs.size() + 1024) * sizeof(hulk::LongSeqDesc)));
+            c->long_desc_cap = descs.size() + 1024;
+        }
+        // pageable source: the copy is staged before the call returns, descs may be reused afterwards
+        HIPCHK(c, hipMemcpyAsync(c->d_long_desc, descs.data(), descs.size() * sizeof(hulk::LongSeqDesc),
+                                 hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, launch_long_group(c->stream, d_bases, (const hulk::LongSeqDesc *)c->d_long_desc, (uint32_t)descs.size(),
+                                    max_npos, P, c->d_long_xs, c->d_long_valid, c->d_long_table, tab_total, hist,
+                                    c->d_min_slots));
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // descs.data() is pageable memory: keep it simple and ordered
+        descs.clear(); pos_total = tab_total = max_npos = 0;
+        return HULK_OK;
+    };
     for (uint64_t rd = 0; rd < n; rd++) {
         const uint64_t L = off[rd + 1] - off[rd];
         if (L < (uint64_t)P.k || L - P.k + 1 <= GENERIC_XCAP_MAX) continue;
         const uint64_t npos = L - P.k + 1;
-        uint64_t tsize = 1; while (tsize < 2 * npos) tsize <<= 1;
-        if (npos > c->long_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            hipFree(c->d_long_xs); hipFree(c->d_long_valid); c->d_long_xs = nullptr; c->d_long_valid = nullptr; c->long_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->d_long_xs, npos * 8));
-            HIPCHK(c, hipMalloc((void **)&c->d_long_valid, npos));
-            c->long_cap = npos;
+        uint64_t tsize = 1; while (tsize < npos) tsize <<= 1;      // <= ~0.2 distinct minimizers per position: load <= 0.2
+        if (!descs.empty() && (pos_total + npos > GROUP_POS || descs.size() >= GROUP_SEQS)) {
+            const int rc = launch_group();
+            if (rc != HULK_OK) return rc;
         }
-        if (tsize > c->long_table_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            hipFree(c->d_long_table); c->d_long_table = nullptr; c->long_table_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->d_long_table, tsize * 8));
-            c->long_table_cap = tsize;
-        }
-        uint32_t slot = P.ring_base;
-        if (P.interval) slot = (uint32_t)(((P.fill + rd) / P.interval + P.ring_base) % P.ring_n);
-        HIPCHK(c, launch_long_read(c->stream, d_bases + off[rd], L, P, c->d_long_xs, c->d_long_valid, c->d_long_table,
-                                   tsize, hist + (size_t)slot * (size_t)c->B, c->d_min_slots));
+        hulk::LongSeqDesc d{};
+        d.seq_off = off[rd]; d.L = L; d.xs_off = pos_total; d.tab_off = tab_total; d.tab_mask = tsize - 1;
+        d.hslot = P.ring_base;
+        if (P.interval) d.hslot = (uint32_t)(((P.fill + rd) / P.interval + P.ring_base) % P.ring_n);
+        descs.push_back(d);
+        pos_total += npos; tab_total += tsize; if (npos > max_npos) max_npos = npos;
     }
-    return HULK_OK;
+    return launch_group();
 }
 
 int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
@@ -360,8 +391,7 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
         const uint64_t rcap = minimizer_list_rcap(c->p.w);
         if (regions > c->ml_regions || c->ml.rcap != rcap) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            hipFree(c->d_long_xs); hipFree(c->d_long_table); hipFree(c->d_long_valid);
-    hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum);
+            hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum);
             uint32_t *keep_partial = c->ml.partial; const uint32_t keep_parts = c->ml.max_parts;
             c->ml = MinimizerList{}; c->ml_regions = 0;
             c->ml.partial = keep_partial; c->ml.max_parts = keep_parts;
@@ -611,6 +641,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
     hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
     hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial);
+    hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }

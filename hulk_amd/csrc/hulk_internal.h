@@ -42,6 +42,17 @@ struct MinimizerList {
     uint64_t rcap;
 };
 
+// one long sequence of a group launch (k_long_hash / k_long_emit)
+struct LongSeqDesc {
+    uint64_t seq_off;    // first base, offset into the bases buffer
+    uint64_t L;          // bases
+    uint64_t xs_off;     // slice of the per-position scratch (hashed k-mers, valid flags)
+    uint64_t tab_off;    // slice of the set table
+    uint64_t tab_mask;   // slice size - 1 (power of two)
+    uint32_t hslot;      // spectrum (ring slot) of this sequence
+    uint32_t pad;
+};
+
 struct MinimizerParams {
     uint32_t k, w;
     int32_t num_bins;
@@ -72,9 +83,9 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
 hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
                                  uint32_t *d_hists);
 uint32_t minimizer_list_rcap(uint32_t w);
-hipError_t launch_long_read(hipStream_t s, const uint8_t *d_seq, uint64_t L, MinimizerParams P, uint64_t *d_xs,
-                            uint8_t *d_valid, uint64_t *d_table, uint64_t table_size, uint32_t *d_hist_slot,
-                            unsigned long long *d_min_slots);
+hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSeqDesc *d_desc, uint32_t n_seqs,
+                             uint64_t max_npos, MinimizerParams P, uint64_t *d_xs, uint8_t *d_valid, uint64_t *d_table,
+                             uint64_t table_total, uint32_t *d_hists, unsigned long long *d_min_slots);
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb);
 hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,
                              const uint32_t *d_chain_start, unsigned long long *d_ctr,

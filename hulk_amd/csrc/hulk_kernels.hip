@@ -824,62 +824,104 @@ __global__ __launch_bounds__(256) void k_merge_hist(const uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// Long sequences (FASTA contigs, anything beyond the generic kernel's 4096 k-mer positions): one
-// sequence at a time over the whole grid.  k_long_hash: hashed canonical k-mer per position with
-// the literal recurrence (N-safe); k_long_emit: windowed minimum per position, per-read set =
-// open-addressing table in HBM (64-bit compare-and-swap), new values are jump-hashed and counted.
+// Long sequences (long reads, FASTA contigs: anything beyond the generic kernel's 1024 k-mer positions).
+// A launch covers a GROUP of sequences (blockIdx.y = sequence of the group, blockIdx.x strides over its
+// positions), each with its own slice of the scratch arrays and of the set table (LongSeqDesc), so
+// 10-kb reads are not launch-bound.  k_long_hash: hashed canonical k-mer per position with the literal
+// recurrence (N-safe); k_long_emit: windowed minimum per position; per-sequence set = open-addressing
+// table in HBM (64-bit compare-and-swap), tried only where the window minimum differs from the one the
+// previous position emitted (same set, ~5x fewer atomics); new values are jump-hashed and counted.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_long_hash(const uint8_t *__restrict__ seq, uint64_t L, MinimizerParams P,
-                                                   uint64_t *__restrict__ Xs, uint8_t *__restrict__ valid) {
+constexpr int LONG_PPT = 8;        // consecutive positions per thread in the long-sequence kernels
+__global__ __launch_bounds__(256) void k_long_hash(const uint8_t *__restrict__ bases, const LongSeqDesc *__restrict__ desc,
+                                                   MinimizerParams P, uint64_t *__restrict__ Xs_all,
+                                                   uint8_t *__restrict__ valid_all) {
     __shared__ uint8_t lut[256];
     for (int t = threadIdx.x; t < 256; t += blockDim.x) lut[t] = nt4_of((unsigned)t);
     __syncthreads();
+    const LongSeqDesc d = desc[blockIdx.y];
+    const uint8_t *seq = bases + d.seq_off;
+    uint64_t *Xs = Xs_all + d.xs_off;
+    uint8_t *valid = valid_all + d.xs_off;
     const int64_t k = (int64_t)P.k, w = (int64_t)P.w;
     const uint64_t mask = (1ull << (2 * k)) - 1, shift = (uint64_t)(2 * (k - 1));
-    const uint64_t npos = L - (uint64_t)k + 1;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < npos; j += (uint64_t)gridDim.x * blockDim.x) {
-        const int64_t i = (int64_t)j + k - 1;
+    const uint64_t npos = d.L - (uint64_t)k + 1;
+    // a thread rolls through LONG_PPT consecutive positions: k + LONG_PPT bases instead of LONG_PPT * (k + 1)
+    for (uint64_t j0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * LONG_PPT; j0 < npos;
+         j0 += (uint64_t)gridDim.x * blockDim.x * LONG_PPT) {
+        const uint64_t jend = j0 + LONG_PPT < npos ? j0 + LONG_PPT : npos;
         uint64_t f = 0, r = 0;
-        int64_t p0 = i - k; if (p0 < 0) p0 = 0;
-        for (int64_t p = p0; p <= i; p++) {                     // bases before i-k cannot survive (see k_minimizer_bin)
+        // bases before (first position) - 1 cannot survive in f (masked) or r (shifted out): see k_minimizer_bin
+        for (int64_t p = j0 > 0 ? (int64_t)j0 - 1 : 0; p < (int64_t)jend + k - 1; p++) {
             const uint64_t c = lut[seq[p]];
             f = (f << 2 | c) & mask;
             r = (r >> 2) | ((3ull ^ c) << shift);
+            const int64_t j = p - (k - 1);
+            if (j < (int64_t)j0) continue;
+            uint64_t X = X_NONE; uint8_t ok = 0;
+            if (f != r) {
+                const uint64_t canon = f > r ? r : f;
+                int64_t span = p - w + 2;
+                if (span >= k) span = k;
+                X = hash64(canon, mask) << 8 | (uint64_t)(int64_t)(int32_t)span;
+                ok = 1;
+            }
+            Xs[j] = X; valid[j] = ok;
         }
-        uint64_t X = X_NONE; uint8_t ok = 0;
-        if (f != r) {
-            const uint64_t canon = f > r ? r : f;
-            int64_t span = i - w + 2;
-            if (span >= k) span = k;
-            X = hash64(canon, mask) << 8 | (uint64_t)(int64_t)(int32_t)span;
-            ok = 1;
-        }
-        Xs[j] = X; valid[j] = ok;
     }
 }
 
-__global__ __launch_bounds__(256) void k_long_emit(const uint64_t *__restrict__ Xs, const uint8_t *__restrict__ valid,
-                                                   uint64_t L, MinimizerParams P, uint64_t *__restrict__ table,
-                                                   uint64_t table_mask, uint32_t *__restrict__ hist,
+__global__ __launch_bounds__(256) void k_long_emit(const LongSeqDesc *__restrict__ desc, const uint64_t *__restrict__ Xs_all,
+                                                   const uint8_t *__restrict__ valid_all, MinimizerParams P,
+                                                   uint64_t *__restrict__ table_all, uint32_t *__restrict__ hists,
                                                    unsigned long long *__restrict__ min_slots) {
     __shared__ unsigned red[4];
-    const int64_t k = (int64_t)P.k, w = (int64_t)P.w, wwin = w > 0 ? w : 1;
-    const uint64_t npos = L - (uint64_t)k + 1;
+    const LongSeqDesc d = desc[blockIdx.y];
+    const uint64_t *Xs = Xs_all + d.xs_off;
+    const uint8_t *valid = valid_all + d.xs_off;
+    uint64_t *table = table_all + d.tab_off;
+    const uint64_t table_mask = d.tab_mask;
+    uint32_t *hist = hists + (size_t)d.hslot * (size_t)P.num_bins;
+    const int64_t k = (int64_t)P.k, w = (int64_t)P.w;
+    const uint64_t wwin = (uint64_t)(w > 0 ? w : 1);
+    const uint64_t npos = d.L - (uint64_t)k + 1;
     unsigned fresh = 0;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < npos; j += (uint64_t)gridDim.x * blockDim.x) {
-        const int64_t i = (int64_t)j + k - 1;
-        if (!valid[j] || i < w - 1) continue;
-        uint64_t lo = j >= (uint64_t)(wwin - 1) ? j - (uint64_t)(wwin - 1) : 0;
-        uint64_t m = X_NONE;
-        for (uint64_t p = lo; p <= j; p++) { const uint64_t x = Xs[p]; m = x < m ? x : m; }
-        // per-read set: only the thread whose compare-and-swap claims the slot counts the value
-        uint64_t slot = (m ^ (m >> 29)) * 0x9E3779B97F4A7C15ull >> 20 & table_mask;
-        for (;;) {
-            const unsigned long long old = atomicCAS((unsigned long long *)&table[slot], (unsigned long long)TAB_EMPTY,
-                                                     (unsigned long long)m);
-            if (old == TAB_EMPTY) { atomicAdd(&hist[jump_hash(m, P.num_bins)], 1u); fresh++; break; }
-            if (old == m) break;
-            slot = (slot + 1) & table_mask;
+    for (uint64_t j0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * LONG_PPT; j0 < npos;
+         j0 += (uint64_t)gridDim.x * blockDim.x * LONG_PPT) {
+        const uint64_t jend = j0 + LONG_PPT < npos ? j0 + LONG_PPT : npos;
+        // sliding window minimum: m = min Xs[max(j-w+1,0) .. j]; a full rescan only when the value that
+        // leaves the window is the current minimum (probability ~1/w per step)
+        uint64_t m = X_NONE, mprev = X_NONE;
+        bool prev_emit = false;
+        if (j0 > 0) {                                           // window of position j0 - 1
+            const uint64_t q = j0 - 1, lo = q >= wwin - 1 ? q - (wwin - 1) : 0;
+            for (uint64_t p = lo; p <= q; p++) { const uint64_t x = Xs[p]; m = x < m ? x : m; }
+            prev_emit = valid[q] && (int64_t)q + k - 1 >= w - 1;
+            mprev = m;
+        }
+        for (uint64_t j = j0; j < jend; j++) {
+            const uint64_t x = Xs[j];
+            if (j >= wwin && Xs[j - wwin] == m) {               // the minimum leaves: rescan
+                m = x;
+                for (uint64_t p = j - wwin + 1; p < j; p++) { const uint64_t y = Xs[p]; m = y < m ? y : m; }
+            } else {
+                m = x < m ? x : m;
+            }
+            const bool emit = valid[j] && (int64_t)j + k - 1 >= w - 1;
+            // the reference inserts the window minimum into the read's set at every emitting position; the
+            // previous position already inserted the same value if it emitted with the same minimum
+            if (emit && !(prev_emit && mprev == m)) {
+                // per-read set: only the thread whose compare-and-swap claims the slot counts the value
+                uint64_t slot = (m ^ (m >> 29)) * 0x9E3779B97F4A7C15ull >> 20 & table_mask;
+                for (;;) {
+                    const unsigned long long old = atomicCAS((unsigned long long *)&table[slot], (unsigned long long)TAB_EMPTY,
+                                                             (unsigned long long)m);
+                    if (old == TAB_EMPTY) { atomicAdd(&hist[jump_hash(m, P.num_bins)], 1u); fresh++; break; }
+                    if (old == m) break;
+                    slot = (slot + 1) & table_mask;
+                }
+            }
+            prev_emit = emit; mprev = m;
         }
     }
     for (int off = 32; off; off >>= 1) fresh += __shfl_xor(fresh, off);
@@ -887,7 +929,7 @@ __global__ __launch_bounds__(256) void k_long_emit(const uint64_t *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = red[0] + red[1] + red[2] + red[3];
-        if (t) atomicAdd(&min_slots[blockIdx.x & (MIN_SLOTS - 1)], (unsigned long long)t);
+        if (t) atomicAdd(&min_slots[(blockIdx.x + 131u * blockIdx.y) & (MIN_SLOTS - 1)], (unsigned long long)t);
     }
 }
 
@@ -2103,15 +2145,18 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
 
 uint32_t minimizer_list_rcap(uint32_t w) { return FAST_READS_PER_WAVE * 16u * w; }
 
-hipError_t launch_long_read(hipStream_t s, const uint8_t *d_seq, uint64_t L, MinimizerParams P, uint64_t *d_xs,
-                            uint8_t *d_valid, uint64_t *d_table, uint64_t table_size, uint32_t *d_hist_slot,
-                            unsigned long long *d_min_slots) {
-    const uint64_t npos = L - P.k + 1;
-    unsigned blocks = (unsigned)std::min<uint64_t>((npos + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_fill_u64, dim3(2048), dim3(256), 0, s, d_table, table_size, TAB_EMPTY);
-    hipLaunchKernelGGL(k_long_hash, dim3(blocks), dim3(256), 0, s, d_seq, L, P, d_xs, d_valid);
-    hipLaunchKernelGGL(k_long_emit, dim3(blocks), dim3(256), 0, s, d_xs, d_valid, L, P, d_table, table_size - 1,
-                       d_hist_slot, d_min_slots);
+hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSeqDesc *d_desc, uint32_t n_seqs,
+                             uint64_t max_npos, MinimizerParams P, uint64_t *d_xs, uint8_t *d_valid, uint64_t *d_table,
+                             uint64_t table_total, uint32_t *d_hists, unsigned long long *d_min_slots) {
+    // blocks per sequence: enough for the longest of the group, bounded so that the grid stays ~2^17 blocks
+    uint64_t bx = (max_npos + 256 * LONG_PPT - 1) / (256 * LONG_PPT);
+    const uint64_t cap = std::max<uint64_t>(1, 131072 / n_seqs);
+    if (bx > cap) bx = cap;
+    if (bx > 8192) bx = 8192;
+    hipLaunchKernelGGL(k_fill_u64, dim3(4096), dim3(256), 0, s, d_table, table_total, TAB_EMPTY);
+    hipLaunchKernelGGL(k_long_hash, dim3((unsigned)bx, n_seqs), dim3(256), 0, s, d_bases, d_desc, P, d_xs, d_valid);
+    hipLaunchKernelGGL(k_long_emit, dim3((unsigned)bx, n_seqs), dim3(256), 0, s, d_desc, d_xs, d_valid, P, d_table,
+                       d_hists, d_min_slots);
     return hipGetLastError();
 }
 

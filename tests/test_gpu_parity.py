@@ -357,3 +357,32 @@ def test_against_committed_golden_sketches(name, k, S, interval, decay, fq_reads
     assert np.allclose(hs.weights, gold.weights, rtol=1e-5, atol=0)
     assert np.allclose(hs.weights, gold.weights, rtol=1e-7, atol=0)
     g.close()
+
+
+def test_many_long_reads_grouped_launches():
+    """Long reads (beyond the one-wave kernel's 4096 positions) go through the grouped long-sequence path:
+    240 reads of 4.2-30 kb with N runs, lowercase and repeats, intervals crossing inside the batch,
+    mixed with short and medium reads in the same call."""
+    rng = np.random.default_rng(99)
+    seqs = []
+    for i in range(240):
+        L = int(rng.integers(4200, 30000))
+        s = bytearray(random_reads(rng, 1, L, b"ACGTacgt")[0])
+        if i % 7 == 0:
+            a = int(rng.integers(0, L - 300)); s[a:a + int(rng.integers(1, 250))] = b"N" * 1      # shortens: fine
+        if i % 5 == 0:
+            a = int(rng.integers(0, L // 2)); s[a + 500:a + 1500] = s[a:a + 1000]                    # internal repeat
+        if i % 11 == 0:
+            s = s[:5000] + b"N" * 40 + s[5000:]
+        seqs.append(bytes(s))
+        if i % 3 == 0:
+            seqs.extend(random_reads(rng, 4, (60, 150)))
+        if i % 17 == 0:
+            seqs.extend(random_reads(rng, 1, (500, 3000)))
+    o, g = run_both(seqs, 15, 9, 32, interval=37, batches=3)
+    o.finish(); g.finish()
+    oc, gc = o.counters(), g.counters()
+    assert all(oc[key] == gc[key] for key in ("n_reads", "n_minimizers", "total_len"))
+    assert np.array_equal(g.cms(), o.cms())
+    assert_same_sketch(o, g)
+    g.close(); o.close()
