@@ -1,0 +1,67 @@
+"""The C++ host mirror (include/hulk.hpp: Boss / HistoSketch with the reference's method names) built
+with g++ against libhulkhip.so and compared with the ctypes path and the oracle."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, pack_reads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "hulk_amd", "csrc")
+
+
+def build(tmp_path):
+    exe = str(tmp_path / "boss_driver")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "boss_driver.cpp"), "-o", exe,
+           "-L", LIBDIR, "-lhulkhip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return exe
+
+
+def test_cpp_host_header_compiles_and_links(tmp_path):
+    """CPU side: hulk.hpp is valid C++17 and every symbol it uses resolves against libhulkhip.so."""
+    build(tmp_path)
+
+
+@pytest.mark.gpu
+def test_cpp_boss_matches_python_and_oracle(tmp_path, fq_reads):
+    import hulk_amd
+    from oracle import pyorc
+    exe = build(tmp_path)
+    txt = tmp_path / "reads.txt"
+    txt.write_bytes(b"\n".join(fq_reads) + b"\n")
+    for k, S, interval, decay in ((21, 64, 0, 1.0), (15, 32, 250, 0.05)):
+        g = hulk_amd.GpuSketcher(k, 9, S, interval, decay)
+        g.add_reads(*pack_reads(fq_reads))
+        g.finish()
+        m, w = g.sketch()
+        for mode, path in (("addseq", str(txt)), ("files", os.path.join(GOLDEN, "test-reads-small.fq.gz"))):
+            p = subprocess.run([exe, mode, path, str(k), "9", str(S), str(interval), repr(decay)],
+                               capture_output=True, text=True, timeout=300)
+            assert p.returncode == 0, p.stdout + p.stderr
+            doc = json.loads(p.stdout)
+            assert doc["n_seqs"] == 1000 and doc["n_minimizers"] == g.get_minimizer_count()
+            assert doc["ksize"] == k and doc["num"] == S and doc["bins"] == k ** 4 and doc["drift"] == (decay != 1.0)
+            assert np.array_equal(np.array(doc["mins"], dtype=np.uint64), m)
+            assert np.array_equal(np.array(doc["weights"]), w)              # %.17g round-trips
+        o = pyorc.Sketcher(k, 9, S, 0, decay, interval)
+        for r in fq_reads:
+            o.add_read(r)
+        o.finish()
+        assert np.array_equal(o.sketch()[0], m)
+        g.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_cpp_errors_carry_the_reference_text(tmp_path):
+    exe = build(tmp_path)
+    p = subprocess.run([exe, "errors"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = p.stdout.strip().splitlines()
+    assert lines == ["-1|w must be: 0 < w < 257", "-6|histosketching only supports k <= 31",
+                     "-7|decay ratio must be between 0.0 and 1.0", "-4|sequence length must be >= w + k - 1"]
