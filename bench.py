@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-pass", action="store_true",
+                    help="skip the second timed pass (CWS-scan pruning disabled) that fills value_unpruned")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-reduce path even at world size 1 (test aid)")
     args = ap.parse_args()
@@ -101,11 +103,6 @@ def main():
     stream = torch.cuda.Stream(device=device)
     coll_stream = torch.cuda.Stream(device=device) if use_dist else None
     torch.cuda.set_stream(stream)
-    sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=local_rank,
-                              slot_begin=sb, slot_count=sc, stream=stream.cuda_stream)
-    assert sk.batch_size == BATCH
-    eng = GpuEngine(sk, device, n_spectra=BATCH)
-    sh = ShardedSketcher(eng, S, rank, world if use_dist else 1, dist if use_dist else None)
 
     # synthetic reads, resident in HBM.  Interval t of step s = global reads
     # [(s*BATCH+t)*world*INTERVAL, +world*INTERVAL); this rank owns the slice [rank*INTERVAL, +INTERVAL)
@@ -123,45 +120,72 @@ def main():
     offsets = torch.arange(reads_per_rank_step + 1, dtype=torch.int64, device=device) * READ_LEN
     torch.cuda.synchronize()
 
-    def one_step(t):
-        b = step_bases[t % n_buf]
-        sk.bin_reads_device(b.data_ptr(), offsets.data_ptr(), reads_per_rank_step, READ_LEN, b.numel(),
-                            reads_per_spectrum=INTERVAL)
-        if use_dist:
-            h = eng.histogram_tensor()                 # view of the ring the reads were just binned into
-            coll_stream.wait_stream(stream)
-            with torch.cuda.stream(coll_stream):
-                dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            sk.flush_batch(BATCH, after_stream=coll_stream.cuda_stream)
+
+    def run_pass(prune):
+        """warm-up + the timed K steps on a fresh context; prune=False disables the exact bound test of the
+        CWS scan (HULK_NO_PRUNE), so that every interval streams the whole table like the reference does."""
+        if prune:
+            os.environ.pop("HULK_NO_PRUNE", None)
         else:
-            sk.flush_batch(BATCH)
+            os.environ["HULK_NO_PRUNE"] = "1"
+        sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=local_rank,
+                                  slot_begin=sb, slot_count=sc, stream=stream.cuda_stream)
+        assert sk.batch_size == BATCH
+        eng = GpuEngine(sk, device, n_spectra=BATCH)
+        sh = ShardedSketcher(eng, S, rank, world if use_dist else 1, dist if use_dist else None)
 
-    for t in range(warmup):
-        one_step(t)
-    torch.cuda.synchronize()
-    sk.set_profiling(True)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(warmup, total_steps):
-        one_step(t)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    n_launch, scan_ms = sk.get_profile("k_cws_scan")
-    n_k1, k1_ms = sk.get_profile("k_minimizer_fast")
-    sk.set_profiling(False)
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        def one_step(t):
+            b = step_bases[t % n_buf]
+            sk.bin_reads_device(b.data_ptr(), offsets.data_ptr(), reads_per_rank_step, READ_LEN, b.numel(),
+                                reads_per_spectrum=INTERVAL)
+            if use_dist:
+                h = eng.histogram_tensor()                 # view of the ring the reads were just binned into
+                coll_stream.wait_stream(stream)
+                with torch.cuda.stream(coll_stream):
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                sk.flush_batch(BATCH, after_stream=coll_stream.cuda_stream)
+            else:
+                sk.flush_batch(BATCH)
 
-    sk.finish()
-    counters = sk.counters()
-    mins, weights = sh.gather_sketch() if (use_dist and world > 1) else sk.sketch()
+        for t in range(warmup):
+            one_step(t)
+        torch.cuda.synchronize()
+        sk.set_profiling(True)
+        tiles0 = sk.scan_stats()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(warmup, total_steps):
+            one_step(t)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        tiles1 = sk.scan_stats()
+        n_launch, scan_ms = sk.get_profile("k_cws_scan")
+        n_k1, k1_ms = sk.get_profile("k_minimizer_fast")
+        sk.set_profiling(False)
+        if use_dist:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+
+        sk.finish()
+        counters = sk.counters()
+        mins, weights = sh.gather_sketch() if (use_dist and world > 1) else sk.sketch()
+
+        sk.close()
+        return dict(elapsed=elapsed, n_launch=n_launch, scan_ms=scan_ms, n_k1=n_k1, k1_ms=k1_ms, counters=counters,
+                    mins=mins, weights=weights, tiles0=tiles0, tiles1=tiles1)
+
+    full = run_pass(False) if not args.single_pass else None
+    main_pass = run_pass(True)
+    elapsed, n_launch, scan_ms, n_k1, k1_ms = (main_pass[k] for k in ("elapsed", "n_launch", "scan_ms", "n_k1", "k1_ms"))
+    counters, mins, weights, tiles0, tiles1 = (main_pass[k] for k in ("counters", "mins", "weights", "tiles0", "tiles1"))
+    if full is not None and rank == 0:
+        assert np.array_equal(full["mins"], mins) and np.array_equal(full["weights"], weights), "pruning changed the sketch"
 
     if rank == 0:
         total_reads = steps * reads_per_rank_step * world
@@ -177,9 +201,15 @@ def main():
         per_read_min = counters["n_minimizers"] / float(counters["n_reads"])
         k1_bytes = float(reads_per_rank_step) * (READ_LEN + 8 + 9.0 * per_read_min)
         k1_ach = k1_bytes / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
-        # The HBM-streaming kernel of the path = k_cws_scan: algorithmic bytes per launch = ONE fp32
-        # pass over this rank's slice of K (4*slots*k^4) + the BATCH reciprocal vectors.
-        alg_bytes = 4.0 * sc * (K ** 4) + 4.0 * BATCH * (K ** 4)
+        # The HBM-streaming kernel of the path = k_cws_scan.  Unpruned it makes ONE fp32 pass over this rank's
+        # slice of K per launch (4*slots*k^4 bytes) + the BATCH reciprocal vectors; with the exact
+        # bound test (no concept drift) it only reads the 8-slot x 256-bin tiles that can still lower a weight,
+        # so the bytes it is priced on are the tiles it actually read (hulk_get_scan_stats) + the small tables.
+        wtiles = ((K ** 4 + 1023) // 1024) * 4
+        full_bytes = 4.0 * sc * (K ** 4) + 4.0 * BATCH * (K ** 4)
+        visited = (tiles1[0] - tiles0[0]) / max(n_launch, 1)
+        covered = (tiles1[1] - tiles0[1]) / max(n_launch, 1)
+        alg_bytes = visited * 8 * 256 * 4.0 + 4.0 * BATCH * (K ** 4) + 4.0 * sc * wtiles + 8.0 * BATCH * wtiles
         avg_s = (scan_ms / 1e3) / max(n_launch, 1)
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         out = {
@@ -202,9 +232,16 @@ def main():
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                   "traffic": None, "launches": int(n_launch),
                                   "avg_launch_us": avg_s * 1e6, "alg_bytes_per_launch": alg_bytes,
-                                  "intervals_per_launch": BATCH},
+                                  "intervals_per_launch": BATCH, "tiles_read_per_launch": visited,
+                                  "tiles_covered_per_launch": covered, "unpruned_bytes_per_launch": full_bytes,
+                                  "note": "exact branch-and-bound: only tiles whose lower bound can beat a slot's "
+                                          "current weight are read (identical sketch; HULK_NO_PRUNE=1 disables)"},
             "path_bytes_per_read": READ_LEN + 4.0 * S * (K ** 4) / (INTERVAL * world),
             "sketch_md5": __import__("hashlib").md5(mins.astype("<u8").tobytes()).hexdigest(),
+            # same K steps with the exact pruning of the CWS scan switched off: every interval streams the whole
+            # table, as the reference's algorithm does (sketch asserted identical)
+            "value_unpruned": (total_reads / full["elapsed"]) if full is not None else None,
+            "ms_per_step_unpruned": (full["elapsed"] / steps * 1e3) if full is not None else None,
             "n_minimizers_rank0": counters["n_minimizers"],
         }
         # HBM traffic per launch from rocprofv3 PMC (FETCH_SIZE/WRITE_SIZE, separate passes of this same
@@ -213,9 +250,12 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
             if world == 1:
                 out["roofline"]["traffic"] = pmc["k_minimizer_fast"]["hbm_bytes_per_launch"]
-                out["roofline_cws_scan"]["traffic"] = pmc["k_cws_scan"]["hbm_bytes_per_launch"]
+                out["roofline_cws_scan"]["traffic"] = pmc["k_cws_scan"]["hbm_bytes_per_launch"]   # PMC run, same command
         except Exception:
             pass
+        # SURVEY.md §8(d) prices the path at L + 4*S*k^4/I bytes per read (one K pass per interval) => a roofline of
+        # 1.94e9 reads/s/GPU at C2; this is value / that rate.  The path itself moves far fewer bytes (one K pass
+        # per BATCH intervals, and only the tiles that can still change a slot).
         out["path_hbm_frac"] = value * out["path_bytes_per_read"] / 1e9 / (HBM_PEAK_GBS * world)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
@@ -224,7 +264,6 @@ def main():
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    sk.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "hulk_batch_size", "hulk_bin_reads_device", "hulk_histogram_device", "hulk_flush_batch", "hulk_flush_batch_after", "hulk_add_histogram", "hulk_flush",
     "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
     "hulk_get_cws_tables", "hulk_smash", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
-    "hulk_parse_files", "hulk_sketch_files",
+    "hulk_parse_files", "hulk_sketch_files", "hulk_get_scan_stats",
 )
 
 
@@ -94,6 +94,7 @@ def load():
     L.hulk_selftest_reciprocal.restype = ctypes.c_int; L.hulk_selftest_reciprocal.argtypes = [vp, vp]
     L.hulk_set_profiling.restype = ctypes.c_int; L.hulk_set_profiling.argtypes = [vp, ctypes.c_int]
     L.hulk_get_profile.restype = ctypes.c_int; L.hulk_get_profile.argtypes = [vp, ctypes.c_char_p, vp, vp]
+    L.hulk_get_scan_stats.restype = ctypes.c_int; L.hulk_get_scan_stats.argtypes = [vp, vp, vp]
     L.hulk_parse_files.restype = ctypes.c_int
     L.hulk_parse_files.argtypes = [ctypes.POINTER(ctypes.c_char_p), u32, ctypes.c_int, u32, BATCH_FN, vp,
                                    ctypes.POINTER(IngestStats), ctypes.c_char_p, u64]

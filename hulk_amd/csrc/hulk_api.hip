@@ -96,6 +96,8 @@ struct hulk_ctx {
     double *d_segadd = nullptr, *d_segfac = nullptr, *d_cstart = nullptr; uint32_t *d_sege0 = nullptr; // ... with decay
     double *d_f64 = nullptr, *d_weights = nullptr, *d_rcb = nullptr;
     float *d_rcp32 = nullptr, *d_k32 = nullptr, *d_tilemin = nullptr;
+    float *d_kmin32 = nullptr, *d_rext = nullptr;          // bound test of k_cws_scan (no concept drift only)
+    unsigned long long *d_visited = nullptr; uint64_t scan_tiles_total = 0; bool prune = false;
     double *d_candA = nullptr; int32_t *d_candB = nullptr;
     // staging for host reads
     uint8_t *d_bases = nullptr; size_t d_bases_cap = 0;
@@ -189,6 +191,7 @@ int install_tables(hulk_ctx *c, const double *r, const double *cc, const double 
         HIPCHK(c, hipMemcpy(c->d_rcb + (size_t)s * B * 3, row.data(), B * 3 * sizeof(double), hipMemcpyHostToDevice));
     }
     HIPCHK(c, launch_build_k32(c->stream, c->d_rcb, c->d_k32, (int)c->slots, c->B, c->row_stride));
+    if (c->slots) HIPCHK(c, launch_tile_kmin(c->stream, c->d_k32, c->d_kmin32, (int)c->slots, c->ntiles, c->row_stride));
     c->tables_ready = true;
     return HULK_OK;
 }
@@ -260,6 +263,7 @@ int generate_tables(hulk_ctx *c) {
         }
     }
     GEN_CHK(launch_build_k32(c->stream, c->d_rcb, c->d_k32, (int)c->slots, c->B, c->row_stride));
+    if (c->slots) GEN_CHK(launch_tile_kmin(c->stream, c->d_k32, c->d_kmin32, (int)c->slots, c->ntiles, c->row_stride));
     GEN_CHK(hipStreamSynchronize(c->stream));
 #undef GEN_CHK
     cleanup();
@@ -484,7 +488,9 @@ int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, b
             HIPCHK(c, hipEventRecord(pr.a, s));
         }
         HIPCHK(c, launch_cws_scan(s, c->d_k32, c->d_rcp32, c->d_tilemin, (int)c->slots, c->ntiles,
-                                  c->row_stride, c->d_state, fb));
+                                  c->row_stride, c->d_state, fb, c->prune ? c->d_kmin32 : nullptr, c->d_rext,
+                                  c->d_weights, (int)c->slot_begin, c->d_visited));
+        c->scan_tiles_total += (uint64_t)((c->slots + SCAN_ROWS - 1) / SCAN_ROWS) * (uint64_t)c->ntiles * 4u;
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
         if (c->drift)
             HIPCHK(c, launch_cws_resolve_drift(s, c->d_rcb, c->d_f64, c->d_tilemin, c->d_mins, c->d_weights, (int)c->slots,
@@ -592,6 +598,12 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_rcb, SL * B * 3));
     CHK_CREATE(dalloc(&c->d_k32, SL * c->row_stride));
     CHK_CREATE(dalloc(&c->d_tilemin, T * ((SL + SCAN_ROWS - 1) / SCAN_ROWS) * SCAN_ROWS * (size_t)c->ntiles * 4));
+    CHK_CREATE(dalloc(&c->d_kmin32, (SL ? SL : 1) * (size_t)c->ntiles * 4));
+    CHK_CREATE(dalloc(&c->d_rext, T * (size_t)c->ntiles * 4 * 2));
+    CHK_CREATE(dalloc(&c->d_visited, (size_t)MIN_SLOTS));
+    CHK_CREATE(hipMemsetAsync(c->d_visited, 0, (size_t)MIN_SLOTS * 8, c->stream));
+    // exact pruning of the K scan needs "weights only fall": off with concept drift (curMin = w / decayWeight)
+    c->prune = !c->drift && !getenv("HULK_NO_PRUNE");
     if (c->scaling) {
         const size_t NC = (size_t)c->cms_depth * c->cms_width;
         CHK_CREATE(dalloc(&c->d_blkcnt, T * (size_t)elem_index_blocks(c->B)));
@@ -639,6 +651,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_ctr); hipFree(c->d_estl); hipFree(c->d_basearr); hipFree(c->d_invperm); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
     hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd); hipFree(c->d_estd);
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
+    hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited);
     hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
     hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial);
     hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);
@@ -913,6 +926,19 @@ int hulk_smash(int device, const uint64_t *mins, const double *weights, uint32_t
     SM_CHK(hipMemcpy(distances, d_o, NN * 8, hipMemcpyDeviceToHost));
 #undef SM_CHK
     hipFree(d_m); hipFree(d_w); hipFree(d_o);
+    return HULK_OK;
+}
+
+int hulk_get_scan_stats(hulk_ctx *c, uint64_t *tiles_visited, uint64_t *tiles_total) {
+    if (!c) return HULK_ERR_ARG;
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
+    std::vector<unsigned long long> v(MIN_SLOTS);
+    HIPCHK(c, hipMemcpyAsync(v.data(), c->d_visited, (size_t)MIN_SLOTS * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t sum = 0;
+    for (auto x : v) sum += x;
+    if (tiles_visited) *tiles_visited = c->prune ? sum : c->scan_tiles_total;
+    if (tiles_total) *tiles_total = c->scan_tiles_total;
     return HULK_OK;
 }
 

@@ -105,7 +105,10 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
                                 double *d_segfac, uint32_t *d_sege0, double *d_cstart, double *d_f64, float *d_rcp32,
                                 int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb);
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
-                           int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb);
+                           int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
+                           const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
+                           unsigned long long *d_visited);
+hipError_t launch_tile_kmin(hipStream_t s, const float *d_k32, float *d_kmin32, int slots, int ntiles, size_t row_stride);
 hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,
                               const float *d_tilemin, double *d_candA, int32_t *d_candB,
                               unsigned long long *d_mins, double *d_weights,

@@ -1462,6 +1462,30 @@ __device__ __forceinline__ float wave_min8_by_row(float (&m)[8]) {
     return m[0];
 }
 
+// Static per (slot, 256-bin wave tile) minimum of K32, and per flush the extrema of the reciprocal
+// vectors per (interval, wave tile): the inputs of k_cws_scan's bound test.
+__global__ __launch_bounds__(256) void k_tile_kmin(const float *__restrict__ k32, float *__restrict__ kmin32,
+                                                   int ntiles, size_t row_stride) {
+    const int slot = blockIdx.y, tile = blockIdx.x, wid = threadIdx.x >> 6;
+    const floatx4 v = *(const floatx4 *)(k32 + (size_t)slot * row_stride + (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * 4);
+    float m = fminf(fminf(v.x, v.y), fminf(v.z, v.w));
+    for (int off = 32; off; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) kmin32[(size_t)slot * (size_t)(ntiles * 4) + (size_t)(tile * 4 + wid)] = m;
+}
+__global__ __launch_bounds__(256) void k_rcp_extrema(const float *__restrict__ rcp32, float *__restrict__ rext,
+                                                     int ntiles, size_t row_stride) {
+    const int t = blockIdx.y, tile = blockIdx.x, wid = threadIdx.x >> 6;
+    const floatx4 v = *(const floatx4 *)(rcp32 + (size_t)t * row_stride + (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * 4);
+    // NaN = bin not in the stream: fmaxf / fminf return the other operand
+    float hi = fmaxf(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), -INFINITY);
+    float lo = fminf(fminf(fminf(v.x, v.y), fminf(v.z, v.w)), INFINITY);
+    for (int off = 32; off; off >>= 1) { hi = fmaxf(hi, __shfl_xor(hi, off)); lo = fminf(lo, __shfl_xor(lo, off)); }
+    if ((threadIdx.x & 63) == 0) {
+        float *o = rext + ((size_t)t * (size_t)(ntiles * 4) + (size_t)(tile * 4 + wid)) * 2;
+        o[0] = hi; o[1] = lo;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K4a: the HBM-bound pass.  A[t][slot][bin] = K[slot][bin] * (1/f_t[bin]); minimum per
 // (interval t, slot, 256-bin wave tile).  A workgroup streams SCAN_ROWS rows x SCAN_TILE bins of K
@@ -1471,7 +1495,10 @@ __device__ __forceinline__ float wave_min8_by_row(float (&m)[8]) {
 __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
                                                   const float *__restrict__ rcp32,
                                                   float *__restrict__ tilemin, int slots, int ntiles,
-                                                  size_t row_stride, const DevState *st, FlushBatch fb) {
+                                                  size_t row_stride, const DevState *st, FlushBatch fb,
+                                                  const float *__restrict__ kmin32, const float *__restrict__ rext,
+                                                  const double *__restrict__ weights, int slot_begin,
+                                                  unsigned long long *__restrict__ visited) {
     // XCD-aware order (workgroup b lands on XCD b % 8): XCD x works through column tile 8*chunk + x for
     // ALL slot groups before moving on, so a column's reciprocal vectors (T x 4 KB) are fetched into
     // that XCD's L2 once and re-used by the other groups; the 8 XCDs stream 8 adjacent 4 KB pieces of
@@ -1483,6 +1510,37 @@ __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
     const int tid = threadIdx.x, wid = tid >> 6;
     const size_t col = (size_t)tile * SCAN_TILE + (size_t)tid * 4;
     const int wtiles = ntiles * 4;                               // 256-bin wave tiles per row
+    const uint32_t gomask = batch_gomask(st, fb);
+    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    const int lane = tid & 63;
+    // ---- branch and bound (no concept drift): AddElement only ever replaces a slot's weight by a SMALLER
+    // A, and A = K * (1/f) >= min(K) * max(1/f) over a tile (min(K) < 0; min(K) * min(1/f) otherwise).  A wave
+    // tile whose bound cannot get below the slot's current weight for any row and interval of the batch is
+    // not read at all — after the first intervals of a stream that is nearly every tile, because count-min
+    // estimates only grow.  The weights at batch start are used (they only fall during the batch), with the
+    // same 1e-5 relative band the fp64 resolve uses around fp32 values; skipped tiles report +inf.
+    if (kmin32) {
+        const int wt = tile * 4 + wid, row = lane & 7, slot = grp * SCAN_ROWS + row;
+        bool pass = false;
+        if (slot < slots) {
+            const double km = (double)kmin32[(size_t)slot * wtiles + wt];
+            const double w = weights[slot_begin + slot];
+            const double thr = w + 1e-5 * fabs(w) + 1e-37;
+            for (int t = lane >> 3; t < (int)fb.count; t += 8) {
+                if (!((gomask >> t) & 1u)) continue;
+                const float rmax = rext[((size_t)t * wtiles + wt) * 2], rmin = rext[((size_t)t * wtiles + wt) * 2 + 1];
+                if (!(rmax > 0.f)) continue;                     // no element of this interval falls into the tile
+                const double bound = km < 0.0 ? km * (double)rmax : km * (double)rmin;
+                if (bound <= thr) pass = true;
+            }
+        }
+        if (!__ballot(pass)) {
+            for (int t = lane >> 3; t < (int)fb.count; t += 8)
+                tilemin[(((size_t)t * ngroups + grp) * wtiles + (size_t)wt) * SCAN_ROWS + row] = INFINITY;
+            return;
+        }
+        if (lane == 0) atomicAdd(&visited[blockIdx.x & (MIN_SLOTS - 1)], 1ull);
+    }
     floatx4 kv[SCAN_ROWS];
 #pragma unroll
     for (int r = 0; r < SCAN_ROWS; r++) {
@@ -1492,9 +1550,6 @@ __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
         else
             kv[r] = (floatx4)(0.f);
     }
-    const uint32_t gomask = batch_gomask(st, fb);
-    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
-    const int lane = tid & 63;
     floatx4 rc_next = *(const floatx4 *)(rcp32 + col);
     for (int t = 0; t < (int)fb.count; t++) {
         const floatx4 rc = rc_next;
@@ -2235,11 +2290,20 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
 }
 
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
-                           int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb) {
+                           int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
+                           const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
+                           unsigned long long *d_visited) {
     const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
     const int chunks = (ntiles + 7) / 8;
+    if (d_kmin32)
+        hipLaunchKernelGGL(k_rcp_extrema, dim3(ntiles, fb.count), dim3(256), 0, s, d_rcp32, d_rext, ntiles, row_stride);
     hipLaunchKernelGGL(k_cws_scan, dim3((unsigned)(chunks * 8 * groups)), dim3(256), 0, s, d_k32, d_rcp32,
-                       d_tilemin, slots, ntiles, row_stride, st, fb);
+                       d_tilemin, slots, ntiles, row_stride, st, fb, d_kmin32, d_rext, d_weights, slot_begin, d_visited);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_kmin(hipStream_t s, const float *d_k32, float *d_kmin32, int slots, int ntiles, size_t row_stride) {
+    hipLaunchKernelGGL(k_tile_kmin, dim3(ntiles, slots), dim3(256), 0, s, d_k32, d_kmin32, ntiles, row_stride);
     return hipGetLastError();
 }
 

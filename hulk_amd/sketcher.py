@@ -102,6 +102,13 @@ class GpuSketcher:
         self._chk(self._L.hulk_add_reads(self._ctx, bases.ctypes.data, offsets.ctypes.data,
                                          len(offsets) - 1))
 
+    def scan_stats(self):
+        """(tiles of the CWS table the scans read, tiles they covered) — see hulk_get_scan_stats."""
+        import ctypes
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._chk(self._L.hulk_get_scan_stats(self._ctx, ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
+
     def sketch_files(self, paths, fasta=False, threads=0):
         """DataStreamer + FastqHandler + the AddSeq loop (pipeline/sketch.go:40-217) in native code:
         parse the inputs ([] = STDIN, *.gz gunzipped) and add every read.  Returns the ingest stats."""

@@ -197,6 +197,12 @@ int hulk_smash(int device, const uint64_t *mins, const double *weights, uint32_t
  * checks RN(1/r) against IEEE division for EVERY r in [1, 2^31] and returns the mismatch count. */
 int hulk_selftest_reciprocal(hulk_ctx *ctx, uint64_t *mismatches);
 
+/* Exact pruning of the CWS table scan (no concept drift): a 256-bin x 8-slot tile of K is only read when
+ * min(K) * max(1/f) (or min(K) * min(1/f) for min(K) >= 0) can get below one of its slots' current weights —
+ * AddElement only replaces a weight by a smaller A (histosketch.go:139-153), so the sketch is unchanged.
+ * Reports how many tiles the scans read out of how many they covered (both cumulative). */
+int hulk_get_scan_stats(hulk_ctx *ctx, uint64_t *tiles_visited, uint64_t *tiles_total);
+
 /* Per-kernel timing for bench.py: when enabled, hipEvents bracket every launch of the two heavy
  * kernels ("k_minimizer_fast", "k_cws_scan") on the work stream. */
 int hulk_set_profiling(hulk_ctx *ctx, int enabled);

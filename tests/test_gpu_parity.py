@@ -386,3 +386,32 @@ def test_many_long_reads_grouped_launches():
     assert np.array_equal(g.cms(), o.cms())
     assert_same_sketch(o, g)
     g.close(); o.close()
+
+
+def test_scan_pruning_is_exact_and_effective(monkeypatch):
+    """The bound test of k_cws_scan must not change a single bit of the sketch, and after the first
+    intervals of a stream it must skip most of the table (count-min estimates only grow)."""
+    from hulk_amd import synth
+    bases, offsets = synth.reads_numpy(0, 60000, 150)
+    res = {}
+    for prune in (True, False):
+        if prune:
+            monkeypatch.delenv("HULK_NO_PRUNE", raising=False)
+        else:
+            monkeypatch.setenv("HULK_NO_PRUNE", "1")
+        monkeypatch.setenv("HULK_BATCH", "4")
+        g = gpu().GpuSketcher(15, 9, 96, interval=2000)
+        g.add_reads(bases, offsets)
+        g.finish()
+        res[prune] = (g.sketch(), g.scan_stats(), g.cms())
+        g.close()
+    (m1, w1), (v1, t1), c1 = res[True]
+    (m0, w0), (v0, t0), c0 = res[False]
+    assert np.array_equal(m1, m0) and np.array_equal(w1, w0) and np.array_equal(c1, c0)
+    assert t1 == t0 and v0 == t0                       # unpruned: every covered tile is read
+    assert v1 < 0.35 * t1, (v1, t1)                    # 30 intervals: only the first batches read everything
+    o = pyorc.Sketcher(15, 9, 96, 0, 1.0, 2000)
+    o.add_reads(bases, offsets)
+    o.finish()
+    assert np.array_equal(o.sketch()[0], m1) and np.allclose(o.sketch()[1], w1, rtol=WEIGHT_RTOL, atol=0)
+    o.close()
