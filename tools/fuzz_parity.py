@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Randomised differential test: libhulkhip (GPU) vs the CPU oracle over random parameters and inputs.
+usage: fuzz_parity.py [n_cases] [seed]     (run on the GPU box; prints every mismatch and a summary)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch  # noqa: F401  (before libhulkhip, see hulk_amd/_lib.py)
+import hulk_amd
+from hulk_amd._lib import HulkError
+from oracle import pyorc
+from conftest import pack_reads
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ALPH = [b"ACGT", b"ACGT", b"ACGTN", b"ACGTacgt", b"ACGTNnRYU\x00\x03", b"AC"]
+bad = 0
+n_err = 0
+errs = {}
+t_start = time.time()
+for case in range(n_cases):
+    k = int(rng.choice([3, 5, 7, 8, 9, 11, 12, 13, 15, 16, 17]))         # k^4 bins and S*k^4 tables stay small
+    w = int(rng.choice([1, 2, 3, 4, 5, 9, 9, 9, 10, 16, 17, 25, 40]))
+    S = int(rng.choice([1, 2, 7, 8, 9, 16, 31, 50]))
+    decay = float(rng.choice([1.0, 1.0, 1.0, 0.0, 0.02, 0.3, 0.97]))
+    interval = int(rng.choice([0, 0, 1, 7, 50, 333]))
+    batch = int(rng.choice([1, 2, 5, 8, 16]))
+    alph = ALPH[int(rng.integers(0, len(ALPH)))]
+    n = int(rng.integers(1, 1500))
+    lo = w + k - 1
+    shape = int(rng.integers(0, 5))
+    if shape == 0:
+        lens = rng.integers(lo, lo + 40, size=n)
+    elif shape == 1:
+        lens = rng.integers(lo, 300, size=n) if lo < 300 else np.full(n, lo)
+    elif shape == 2:
+        lens = np.full(n, max(lo, 150))
+    elif shape == 3:
+        lens = rng.integers(lo, 3000, size=max(1, n // 10))
+    else:
+        lens = np.concatenate([rng.integers(lo, lo + 200, size=max(1, n // 2)), rng.integers(1100, 9000, size=3)])
+    a = np.frombuffer(alph, dtype=np.uint8)
+    seqs = []
+    for L in lens:
+        s = a[rng.integers(0, len(a), size=int(L))]
+        if rng.random() < 0.1 and L > 60:                       # internal repeat / low complexity
+            s[20:40] = s[0:20]
+        if rng.random() < 0.05:
+            s[:] = s[0]
+        seqs.append(bytes(s))
+    desc = f"case {case}: k={k} w={w} S={S} decay={decay} I={interval} batch={batch} alph={alph!r} reads={len(seqs)} shape={shape}"
+    os.environ["HULK_BATCH"] = str(batch)
+    oerr = gerr = None
+    o = pyorc.Sketcher(k, w, S, 0, decay, interval)
+    bases, offsets = pack_reads(seqs)
+    try:
+        o.add_reads(bases, offsets); o.finish()
+    except pyorc.OracleError as e:
+        oerr = str(e)
+    g = hulk_amd.GpuSketcher(k, w, S, interval, decay)
+    try:
+        cuts = sorted(set([0, len(seqs)] + [int(x) for x in rng.integers(0, len(seqs) + 1, size=3)]))
+        for x, y in zip(cuts[:-1], cuts[1:]):
+            g.add_reads(bases, offsets[x:y + 1])
+        g.finish()
+    except HulkError as e:
+        gerr = e.message
+    ok = True
+    if (oerr is None) != (gerr is None) or (oerr is not None and oerr != gerr):
+        ok = False; why = f"errors differ: oracle={oerr!r} gpu={gerr!r}"
+    elif oerr is None:
+        om, ow = o.sketch(); gm, gw = g.sketch()
+        if not np.array_equal(om, gm):
+            ok = False; why = f"{int((om != gm).sum())} of {S} mins differ"
+        elif not np.allclose(gw, ow, rtol=1e-7 if decay != 1.0 else 1e-9, atol=0):
+            ok = False; why = "weights differ: max rel %.3g" % float(np.max(np.abs(gw - ow) / np.abs(ow)))
+        elif o.counters()["n_minimizers"] != g.counters()["n_minimizers"]:
+            ok = False; why = "minimizer counts differ"
+    if oerr is not None:
+        n_err += 1; errs[oerr] = errs.get(oerr, 0) + 1
+    if not ok:
+        bad += 1
+        print("MISMATCH", desc, "::", why, flush=True)
+    g.close(); o.close()
+print(f"{n_cases} cases ({n_cases - n_err} sketches compared, {n_err} agreed on an error: {errs}), {bad} mismatches, "
+      f"{time.time() - t_start:.1f} s (seed {seed})")
+sys.exit(1 if bad else 0)
