@@ -209,3 +209,10 @@ def test_stdin(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], input=data, capture_output=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.decode().strip() == "ACGTGGCC [0, 4, 8]"
+
+
+def test_fuzz_slice():
+    """Fixed-seed slice of tools/fuzz_ingest.py (random line soups, CR/LF, several inputs, gzip, both modes)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ingest.py"), "120", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
