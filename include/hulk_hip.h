@@ -116,7 +116,10 @@ int hulk_set_cws_tables(hulk_ctx *ctx, const double *r, const double *c, const d
 int hulk_add_reads(hulk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads);
 /* Same, buffers already resident in this device's memory (offsets too).  `max_read_len` is an
  * upper bound on the read lengths in the batch (selects the kernel configuration);
- * `bases_bytes` is the size of the bases allocation.  Length validation happens on device. */
+ * `bases_bytes` is the size of the bases allocation.  Length validation happens on device.
+ * Stream order: the kernels run on the context's stream (private and non-blocking unless
+ * hulk_set_stream was called), so the buffers must be complete before the call — produce them on
+ * that stream or synchronise first — and must stay alive until the stream has passed the call. */
 int hulk_add_reads_device(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets,
                           uint64_t n_reads, uint32_t max_read_len, uint64_t bases_bytes);
 
