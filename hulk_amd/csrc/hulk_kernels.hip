@@ -369,7 +369,21 @@ __device__ __forceinline__ uint64_t dpp_row_shr1_u64(uint64_t v) {
     return (uint64_t)dpp_row_shr1((uint32_t)v) | ((uint64_t)dpp_row_shr1((uint32_t)(v >> 32)) << 32);
 }
 
-template <int WM>
+// 64-bit unsigned minimum.  For k <= 27 every minimizer value (hash64 << 8 | span < 2^62) and every
+// 2k-bit k-mer is the bit pattern of a non-negative finite double, whose order is the integer order, so
+// v_min_f64 (denormals preserved, kernel descriptor float_denorm_mode_16_64 = 3) does in ONE instruction
+// what v_cmp_lt_u64 + 2 v_cndmask do in three; "no value" is then +inf (0x7FF0...) instead of ~0.
+// Inline asm: the builtin would add a canonicalising v_max_f64 per operand.
+template <bool FM> __device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) {
+    if (FM) {
+        double d;
+        asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+        return (uint64_t)__double_as_longlong(d);
+    }
+    return a < b ? a : b;
+}
+
+template <int WM, bool FM>
 __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__restrict__ bases,
                                                         const uint64_t *__restrict__ offsets,
                                                         uint64_t n_reads, MinimizerParams P,
@@ -386,6 +400,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
         lut16[i] = (uint16_t)(((c & 3u) << (2 * t)) | ((c > 3 ? 1u : 0u) << (8 + t)));
     }
 
+    constexpr uint64_t XN = FM ? 0x7FF0000000000000ull : X_NONE;   // "no value": above every minimizer value
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, gsh = lane & 48;
     const int32_t k = (int32_t)P.k, w = (int32_t)P.w;
@@ -525,7 +540,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
         uint32_t validbits = 0;
         uint64_t X[WM];
 #pragma unroll
-        for (int t = 0; t < WM; t++) X[t] = X_NONE;
+        for (int t = 0; t < WM; t++) X[t] = XN;
         if (mine) {
             uint64_t f, r;
             {
@@ -552,7 +567,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     r = (r >> 2) | ((3ull ^ c) << shift);
                 }
                 if (t < w && p0 + t < npos && f != r) {
-                    const uint64_t canon = f > r ? r : f;
+                    const uint64_t canon = umin64<FM>(f, r);
                     int32_t span = span0 + t;
                     if (span >= k) span = k;
                     X[t] = ((dbg & 16u) ? canon * 0x9E3779B97F4A7C15ull : hash64(canon, mask)) << 8 | (uint64_t)(int64_t)span;
@@ -573,27 +588,27 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             // own suffix minima h[t] = min(X[t..w-1]); the next lane needs h[t+1] as hp[t]
             uint64_t hp[WM];
             {
-                uint64_t h = X_NONE;
+                uint64_t h = XN;
 #pragma unroll
                 for (int t = WM - 1; t >= 0; t--) {
-                    if (t < w) h = X[t] < h ? X[t] : h;
+                    if (t < w) h = umin64<FM>(X[t], h);
                     hp[t] = h;                                 // h[t]
                 }
             }
             const uint64_t whole = dpp_row_shr1_u64(hp[0]);    // min of the whole previous block
 #pragma unroll
             for (int t = 0; t < WM - 1; t++) hp[t] = dpp_row_shr1_u64(hp[t + 1]);
-            hp[WM - 1] = X_NONE;
+            hp[WM - 1] = XN;
             const uint32_t pv = dpp_row_shr1(validbits);
             bool pe = false; uint64_t pm = 0;
             if (gl > 0) { pe = ((pv >> (w - 1)) & 1u) && (p0 - 1 + k - 1 >= w - 1); pm = whole; }
-            uint64_t g = X_NONE;
+            uint64_t g = XN;
 #pragma unroll
             for (int t = 0; t < WM; t++) {
                 const uint64_t x = X[t];
-                g = x < g ? x : g;
-                const uint64_t hpt = (gl > 0 && t + 1 < w) ? hp[t] : X_NONE;
-                const uint64_t m = hpt < g ? hpt : g;
+                g = umin64<FM>(x, g);
+                const uint64_t hpt = (gl > 0 && t + 1 < w) ? hp[t] : XN;
+                const uint64_t m = umin64<FM>(hpt, g);
                 const bool emit = ((validbits >> t) & 1u) && (p0 + t + k - 1 >= w - 1);
                 if (emit && !(pe && pm == m)) startbits |= 1u << t;
                 X[t] = m;
@@ -2152,15 +2167,20 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
     const size_t lds = minimizer_fast_lds(P.w);
     const uint64_t blocks = (n_reads + 4 * FAST_READS_PER_WAVE - 1) / (4 * FAST_READS_PER_WAVE);
     const dim3 g((unsigned)blocks), b(256);
-    if (P.w <= 4)
-        hipLaunchKernelGGL(k_minimizer_fast<4>, g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,
-                           d_state, d_min_slots, d_slow_list, d_slow_count);
-    else if (P.w <= 9)
-        hipLaunchKernelGGL(k_minimizer_fast<9>, g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,
-                           d_state, d_min_slots, d_slow_list, d_slow_count);
-    else
-        hipLaunchKernelGGL(k_minimizer_fast<16>, g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,
-                           d_state, d_min_slots, d_slow_list, d_slow_count);
+    // k <= 27: 64-bit minima through v_min_f64 (see umin64); HULK_NO_FMIN keeps the integer compares (A/B aid)
+    static const bool no_fmin = getenv("HULK_NO_FMIN") != nullptr;
+    const bool fm = P.k <= 27 && !no_fmin;
+#define HULK_LAUNCH_FAST(WM)                                                                                         \
+    do {                                                                                                             \
+        if (fm) hipLaunchKernelGGL((k_minimizer_fast<WM, true>), g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,   \
+                                   d_state, d_min_slots, d_slow_list, d_slow_count);                                 \
+        else hipLaunchKernelGGL((k_minimizer_fast<WM, false>), g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,     \
+                                d_state, d_min_slots, d_slow_list, d_slow_count);                                    \
+    } while (0)
+    if (P.w <= 4) HULK_LAUNCH_FAST(4);
+    else if (P.w <= 9) HULK_LAUNCH_FAST(9);
+    else HULK_LAUNCH_FAST(16);
+#undef HULK_LAUNCH_FAST
     return hipGetLastError();
 }
 
