@@ -714,15 +714,20 @@ __global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_r
         const uint32_t nidx = idx + 64;
         if (nidx < cnt) { nx = xl[nidx]; ns = sl[nidx]; }      // prefetch the lane's next value
         // b+1 and the candidate j stay in fp64 (exact integers < 2^31): no int<->double round trip per step
-        double fj1 = 1.0, fres = 0.0;                           // float64(b+1) with b = -1+1.. ; result b
+        // only float64(b+1) is carried (the bucket is fj1 - 1 at the exit), and the loop is unrolled by two so that
+        // the LCG state ping-pongs between two register pairs: no v_mov_b64 per step (2 of 19 instructions)
+        double fj1 = 1.0;
         for (;;) {
             key = key * 2862933555777941757ull + 1;
-            const double p = fj1 * rcp_exact_u31((uint32_t)(key >> 33) + 1u);
+            double p = fj1 * rcp_exact_u31((uint32_t)(key >> 33) + 1u);
             if (p >= dn) break;                                 // j >= n: b (= fj1 - 1) is the bucket
-            fres = __builtin_trunc(p * 0x1p31);                 // j = int64(p * 2^31), exact
-            fj1 = fres + 1.0;
+            fj1 = __builtin_trunc(p * 0x1p31) + 1.0;            // j = int64(p * 2^31), exact; float64(j + 1)
+            key = key * 2862933555777941757ull + 1;
+            p = fj1 * rcp_exact_u31((uint32_t)(key >> 33) + 1u);
+            if (p >= dn) break;
+            fj1 = __builtin_trunc(p * 0x1p31) + 1.0;
         }
-        const int32_t res = (int32_t)fres;
+        const int32_t res = (int32_t)fj1 - 1;
         kl[idx] = (slot << 20) | (uint32_t)res;
         idx = nidx;
     }
