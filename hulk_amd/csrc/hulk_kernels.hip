@@ -369,6 +369,29 @@ __device__ __forceinline__ uint64_t dpp_row_shr1_u64(uint64_t v) {
     return (uint64_t)dpp_row_shr1((uint32_t)v) | ((uint64_t)dpp_row_shr1((uint32_t)(v >> 32)) << 32);
 }
 
+// hash64 for 2k <= 54 (FM kernels): the upper dword then has at most 22 bits, so the two multiply steps
+// (x265, x21) take v_mad_u64_u32 for the low dword and ONE full-rate v_mad_u32_u24 for the upper one,
+// instead of two v_mad_u64_u32 with a v_mov between them.  Same value as hash64 (mod 2^2k).
+template <bool FM> __device__ __forceinline__ uint64_t hash64_fm(uint64_t key, uint64_t mask) {
+    if (!FM) return hash64(key, mask);
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    {
+        const uint64_t p = (uint64_t)(uint32_t)key * 265u;
+        const uint32_t hi = (uint32_t)(p >> 32) + __umul24((uint32_t)(key >> 32), 265u);
+        key = (((uint64_t)hi << 32) | (uint32_t)p) & mask;
+    }
+    key = key ^ key >> 14;
+    {
+        const uint64_t p = (uint64_t)(uint32_t)key * 21u;
+        const uint32_t hi = (uint32_t)(p >> 32) + __umul24((uint32_t)(key >> 32), 21u);
+        key = (((uint64_t)hi << 32) | (uint32_t)p) & mask;
+    }
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
 // 64-bit unsigned minimum.  For k <= 27 every minimizer value (hash64 << 8 | span < 2^62) and every
 // 2k-bit k-mer is the bit pattern of a non-negative finite double, whose order is the integer order, so
 // v_min_f64 (denormals preserved, kernel descriptor float_denorm_mode_16_64 = 3) does in ONE instruction
@@ -383,7 +406,7 @@ template <bool FM> __device__ __forceinline__ uint64_t umin64(uint64_t a, uint64
     return a < b ? a : b;
 }
 
-template <int WM, bool FM>
+template <int WM, bool FM, bool DBG, bool WEQ, int KC>
 __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__restrict__ bases,
                                                         const uint64_t *__restrict__ offsets,
                                                         uint64_t n_reads, MinimizerParams P,
@@ -403,7 +426,9 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     constexpr uint64_t XN = FM ? 0x7FF0000000000000ull : X_NONE;   // "no value": above every minimizer value
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, gsh = lane & 48;
-    const int32_t k = (int32_t)P.k, w = (int32_t)P.w;
+    // WEQ: the window size equals the block size WM (w = 9 is the reference's default): every `t < w` test and
+    // every multiple of w becomes a compile-time constant
+    const int32_t k = KC ? KC : (int32_t)P.k, w = WEQ ? WM : (int32_t)P.w;   // KC: k fixed at compile time (21 = the default)
     const uint64_t mask = (1ull << (2 * k)) - 1;
     const uint64_t shift = (uint64_t)(2 * (k - 1));
     uint64_t *tab = (uint64_t *)(smem + 2048) + (size_t)grp * FAST_TAB;
@@ -420,7 +445,9 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     uint64_t *xl = ml.x + region * ml.rcap;
     uint8_t *sl8 = ml.slot + region * ml.rcap;
     uint32_t wcount = 0;              // wave-uniform: values written to the region so far
-    const uint32_t dbg = P.debug;     // ablation switches (tools/k1_ablate.py); 0 in production
+    // ablation switches (tools/k1_ablate.py) exist only in the DBG instantiation: in the production kernel they
+    // cost a branch per k-mer position and SGPRs the compiler then spills to VGPR lanes
+    const uint32_t dbg = DBG ? P.debug : 0u;
     uint32_t sink = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0 && n_reads)
         atomicAdd(&st->total_len, (unsigned long long)(offsets[n_reads] - offsets[0]));
@@ -570,7 +597,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     const uint64_t canon = umin64<FM>(f, r);
                     int32_t span = span0 + t;
                     if (span >= k) span = k;
-                    X[t] = ((dbg & 16u) ? canon * 0x9E3779B97F4A7C15ull : hash64(canon, mask)) << 8 | (uint64_t)(int64_t)span;
+                    X[t] = ((dbg & 16u) ? canon * 0x9E3779B97F4A7C15ull : hash64_fm<FM>(canon, mask)) << 8 | (uint64_t)(int64_t)span;
                     validbits |= 1u << t;
                 }
             }
@@ -2175,16 +2202,24 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
     // k <= 27: 64-bit minima through v_min_f64 (see umin64); HULK_NO_FMIN keeps the integer compares (A/B aid)
     static const bool no_fmin = getenv("HULK_NO_FMIN") != nullptr;
     const bool fm = P.k <= 27 && !no_fmin;
+#define HULK_LAUNCH_FAST2(WM, FMv, DBGv, WEQv, KCv)                                                                  \
+    hipLaunchKernelGGL((k_minimizer_fast<WM, FMv, DBGv, WEQv, KCv>), g, b, lds, s, d_bases, d_offsets, n_reads, P,   \
+                       ml, d_state, d_min_slots, d_slow_list, d_slow_count)
 #define HULK_LAUNCH_FAST(WM)                                                                                         \
     do {                                                                                                             \
-        if (fm) hipLaunchKernelGGL((k_minimizer_fast<WM, true>), g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,   \
-                                   d_state, d_min_slots, d_slow_list, d_slow_count);                                 \
-        else hipLaunchKernelGGL((k_minimizer_fast<WM, false>), g, b, lds, s, d_bases, d_offsets, n_reads, P, ml,     \
-                                d_state, d_min_slots, d_slow_list, d_slow_count);                                    \
+        const bool weq = P.w == WM;                                                                                  \
+        if (P.debug) HULK_LAUNCH_FAST2(WM, false, true, false, 0);                                                   \
+        else if (fm && weq && P.k == 21) HULK_LAUNCH_FAST2(WM, true, false, true, 21);   /* hulk's defaults: k=21, w=9 */ \
+        else if (!fm && weq && P.k == 31) HULK_LAUNCH_FAST2(WM, false, false, true, 31); /* the largest k */          \
+        else if (fm && weq) HULK_LAUNCH_FAST2(WM, true, false, true, 0);                                             \
+        else if (fm) HULK_LAUNCH_FAST2(WM, true, false, false, 0);                                                   \
+        else if (weq) HULK_LAUNCH_FAST2(WM, false, false, true, 0);                                                  \
+        else HULK_LAUNCH_FAST2(WM, false, false, false, 0);                                                          \
     } while (0)
     if (P.w <= 4) HULK_LAUNCH_FAST(4);
     else if (P.w <= 9) HULK_LAUNCH_FAST(9);
     else HULK_LAUNCH_FAST(16);
+#undef HULK_LAUNCH_FAST2
 #undef HULK_LAUNCH_FAST
     return hipGetLastError();
 }
