@@ -80,6 +80,20 @@ __device__ __forceinline__ double rcp_exact_u31(uint32_t r) {
     return y;
 }
 
+// The same quotient the reference forms: float64(1<<31) / float64(r) = RN(2^31 / r).  r * 2^-31 is built by
+// lowering the exponent field of float64(r) (an integer add on the upper dword), the Newton iteration is the
+// scaled image of rcp_exact_u31's; k_selftest_rcp checks every r in [1, 2^31] against the IEEE quotient too.
+__device__ __forceinline__ double quot31_exact(uint32_t r) {
+    uint64_t bits = (uint64_t)__double_as_longlong((double)r) - (31ull << 52);
+    const double d = __longlong_as_double((long long)bits);          // r * 2^-31, exact
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+
 __device__ __forceinline__ int32_t jump_hash(uint64_t key, int32_t n) {
     // b+1 <= n < 2^31 and (key>>33)+1 <= 2^31 convert exactly from uint32; the product is only
     // needed (a) to decide j >= n and (b), when j < n, as a value below 2^31 — so the int64
@@ -732,7 +746,6 @@ __global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_r
     const uint64_t *xl = ml.x + (size_t)region * ml.rcap;
     const uint8_t *sl = ml.slot + (size_t)region * ml.rcap;
     uint32_t *kl = ml.key + ml.off[region];                   // dense: regions back to back
-    const double dn = (double)num_bins * 0x1p-31;
     uint32_t idx = (uint32_t)lane;
     uint64_t nx = 0; uint32_t ns = 0;
     if (idx < cnt) { nx = xl[idx]; ns = sl[idx]; }
@@ -741,20 +754,24 @@ __global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_r
         const uint32_t nidx = idx + 64;
         if (nidx < cnt) { nx = xl[nidx]; ns = sl[nidx]; }      // prefetch the lane's next value
         // b+1 and the candidate j stay in fp64 (exact integers < 2^31): no int<->double round trip per step
-        // only float64(b+1) is carried (the bucket is fj1 - 1 at the exit), and the loop is unrolled by two so that
-        // the LCG state ping-pongs between two register pairs: no v_mov_b64 per step (2 of 19 instructions)
-        double fj1 = 1.0;
+        // Literally the reference's step: j = int64(float64(b+1) * (float64(1<<31) / float64(r))).  float64(b) = t is
+        // carried; (t + 1) * q is ONE fma(t, q, q) — the exact product rounded once, as the multiplication is —
+        // so a step needs no add and no ldexp.  Unrolled by two: the LCG state ping-pongs between register pairs.
+        const double fn = (double)num_bins;
+        double t = 0.0;                                         // float64(b), b = 0 before the first step
         for (;;) {
             key = key * 2862933555777941757ull + 1;
-            double p = fj1 * rcp_exact_u31((uint32_t)(key >> 33) + 1u);
-            if (p >= dn) break;                                 // j >= n: b (= fj1 - 1) is the bucket
-            fj1 = __builtin_trunc(p * 0x1p31) + 1.0;            // j = int64(p * 2^31), exact; float64(j + 1)
+            double q = quot31_exact((uint32_t)(key >> 33) + 1u);
+            double p = __builtin_fma(t, q, q);
+            if (p >= fn) break;                                 // j >= n: t is the bucket
+            t = __builtin_trunc(p);                             // j = int64(p): exact, < 2^31
             key = key * 2862933555777941757ull + 1;
-            p = fj1 * rcp_exact_u31((uint32_t)(key >> 33) + 1u);
-            if (p >= dn) break;
-            fj1 = __builtin_trunc(p * 0x1p31) + 1.0;
+            q = quot31_exact((uint32_t)(key >> 33) + 1u);
+            p = __builtin_fma(t, q, q);
+            if (p >= fn) break;
+            t = __builtin_trunc(p);
         }
-        const int32_t res = (int32_t)fj1 - 1;
+        const int32_t res = (int32_t)t;
         kl[idx] = (slot << 20) | (uint32_t)res;
         idx = nidx;
     }
@@ -2138,6 +2155,7 @@ __global__ __launch_bounds__(256) void k_selftest_rcp(unsigned long long *mismat
         const double a = rcp_exact_u31((uint32_t)r);
         const double b = 1.0 / (double)(uint32_t)r;
         bad += (a != b);
+        bad += (quot31_exact((uint32_t)r) != 0x1p31 / (double)(uint32_t)r);
     }
     for (int off = 32; off; off >>= 1) bad += __shfl_xor(bad, off);
     if (lane_id() == 0 && bad) atomicAdd(mismatches, (unsigned long long)bad);
