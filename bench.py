@@ -234,8 +234,10 @@ def main():
                                   "avg_launch_us": avg_s * 1e6, "alg_bytes_per_launch": alg_bytes,
                                   "intervals_per_launch": BATCH, "tiles_read_per_launch": visited,
                                   "tiles_covered_per_launch": covered, "unpruned_bytes_per_launch": full_bytes,
-                                  "note": "exact branch-and-bound: only tiles whose lower bound can beat a slot's "
-                                          "current weight are read (identical sketch; HULK_NO_PRUNE=1 disables)"},
+                                  "note": "exact branch-and-bound: a batch whose smallest count-min counter already rules "
+                                          "out every slot skips the estimates/scan/resolve, otherwise only tiles whose "
+                                          "lower bound can beat a slot's current weight are read (identical sketch; "
+                                          "HULK_NO_PRUNE=1 disables both = value_unpruned)"},
             "path_bytes_per_read": READ_LEN + 4.0 * S * (K ** 4) / (INTERVAL * world),
             "sketch_md5": __import__("hashlib").md5(mins.astype("<u8").tobytes()).hexdigest(),
             # same K steps with the exact pruning of the CWS scan switched off: every interval streams the whole

@@ -96,7 +96,7 @@ struct hulk_ctx {
     double *d_segadd = nullptr, *d_segfac = nullptr, *d_cstart = nullptr; uint32_t *d_sege0 = nullptr; // ... with decay
     double *d_f64 = nullptr, *d_weights = nullptr, *d_rcb = nullptr;
     float *d_rcp32 = nullptr, *d_k32 = nullptr, *d_tilemin = nullptr;
-    float *d_kmin32 = nullptr, *d_rext = nullptr;          // bound test of k_cws_scan (no concept drift only)
+    float *d_kmin32 = nullptr, *d_rext = nullptr, *d_kminslot = nullptr;          // bound test of k_cws_scan (no concept drift only)
     unsigned long long *d_visited = nullptr; uint64_t scan_tiles_total = 0; bool prune = false;
     double *d_candA = nullptr; int32_t *d_candB = nullptr;
     // staging for host reads
@@ -191,7 +191,10 @@ int install_tables(hulk_ctx *c, const double *r, const double *cc, const double 
         HIPCHK(c, hipMemcpy(c->d_rcb + (size_t)s * B * 3, row.data(), B * 3 * sizeof(double), hipMemcpyHostToDevice));
     }
     HIPCHK(c, launch_build_k32(c->stream, c->d_rcb, c->d_k32, (int)c->slots, c->B, c->row_stride));
-    if (c->slots) HIPCHK(c, launch_tile_kmin(c->stream, c->d_k32, c->d_kmin32, (int)c->slots, c->ntiles, c->row_stride));
+    if (c->slots) {
+        HIPCHK(c, launch_tile_kmin(c->stream, c->d_k32, c->d_kmin32, (int)c->slots, c->ntiles, c->row_stride));
+        HIPCHK(c, launch_slot_kmin(c->stream, c->d_kmin32, c->d_kminslot, (int)c->slots, c->ntiles));
+    }
     c->tables_ready = true;
     return HULK_OK;
 }
@@ -263,7 +266,10 @@ int generate_tables(hulk_ctx *c) {
         }
     }
     GEN_CHK(launch_build_k32(c->stream, c->d_rcb, c->d_k32, (int)c->slots, c->B, c->row_stride));
-    if (c->slots) GEN_CHK(launch_tile_kmin(c->stream, c->d_k32, c->d_kmin32, (int)c->slots, c->ntiles, c->row_stride));
+    if (c->slots) {
+        GEN_CHK(launch_tile_kmin(c->stream, c->d_k32, c->d_kmin32, (int)c->slots, c->ntiles, c->row_stride));
+        GEN_CHK(launch_slot_kmin(c->stream, c->d_kmin32, c->d_kminslot, (int)c->slots, c->ntiles));
+    }
     GEN_CHK(hipStreamSynchronize(c->stream));
 #undef GEN_CHK
     cleanup();
@@ -456,6 +462,11 @@ int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, b
     }
     uint32_t *hist = ring_hist(c);
     HIPCHK(c, launch_count_used(s, hist, c->d_state, fb));
+    {   // whole-batch bound on the counters as they stand BEFORE this batch is added (see k_flush_decide)
+        static const bool no_skip = getenv("HULK_NO_SKIP") != nullptr;
+        HIPCHK(c, launch_flush_decide(s, c->d_ctr, c->cms_depth * c->cms_width, c->d_kminslot, c->d_weights, (int)c->slots,
+                                      (int)c->slot_begin, c->d_state, fb, (c->prune && !no_skip && c->slots) ? 1 : 0));
+    }
     if (c->scaling) {
         HIPCHK(c, launch_elem_index(s, hist, c->d_blkcnt, c->d_eidx, c->d_etot, fb));
         static const bool chain_order_d = getenv("HULK_CMS_CHAINS") != nullptr;
@@ -600,6 +611,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_tilemin, T * ((SL + SCAN_ROWS - 1) / SCAN_ROWS) * SCAN_ROWS * (size_t)c->ntiles * 4));
     CHK_CREATE(dalloc(&c->d_kmin32, (SL ? SL : 1) * (size_t)c->ntiles * 4));
     CHK_CREATE(dalloc(&c->d_rext, T * (size_t)c->ntiles * 4 * 2));
+    CHK_CREATE(dalloc(&c->d_kminslot, (SL ? SL : 1)));
     CHK_CREATE(dalloc(&c->d_visited, (size_t)MIN_SLOTS));
     CHK_CREATE(hipMemsetAsync(c->d_visited, 0, (size_t)MIN_SLOTS * 8, c->stream));
     // exact pruning of the K scan needs "weights only fall": off with concept drift (curMin = w / decayWeight)
@@ -651,7 +663,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_ctr); hipFree(c->d_estl); hipFree(c->d_basearr); hipFree(c->d_invperm); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
     hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd); hipFree(c->d_estd);
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
-    hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited);
+    hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited); hipFree(c->d_kminslot);
     hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
     hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial);
     hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);

@@ -18,6 +18,8 @@ struct DevState {
     unsigned long long n_elements;    // AddElement calls (non-zero bins streamed)
     unsigned int used[2][RING_MAX];   // KmerSpectrum.Cardinality() per ring spectrum (ping-pong by flush parity)
     int err;                          // first deferred HULK_ERR_* (0 = none)
+    unsigned int skip_exact[2];       // by flush parity: no element of this batch can lower any slot's weight
+                                      // (k_flush_decide) -> the estimates, the K scan and the resolve are not run
     unsigned int pad;
 };
 
@@ -109,6 +111,10 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
                            unsigned long long *d_visited);
 hipError_t launch_tile_kmin(hipStream_t s, const float *d_k32, float *d_kmin32, int slots, int ntiles, size_t row_stride);
+hipError_t launch_slot_kmin(hipStream_t s, const float *d_kmin32, float *d_kminslot, int slots, int ntiles);
+hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, int ncounters, const float *d_kminslot,
+                               const double *d_weights, int slots, int slot_begin, DevState *st, const FlushBatch &fb,
+                               int enable);
 hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,
                               const float *d_tilemin, double *d_candA, int32_t *d_candB,
                               unsigned long long *d_mins, double *d_weights,

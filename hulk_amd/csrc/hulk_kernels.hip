@@ -1241,6 +1241,12 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
     }
     if (!go) return;
     const size_t B = (size_t)fb.num_bins;
+    if (st->skip_exact[fb.parity]) {                                             // k_flush_decide: only Wipe is left to do
+        uint32_t *hw = hists + (size_t)slot * B;
+        const int64_t w0 = (int64_t)seg * seg_chunks * 64, w1 = w0 + (int64_t)seg_chunks * 64;
+        for (int64_t b = w0 + tid; b < w1 && b < (int64_t)B; b += blockDim.x) hw[b] = 0;
+        return;
+    }
     {
         const unsigned long long *bt = base + (((size_t)t * depth) * CMS_SEGS) * width;
         for (int i = tid; i < depth * width; i += blockDim.x) {
@@ -1526,6 +1532,55 @@ __device__ __forceinline__ float wave_min8_by_row(float (&m)[8]) {
     return m[0];
 }
 
+// Whole-batch bound (no concept drift).  Every count-min estimate of the batch is at least the smallest
+// counter at batch start (an estimate is a minimum over counters that only grow), so A = K/f >= min_slot(K) / Cmin
+// for every negative K of a slot's row (>= 0 otherwise).  If that cannot get below the current weight of ANY slot
+// (same 1e-5 band as the scan), no AddElement of the batch can change the sketch: skip_exact is raised and
+// k_cms_freq only wipes the spectra, k_rcp_extrema / k_cws_scan / k_cws_resolve / k_cws_apply return at once.
+// The count-min counters are still advanced (k_cms_segsum + k_cms_base).  After the first intervals of a stream
+// this is the normal case: counters are in the tens of thousands while the winning weights came from f ~ 10.
+__global__ __launch_bounds__(1024) void k_flush_decide(const unsigned long long *__restrict__ ctr, int ncounters,
+                                                       const float *__restrict__ kminslot,
+                                                       const double *__restrict__ weights, int slots, int slot_begin,
+                                                       DevState *st, FlushBatch fb, int enable) {
+    __shared__ unsigned long long red[16];
+    __shared__ int anypass;
+    const int tid = threadIdx.x;
+    if (tid == 0) anypass = 0;
+    unsigned long long m = ~0ull;
+    for (int i = tid; i < ncounters; i += blockDim.x) { const unsigned long long v = ctr[i]; m = v < m ? v : m; }
+    for (int off = 32; off; off >>= 1) { const unsigned long long o = __shfl_xor(m, off); m = o < m ? o : m; }
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = red[0];
+    for (int i = 1; i < 16; i++) m = red[i] < m ? red[i] : m;
+    bool pass = false;
+    if (!enable || m == 0) pass = true;                          // an untouched counter: estimates can be as small as 1
+    else {
+        const double rmax = 1.0 / (double)m;
+        for (int s = tid; s < slots; s += blockDim.x) {
+            const double km = (double)kminslot[s];
+            const double w = weights[slot_begin + s];
+            const double thr = w + 1e-5 * fabs(w) + 1e-37;
+            const double bound = km < 0.0 ? km * rmax : 0.0;
+            if (bound <= thr) pass = true;
+        }
+    }
+    if (pass) atomicOr(&anypass, 1);
+    __syncthreads();
+    if (tid == 0) st->skip_exact[fb.parity] = anypass ? 0u : 1u;
+}
+__global__ __launch_bounds__(256) void k_slot_kmin(const float *__restrict__ kmin32, float *__restrict__ kminslot, int wtiles) {
+    __shared__ float red[4];
+    const int slot = blockIdx.x;
+    float m = INFINITY;
+    for (int i = threadIdx.x; i < wtiles; i += blockDim.x) m = fminf(m, kmin32[(size_t)slot * wtiles + i]);
+    for (int off = 32; off; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) kminslot[slot] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+}
+
 // Static per (slot, 256-bin wave tile) minimum of K32, and per flush the extrema of the reciprocal
 // vectors per (interval, wave tile): the inputs of k_cws_scan's bound test.
 __global__ __launch_bounds__(256) void k_tile_kmin(const float *__restrict__ k32, float *__restrict__ kmin32,
@@ -1537,7 +1592,8 @@ __global__ __launch_bounds__(256) void k_tile_kmin(const float *__restrict__ k32
     if ((threadIdx.x & 63) == 0) kmin32[(size_t)slot * (size_t)(ntiles * 4) + (size_t)(tile * 4 + wid)] = m;
 }
 __global__ __launch_bounds__(256) void k_rcp_extrema(const float *__restrict__ rcp32, float *__restrict__ rext,
-                                                     int ntiles, size_t row_stride) {
+                                                     int ntiles, size_t row_stride, const DevState *st, FlushBatch fb) {
+    if (st->skip_exact[fb.parity]) return;
     const int t = blockIdx.y, tile = blockIdx.x, wid = threadIdx.x >> 6;
     const floatx4 v = *(const floatx4 *)(rcp32 + (size_t)t * row_stride + (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * 4);
     // NaN = bin not in the stream: fmaxf / fminf return the other operand
@@ -1567,6 +1623,7 @@ __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
     // ALL slot groups before moving on, so a column's reciprocal vectors (T x 4 KB) are fetched into
     // that XCD's L2 once and re-used by the other groups; the 8 XCDs stream 8 adjacent 4 KB pieces of
     // the same K rows at the same time (32 KB contiguous per row).
+    if (st->skip_exact[fb.parity]) return;                       // k_flush_decide: nothing in this batch can matter
     const int ngrp = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
     const int chunk = blockIdx.x / (8 * ngrp), rem = blockIdx.x % (8 * ngrp);
     const int grp = rem / 8, tile = chunk * 8 + (rem % 8);
@@ -1655,6 +1712,7 @@ __global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ 
     __shared__ int32_t redB[4];
     __shared__ int ncand;
     __shared__ int cand[64];
+    if (st->skip_exact[fb.parity]) return;
     const int slot = blockIdx.x, t = blockIdx.y;     // local slot, interval of the batch
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wtiles = ntiles * 4;
@@ -1739,7 +1797,7 @@ __global__ void k_cws_apply(const double *__restrict__ candA, const int32_t *__r
                             unsigned long long *__restrict__ mins, double *__restrict__ weights,
                             int slots, int slot_begin, const DevState *st, FlushBatch fb) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= slots) return;
+    if (slot >= slots || st->skip_exact[fb.parity]) return;
     const int gs = slot_begin + slot;
     double w = weights[gs]; unsigned long long m = mins[gs];
     for (int t = 0; t < (int)fb.count; t++) {
@@ -2374,9 +2432,22 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
     const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
     const int chunks = (ntiles + 7) / 8;
     if (d_kmin32)
-        hipLaunchKernelGGL(k_rcp_extrema, dim3(ntiles, fb.count), dim3(256), 0, s, d_rcp32, d_rext, ntiles, row_stride);
+        hipLaunchKernelGGL(k_rcp_extrema, dim3(ntiles, fb.count), dim3(256), 0, s, d_rcp32, d_rext, ntiles, row_stride, st, fb);
     hipLaunchKernelGGL(k_cws_scan, dim3((unsigned)(chunks * 8 * groups)), dim3(256), 0, s, d_k32, d_rcp32,
                        d_tilemin, slots, ntiles, row_stride, st, fb, d_kmin32, d_rext, d_weights, slot_begin, d_visited);
+    return hipGetLastError();
+}
+
+hipError_t launch_slot_kmin(hipStream_t s, const float *d_kmin32, float *d_kminslot, int slots, int ntiles) {
+    hipLaunchKernelGGL(k_slot_kmin, dim3(slots), dim3(256), 0, s, d_kmin32, d_kminslot, ntiles * 4);
+    return hipGetLastError();
+}
+
+hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, int ncounters, const float *d_kminslot,
+                               const double *d_weights, int slots, int slot_begin, DevState *st, const FlushBatch &fb,
+                               int enable) {
+    hipLaunchKernelGGL(k_flush_decide, dim3(1), dim3(1024), 0, s, d_ctr, ncounters, d_kminslot, d_weights, slots,
+                       slot_begin, st, fb, enable);
     return hipGetLastError();
 }
 

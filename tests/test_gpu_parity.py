@@ -394,11 +394,13 @@ def test_scan_pruning_is_exact_and_effective(monkeypatch):
     from hulk_amd import synth
     bases, offsets = synth.reads_numpy(0, 60000, 150)
     res = {}
-    for prune in (True, False):
-        if prune:
-            monkeypatch.delenv("HULK_NO_PRUNE", raising=False)
-        else:
+    for prune in (True, False, "tiles-only"):
+        monkeypatch.delenv("HULK_NO_PRUNE", raising=False)
+        monkeypatch.delenv("HULK_NO_SKIP", raising=False)
+        if prune is False:
             monkeypatch.setenv("HULK_NO_PRUNE", "1")
+        elif prune == "tiles-only":
+            monkeypatch.setenv("HULK_NO_SKIP", "1")            # per-tile bound only, no whole-batch bound
         monkeypatch.setenv("HULK_BATCH", "4")
         g = gpu().GpuSketcher(15, 9, 96, interval=2000)
         g.add_reads(bases, offsets)
@@ -408,6 +410,8 @@ def test_scan_pruning_is_exact_and_effective(monkeypatch):
     (m1, w1), (v1, t1), c1 = res[True]
     (m0, w0), (v0, t0), c0 = res[False]
     assert np.array_equal(m1, m0) and np.array_equal(w1, w0) and np.array_equal(c1, c0)
+    (m2, w2), (v2, t2), c2 = res["tiles-only"]
+    assert np.array_equal(m2, m0) and np.array_equal(w2, w0) and np.array_equal(c2, c0) and v2 >= v1
     assert t1 == t0 and v0 == t0                       # unpruned: every covered tile is read
     assert v1 < 0.35 * t1, (v1, t1)                    # 30 intervals: only the first batches read everything
     o = pyorc.Sketcher(15, 9, 96, 0, 1.0, 2000)
