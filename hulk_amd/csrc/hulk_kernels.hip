@@ -2317,7 +2317,8 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     const uint32_t n_spectra = P.interval ? (uint32_t)((P.fill + n_reads + P.interval - 1) / P.interval) : 1u;
     const int nranges = (P.num_bins + HIST_RANGE - 1) / HIST_RANGE;
     static int parts_target = -1;
-    if (parts_target < 0) { const char *ep = getenv("HULK_HIST_BLOCKS"); parts_target = ep ? atoi(ep) : 512;   // workgroups per launch (swept 256..768: 110-123 us, flat) }
+    // workgroups per launch (swept 256..768: 110-123 us for histogram + merge, flat)
+    if (parts_target < 0) { const char *ep = getenv("HULK_HIST_BLOCKS"); parts_target = ep ? atoi(ep) : 512; }
     uint32_t n_parts = (uint32_t)parts_target / (uint32_t)(nranges * n_spectra);
     if (n_parts < 1) n_parts = 1;
     if (n_parts > ml.max_parts) n_parts = ml.max_parts;
