@@ -78,7 +78,7 @@ struct hulk_ctx {
     int ntiles = 0; size_t row_stride = 0;
     bool drift = false, scaling = false;   // ApplyConceptDrift (histosketch.go:79-81), applyScaling (countmin.go:50-55)
     double decay_weight = 0.0;
-    uint32_t *d_blkcnt = nullptr, *d_eidx = nullptr, *d_etot = nullptr; double *d_ctrd = nullptr, *d_estd = nullptr;
+    uint32_t *d_blkcnt = nullptr, *d_eidx = nullptr, *d_etot = nullptr; double *d_ctrd = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // Flushes run on their own stream so that the (memory/latency-bound) count-min + CWS kernels of
     // batch n overlap the (VALU-bound) minimizer kernels of batch n+1.  Two spectrum rings alternate.
@@ -89,9 +89,8 @@ struct hulk_ctx {
     // device state
     DevState *d_state = nullptr;
     uint32_t *d_hist = nullptr, *d_hist_tmp = nullptr;
-    uint32_t *d_perm = nullptr, *d_chain_start = nullptr;
-    unsigned long long *d_ctr = nullptr, *d_basearr = nullptr, *d_mins = nullptr, *d_min_slots = nullptr;
-    uint32_t *d_estl = nullptr, *d_invperm = nullptr; uint16_t *d_pos16 = nullptr;
+    unsigned long long *d_ctr = nullptr, *d_mins = nullptr, *d_min_slots = nullptr;
+    uint16_t *d_pos16 = nullptr;
     uint8_t *d_meta8 = nullptr; uint32_t *d_segsum = nullptr; unsigned long long *d_cbase = nullptr;   // bin-order count-min
     double *d_segadd = nullptr, *d_segfac = nullptr, *d_cstart = nullptr; uint32_t *d_sege0 = nullptr; // ... with decay
     double *d_f64 = nullptr, *d_weights = nullptr, *d_rcb = nullptr;
@@ -137,23 +136,13 @@ template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((voi
 // position g = jump(bin*(d+1), width) (countmin.go:122-125), ascending bin inside a group.
 int build_chains(hulk_ctx *c) {
     const int D = c->cms_depth, W = c->cms_width; const int32_t B = c->B;
-    std::vector<uint32_t> perm((size_t)D * B), start((size_t)D * (W + 1)), pos(B), invperm((size_t)D * B);
+    std::vector<uint32_t> pos(B);
     std::vector<uint16_t> pos16((size_t)D * B);
     std::vector<uint8_t> meta8((size_t)D * B);       // bits 0-6: previous lane of the 64-bin chunk on the same counter (64 = none); bit 7: last one
     for (int d = 0; d < D; d++) {
-        std::vector<uint32_t> cnt(W + 1, 0);
         for (int32_t b = 0; b < B; b++) {
-            uint64_t h = (uint64_t)b + (uint64_t)d * (uint64_t)b;
+            uint64_t h = (uint64_t)b + (uint64_t)d * (uint64_t)b;      // countmin.go:123-125: hash(bin + d * bin)
             pos[b] = (uint32_t)jump_host(h, W);
-            cnt[pos[b] + 1]++;
-        }
-        for (int g = 0; g < W; g++) cnt[g + 1] += cnt[g];
-        for (int g = 0; g <= W; g++) start[(size_t)d * (W + 1) + g] = cnt[g];
-        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
-        for (int32_t b = 0; b < B; b++) {
-            const uint32_t at = cur[pos[b]]++;
-            perm[(size_t)d * B + at] = (uint32_t)b;
-            invperm[(size_t)d * B + b] = at;
             pos16[(size_t)d * B + b] = (uint16_t)pos[b];
         }
         std::vector<int32_t> last_bin(W, -1);
@@ -170,14 +159,8 @@ int build_chains(hulk_ctx *c) {
     }
     HIPCHK(c, dalloc(&c->d_meta8, meta8.size()));
     HIPCHK(c, hipMemcpy(c->d_meta8, meta8.data(), meta8.size(), hipMemcpyHostToDevice));
-    HIPCHK(c, dalloc(&c->d_invperm, invperm.size()));
     HIPCHK(c, dalloc(&c->d_pos16, pos16.size()));
-    HIPCHK(c, hipMemcpy(c->d_invperm, invperm.data(), invperm.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_pos16, pos16.data(), pos16.size() * 2, hipMemcpyHostToDevice));
-    HIPCHK(c, dalloc(&c->d_perm, perm.size()));
-    HIPCHK(c, dalloc(&c->d_chain_start, start.size()));
-    HIPCHK(c, hipMemcpy(c->d_perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_chain_start, start.data(), start.size() * 4, hipMemcpyHostToDevice));
     return HULK_OK;
 }
 
@@ -469,28 +452,12 @@ int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, b
     }
     if (c->scaling) {
         HIPCHK(c, launch_elem_index(s, hist, c->d_blkcnt, c->d_eidx, c->d_etot, fb));
-        static const bool chain_order_d = getenv("HULK_CMS_CHAINS") != nullptr;
-        if (chain_order_d) {
-            HIPCHK(c, launch_cms_chains_decay(s, hist, c->d_perm, c->d_chain_start, c->d_eidx, c->d_etot, c->d_ctrd,
-                                              c->d_estd, c->cms_depth, c->cms_width, c->decay_weight, c->d_state, fb));
-            HIPCHK(c, launch_freq_decay(s, hist, c->d_estd, c->d_invperm, c->d_f64, c->d_rcp32, c->cms_depth,
-                                        c->row_stride, c->d_state, fb));
-        } else {
-            HIPCHK(c, launch_cmsd_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_eidx, c->d_etot, c->d_ctrd, c->d_segadd,
-                                           c->d_segfac, c->d_sege0, c->d_cstart, c->d_f64, c->d_rcp32, c->cms_depth,
-                                           c->cms_width, c->row_stride, c->decay_weight, c->d_state, fb));
-        }
+        HIPCHK(c, launch_cmsd_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_eidx, c->d_etot, c->d_ctrd, c->d_segadd,
+                                       c->d_segfac, c->d_sege0, c->d_cstart, c->d_f64, c->d_rcp32, c->cms_depth,
+                                       c->cms_width, c->row_stride, c->decay_weight, c->d_state, fb));
     } else {
-        static const bool chain_order = getenv("HULK_CMS_CHAINS") != nullptr;   // the earlier chain-order kernels (A/B aid)
-        if (chain_order) {
-            HIPCHK(c, launch_cms_chains(s, hist, c->d_perm, c->d_chain_start, c->d_ctr, c->d_estl, c->d_basearr,
-                                        c->cms_depth, c->cms_width, c->d_state, fb));
-            HIPCHK(c, launch_freq(s, hist, c->d_estl, c->d_basearr, c->d_invperm, c->d_pos16, c->d_f64, c->d_rcp32,
-                                  c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
-        } else {
-            HIPCHK(c, launch_cms_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_ctr, c->d_segsum, c->d_cbase, c->d_f64,
-                                          c->d_rcp32, c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
-        }
+        HIPCHK(c, launch_cms_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_ctr, c->d_segsum, c->d_cbase, c->d_f64,
+                                      c->d_rcp32, c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
     }
     if (c->slots) {
         ProfileRec pr{};
@@ -598,10 +565,8 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_min_slots, (size_t)MIN_SLOTS));
     CHK_CREATE(hipMemsetAsync(c->d_min_slots, 0, (size_t)MIN_SLOTS * 8, c->stream));
     CHK_CREATE(dalloc(&c->d_ctr, (size_t)c->cms_depth * c->cms_width));
-    CHK_CREATE(dalloc(&c->d_estl, T * B * (size_t)c->cms_depth));
     CHK_CREATE(dalloc(&c->d_segsum, T * cms_binorder_entries(c->cms_depth, c->cms_width)));
     CHK_CREATE(dalloc(&c->d_cbase, T * cms_binorder_entries(c->cms_depth, c->cms_width)));
-    CHK_CREATE(dalloc(&c->d_basearr, T * (size_t)c->cms_depth * c->cms_width));
     CHK_CREATE(dalloc(&c->d_f64, T * B));
     CHK_CREATE(dalloc(&c->d_rcp32, T * c->row_stride));
     CHK_CREATE(dalloc(&c->d_mins, S));
@@ -622,7 +587,6 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
         CHK_CREATE(dalloc(&c->d_eidx, T * B));
         CHK_CREATE(dalloc(&c->d_etot, T));
         CHK_CREATE(dalloc(&c->d_ctrd, NC));
-        CHK_CREATE(dalloc(&c->d_estd, T * B * (size_t)c->cms_depth));
         CHK_CREATE(dalloc(&c->d_segadd, T * cms_binorder_entries(c->cms_depth, c->cms_width)));
         CHK_CREATE(dalloc(&c->d_cstart, T * cms_binorder_entries(c->cms_depth, c->cms_width)));
         CHK_CREATE(dalloc(&c->d_segfac, T * 64));
@@ -657,11 +621,11 @@ void hulk_destroy(hulk_ctx *c) {
     if (c->ev_binned) hipEventDestroy(c->ev_binned);
     for (int i = 0; i < 2; i++) if (c->ev_flushed[i]) hipEventDestroy(c->ev_flushed[i]);
     for (auto &pr : c->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
-    hipFree(c->d_state); hipFree(c->d_hist); hipFree(c->d_hist_tmp); hipFree(c->d_perm); hipFree(c->d_chain_start);
+    hipFree(c->d_state); hipFree(c->d_hist); hipFree(c->d_hist_tmp);
     hipFree(c->d_meta8); hipFree(c->d_segsum); hipFree(c->d_cbase);
     hipFree(c->d_segadd); hipFree(c->d_segfac); hipFree(c->d_cstart); hipFree(c->d_sege0);
-    hipFree(c->d_ctr); hipFree(c->d_estl); hipFree(c->d_basearr); hipFree(c->d_invperm); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
-    hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd); hipFree(c->d_estd);
+    hipFree(c->d_ctr); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
+    hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd);
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
     hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited); hipFree(c->d_kminslot);
     hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);

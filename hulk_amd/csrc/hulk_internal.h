@@ -89,14 +89,6 @@ hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSe
                              uint64_t max_npos, MinimizerParams P, uint64_t *d_xs, uint8_t *d_valid, uint64_t *d_table,
                              uint64_t table_total, uint32_t *d_hists, unsigned long long *d_min_slots);
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb);
-hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,
-                             const uint32_t *d_chain_start, unsigned long long *d_ctr,
-                             uint32_t *d_estl, unsigned long long *d_basearr, int depth, int width,
-                             DevState *st, const FlushBatch &fb);
-hipError_t launch_freq(hipStream_t s, uint32_t *d_hists, const uint32_t *d_estl,
-                       const unsigned long long *d_basearr, const uint32_t *d_invperm,
-                       const uint16_t *d_pos16, double *d_f64, float *d_rcp32, int depth, int width,
-                       size_t row_stride, DevState *st, const FlushBatch &fb);
 hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
                                unsigned long long *d_ctr, uint32_t *d_segsum, unsigned long long *d_base,
                                double *d_f64, float *d_rcp32, int depth, int width, size_t row_stride,
@@ -122,13 +114,6 @@ hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *
 hipError_t launch_elem_index(hipStream_t s, const uint32_t *d_hists, uint32_t *d_blkcnt, uint32_t *d_eidx,
                              uint32_t *d_etot, const FlushBatch &fb);
 int elem_index_blocks(int32_t num_bins);
-hipError_t launch_cms_chains_decay(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,
-                                   const uint32_t *d_chain_start, const uint32_t *d_eidx,
-                                   const uint32_t *d_etot, double *d_ctrd, double *d_estd, int depth,
-                                   int width, double omega, DevState *st, const FlushBatch &fb);
-hipError_t launch_freq_decay(hipStream_t s, uint32_t *d_hists, const double *d_estd,
-                             const uint32_t *d_invperm, double *d_f64, float *d_rcp32, int depth,
-                             size_t row_stride, DevState *st, const FlushBatch &fb);
 hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const double *d_f64,
                                     const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
                                     int slots, int slot_begin, int ntiles, double decay_weight,

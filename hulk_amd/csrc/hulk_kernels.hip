@@ -1,15 +1,20 @@
-// hulk_kernels.hip — gfx950 kernels of the HULK `sketch` hot path.
+// hulk_kernels.hip — gfx950 kernels of the HULK `sketch` hot path (DESIGN.md §3 describes each).
 //
-//   K1  k_minimizer_bin   reads -> distinct minimizers per read -> jump hash -> histogram
-//                         (reference: src/minimizer/minimizer.go:96-204,
-//                          src/kmerspectrum/kmerspectrum.go:67-81)
-//   K2  k_count_used      KmerSpectrum.Cardinality()            (kmerspectrum.go:53-55)
-//   K3  k_cms_chains      count-min sketch Add() for a whole flush, as 7x2000 independent
-//       k_freq            ordered prefix sums (src/countmin/countmin.go:103-138)
-//   K4  k_cws_scan        fp32 streaming pass over K = c*exp(b-r): per (slot, tile) minimum
-//       k_cws_resolve     exact fp64 re-evaluation (literal formula of
-//                         src/histosketch/histosketch.go:30-33) of the candidate tiles and the
-//                         slot update (histosketch.go:135-153)
+//   K1a k_minimizer_fast   short reads -> distinct minimizers per read (list in HBM)
+//   K1b k_jump_bin         jump hash of the list                  (kmerspectrum.go:67-81, go-jump)
+//   K1c k_range_hist/k_merge_hist   k-mer spectrum in LDS, no global atomics
+//       k_minimizer_bin    reads of up to 1024 k-mer positions, any bytes (fused jump hash + atomics)
+//       k_long_hash/k_long_emit   long reads and contigs, grouped launches
+//                          (reference: src/minimizer/minimizer.go:96-204)
+//   K2  k_count_used       KmerSpectrum.Cardinality(), the 1 % rule       (kmerspectrum.go:53-55,84-96)
+//       k_flush_decide     whole-batch bound: can any element still change the sketch?
+//   K3  k_cms_segsum/k_cms_base/k_cms_freq   count-min Add() for a batch of spectra, bin order
+//       k_cmsd_*           the same with uniform scaling (src/countmin/countmin.go:103-147)
+//   K4  k_cws_scan         fp32 pass over K = c*exp(b-r): per (interval, slot, tile) minimum, bound-pruned
+//       k_cws_resolve(+_drift)/k_cws_apply   exact fp64 re-evaluation with the literal formula of
+//                          src/histosketch/histosketch.go:30-33 and the slot update (histosketch.go:135-153)
+//       k_cws_eval/k_cws_scatter/k_cws_beta/k_build_k32   the CWS tables (histosketch.go:95-126)
+//       k_smash            pairwise distances of `hulk smash`
 //
 // All kernels are wave64 code for CDNA4; none of them has a CPU or library fallback.
 #include "hulk_internal.h"
@@ -110,24 +115,6 @@ __device__ __forceinline__ int32_t jump_hash(uint64_t key, int32_t n) {
         j = (uint32_t)(int32_t)(p * 0x1p31);   // trunc, exact (< n < 2^31)
     }
     return res;
-}
-
-// two keys at once (independent chains; the loop runs until both are done)
-__device__ __forceinline__ void jump_hash2(uint64_t k0, uint64_t k1, int32_t n, int32_t &r0, int32_t &r1) {
-    const double dn = (double)n * 0x1p-31;
-    uint32_t j0 = 0, j1 = 0;
-    bool d0 = false, d1 = false;
-    r0 = 0; r1 = 0;
-    while (!(d0 && d1)) {
-        if (!d0) r0 = (int32_t)j0;
-        if (!d1) r1 = (int32_t)j1;
-        k0 = k0 * 2862933555777941757ull + 1;
-        k1 = k1 * 2862933555777941757ull + 1;
-        const double p0 = (double)(j0 + 1u) * rcp_exact_u31((uint32_t)(k0 >> 33) + 1u);
-        const double p1 = (double)(j1 + 1u) * rcp_exact_u31((uint32_t)(k1 >> 33) + 1u);
-        if (!d0) { if (p0 >= dn) d0 = true; else j0 = (uint32_t)(int32_t)(p0 * 0x1p31); }
-        if (!d1) { if (p1 >= dn) d1 = true; else j1 = (uint32_t)(int32_t)(p1 * 0x1p31); }
-    }
 }
 
 // spectrum (ring slot) a read is binned into: interval rule of pipeline/sketch.go:211
@@ -1046,106 +1033,7 @@ __global__ __launch_bounds__(256) void k_count_used(const uint32_t *__restrict__
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// K3: count-min.  Without decay every counter is an integer sum, and the stream order of a flush
-// is ascending bin id, so the value returned by Add() for bin x in row d is
-//     ctr_before[d][g] + sum{ v(y) : y <= x, pos_d(y) == g },   g = jump(x*(d+1), width)
-// i.e. an ordered prefix sum along the static chain of bins that share counter (d,g).
-// One wave per chain, spectra of the batch in order; perm/chain_start are built once on the host.
-// est[t][bin][d] receives the estimate of row d.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cms_chains(const uint32_t *__restrict__ hists,
-                                                    const uint32_t *__restrict__ perm,
-                                                    const uint32_t *__restrict__ chain_start,
-                                                    unsigned long long *__restrict__ ctr,
-                                                    uint32_t *__restrict__ estl,
-                                                    unsigned long long *__restrict__ basearr,
-                                                    int depth, int width, const DevState *st,
-                                                    FlushBatch fb) {
-    // estl[t][d][idx]  : prefix sum inside the chain, stored in CHAIN order (coalesced)
-    // basearr[t][chain]: counter value in front of spectrum t
-    const int lane = lane_id();
-    const int chain = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t gomask = batch_gomask(st, fb);
-    if (chain >= depth * width) return;
-    const int d = chain / width, g = chain - d * width;
-    const uint32_t s = chain_start[d * (width + 1) + g], e = chain_start[d * (width + 1) + g + 1];
-    const uint32_t *pd = perm + (size_t)d * fb.num_bins;
-    const size_t B = (size_t)fb.num_bins;
-    const int count = (int)fb.count;
 
-    uint32_t carry[SCAN_BATCH_MAX];
-#pragma unroll
-    for (int t = 0; t < SCAN_BATCH_MAX; t++) carry[t] = 0;
-    for (uint32_t base = s; base < e; base += 64) {
-        const uint32_t idx = base + lane;
-        const uint32_t bin = idx < e ? pd[idx] : 0u;
-        uint32_t v[SCAN_BATCH_MAX];
-#pragma unroll
-        for (int t = 0; t < SCAN_BATCH_MAX; t++)
-            v[t] = (t < count && idx < e && ((gomask >> t) & 1u)) ? hists[(size_t)ring_slot(fb, t) * B + bin] : 0u;
-#pragma unroll
-        for (int t = 0; t < SCAN_BATCH_MAX; t++) {
-            if (t < count && ((gomask >> t) & 1u)) {
-                const uint32_t incl = wave_scan_incl(v[t]);
-                if (idx < e) estl[((size_t)t * depth + d) * B + idx] = carry[t] + incl;
-                carry[t] += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            }
-        }
-    }
-    if (lane == 0) {
-        unsigned long long run = ctr[chain];
-#pragma unroll
-        for (int t = 0; t < SCAN_BATCH_MAX; t++)
-            if (t < count) { basearr[(size_t)t * (depth * width) + chain] = run; run += carry[t]; }
-        ctr[chain] = run;
-    }
-}
-
-// estiFreq = min over rows of (counter in front of the spectrum + prefix inside the chain);
-// fp32 reciprocal for the streaming pass; wipe the spectrum (kmerspectrum.go:58-64).
-// Excluded (zero) bins get rcp = NaN so that fminf() ignores them.   grid = (blocks, count)
-__global__ __launch_bounds__(256) void k_freq(uint32_t *__restrict__ hists,
-                                              const uint32_t *__restrict__ estl,
-                                              const unsigned long long *__restrict__ basearr,
-                                              const uint32_t *__restrict__ invperm,
-                                              const uint16_t *__restrict__ pos16,
-                                              double *__restrict__ f64, float *__restrict__ rcp32,
-                                              int depth, int width, size_t row_stride, DevState *st,
-                                              FlushBatch fb) {
-    const int t = blockIdx.y;
-    const bool go = flush_go(st, fb, t);
-    const uint32_t slot = ring_slot(fb, t);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const unsigned used = st->used[fb.parity][slot];
-        if (used != 0 && !go) set_error(st, -5);
-        if (go) atomicAdd(&st->n_elements, (unsigned long long)used);
-    }
-    if (!go) return;      // reference: empty spectrum is skipped un-wiped (it is all zero); error is fatal
-    const size_t B = (size_t)fb.num_bins;
-    uint32_t *hist = hists + (size_t)slot * B;
-    double *ft = f64 + (size_t)t * B;
-    float *rt = rcp32 + (size_t)t * row_stride;
-    const unsigned long long *bt = basearr + (size_t)t * (depth * width);
-    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < fb.num_bins; b += gridDim.x * blockDim.x) {
-        const uint32_t h = hist[b];
-        if (h) {
-            unsigned long long m = ~0ull;
-            for (int d = 0; d < depth; d++) {
-                const unsigned long long e = bt[d * width + pos16[(size_t)d * B + b]] +
-                                             estl[((size_t)t * depth + d) * B + invperm[(size_t)d * B + b]];
-                m = e < m ? e : m;
-            }
-            const double f = (double)m;
-            ft[b] = f;
-            rt[b] = (float)(1.0 / f);
-            hist[b] = 0;
-        } else {
-            ft[b] = 0.0;
-            rt[b] = __builtin_nanf("");
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // K3 (no decay), bin-order form.  The chain-order kernels above gather 4-byte values along chains
@@ -1871,100 +1759,6 @@ __global__ __launch_bounds__(256) void k_elem_index(const uint32_t *__restrict__
     for (int x = 0; x < 8; x++) { if (b0 + x < fb.num_bins) eidx[(size_t)t * B + b0 + x] = before; before += nz[x]; }
 }
 
-// affine map composition for the chain recurrence: apply (a1,b1) first, then (a2,b2)
-struct Affine { double a, b; };
-__device__ __forceinline__ Affine affine_then(const Affine &first, const Affine &second) {
-    Affine r; r.a = first.a * second.a; r.b = second.a * first.b + second.b; return r;
-}
-
-// One wave per chain, spectra of the batch in order (the counter state flows through them).
-// estd[t][d][idx] (chain order) = value returned for row d.   ctrd = fp64 counters.
-__global__ __launch_bounds__(256) void k_cms_chains_decay(const uint32_t *__restrict__ hists,
-                                                          const uint32_t *__restrict__ perm,
-                                                          const uint32_t *__restrict__ chain_start,
-                                                          const uint32_t *__restrict__ eidx,
-                                                          const uint32_t *__restrict__ etot,
-                                                          double *__restrict__ ctrd, double *__restrict__ estd,
-                                                          int depth, int width, double omega,
-                                                          const DevState *st, FlushBatch fb) {
-    const int lane = lane_id();
-    const int chain = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t gomask = batch_gomask(st, fb);
-    if (chain >= depth * width) return;
-    const int d = chain / width, g = chain - d * width;
-    const uint32_t s = chain_start[d * (width + 1) + g], e = chain_start[d * (width + 1) + g + 1];
-    const uint32_t *pd = perm + (size_t)d * fb.num_bins;
-    const size_t B = (size_t)fb.num_bins;
-    double cval = ctrd[chain];
-    for (int t = 0; t < (int)fb.count; t++) {
-        if (!((gomask >> t) & 1u)) continue;
-        const uint32_t *hist = hists + (size_t)ring_slot(fb, t) * B;
-        const uint32_t *ei = eidx + (size_t)t * B;
-        long long lastj = -1;                           // element index of the previous chain element
-        for (uint32_t base = s; base < e; base += 64) {
-            const uint32_t idx = base + lane;
-            uint32_t bin = 0, v = 0; long long j = -1;
-            if (idx < e) { bin = pd[idx]; v = hist[bin]; if (v) j = (long long)ei[bin]; }
-            // previous element index: running max over the lanes in front (j ascends along the chain)
-            long long pj = j;
-            for (int off = 1; off < 64; off <<= 1) {
-                const long long x = __shfl_up(pj, off);
-                if (lane >= off && x > pj) pj = x;
-            }
-            long long prevj = __shfl_up(pj, 1);
-            if (lane == 0 || prevj < 0) prevj = lastj;
-            Affine m; m.a = 1.0; m.b = 0.0;             // identity for lanes that are not stream elements
-            if (v) { m.a = pow(omega, (double)(j - prevj)); m.b = (double)v; }
-            for (int off = 1; off < 64; off <<= 1) {
-                Affine o; o.a = __shfl_up(m.a, off); o.b = __shfl_up(m.b, off);
-                if (lane >= off) m = affine_then(o, m);
-            }
-            const double val = m.a * cval + m.b;       // counter right after this lane's element
-            if (v) estd[((size_t)t * depth + d) * B + idx] = val;
-            cval = __shfl(val, 63);
-            const long long lj = __shfl(pj, 63);
-            if (lj >= 0) lastj = lj;
-        }
-        cval *= pow(omega, (double)((long long)etot[t] - 1 - lastj));   // scalings by the rest of the flush
-    }
-    if (lane == 0) ctrd[chain] = cval;
-}
-
-__global__ __launch_bounds__(256) void k_freq_decay(uint32_t *__restrict__ hists,
-                                                    const double *__restrict__ estd,
-                                                    const uint32_t *__restrict__ invperm,
-                                                    double *__restrict__ f64, float *__restrict__ rcp32,
-                                                    int depth, size_t row_stride, DevState *st, FlushBatch fb) {
-    const int t = blockIdx.y;
-    const bool go = flush_go(st, fb, t);
-    const uint32_t slot = ring_slot(fb, t);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const unsigned used = st->used[fb.parity][slot];
-        if (used != 0 && !go) set_error(st, -5);
-        if (go) atomicAdd(&st->n_elements, (unsigned long long)used);
-    }
-    if (!go) return;
-    const size_t B = (size_t)fb.num_bins;
-    uint32_t *hist = hists + (size_t)slot * B;
-    double *ft = f64 + (size_t)t * B;
-    float *rt = rcp32 + (size_t)t * row_stride;
-    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < fb.num_bins; b += gridDim.x * blockDim.x) {
-        if (hist[b]) {
-            double m = INFINITY;                       // currentMinimum starts at MaxFloat64 (countmin.go:116)
-            for (int d = 0; d < depth; d++) {
-                const double e = estd[((size_t)t * depth + d) * B + invperm[(size_t)d * B + b]];
-                m = e < m ? e : m;
-            }
-            ft[b] = m;
-            rt[b] = (float)(1.0 / m);
-            hist[b] = 0;
-        } else {
-            ft[b] = 0.0;
-            rt[b] = __builtin_nanf("");
-        }
-    }
-}
-
 // AddElement with concept drift, per slot, in stream order:  if A < w/decayWeight { w = A; min = bin }
 // (histosketch.go:139-153).  Not a minimum: w may move either way, so elements are taken in order,
 // but a wave tile whose fp32 minimum is not below the current threshold (with the fp32 band) cannot
@@ -2360,27 +2154,6 @@ hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *s
     return hipGetLastError();
 }
 
-hipError_t launch_cms_chains(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,
-                             const uint32_t *d_chain_start, unsigned long long *d_ctr,
-                             uint32_t *d_estl, unsigned long long *d_basearr, int depth, int width,
-                             DevState *st, const FlushBatch &fb) {
-    const int chains = depth * width;
-    const int blocks = (chains + 3) / 4;
-    hipLaunchKernelGGL(k_cms_chains, dim3(blocks), dim3(256), 0, s, d_hists, d_perm, d_chain_start,
-                       d_ctr, d_estl, d_basearr, depth, width, st, fb);
-    return hipGetLastError();
-}
-
-hipError_t launch_freq(hipStream_t s, uint32_t *d_hists, const uint32_t *d_estl,
-                       const unsigned long long *d_basearr, const uint32_t *d_invperm,
-                       const uint16_t *d_pos16, double *d_f64, float *d_rcp32, int depth, int width,
-                       size_t row_stride, DevState *st, const FlushBatch &fb) {
-    int blocks = (fb.num_bins + 255) / 256; if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_freq, dim3(blocks, fb.count), dim3(256), 0, s, d_hists, d_estl, d_basearr,
-                       d_invperm, d_pos16, d_f64, d_rcp32, depth, width, row_stride, st, fb);
-    return hipGetLastError();
-}
-
 hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
                                unsigned long long *d_ctr, uint32_t *d_segsum, unsigned long long *d_base,
                                double *d_f64, float *d_rcp32, int depth, int width, size_t row_stride,
@@ -2478,25 +2251,6 @@ hipError_t launch_elem_index(hipStream_t s, const uint32_t *d_hists, uint32_t *d
     return hipGetLastError();
 }
 int elem_index_blocks(int32_t num_bins) { return (num_bins + EIDX_BLOCK - 1) / EIDX_BLOCK; }
-
-hipError_t launch_cms_chains_decay(hipStream_t s, const uint32_t *d_hists, const uint32_t *d_perm,
-                                   const uint32_t *d_chain_start, const uint32_t *d_eidx,
-                                   const uint32_t *d_etot, double *d_ctrd, double *d_estd, int depth,
-                                   int width, double omega, DevState *st, const FlushBatch &fb) {
-    const int chains = depth * width;
-    hipLaunchKernelGGL(k_cms_chains_decay, dim3((chains + 3) / 4), dim3(256), 0, s, d_hists, d_perm,
-                       d_chain_start, d_eidx, d_etot, d_ctrd, d_estd, depth, width, omega, st, fb);
-    return hipGetLastError();
-}
-
-hipError_t launch_freq_decay(hipStream_t s, uint32_t *d_hists, const double *d_estd,
-                             const uint32_t *d_invperm, double *d_f64, float *d_rcp32, int depth,
-                             size_t row_stride, DevState *st, const FlushBatch &fb) {
-    int blocks = (fb.num_bins + 255) / 256; if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_freq_decay, dim3(blocks, fb.count), dim3(256), 0, s, d_hists, d_estd, d_invperm,
-                       d_f64, d_rcp32, depth, row_stride, st, fb);
-    return hipGetLastError();
-}
 
 hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const double *d_f64,
                                     const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
