@@ -81,6 +81,10 @@ def test_sketch_fixture_c1(fq_reads):
     (21, 9, 16, 5000, 150, 2500),
     (7, 3, 8, 600, 64, 100),
     (31, 9, 8, 12000, 150, 0),          # k=31: the <<8 wraps
+    # v_min_f64 path (k <= 27): values up to 2^62 are normal doubles (at k = 21 all of them are denormal
+    # patterns); k = 28 is the first k that must use the integer compares again.  Enough reads for the 1 % rule.
+    (25, 9, 3, 9000, (100, 150), 0), (27, 9, 2, 14000, (90, 151), 0), (28, 9, 2, 16000, (90, 151), 0),
+    (23, 5, 4, 6000, (60, 120), 2500),
 ])
 def test_random_reads(k, w, S, n, L, interval):
     rng = np.random.default_rng(k * 1000 + w)
