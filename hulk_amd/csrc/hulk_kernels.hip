@@ -725,7 +725,59 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
 // with its own chain of ~ln(k^4) fp64 steps (no lock-step tail per 64 values); 8 waves/SIMD.
 // Output: key = spectrum slot << 20 | bin  (k^4 < 2^20 for k <= 31).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_regions, int32_t num_bins) {
+// The step loop of k_jump_bin in assembly (fixed registers v40..v57, s60..s63): hipcc's version of the same loop
+// carries two v_mov_b64 and a dozen scalar mask instructions per pair of steps; this one is the 17 VALU
+// instructions of a step plus v_cmp / s_and / s_cbranch, the LCG state ping-ponging between v[40:41] and
+// v[42:43].  Lanes that reach p >= n leave the exec mask and keep their t.  HULK_JUMP_C=1 selects the C++ loop.
+__device__ __forceinline__ double jump_steps_asm(uint32_t klo, uint32_t khi, double fn) {
+    uint32_t tlo, thi;
+    const uint64_t fb = (uint64_t)__double_as_longlong(fn);
+    const uint32_t flo = (uint32_t)fb, fhi = (uint32_t)(fb >> 32);
+#define HULK_JSTEP(KS_LO, KS_HI, KD, KD_HI)                                          \
+    "v_mad_u64_u32 " KD ", s[62:63], " KS_LO ", %[alo], 1\n\t"                       \
+    "v_mul_lo_u32 v54, " KS_LO ", %[ahi]\n\t"                                        \
+    "v_mul_lo_u32 v55, " KS_HI ", %[alo]\n\t"                                        \
+    "v_add3_u32 " KD_HI ", v55, " KD_HI ", v54\n\t"                                  \
+    "v_lshrrev_b32 v54, 1, " KD_HI "\n\t"                                            \
+    "v_add_u32 v54, 1, v54\n\t"                                                      \
+    "v_cvt_f64_u32 v[46:47], v54\n\t"                                                \
+    "v_add_u32 v47, 0xfe100000, v47\n\t"                                             \
+    "v_rcp_f64 v[48:49], v[46:47]\n\t"                                               \
+    "s_nop 0\n\t"                                                                    \
+    "v_fma_f64 v[50:51], -v[46:47], v[48:49], 1.0\n\t"                               \
+    "v_fma_f64 v[48:49], v[48:49], v[50:51], v[48:49]\n\t"                           \
+    "v_fma_f64 v[50:51], -v[46:47], v[48:49], 1.0\n\t"                               \
+    "v_fma_f64 v[48:49], v[48:49], v[50:51], v[48:49]\n\t"                           \
+    "v_fma_f64 v[52:53], v[44:45], v[48:49], v[48:49]\n\t"                           \
+    "v_cmp_nge_f64 vcc, v[52:53], v[56:57]\n\t"                                      \
+    "s_and_b64 exec, exec, vcc\n\t"                                                  \
+    "s_cbranch_execz 2f\n\t"                                                         \
+    "v_trunc_f64 v[44:45], v[52:53]\n\t"
+    asm volatile(
+        "s_mov_b64 s[60:61], exec\n\t"
+        "v_mov_b32 v40, %[klo]\n\t"
+        "v_mov_b32 v41, %[khi]\n\t"
+        "v_mov_b32 v56, %[flo]\n\t"
+        "v_mov_b32 v57, %[fhi]\n\t"
+        "v_mov_b32 v44, 0\n\t"
+        "v_mov_b32 v45, 0\n\t"
+        "1:\n\t"
+        HULK_JSTEP("v40", "v41", "v[42:43]", "v43")
+        HULK_JSTEP("v42", "v43", "v[40:41]", "v41")
+        "s_branch 1b\n\t"
+        "2:\n\t"
+        "s_mov_b64 exec, s[60:61]\n\t"
+        "v_mov_b32 %[tlo], v44\n\t"
+        "v_mov_b32 %[thi], v45\n\t"
+        : [tlo] "=v"(tlo), [thi] "=v"(thi)
+        : [klo] "v"(klo), [khi] "v"(khi), [flo] "v"(flo), [fhi] "v"(fhi), [alo] "s"(0x87B0B0FDu), [ahi] "s"(0x27BB2EE6u)
+        : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+          "v56", "v57", "s60", "s61", "s62", "s63", "vcc", "memory");
+#undef HULK_JSTEP
+    return __longlong_as_double((long long)(((uint64_t)thi << 32) | tlo));
+}
+
+__global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_regions, int32_t num_bins, int use_c) {
     const int lane = lane_id();
     const uint32_t region = (uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (region >= n_regions) return;
@@ -746,6 +798,9 @@ __global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_r
         // so a step needs no add and no ldexp.  Unrolled by two: the LCG state ping-pongs between register pairs.
         const double fn = (double)num_bins;
         double t = 0.0;                                         // float64(b), b = 0 before the first step
+        if (!use_c) {
+            t = jump_steps_asm((uint32_t)key, (uint32_t)(key >> 32), fn);
+        } else
         for (;;) {
             key = key * 2862933555777941757ull + 1;
             double q = quot31_exact((uint32_t)(key >> 33) + 1u);
@@ -2107,7 +2162,9 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     // previous batch (other stream) find free wave slots next to it
     static int jump_lds = -1;
     if (jump_lds < 0) { const char *e = getenv("HULK_JUMP_LDS"); jump_lds = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(k_jump_bin, dim3((n_regions + 3) / 4), dim3(256), (size_t)jump_lds, s, ml, n_regions, P.num_bins);
+    static int jump_c = -1;
+    if (jump_c < 0) { const char *ec = getenv("HULK_JUMP_C"); jump_c = ec ? atoi(ec) : 0; }
+    hipLaunchKernelGGL(k_jump_bin, dim3((n_regions + 3) / 4), dim3(256), (size_t)jump_lds, s, ml, n_regions, P.num_bins, jump_c);
     const uint32_t n_spectra = P.interval ? (uint32_t)((P.fill + n_reads + P.interval - 1) / P.interval) : 1u;
     const int nranges = (P.num_bins + HIST_RANGE - 1) / HIST_RANGE;
     static int parts_target = -1;
