@@ -108,7 +108,7 @@ struct hulk_ctx {
     uint64_t long_cap = 0, long_table_cap = 0;   // minimizer list of the short-read kernel (grow-only)
     // host-side run state
     uint64_t seq_count = 0, flush_index = 0;
-    uint32_t T = 8, ring_n = 9, ring_base = 0;   // interval batch size and spectrum ring
+    uint32_t T = 16, ring_n = 17, ring_base = 0;   // interval batch size and spectrum ring
     bool tables_ready = false, finished = false, hist_hook_used = false;
     int sticky = HULK_OK;
     std::string last_error;
