@@ -386,8 +386,10 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             HIPCHK(c, hipStreamSynchronize(c->stream));
             hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum);
             uint32_t *keep_partial = c->ml.partial; const uint32_t keep_parts = c->ml.max_parts;
+            uint32_t *keep_nib = c->ml.nib, *keep_over = c->ml.nib_over; const uint32_t keep_np = c->ml.nib_parts;
             c->ml = MinimizerList{}; c->ml_regions = 0;
             c->ml.partial = keep_partial; c->ml.max_parts = keep_parts;
+            c->ml.nib = keep_nib; c->ml.nib_over = keep_over; c->ml.nib_parts = keep_np;
             const uint64_t cap = regions + regions / 8 + 64;
             HIPCHK(c, hipMalloc((void **)&c->ml.x, cap * rcap * 8));
             HIPCHK(c, hipMalloc((void **)&c->ml.slot, cap * rcap));
@@ -395,6 +397,13 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             HIPCHK(c, hipMalloc((void **)&c->ml.cnt, cap * 4));
             HIPCHK(c, hipMalloc((void **)&c->ml.off, (cap + 1) * 4));
             HIPCHK(c, hipMalloc((void **)&c->ml.bsum, (cap / 1024 + 2) * 4));
+            if (!c->ml.nib) {
+                const size_t nr = ((size_t)c->B + 262143) / 262144;
+                c->ml.nib_parts = 48;
+                HIPCHK(c, hipMalloc((void **)&c->ml.nib, (size_t)c->ml.nib_parts * c->ring_n * nr * (262144 / 8) * 4));
+                HIPCHK(c, hipMalloc((void **)&c->ml.nib_over, RING_MAX * 4));
+                HIPCHK(c, hipMemsetAsync(c->ml.nib_over, 0, RING_MAX * 4, c->stream));
+            }
             if (!c->ml.partial) {
                 c->ml.max_parts = 8;
                 HIPCHK(c, hipMalloc((void **)&c->ml.partial, (size_t)c->ml.max_parts * c->ring_n * (size_t)c->B * 4));
@@ -629,7 +638,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
     hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited); hipFree(c->d_kminslot);
     hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
-    hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial);
+    hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial); hipFree(c->ml.nib); hipFree(c->ml.nib_over);
     hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;

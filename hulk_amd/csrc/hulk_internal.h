@@ -41,6 +41,9 @@ struct MinimizerList {
     uint32_t *bsum;     // [regions / 1024 + 1] per-block sums for the prefix
     uint32_t *partial;  // [max_parts][ring_n][num_bins] per-part spectra of k_range_hist
     uint32_t max_parts;
+    uint32_t *nib;      // [nib_parts][ring_n][nranges][NIB_WORDS] per-part spectra of k_nibble_hist, 8 four-bit counters per word
+    uint32_t *nib_over; // [RING_MAX] a 4-bit counter overflowed in this spectrum: k_range_hist recounts it
+    uint32_t nib_parts;
     uint64_t rcap;
 };
 

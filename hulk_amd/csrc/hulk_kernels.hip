@@ -841,7 +841,9 @@ __global__ __launch_bounds__(1024) void k_region_bsum(const uint32_t *__restrict
     if (threadIdx.x == 0) { uint32_t t = 0; for (int x = 0; x < 16; x++) t += wsum[x]; bsum[blockIdx.x] = t; }
 }
 __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ bsum,
-                                                         uint32_t *__restrict__ off, uint32_t n_regions) {
+                                                         uint32_t *__restrict__ off, uint32_t n_regions,
+                                                         uint32_t *__restrict__ nib_over) {
+    if (nib_over && blockIdx.x == 0 && threadIdx.x < RING_MAX) nib_over[threadIdx.x] = 0;
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t i = blockIdx.x * 1024u + (uint32_t)tid;
@@ -859,7 +861,8 @@ __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *__restr
 // workgroup (r, t, part): LDS spectrum of bins [r*RANGE, (r+1)*RANGE) over part `part` of interval t's keys
 __global__ __launch_bounds__(1024) void k_range_hist(MinimizerList ml, uint32_t n_regions,
                                                      uint32_t *__restrict__ partial, MinimizerParams P,
-                                                     uint32_t n_spectra, uint32_t n_parts, uint64_t n_reads, int nranges) {
+                                                     uint32_t n_spectra, uint32_t n_parts, uint64_t n_reads, int nranges,
+                                                     const uint32_t *__restrict__ only_if) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *lh = (uint32_t *)smem;
     // XCD-aware order (workgroup b lands on XCD b % 8): the nranges workgroups that stream the SAME keys
@@ -869,6 +872,7 @@ __global__ __launch_bounds__(1024) void k_range_hist(MinimizerList ml, uint32_t 
     const int pr = (seq / nranges) * 8 + xcd, r = seq % nranges;
     if (pr >= (int)(n_spectra * n_parts)) return;
     const int t = pr % (int)n_spectra, part = pr / (int)n_spectra;
+    if (only_if && !only_if[t]) return;                          // fallback mode: only spectra whose nibble count overflowed
     const int tid = threadIdx.x;
     for (int i = tid; i < HIST_RANGE; i += blockDim.x) lh[i] = 0;
     __syncthreads();
@@ -917,9 +921,120 @@ __global__ __launch_bounds__(1024) void k_range_hist(MinimizerList ml, uint32_t 
 }
 
 // spectrum[slot_t][bin] += sum over parts    grid = (blocks, n_spectra)
-__global__ __launch_bounds__(256) void k_merge_hist(const uint32_t *__restrict__ partial, uint32_t *__restrict__ hists,
-                                                    MinimizerParams P, uint32_t n_spectra, uint32_t n_parts) {
+// K1c': the same spectrum with FOUR-BIT counters, so that one workgroup holds a whole range of 2^18 bins in LDS
+// (all 194,481 bins at k = 21) and every key is read ONCE instead of once per 32768-bin range (k_range_hist was
+// bound by those re-reads through L2).  A part is ~131 k keys over ~2*10^5 bins, so a counter reaching 16 needs
+// grossly repetitive input (Poisson mean < 1 per bin); it cannot go unnoticed: every ds_add returns the previous word, a previous nibble
+// of 15 raises nib_over[t] and k_range_hist / k_merge_hist recount that spectrum exactly (they return at once
+// otherwise).  Layout of a part: words of 8 nibbles, bin b -> word b >> 3, nibble b & 7.
+constexpr int NIB_BINS = 262144;                       // bins per range (128 KB of LDS)
+constexpr int NIB_WORDS = NIB_BINS / 8;
+__global__ __launch_bounds__(1024) void k_nibble_hist(MinimizerList ml, uint32_t n_regions, MinimizerParams P,
+                                                      uint32_t n_spectra, uint32_t n_parts, uint64_t n_reads, int nranges) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *lw = (uint32_t *)smem;
+    // XCD-aware order as in k_range_hist: the ranges of one (spectrum, part) pair share an XCD's L2
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int pr = (seq / nranges) * 8 + xcd, r = seq % nranges;
+    if (pr >= (int)(n_spectra * n_parts)) return;
+    const int t = pr % (int)n_spectra, part = pr / (int)n_spectra;
+    const int tid = threadIdx.x;
+    const int32_t rbase = r * NIB_BINS;
+    const int32_t rbins = P.num_bins - rbase < NIB_BINS ? P.num_bins - rbase : NIB_BINS;
+    const int words = (rbins + 7) >> 3;
+    for (int i = tid; i < words; i += blockDim.x) lw[i] = 0;
+    __syncthreads();
+    uint64_t rd0 = 0, rd1 = n_reads;
+    if (P.interval) {
+        const uint64_t lo = (uint64_t)t * P.interval, hi = lo + P.interval;
+        rd0 = lo > P.fill ? lo - P.fill : 0;
+        rd1 = hi > P.fill ? hi - P.fill : 0;
+        if (rd1 > n_reads) rd1 = n_reads;
+    }
+    const uint32_t slot = P.interval ? (uint32_t)(((uint64_t)t + P.ring_base) % P.ring_n) : P.ring_base;
+    bool over = false;
+    if (rd0 < rd1) {
+        const uint32_t g0 = (uint32_t)(rd0 / FAST_READS_PER_WAVE), g1 = (uint32_t)((rd1 - 1) / FAST_READS_PER_WAVE);
+        const uint32_t a = ml.off[g0], b = ml.off[(g1 + 1 < n_regions ? g1 + 1 : n_regions)];
+        const uint32_t len = b - a, per = (len + n_parts - 1) / n_parts;
+        const uint32_t lo = a + (uint32_t)part * per, hi = (lo + per < b) ? lo + per : b;
+        const uint32_t *kl = ml.key;
+#define HULK_NIB1(k)                                                                                   \
+        if (((k) >> 20) == slot) {                                                                     \
+            const uint32_t rel = ((k) & 0xFFFFFu) - (uint32_t)rbase;                                   \
+            if (rel < (uint32_t)rbins) {                                                               \
+                const uint32_t sh = (rel & 7u) * 4u;                                                   \
+                const uint32_t old = atomicAdd(&lw[rel >> 3], 1u << sh);                               \
+                over |= ((old >> sh) & 15u) == 15u;                                                    \
+            }                                                                                          \
+        }
+        uint32_t i = lo;
+        const uint32_t head_end = ((lo + 3u) & ~3u) < hi ? ((lo + 3u) & ~3u) : hi;
+        if (i + (uint32_t)tid < head_end) { const uint32_t k = kl[i + tid]; HULK_NIB1(k) }
+        i = head_end;
+        const uint4 *k4 = (const uint4 *)(kl + i);
+        const uint32_t n4 = hi > i ? (hi - i) / 4u : 0u;
+        uint32_t j = (uint32_t)tid;
+        for (; j + 3u * 1024u < n4; j += 4u * 1024u) {
+            const uint4 q0 = k4[j], q1 = k4[j + 1024u], q2 = k4[j + 2048u], q3 = k4[j + 3072u];
+            HULK_NIB1(q0.x) HULK_NIB1(q0.y) HULK_NIB1(q0.z) HULK_NIB1(q0.w)
+            HULK_NIB1(q1.x) HULK_NIB1(q1.y) HULK_NIB1(q1.z) HULK_NIB1(q1.w)
+            HULK_NIB1(q2.x) HULK_NIB1(q2.y) HULK_NIB1(q2.z) HULK_NIB1(q2.w)
+            HULK_NIB1(q3.x) HULK_NIB1(q3.y) HULK_NIB1(q3.z) HULK_NIB1(q3.w)
+        }
+        for (; j < n4; j += 1024u) { const uint4 q0 = k4[j]; HULK_NIB1(q0.x) HULK_NIB1(q0.y) HULK_NIB1(q0.z) HULK_NIB1(q0.w) }
+        const uint32_t tail = i + n4 * 4u + (uint32_t)tid;
+        if (tail < hi) { const uint32_t k = kl[tail]; HULK_NIB1(k) }
+#undef HULK_NIB1
+    }
+    if (__any((int)over) && (tid & 63) == 0) ml.nib_over[t] = 1u;
+    __syncthreads();
+    uint32_t *out = ml.nib + (((size_t)part * n_spectra + t) * (size_t)nranges + r) * NIB_WORDS;
+    for (int i = tid; i < words; i += blockDim.x) out[i] = lw[i];
+}
+
+// adds the parts of a spectrum (8 bins per thread and step) to the ring spectrum; a spectrum flagged in nib_over
+// is left to the exact recount
+__global__ __launch_bounds__(256) void k_nibble_merge(MinimizerList ml, uint32_t *__restrict__ hists, MinimizerParams P,
+                                                      uint32_t n_spectra, uint32_t n_parts, int nranges) {
     const int t = blockIdx.y;
+    if (ml.nib_over[t]) return;
+    const uint32_t slot = P.interval ? (uint32_t)(((uint64_t)t + P.ring_base) % P.ring_n) : P.ring_base;
+    uint32_t *hist = hists + (size_t)slot * (size_t)P.num_bins;
+    const int total_words = nranges * NIB_WORDS;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < total_words; w += gridDim.x * blockDim.x) {
+        const int r = w / NIB_WORDS, wi = w - r * NIB_WORDS;
+        const int32_t b0 = r * NIB_BINS + wi * 8;
+        if (b0 >= P.num_bins) continue;
+        uint32_t even = 0, odd = 0, c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t pending = 0;
+        const size_t pstride = (size_t)n_spectra * (size_t)nranges * NIB_WORDS;
+        const uint32_t *src = ml.nib + ((size_t)t * (size_t)nranges + r) * NIB_WORDS + wi;
+        for (uint32_t p = 0; p < n_parts; p++) {
+            uint32_t v = src[(size_t)p * pstride];
+            if ((p & 3u) == 0 && p + 3 < n_parts) {                           // four independent loads in flight
+                const uint32_t v1 = src[(size_t)(p + 1) * pstride], v2 = src[(size_t)(p + 2) * pstride], v3 = src[(size_t)(p + 3) * pstride];
+                even += (v & 0x0F0F0F0Fu) + (v1 & 0x0F0F0F0Fu) + (v2 & 0x0F0F0F0Fu);
+                odd += ((v >> 4) & 0x0F0F0F0Fu) + ((v1 >> 4) & 0x0F0F0F0Fu) + ((v2 >> 4) & 0x0F0F0F0Fu);
+                v = v3; p += 3; pending += 3;
+            }
+            even += v & 0x0F0F0F0Fu; odd += (v >> 4) & 0x0F0F0F0Fu;          // byte lanes: at most 17 parts before widening
+            if (++pending >= 14u || p + 1 == n_parts) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) { c[2 * q] += (even >> (8 * q)) & 0xFFu; c[2 * q + 1] += (odd >> (8 * q)) & 0xFFu; }
+                even = odd = 0; pending = 0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (c[q] && b0 + q < P.num_bins) hist[b0 + q] += c[q];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_merge_hist(const uint32_t *__restrict__ partial, uint32_t *__restrict__ hists,
+                                                    MinimizerParams P, uint32_t n_spectra, uint32_t n_parts,
+                                                    const uint32_t *__restrict__ only_if) {
+    const int t = blockIdx.y;
+    if (only_if && !only_if[t]) return;
     const uint32_t slot = P.interval ? (uint32_t)(((uint64_t)t + P.ring_base) % P.ring_n) : P.ring_base;
     uint32_t *hist = hists + (size_t)slot * (size_t)P.num_bins;
     for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < P.num_bins; b += gridDim.x * blockDim.x) {
@@ -2157,7 +2272,7 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     const uint32_t n_regions = (uint32_t)((n_reads + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE);
     const uint32_t nblk = (n_regions + 1023) / 1024;
     hipLaunchKernelGGL(k_region_bsum, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, n_regions);
-    hipLaunchKernelGGL(k_region_offsets, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.off, n_regions);
+    hipLaunchKernelGGL(k_region_offsets, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.off, n_regions, ml.nib_over);
     // k_jump_bin needs no LDS; a dummy allocation caps its occupancy so that the flush kernels of the
     // previous batch (other stream) find free wave slots next to it
     static int jump_lds = -1;
@@ -2180,11 +2295,39 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    static int use_nib = -1;
+    if (use_nib < 0) use_nib = getenv("HULK_NO_NIBBLE") ? 0 : 1;
+    const uint32_t *only_if = nullptr;
+    if (use_nib && ml.nib && ml.nib_over) {
+        // ~131 k keys per part (16 parts per 100k-read interval, swept 49k..197k): a 4-bit counter then overflows only on
+        // grossly repetitive input, which the exact kernels below pick up
+        const int nr = (P.num_bins + NIB_BINS - 1) / NIB_BINS;
+        const uint64_t rps = P.interval ? std::min<uint64_t>(P.interval, n_reads) : n_reads;
+        static int keys_per_part = -1;
+        if (keys_per_part < 0) { const char *ek = getenv("HULK_NIB_KEYS"); keys_per_part = ek ? atoi(ek) : 131072; }
+        uint32_t np = (uint32_t)((rps * 20 + (uint64_t)keys_per_part - 1) / (uint64_t)keys_per_part);
+        if (np < 1) np = 1;
+        if (np > ml.nib_parts) np = ml.nib_parts;
+        while (np > 1 && (uint64_t)np * n_spectra * nr > 2048) np--;
+        const int words = ((std::min<int32_t>(P.num_bins, NIB_BINS) + 7) >> 3);
+        static bool nib_attr = false;
+        if (!nib_attr) {
+            e = hipFuncSetAttribute((const void *)k_nibble_hist, hipFuncAttributeMaxDynamicSharedMemorySize, NIB_WORDS * 4);
+            if (e != hipSuccess) return e;
+            nib_attr = true;
+        }
+        const unsigned pg = (n_spectra * np + 7) / 8;
+        hipLaunchKernelGGL(k_nibble_hist, dim3(8u * (unsigned)nr * pg), dim3(1024), (size_t)words * 4, s, ml, n_regions, P,
+                           n_spectra, np, n_reads, nr);
+        int nb = (nr * NIB_WORDS + 255) / 256; if (nb > 256) nb = 256;
+        hipLaunchKernelGGL(k_nibble_merge, dim3(nb, n_spectra), dim3(256), 0, s, ml, d_hists, P, n_spectra, np, nr);
+        only_if = ml.nib_over;                              // the exact kernels only recount flagged spectra
+    }
     const unsigned pair_groups = (n_spectra * n_parts + 7) / 8;
     hipLaunchKernelGGL(k_range_hist, dim3(8u * (unsigned)nranges * pair_groups), dim3(1024), HIST_RANGE * 4, s, ml, n_regions,
-                       ml.partial, P, n_spectra, n_parts, n_reads, nranges);
+                       ml.partial, P, n_spectra, n_parts, n_reads, nranges, only_if);
     int mb = (P.num_bins + 255) / 256; if (mb > 512) mb = 512;
-    hipLaunchKernelGGL(k_merge_hist, dim3(mb, n_spectra), dim3(256), 0, s, ml.partial, d_hists, P, n_spectra, n_parts);
+    hipLaunchKernelGGL(k_merge_hist, dim3(mb, n_spectra), dim3(256), 0, s, ml.partial, d_hists, P, n_spectra, n_parts, only_if);
     return hipGetLastError();
 }
 

@@ -423,3 +423,21 @@ def test_scan_pruning_is_exact_and_effective(monkeypatch):
     o.finish()
     assert np.array_equal(o.sketch()[0], m1) and np.allclose(o.sketch()[1], w1, rtol=WEIGHT_RTOL, atol=0)
     o.close()
+
+
+def test_nibble_histogram_overflow_falls_back_to_exact_count():
+    """k_nibble_hist counts with 4-bit counters; thousands of identical reads push single bins far past 15 per
+    part, which must be detected (nib_over) and recounted exactly — per spectrum, so clean and overflowing
+    intervals mix in one launch."""
+    rng = np.random.default_rng(5)
+    same = random_reads(rng, 1, 150)[0]
+    seqs = random_reads(rng, 4000, 150)                      # interval 0: clean
+    seqs += random_reads(rng, 1000, 150) + [same] * 3000      # interval 1: 3000 hits in ~17 bins (+ enough bins for the 1 % rule)
+    seqs += [same] * 2000 + random_reads(rng, 2000, 150)      # interval 2: mixed, the copies first
+    seqs += random_reads(rng, 4000, 150)                      # interval 3: clean again
+    o, g = run_both(seqs, 15, 9, 24, interval=4000, batches=1)
+    o.finish(); g.finish()
+    assert o.counters()["n_minimizers"] == g.counters()["n_minimizers"]
+    assert np.array_equal(g.cms(), o.cms())
+    assert_same_sketch(o, g)
+    g.close(); o.close()
