@@ -385,6 +385,7 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
         if (regions > c->ml_regions || c->ml.rcap != rcap) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum);
+            hipFree(c->ml.lo); hipFree(c->ml.lo_cnt);
             uint32_t *keep_partial = c->ml.partial; const uint32_t keep_parts = c->ml.max_parts;
             uint32_t *keep_nib = c->ml.nib, *keep_over = c->ml.nib_over; const uint32_t keep_np = c->ml.nib_parts;
             c->ml = MinimizerList{}; c->ml_regions = 0;
@@ -397,6 +398,8 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             HIPCHK(c, hipMalloc((void **)&c->ml.cnt, cap * 4));
             HIPCHK(c, hipMalloc((void **)&c->ml.off, (cap + 1) * 4));
             HIPCHK(c, hipMalloc((void **)&c->ml.bsum, (cap / 1024 + 2) * 4));
+            HIPCHK(c, hipMalloc((void **)&c->ml.lo, cap * JUMP_LO_CAP * sizeof(uint4)));
+            HIPCHK(c, hipMalloc((void **)&c->ml.lo_cnt, cap * 4));
             if (!c->ml.nib) {
                 const size_t nr = ((size_t)c->B + 262143) / 262144;
                 c->ml.nib_parts = 48;
@@ -638,7 +641,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
     hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited); hipFree(c->d_kminslot);
     hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
-    hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial); hipFree(c->ml.nib); hipFree(c->ml.nib_over);
+    hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial); hipFree(c->ml.nib); hipFree(c->ml.nib_over); hipFree(c->ml.lo); hipFree(c->ml.lo_cnt);
     hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;

@@ -32,6 +32,7 @@ struct FlushBatch {
 
 // Minimizer list written by k_minimizer_fast: one region of `rcap` entries per wave (16 reads).
 constexpr int FAST_READS_PER_WAVE = 16;
+constexpr int JUMP_LO_CAP = 64;        // unfinished chains a region may hand to k_jump_left (one round of a wave)
 struct MinimizerList {
     uint64_t *x;        // [regions][rcap] distinct minimizer values
     uint8_t *slot;      // [regions][rcap] spectrum (ring slot) of the read each value came from
@@ -41,6 +42,8 @@ struct MinimizerList {
     uint32_t *bsum;     // [regions / 1024 + 1] per-block sums for the prefix
     uint32_t *partial;  // [max_parts][ring_n][num_bins] per-part spectra of k_range_hist
     uint32_t max_parts;
+    uint4 *lo;          // [regions][JUMP_LO_CAP] unfinished jump chains of k_jump_bin: {key lo, key hi, float-as-int t, idx | slot << 16}
+    uint32_t *lo_cnt;   // [regions]
     uint32_t *nib;      // [nib_parts][ring_n][nranges][NIB_WORDS] per-part spectra of k_nibble_hist, 8 four-bit counters per word
     uint32_t *nib_over; // [RING_MAX] a 4-bit counter overflowed in this spectrum: k_range_hist recounts it
     uint32_t nib_parts;

@@ -727,13 +727,17 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
 // ------------------------------------------------------------------------------------------
 // The step loop of k_jump_bin in assembly (fixed registers v40..v57, s60..s63): hipcc's version of the same loop
 // carries two v_mov_b64 and a dozen scalar mask instructions per pair of steps; this one is the 17 VALU
-// instructions of a step plus v_cmp / s_and / s_cbranch, the LCG state ping-ponging between v[40:41] and
-// v[42:43].  Lanes that reach p >= n leave the exec mask and keep their t.  HULK_JUMP_C=1 selects the C++ loop.
-__device__ __forceinline__ double jump_steps_asm(uint32_t klo, uint32_t khi, double fn) {
-    uint32_t tlo, thi;
-    const uint64_t fb = (uint64_t)__double_as_longlong(fn);
-    const uint32_t flo = (uint32_t)fb, fhi = (uint32_t)(fb >> 32);
-#define HULK_JSTEP(KS_LO, KS_HI, KD, KD_HI)                                          \
+// instructions of a step plus v_cmp / s_and and the exit test, the LCG state ping-ponging between v[40:41] and
+// v[42:43].  Lanes that reach p >= n leave the exec mask and keep their t.  The loop ends when at most `cut`
+// lanes are still running (cut = 0: when none is): chains take 12.8 +- 3.5 steps, so the last few lanes of a round
+// of 64 would keep the whole wave busy for ~24 — they are handed over instead (`left` = their mask, key/t = their
+// state at a step boundary) and finished by k_jump_left in a denser wave.
+__device__ __forceinline__ double jump_steps_asm(uint32_t &klo, uint32_t &khi, double fn, double t0, uint32_t cut,
+                                                 unsigned long long &left) {
+    uint32_t tlo, thi, mlo, mhi, olo, ohi;
+    const uint64_t fb = (uint64_t)__double_as_longlong(fn), tb = (uint64_t)__double_as_longlong(t0);
+    const uint32_t flo = (uint32_t)fb, fhi = (uint32_t)(fb >> 32), t0lo = (uint32_t)tb, t0hi = (uint32_t)(tb >> 32);
+#define HULK_JSTEP(KS_LO, KS_HI, KD, KD_HI, EXIT)                                    \
     "v_mad_u64_u32 " KD ", s[62:63], " KS_LO ", %[alo], 1\n\t"                       \
     "v_mul_lo_u32 v54, " KS_LO ", %[ahi]\n\t"                                        \
     "v_mul_lo_u32 v55, " KS_HI ", %[alo]\n\t"                                        \
@@ -751,33 +755,46 @@ __device__ __forceinline__ double jump_steps_asm(uint32_t klo, uint32_t khi, dou
     "v_fma_f64 v[52:53], v[44:45], v[48:49], v[48:49]\n\t"                           \
     "v_cmp_nge_f64 vcc, v[52:53], v[56:57]\n\t"                                      \
     "s_and_b64 exec, exec, vcc\n\t"                                                  \
-    "s_cbranch_execz 2f\n\t"                                                         \
-    "v_trunc_f64 v[44:45], v[52:53]\n\t"
+    "v_trunc_f64 v[44:45], v[52:53]\n\t"                                             \
+    "s_bcnt1_i32_b64 s62, exec\n\t"                                                  \
+    "s_cmp_le_u32 s62, %[cut]\n\t"                                                   \
+    "s_cbranch_scc1 " EXIT "\n\t"
     asm volatile(
         "s_mov_b64 s[60:61], exec\n\t"
         "v_mov_b32 v40, %[klo]\n\t"
         "v_mov_b32 v41, %[khi]\n\t"
         "v_mov_b32 v56, %[flo]\n\t"
         "v_mov_b32 v57, %[fhi]\n\t"
-        "v_mov_b32 v44, 0\n\t"
-        "v_mov_b32 v45, 0\n\t"
+        "v_mov_b32 v44, %[t0lo]\n\t"
+        "v_mov_b32 v45, %[t0hi]\n\t"
         "1:\n\t"
-        HULK_JSTEP("v40", "v41", "v[42:43]", "v43")
-        HULK_JSTEP("v42", "v43", "v[40:41]", "v41")
+        HULK_JSTEP("v40", "v41", "v[42:43]", "v43", "3f")
+        HULK_JSTEP("v42", "v43", "v[40:41]", "v41", "2f")
         "s_branch 1b\n\t"
+        "3:\n\t"                                   // left after the first half: the live key is in v[42:43]
+        "v_mov_b32 v40, v42\n\t"
+        "v_mov_b32 v41, v43\n\t"
         "2:\n\t"
+        "s_mov_b32 %[mlo], exec_lo\n\t"
+        "s_mov_b32 %[mhi], exec_hi\n\t"
         "s_mov_b64 exec, s[60:61]\n\t"
         "v_mov_b32 %[tlo], v44\n\t"
         "v_mov_b32 %[thi], v45\n\t"
-        : [tlo] "=v"(tlo), [thi] "=v"(thi)
-        : [klo] "v"(klo), [khi] "v"(khi), [flo] "v"(flo), [fhi] "v"(fhi), [alo] "s"(0x87B0B0FDu), [ahi] "s"(0x27BB2EE6u)
+        "v_mov_b32 %[olo], v40\n\t"
+        "v_mov_b32 %[ohi], v41\n\t"
+        : [tlo] "=v"(tlo), [thi] "=v"(thi), [olo] "=v"(olo), [ohi] "=v"(ohi), [mlo] "=s"(mlo), [mhi] "=s"(mhi)
+        : [klo] "v"(klo), [khi] "v"(khi), [flo] "v"(flo), [fhi] "v"(fhi), [t0lo] "v"(t0lo), [t0hi] "v"(t0hi),
+          [alo] "s"(0x87B0B0FDu), [ahi] "s"(0x27BB2EE6u), [cut] "s"(cut)
         : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
-          "v56", "v57", "s60", "s61", "s62", "s63", "vcc", "memory");
+          "v56", "v57", "s60", "s61", "s62", "s63", "vcc", "scc", "memory");
 #undef HULK_JSTEP
+    klo = olo; khi = ohi;
+    left = ((unsigned long long)mhi << 32) | mlo;
     return __longlong_as_double((long long)(((uint64_t)thi << 32) | tlo));
 }
 
-__global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_regions, int32_t num_bins, int use_c) {
+__global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_regions, int32_t num_bins, int use_c,
+                                                  uint32_t cut) {
     const int lane = lane_id();
     const uint32_t region = (uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (region >= n_regions) return;
@@ -785,21 +802,40 @@ __global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_r
     const uint64_t *xl = ml.x + (size_t)region * ml.rcap;
     const uint8_t *sl = ml.slot + (size_t)region * ml.rcap;
     uint32_t *kl = ml.key + ml.off[region];                   // dense: regions back to back
+    uint4 *lo = ml.lo + (size_t)region * JUMP_LO_CAP;
+    uint32_t nleft = 0;                                        // wave-uniform: chains handed to k_jump_left so far
     uint32_t idx = (uint32_t)lane;
     uint64_t nx = 0; uint32_t ns = 0;
     if (idx < cnt) { nx = xl[idx]; ns = sl[idx]; }
+    const double fn = (double)num_bins;
     while (idx < cnt) {
         uint64_t key = nx; const uint32_t slot = ns;
         const uint32_t nidx = idx + 64;
         if (nidx < cnt) { nx = xl[nidx]; ns = sl[nidx]; }      // prefetch the lane's next value
-        // b+1 and the candidate j stay in fp64 (exact integers < 2^31): no int<->double round trip per step
         // Literally the reference's step: j = int64(float64(b+1) * (float64(1<<31) / float64(r))).  float64(b) = t is
         // carried; (t + 1) * q is ONE fma(t, q, q) — the exact product rounded once, as the multiplication is —
-        // so a step needs no add and no ldexp.  Unrolled by two: the LCG state ping-pongs between register pairs.
-        const double fn = (double)num_bins;
+        // so a step needs no add and no ldexp.
         double t = 0.0;                                         // float64(b), b = 0 before the first step
         if (!use_c) {
-            t = jump_steps_asm((uint32_t)key, (uint32_t)(key >> 32), fn);
+            uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+            unsigned long long left = 0;
+            t = jump_steps_asm(klo, khi, fn, 0.0, cut, left);
+            const bool mine = (left >> lane) & 1ull;            // this lane's chain is not finished
+            if (left) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(left >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)left, 0u));
+                const uint32_t pos = nleft + rank;
+                bool stored = false;
+                if (mine && pos < (uint32_t)JUMP_LO_CAP) {
+                    lo[pos] = make_uint4(klo, khi, (uint32_t)(int32_t)t, idx | (slot << 16));
+                    stored = true;
+                }
+                const unsigned long long spill = __ballot(mine && !stored);
+                if (spill) {                                    // the region's hand-over area is full: finish here
+                    if (mine && !stored) { unsigned long long none; t = jump_steps_asm(klo, khi, fn, t, 0u, none); }
+                }
+                nleft += (uint32_t)__popcll(left);
+                if (mine && stored) { idx = nidx; continue; }
+            }
         } else
         for (;;) {
             key = key * 2862933555777941757ull + 1;
@@ -817,6 +853,21 @@ __global__ __launch_bounds__(256) void k_jump_bin(MinimizerList ml, uint32_t n_r
         kl[idx] = (slot << 20) | (uint32_t)res;
         idx = nidx;
     }
+    if (lane == 0) ml.lo_cnt[region] = nleft < (uint32_t)JUMP_LO_CAP ? nleft : (uint32_t)JUMP_LO_CAP;
+}
+
+// finishes the chains k_jump_bin handed over: one wave per region, at most one round
+__global__ __launch_bounds__(256) void k_jump_left(MinimizerList ml, uint32_t n_regions, int32_t num_bins) {
+    const int lane = lane_id();
+    const uint32_t region = (uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (region >= n_regions) return;
+    const uint32_t n = ml.lo_cnt[region];
+    if ((uint32_t)lane >= n) return;
+    const uint4 st = ml.lo[(size_t)region * JUMP_LO_CAP + lane];
+    uint32_t klo = st.x, khi = st.y;
+    unsigned long long none;
+    const double t = jump_steps_asm(klo, khi, (double)num_bins, (double)(int32_t)st.z, 0u, none);
+    ml.key[ml.off[region] + (st.w & 0xffffu)] = ((st.w >> 16) << 20) | (uint32_t)(int32_t)t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2279,7 +2330,11 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     if (jump_lds < 0) { const char *e = getenv("HULK_JUMP_LDS"); jump_lds = e ? atoi(e) : 0; }
     static int jump_c = -1;
     if (jump_c < 0) { const char *ec = getenv("HULK_JUMP_C"); jump_c = ec ? atoi(ec) : 0; }
-    hipLaunchKernelGGL(k_jump_bin, dim3((n_regions + 3) / 4), dim3(256), (size_t)jump_lds, s, ml, n_regions, P.num_bins, jump_c);
+    static int jump_cut = -1;
+    if (jump_cut < 0) { const char *ec = getenv("HULK_JUMP_CUT"); jump_cut = ec ? atoi(ec) : 10; }
+    const uint32_t cut = (jump_c || !ml.lo) ? 0u : (uint32_t)jump_cut;
+    hipLaunchKernelGGL(k_jump_bin, dim3((n_regions + 3) / 4), dim3(256), (size_t)jump_lds, s, ml, n_regions, P.num_bins, jump_c, cut);
+    if (cut) hipLaunchKernelGGL(k_jump_left, dim3((n_regions + 3) / 4), dim3(256), 0, s, ml, n_regions, P.num_bins);
     const uint32_t n_spectra = P.interval ? (uint32_t)((P.fill + n_reads + P.interval - 1) / P.interval) : 1u;
     const int nranges = (P.num_bins + HIST_RANGE - 1) / HIST_RANGE;
     static int parts_target = -1;
