@@ -101,7 +101,8 @@ struct hulk_ctx {
     // staging for host reads
     uint8_t *d_bases = nullptr; size_t d_bases_cap = 0;
     uint64_t *d_offsets = nullptr; size_t d_offsets_cap = 0;
-    uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;
+    uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;   // d_slow_count[2]: alternate per launch
+    uint32_t slow_parity = 0;
     MinimizerList ml{}; uint64_t ml_regions = 0;
     uint64_t *d_long_xs = nullptr, *d_long_table = nullptr; uint8_t *d_long_valid = nullptr;   // long-sequence scratch
     void *d_long_desc = nullptr; uint64_t long_desc_cap = 0;
@@ -379,7 +380,10 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             HIPCHK(c, hipMalloc((void **)&c->d_slow_list, (size_t)(n + n / 4 + 1024) * 4));
             c->d_slow_cap = n + n / 4 + 1024;
         }
-        HIPCHK(c, hipMemsetAsync(c->d_slow_count, 0, 4, c->stream));
+        // the slow-list counter alternates between two words; the launch zeroes the one the NEXT launch will use
+        // (in k_region_offsets), so no memset sits in front of the minimizer kernel
+        uint32_t *slow_cnt = c->d_slow_count + c->slow_parity, *slow_cnt_next = c->d_slow_count + (c->slow_parity ^ 1u);
+        c->slow_parity ^= 1u;
         const uint64_t regions = (n + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE;
         const uint64_t rcap = minimizer_list_rcap(c->p.w);
         if (regions > c->ml_regions || c->ml.rcap != rcap) {
@@ -419,13 +423,13 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             HIPCHK(c, hipEventRecord(pr.a, c->stream));
         }
         HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->ml, c->d_state,
-                                        c->d_min_slots, c->d_slow_list, c->d_slow_count));
+                                        c->d_min_slots, c->d_slow_list, slow_cnt));
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
-        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist));
+        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist, slow_cnt_next));
         pick_config(c->p.k, max_len, P, threads);      // (fast_ok implies max_len <= 256: always fits)
-        const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(1024, (n + 3) / 4);
+        const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(128, (n + 3) / 4);   // the list is normally empty or short
         HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, hist, c->d_state,
-                                       c->d_min_slots, c->d_slow_list, c->d_slow_count, list_blocks));
+                                       c->d_min_slots, c->d_slow_list, slow_cnt, list_blocks));
         return HULK_OK;
     }
     const bool fits = pick_config(c->p.k, max_len, P, threads);
@@ -573,7 +577,8 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(hipEventCreateWithFlags(&c->ev_flushed[0], hipEventDisableTiming));
     CHK_CREATE(hipEventCreateWithFlags(&c->ev_flushed[1], hipEventDisableTiming));
     CHK_CREATE(dalloc(&c->d_hist_tmp, B));
-    CHK_CREATE(dalloc(&c->d_slow_count, 1));
+    CHK_CREATE(dalloc(&c->d_slow_count, 2));
+    CHK_CREATE(hipMemsetAsync(c->d_slow_count, 0, 8, c->stream));
     CHK_CREATE(dalloc(&c->d_min_slots, (size_t)MIN_SLOTS));
     CHK_CREATE(hipMemsetAsync(c->d_min_slots, 0, (size_t)MIN_SLOTS * 8, c->stream));
     CHK_CREATE(dalloc(&c->d_ctr, (size_t)c->cms_depth * c->cms_width));

@@ -893,8 +893,9 @@ __global__ __launch_bounds__(1024) void k_region_bsum(const uint32_t *__restrict
 }
 __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ bsum,
                                                          uint32_t *__restrict__ off, uint32_t n_regions,
-                                                         uint32_t *__restrict__ nib_over) {
+                                                         uint32_t *__restrict__ nib_over, uint32_t *__restrict__ zero_word) {
     if (nib_over && blockIdx.x == 0 && threadIdx.x < RING_MAX) nib_over[threadIdx.x] = 0;
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;      // the next launch's slow-list counter
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t i = blockIdx.x * 1024u + (uint32_t)tid;
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *__restr
 __global__ __launch_bounds__(1024) void k_range_hist(MinimizerList ml, uint32_t n_regions,
                                                      uint32_t *__restrict__ partial, MinimizerParams P,
                                                      uint32_t n_spectra, uint32_t n_parts, uint64_t n_reads, int nranges,
-                                                     const uint32_t *__restrict__ only_if) {
+                                                     const uint32_t *__restrict__ only_if, uint32_t *__restrict__ hists_direct) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *lh = (uint32_t *)smem;
     // XCD-aware order (workgroup b lands on XCD b % 8): the nranges workgroups that stream the SAME keys
@@ -966,8 +967,13 @@ __global__ __launch_bounds__(1024) void k_range_hist(MinimizerList ml, uint32_t 
         if (tail < hi) { const uint32_t k = kl[tail]; if ((k >> 15) == want) atomicAdd(&lh[k & (HIST_RANGE - 1)], 1u); }
     }
     __syncthreads();
-    uint32_t *out = partial + ((size_t)part * n_spectra + t) * (size_t)P.num_bins + (size_t)r * HIST_RANGE;
     const int32_t nb = P.num_bins - r * HIST_RANGE;
+    if (hists_direct) {                                          // recount mode: straight into the spectrum (coalesced atomics)
+        uint32_t *h = hists_direct + (size_t)slot * (size_t)P.num_bins + (size_t)r * HIST_RANGE;
+        for (int i = tid; i < HIST_RANGE && i < nb; i += blockDim.x) if (lh[i]) atomicAdd(&h[i], lh[i]);
+        return;
+    }
+    uint32_t *out = partial + ((size_t)part * n_spectra + t) * (size_t)P.num_bins + (size_t)r * HIST_RANGE;
     for (int i = tid; i < HIST_RANGE && i < nb; i += blockDim.x) out[i] = lh[i];
 }
 
@@ -2317,13 +2323,13 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
 
 // K1b: jump hash of the list (dense key array); K1c: spectrum ranges in LDS, merged without atomics
 hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
-                                 uint32_t *d_hists) {
+                                 uint32_t *d_hists, uint32_t *d_zero_word) {
     if (n_reads == 0) return hipSuccess;
     hipError_t e = hipSuccess;
     const uint32_t n_regions = (uint32_t)((n_reads + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE);
     const uint32_t nblk = (n_regions + 1023) / 1024;
     hipLaunchKernelGGL(k_region_bsum, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, n_regions);
-    hipLaunchKernelGGL(k_region_offsets, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.off, n_regions, ml.nib_over);
+    hipLaunchKernelGGL(k_region_offsets, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.off, n_regions, ml.nib_over, d_zero_word);
     // k_jump_bin needs no LDS; a dummy allocation caps its occupancy so that the flush kernels of the
     // previous batch (other stream) find free wave slots next to it
     static int jump_lds = -1;
@@ -2378,11 +2384,14 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
         hipLaunchKernelGGL(k_nibble_merge, dim3(nb, n_spectra), dim3(256), 0, s, ml, d_hists, P, n_spectra, np, nr);
         only_if = ml.nib_over;                              // the exact kernels only recount flagged spectra
     }
+    if (only_if) n_parts = 1;                                  // recount mode: rare, a small grid is enough
     const unsigned pair_groups = (n_spectra * n_parts + 7) / 8;
     hipLaunchKernelGGL(k_range_hist, dim3(8u * (unsigned)nranges * pair_groups), dim3(1024), HIST_RANGE * 4, s, ml, n_regions,
-                       ml.partial, P, n_spectra, n_parts, n_reads, nranges, only_if);
-    int mb = (P.num_bins + 255) / 256; if (mb > 512) mb = 512;
-    hipLaunchKernelGGL(k_merge_hist, dim3(mb, n_spectra), dim3(256), 0, s, ml.partial, d_hists, P, n_spectra, n_parts, only_if);
+                       ml.partial, P, n_spectra, n_parts, n_reads, nranges, only_if, only_if ? d_hists : nullptr);
+    if (!only_if) {
+        int mb = (P.num_bins + 255) / 256; if (mb > 512) mb = 512;
+        hipLaunchKernelGGL(k_merge_hist, dim3(mb, n_spectra), dim3(256), 0, s, ml.partial, d_hists, P, n_spectra, n_parts, only_if);
+    }
     return hipGetLastError();
 }
 
