@@ -32,6 +32,11 @@ class GoRandSource {
             }
         }
     }
+    // the 607 sequence values y[-606..0] a freshly seeded source starts from (y[1] is the first next_u64()); only
+    // valid before the first draw
+    void initial_window(uint64_t out[607]) const {
+        for (int j = 0; j < kLen; j++) out[j] = vec_[((kLen - kTap) + (kLen - 1) - j + kLen) % kLen];
+    }
     inline uint64_t next_u64() {
         if (--tap_ < 0) tap_ += kLen;
         if (--feed_ < 0) feed_ += kLen;

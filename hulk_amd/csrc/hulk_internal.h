@@ -127,7 +127,12 @@ hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const do
 hipError_t launch_cws_chunk(hipStream_t s, const uint64_t *d_pairs, uint64_t n_attempts, double *d_val,
                             uint32_t *d_blkcnt, unsigned long long *d_gamma_total, unsigned long long *d_chunk_base,
                             double *d_rcb, uint64_t num_bins, uint64_t slot_begin, uint64_t slots,
-                            uint64_t sketch_size, double ainv, double bbb, double ccc, double magic);
+                            uint64_t sketch_size, double ainv, double bbb, double ccc, double magic,
+                            const uint64_t *d_raw, uint64_t first_attempt, const uint64_t *d_ev, uint32_t n_ev);
+hipError_t launch_alfg(hipStream_t s, const uint64_t *d_coef, uint64_t *d_windows, uint64_t *d_raw, uint32_t first_chunk,
+                       uint32_t n_chunks, uint64_t chunk_len);
+hipError_t launch_rng_candidates(hipStream_t s, const uint64_t *d_raw, uint64_t n, uint64_t *d_list, uint32_t cap,
+                                 unsigned int *d_count);
 hipError_t launch_cws_beta(hipStream_t s, const uint64_t *d_uraw, uint64_t first_entry, uint64_t n, double *d_rcb,
                            uint64_t num_bins, uint64_t slot_begin, uint64_t slots);
 hipError_t launch_smash(hipStream_t s, const unsigned long long *d_mins, const double *d_weights, uint32_t N, uint32_t S,

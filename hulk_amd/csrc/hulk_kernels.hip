@@ -2075,11 +2075,75 @@ __global__ __launch_bounds__(256) void k_cws_resolve_drift(const double *__restr
 // evaluated in parallel and the accepted gamma variates are compacted IN ORDER into the table:
 // gamma #n -> entry n/2 = slot*B + bin, r if n is even, c = ln(gamma) if n is odd.
 // ==========================================================================================
+// ---- Go math/rand's additive lagged-Fibonacci stream, generated on the device -------------------
+// y[m] = y[m-607] + y[m-273] (mod 2^64).  The stream itself does not depend on how the gamma sampler consumes it,
+// so it is produced in chunks of 2^GO_RNG_JUMP_LOG2 values: k_alfg_jump walks the chunk start states with the
+// jump polynomial (go_rng_jump.h: y[n + C + j] = sum_i coef[i] * y[n + i + j]), k_alfg_fill expands every chunk in
+// parallel, 256 values per step (the shorter lag is 273).  windows[c] = the 607 values that end where chunk c begins.
+__global__ __launch_bounds__(640) void k_alfg_jump(const uint64_t *__restrict__ coef, uint64_t *__restrict__ windows,
+                                                   uint32_t first_chunk, uint32_t n_chunks) {
+    __shared__ uint64_t E[1216], C[608];
+    const int tid = threadIdx.x;
+    if (tid < 607) { C[tid] = coef[tid]; E[tid] = windows[(size_t)first_chunk * 607 + tid]; }
+    __syncthreads();
+    for (uint32_t c = first_chunk; c + 1 < first_chunk + n_chunks; c++) {
+        for (int base = 607; base < 1213; base += 273) {          // extend the window by 606 values, 273 at a time
+            const int j = base + tid;
+            if (tid < 273 && j < 1213) E[j] = E[j - 607] + E[j - 273];
+            __syncthreads();
+        }
+        uint64_t acc = 0;
+        if (tid < 607) for (int i = 0; i < 607; i++) acc += C[i] * E[i + tid];
+        __syncthreads();
+        if (tid < 607) { E[tid] = acc; windows[(size_t)(c + 1) * 607 + tid] = acc; }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_alfg_fill(const uint64_t *__restrict__ windows, uint64_t *__restrict__ raw,
+                                                   uint32_t first_chunk, uint64_t chunk_len) {
+    __shared__ uint64_t ring[1024];                               // the last 607 values live in a ring of 1024
+    const int tid = threadIdx.x;
+    const uint32_t c = first_chunk + blockIdx.x;
+    const uint64_t *w = windows + (size_t)c * 607;
+    for (int i = tid; i < 607; i += 256) ring[(1024 - 607 + i) & 1023] = w[i];   // window value i sits at position i - 607
+    __syncthreads();
+    uint64_t *out = raw + (size_t)c * chunk_len;
+    for (uint64_t n = 0; n < chunk_len; n += 256) {
+        const uint32_t at = (uint32_t)(n + tid);
+        const uint64_t v = ring[(at - 607u) & 1023u] + ring[(at - 273u) & 1023u];
+        __syncthreads();                                          // every read of this step before any write
+        ring[at & 1023u] = v;
+        out[n + tid] = v;
+        __syncthreads();
+    }
+}
+// positions of the stream whose value fails the gamma sampler's u1 range test or would make Float64() resample
+// (type 1): rare (2e-7 / 2^-54 per value), resolved on the host into the `ev` list of k_cws_eval
+__global__ __launch_bounds__(256) void k_rng_candidates(const uint64_t *__restrict__ raw, uint64_t n,
+                                                        uint64_t *__restrict__ list, uint32_t cap,
+                                                        unsigned int *__restrict__ count) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t x = raw[i] & 0x7fffffffffffffffull;
+        const double u = (double)(long long)x * 0x1p-63;
+        const bool skip = u == 1.0, fail = !(1e-7 < u && u < .9999999);
+        if (skip || fail) {
+            const unsigned at = atomicAdd(count, 1u);
+            if (at < cap) list[at] = (i << 1) | (skip ? 1ull : 0ull);
+        }
+    }
+}
+
 constexpr int CWS_BLOCK = 1024;     // attempts per block (256 threads x 4)
 
+// `pairs` is either the host-prepared (u1, u2) list of this chunk (raw == nullptr) or, in raw mode, unused: attempt
+// g = first_attempt + i then reads the device-resident math/rand stream at raw[2g + d], raw[2g + d + 1], where d is
+// the number of earlier attempts that died on the u1 range test (each consumed ONE value; `ev` holds, sorted, the
+// index of the valid attempt that followed each of them).
 __global__ __launch_bounds__(256) void k_cws_eval(const uint64_t *__restrict__ pairs, uint64_t n_attempts,
                                                   double *__restrict__ val, uint32_t *__restrict__ blkcnt,
-                                                  double ainv, double bbb, double ccc, double magic) {
+                                                  double ainv, double bbb, double ccc, double magic,
+                                                  const uint64_t *__restrict__ raw, uint64_t first_attempt,
+                                                  const uint64_t *__restrict__ ev, uint32_t n_ev) {
     __shared__ unsigned red[4];
     unsigned cnt = 0;
 #pragma unroll
@@ -2087,8 +2151,16 @@ __global__ __launch_bounds__(256) void k_cws_eval(const uint64_t *__restrict__ p
         const uint64_t i = (uint64_t)blockIdx.x * CWS_BLOCK + (uint64_t)x * 256 + threadIdx.x;
         double out = -1.0;                                       // < 0 marks a rejected attempt
         if (i < n_attempts) {
-            const double u1 = (double)(long long)pairs[2 * i] * 0x1p-63;
-            const double u2 = 1.0 - (double)(long long)pairs[2 * i + 1] * 0x1p-63;
+            uint64_t p0, p1;
+            if (raw) {
+                const uint64_t g = first_attempt + i;
+                uint32_t lo = 0, hi = n_ev;                      // upper_bound(ev, g)
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ev[mid] <= g) lo = mid + 1; else hi = mid; }
+                const uint64_t a = 2 * g + lo;
+                p0 = raw[a] & 0x7fffffffffffffffull; p1 = raw[a + 1] & 0x7fffffffffffffffull;
+            } else { p0 = pairs[2 * i]; p1 = pairs[2 * i + 1]; }
+            const double u1 = (double)(long long)p0 * 0x1p-63;
+            const double u2 = 1.0 - (double)(long long)p1 * 0x1p-63;
             const double v = log(u1 / (1.0 - u1)) / ainv;
             const double xx = 2.0 * exp(v);
             const double z = u1 * u1 * u2;
@@ -2160,7 +2232,7 @@ __global__ __launch_bounds__(256) void k_cws_beta(const uint64_t *__restrict__ u
         const uint64_t entry = first_entry + i, slot = entry / num_bins;
         if (slot >= slot_begin && slot < slot_begin + slots) {
             const uint64_t at = (entry - slot_begin * num_bins) * 3;
-            const double u = 0.0 + (double)(long long)uraw[i] * 0x1p-63 * (1.0 - 0.0);   // Float64Range(0, 1)
+            const double u = 0.0 + (double)(long long)(uraw[i] & 0x7fffffffffffffffull) * 0x1p-63 * (1.0 - 0.0);   // Float64Range(0, 1)
             rcb[at + 2] = u * rcb[at];
         }
     }
@@ -2528,12 +2600,28 @@ hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const do
 hipError_t launch_cws_chunk(hipStream_t s, const uint64_t *d_pairs, uint64_t n_attempts, double *d_val,
                             uint32_t *d_blkcnt, unsigned long long *d_gamma_total, unsigned long long *d_chunk_base,
                             double *d_rcb, uint64_t num_bins, uint64_t slot_begin, uint64_t slots,
-                            uint64_t sketch_size, double ainv, double bbb, double ccc, double magic) {
+                            uint64_t sketch_size, double ainv, double bbb, double ccc, double magic,
+                            const uint64_t *d_raw, uint64_t first_attempt, const uint64_t *d_ev, uint32_t n_ev) {
     const uint32_t nblk = (uint32_t)((n_attempts + CWS_BLOCK - 1) / CWS_BLOCK);
-    hipLaunchKernelGGL(k_cws_eval, dim3(nblk), dim3(256), 0, s, d_pairs, n_attempts, d_val, d_blkcnt, ainv, bbb, ccc, magic);
+    hipLaunchKernelGGL(k_cws_eval, dim3(nblk), dim3(256), 0, s, d_pairs, n_attempts, d_val, d_blkcnt, ainv, bbb, ccc, magic,
+                       d_raw, first_attempt, d_ev, n_ev);
     hipLaunchKernelGGL(k_cws_scan_blocks, dim3(1), dim3(1024), 0, s, d_blkcnt, nblk, d_gamma_total, d_chunk_base);
     hipLaunchKernelGGL(k_cws_scatter, dim3(nblk), dim3(256), 0, s, d_val, n_attempts, d_blkcnt, d_chunk_base, d_rcb,
                        num_bins, slot_begin, slots, sketch_size);
+    return hipGetLastError();
+}
+
+hipError_t launch_alfg(hipStream_t s, const uint64_t *d_coef, uint64_t *d_windows, uint64_t *d_raw, uint32_t first_chunk,
+                       uint32_t n_chunks, uint64_t chunk_len) {
+    // windows[first_chunk] is valid; produces windows[first_chunk + 1 .. first_chunk + n_chunks) and the chunks themselves
+    hipLaunchKernelGGL(k_alfg_jump, dim3(1), dim3(640), 0, s, d_coef, d_windows, first_chunk, n_chunks);
+    hipLaunchKernelGGL(k_alfg_fill, dim3(n_chunks), dim3(256), 0, s, d_windows, d_raw, first_chunk, chunk_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_rng_candidates(hipStream_t s, const uint64_t *d_raw, uint64_t n, uint64_t *d_list, uint32_t cap,
+                                 unsigned int *d_count) {
+    hipLaunchKernelGGL(k_rng_candidates, dim3(4096), dim3(256), 0, s, d_raw, n, d_list, cap, d_count);
     return hipGetLastError();
 }
 
