@@ -572,7 +572,7 @@ int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, b
     {   // whole-batch bound on the counters as they stand BEFORE this batch is added (see k_flush_decide)
         static const bool no_skip = getenv("HULK_NO_SKIP") != nullptr;
         HIPCHK(c, launch_flush_decide(s, c->d_ctr, c->cms_depth * c->cms_width, c->d_kminslot, c->d_weights, (int)c->slots,
-                                      (int)c->slot_begin, c->d_state, fb, (c->prune && !no_skip && c->slots) ? 1 : 0));
+                                      (int)c->slot_begin, c->d_state, fb, (c->prune && !c->drift && !no_skip && c->slots) ? 1 : 0));
     }
     if (c->scaling) {
         HIPCHK(c, launch_elem_index(s, hist, c->d_blkcnt, c->d_eidx, c->d_etot, fb));
@@ -591,7 +591,7 @@ int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, b
         }
         HIPCHK(c, launch_cws_scan(s, c->d_k32, c->d_rcp32, c->d_tilemin, (int)c->slots, c->ntiles,
                                   c->row_stride, c->d_state, fb, c->prune ? c->d_kmin32 : nullptr, c->d_rext,
-                                  c->d_weights, (int)c->slot_begin, c->d_visited));
+                                  c->d_weights, (int)c->slot_begin, c->d_visited, c->drift ? c->decay_weight : 0.0));
         c->scan_tiles_total += (uint64_t)((c->slots + SCAN_ROWS - 1) / SCAN_ROWS) * (uint64_t)c->ntiles * 4u;
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
         if (c->drift)
@@ -704,8 +704,9 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_kminslot, (SL ? SL : 1)));
     CHK_CREATE(dalloc(&c->d_visited, (size_t)MIN_SLOTS));
     CHK_CREATE(hipMemsetAsync(c->d_visited, 0, (size_t)MIN_SLOTS * 8, c->stream));
-    // exact pruning of the K scan needs "weights only fall": off with concept drift (curMin = w / decayWeight)
-    c->prune = !c->drift && !getenv("HULK_NO_PRUNE");
+    // exact pruning of the K scan: without drift weights only fall; with drift (curMin = w / decayWeight) that still
+    // holds for negative weights, which is what k_cws_scan tests then; decayRatio == 0 (decayWeight 0) is left alone
+    c->prune = !(c->drift && c->decay_weight <= 0.0) && !getenv("HULK_NO_PRUNE");
     if (c->scaling) {
         const size_t NC = (size_t)c->cms_depth * c->cms_width;
         CHK_CREATE(dalloc(&c->d_blkcnt, T * (size_t)elem_index_blocks(c->B)));

@@ -1733,7 +1733,7 @@ __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
                                                   size_t row_stride, const DevState *st, FlushBatch fb,
                                                   const float *__restrict__ kmin32, const float *__restrict__ rext,
                                                   const double *__restrict__ weights, int slot_begin,
-                                                  unsigned long long *__restrict__ visited) {
+                                                  unsigned long long *__restrict__ visited, double drift_dw) {
     // XCD-aware order (workgroup b lands on XCD b % 8): XCD x works through column tile 8*chunk + x for
     // ALL slot groups before moving on, so a column's reciprocal vectors (T x 4 KB) are fetched into
     // that XCD's L2 once and re-used by the other groups; the 8 XCDs stream 8 adjacent 4 KB pieces of
@@ -1760,8 +1760,14 @@ __global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
         bool pass = false;
         if (slot < slots) {
             const double km = (double)kmin32[(size_t)slot * wtiles + wt];
-            const double w = weights[slot_begin + slot];
+            double w = weights[slot_begin + slot];
+            // concept drift (drift_dw = decayWeight > 0): the update test is A < w / decayWeight and w may move either
+            // way — but a NEGATIVE weight can only be replaced by a smaller one (A < w/dw < w), so its threshold of
+            // the whole batch is at most w_start / dw; a slot whose weight is not negative is simply never pruned
+            bool never = false;
+            if (drift_dw > 0.0) { if (w < 0.0) w = w / drift_dw; else never = true; }
             const double thr = w + 1e-5 * fabs(w) + 1e-37;
+            if (never) pass = true;
             for (int t = lane >> 3; t < (int)fb.count; t += 8) {
                 if (!((gomask >> t) & 1u)) continue;
                 const float rmax = rext[((size_t)t * wtiles + wt) * 2], rmin = rext[((size_t)t * wtiles + wt) * 2 + 1];
@@ -2540,13 +2546,13 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
-                           unsigned long long *d_visited) {
+                           unsigned long long *d_visited, double drift_dw) {
     const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
     const int chunks = (ntiles + 7) / 8;
     if (d_kmin32)
         hipLaunchKernelGGL(k_rcp_extrema, dim3(ntiles, fb.count), dim3(256), 0, s, d_rcp32, d_rext, ntiles, row_stride, st, fb);
     hipLaunchKernelGGL(k_cws_scan, dim3((unsigned)(chunks * 8 * groups)), dim3(256), 0, s, d_k32, d_rcp32,
-                       d_tilemin, slots, ntiles, row_stride, st, fb, d_kmin32, d_rext, d_weights, slot_begin, d_visited);
+                       d_tilemin, slots, ntiles, row_stride, st, fb, d_kmin32, d_rext, d_weights, slot_begin, d_visited, drift_dw);
     return hipGetLastError();
 }
 
