@@ -67,11 +67,12 @@ def test_c2_full_size_invariances():
 
 
 def test_c2_prefix_against_oracle():
-    """The first 3 intervals of the C2 stream (300k reads) against the CPU oracle, C2 parameters."""
+    """The first 8 intervals of the C2 stream (800k reads) against the CPU oracle, C2 parameters: the first batch
+    evaluates everything, later intervals run through the per-tile and whole-batch bounds."""
     from oracle import pyorc
     from hulk_amd import synth
-    n = 300_000
-    m, w, c = _run_stream(21, 512, 100_000, 1.0, n, 170_000, 16)
+    n = 800_000
+    m, w, c = _run_stream(21, 512, 100_000, 1.0, n, 170_000, 3)
     bases, offsets = synth.reads_numpy(0, n, L)
     o = pyorc.Sketcher(21, 9, 512, 0, 1.0, 100_000)
     o.add_reads(bases, offsets)
