@@ -116,3 +116,22 @@ def test_c3_shape_drift_batch_invariance():
     assert c1 == c2 and c1["n_reads"] == n
     assert np.array_equal(m1, m2) and np.array_equal(w1, w2)
     assert m1.max() < 31 ** 4 and np.all(np.isfinite(w1))
+
+
+@pytest.mark.parametrize("decay", [0.02, 0.5])
+def test_drift_pruning_against_oracle_many_intervals(decay):
+    """Concept drift with the scan pruned against w_start/decayWeight (negative weights only): 10 intervals of
+    20k reads, k=17, against the oracle's element-by-element AddElement."""
+    from oracle import pyorc
+    from hulk_amd import synth
+    n, interval = 200_000, 20_000
+    m, w, c = _run_stream(17, 48, interval, decay, n, 70_001, 4)
+    bases, offsets = synth.reads_numpy(0, n, L)
+    o = pyorc.Sketcher(17, 9, 48, 0, decay, interval)
+    o.add_reads(bases, offsets)
+    o.finish()
+    mo, wo = o.sketch()
+    assert np.array_equal(m, mo)
+    assert np.allclose(w, wo, rtol=1e-7, atol=0)
+    assert (wo < 0).all()                      # the regime the drift pruning relies on
+    o.close()
