@@ -477,8 +477,14 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
     int threads = 256;
     // the short-read kernel takes reads of <= 16*w k-mer positions and <= 256 bases; when the batch's
     // length bound already exceeds that, go straight to the generic kernel
-    const bool fast_ok = c->p.w >= 1 && c->p.w <= 16 && !getenv("HULK_NO_FAST_K1") && n < 0xffffffffull &&
-                         max_len <= 256 && (uint64_t)max_len < (uint64_t)c->p.k + 16ull * c->p.w;
+    // ... or, two groups per read, <= 2*16w - (w-1) positions (300 bases at k = 21, w = 9) while a group's own
+    // 16w + k - 1 bases fit its 256-base staging
+    const bool fast_base = c->p.w >= 1 && c->p.w <= 16 && !getenv("HULK_NO_FAST_K1") && n < 0xffffffffull;
+    const bool single_ok = max_len <= 256 && (uint64_t)max_len < (uint64_t)c->p.k + 16ull * c->p.w;
+    const bool pair_ok = !single_ok && !getenv("HULK_NO_PAIR") && 16ull * c->p.w + c->p.k - 1 <= 256 && max_len <= 512 &&
+                         (uint64_t)max_len < (uint64_t)c->p.k + 32ull * c->p.w - (c->p.w - 1);
+    const bool fast_ok = fast_base && (single_ok || pair_ok);
+    P.pair = pair_ok ? 1u : 0u;
     if (fast_ok) {
         // short-read kernel first; reads it cannot take (N bases, too long for 16 blocks of w
         // positions) are queued on the device and binned by the generic kernel right after

@@ -69,6 +69,7 @@ struct MinimizerParams {
     uint32_t lds_per_wave;  // filled by launch_minimizer_bin
     uint32_t debug;         // ablation switches (env HULK_K1_DEBUG), 0 in production
     uint32_t skip_long;     // reads beyond xcap are handled by the long-read path, not an error
+    uint32_t pair;          // k_minimizer_fast: two 16-lane groups per read (reads of up to 2*16w - (w-1) positions)
     uint64_t bases_bytes;
     uint64_t interval;   // reads per k-mer spectrum (0 = everything into ring_base)
     uint64_t fill;       // reads already counted into the first spectrum of this launch

@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
 constexpr int FAST_TAB = 128;
 constexpr int FAST_CAND = 64;          // max run starts per read on the fast path
 constexpr int FAST_RAW = 3072 + 64;    // raw ASCII of the wave's 16 reads, staged once (bytes per wave)
+constexpr int FAST_RAW_PAIR = 5120 + 64;   // ... when two groups share a read (reads of up to ~300 bases)
 
 __device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
@@ -407,7 +408,10 @@ template <bool FM> __device__ __forceinline__ uint64_t umin64(uint64_t a, uint64
     return a < b ? a : b;
 }
 
-template <int WM, bool FM, bool DBG, bool WEQ, int KC>
+// PAIR: two neighbouring 16-lane groups share a read (2 x 16w - (w-1) k-mer positions: 300 bp at k = 21, w = 9).
+// The second group starts w-1 positions before the first one ends, so that every window it reports is complete,
+// and reports nothing for those w-1 positions; both groups feed the same per-read set.
+template <int WM, bool FM, bool DBG, bool WEQ, int KC, bool PAIR>
 __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__restrict__ bases,
                                                         const uint64_t *__restrict__ offsets,
                                                         uint64_t n_reads, MinimizerParams P,
@@ -432,10 +436,15 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     const int32_t k = KC ? KC : (int32_t)P.k, w = WEQ ? WM : (int32_t)P.w;   // KC: k fixed at compile time (21 = the default)
     const uint64_t mask = (1ull << (2 * k)) - 1;
     const uint64_t shift = (uint64_t)(2 * (k - 1));
-    uint64_t *tab = (uint64_t *)(smem + 2048) + (size_t)grp * FAST_TAB;
+    constexpr int RAWB = PAIR ? FAST_RAW_PAIR : FAST_RAW;          // raw ASCII of the wave's 16 reads (bytes per wave)
+    constexpr int RPI = PAIR ? 2 : 4;                              // reads per iteration of a wave
+    const int half = PAIR ? (grp & 1) : 0;                         // which half of the read this group takes
+    const int sub = PAIR ? ((grp & 3) >> 1) : (grp & 3);           // read of the iteration
+    const int32_t posoff = half ? 16 * w - (w - 1) : 0;            // first k-mer position of this group
+    uint64_t *tab = (uint64_t *)(smem + 2048) + (size_t)(PAIR ? (grp & ~1) : grp) * FAST_TAB;   // the per-read set
     uint32_t *pk32 = (uint32_t *)(smem + 2048 + 16 * FAST_TAB * 8) + grp * 20;
-    uint32_t *raw32 = (uint32_t *)(smem + 2048 + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * (FAST_RAW / 4);
-    uint64_t *cs = (uint64_t *)(smem + 2048 + 16 * FAST_TAB * 8 + 16 * 20 * 4 + 4 * FAST_RAW) + (size_t)grp * FAST_CAND;
+    uint32_t *raw32 = (uint32_t *)(smem + 2048 + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * (RAWB / 4);
+    uint64_t *cs = (uint64_t *)(smem + 2048 + 16 * FAST_TAB * 8 + 16 * 20 * 4 + 4 * RAWB) + (size_t)grp * FAST_CAND;
 #pragma unroll
     for (int x = 0; x < FAST_TAB / 16; x++) tab[gl + 16 * x] = TAB_EMPTY;
     __syncthreads();
@@ -462,11 +471,11 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     const uint64_t span_lo = __shfl(myoff, 0), span_hi = __shfl(myoff, (int)nrd);
     const uintptr_t raw_a0 = ((uintptr_t)bases + span_lo) & ~(uintptr_t)15;
     const uintptr_t raw_end = (uintptr_t)bases + span_hi;
-    const bool bulk = nrd && (raw_end - raw_a0) <= (uintptr_t)(FAST_RAW - 64);
+    const bool bulk = nrd && (raw_end - raw_a0) <= (uintptr_t)(RAWB - 64);
     if (bulk) {
         const uintptr_t lim = (uintptr_t)bases + P.bases_bytes;
 #pragma unroll
-        for (int x = 0; x < 3; x++) {
+        for (int x = 0; x < (PAIR ? 5 : 3); x++) {
             const uintptr_t a = raw_a0 + 16u * (uint32_t)(lane + 64 * x);
             if (a < raw_end + 16 && a + 16 <= lim) {
                 const uint4 v = *(const uint4 *)a;
@@ -495,19 +504,19 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
         while (slot0 >= P.ring_n) slot0 -= P.ring_n;
     }
 
-    for (int it = 0; it < FAST_READS_PER_WAVE / 4; it++) {
-        const uint64_t base = wave_first + 4u * (uint32_t)it;
+    for (int it = 0; it < FAST_READS_PER_WAVE / RPI; it++) {
+        const uint64_t base = wave_first + (uint32_t)RPI * (uint32_t)it;
         if (base >= n_reads) break;
-        const uint64_t rd = base + (uint64_t)(grp & 3);
+        const uint64_t rd = base + (uint64_t)sub;
         bool act = rd < n_reads;                               // group-uniform
         uint32_t hslot = slot0;
         if (P.interval) {
-            uint64_t x = rem0 + (uint64_t)(4 * it + (grp & 3));
+            uint64_t x = rem0 + (uint64_t)(RPI * it + sub);
             while (x >= P.interval) { x -= P.interval; hslot = hslot + 1 == P.ring_n ? 0u : hslot + 1; }
         }
         uint64_t o0 = 0; int64_t L = 0; int32_t npos = 0;
         {
-            const int oi = 4 * it + (grp & 3);
+            const int oi = RPI * it + sub;
             const uint64_t a = __shfl(myoff, oi), b = __shfl(myoff, oi + 1);
             if (act) { o0 = a; L = (int64_t)(b - a); }
         }
@@ -518,16 +527,19 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
         bool defer = false;
         if (act) {
             npos = (int32_t)(L - k + 1 > 0x7fffffff ? 0x7fffffff : L - k + 1);
-            if (npos > 16 * w || L > 256) defer = true;
+            if (npos > (PAIR ? 2 * 16 * w - (w - 1) : 16 * w) || L > (PAIR ? 512 : 256)) defer = true;
         }
+        // this group's part of the read: bases from posoff on, k-mer positions posoff .. posoff + 16w - 1
+        const int64_t Lg = L - posoff;
+        const int32_t nposg = npos - posoff < 0 ? 0 : (npos - posoff > 16 * w ? 16 * w : npos - posoff);
         if (dbg & 64u) { sink += (uint32_t)o0 + (uint32_t)npos + hslot; continue; }   // ablation: per-iteration bookkeeping only
         // ---- stage 16 bases per lane: ASCII -> 2-bit pack (one dword per lane), detect code 4
         bool sawN = false;
         if (act && !defer) {
             const int64_t p = 16 * gl;
             uint32_t pack = 0;
-            if (p < L) {
-                const uintptr_t addr = (uintptr_t)(bases + o0 + (uint64_t)p);
+            if (p < Lg) {
+                const uintptr_t addr = (uintptr_t)(bases + o0 + (uint64_t)posoff + (uint64_t)p);
                 const uintptr_t al = addr & ~(uintptr_t)3, end = (uintptr_t)bases + P.bases_bytes;
                 const unsigned sh = (unsigned)(addr & 3) * 8;
                 uint32_t d[5];
@@ -539,7 +551,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
 #pragma unroll
                     for (int x = 0; x < 5; x++) d[x] = (al + 4 * (x + 1) <= end) ? *(const uint32_t *)(al + 4 * x) : 0u;
                 }
-                const int nv = L - p < 16 ? (int)(L - p) : 16;
+                const int nv = Lg - p < 16 ? (int)(Lg - p) : 16;
                 uint32_t nflags = 0;
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
@@ -556,15 +568,17 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             if (gl < 4) pk32[16 + gl] = 0;                     // slack for 3-dword window reads
         }
         {
-            const uint32_t gN = (uint32_t)(__ballot(sawN) >> gsh) & 0xffffu;
+            // code 4 anywhere in the read defers it as a whole (both groups of a pair must agree)
+            const uint32_t gN = PAIR ? (uint32_t)(__ballot(sawN) >> (lane & 32)) : (uint32_t)(__ballot(sawN) >> gsh) & 0xffffu;
             if (gN) defer = true;
         }
         wave_sync();
         if (dbg & 32u) { sink += pk32[gl]; wave_sync(); continue; }      // ablation: staging only
 
         // ---- phase A: rolling k-mers over the own block (registers)
-        const int32_t p0 = gl * w;
-        const bool mine = act && !defer && p0 < npos;
+        const int32_t p0 = gl * w;                              // first position of the lane's block, within the group
+        const int32_t ap0 = posoff + p0;                        // ... within the read
+        const bool mine = act && !defer && p0 < nposg;
         uint32_t validbits = 0;
         uint64_t X[WM];
 #pragma unroll
@@ -586,7 +600,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                 const uint64_t lo = (uint64_t)pk32[d] | ((uint64_t)pk32[d + 1] << 32);
                 nb = (uint32_t)(lo >> o);
             }
-            const int32_t span0 = p0 + k - 1 - w + 2;
+            const int32_t span0 = ap0 + k - 1 - w + 2;
 #pragma unroll
             for (int t = 0; t < WM; t++) {
                 if (t) {
@@ -594,7 +608,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     f = (f << 2 | c) & mask;
                     r = (r >> 2) | ((3ull ^ c) << shift);
                 }
-                if (t < w && p0 + t < npos && f != r) {
+                if (t < w && p0 + t < nposg && f != r) {
                     const uint64_t canon = umin64<FM>(f, r);
                     int32_t span = span0 + t;
                     if (span >= k) span = k;
@@ -629,7 +643,8 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             hp[WM - 1] = XN;
             const uint32_t pv = dpp_row_shr1(validbits);
             bool pe = false; uint64_t pm = 0;
-            if (gl > 0) { pe = ((pv >> (w - 1)) & 1u) && (p0 - 1 + k - 1 >= w - 1); pm = whole; }
+            // (the second group of a pair reports nothing for its first w-1 positions: the first group has them)
+            if (gl > 0) { pe = ((pv >> (w - 1)) & 1u) && (ap0 - 1 + k - 1 >= w - 1) && !(half && p0 - 1 < w - 1); pm = whole; }
             uint64_t g = XN;
 #pragma unroll
             for (int t = 0; t < WM; t++) {
@@ -637,7 +652,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                 g = umin64<FM>(x, g);
                 const uint64_t hpt = (gl > 0 && t + 1 < w) ? hp[t] : XN;
                 const uint64_t m = umin64<FM>(hpt, g);
-                const bool emit = ((validbits >> t) & 1u) && (p0 + t + k - 1 >= w - 1);
+                const bool emit = ((validbits >> t) & 1u) && (ap0 + t + k - 1 >= w - 1) && !(half && p0 + t < w - 1);
                 if (emit && !(pe && pm == m)) startbits |= 1u << t;
                 X[t] = m;
                 if (t < w) { pe = emit; pm = m; }
@@ -653,7 +668,9 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);
             total = (uint32_t)__shfl((int)incl, (lane & 48) | 15);
-            if (total > (uint32_t)FAST_CAND) { defer = true; total = 0; }    // very repetitive read: generic kernel
+            bool ovf = total > (uint32_t)FAST_CAND;                         // very repetitive read: generic kernel
+            if (PAIR) ovf = ((uint32_t)(__ballot(ovf) >> (lane & 32))) != 0u;  // ... for both halves of it
+            if (ovf) { defer = true; total = 0; }
             else {
                 uint32_t at = incl - cnt;
 #pragma unroll
@@ -662,7 +679,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             }
         }
         if (act && defer) {
-            if (gl == 0) { const uint32_t at = atomicAdd(slow_count, 1u); slow_list[at] = (uint32_t)rd; }
+            if (gl == 0 && half == 0) { const uint32_t at = atomicAdd(slow_count, 1u); slow_list[at] = (uint32_t)rd; }
             act = false;
         }
         wave_sync();
@@ -2362,8 +2379,8 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
     return hipGetLastError();
 }
 
-size_t minimizer_fast_lds(uint32_t) {
-    return 2048 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)FAST_RAW + 16 * (size_t)FAST_CAND * 8;
+size_t minimizer_fast_lds(uint32_t, bool pair) {
+    return 2048 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)(pair ? FAST_RAW_PAIR : FAST_RAW) + 16 * (size_t)FAST_CAND * 8;
 }
 
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
@@ -2371,15 +2388,18 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
                                  DevState *d_state, unsigned long long *d_min_slots, uint32_t *d_slow_list,
                                  uint32_t *d_slow_count) {
     if (n_reads == 0) return hipSuccess;
-    const size_t lds = minimizer_fast_lds(P.w);
+    const bool pair = P.pair != 0;
+    const size_t lds = minimizer_fast_lds(P.w, pair);
     const uint64_t blocks = (n_reads + 4 * FAST_READS_PER_WAVE - 1) / (4 * FAST_READS_PER_WAVE);
     const dim3 g((unsigned)blocks), b(256);
     // k <= 27: 64-bit minima through v_min_f64 (see umin64); HULK_NO_FMIN keeps the integer compares (A/B aid)
     static const bool no_fmin = getenv("HULK_NO_FMIN") != nullptr;
     const bool fm = P.k <= 27 && !no_fmin;
+#define HULK_LAUNCH_FAST3(WM, FMv, DBGv, WEQv, KCv, PAIRv)                                                           \
+    hipLaunchKernelGGL((k_minimizer_fast<WM, FMv, DBGv, WEQv, KCv, PAIRv>), g, b, lds, s, d_bases, d_offsets, n_reads, \
+                       P, ml, d_state, d_min_slots, d_slow_list, d_slow_count)
 #define HULK_LAUNCH_FAST2(WM, FMv, DBGv, WEQv, KCv)                                                                  \
-    hipLaunchKernelGGL((k_minimizer_fast<WM, FMv, DBGv, WEQv, KCv>), g, b, lds, s, d_bases, d_offsets, n_reads, P,   \
-                       ml, d_state, d_min_slots, d_slow_list, d_slow_count)
+    do { if (pair) HULK_LAUNCH_FAST3(WM, FMv, DBGv, WEQv, KCv, true); else HULK_LAUNCH_FAST3(WM, FMv, DBGv, WEQv, KCv, false); } while (0)
 #define HULK_LAUNCH_FAST(WM)                                                                                         \
     do {                                                                                                             \
         const bool weq = P.w == WM;                                                                                  \
@@ -2394,6 +2414,7 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
     if (P.w <= 4) HULK_LAUNCH_FAST(4);
     else if (P.w <= 9) HULK_LAUNCH_FAST(9);
     else HULK_LAUNCH_FAST(16);
+#undef HULK_LAUNCH_FAST3
 #undef HULK_LAUNCH_FAST2
 #undef HULK_LAUNCH_FAST
     return hipGetLastError();

@@ -441,3 +441,30 @@ def test_nibble_histogram_overflow_falls_back_to_exact_count():
     assert np.array_equal(g.cms(), o.cms())
     assert_same_sketch(o, g)
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("k,w,lens,n", [
+    (21, 9, (250, 250), 4000),        # MiSeq 2x250: two 16-lane groups per read
+    (21, 9, (300, 300), 4000),        # exactly the capacity: 280 positions
+    (21, 9, (29, 300), 5000),         # everything from the minimum length up, in one launch
+    (21, 9, (290, 330), 3000),        # some fit the pair (<= 300), the others go to the one-wave kernel
+    (15, 5, (100, 169), 4000),        # w = 5: 80 / 156 positions
+    (27, 16, (260, 300), 3000),       # 16w + k - 1 > 256: the pair mode must not be used
+    (9, 4, (64, 135), 3000),
+])
+def test_two_groups_per_read(k, w, lens, n):
+    """Reads beyond one group's 16w positions take two neighbouring groups (k_minimizer_fast<..., PAIR>): the
+    second one re-derives w-1 positions of context, reports none of them, and shares the read's set."""
+    rng = np.random.default_rng(k * 1000 + w)
+    seqs = random_reads(rng, n, lens)
+    for i in range(0, n, 97):                                  # a few N reads and repeats (deferred / deduplicated)
+        s = bytearray(seqs[i]); s[len(s) // 2] = ord("N"); seqs[i] = bytes(s)
+    for i in range(5, n, 101):
+        s = seqs[i]; seqs[i] = (s[:60] * 6)[:len(s)]
+    o, g = run_both(seqs, k, w, 8, interval=1500, batches=2)
+    o.finish(); g.finish()
+    oc, gc = o.counters(), g.counters()
+    assert all(oc[key] == gc[key] for key in ("n_reads", "n_minimizers", "total_len"))
+    assert np.array_equal(g.cms(), o.cms())
+    assert_same_sketch(o, g)
+    g.close(); o.close()
