@@ -216,3 +216,28 @@ def test_fuzz_slice():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ingest.py"), "120", "5"],
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+def test_default_blocks_parallel_reads(tmp_path):
+    """Default 32 MB blocks: a plain file is pread() in pieces side by side (ByteSource::read_pieces); two inputs,
+    the first without a final newline and neither a multiple of the piece size — the reads must come out in
+    order and complete."""
+    rng = np.random.default_rng(11)
+    paths, want = [], []
+    for f, n in enumerate((190_000, 70_001)):
+        lens = rng.integers(30, 251, n)
+        tot = int(lens.sum())
+        flat = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, tot)]
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        chunks = []
+        for i in range(n):
+            s = flat[offs[i]:offs[i + 1]].tobytes()
+            want.append(s)
+            chunks.append(b"@%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
+        data = b"".join(chunks)
+        if f == 0:
+            data = data[:-1]
+        assert len(data) > (32 << 20) or f == 1
+        paths.append(write(tmp_path, "big%d.fq" % f, data))
+    got = native(paths)
+    assert len(got) == len(want) and got == want
