@@ -499,7 +499,8 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
         uint32_t *slow_cnt = c->d_slow_count + c->slow_parity, *slow_cnt_next = c->d_slow_count + (c->slow_parity ^ 1u);
         c->slow_parity ^= 1u;
         const uint64_t regions = (n + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE;
-        const uint64_t rcap = minimizer_list_rcap(c->p.w);
+        // (a region never shrinks again: calls with and without reads of two groups may alternate)
+        const uint64_t rcap = std::max<uint64_t>(minimizer_list_rcap(c->p.w, pair_ok), c->ml.rcap);
         if (regions > c->ml_regions || c->ml.rcap != rcap) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum);

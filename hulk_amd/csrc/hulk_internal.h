@@ -91,7 +91,7 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
                                  uint32_t *d_slow_count);
 hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
                                  uint32_t *d_hists, uint32_t *d_zero_word);
-uint32_t minimizer_list_rcap(uint32_t w);
+uint32_t minimizer_list_rcap(uint32_t w, bool pair);
 hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSeqDesc *d_desc, uint32_t n_seqs,
                              uint64_t max_npos, MinimizerParams P, uint64_t *d_xs, uint8_t *d_valid, uint64_t *d_table,
                              uint64_t table_total, uint32_t *d_hists, unsigned long long *d_min_slots);

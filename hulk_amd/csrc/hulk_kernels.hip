@@ -438,6 +438,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     const uint64_t shift = (uint64_t)(2 * (k - 1));
     constexpr int RAWB = PAIR ? FAST_RAW_PAIR : FAST_RAW;          // raw ASCII of the wave's 16 reads (bytes per wave)
     constexpr int RPI = PAIR ? 2 : 4;                              // reads per iteration of a wave
+    constexpr bool DX = KC != 0 && WEQ && 2 * (KC + WM - 1) <= 64;     // direct k-mer extraction (phase A)
     const int half = PAIR ? (grp & 1) : 0;                         // which half of the read this group takes
     const int sub = PAIR ? ((grp & 3) >> 1) : (grp & 3);           // read of the iteration
     const int32_t posoff = half ? 16 * w - (w - 1) : 0;            // first k-mer position of this group
@@ -584,36 +585,61 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
 #pragma unroll
         for (int t = 0; t < WM; t++) X[t] = XN;
         if (mine) {
-            uint64_t f, r;
-            {
+            // Positions past the read's end are always the END of a lane's block and of the read: their values only
+            // reach windows that are not reported (validbits gates every report), so they are computed like any
+            // other instead of being replaced by "no value" one by one.
+            validbits = (1u << (nposg - p0 < w ? nposg - p0 : w)) - 1u;
+            const int32_t span0 = ap0 + k - 1 - w + 2;
+            uint64_t f = 0, r = 0;
+            uint32_t nb = 0;                                    // next <=15 bases, 2 bits each
+            uint64_t Bb = 0, Cl = 0;
+            if (DX) {
+                // the block's w+k-1 bases fit one 64-bit window: every k-mer of the block is a shift + mask of the
+                // window in the forward (first base on top: Bb) or the complemented (first base at the bottom: Cl)
+                // layout, instead of the rolling update per base
+                constexpr int NBW = KC + WM - 1;
                 const uint32_t bo = 2u * (uint32_t)p0, d = bo >> 5, o = bo & 31u;
                 const uint64_t lo = (uint64_t)pk32[d] | ((uint64_t)pk32[d + 1] << 32);
-                uint64_t W = o ? (lo >> o) | ((uint64_t)pk32[d + 2] << (64 - o)) : lo;
-                W &= mask;
-                const uint64_t rev = __brevll(W) >> (64 - 2 * k);
-                f = ((rev >> 1) & 0x5555555555555555ull) | ((rev & 0x5555555555555555ull) << 1);
-                r = (~W) & mask;
+                uint64_t Wl = o ? (lo >> o) | ((uint64_t)pk32[d + 2] << (64 - o)) : lo;
+                if (NBW < 32) Wl &= (1ull << (2 * NBW)) - 1;
+                const uint64_t rv = __brevll(Wl) >> (64 - 2 * NBW);
+                Bb = ((rv >> 1) & 0x5555555555555555ull) | ((rv & 0x5555555555555555ull) << 1);
+                Cl = ~Wl;
+            } else {
+                {
+                    const uint32_t bo = 2u * (uint32_t)p0, d = bo >> 5, o = bo & 31u;
+                    const uint64_t lo = (uint64_t)pk32[d] | ((uint64_t)pk32[d + 1] << 32);
+                    uint64_t W = o ? (lo >> o) | ((uint64_t)pk32[d + 2] << (64 - o)) : lo;
+                    W &= mask;
+                    const uint64_t rev = __brevll(W) >> (64 - 2 * k);
+                    f = ((rev >> 1) & 0x5555555555555555ull) | ((rev & 0x5555555555555555ull) << 1);
+                    r = (~W) & mask;
+                }
+                {
+                    const uint32_t bo = 2u * (uint32_t)(p0 + k), d = bo >> 5, o = bo & 31u;
+                    const uint64_t lo = (uint64_t)pk32[d] | ((uint64_t)pk32[d + 1] << 32);
+                    nb = (uint32_t)(lo >> o);
+                }
             }
-            uint32_t nb;                                        // next <=15 bases, 2 bits each
-            {
-                const uint32_t bo = 2u * (uint32_t)(p0 + k), d = bo >> 5, o = bo & 31u;
-                const uint64_t lo = (uint64_t)pk32[d] | ((uint64_t)pk32[d + 1] << 32);
-                nb = (uint32_t)(lo >> o);
-            }
-            const int32_t span0 = ap0 + k - 1 - w + 2;
 #pragma unroll
             for (int t = 0; t < WM; t++) {
-                if (t) {
+                if (DX) {
+                    f = (Bb >> (2 * (WM - 1 - t))) & mask;
+                    r = (Cl >> (2 * t)) & mask;
+                } else if (t) {
                     const uint64_t c = nb & 3u; nb >>= 2;
                     f = (f << 2 | c) & mask;
                     r = (r >> 2) | ((3ull ^ c) << shift);
                 }
-                if (t < w && p0 + t < nposg && f != r) {
+                if (t < w) {
                     const uint64_t canon = umin64<FM>(f, r);
                     int32_t span = span0 + t;
                     if (span >= k) span = k;
-                    X[t] = ((dbg & 16u) ? canon * 0x9E3779B97F4A7C15ull : hash64_fm<FM>(canon, mask)) << 8 | (uint64_t)(int64_t)span;
-                    validbits |= 1u << t;
+                    uint64_t x = ((dbg & 16u) ? canon * 0x9E3779B97F4A7C15ull : hash64_fm<FM>(canon, mask)) << 8 | (uint64_t)(int64_t)span;
+                    // f == r (a k-mer that is its own reverse complement: even k only, reads with N never get
+                    // here) is skipped by the reference: the position neither reports nor takes part in a window
+                    if (!(k & 1) && f == r) { x = XN; validbits &= ~(1u << t); }
+                    X[t] = x;
                 }
             }
         }
@@ -2494,7 +2520,8 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     return hipGetLastError();
 }
 
-uint32_t minimizer_list_rcap(uint32_t w) { return FAST_READS_PER_WAVE * 16u * w; }
+// a region holds at most one value per k-mer position of the wave's 16 reads
+uint32_t minimizer_list_rcap(uint32_t w, bool pair) { return FAST_READS_PER_WAVE * (pair ? 2u * 16u * w - (w - 1u) : 16u * w); }
 
 hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSeqDesc *d_desc, uint32_t n_seqs,
                              uint64_t max_npos, MinimizerParams P, uint64_t *d_xs, uint8_t *d_valid, uint64_t *d_table,

@@ -451,6 +451,9 @@ def test_nibble_histogram_overflow_falls_back_to_exact_count():
     (15, 5, (100, 169), 4000),        # w = 5: 80 / 156 positions
     (27, 16, (260, 300), 3000),       # 16w + k - 1 > 256: the pair mode must not be used
     (9, 4, (64, 135), 3000),
+    (7, 3, (100, 100), 3000),         # dense: ~51 distinct minimizers per read, more than one group's 16w positions
+    (5, 1, (21, 36), 3000),           # w = 1: every position is a minimizer
+    (6, 2, (40, 66), 3000),           # even k: self-complementary k-mers are skipped
 ])
 def test_two_groups_per_read(k, w, lens, n):
     """Reads beyond one group's 16w positions take two neighbouring groups (k_minimizer_fast<..., PAIR>): the
