@@ -374,24 +374,68 @@ __device__ __forceinline__ uint64_t dpp_row_shr1_u64(uint64_t v) {
 // hash64 for 2k <= 54 (FM kernels): the upper dword then has at most 22 bits, so the two multiply steps
 // (x265, x21) take v_mad_u64_u32 for the low dword and ONE full-rate v_mad_u32_u24 for the upper one,
 // instead of two v_mad_u64_u32 with a v_mov between them.  Same value as hash64 (mod 2^2k).
+// 32 x 32 -> 64 multiply as ONE v_mad_u64_u32.  In C++ hipcc folds the upper-dword addend into the mad, feeds it
+// through a v_mov, and then recomputes the product's low dword with a second v_mul_lo_u32 for the next xor.
+__device__ __forceinline__ uint64_t mul_u32_u64(uint32_t a, uint32_t b) {
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
 template <bool FM> __device__ __forceinline__ uint64_t hash64_fm(uint64_t key, uint64_t mask) {
     if (!FM) return hash64(key, mask);
     key = (~key + (key << 21)) & mask;
     key = key ^ key >> 24;
     {
-        const uint64_t p = (uint64_t)(uint32_t)key * 265u;
-        const uint32_t hi = (uint32_t)(p >> 32) + __umul24((uint32_t)(key >> 32), 265u);
+        const uint64_t p = mul_u32_u64((uint32_t)key, 265u);
+        const uint32_t hi = mad_u24((uint32_t)(key >> 32), 265u, (uint32_t)(p >> 32));
         key = (((uint64_t)hi << 32) | (uint32_t)p) & mask;
     }
     key = key ^ key >> 14;
     {
-        const uint64_t p = (uint64_t)(uint32_t)key * 21u;
-        const uint32_t hi = (uint32_t)(p >> 32) + __umul24((uint32_t)(key >> 32), 21u);
+        const uint64_t p = mul_u32_u64((uint32_t)key, 21u);
+        const uint32_t hi = mad_u24((uint32_t)(key >> 32), 21u, (uint32_t)(p >> 32));
         key = (((uint64_t)hi << 32) | (uint32_t)p) & mask;
     }
     key = key ^ key >> 28;
     key = (key + (key << 31)) & mask;
     return key;
+}
+
+// hash64 of a 2KC-bit k-mer (17 <= KC <= 27: the upper dword has 2KC-32 <= 22 bits) and the packing
+// X = hash << 8 | span, in explicit dword form: every "key +- key << n" step of the hash is a multiplication by a
+// constant mod 2^2KC (x(2^21-1) - 1, x265, x21, x(2^31+1)) = ONE v_mad_u64_u32 on the low dword + one
+// v_mad_u32_u24 / v_add on the upper one + its mask; every xor-shift is one v_alignbit + v_xor on the low dword
+// (the upper dword shifted by 24 or 28 is zero).  20 instructions, 4 of them multiplies; hipcc's rendering of
+// hash64() + the packing had 30 with 6 multiplies.
+__device__ __forceinline__ uint64_t mad_u32_u64_m1(uint32_t a, uint32_t b) {
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, -1" : "=v"(d), "=s"(carry) : "v"(a), "s"(b));
+    return d;
+}
+template <int KC> __device__ __forceinline__ uint64_t hash64_pack_kc(uint64_t key, uint32_t span) {
+    static_assert(KC >= 17 && KC <= 27, "upper dword of the k-mer must have 2..22 bits");
+    constexpr uint32_t HM = (1u << (2 * KC - 32)) - 1u;
+    uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    uint64_t p;
+    p = mad_u32_u64_m1(lo, 0x1FFFFFu);                             // ~key + (key << 21) = key * (2^21 - 1) - 1
+    hi = mad_u24(hi, 0x1FFFFFu, (uint32_t)(p >> 32)) & HM; lo = (uint32_t)p;
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 24);                   // key ^= key >> 24
+    p = mul_u32_u64(lo, 265u);                                     // key + (key << 3) + (key << 8)
+    hi = mad_u24(hi, 265u, (uint32_t)(p >> 32)) & HM; lo = (uint32_t)p;
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 14);                   // key ^= key >> 14
+    if (2 * KC - 32 > 14) hi ^= hi >> 14;
+    p = mul_u32_u64(lo, 21u);                                      // key + (key << 2) + (key << 4)
+    hi = mad_u24(hi, 21u, (uint32_t)(p >> 32)) & HM; lo = (uint32_t)p;
+    lo ^= __builtin_amdgcn_alignbit(hi, lo, 28);                   // key ^= key >> 28
+    p = mul_u32_u64(lo, 0x80000001u);                              // key + (key << 31)
+    hi = ((uint32_t)(p >> 32) + hi) & HM; lo = (uint32_t)p;
+    const uint32_t xh = __builtin_amdgcn_alignbit(hi, lo, 24), xl = (lo << 8) | span;   // << 8 | span
+    return ((uint64_t)xh << 32) | xl;
 }
 
 // 64-bit unsigned minimum.  For k <= 27 every minimizer value (hash64 << 8 | span < 2^62) and every
@@ -439,6 +483,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     constexpr int RAWB = PAIR ? FAST_RAW_PAIR : FAST_RAW;          // raw ASCII of the wave's 16 reads (bytes per wave)
     constexpr int RPI = PAIR ? 2 : 4;                              // reads per iteration of a wave
     constexpr bool DX = KC != 0 && WEQ && 2 * (KC + WM - 1) <= 64;     // direct k-mer extraction (phase A)
+    constexpr bool HP = FM && WEQ && KC >= 17 && KC <= 27;                    // hash + packing in explicit dword form
     const int half = PAIR ? (grp & 1) : 0;                         // which half of the read this group takes
     const int sub = PAIR ? ((grp & 3) >> 1) : (grp & 3);           // read of the iteration
     const int32_t posoff = half ? 16 * w - (w - 1) : 0;            // first k-mer position of this group
@@ -624,8 +669,16 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
 #pragma unroll
             for (int t = 0; t < WM; t++) {
                 if (DX) {
-                    f = (Bb >> (2 * (WM - 1 - t))) & mask;
-                    r = (Cl >> (2 * t)) & mask;
+                    // dword form (v_alignbit + v_bfe) of f = (Bb >> 2(WM-1-t)) & mask, r = (Cl >> 2t) & mask
+                    constexpr int HB = 2 * KC - 32;
+                    const int sf = 2 * (WM - 1 - t), sr = 2 * t;
+                    const uint32_t bl = (uint32_t)Bb, cl = (uint32_t)Cl;
+                    uint32_t bh = (uint32_t)(Bb >> 32), ch = (uint32_t)(Cl >> 32);
+                    asm("" : "+v"(bh), "+v"(ch));   // opaque: or hipcc re-fuses the dwords into 64-bit shifts + masks
+                    const uint32_t fl = sf ? __builtin_amdgcn_alignbit(bh, bl, sf) : bl, fh = __builtin_amdgcn_ubfe(bh, sf, HB);
+                    const uint32_t rl = sr ? __builtin_amdgcn_alignbit(ch, cl, sr) : cl, rh = __builtin_amdgcn_ubfe(ch, sr, HB);
+                    f = ((uint64_t)fh << 32) | fl;
+                    r = ((uint64_t)rh << 32) | rl;
                 } else if (t) {
                     const uint64_t c = nb & 3u; nb >>= 2;
                     f = (f << 2 | c) & mask;
@@ -635,7 +688,9 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     const uint64_t canon = umin64<FM>(f, r);
                     int32_t span = span0 + t;
                     if (span >= k) span = k;
-                    uint64_t x = ((dbg & 16u) ? canon * 0x9E3779B97F4A7C15ull : hash64_fm<FM>(canon, mask)) << 8 | (uint64_t)(int64_t)span;
+                    uint64_t x;
+                    if (HP && !(dbg & 16u)) x = hash64_pack_kc<HP ? KC : 21>(canon, (uint32_t)span);
+                    else x = ((dbg & 16u) ? canon * 0x9E3779B97F4A7C15ull : hash64_fm<FM>(canon, mask)) << 8 | (uint64_t)(int64_t)span;
                     // f == r (a k-mer that is its own reverse complement: even k only, reads with N never get
                     // here) is skipped by the reference: the position neither reports nor takes part in a window
                     if (!(k & 1) && f == r) { x = XN; validbits &= ~(1u << t); }
