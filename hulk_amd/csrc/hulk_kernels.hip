@@ -464,13 +464,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                                                         uint32_t *__restrict__ slow_list,
                                                         uint32_t *__restrict__ slow_count) {
     extern __shared__ __align__(16) unsigned char smem[];
-    // positional nt4 tables: lut16[t][byte] = (code & 3) << 2t | (code > 3) << (8 + t), so the four
-    // lookups of a dword OR straight into an 8-bit pack plus 4 "is code 4" flags
-    uint16_t *lut16 = (uint16_t *)smem;
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
-        const unsigned c = nt4_of((unsigned)(i & 255)), t = (unsigned)i >> 8;
-        lut16[i] = (uint16_t)(((c & 3u) << (2 * t)) | ((c > 3 ? 1u : 0u) << (8 + t)));
-    }
+    // (the first 2 KB of LDS held ASCII -> 2-bit tables once; the layout behind them is unchanged)
 
     constexpr uint64_t XN = FM ? 0x7FF0000000000000ull : X_NONE;   // "no value": above every minimizer value
     const int lane = lane_id(), wid = threadIdx.x >> 6;
@@ -597,18 +591,36 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
 #pragma unroll
                     for (int x = 0; x < 5; x++) d[x] = (al + 4 * (x + 1) <= end) ? *(const uint32_t *)(al + 4 * x) : 0u;
                 }
-                const int nv = Lg - p < 16 ? (int)(Lg - p) : 16;
-                uint32_t nflags = 0;
+                // ASCII -> 2-bit, four bases per dword, no table: fold the case, code = (c >> 1 ^ c >> 2) & 3
+                // (A 0, C 1, G 2, T 3), and prove it by mapping the codes back to letters with one v_perm_b32:
+                // any byte that does not come back (N, U, 0..3, anything else) defers the read to the generic
+                // kernel, which has the full nt4 table.  (c * 0x01041040) >> 24 gathers the four codes of a dword
+                // into one byte.  Bytes past the read's end are the next read's (or zero): they only reach k-mer
+                // positions that are not reported, and at worst defer a read that did not need it.
+                uint32_t bad = 0;
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
                     const uint32_t by = sh ? (d[x] >> sh) | (d[x + 1] << (32 - sh)) : d[x];
-                    const uint32_t v = (uint32_t)lut16[by & 0xff] | (uint32_t)lut16[256 + ((by >> 8) & 0xff)] |
-                                       (uint32_t)lut16[512 + ((by >> 16) & 0xff)] | (uint32_t)lut16[768 + (by >> 24)];
-                    pack |= (v & 0xffu) << (8 * x);
-                    nflags |= (v >> 8) << (4 * x);
+                    const uint32_t up = by & 0xDFDFDFDFu;
+                    const uint32_t e = up >> 1;
+                    const uint32_t c = (e ^ (e >> 1)) & 0x03030303u;
+                    bad |= __builtin_amdgcn_perm(0u, 0x54474341u, c) ^ up;
+                    pack |= ((c * 0x01041040u) >> 24) << (8 * x);
                 }
-                if (nv < 16) { pack &= (1u << (2 * nv)) - 1u; nflags &= (1u << nv) - 1u; }   // bytes past the read's end
-                sawN = nflags != 0;
+                if (Lg - p < 16 && rd + 1 == n_reads) {
+                    // the last read of the call: what follows it is not a read; test its own bytes only
+                    const int nv = (int)(Lg - p);
+                    bad = 0;
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const uint32_t by = sh ? (d[x] >> sh) | (d[x + 1] << (32 - sh)) : d[x];
+                        const uint32_t up = by & 0xDFDFDFDFu, e = up >> 1, c = (e ^ (e >> 1)) & 0x03030303u;
+                        const int nb = nv - 4 * x;
+                        const uint32_t m = nb >= 4 ? ~0u : nb <= 0 ? 0u : (1u << (8 * nb)) - 1u;
+                        bad |= (__builtin_amdgcn_perm(0u, 0x54474341u, c) ^ up) & m;
+                    }
+                }
+                sawN = bad != 0;
             }
             pk32[gl] = pack;
             if (gl < 4) pk32[16 + gl] = 0;                     // slack for 3-dword window reads
