@@ -544,50 +544,60 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
         while (slot0 >= P.ring_n) slot0 -= P.ring_n;
     }
 
+    const bool crosses = P.interval && rem0 + FAST_READS_PER_WAVE > P.interval;
+    // Per-read bookkeeping in 32 bits: offsets relative to the wave's first base.  (A wave whose 16 reads span
+    // 2 GB or more hands all of them to the generic kernel, which works on the 64-bit offsets.)
+    const bool wide = nrd && (span_hi - span_lo) >= 0x7fffffffull;
+    const uint32_t myrel = (uint32_t)(myoff - span_lo);
+    const uint32_t delta = (uint32_t)(((uintptr_t)bases + span_lo) - raw_a0);      // 0..15: first base within the staged bytes
+    const bool lastwave = wave_first + nrd == n_reads;
     for (int it = 0; it < FAST_READS_PER_WAVE / RPI; it++) {
-        const uint64_t base = wave_first + (uint32_t)RPI * (uint32_t)it;
-        if (base >= n_reads) break;
-        const uint64_t rd = base + (uint64_t)sub;
-        bool act = rd < n_reads;                               // group-uniform
+        if ((uint32_t)(RPI * it) >= nrd) break;
+        const uint32_t idx = (uint32_t)(RPI * it + sub);       // read of the wave
+        bool act = idx < nrd;                                  // group-uniform
         uint32_t hslot = slot0;
-        if (P.interval) {
-            uint64_t x = rem0 + (uint64_t)(RPI * it + sub);
+        if (crosses) {                                          // wave-uniform: an interval ends inside the wave's reads
+            uint64_t x = rem0 + (uint64_t)idx;
             while (x >= P.interval) { x -= P.interval; hslot = hslot + 1 == P.ring_n ? 0u : hslot + 1; }
         }
-        uint64_t o0 = 0; int64_t L = 0; int32_t npos = 0;
+        uint32_t a32 = 0; int32_t L = 0, npos = 0;
         {
-            const int oi = RPI * it + sub;
-            const uint64_t a = __shfl(myoff, oi), b = __shfl(myoff, oi + 1);
-            if (act) { o0 = a; L = (int64_t)(b - a); }
-        }
-        if (act) {
-            if (L < 1) { if (gl == 0) set_error(st, -3); act = false; }
-            else if (L < (int64_t)(w + k - 1)) { if (gl == 0) set_error(st, -4); act = false; }
+            const uint32_t a = (uint32_t)__shfl((int)myrel, (int)idx), b = (uint32_t)__shfl((int)myrel, (int)idx + 1);
+            if (act) { a32 = a; L = (int32_t)(b - a); }
         }
         bool defer = false;
         if (act) {
-            npos = (int32_t)(L - k + 1 > 0x7fffffff ? 0x7fffffff : L - k + 1);
-            if (npos > (PAIR ? 2 * 16 * w - (w - 1) : 16 * w) || L > (PAIR ? 512 : 256)) defer = true;
+            if (wide) defer = true;
+            else if (L < 1) { if (gl == 0) set_error(st, -3); act = false; }
+            else if (L < w + k - 1) { if (gl == 0) set_error(st, -4); act = false; }
+            else {
+                npos = L - k + 1;
+                if (npos > (PAIR ? 2 * 16 * w - (w - 1) : 16 * w) || L > (PAIR ? 512 : 256)) defer = true;
+            }
         }
         // this group's part of the read: bases from posoff on, k-mer positions posoff .. posoff + 16w - 1
-        const int64_t Lg = L - posoff;
+        const int32_t Lg = L - posoff;
         const int32_t nposg = npos - posoff < 0 ? 0 : (npos - posoff > 16 * w ? 16 * w : npos - posoff);
-        if (dbg & 64u) { sink += (uint32_t)o0 + (uint32_t)npos + hslot; continue; }   // ablation: per-iteration bookkeeping only
+        if (dbg & 64u) { sink += a32 + (uint32_t)npos + hslot; continue; }   // ablation: per-iteration bookkeeping only
         // ---- stage 16 bases per lane: ASCII -> 2-bit pack (one dword per lane), detect code 4
         bool sawN = false;
         if (act && !defer) {
-            const int64_t p = 16 * gl;
+            const int32_t p = 16 * gl;
             uint32_t pack = 0;
             if (p < Lg) {
-                const uintptr_t addr = (uintptr_t)(bases + o0 + (uint64_t)posoff + (uint64_t)p);
-                const uintptr_t al = addr & ~(uintptr_t)3, end = (uintptr_t)bases + P.bases_bytes;
-                const unsigned sh = (unsigned)(addr & 3) * 8;
+                const uint32_t ro = a32 + (uint32_t)posoff + (uint32_t)p;     // first of the lane's bytes, from the wave's first base
+                unsigned sh;
                 uint32_t d[5];
                 if (bulk) {
-                    const uint32_t *src = raw32 + ((al - raw_a0) >> 2);
+                    const uint32_t lo = ro + delta;                // raw_a0 is 16-byte aligned
+                    const uint32_t *src = raw32 + (lo >> 2);
+                    sh = (lo & 3u) * 8u;
 #pragma unroll
                     for (int x = 0; x < 5; x++) d[x] = src[x];
                 } else {
+                    const uintptr_t addr = (uintptr_t)bases + span_lo + ro;
+                    const uintptr_t al = addr & ~(uintptr_t)3, end = (uintptr_t)bases + P.bases_bytes;
+                    sh = (unsigned)(addr & 3) * 8;
 #pragma unroll
                     for (int x = 0; x < 5; x++) d[x] = (al + 4 * (x + 1) <= end) ? *(const uint32_t *)(al + 4 * x) : 0u;
                 }
@@ -600,20 +610,20 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                 uint32_t bad = 0;
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
-                    const uint32_t by = sh ? (d[x] >> sh) | (d[x + 1] << (32 - sh)) : d[x];
+                    const uint32_t by = __builtin_amdgcn_alignbit(d[x + 1], d[x], sh);   // (sh = 0: d[x])
                     const uint32_t up = by & 0xDFDFDFDFu;
                     const uint32_t e = up >> 1;
                     const uint32_t c = (e ^ (e >> 1)) & 0x03030303u;
                     bad |= __builtin_amdgcn_perm(0u, 0x54474341u, c) ^ up;
                     pack |= ((c * 0x01041040u) >> 24) << (8 * x);
                 }
-                if (Lg - p < 16 && rd + 1 == n_reads) {
+                if (Lg - p < 16 && lastwave && idx + 1 == nrd) {
                     // the last read of the call: what follows it is not a read; test its own bytes only
                     const int nv = (int)(Lg - p);
                     bad = 0;
 #pragma unroll
                     for (int x = 0; x < 4; x++) {
-                        const uint32_t by = sh ? (d[x] >> sh) | (d[x + 1] << (32 - sh)) : d[x];
+                        const uint32_t by = __builtin_amdgcn_alignbit(d[x + 1], d[x], sh);   // (sh = 0: d[x])
                         const uint32_t up = by & 0xDFDFDFDFu, e = up >> 1, c = (e ^ (e >> 1)) & 0x03030303u;
                         const int nb = nv - 4 * x;
                         const uint32_t m = nb >= 4 ? ~0u : nb <= 0 ? 0u : (1u << (8 * nb)) - 1u;
@@ -772,7 +782,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             }
         }
         if (act && defer) {
-            if (gl == 0 && half == 0) { const uint32_t at = atomicAdd(slow_count, 1u); slow_list[at] = (uint32_t)rd; }
+            if (gl == 0 && half == 0) { const uint32_t at = atomicAdd(slow_count, 1u); slow_list[at] = (uint32_t)(wave_first + idx); }
             act = false;
         }
         wave_sync();
