@@ -741,25 +741,38 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                 }
             }
             const uint64_t whole = dpp_row_shr1_u64(hp[0]);    // min of the whole previous block
+            // lane 0 of a row has no previous block: DPP hands it zeros, which "no value" (+inf, FM) differs from in
+            // the upper dword only — one v_or per value instead of a 64-bit select
+            const uint64_t xnfix = gl == 0 ? XN : 0ull;
 #pragma unroll
-            for (int t = 0; t < WM - 1; t++) hp[t] = dpp_row_shr1_u64(hp[t + 1]);
+            for (int t = 0; t < WM - 1; t++) {
+                const uint64_t v = dpp_row_shr1_u64(hp[t + 1]);
+                hp[t] = FM ? (v | (xnfix & 0xffffffff00000000ull)) : (v | xnfix);
+            }
             hp[WM - 1] = XN;
             const uint32_t pv = dpp_row_shr1(validbits);
-            bool pe = false; uint64_t pm = 0;
-            // (the second group of a pair reports nothing for its first w-1 positions: the first group has them)
-            if (gl > 0) { pe = ((pv >> (w - 1)) & 1u) && (ap0 - 1 + k - 1 >= w - 1) && !(half && p0 - 1 < w - 1); pm = whole; }
-            uint64_t g = XN;
+            // m(pos) for the block, and for each position whether it continues the previous position's value
+            uint32_t eqbits = 0;
+            uint64_t g = XN, pm = whole;
 #pragma unroll
             for (int t = 0; t < WM; t++) {
-                const uint64_t x = X[t];
-                g = umin64<FM>(x, g);
-                const uint64_t hpt = (gl > 0 && t + 1 < w) ? hp[t] : XN;
+                g = umin64<FM>(X[t], g);
+                const uint64_t hpt = (t + 1 < w) ? hp[t] : XN;
                 const uint64_t m = umin64<FM>(hpt, g);
-                const bool emit = ((validbits >> t) & 1u) && (ap0 + t + k - 1 >= w - 1) && !(half && p0 + t < w - 1);
-                if (emit && !(pe && pm == m)) startbits |= 1u << t;
+                if (t < w) { eqbits |= (m == pm) ? (1u << t) : 0u; pm = m; }
                 X[t] = m;
-                if (t < w) { pe = emit; pm = m; }
             }
+            // positions that report: valid, at or past the first window end (i >= w-1: always when k >= w), and not
+            // one of the w-1 context positions of a pair's second group
+            uint32_t emitbits = validbits;
+            {
+                const int32_t t1 = (w - 1) - (k - 1) - ap0;
+                if (t1 > 0) emitbits &= ~((1u << t1) - 1u);
+                if (PAIR && half) { const int32_t t2 = (w - 1) - p0; if (t2 > 0) emitbits &= ~((1u << t2) - 1u); }
+            }
+            const uint32_t pe0 = (gl > 0 && ((pv >> (w - 1)) & 1u) && (ap0 - 1 + k - 1 >= w - 1) && !(half && p0 - 1 < w - 1)) ? 1u : 0u;
+            // a run starts where a reporting position does not repeat the value of a reporting predecessor
+            startbits = emitbits & ~(((emitbits << 1) | pe0) & eqbits);
         }
         // ---- compact the run-start values of the read into the group's candidate list (LDS)
         uint32_t total;
