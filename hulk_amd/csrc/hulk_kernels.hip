@@ -865,6 +865,8 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
 // lanes are still running (cut = 0: when none is): chains take 12.8 +- 3.5 steps, so the last few lanes of a round
 // of 64 would keep the whole wave busy for ~24 — they are handed over instead (`left` = their mask, key/t = their
 // state at a step boundary) and finished by k_jump_left in a denser wave.
+// p >= n is tested on the upper dwords alone: p is a non-negative finite double and n < 2^20 is an integer whose
+// double has a zero lower dword, so bits(p) >= bits(n) <=> hi(p) >= hi(n)  (v_cmp_lt_u32 instead of v_cmp_nge_f64).
 __device__ __forceinline__ double jump_steps_asm(uint32_t &klo, uint32_t &khi, double fn, double t0, uint32_t cut,
                                                  unsigned long long &left) {
     uint32_t tlo, thi, mlo, mhi, olo, ohi;
@@ -886,7 +888,7 @@ __device__ __forceinline__ double jump_steps_asm(uint32_t &klo, uint32_t &khi, d
     "v_fma_f64 v[50:51], -v[46:47], v[48:49], 1.0\n\t"                               \
     "v_fma_f64 v[48:49], v[48:49], v[50:51], v[48:49]\n\t"                           \
     "v_fma_f64 v[52:53], v[44:45], v[48:49], v[48:49]\n\t"                           \
-    "v_cmp_nge_f64 vcc, v[52:53], v[56:57]\n\t"                                      \
+    "v_cmp_lt_u32 vcc, v53, v57\n\t"                                                 \
     "s_and_b64 exec, exec, vcc\n\t"                                                  \
     "v_trunc_f64 v[44:45], v[52:53]\n\t"                                             \
     "s_bcnt1_i32_b64 s62, exec\n\t"                                                  \
