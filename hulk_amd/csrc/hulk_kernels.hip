@@ -513,16 +513,24 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     const uintptr_t raw_end = (uintptr_t)bases + span_hi;
     const bool bulk = nrd && (raw_end - raw_a0) <= (uintptr_t)(RAWB - 64);
     if (bulk) {
+        // all chunks are requested before the first one is waited for: a chunk that is not wanted (past the wave's
+        // reads) or not wholly inside the buffer re-reads the wave's first chunk instead of branching around the load
         const uintptr_t lim = (uintptr_t)bases + P.bases_bytes;
+        constexpr int NCH = PAIR ? 5 : 3;
+        uint4 v[NCH]; bool whole[NCH];
+        const bool first_ok = raw_a0 + 16 <= lim;               // (false only for a buffer of < 16 bytes)
 #pragma unroll
-        for (int x = 0; x < (PAIR ? 5 : 3); x++) {
+        for (int x = 0; x < NCH; x++) {
             const uintptr_t a = raw_a0 + 16u * (uint32_t)(lane + 64 * x);
-            if (a < raw_end + 16 && a + 16 <= lim) {
-                const uint4 v = *(const uint4 *)a;
-                *(uint4 *)(raw32 + 4 * (lane + 64 * x)) = v;
-            } else if (a < raw_end + 16) {
+            whole[x] = a < raw_end + 16 && a + 16 <= lim;
+            v[x] = first_ok ? *(const uint4 *)(whole[x] ? a : raw_a0) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int x = 0; x < NCH; x++) {
+            const uintptr_t a = raw_a0 + 16u * (uint32_t)(lane + 64 * x);
+            if (whole[x]) *(uint4 *)(raw32 + 4 * (lane + 64 * x)) = v[x];
+            else if (a < raw_end + 16)                          // the buffer ends inside this chunk
                 for (int y = 0; y < 4; y++) raw32[4 * (lane + 64 * x) + y] = (a + 4 * y + 4 <= lim) ? *(const uint32_t *)(a + 4 * y) : 0u;
-            }
         }
     }
     wave_sync();
