@@ -1598,6 +1598,20 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
 //                   transparent; same-counter lanes of a 64-bin chunk resolve in lane order
 // (fp64 sums are re-associated w.r.t. the reference's step-by-step scaling: ~1e-13 relative)
 // ------------------------------------------------------------------------------------------
+// w^x for an element gap 0 <= x < 2^21 (a spectrum has < 2^20 elements): three 128-entry tables in LDS
+// (w^a, w^(128 b), w^(16384 c)) and two multiplications instead of an fp64 exp() per counter update — 3 ulp.
+constexpr int POWW_N = 384;
+__device__ __forceinline__ void poww_build(double *tab, double lnw, int tid, int nthreads) {
+    for (int i = tid; i < POWW_N; i += nthreads) {
+        const int lvl = i >> 7, a = i & 127;
+        tab[i] = exp((double)a * (lvl == 0 ? 1.0 : lvl == 1 ? 128.0 : 16384.0) * lnw);
+    }
+}
+__device__ __forceinline__ double poww(const double *tab, long long x, double lnw) {
+    if ((unsigned long long)x >= (1ull << 21)) return exp((double)x * lnw);
+    const uint32_t u = (uint32_t)x;
+    return tab[u & 127u] * tab[128u + ((u >> 7) & 127u)] * tab[256u + (u >> 14)];
+}
 constexpr int CMSD_GROUP = 2;         // chunks staged per barrier (LDS: 112 KB values + 28 KB times + 14 KB stage)
 
 __global__ __launch_bounds__(512) void k_cmsd_segsum(const uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
@@ -1695,27 +1709,49 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
     constexpr int GB = CMSD_GROUP * 64;
     const double lnw = log(omega);
     __shared__ double pw[64];                                     // w^x for the gaps inside one 64-bin chunk
+    __shared__ double pwt[POWW_N];                                // ... and for any gap (poww)
     if (tid < 64) pw[tid] = exp((double)tid * lnw);
+    poww_build(pwt, lnw, tid, (int)blockDim.x);
     __syncthreads();
     const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
     const uint8_t *md = meta8 + (size_t)(d < depth ? d : 0) * B;
+    // the four per-bin inputs of group g+1 are requested before group g is computed: with one workgroup per CU
+    // (LDS) and a barrier per group, their latency was the kernel's time
+    uint32_t nh[CMSD_GROUP], np_[CMSD_GROUP], nm[CMSD_GROUP], nj[CMSD_GROUP];
+    auto fetch = [&](int g) {
+#pragma unroll
+        for (int c = 0; c < CMSD_GROUP; c++) {
+            const int ch = g * CMSD_GROUP + c;
+            const int64_t b = b0 + (int64_t)ch * 64 + lane;
+            nh[c] = 0; np_[c] = 0; nm[c] = 64u | 0x80u; nj[c] = 0;
+            if (d <= depth && ch < seg_chunks && b < (int64_t)B) {
+                nh[c] = hist[b];                                   // (the combiner wave, d == depth, needs only this one)
+                if (d < depth) { np_[c] = pd[b]; nm[c] = md[b]; nj[c] = ei[b]; }
+            }
+        }
+    };
+    fetch(0);
+    uint32_t ch_[CMSD_GROUP] = {}, cp[CMSD_GROUP], cm[CMSD_GROUP], cj[CMSD_GROUP], ph[CMSD_GROUP];
     for (int g = 0; g <= ngroups; g++) {
+#pragma unroll
+        for (int c = 0; c < CMSD_GROUP; c++) { ph[c] = ch_[c]; ch_[c] = nh[c]; cp[c] = np_[c]; cm[c] = nm[c]; cj[c] = nj[c]; }
+        if (g + 1 < ngroups) fetch(g + 1);
         if (d < depth && g < ngroups) {
             double *my = stage + ((size_t)(g & 1) * depth + d) * GB;
             double *rv = lval + (size_t)d * width;
             uint16_t *rtm = ltime + (size_t)d * width;
+#pragma unroll
             for (int c = 0; c < CMSD_GROUP; c++) {
                 const int ch = g * CMSD_GROUP + c;
                 if (ch >= seg_chunks) break;
                 const int64_t b = b0 + (int64_t)ch * 64 + lane;
-                uint32_t h = 0, p = 0, m = 64u | 0x80u; long long j = 0;
-                if (b < (int64_t)B) { h = hist[b]; p = pd[b]; m = md[b]; j = (long long)ei[b]; }
+                const uint32_t h = ch_[c], p = cp[c], m = cm[c]; const long long j = (long long)cj[c];
                 // resolve the lanes in same-counter order: a lane is computed once its predecessor is
                 const uint32_t prev = m & 0x7fu;
                 bool ready = false; double C = 0.0; long long tj = 0;
                 if (prev >= 64u) {                                  // first lane of the chunk on this counter: LDS state
                     const double C0 = rv[p]; const long long t0 = tref + (long long)rtm[p];
-                    if (h) { C = C0 * exp((double)(j - t0) * lnw) + (double)h; tj = j; } else { C = C0; tj = t0; }
+                    if (h) { C = C0 * poww(pwt, j - t0, lnw) + (double)h; tj = j; } else { C = C0; tj = t0; }
                     ready = true;
                 }
                 while (__any((int)!ready)) {
@@ -1738,7 +1774,7 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
                 if (ch >= seg_chunks) break;
                 const int64_t b = b0 + (int64_t)ch * 64 + lane;
                 if (b < (int64_t)B) {
-                    if (hist[b]) {
+                    if (ph[c]) {                                   // hist[b], fetched two groups ago
                         double mn = INFINITY;
                         for (int dd = 0; dd < depth; dd++) { const double e = src[(size_t)dd * GB + c * 64 + lane]; mn = e < mn ? e : mn; }
                         ft[b] = mn; rt[b] = (float)(1.0 / mn);
