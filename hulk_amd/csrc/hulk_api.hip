@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace hulk;
@@ -100,8 +101,13 @@ struct hulk_ctx {
     unsigned long long *d_visited = nullptr; uint64_t scan_tiles_total = 0; bool prune = false;
     double *d_candA = nullptr; int32_t *d_candB = nullptr;
     // staging for host reads
-    uint8_t *d_bases = nullptr; size_t d_bases_cap = 0;
-    uint64_t *d_offsets = nullptr; size_t d_offsets_cap = 0;
+    // hulk_add_reads (host buffers): two sets of pinned + device staging; the copy of chunk i+1 into pinned memory
+    // and over PCIe runs while the kernels of chunk i do
+    struct HostStage {
+        uint8_t *h_bases = nullptr, *d_bases = nullptr; uint64_t *h_off = nullptr, *d_off = nullptr;
+        size_t cap_bases = 0, cap_off = 0; hipEvent_t ev = nullptr; bool busy = false;
+    } hstage[2];
+    int hstage_cur = 0;
     uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;   // d_slow_count[2]: alternate per launch
     uint32_t slow_parity = 0;
     MinimizerList ml{}; uint64_t ml_regions = 0;
@@ -761,7 +767,13 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd);
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
     hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited); hipFree(c->d_kminslot);
-    hipFree(c->d_bases); hipFree(c->d_offsets); hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
+    for (auto &hs : c->hstage) {
+        if (hs.ev) hipEventDestroy(hs.ev);
+        if (hs.h_bases) hipHostFree(hs.h_bases);
+        if (hs.h_off) hipHostFree(hs.h_off);
+        hipFree(hs.d_bases); hipFree(hs.d_off);
+    }
+    hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
     hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial); hipFree(c->ml.nib); hipFree(c->ml.nib_over); hipFree(c->ml.lo); hipFree(c->ml.lo_cnt);
     hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -884,28 +896,61 @@ int hulk_add_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, u
         if (L > max_len) max_len = L;
     }
     if (max_len > 0xffffffffull) return fail(c, HULK_ERR_READ_TOO_LONG);
-    const uint64_t lo = offsets[0], hi = offsets[n];
-    const size_t nbytes = (size_t)(hi - lo), padded = (nbytes + 15) & ~(size_t)7;
-    if (padded > c->d_bases_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        hipFree(c->d_bases); c->d_bases = nullptr; c->d_bases_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->d_bases, padded + padded / 4));
-        c->d_bases_cap = padded + padded / 4;
+    // Chunks of <= 2^19 reads / 96 MB go through two pinned staging sets: host copy (several threads: one core
+    // copies ~10 GB/s, a PCIe 5 x16 link moves ~50) -> hipMemcpyAsync -> kernels, all queued on the context's
+    // stream; the call returns when the caller's buffers have been read, not when the kernels have run.
+    constexpr uint64_t CHUNK_READS = 1ull << 19, CHUNK_BYTES = 96ull << 20;
+    uint64_t i0 = 0;
+    while (i0 < n) {
+        uint64_t i1 = i0, cmax = 0;
+        while (i1 < n && i1 - i0 < CHUNK_READS && (i1 == i0 || offsets[i1 + 1] - offsets[i0] <= CHUNK_BYTES)) {
+            const uint64_t L = offsets[i1 + 1] - offsets[i1];
+            if (L > cmax) cmax = L;
+            i1++;
+        }
+        const uint64_t cn = i1 - i0, lo = offsets[i0];
+        const size_t nbytes = (size_t)(offsets[i1] - lo);
+        hulk_ctx::HostStage &hs = c->hstage[c->hstage_cur];
+        if (!hs.ev) HIPCHK(c, hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
+        if (hs.busy) { HIPCHK(c, hipEventSynchronize(hs.ev)); hs.busy = false; }     // its copies and kernels are done
+        if (nbytes + 32 > hs.cap_bases) {
+            if (hs.h_bases) hipHostFree(hs.h_bases);
+            hipFree(hs.d_bases); hs.h_bases = hs.d_bases = nullptr;
+            hs.cap_bases = (nbytes + 32) + (nbytes + 32) / 4;
+            HIPCHK(c, hipHostMalloc((void **)&hs.h_bases, hs.cap_bases, hipHostMallocDefault));
+            HIPCHK(c, hipMalloc((void **)&hs.d_bases, hs.cap_bases));
+        }
+        if (cn + 2 > hs.cap_off) {
+            if (hs.h_off) hipHostFree(hs.h_off);
+            hipFree(hs.d_off); hs.h_off = hs.d_off = nullptr;
+            hs.cap_off = (cn + 2) + (cn + 2) / 4;
+            HIPCHK(c, hipHostMalloc((void **)&hs.h_off, hs.cap_off * 8, hipHostMallocDefault));
+            HIPCHK(c, hipMalloc((void **)&hs.d_off, hs.cap_off * 8));
+        }
+        {
+            static const unsigned tmax = [] { const char *e = getenv("HULK_HOST_COPY_THREADS"); const long v = e ? atol(e) : 4; return (unsigned)(v < 1 ? 1 : v > 32 ? 32 : v); }();
+            const unsigned T = nbytes >= (8u << 20) ? tmax : 1u;
+            const size_t piece = (nbytes / T + 63) & ~(size_t)63;
+            std::vector<std::thread> th;
+            auto work = [&](unsigned t) {
+                const size_t at = (size_t)t * piece;
+                if (at < nbytes) memcpy(hs.h_bases + at, bases + lo + at, std::min(piece, nbytes - at));
+            };
+            for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
+            work(0);
+            for (uint64_t i = 0; i <= cn; i++) hs.h_off[i] = offsets[i0 + i] - lo;
+            for (auto &x : th) x.join();
+        }
+        HIPCHK(c, hipMemcpyAsync(hs.d_bases, hs.h_bases, nbytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hs.d_off, hs.h_off, (cn + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        const int rc = hulk_add_reads_device(c, hs.d_bases, hs.d_off, cn, (uint32_t)cmax, hs.cap_bases);
+        if (rc != HULK_OK) return rc;
+        HIPCHK(c, hipEventRecord(hs.ev, c->stream));
+        hs.busy = true;
+        c->hstage_cur ^= 1;
+        i0 = i1;
     }
-    if (n + 1 > c->d_offsets_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        hipFree(c->d_offsets); c->d_offsets = nullptr; c->d_offsets_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->d_offsets, (n + 1 + n / 4) * 8));
-        c->d_offsets_cap = n + 1 + n / 4;
-    }
-    // staging is reused batch to batch: wait for the kernels of the previous batch
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<uint64_t> rel(n + 1);
-    for (uint64_t i = 0; i <= n; i++) rel[i] = offsets[i] - lo;
-    HIPCHK(c, hipMemcpyAsync(c->d_bases, bases + lo, nbytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_offsets, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return hulk_add_reads_device(c, c->d_bases, c->d_offsets, n, (uint32_t)max_len, c->d_bases_cap);
+    return HULK_OK;
 }
 
 int hulk_add_histogram(hulk_ctx *c, const uint32_t *bins) {
