@@ -112,7 +112,10 @@ int hulk_set_cws_tables(hulk_ctx *ctx, const double *r, const double *c, const d
 
 /* AddSeq for a batch.  Read i is bases[offsets[i] .. offsets[i+1]) (ASCII, any case).
  * The interval rule is applied inside: a flush is queued whenever the global read count hits a
- * multiple of params.interval.  Host variant validates lengths and copies before returning. */
+ * multiple of params.interval.  The host variant validates the lengths and has copied the caller's
+ * buffers (into pinned staging, in chunks) when it returns — they may be reused at once (the cgo rule);
+ * the PCIe copies and the kernels are queued on the context's stream and may still be running:
+ * hulk_flush / hulk_finish / the getters are the synchronisation points. */
 int hulk_add_reads(hulk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads);
 /* Same, buffers already resident in this device's memory (offsets too).  `max_read_len` is an
  * upper bound on the read lengths in the batch (selects the kernel configuration);
