@@ -34,6 +34,7 @@
 
 #include "../../include/hulk_hip.h"
 #include "hulk_internal.h"
+#include "fast_inflate.h"
 
 namespace {
 
@@ -54,6 +55,185 @@ struct IngestError {
     int code = HULK_OK;
     std::string msg;
     bool set(int c, const std::string &m) { if (code == HULK_OK) { code = c; msg = m; } return false; }
+};
+
+// ------------------------------------------------------------------------------------------
+// gzip reader on hulk::inflate (fast_inflate.h).  A producer thread inflates into 1 MB chunks (each
+// with the previous chunk's last 32 KiB in front of it as match history); the consumer — the block
+// reader's thread — takes the CRC-32 of a chunk (zlib's crc32) while copying it out, so that inflate
+// and checksum run side by side.  Members are concatenated (compress/gzip's multistream default);
+// what follows the last member and is not a gzip header is ignored, as zlib's gzread does.
+// HULK_GZ_ZLIB=1 keeps zlib's inflate (gzread) instead.
+// ------------------------------------------------------------------------------------------
+class GzFast {
+ public:
+    explicit GzFast(int fd) : fd_(fd) {
+        for (auto &c : chunks_) { c.buf.resize(HIST + CHUNK + hulk::inflate::OUT_SLACK + 64); free_.push_back(&c); }
+        th_ = std::thread([this] { produce(); });
+    }
+    ~GzFast() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+        if (fd_ > 0) ::close(fd_);
+    }
+    // up to cap bytes; 0 = end of the stream; -1 = error (msg filled)
+    long read(uint8_t *dst, size_t cap, std::string &msg) {
+        for (;;) {
+            if (!cur_) {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return !ready_.empty(); });
+                cur_ = ready_.front(); ready_.pop_front();
+            }
+            if (cur_->off < cur_->len) {
+                const size_t n = std::min(cap, cur_->len - cur_->off);
+                const uint8_t *src = cur_->buf.data() + HIST + cur_->off;
+                // (zlib's crc32 takes a uInt length)
+                for (size_t at = 0; at < n; at += 1u << 30) crc_ = (uint32_t)crc32(crc_, src + at, (uInt)std::min<size_t>(n - at, 1u << 30));
+                memcpy(dst, src, n);
+                cur_->off += n; size_ += (uint32_t)n;
+                return (long)n;
+            }
+            // chunk drained: its end-of-member / end-of-stream / error marks
+            if (cur_->member_end) {
+                if (crc_ != cur_->crc || size_ != cur_->isize) { msg = "gzip: invalid checksum"; return -1; }
+                crc_ = 0; size_ = 0;
+            }
+            if (!cur_->err.empty()) { msg = cur_->err; return -1; }
+            const bool eof = cur_->eof;
+            if (eof) return 0;                                     // (the chunk stays current: every later call ends here too)
+            { std::lock_guard<std::mutex> g(m_); free_.push_back(cur_); }
+            cv_.notify_all();
+            cur_ = nullptr;
+        }
+    }
+
+ private:
+    static constexpr size_t HIST = 32768, CHUNK = 1u << 20, INBUF = 1u << 20;
+    struct Chunk { std::vector<uint8_t> buf; size_t len = 0, off = 0; bool member_end = false, eof = false; uint32_t crc = 0, isize = 0; std::string err; };
+
+    Chunk *get_free() {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return !free_.empty() || stop_; });
+        if (stop_) return nullptr;
+        Chunk *c = free_.back(); free_.pop_back();
+        c->len = c->off = 0; c->member_end = c->eof = false; c->err.clear();
+        return c;
+    }
+    void publish(Chunk *c) { { std::lock_guard<std::mutex> g(m_); ready_.push_back(c); } cv_.notify_all(); }
+
+    // compressed input: inbuf_[ipos .. iend) is unread (the decoder's `in` pointer is the read position)
+    bool refill() {                                                // keeps the unread tail; false = no more input
+        const size_t tail = dec_.in ? dec_.in_left() : 0;
+        if (tail) memmove(inbuf_.data(), dec_.in, tail);
+        size_t got = 0;
+        while (!in_eof_ && tail + got < INBUF) {
+            const ssize_t m = ::read(fd_, inbuf_.data() + tail + got, INBUF - tail - got);
+            if (m < 0) { if (errno == EINTR) continue; io_err_ = std::string("read: ") + strerror(errno); in_eof_ = true; break; }
+            if (m == 0) { in_eof_ = true; break; }
+            got += (size_t)m;
+            break;                                                  // one read per refill is enough
+        }
+        memset(inbuf_.data() + tail + got, 0, 16);                  // the fast loop loads 8 bytes at a time
+        dec_.feed(inbuf_.data(), tail + got);
+        return got != 0;
+    }
+    bool next_byte(uint8_t &b) { while (!dec_.take_byte(b)) { if (!refill()) return false; } return true; }
+
+    // 1 = header read, 0 = clean end (no more members), -1 = error (msg)
+    int read_header(bool first, std::string &msg) {
+        uint8_t h[10];
+        for (int i = 0; i < 10; i++) {
+            if (!next_byte(h[i])) {
+                if (i == 0 && !first) return 0;
+                if (!first && i < 2) return 0;                      // trailing bytes that are not a member
+                msg = first && i == 0 ? "EOF" : "unexpected EOF"; return -1;
+            }
+            if (i == 1 && (h[0] != 0x1f || h[1] != 0x8b)) { if (!first) return 0; msg = "gzip: invalid header"; return -1; }
+        }
+        if (h[2] != 8) { msg = "gzip: invalid header"; return -1; }
+        const uint8_t flg = h[3];
+        uint8_t b;
+        if (flg & 4) {                                              // FEXTRA
+            uint8_t l0, l1; if (!next_byte(l0) || !next_byte(l1)) { msg = "unexpected EOF"; return -1; }
+            for (uint32_t n = (uint32_t)l0 | ((uint32_t)l1 << 8); n; n--) if (!next_byte(b)) { msg = "unexpected EOF"; return -1; }
+        }
+        if (flg & 8) do { if (!next_byte(b)) { msg = "unexpected EOF"; return -1; } } while (b);     // FNAME
+        if (flg & 16) do { if (!next_byte(b)) { msg = "unexpected EOF"; return -1; } } while (b);    // FCOMMENT
+        if (flg & 2) { if (!next_byte(b) || !next_byte(b)) { msg = "unexpected EOF"; return -1; } }  // FHCRC (not verified)
+        return 1;
+    }
+
+    // A member always starts a chunk (the end of a member ends its chunk), so the window of the running member is
+    // the `hist_have` bytes in front of the chunk's data plus what the chunk holds so far.
+    void produce() {
+        inbuf_.resize(INBUF + 64);
+        dec_.feed(inbuf_.data(), 0);
+        Chunk *c = get_free();
+        if (!c) return;
+        auto finish = [&](Chunk *ch, size_t len, const std::string &e) { ch->len = len; ch->err = e; ch->eof = true; publish(ch); };
+        bool first = true;
+        for (;;) {
+            uint8_t *base = c->buf.data() + HIST, *out = base;
+            size_t hist_have = 0;
+            std::string msg;
+            const int hr = read_header(first, msg);
+            if (hr <= 0) { finish(c, 0, hr < 0 ? msg : io_err_); return; }
+            first = false;
+            dec_.reset();
+            for (;;) {
+                uint8_t *lim = base + CHUNK;
+                out = dec_.run(out, lim, base - hist_have, false);
+                if (dec_.state == hulk::inflate::Decoder::DONE) break;
+                if (dec_.state == hulk::inflate::Decoder::ERROR) { finish(c, (size_t)(out - base), std::string("gzip: ") + dec_.err); return; }
+                if (out >= lim) {                                   // chunk full: hand it over, go on in the next one
+                    c->len = (size_t)(out - base);
+                    Chunk *nx = get_free();
+                    if (!nx) return;
+                    const size_t hh = std::min(HIST, hist_have + c->len);      // history = tail of (old history + chunk)
+                    memcpy(nx->buf.data() + HIST - hh, out - hh, hh);
+                    hist_have = hh;
+                    publish(c); c = nx;
+                    base = c->buf.data() + HIST; out = base;
+                    continue;
+                }
+                if (!refill()) {                                    // starved and nothing more to read
+                    out = dec_.run(out, lim, base - hist_have, true);          // reports the truncation
+                    if (dec_.state == hulk::inflate::Decoder::DONE) break;
+                    if (out >= lim) continue;
+                    finish(c, (size_t)(out - base), !io_err_.empty() ? io_err_ : std::string("unexpected EOF"));
+                    return;
+                }
+            }
+            // trailer: CRC-32 and ISIZE, little endian, after the next byte boundary
+            dec_.align_to_byte();
+            uint8_t t[8];
+            for (int i = 0; i < 8; i++) if (!next_byte(t[i])) { finish(c, (size_t)(out - base), "unexpected EOF"); return; }
+            c->len = (size_t)(out - base);
+            c->member_end = true;
+            c->crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+            c->isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+            Chunk *nx = get_free();
+            if (!nx) return;
+            publish(c); c = nx;
+        }
+    }
+
+    int fd_;
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    Chunk chunks_[4];
+    std::deque<Chunk *> free_, ready_;
+    bool stop_ = false;
+    // producer side
+    hulk::inflate::Decoder dec_;
+    std::vector<uint8_t> inbuf_;
+    bool in_eof_ = false;
+    std::string io_err_;
+    // consumer side
+    Chunk *cur_ = nullptr;
+    uint32_t crc_ = 0, size_ = 0;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -80,7 +260,11 @@ class ByteSource {
                 last_ = '\n'; got_any_ = false;
             }
             long n;
-            if (is_gz_) {
+            if (gzf_) {
+                std::string msg;
+                n = gzf_->read(dst, cap, msg);
+                if (n < 0) { err.set(HULK_ERR_IO, msg); return -1; }
+            } else if (is_gz_) {
                 n = gzread(gz_, dst, (unsigned)std::min<size_t>(cap, 1u << 30));
                 if (n < 0) { int e = 0; const char *m = gzerror(gz_, &e); err.set(HULK_ERR_IO, std::string("gzip: ") + (m ? m : "read error")); return -1; }
             } else if (regular_ && cap >= PAR_READ_MIN && readers() > 1) {
@@ -162,6 +346,8 @@ class ByteSource {
             const ssize_t m = ::pread(fd_, magic, 2, 0);
             if (m == 0) { close_current(); return err.set(HULK_ERR_IO, "EOF"); }                    // gzip.NewReader on an empty file
             if (m < 2 || magic[0] != 0x1f || magic[1] != 0x8b) { close_current(); return err.set(HULK_ERR_IO, "gzip: invalid header"); }
+            static const bool use_zlib = getenv("HULK_GZ_ZLIB") != nullptr;
+            if (!use_zlib) { gzf_.reset(new GzFast(fd_)); return true; }
             gz_ = gzdopen(fd_, "rb");
             if (!gz_) { close_current(); return err.set(HULK_ERR_IO, "gzip: cannot open stream"); }
             gzbuffer(gz_, 1u << 20);
@@ -169,7 +355,8 @@ class ByteSource {
         return true;
     }
     void close_current() {
-        if (gz_) { gzclose(gz_); gz_ = nullptr; fd_ = -1; }       // gzclose closes the descriptor
+        if (gzf_) { gzf_.reset(); fd_ = -1; }                     // (GzFast closes the descriptor)
+        else if (gz_) { gzclose(gz_); gz_ = nullptr; fd_ = -1; }  // gzclose closes the descriptor
         else if (fd_ > 0) ::close(fd_);
         fd_ = -1; open_ = false;
     }
@@ -180,6 +367,7 @@ class ByteSource {
     bool regular_ = false;
     off_t pos_ = 0;
     gzFile gz_ = nullptr;
+    std::unique_ptr<GzFast> gzf_;
     uint8_t last_ = '\n';
 };
 

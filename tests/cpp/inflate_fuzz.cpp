@@ -1,0 +1,92 @@
+// Differential test of hulk::inflate (hulk_amd/csrc/fast_inflate.h) against zlib: random inputs of several kinds,
+// every compression level and strategy (fixed / dynamic / stored blocks, Huffman-only, RLE), fed in random input
+// pieces (down to 1 byte) with random output pieces, so that every resume point of the decoder is exercised.
+// usage: inflate_fuzz [cases] [seed]      exit code 0 = all equal
+#include "../../hulk_amd/csrc/fast_inflate.h"
+#include <zlib.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+using namespace hulk::inflate;
+
+static std::vector<uint8_t> deflate_raw(const std::vector<uint8_t> &src, int level, int strategy) {
+    z_stream z{};
+    deflateInit2(&z, level, Z_DEFLATED, -15, 8, strategy);
+    std::vector<uint8_t> out(deflateBound(&z, src.size()) + 64);
+    z.next_in = (Bytef *)src.data(); z.avail_in = (uInt)src.size(); z.next_out = out.data(); z.avail_out = (uInt)out.size();
+    deflate(&z, Z_FINISH);
+    out.resize(z.total_out);
+    deflateEnd(&z);
+    return out;
+}
+
+static bool decode(Decoder &d, const std::vector<uint8_t> &comp, size_t piece, size_t opiece, size_t n_expected,
+                   std::vector<uint8_t> &res, std::string &err) {
+    d.reset(); d.have_fixed = false;
+    std::vector<uint8_t> win(n_expected + 65536 + OUT_SLACK + 1024);
+    std::vector<uint8_t> inbuf(comp.size() + 64, 0);
+    uint8_t *out = win.data();
+    size_t fed = 0;
+    d.feed(inbuf.data(), 0);
+    for (;;) {
+        const size_t tail = d.in_left();
+        if (tail) memmove(inbuf.data(), d.in, tail);
+        const size_t add = std::min(piece, comp.size() - fed);
+        memcpy(inbuf.data() + tail, comp.data() + fed, add); fed += add;
+        memset(inbuf.data() + tail + add, 0, 16);
+        d.feed(inbuf.data(), tail + add);
+        const bool eof = fed == comp.size();
+        for (;;) {
+            uint8_t *lim = out + opiece;
+            uint8_t *end = win.data() + win.size() - OUT_SLACK - 16;
+            if (lim > end || lim < out) lim = end;
+            out = d.run(out, lim, win.data(), eof);
+            if (d.state == Decoder::DONE) { res.assign(win.data(), out); return true; }
+            if (d.state == Decoder::ERROR) { err = d.err; return false; }
+            if (out < lim) break;                               // starved
+            if (lim == end) { err = "output overrun"; return false; }
+        }
+        if (eof && add == 0) { err = "stuck"; return false; }
+    }
+}
+
+int main(int argc, char **argv) {
+    const int cases = argc > 1 ? atoi(argv[1]) : 400;
+    srand(argc > 2 ? atoi(argv[2]) : 1);
+    Decoder *d = new Decoder;
+    int bad = 0;
+    for (int it = 0; it < cases; it++) {
+        const size_t n = rand() % 4 == 0 ? rand() % 2000 : rand() % 300000;
+        std::vector<uint8_t> src(n);
+        const int kind = rand() % 5;
+        for (size_t i = 0; i < n; i++) {
+            if (kind == 0) src[i] = (uint8_t)rand();
+            else if (kind == 1) src[i] = "ACGT"[rand() & 3];
+            else if (kind == 2) src[i] = (i % 150 < 100) ? "ACGTN"[rand() % 5] : 'I';
+            else if (kind == 3) src[i] = (uint8_t)(i * 7 / 13);
+            else src[i] = (rand() % 50) ? 'A' : (uint8_t)rand();
+        }
+        const int level = rand() % 10;
+        const int strat = (rand() % 4 == 0) ? Z_FIXED : (rand() % 5 == 0 ? Z_HUFFMAN_ONLY : (rand() % 7 == 0 ? Z_RLE : Z_DEFAULT_STRATEGY));
+        const std::vector<uint8_t> comp = deflate_raw(src, level, strat);
+        const size_t piece = rand() % 3 == 0 ? 1 + rand() % 40 : (rand() % 2 ? (size_t)1 << 20 : 1 + rand() % 5000);
+        const size_t opiece = rand() % 3 == 0 ? 1 + rand() % 600 : (size_t)1 << 22;
+        std::vector<uint8_t> res; std::string err;
+        const bool ok = decode(*d, comp, piece, opiece, n, res, err);
+        if (!ok || res != src) {
+            bad++;
+            if (bad < 10) printf("FAIL it=%d n=%zu kind=%d level=%d strat=%d piece=%zu opiece=%zu ok=%d err=%s got=%zu\n",
+                                 it, n, kind, level, strat, piece, opiece, (int)ok, err.c_str(), res.size());
+        }
+        // a truncated stream must end in an error, never in DONE with wrong data
+        if (comp.size() > 8 && it % 7 == 0) {
+            std::vector<uint8_t> cut(comp.begin(), comp.begin() + (long)(comp.size() - 1 - (size_t)rand() % std::min<size_t>(comp.size() - 1, 50)));
+            std::vector<uint8_t> r2; std::string e2;
+            if (decode(*d, cut, piece, opiece, n, r2, e2) && r2 != src) { bad++; printf("FAIL truncated it=%d accepted\n", it); }
+        }
+    }
+    printf("%d cases, %d bad\n", cases, bad);
+    return bad != 0;
+}

@@ -241,3 +241,96 @@ def test_default_blocks_parallel_reads(tmp_path):
         paths.append(write(tmp_path, "big%d.fq" % f, data))
     got = native(paths)
     assert len(got) == len(want) and got == want
+
+
+# ---- gzip input through hulk::inflate (fast_inflate.h) ----
+
+def _fastq_blob(rng, n, lo=30, hi=251):
+    lens = rng.integers(lo, hi, n)
+    seqs = [bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(L))]) for L in lens]
+    return seqs, b"".join(b"@r%d\n%s\n+\n%s\n" % (i, s, b"F" * len(s)) for i, s in enumerate(seqs))
+
+
+def test_gzip_large_levels_and_members(tmp_path):
+    """Several MB of FASTQ (many 1 MB inflate chunks, matches that reach across them) at compression levels 1 / 6 / 9,
+    as one member and as three concatenated members (compress/gzip reads multistream), with FNAME/FEXTRA/FCOMMENT
+    header fields; the same through zlib's inflate (HULK_GZ_ZLIB=1) in a child process."""
+    import zlib
+    rng = np.random.default_rng(5)
+    seqs, blob = _fastq_blob(rng, 40_000)
+    assert len(blob) > 10 << 20
+
+    def member(data, level, flags=0):
+        hdr = bytearray(b"\x1f\x8b\x08" + bytes([flags]) + b"\0\0\0\0\0\xff")
+        if flags & 4: hdr += b"\x05\x00hello"
+        if flags & 8: hdr += b"name.fq\0"
+        if flags & 16: hdr += b"a comment\0"
+        if flags & 2: hdr += b"\x12\x34"
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(data) + c.flush()
+        return bytes(hdr) + body + (zlib.crc32(data) & 0xffffffff).to_bytes(4, "little") + (len(data) & 0xffffffff).to_bytes(4, "little")
+
+    paths = []
+    for level in (1, 6, 9):
+        p = str(tmp_path / ("one%d.fq.gz" % level))
+        open(p, "wb").write(member(blob, level, flags=4 | 8 | 16 | 2))
+        assert native([p]) == seqs
+        paths.append(p)
+    cut1, cut2 = blob.index(b"\n@r9000\n") + 1, blob.index(b"\n@r30000\n") + 1
+    p3 = str(tmp_path / "three.fq.gz")
+    open(p3, "wb").write(member(blob[:cut1], 6) + member(blob[cut1:cut2], 1, flags=8) + member(blob[cut2:], 9) + b"\0\0trailing garbage")
+    assert native([p3]) == seqs
+    # stored blocks (level 0) and an empty member in the middle
+    p0 = str(tmp_path / "stored.fq.gz")
+    open(p0, "wb").write(member(blob[:cut1], 0) + member(b"", 6) + member(blob[cut1:], 0))
+    assert native([p0]) == seqs
+    code = ("import sys; sys.path.insert(0, %r)\nfrom hulk_amd import ingest\n"
+            "b, o, st = ingest.parse_files(%r)\nimport hashlib; print(st['n_seqs'], hashlib.md5(b.tobytes()).hexdigest())" % (ROOT, [p3, p0]))
+    outs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **extra)).stdout.strip() for extra in ({}, {"HULK_GZ_ZLIB": "1"})]
+    assert outs[0] == outs[1] and outs[0].startswith(str(2 * len(seqs)) + " ")
+
+
+def test_gzip_errors(tmp_path):
+    import zlib
+    rng = np.random.default_rng(6)
+    seqs, blob = _fastq_blob(rng, 3000)
+    good = gzip.compress(blob, 6)
+    bad_crc = bytearray(good); bad_crc[-5] ^= 0x40
+    p = write(tmp_path, "crc.fq", b""); p = str(tmp_path / "crc.fq.gz"); open(p, "wb").write(bytes(bad_crc))
+    with pytest.raises(HulkError) as e:
+        native([p])
+    assert e.value.message == "gzip: invalid checksum"
+    bad_size = bytearray(good); bad_size[-1] ^= 0x01
+    p = str(tmp_path / "size.fq.gz"); open(p, "wb").write(bytes(bad_size))
+    with pytest.raises(HulkError) as e:
+        native([p])
+    assert e.value.message == "gzip: invalid checksum"
+    p = str(tmp_path / "cut.fq.gz"); open(p, "wb").write(good[:len(good) // 2])
+    with pytest.raises(HulkError) as e:
+        native([p])
+    assert e.value.message == "unexpected EOF"
+    p = str(tmp_path / "cuttrailer.fq.gz"); open(p, "wb").write(good[:-3])
+    with pytest.raises(HulkError) as e:
+        native([p])
+    assert e.value.message == "unexpected EOF"
+    # a flipped bit in the deflate data: a flate error or a checksum error, never silent acceptance
+    for at in (40, len(good) // 3, len(good) // 2):
+        mangled = bytearray(good); mangled[at] ^= 0x10
+        p = str(tmp_path / ("flip%d.fq.gz" % at)); open(p, "wb").write(bytes(mangled))
+        with pytest.raises(HulkError) as e:
+            native([p])
+        assert e.value.message.startswith("gzip: ") or e.value.message in ("unexpected EOF",) or "FASTQ" in e.value.message or "@" in e.value.message
+    p = str(tmp_path / "method.fq.gz"); open(p, "wb").write(b"\x1f\x8b\x07" + good[3:])
+    with pytest.raises(HulkError) as e:
+        native([p])
+    assert e.value.message == "gzip: invalid header"
+
+
+def test_inflate_against_zlib(tmp_path):
+    """tests/cpp/inflate_fuzz.cpp: the decoder against zlib on random data, all levels/strategies, random feed sizes."""
+    exe = str(tmp_path / "inflate_fuzz")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "inflate_fuzz.cpp"), "-lz"],
+                   check=True, timeout=300)
+    r = subprocess.run([exe, "250", "11"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
