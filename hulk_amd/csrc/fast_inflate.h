@@ -253,48 +253,62 @@ inline uint8_t *Decoder::run(uint8_t *out, uint8_t *out_limit, const uint8_t *hi
             while (pend_len && out < out_limit) { *out = *(out - pend_dist); out++; pend_len--; }
             if (pend_len) return out;
         }
-        // fast loop: >= 16 input bytes and >= OUT_SLACK output bytes ahead
-        while ((size_t)(in_end - in) >= 16 && (size_t)(out_limit - out) >= OUT_SLACK) {
-            uint64_t w; memcpy(&w, in, 8);
-            bitbuf |= w << bitcnt; in += (63 - bitcnt) >> 3; bitcnt |= 56;
-            uint32_t e = litlen[bitbuf & ((1u << LITLEN_BITS) - 1)];
-            if (((e >> 4) & 7u) == K_SUB) { bitbuf >>= LITLEN_BITS; bitcnt -= LITLEN_BITS; e = litlen[(e >> 16) + (bitbuf & ((1u << ((e >> 8) & 31u)) - 1))]; }
-            bitbuf >>= (e & 15u); bitcnt -= (int)(e & 15u);
-            uint32_t kind = (e >> 4) & 7u;
-            if (kind == K_LIT) {
-                *out++ = (uint8_t)(e >> 16);
-                // up to two more literals from the same refill (>= 56 - 15 - 15 bits left)
-                e = litlen[bitbuf & ((1u << LITLEN_BITS) - 1)];
-                if (((e >> 4) & 7u) != K_LIT) continue;
-                bitbuf >>= (e & 15u); bitcnt -= (int)(e & 15u);
-                *out++ = (uint8_t)(e >> 16);
-                e = litlen[bitbuf & ((1u << LITLEN_BITS) - 1)];
-                if (((e >> 4) & 7u) != K_LIT) continue;
-                bitbuf >>= (e & 15u); bitcnt -= (int)(e & 15u);
-                *out++ = (uint8_t)(e >> 16);
-                continue;
-            }
-            if (kind != K_LEN) {
-                if (kind == K_EOB) { state = last_block ? DONE : HEADER; goto next_state; }
-                fail("flate: corrupt input (literal/length code)"); return out;
-            }
-            {
+        // fast loop: >= 16 input bytes and >= OUT_SLACK output bytes ahead.  The reader state lives in locals here:
+        // stores through the (byte) output pointer may alias anything, and would force the members to be re-read
+        // after every literal.
+        {
+            uint64_t bb = bitbuf; int bc = bitcnt; const uint8_t *ip = in;
+            const uint8_t *const ip_stop = in_end - 16;
+            uint8_t *const out_stop = out_limit - OUT_SLACK;
+            const uint32_t *const lt = litlen, *const dt = dist;
+            int leave = 0;                                          // 1 = end of block, 2 = error (err set)
+            while (ip <= ip_stop && out <= out_stop) {
+                uint64_t w; memcpy(&w, ip, 8);
+                bb |= w << bc; ip += (63 - bc) >> 3; bc |= 56;
+                uint32_t e = lt[bb & ((1u << LITLEN_BITS) - 1)];
+                if (((e >> 4) & 7u) == K_LIT) {
+                    // up to four literals from one refill (each <= 11 bits here: first-level hits)
+                    bb >>= (e & 15u); bc -= (int)(e & 15u); *out++ = (uint8_t)(e >> 16);
+                    e = lt[bb & ((1u << LITLEN_BITS) - 1)];
+                    if (((e >> 4) & 7u) != K_LIT) goto not_literal;
+                    bb >>= (e & 15u); bc -= (int)(e & 15u); *out++ = (uint8_t)(e >> 16);
+                    e = lt[bb & ((1u << LITLEN_BITS) - 1)];
+                    if (((e >> 4) & 7u) != K_LIT) goto not_literal;
+                    bb >>= (e & 15u); bc -= (int)(e & 15u); *out++ = (uint8_t)(e >> 16);
+                    e = lt[bb & ((1u << LITLEN_BITS) - 1)];
+                    if (((e >> 4) & 7u) != K_LIT) goto not_literal;
+                    bb >>= (e & 15u); bc -= (int)(e & 15u); *out++ = (uint8_t)(e >> 16);
+                    continue;
+                not_literal:
+                    // <= 33 bits used, >= 23 left: not enough for a length + distance pair (<= 48): refill first
+                    if (ip > ip_stop) break;
+                    memcpy(&w, ip, 8);
+                    bb |= w << bc; ip += (63 - bc) >> 3; bc |= 56;
+                }
+                if (((e >> 4) & 7u) == K_SUB) { bb >>= LITLEN_BITS; bc -= LITLEN_BITS; e = lt[(e >> 16) + (bb & ((1u << ((e >> 8) & 31u)) - 1))]; }
+                bb >>= (e & 15u); bc -= (int)(e & 15u);
+                const uint32_t kind = (e >> 4) & 7u;
+                if (kind == K_LIT) { *out++ = (uint8_t)(e >> 16); continue; }           // (a literal with a long code)
+                if (kind != K_LEN) {
+                    if (kind == K_EOB) { leave = 1; break; }
+                    err = "flate: corrupt input (literal/length code)"; leave = 2; break;
+                }
                 const uint32_t xb = (e >> 8) & 31u;
-                uint32_t len = (e >> 16) + (uint32_t)(bitbuf & ((1u << xb) - 1));
-                bitbuf >>= xb; bitcnt -= (int)xb;
+                const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << xb) - 1));
+                bb >>= xb; bc -= (int)xb;
                 // <= 15 + 5 bits of >= 56 used so far; the distance needs <= 15 + 13 more
-                uint32_t d = dist[bitbuf & ((1u << DIST_BITS) - 1)];
-                if (((d >> 4) & 7u) == K_SUB) { bitbuf >>= DIST_BITS; bitcnt -= DIST_BITS; d = dist[(d >> 16) + (bitbuf & ((1u << ((d >> 8) & 31u)) - 1))]; }
-                if (((d >> 4) & 7u) != K_LEN) { fail("flate: corrupt input (distance code)"); return out; }
-                bitbuf >>= (d & 15u); bitcnt -= (int)(d & 15u);
+                uint32_t d = dt[bb & ((1u << DIST_BITS) - 1)];
+                if (((d >> 4) & 7u) == K_SUB) { bb >>= DIST_BITS; bc -= DIST_BITS; d = dt[(d >> 16) + (bb & ((1u << ((d >> 8) & 31u)) - 1))]; }
+                if (((d >> 4) & 7u) != K_LEN) { err = "flate: corrupt input (distance code)"; leave = 2; break; }
+                bb >>= (d & 15u); bc -= (int)(d & 15u);
                 const uint32_t dxb = (d >> 8) & 31u;
-                const uint32_t distance = (d >> 16) + (uint32_t)(bitbuf & ((1u << dxb) - 1));
-                bitbuf >>= dxb; bitcnt -= (int)dxb;
-                if (distance > (size_t)(out - hist)) { fail("flate: corrupt input (distance too far back)"); return out; }
+                const uint32_t distance = (d >> 16) + (uint32_t)(bb & ((1u << dxb) - 1));
+                bb >>= dxb; bc -= (int)dxb;
+                if (distance > (size_t)(out - hist)) { err = "flate: corrupt input (distance too far back)"; leave = 2; break; }
                 const uint8_t *src = out - distance;
                 uint8_t *dst = out; out += len;
                 if (distance >= 8) {
-                    // 8 bytes at a time; may write up to 7 bytes past the match (inside OUT_SLACK)
+                    // 8 bytes at a time; may write up to 15 bytes past the match (inside OUT_SLACK)
                     uint64_t t;
                     memcpy(&t, src, 8); memcpy(dst, &t, 8); src += 8; dst += 8;
                     memcpy(&t, src, 8); memcpy(dst, &t, 8); src += 8; dst += 8;
@@ -305,6 +319,9 @@ inline uint8_t *Decoder::run(uint8_t *out, uint8_t *out_limit, const uint8_t *hi
                     while (dst < out) *dst++ = *src++;
                 }
             }
+            bitbuf = bb; bitcnt = bc; in = ip;
+            if (leave == 1) { state = last_block ? DONE : HEADER; continue; }
+            if (leave == 2) { state = ERROR; return out; }
         }
         // careful loop: one symbol at a time with explicit availability checks
         for (;;) {
