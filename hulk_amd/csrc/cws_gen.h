@@ -67,7 +67,7 @@ class GoRandSource {
 // The uniform stream is sequential, the transcendental math is not: the host only walks the raw
 // stream and pairs every attempt's (u1, u2) — integer compares, ~1 ns per value — and the GPU
 // evaluates all attempts of a chunk in parallel and compacts the accepted values in order
-// (k_cws_eval / k_cws_scatter in hulk_kernels.hip).
+// (k_cws_eval / k_cws_scatter in hulk_cws.hip).
 struct CwsConstants {
     double ainv, bbb, ccc, magic;            // alpha = 2, beta = 1 (histosketch.go:112-113)
     CwsConstants() {

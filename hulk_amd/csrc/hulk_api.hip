@@ -1,6 +1,6 @@
 // hulk_api.hip — the C ABI of libhulkhip.so (see include/hulk_hip.h for the reference seam each
 // entry point replaces).  Host-side orchestration only: every numeric step of the path runs in
-// the kernels of hulk_kernels.hip; there is no CPU fallback.
+// the kernels of hulk_minimizer / hulk_spectrum / hulk_countmin / hulk_cws .hip; there is no CPU fallback.
 #include "../../include/hulk_hip.h"
 #include "hulk_internal.h"
 #include "cws_gen.h"

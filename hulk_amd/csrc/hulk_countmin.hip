@@ -1,0 +1,547 @@
+// hulk_countmin.hip — KmerSpectrum.Cardinality and count-min Add() for a batch of spectra, bin order.
+//   K2  k_count_used       the 1 % rule (kmerspectrum.go:53-55,84-96)
+//   K3  k_cms_segsum/k_cms_base/k_cms_freq   src/countmin/countmin.go:103-147
+//       k_elem_*/k_cmsd_*  the same with uniform scaling (0 < decay < 1)
+#include "hulk_device.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <algorithm>
+
+namespace hulk {
+namespace {
+
+// K2: number of used bins (bitvector PopCount in the reference).  grid = (blocks, count)
+__global__ __launch_bounds__(256) void k_count_used(const uint32_t *__restrict__ hists, DevState *st,
+                                                    FlushBatch fb) {
+    __shared__ unsigned red[4];
+    const int t = blockIdx.y;
+    const uint32_t slot = ring_slot(fb, t);
+    if (blockIdx.x == 0 && t == 0 && threadIdx.x < RING_MAX) st->used[fb.parity ^ 1][threadIdx.x] = 0;  // arm the next flush
+    const uint32_t *hist = hists + (size_t)slot * (size_t)fb.num_bins;
+    unsigned cnt = 0;
+    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < fb.num_bins; b += gridDim.x * blockDim.x)
+        cnt += hist[b] != 0;
+    for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt = red[0] + red[1] + red[2] + red[3];
+        if (cnt) atomicAdd(&st->used[fb.parity][slot], cnt);   // one per block; the grid is small
+    }
+}
+
+
+
+// ------------------------------------------------------------------------------------------
+// K3 (no decay), bin-order form.  The chain-order kernels above gather 4-byte values along chains
+// whose bins are ~2000 apart: rocprofv3 showed 13x more HBM traffic than the algorithmic bytes.
+// Here every array is read in BIN order (coalesced) and the 7 x 2000 running counters live in LDS:
+//   k_cms_segsum : per (spectrum, row, bin segment) sums per counter            (LDS atomics)
+//   k_cms_base   : counter value in front of every (spectrum, segment)          (tiny prefix kernel)
+//   k_cms_freq   : one workgroup per (segment, spectrum): waves 0..6 replay their row in bin order —
+//                  est = ctr[pos] + (own + earlier same-counter bins of the 64-bin chunk, followed
+//                  through a static "previous lane with the same counter" table) — wave 7 takes the
+//                  minimum over the rows, writes f / 1/f and wipes the spectrum.  No est arrays at all.
+// ------------------------------------------------------------------------------------------
+constexpr int CMS_SEGS = 16;          // bin segments per spectrum
+constexpr int CMS_GROUP = 4;          // 64-bin chunks staged per barrier
+
+__global__ __launch_bounds__(512) void k_cms_segsum(const uint32_t *__restrict__ hists,
+                                                    const uint16_t *__restrict__ pos16,
+                                                    uint32_t *__restrict__ segsum, int depth, int width,
+                                                    int seg_chunks, const DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *lctr = (uint32_t *)smem;                           // [depth][width]
+    const int seg = blockIdx.x, t = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;  // wave d = row d (depth waves + 1 idle)
+    const uint32_t gomask = batch_gomask(st, fb);
+    if (!((gomask >> t) & 1u)) return;
+    for (int i = tid; i < depth * width; i += blockDim.x) lctr[i] = 0;
+    __syncthreads();
+    const size_t B = (size_t)fb.num_bins;
+    const uint32_t *hist = hists + (size_t)ring_slot(fb, t) * B;
+    if (d < depth) {
+        const uint16_t *pd = pos16 + (size_t)d * B;
+        const int64_t b0 = (int64_t)seg * seg_chunks * 64;
+        for (int c0 = 0; c0 < seg_chunks; c0 += 8) {              // 8 chunks of loads in flight
+            uint32_t h[8]; uint32_t p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int64_t b = b0 + (int64_t)(c0 + u) * 64 + lane;
+                const bool ok = (c0 + u < seg_chunks) && b < (int64_t)B;
+                h[u] = ok ? hist[b] : 0u; p[u] = ok ? pd[b] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (h[u]) atomicAdd(&lctr[d * width + p[u]], h[u]);
+        }
+    }
+    __syncthreads();
+    uint32_t *out = segsum + (((size_t)t * depth) * CMS_SEGS + 0) * width;
+    for (int i = tid; i < depth * width; i += blockDim.x) {
+        const int dd = i / width, p = i - dd * width;
+        out[((size_t)dd * CMS_SEGS + seg) * width + p] = lctr[i];
+    }
+}
+
+// base[t][d][seg][p] = counter (d,p) in front of segment seg of spectrum t; advances the persistent counters
+__global__ __launch_bounds__(256) void k_cms_base(const uint32_t *__restrict__ segsum,
+                                                  unsigned long long *__restrict__ ctr,
+                                                  unsigned long long *__restrict__ base, int depth, int width,
+                                                  const DevState *st, FlushBatch fb) {
+    const uint32_t gomask = batch_gomask(st, fb);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= depth * width) return;
+    const int d = i / width, p = i - d * width;
+    unsigned long long run = ctr[i];
+    for (int t = 0; t < (int)fb.count; t++) {
+        if (!((gomask >> t) & 1u)) continue;
+        uint32_t sv[CMS_SEGS];
+        const size_t at0 = (((size_t)t * depth + d) * CMS_SEGS) * width + p;
+#pragma unroll
+        for (int seg = 0; seg < CMS_SEGS; seg++) sv[seg] = segsum[at0 + (size_t)seg * width];   // independent loads
+#pragma unroll
+        for (int seg = 0; seg < CMS_SEGS; seg++) { base[at0 + (size_t)seg * width] = run; run += sv[seg]; }
+    }
+    ctr[i] = run;
+}
+
+__global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
+                                                  const uint8_t *__restrict__ meta8,
+                                                  const unsigned long long *__restrict__ base,
+                                                  double *__restrict__ f64, float *__restrict__ rcp32,
+                                                  int depth, int width, int seg_chunks, size_t row_stride,
+                                                  DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long *lctr = (unsigned long long *)smem;                       // [depth][width]
+    unsigned long long *stage = lctr + (size_t)depth * width;                    // [2][depth][CMS_GROUP*64]
+    const int seg = blockIdx.x, t = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;                  // waves 0..depth-1: rows; wave depth: combiner
+    const uint32_t gomask = batch_gomask(st, fb);
+    const bool go = (gomask >> t) & 1u;
+    const uint32_t slot = ring_slot(fb, t);
+    if (seg == 0 && tid == 0) {
+        const unsigned used = st->used[fb.parity][slot];
+        if (used != 0 && !go) set_error(st, -5);                                 // "not used yet" (kmerspectrum.go:94-96)
+        if (go) atomicAdd(&st->n_elements, (unsigned long long)used);
+    }
+    if (!go) return;
+    const size_t B = (size_t)fb.num_bins;
+    if (st->skip_exact[fb.parity]) {                                             // k_flush_decide: only Wipe is left to do
+        uint32_t *hw = hists + (size_t)slot * B;
+        const int64_t w0 = (int64_t)seg * seg_chunks * 64, w1 = w0 + (int64_t)seg_chunks * 64;
+        for (int64_t b = w0 + tid; b < w1 && b < (int64_t)B; b += blockDim.x) hw[b] = 0;
+        return;
+    }
+    {
+        const unsigned long long *bt = base + (((size_t)t * depth) * CMS_SEGS) * width;
+        for (int i = tid; i < depth * width; i += blockDim.x) {
+            const int dd = i / width, p = i - dd * width;
+            lctr[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];
+        }
+    }
+    __syncthreads();
+    uint32_t *hist = hists + (size_t)slot * B;
+    double *ft = f64 + (size_t)t * B;
+    float *rt = rcp32 + (size_t)t * row_stride;
+    const int64_t b0 = (int64_t)seg * seg_chunks * 64;
+    const int ngroups = (seg_chunks + CMS_GROUP - 1) / CMS_GROUP;
+    constexpr int GB = CMS_GROUP * 64;
+    // software pipeline: the loads of group g+1 are issued before group g is processed
+    const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
+    const uint8_t *md = meta8 + (size_t)(d < depth ? d : 0) * B;
+    uint32_t nh[CMS_GROUP], np_[CMS_GROUP], nm[CMS_GROUP];
+    auto load_group = [&](int g) {
+#pragma unroll
+        for (int c = 0; c < CMS_GROUP; c++) {
+            const int ch = g * CMS_GROUP + c;
+            const int64_t b = b0 + (int64_t)ch * 64 + lane;
+            const bool ok = g < ngroups && ch < seg_chunks && b < (int64_t)B;
+            nh[c] = ok ? hist[b] : 0u;
+            if (d < depth) { np_[c] = ok ? pd[b] : 0u; nm[c] = ok ? md[b] : (64u | 0x80u); }
+        }
+    };
+    load_group(0);
+    uint32_t ph[CMS_GROUP];                                      // combiner: spectrum values of the group it finishes next
+#pragma unroll
+    for (int c = 0; c < CMS_GROUP; c++) ph[c] = 0;
+    for (int g = 0; g <= ngroups; g++) {
+        // rows: stage group g        combiner: finish group g-1
+        uint32_t hh[CMS_GROUP], pp[CMS_GROUP], mm[CMS_GROUP];
+#pragma unroll
+        for (int c = 0; c < CMS_GROUP; c++) { hh[c] = nh[c]; pp[c] = np_[c]; mm[c] = nm[c]; }
+        load_group(g + 1);
+        if (d < depth && g < ngroups) {
+            unsigned long long *my = stage + ((size_t)(g & 1) * depth + d) * GB;
+            unsigned long long *rc = lctr + (size_t)d * width;
+#pragma unroll
+            for (int c = 0; c < CMS_GROUP; c++) {
+                const int ch = g * CMS_GROUP + c;
+                if (ch >= seg_chunks) break;
+                const int64_t b = b0 + (int64_t)ch * 64 + lane;
+                const uint32_t h = hh[c], p = pp[c], m = mm[c];
+                // own count + the counts of the earlier lanes of this chunk that share the counter
+                uint32_t acc = h, cur = m & 0x7fu;
+                while (__any((int)(cur < 64u))) {
+                    const uint32_t oh = (uint32_t)__shfl((int)h, (int)(cur & 63u));
+                    const uint32_t oc = (uint32_t)__shfl((int)m, (int)(cur & 63u)) & 0x7fu;
+                    if (cur < 64u) { acc += oh; cur = oc; }
+                }
+                const unsigned long long est = rc[p] + acc;          // every lane reads before any lane writes
+                my[c * 64 + lane] = est;
+                if ((m & 0x80u) && b < (int64_t)B) rc[p] = est;      // last lane of the chunk for this counter
+            }
+        }
+        if (d == depth && g > 0) {
+            const unsigned long long *src = stage + ((size_t)((g - 1) & 1) * depth) * GB;
+#pragma unroll
+            for (int c = 0; c < CMS_GROUP; c++) {
+                const int ch = (g - 1) * CMS_GROUP + c;
+                if (ch >= seg_chunks) break;
+                const int64_t b = b0 + (int64_t)ch * 64 + lane;
+                if (b < (int64_t)B) {
+                    if (ph[c]) {
+                        unsigned long long mn = ~0ull;
+                        for (int dd = 0; dd < depth; dd++) { const unsigned long long e = src[(size_t)dd * GB + c * 64 + lane]; mn = e < mn ? e : mn; }
+                        const double f = (double)mn;
+                        ft[b] = f; rt[b] = (float)(1.0 / f);
+                        hist[b] = 0;                                 // Wipe (kmerspectrum.go:58-64)
+                    } else { ft[b] = 0.0; rt[b] = __builtin_nanf(""); }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CMS_GROUP; c++) ph[c] = hh[c];          // group g is finished by the combiner at g+1
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3 with uniform scaling (0 < decay < 1), bin-order form.  Counter (d,p) right after stream element j
+// is C(j) = w*C(j-1) + (v_j if element j hits it).  Over a bin segment holding elements [e0,e1):
+//     C(e1-1) = w^(e1-e0) * C(e0-1) + sum{ v_j * w^(e1-1-j) : hits }
+//   k_cmsd_segsum : the sum (one w^x per element, LDS fp64 atomics) and the factor per segment
+//   k_cmsd_base   : C in front of every (spectrum, segment), advancing the persistent fp64 counters
+//   k_cmsd_freq   : replay in bin order with lazily decayed LDS counters {value, time}; zero bins are
+//                   transparent; same-counter lanes of a 64-bin chunk resolve in lane order
+// (fp64 sums are re-associated w.r.t. the reference's step-by-step scaling: ~1e-13 relative)
+// ------------------------------------------------------------------------------------------
+// w^x for an element gap 0 <= x < 2^21 (a spectrum has < 2^20 elements): three 128-entry tables in LDS
+// (w^a, w^(128 b), w^(16384 c)) and two multiplications instead of an fp64 exp() per counter update — 3 ulp.
+constexpr int POWW_N = 384;
+__device__ __forceinline__ void poww_build(double *tab, double lnw, int tid, int nthreads) {
+    for (int i = tid; i < POWW_N; i += nthreads) {
+        const int lvl = i >> 7, a = i & 127;
+        tab[i] = exp((double)a * (lvl == 0 ? 1.0 : lvl == 1 ? 128.0 : 16384.0) * lnw);
+    }
+}
+__device__ __forceinline__ double poww(const double *tab, long long x, double lnw) {
+    if ((unsigned long long)x >= (1ull << 21)) return exp((double)x * lnw);
+    const uint32_t u = (uint32_t)x;
+    return tab[u & 127u] * tab[128u + ((u >> 7) & 127u)] * tab[256u + (u >> 14)];
+}
+constexpr int CMSD_GROUP = 2;         // chunks staged per barrier (LDS: 112 KB values + 28 KB times + 14 KB stage)
+
+__global__ __launch_bounds__(512) void k_cmsd_segsum(const uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
+                                                     const uint32_t *__restrict__ eidx, const uint32_t *__restrict__ etot,
+                                                     double *__restrict__ segadd, double *__restrict__ segfac,
+                                                     uint32_t *__restrict__ sege0, int depth, int width, int seg_chunks,
+                                                     double omega, const DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *ladd = (double *)smem;                                // [depth][width]
+    const int seg = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const uint32_t gomask = batch_gomask(st, fb);
+    if (!((gomask >> t) & 1u)) return;
+    for (int i = tid; i < depth * width; i += blockDim.x) ladd[i] = 0.0;
+    __syncthreads();
+    const size_t B = (size_t)fb.num_bins;
+    const uint32_t *hist = hists + (size_t)ring_slot(fb, t) * B;
+    const uint32_t *ei = eidx + (size_t)t * B;
+    const int64_t b0 = (int64_t)seg * seg_chunks * 64, b1 = b0 + (int64_t)seg_chunks * 64;
+    const uint32_t e0 = b0 < (int64_t)B ? ei[b0] : etot[t];
+    const uint32_t e1 = b1 < (int64_t)B ? ei[b1] : etot[t];
+    const double lnw = log(omega);                                // w^x = exp(x ln w): |x ln w| * 2^-53 relative, far below the tolerance
+    if (tid == 0) { segfac[(size_t)t * CMS_SEGS + seg] = exp((double)(e1 - e0) * lnw); sege0[(size_t)t * CMS_SEGS + seg] = e0; }
+    for (int64_t b = b0 + tid; b < b1 && b < (int64_t)B; b += blockDim.x) {
+        const uint32_t h = hist[b];
+        if (h) {
+            const double wgt = (double)h * exp((double)(e1 - 1u - ei[b]) * lnw);
+            for (int d = 0; d < depth; d++) atomicAdd(&ladd[d * width + pos16[(size_t)d * B + b]], wgt);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < depth * width; i += blockDim.x) {
+        const int dd = i / width, p = i - dd * width;
+        segadd[((((size_t)t * depth) + dd) * CMS_SEGS + seg) * width + p] = ladd[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cmsd_base(const double *__restrict__ segadd, const double *__restrict__ segfac,
+                                                   double *__restrict__ ctrd, double *__restrict__ cstart, int depth,
+                                                   int width, const DevState *st, FlushBatch fb) {
+    const uint32_t gomask = batch_gomask(st, fb);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= depth * width) return;
+    const int d = i / width, p = i - d * width;
+    double C = ctrd[i];
+    for (int t = 0; t < (int)fb.count; t++) {
+        if (!((gomask >> t) & 1u)) continue;
+        double sv[CMS_SEGS], fv[CMS_SEGS];
+        const size_t at0 = (((size_t)t * depth + d) * CMS_SEGS) * width + p;
+#pragma unroll
+        for (int seg = 0; seg < CMS_SEGS; seg++) { sv[seg] = segadd[at0 + (size_t)seg * width]; fv[seg] = segfac[(size_t)t * CMS_SEGS + seg]; }
+#pragma unroll
+        for (int seg = 0; seg < CMS_SEGS; seg++) { cstart[at0 + (size_t)seg * width] = C; C = C * fv[seg] + sv[seg]; }
+    }
+    ctrd[i] = C;
+}
+
+__global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
+                                                   const uint8_t *__restrict__ meta8, const uint32_t *__restrict__ eidx,
+                                                   const uint32_t *__restrict__ sege0, const double *__restrict__ cstart,
+                                                   double *__restrict__ f64, float *__restrict__ rcp32, int depth,
+                                                   int width, int seg_chunks, size_t row_stride, double omega,
+                                                   DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *lval = (double *)smem;                                               // [depth][width] counter value ...
+    double *stage = lval + (size_t)depth * width;                                // [2][depth][CMSD_GROUP*64]
+    uint16_t *ltime = (uint16_t *)(stage + (size_t)2 * depth * CMSD_GROUP * 64); // ... as of element e0 - 1 + ltime
+    const int seg = blockIdx.x, t = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;
+    const uint32_t gomask = batch_gomask(st, fb);
+    const bool go = (gomask >> t) & 1u;
+    const uint32_t slot = ring_slot(fb, t);
+    if (seg == 0 && tid == 0) {
+        const unsigned used = st->used[fb.parity][slot];
+        if (used != 0 && !go) set_error(st, -5);
+        if (go) atomicAdd(&st->n_elements, (unsigned long long)used);
+    }
+    if (!go) return;
+    const size_t B = (size_t)fb.num_bins;
+    {
+        const double *bt = cstart + (((size_t)t * depth) * CMS_SEGS) * width;
+        for (int i = tid; i < depth * width; i += blockDim.x) {
+            const int dd = i / width, p = i - dd * width;
+            lval[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];
+            ltime[i] = 0;
+        }
+    }
+    __syncthreads();
+    uint32_t *hist = hists + (size_t)slot * B;
+    const uint32_t *ei = eidx + (size_t)t * B;
+    double *ft = f64 + (size_t)t * B;
+    float *rt = rcp32 + (size_t)t * row_stride;
+    const int64_t b0 = (int64_t)seg * seg_chunks * 64;
+    const long long tref = (long long)sege0[(size_t)t * CMS_SEGS + seg] - 1;     // time of ltime == 0
+    const int ngroups = (seg_chunks + CMSD_GROUP - 1) / CMSD_GROUP;
+    constexpr int GB = CMSD_GROUP * 64;
+    const double lnw = log(omega);
+    __shared__ double pw[64];                                     // w^x for the gaps inside one 64-bin chunk
+    __shared__ double pwt[POWW_N];                                // ... and for any gap (poww)
+    if (tid < 64) pw[tid] = exp((double)tid * lnw);
+    poww_build(pwt, lnw, tid, (int)blockDim.x);
+    __syncthreads();
+    const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
+    const uint8_t *md = meta8 + (size_t)(d < depth ? d : 0) * B;
+    // the four per-bin inputs of group g+1 are requested before group g is computed: with one workgroup per CU
+    // (LDS) and a barrier per group, their latency was the kernel's time
+    uint32_t nh[CMSD_GROUP], np_[CMSD_GROUP], nm[CMSD_GROUP], nj[CMSD_GROUP];
+    auto fetch = [&](int g) {
+#pragma unroll
+        for (int c = 0; c < CMSD_GROUP; c++) {
+            const int ch = g * CMSD_GROUP + c;
+            const int64_t b = b0 + (int64_t)ch * 64 + lane;
+            nh[c] = 0; np_[c] = 0; nm[c] = 64u | 0x80u; nj[c] = 0;
+            if (d <= depth && ch < seg_chunks && b < (int64_t)B) {
+                nh[c] = hist[b];                                   // (the combiner wave, d == depth, needs only this one)
+                if (d < depth) { np_[c] = pd[b]; nm[c] = md[b]; nj[c] = ei[b]; }
+            }
+        }
+    };
+    fetch(0);
+    uint32_t ch_[CMSD_GROUP] = {}, cp[CMSD_GROUP], cm[CMSD_GROUP], cj[CMSD_GROUP], ph[CMSD_GROUP];
+    for (int g = 0; g <= ngroups; g++) {
+#pragma unroll
+        for (int c = 0; c < CMSD_GROUP; c++) { ph[c] = ch_[c]; ch_[c] = nh[c]; cp[c] = np_[c]; cm[c] = nm[c]; cj[c] = nj[c]; }
+        if (g + 1 < ngroups) fetch(g + 1);
+        if (d < depth && g < ngroups) {
+            double *my = stage + ((size_t)(g & 1) * depth + d) * GB;
+            double *rv = lval + (size_t)d * width;
+            uint16_t *rtm = ltime + (size_t)d * width;
+#pragma unroll
+            for (int c = 0; c < CMSD_GROUP; c++) {
+                const int ch = g * CMSD_GROUP + c;
+                if (ch >= seg_chunks) break;
+                const int64_t b = b0 + (int64_t)ch * 64 + lane;
+                const uint32_t h = ch_[c], p = cp[c], m = cm[c]; const long long j = (long long)cj[c];
+                // resolve the lanes in same-counter order: a lane is computed once its predecessor is
+                const uint32_t prev = m & 0x7fu;
+                bool ready = false; double C = 0.0; long long tj = 0;
+                if (prev >= 64u) {                                  // first lane of the chunk on this counter: LDS state
+                    const double C0 = rv[p]; const long long t0 = tref + (long long)rtm[p];
+                    if (h) { C = C0 * poww(pwt, j - t0, lnw) + (double)h; tj = j; } else { C = C0; tj = t0; }
+                    ready = true;
+                }
+                while (__any((int)!ready)) {
+                    const double pc = __shfl(C, (int)(prev & 63u));
+                    const long long pt = __shfl(tj, (int)(prev & 63u));
+                    const int pr = __shfl((int)ready, (int)(prev & 63u));
+                    if (!ready && pr) {
+                        if (h) { C = pc * pw[(int)(j - pt) & 63] + (double)h; tj = j; } else { C = pc; tj = pt; }   // gap < 64 inside a chunk
+                        ready = true;
+                    }
+                }
+                my[c * 64 + lane] = C;
+                if ((m & 0x80u) && b < (int64_t)B) { rv[p] = C; rtm[p] = (uint16_t)(tj - tref); }
+            }
+        }
+        if (d == depth && g > 0) {
+            const double *src = stage + ((size_t)((g - 1) & 1) * depth) * GB;
+            for (int c = 0; c < CMSD_GROUP; c++) {
+                const int ch = (g - 1) * CMSD_GROUP + c;
+                if (ch >= seg_chunks) break;
+                const int64_t b = b0 + (int64_t)ch * 64 + lane;
+                if (b < (int64_t)B) {
+                    if (ph[c]) {                                   // hist[b], fetched two groups ago
+                        double mn = INFINITY;
+                        for (int dd = 0; dd < depth; dd++) { const double e = src[(size_t)dd * GB + c * 64 + lane]; mn = e < mn ? e : mn; }
+                        ft[b] = mn; rt[b] = (float)(1.0 / mn);
+                        hist[b] = 0;
+                    } else { ft[b] = 0.0; rt[b] = __builtin_nanf(""); }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ==========================================================================================
+// Concept drift (decay_ratio != 1): reference src/countmin/countmin.go:49-56,103-110,141-147 and
+// src/histosketch/histosketch.go:79-81,139-153.
+//
+// Count-min with uniform scaling (0 < decay < 1): every Add() first multiplies ALL counters by
+// w = exp(-decay).  With i = index of an element inside its flush (ascending non-zero bins), the
+// counter (d,g) right after element i is  C0*w^(i+1) + sum{ v_j * w^(i-j) : j <= i, pos_d(b_j)=g },
+// i.e. along a chain the first-order recurrence  S_m = w^(gap_m) * S_{m-1} + v_m  — an affine scan.
+// (The reference multiplies step by step; the closed form differs by accumulated rounding of
+// ~gap*2^-53 relative, far inside the 1e-5 tolerance the north star states for CWS values.)
+// ==========================================================================================
+
+// element index of every bin = number of non-zero bins in front of it.  grid = (blocks, count)
+constexpr int EIDX_BLOCK = 2048;
+__global__ __launch_bounds__(256) void k_elem_count(const uint32_t *__restrict__ hists,
+                                                    uint32_t *__restrict__ blkcnt, int nblk, FlushBatch fb) {
+    __shared__ unsigned red[4];
+    const int t = blockIdx.y, blk = blockIdx.x;
+    const uint32_t *hist = hists + (size_t)ring_slot(fb, t) * (size_t)fb.num_bins;
+    unsigned cnt = 0;
+    for (int x = 0; x < EIDX_BLOCK / 256; x++) {
+        const int32_t b = blk * EIDX_BLOCK + x * 256 + threadIdx.x;
+        if (b < fb.num_bins) cnt += hist[b] != 0;
+    }
+    for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) blkcnt[(size_t)t * nblk + blk] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_elem_index(const uint32_t *__restrict__ hists,
+                                                    const uint32_t *__restrict__ blkcnt,
+                                                    uint32_t *__restrict__ eidx, uint32_t *__restrict__ etot,
+                                                    int nblk, FlushBatch fb) {
+    __shared__ unsigned red[4];
+    __shared__ unsigned wsum[4];
+    const int t = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const size_t B = (size_t)fb.num_bins;
+    const uint32_t *hist = hists + (size_t)ring_slot(fb, t) * B;
+    // offset of this block = sum of the counts of the blocks in front of it
+    unsigned off = 0, all = 0;
+    for (int x = tid; x < nblk; x += 256) { const unsigned c = blkcnt[(size_t)t * nblk + x]; all += c; if (x < blk) off += c; }
+    for (int o = 32; o; o >>= 1) { off += __shfl_xor(off, o); all += __shfl_xor(all, o); }
+    if (lane == 0) { red[wid] = off; wsum[wid] = all; }
+    __syncthreads();
+    off = red[0] + red[1] + red[2] + red[3];
+    if (blk == 0 && tid == 0) etot[t] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    // 8 consecutive bins per thread
+    const int32_t b0 = blk * EIDX_BLOCK + tid * 8;
+    unsigned nz[8]; unsigned mine = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++) { nz[x] = (b0 + x < fb.num_bins) ? (hist[b0 + x] != 0) : 0u; mine += nz[x]; }
+    unsigned incl = wave_scan_incl(mine);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    unsigned before = off + incl - mine;
+    for (int x = 0; x < wid; x++) before += wsum[x];
+#pragma unroll
+    for (int x = 0; x < 8; x++) { if (b0 + x < fb.num_bins) eidx[(size_t)t * B + b0 + x] = before; before += nz[x]; }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- host wrappers
+hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb) {
+    int blocks = (fb.num_bins + 2047) / 2048; if (blocks > 128) blocks = 128;
+    hipLaunchKernelGGL(k_count_used, dim3(blocks, fb.count), dim3(256), 0, s, d_hists, st, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
+                               unsigned long long *d_ctr, uint32_t *d_segsum, unsigned long long *d_base,
+                               double *d_f64, float *d_rcp32, int depth, int width, size_t row_stride,
+                               DevState *st, const FlushBatch &fb) {
+    const int chunks = (fb.num_bins + 63) / 64;
+    const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
+    const size_t lds1 = (size_t)depth * width * 4;
+    const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * depth * CMS_GROUP * 64 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_cms_freq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_cms_segsum, dim3(CMS_SEGS, fb.count), dim3(512), lds1, s, d_hists, d_pos16, d_segsum, depth, width,
+                       seg_chunks, st, fb);
+    hipLaunchKernelGGL(k_cms_base, dim3((depth * width + 255) / 256), dim3(256), 0, s, d_segsum, d_ctr, d_base, depth, width, st, fb);
+    hipLaunchKernelGGL(k_cms_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_meta8, d_base, d_f64,
+                       d_rcp32, depth, width, seg_chunks, row_stride, st, fb);
+    return hipGetLastError();
+}
+
+size_t cms_binorder_entries(int depth, int width) { return (size_t)depth * CMS_SEGS * width; }
+
+hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
+                                const uint32_t *d_eidx, const uint32_t *d_etot, double *d_ctrd, double *d_segadd,
+                                double *d_segfac, uint32_t *d_sege0, double *d_cstart, double *d_f64, float *d_rcp32,
+                                int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb) {
+    const int chunks = (fb.num_bins + 63) / 64;
+    const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
+    const size_t lds1 = (size_t)depth * width * 8;
+    const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * depth * CMSD_GROUP * 64 * 8 + (size_t)depth * width * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_cmsd_segsum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cmsd_freq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_cmsd_segsum, dim3(CMS_SEGS, fb.count), dim3(512), lds1, s, d_hists, d_pos16, d_eidx, d_etot, d_segadd,
+                       d_segfac, d_sege0, depth, width, seg_chunks, omega, st, fb);
+    hipLaunchKernelGGL(k_cmsd_base, dim3((depth * width + 255) / 256), dim3(256), 0, s, d_segadd, d_segfac, d_ctrd, d_cstart,
+                       depth, width, st, fb);
+    hipLaunchKernelGGL(k_cmsd_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_meta8, d_eidx, d_sege0,
+                       d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_elem_index(hipStream_t s, const uint32_t *d_hists, uint32_t *d_blkcnt, uint32_t *d_eidx,
+                             uint32_t *d_etot, const FlushBatch &fb) {
+    const int nblk = (fb.num_bins + EIDX_BLOCK - 1) / EIDX_BLOCK;
+    hipLaunchKernelGGL(k_elem_count, dim3(nblk, fb.count), dim3(256), 0, s, d_hists, d_blkcnt, nblk, fb);
+    hipLaunchKernelGGL(k_elem_index, dim3(nblk, fb.count), dim3(256), 0, s, d_hists, d_blkcnt, d_eidx, d_etot, nblk, fb);
+    return hipGetLastError();
+}
+
+int elem_index_blocks(int32_t num_bins) { return (num_bins + EIDX_BLOCK - 1) / EIDX_BLOCK; }
+
+}  // namespace hulk

@@ -1,0 +1,783 @@
+// hulk_cws.hip — consistent weighted sampling: the histosketch update, its tables, `hulk smash`.
+//   k_flush_decide     whole-batch bound: can any element still change the sketch?
+//   K4  k_cws_scan         fp32 pass over K = c*exp(b-r): per (interval, slot, tile) minimum, bound-pruned
+//       k_cws_resolve(+_drift)/k_cws_apply   exact fp64 re-evaluation with the literal formula of
+//                          src/histosketch/histosketch.go:30-33 and the slot update (histosketch.go:135-153)
+//       k_alfg_*/k_rng_candidates/k_cws_eval/k_cws_scatter/k_cws_beta/k_build_k32   the CWS tables (histosketch.go:95-126)
+//       k_smash            pairwise distances of `hulk smash`
+#include "hulk_device.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <algorithm>
+
+namespace hulk {
+namespace {
+
+// Wave-wide minima of 8 independent (non-NaN) values, transposed: 19 instructions instead of the 48
+// of six DPP butterfly steps per value (and hipcc emits mov+mov_dpp+canonicalise+min per step for the
+// equivalent builtins, 4x that again — hence one asm block).
+// v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / 16-lane rows between two
+// registers, so one swap + one v_min folds two rows' partial minima at once and halves the number of
+// live registers: 8 -> 4 (halves) -> 2 (rows); the two survivors are folded over 8-lane halves with
+// row_ror:8, merged into one register (lanes 8..15 of every row take the second) and finished with
+// three DPP steps inside groups of 8 lanes.  Lane l returns the wave minimum of value l / 8.
+__device__ __forceinline__ float wave_min8_by_row(float (&m)[8]) {
+    // one block: the swaps need 2 wait states after a VALU write of either operand (s_nop), DPP sources too
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %4\n\t"        // lanes 0..31: value j, lanes 32..63: value j+4
+                 "v_permlane32_swap_b32 %1, %5\n\t"
+                 "v_permlane32_swap_b32 %2, %6\n\t"
+                 "v_permlane32_swap_b32 %3, %7\n\t"
+                 "v_min_f32 %0, %0, %4\n\t"
+                 "v_min_f32 %2, %2, %6\n\t"
+                 "v_min_f32 %1, %1, %5\n\t"
+                 "v_min_f32 %3, %3, %7\n\t"
+                 "v_permlane16_swap_b32 %0, %2\n\t"        // 16-lane row q: value 2q
+                 "s_nop 0\n\t"
+                 "v_permlane16_swap_b32 %1, %3\n\t"        // 16-lane row q: value 2q+1
+                 "v_min_f32 %0, %0, %2\n\t"
+                 "v_min_f32 %1, %1, %3\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_min_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %1 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xc\n\t"   // lanes 8..15 of each row
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]));
+    return m[0];
+}
+
+// Whole-batch bound (no concept drift).  Every count-min estimate of the batch is at least the smallest
+// counter at batch start (an estimate is a minimum over counters that only grow), so A = K/f >= min_slot(K) / Cmin
+// for every negative K of a slot's row (>= 0 otherwise).  If that cannot get below the current weight of ANY slot
+// (same 1e-5 band as the scan), no AddElement of the batch can change the sketch: skip_exact is raised and
+// k_cms_freq only wipes the spectra, k_rcp_extrema / k_cws_scan / k_cws_resolve / k_cws_apply return at once.
+// The count-min counters are still advanced (k_cms_segsum + k_cms_base).  After the first intervals of a stream
+// this is the normal case: counters are in the tens of thousands while the winning weights came from f ~ 10.
+__global__ __launch_bounds__(1024) void k_flush_decide(const unsigned long long *__restrict__ ctr, int ncounters,
+                                                       const float *__restrict__ kminslot,
+                                                       const double *__restrict__ weights, int slots, int slot_begin,
+                                                       DevState *st, FlushBatch fb, int enable) {
+    __shared__ unsigned long long red[16];
+    __shared__ int anypass;
+    const int tid = threadIdx.x;
+    if (tid == 0) anypass = 0;
+    unsigned long long m = ~0ull;
+    for (int i = tid; i < ncounters; i += blockDim.x) { const unsigned long long v = ctr[i]; m = v < m ? v : m; }
+    for (int off = 32; off; off >>= 1) { const unsigned long long o = __shfl_xor(m, off); m = o < m ? o : m; }
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = red[0];
+    for (int i = 1; i < 16; i++) m = red[i] < m ? red[i] : m;
+    bool pass = false;
+    if (!enable || m == 0) pass = true;                          // an untouched counter: estimates can be as small as 1
+    else {
+        const double rmax = 1.0 / (double)m;
+        for (int s = tid; s < slots; s += blockDim.x) {
+            const double km = (double)kminslot[s];
+            const double w = weights[slot_begin + s];
+            const double thr = w + 1e-5 * fabs(w) + 1e-37;
+            const double bound = km < 0.0 ? km * rmax : 0.0;
+            if (bound <= thr) pass = true;
+        }
+    }
+    if (pass) atomicOr(&anypass, 1);
+    __syncthreads();
+    if (tid == 0) st->skip_exact[fb.parity] = anypass ? 0u : 1u;
+}
+__global__ __launch_bounds__(256) void k_slot_kmin(const float *__restrict__ kmin32, float *__restrict__ kminslot, int wtiles) {
+    __shared__ float red[4];
+    const int slot = blockIdx.x;
+    float m = INFINITY;
+    for (int i = threadIdx.x; i < wtiles; i += blockDim.x) m = fminf(m, kmin32[(size_t)slot * wtiles + i]);
+    for (int off = 32; off; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) kminslot[slot] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+}
+
+// Static per (slot, 256-bin wave tile) minimum of K32, and per flush the extrema of the reciprocal
+// vectors per (interval, wave tile): the inputs of k_cws_scan's bound test.
+__global__ __launch_bounds__(256) void k_tile_kmin(const float *__restrict__ k32, float *__restrict__ kmin32,
+                                                   int ntiles, size_t row_stride) {
+    const int slot = blockIdx.y, tile = blockIdx.x, wid = threadIdx.x >> 6;
+    const floatx4 v = *(const floatx4 *)(k32 + (size_t)slot * row_stride + (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * 4);
+    float m = fminf(fminf(v.x, v.y), fminf(v.z, v.w));
+    for (int off = 32; off; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) kmin32[(size_t)slot * (size_t)(ntiles * 4) + (size_t)(tile * 4 + wid)] = m;
+}
+__global__ __launch_bounds__(256) void k_rcp_extrema(const float *__restrict__ rcp32, float *__restrict__ rext,
+                                                     int ntiles, size_t row_stride, const DevState *st, FlushBatch fb) {
+    if (st->skip_exact[fb.parity]) return;
+    const int t = blockIdx.y, tile = blockIdx.x, wid = threadIdx.x >> 6;
+    const floatx4 v = *(const floatx4 *)(rcp32 + (size_t)t * row_stride + (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * 4);
+    // NaN = bin not in the stream: fmaxf / fminf return the other operand
+    float hi = fmaxf(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), -INFINITY);
+    float lo = fminf(fminf(fminf(v.x, v.y), fminf(v.z, v.w)), INFINITY);
+    for (int off = 32; off; off >>= 1) { hi = fmaxf(hi, __shfl_xor(hi, off)); lo = fminf(lo, __shfl_xor(lo, off)); }
+    if ((threadIdx.x & 63) == 0) {
+        float *o = rext + ((size_t)t * (size_t)(ntiles * 4) + (size_t)(tile * 4 + wid)) * 2;
+        o[0] = hi; o[1] = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4a: the HBM-bound pass.  A[t][slot][bin] = K[slot][bin] * (1/f_t[bin]); minimum per
+// (interval t, slot, 256-bin wave tile).  A workgroup streams SCAN_ROWS rows x SCAN_TILE bins of K
+// exactly once (16 B per lane per row, SCAN_ROWS independent loads in flight) and re-uses the
+// registers for every interval of the batch, so the table is read once per BATCH, not per interval.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
+                                                  const float *__restrict__ rcp32,
+                                                  float *__restrict__ tilemin, int slots, int ntiles,
+                                                  size_t row_stride, const DevState *st, FlushBatch fb,
+                                                  const float *__restrict__ kmin32, const float *__restrict__ rext,
+                                                  const double *__restrict__ weights, int slot_begin,
+                                                  unsigned long long *__restrict__ visited, double drift_dw) {
+    // XCD-aware order (workgroup b lands on XCD b % 8): XCD x works through column tile 8*chunk + x for
+    // ALL slot groups before moving on, so a column's reciprocal vectors (T x 4 KB) are fetched into
+    // that XCD's L2 once and re-used by the other groups; the 8 XCDs stream 8 adjacent 4 KB pieces of
+    // the same K rows at the same time (32 KB contiguous per row).
+    if (st->skip_exact[fb.parity]) return;                       // k_flush_decide: nothing in this batch can matter
+    const int ngrp = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    const int chunk = blockIdx.x / (8 * ngrp), rem = blockIdx.x % (8 * ngrp);
+    const int grp = rem / 8, tile = chunk * 8 + (rem % 8);
+    if (tile >= ntiles) return;
+    const int tid = threadIdx.x, wid = tid >> 6;
+    const size_t col = (size_t)tile * SCAN_TILE + (size_t)tid * 4;
+    const int wtiles = ntiles * 4;                               // 256-bin wave tiles per row
+    const uint32_t gomask = batch_gomask(st, fb);
+    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    const int lane = tid & 63;
+    // ---- branch and bound (no concept drift): AddElement only ever replaces a slot's weight by a SMALLER
+    // A, and A = K * (1/f) >= min(K) * max(1/f) over a tile (min(K) < 0; min(K) * min(1/f) otherwise).  A wave
+    // tile whose bound cannot get below the slot's current weight for any row and interval of the batch is
+    // not read at all — after the first intervals of a stream that is nearly every tile, because count-min
+    // estimates only grow.  The weights at batch start are used (they only fall during the batch), with the
+    // same 1e-5 relative band the fp64 resolve uses around fp32 values; skipped tiles report +inf.
+    if (kmin32) {
+        const int wt = tile * 4 + wid, row = lane & 7, slot = grp * SCAN_ROWS + row;
+        bool pass = false;
+        if (slot < slots) {
+            const double km = (double)kmin32[(size_t)slot * wtiles + wt];
+            double w = weights[slot_begin + slot];
+            // concept drift (drift_dw = decayWeight > 0): the update test is A < w / decayWeight and w may move either
+            // way — but a NEGATIVE weight can only be replaced by a smaller one (A < w/dw < w), so its threshold of
+            // the whole batch is at most w_start / dw; a slot whose weight is not negative is simply never pruned
+            bool never = false;
+            if (drift_dw > 0.0) { if (w < 0.0) w = w / drift_dw; else never = true; }
+            const double thr = w + 1e-5 * fabs(w) + 1e-37;
+            if (never) pass = true;
+            for (int t = lane >> 3; t < (int)fb.count; t += 8) {
+                if (!((gomask >> t) & 1u)) continue;
+                const float rmax = rext[((size_t)t * wtiles + wt) * 2], rmin = rext[((size_t)t * wtiles + wt) * 2 + 1];
+                if (!(rmax > 0.f)) continue;                     // no element of this interval falls into the tile
+                const double bound = km < 0.0 ? km * (double)rmax : km * (double)rmin;
+                if (bound <= thr) pass = true;
+            }
+        }
+        if (!__ballot(pass)) {
+            for (int t = lane >> 3; t < (int)fb.count; t += 8)
+                tilemin[(((size_t)t * ngroups + grp) * wtiles + (size_t)wt) * SCAN_ROWS + row] = INFINITY;
+            return;
+        }
+        if (lane == 0) atomicAdd(&visited[blockIdx.x & (MIN_SLOTS - 1)], 1ull);
+    }
+    floatx4 kv[SCAN_ROWS];
+#pragma unroll
+    for (int r = 0; r < SCAN_ROWS; r++) {
+        const int slot = grp * SCAN_ROWS + r;
+        if (slot < slots)
+            kv[r] = __builtin_nontemporal_load((const floatx4 *)(k32 + (size_t)slot * row_stride + col));
+        else
+            kv[r] = (floatx4)(0.f);
+    }
+    floatx4 rc_next = *(const floatx4 *)(rcp32 + col);
+    for (int t = 0; t < (int)fb.count; t++) {
+        const floatx4 rc = rc_next;
+        if (t + 1 < (int)fb.count) rc_next = *(const floatx4 *)(rcp32 + (size_t)(t + 1) * row_stride + col);
+        if (!((gomask >> t) & 1u)) continue;
+        float m[SCAN_ROWS];
+        // v_mul_f32 x4 + v_min3_f32 x2 per row.  (v_pk_mul_f32 halves the multiplies but runs this loop 2x
+        // SLOWER on MI355X — measured 304 vs 150 us — so the products stay scalar.)  NaN (bin not in the
+        // stream) loses every v_min; INFINITY keeps an all-NaN lane out of the reduction.
+#pragma unroll
+        for (int r = 0; r < SCAN_ROWS; r++)
+            m[r] = fminf(fminf(fminf(fminf(kv[r].x * rc.x, kv[r].y * rc.y), kv[r].z * rc.z), kv[r].w * rc.w), INFINITY);
+        static_assert(SCAN_ROWS == 8, "wave_min8_by_row reduces exactly 8 rows");
+        const float mine = wave_min8_by_row(m);                    // lane l: minimum of row l / 8 over the wave
+        // tilemin[t][slot group][wave tile][row]: 8 lanes write the 8 rows of a wave tile (32 contiguous bytes)
+        if ((lane & 7) == 0)
+            tilemin[(((size_t)t * ngroups + grp) * wtiles + (size_t)(tile * 4 + wid)) * SCAN_ROWS + (lane >> 3)] = mine;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4b: per slot, interval by interval: re-evaluate in fp64 — with the literal getSample formula —
+// every wave tile whose fp32 minimum is within a relative band of the slot's fp32 minimum, then
+// apply AddElement's update rule.  The band (1e-5 rel + 1e-37 abs) is >30x the worst fp32 error
+// of K4a, so the true fp64 argmin (and every exact tie, for earliest-wins) is always inside a
+// re-evaluated tile.
+// ------------------------------------------------------------------------------------------
+constexpr int WTILE = SCAN_TILE / 4;
+__global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ rcb,
+                                                     const double *__restrict__ f64,
+                                                     const float *__restrict__ tilemin,
+                                                     double *__restrict__ candA, int32_t *__restrict__ candB,
+                                                     int slots, int ntiles, const DevState *st,
+                                                     FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *tm = (float *)smem;                       // [wtiles]
+    __shared__ float redf[4];
+    __shared__ double redA[4];
+    __shared__ int32_t redB[4];
+    __shared__ int ncand;
+    __shared__ int cand[64];
+    if (st->skip_exact[fb.parity]) return;
+    const int slot = blockIdx.x, t = blockIdx.y;     // local slot, interval of the batch
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wtiles = ntiles * 4;
+    const int32_t num_bins = fb.num_bins;
+    double bestA = INFINITY; int32_t bestB = 0x7fffffff;
+    if (flush_go(st, fb, t)) {                        // block-uniform
+        const double *row = rcb + (size_t)slot * (size_t)num_bins * 3;
+        const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+        const float *tmin_t = tilemin + (((size_t)t * ngroups + slot / SCAN_ROWS) * wtiles) * SCAN_ROWS + (slot % SCAN_ROWS);
+        const double *ft = f64 + (size_t)t * (size_t)num_bins;
+        if (tid == 0) ncand = 0;
+        float g = INFINITY;
+        for (int x = tid; x < wtiles; x += blockDim.x) {
+            const float v = tmin_t[(size_t)x * SCAN_ROWS];
+            tm[x] = v;
+            g = fminf(g, v);
+        }
+        for (int off = 32; off; off >>= 1) g = fminf(g, __shfl_xor(g, off));
+        if (lane == 0) redf[wid] = g;
+        __syncthreads();
+        g = fminf(fminf(redf[0], redf[1]), fminf(redf[2], redf[3]));
+        if (g < INFINITY) {                           // some element reached this slot's row
+            const float thr = g + 1e-5f * fabsf(g) + 1e-37f;
+            // candidate wave tiles (normally one): every tile whose fp32 minimum is inside the band
+            bool overflow = false;
+            for (int x = tid; x < wtiles; x += blockDim.x)
+                if (tm[x] <= thr) { const int at = atomicAdd(&ncand, 1); if (at < 64) cand[at] = x; else overflow = true; }
+            __syncthreads();
+            const int nc = ncand;                     // block-uniform
+            if (nc <= 64) {
+                for (int ci = 0; ci < nc; ci++) {
+                    const int32_t bin = cand[ci] * WTILE + tid;      // WTILE == blockDim.x
+                    if (bin < num_bins) {
+                        const double f = ft[bin];
+                        if (f != 0.0) {
+                            const double r = row[(size_t)bin * 3 + 0];
+                            const double c = row[(size_t)bin * 3 + 1];
+                            const double b = row[(size_t)bin * 3 + 2];
+                            const double Yka = exp(log(f) - b);
+                            const double A = c / (Yka * exp(r));
+                            if (A < bestA || (A == bestA && bin < bestB)) { bestA = A; bestB = bin; }
+                        }
+                    }
+                }
+            } else {
+                // degenerate spectrum (many equal minima): evaluate every tile inside the band
+                for (int x = 0; x < wtiles; x++) {
+                    if (!(tm[x] <= thr)) continue;
+                    const int32_t bin = x * WTILE + tid;
+                    if (bin < num_bins) {
+                        const double f = ft[bin];
+                        if (f != 0.0) {
+                            const double r = row[(size_t)bin * 3 + 0];
+                            const double c = row[(size_t)bin * 3 + 1];
+                            const double b = row[(size_t)bin * 3 + 2];
+                            const double Yka = exp(log(f) - b);
+                            const double A = c / (Yka * exp(r));
+                            if (A < bestA || (A == bestA && bin < bestB)) { bestA = A; bestB = bin; }
+                        }
+                    }
+                }
+            }
+            (void)overflow;
+            for (int off = 32; off; off >>= 1) {
+                const double oA = __shfl_xor(bestA, off);
+                const int32_t oB = __shfl_xor(bestB, off);
+                if (oA < bestA || (oA == bestA && oB < bestB)) { bestA = oA; bestB = oB; }
+            }
+            if (lane == 0) { redA[wid] = bestA; redB[wid] = bestB; }
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                if (redA[x] < bestA || (redA[x] == bestA && redB[x] < bestB)) { bestA = redA[x]; bestB = redB[x]; }
+        }
+    }
+    if (tid == 0) { candA[(size_t)t * slots + slot] = bestA; candB[(size_t)t * slots + slot] = bestB; }
+}
+
+// AddElement's slot update (histosketch.go:150-153, no drift) in interval order: the element with
+// the smallest A of interval t replaces the slot iff it is strictly below the running weight.
+__global__ void k_cws_apply(const double *__restrict__ candA, const int32_t *__restrict__ candB,
+                            unsigned long long *__restrict__ mins, double *__restrict__ weights,
+                            int slots, int slot_begin, const DevState *st, FlushBatch fb) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= slots || st->skip_exact[fb.parity]) return;
+    const int gs = slot_begin + slot;
+    double w = weights[gs]; unsigned long long m = mins[gs];
+    for (int t = 0; t < (int)fb.count; t++) {
+        if (!flush_go(st, fb, t)) continue;
+        const double A = candA[(size_t)t * slots + slot];
+        const int32_t b = candB[(size_t)t * slots + slot];
+        if (b != 0x7fffffff && A < w) { w = A; m = (unsigned long long)b; }
+    }
+    weights[gs] = w; mins[gs] = m;
+}
+
+// AddElement with concept drift, per slot, in stream order:  if A < w/decayWeight { w = A; min = bin }
+// (histosketch.go:139-153).  Not a minimum: w may move either way, so elements are taken in order,
+// but a wave tile whose fp32 minimum is not below the current threshold (with the fp32 band) cannot
+// contain a trigger and is skipped; tiles that may are evaluated in fp64 and replayed exactly.
+__global__ __launch_bounds__(256) void k_cws_resolve_drift(const double *__restrict__ rcb,
+                                                           const double *__restrict__ f64,
+                                                           const float *__restrict__ tilemin,
+                                                           unsigned long long *__restrict__ mins,
+                                                           double *__restrict__ weights, int slots,
+                                                           int slot_begin, int ntiles, double decay_weight,
+                                                           const DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *tm = (float *)smem;                       // [wtiles]
+    __shared__ int redi[4];
+    __shared__ double s_w;
+    __shared__ int s_first;
+    const int slot = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wtiles = ntiles * 4, ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    const int32_t num_bins = fb.num_bins;
+    const int gs = slot_begin + slot;
+    const double *row = rcb + (size_t)slot * (size_t)num_bins * 3;
+    double w = weights[gs];
+    unsigned long long wm = mins[gs];
+    const uint32_t gomask = batch_gomask(st, fb);
+
+    for (int t = 0; t < (int)fb.count; t++) {
+        if (!((gomask >> t) & 1u)) continue;
+        __syncthreads();
+        const float *tmin_t = tilemin + (((size_t)t * ngroups + slot / SCAN_ROWS) * wtiles) * SCAN_ROWS + (slot % SCAN_ROWS);
+        const double *ft = f64 + (size_t)t * (size_t)num_bins;
+        for (int x = tid; x < wtiles; x += blockDim.x) tm[x] = tmin_t[(size_t)x * SCAN_ROWS];
+        __syncthreads();
+        int from = 0;                                 // first tile not yet passed
+        for (;;) {
+            // first tile >= from that may hold a trigger for the current threshold
+            const double thr = w / decay_weight;      // curMin of the reference (IEEE: +-Inf / NaN when weight is 0)
+            int first = 0x7fffffff;
+            if (!(thr != thr)) {                       // NaN threshold: nothing compares below it
+                // fp32 screen; the band keeps it conservative (fp32 error of K*rcp is ~2e-7 relative)
+                const double lim = thr + 1e-5 * fabs(thr) + 1e-37;
+                for (int x = from + tid; x < wtiles; x += blockDim.x)
+                    if ((double)tm[x] <= lim || !(lim < INFINITY)) { first = x; break; }
+            }
+            for (int off = 32; off; off >>= 1) { const int o = __shfl_xor(first, off); first = o < first ? o : first; }
+            if (lane == 0) redi[wid] = first;
+            __syncthreads();
+            first = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+            __syncthreads();
+            if (first == 0x7fffffff) break;           // block-uniform
+            // exact replay of tile `first`: one element per thread, in bin order
+            const int32_t bin = first * WTILE + tid;
+            double A = INFINITY; bool elem = false;
+            if (bin < num_bins) {
+                const double f = ft[bin];
+                if (f != 0.0) {
+                    const double r = row[(size_t)bin * 3 + 0], c = row[(size_t)bin * 3 + 1], b = row[(size_t)bin * 3 + 2];
+                    const double Yka = exp(log(f) - b);
+                    A = c / (Yka * exp(r));
+                    elem = true;
+                }
+            }
+            int pos = 0;                              // next position of the tile to look at
+            for (;;) {
+                const double th = w / decay_weight;
+                int hit = 0x7fffffff;
+                if (elem && tid >= pos && A < th) hit = tid;
+                for (int off = 32; off; off >>= 1) { const int o = __shfl_xor(hit, off); hit = o < hit ? o : hit; }
+                if (lane == 0) redi[wid] = hit;
+                __syncthreads();
+                hit = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+                if (hit != 0x7fffffff && tid == hit) { s_w = A; s_first = bin; }
+                __syncthreads();
+                if (hit == 0x7fffffff) break;
+                w = s_w; wm = (unsigned long long)s_first;
+                pos = hit + 1;
+            }
+            from = first + 1;
+        }
+    }
+    if (tid == 0) { weights[gs] = w; mins[gs] = wm; }
+}
+
+// ==========================================================================================
+// newCWS on the device (histosketch.go:95-126).  The host walks Go's math/rand stream and hands
+// over the (u1, u2) raw values of every Cheng attempt (cws_gen.h); here all attempts of a chunk are
+// evaluated in parallel and the accepted gamma variates are compacted IN ORDER into the table:
+// gamma #n -> entry n/2 = slot*B + bin, r if n is even, c = ln(gamma) if n is odd.
+// ==========================================================================================
+// ---- Go math/rand's additive lagged-Fibonacci stream, generated on the device -------------------
+// y[m] = y[m-607] + y[m-273] (mod 2^64).  The stream itself does not depend on how the gamma sampler consumes it,
+// so it is produced in chunks of 2^GO_RNG_JUMP_LOG2 values: k_alfg_jump walks the chunk start states with the
+// jump polynomial (go_rng_jump.h: y[n + C + j] = sum_i coef[i] * y[n + i + j]), k_alfg_fill expands every chunk in
+// parallel, 256 values per step (the shorter lag is 273).  windows[c] = the 607 values that end where chunk c begins.
+__global__ __launch_bounds__(640) void k_alfg_jump(const uint64_t *__restrict__ coef, uint64_t *__restrict__ windows,
+                                                   uint32_t first_chunk, uint32_t n_chunks) {
+    __shared__ uint64_t E[1216], C[608];
+    const int tid = threadIdx.x;
+    if (tid < 607) { C[tid] = coef[tid]; E[tid] = windows[(size_t)first_chunk * 607 + tid]; }
+    __syncthreads();
+    for (uint32_t c = first_chunk; c + 1 < first_chunk + n_chunks; c++) {
+        for (int base = 607; base < 1213; base += 273) {          // extend the window by 606 values, 273 at a time
+            const int j = base + tid;
+            if (tid < 273 && j < 1213) E[j] = E[j - 607] + E[j - 273];
+            __syncthreads();
+        }
+        uint64_t acc = 0;
+        if (tid < 607) for (int i = 0; i < 607; i++) acc += C[i] * E[i + tid];
+        __syncthreads();
+        if (tid < 607) { E[tid] = acc; windows[(size_t)(c + 1) * 607 + tid] = acc; }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_alfg_fill(const uint64_t *__restrict__ windows, uint64_t *__restrict__ raw,
+                                                   uint32_t first_chunk, uint64_t chunk_len) {
+    __shared__ uint64_t ring[1024];                               // the last 607 values live in a ring of 1024
+    const int tid = threadIdx.x;
+    const uint32_t c = first_chunk + blockIdx.x;
+    const uint64_t *w = windows + (size_t)c * 607;
+    for (int i = tid; i < 607; i += 256) ring[(1024 - 607 + i) & 1023] = w[i];   // window value i sits at position i - 607
+    __syncthreads();
+    uint64_t *out = raw + (size_t)c * chunk_len;
+    for (uint64_t n = 0; n < chunk_len; n += 256) {
+        const uint32_t at = (uint32_t)(n + tid);
+        const uint64_t v = ring[(at - 607u) & 1023u] + ring[(at - 273u) & 1023u];
+        __syncthreads();                                          // every read of this step before any write
+        ring[at & 1023u] = v;
+        out[n + tid] = v;
+        __syncthreads();
+    }
+}
+// positions of the stream whose value fails the gamma sampler's u1 range test or would make Float64() resample
+// (type 1): rare (2e-7 / 2^-54 per value), resolved on the host into the `ev` list of k_cws_eval
+__global__ __launch_bounds__(256) void k_rng_candidates(const uint64_t *__restrict__ raw, uint64_t n,
+                                                        uint64_t *__restrict__ list, uint32_t cap,
+                                                        unsigned int *__restrict__ count) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t x = raw[i] & 0x7fffffffffffffffull;
+        const double u = (double)(long long)x * 0x1p-63;
+        const bool skip = u == 1.0, fail = !(1e-7 < u && u < .9999999);
+        if (skip || fail) {
+            const unsigned at = atomicAdd(count, 1u);
+            if (at < cap) list[at] = (i << 1) | (skip ? 1ull : 0ull);
+        }
+    }
+}
+
+constexpr int CWS_BLOCK = 1024;     // attempts per block (256 threads x 4)
+
+// `pairs` is either the host-prepared (u1, u2) list of this chunk (raw == nullptr) or, in raw mode, unused: attempt
+// g = first_attempt + i then reads the device-resident math/rand stream at raw[2g + d], raw[2g + d + 1], where d is
+// the number of earlier attempts that died on the u1 range test (each consumed ONE value; `ev` holds, sorted, the
+// index of the valid attempt that followed each of them).
+__global__ __launch_bounds__(256) void k_cws_eval(const uint64_t *__restrict__ pairs, uint64_t n_attempts,
+                                                  double *__restrict__ val, uint32_t *__restrict__ blkcnt,
+                                                  double ainv, double bbb, double ccc, double magic,
+                                                  const uint64_t *__restrict__ raw, uint64_t first_attempt,
+                                                  const uint64_t *__restrict__ ev, uint32_t n_ev) {
+    __shared__ unsigned red[4];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int x = 0; x < CWS_BLOCK / 256; x++) {
+        const uint64_t i = (uint64_t)blockIdx.x * CWS_BLOCK + (uint64_t)x * 256 + threadIdx.x;
+        double out = -1.0;                                       // < 0 marks a rejected attempt
+        if (i < n_attempts) {
+            uint64_t p0, p1;
+            if (raw) {
+                const uint64_t g = first_attempt + i;
+                uint32_t lo = 0, hi = n_ev;                      // upper_bound(ev, g)
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ev[mid] <= g) lo = mid + 1; else hi = mid; }
+                const uint64_t a = 2 * g + lo;
+                p0 = raw[a] & 0x7fffffffffffffffull; p1 = raw[a + 1] & 0x7fffffffffffffffull;
+            } else { p0 = pairs[2 * i]; p1 = pairs[2 * i + 1]; }
+            const double u1 = (double)(long long)p0 * 0x1p-63;
+            const double u2 = 1.0 - (double)(long long)p1 * 0x1p-63;
+            const double v = log(u1 / (1.0 - u1)) / ainv;
+            const double xx = 2.0 * exp(v);
+            const double z = u1 * u1 * u2;
+            const double r = bbb + ccc * v - xx;
+            if (r + magic - 4.5 * z >= 0.0 || r >= log(z)) { out = xx * 1.0; cnt++; }
+            val[i] = out;
+        }
+    }
+    for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) blkcnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of the block counts (single workgroup), advancing the running gamma count
+__global__ __launch_bounds__(1024) void k_cws_scan_blocks(uint32_t *__restrict__ blkcnt, uint32_t nblk,
+                                                          unsigned long long *__restrict__ gamma_total,
+                                                          unsigned long long *__restrict__ chunk_base) {
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t per = (nblk + 1023) / 1024;
+    const uint32_t lo = (uint32_t)tid * per, hi = lo + per < nblk ? lo + per : nblk;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += blkcnt[i];
+    const uint32_t incl = wave_scan_incl(sum);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    uint32_t before = incl - sum;
+    for (int x = 0; x < wid; x++) before += wsum[x];
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t c = blkcnt[i]; blkcnt[i] = before; before += c; }
+    if (tid == 1023) { *chunk_base = *gamma_total; *gamma_total += before; }
+}
+
+__global__ __launch_bounds__(256) void k_cws_scatter(const double *__restrict__ val, uint64_t n_attempts,
+                                                     const uint32_t *__restrict__ blkoff,
+                                                     const unsigned long long *__restrict__ chunk_base,
+                                                     double *__restrict__ rcb, uint64_t num_bins,
+                                                     uint64_t slot_begin, uint64_t slots, uint64_t sketch_size) {
+    __shared__ unsigned wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint64_t i0 = (uint64_t)blockIdx.x * CWS_BLOCK + (uint64_t)tid * 4;   // 4 consecutive attempts per thread
+    double v[4]; unsigned mine = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) { v[x] = (i0 + x < n_attempts) ? val[i0 + x] : -1.0; mine += v[x] >= 0.0; }
+    const unsigned incl = wave_scan_incl(mine);
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    unsigned long long n = *chunk_base + blkoff[blockIdx.x] + (incl - mine);
+    for (int x = 0; x < wid; x++) n += wsum[x];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        if (v[x] >= 0.0) {
+            const unsigned long long entry = n >> 1;                  // slot * B + bin
+            const unsigned long long slot = entry / num_bins;
+            if (slot >= slot_begin && slot < slot_begin + slots && slot < sketch_size) {
+                const unsigned long long at = (entry - slot_begin * num_bins) * 3 + (n & 1ull);
+                rcb[at] = (n & 1ull) ? log(v[x]) : v[x];              // r = Gamma(2,1); c = ln(Gamma(2,1))
+            }
+            n++;
+        }
+    }
+}
+
+// b = U(0,1) * r with the separate uniform generator: entry i uses its i-th Float64
+__global__ __launch_bounds__(256) void k_cws_beta(const uint64_t *__restrict__ uraw, uint64_t first_entry,
+                                                  uint64_t n, double *__restrict__ rcb, uint64_t num_bins,
+                                                  uint64_t slot_begin, uint64_t slots) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t entry = first_entry + i, slot = entry / num_bins;
+        if (slot >= slot_begin && slot < slot_begin + slots) {
+            const uint64_t at = (entry - slot_begin * num_bins) * 3;
+            const double u = 0.0 + (double)(long long)(uraw[i] & 0x7fffffffffffffffull) * 0x1p-63 * (1.0 - 0.0);   // Float64Range(0, 1)
+            rcb[at + 2] = u * rcb[at];
+        }
+    }
+}
+
+// ==========================================================================================
+// hulk smash: pairwise distance matrix over N sketches of S slots.
+// distances.GetDistance "jaccard" (distances.go:19-26) and GetWJD (distances.go:44-72) with the
+// reference's quirk that BOTH weight vectors come from the subject sketch (sketchio.go:293-301).
+// Thread (s, q) accumulates over the slots IN ORDER, so the fp64 sums are bit-identical to the Go
+// loops; a 16x16 tile of pairs shares the slot chunks of its 16 subjects / 16 queries through LDS.
+// ==========================================================================================
+constexpr int SMASH_T = 16, SMASH_CH = 64;
+__global__ __launch_bounds__(256) void k_smash(const unsigned long long *__restrict__ mins,
+                                               const double *__restrict__ weights, uint32_t N, uint32_t S,
+                                               int metric, double *__restrict__ out) {
+    __shared__ unsigned long long ma[SMASH_T][SMASH_CH + 1], mb[SMASH_T][SMASH_CH + 1];
+    __shared__ double wa[SMASH_T][SMASH_CH + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;        // query, subject inside the tile
+    const uint32_t s = blockIdx.y * SMASH_T + ty, q = blockIdx.x * SMASH_T + tx;
+    double intersect = 0.0, uni = 0.0;
+    for (uint32_t c0 = 0; c0 < S; c0 += SMASH_CH) {
+        for (int i = threadIdx.x; i < SMASH_T * SMASH_CH; i += 256) {
+            const int r = i / SMASH_CH, c = i % SMASH_CH;
+            const uint32_t sa = blockIdx.y * SMASH_T + r, qb = blockIdx.x * SMASH_T + r, col = c0 + c;
+            const bool okc = col < S;
+            ma[r][c] = (okc && sa < N) ? mins[(size_t)sa * S + col] : 0ull;
+            wa[r][c] = (okc && sa < N) ? weights[(size_t)sa * S + col] : 0.0;
+            mb[r][c] = (okc && qb < N) ? mins[(size_t)qb * S + col] : 0ull;
+        }
+        __syncthreads();
+        const uint32_t lim = S - c0 < (uint32_t)SMASH_CH ? S - c0 : (uint32_t)SMASH_CH;
+        if (metric == 1) {
+            for (uint32_t c = 0; c < lim; c++) {
+                // math.Max(math.Max(w,0), math.Max(-w,0)) == |w| (NaN stays NaN); weightB == weightA
+                const double wgt = fabs(wa[ty][c]);
+                if ((double)ma[ty][c] == (double)mb[tx][c]) { intersect += wgt; uni += wgt; }
+                else uni += wgt;
+            }
+        } else {
+            for (uint32_t c = 0; c < lim; c++) if ((double)ma[ty][c] == (double)mb[tx][c]) intersect += 1.0;
+        }
+        __syncthreads();
+    }
+    if (s < N && q < N)
+        out[(size_t)s * N + q] = metric == 1 ? 1 - (intersect / uni) : 1.0 - (intersect / (double)S);
+}
+
+// K = c * exp(b - r) in fp64, rounded once to fp32 (pad columns stay 0: 0 * NaN = NaN, ignored)
+__global__ __launch_bounds__(256) void k_build_k32(const double *__restrict__ rcb,
+                                                   float *__restrict__ k32, int32_t num_bins,
+                                                   size_t row_stride) {
+    const int slot = blockIdx.y;
+    const double *row = rcb + (size_t)slot * (size_t)num_bins * 3;
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < row_stride;
+         b += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (b < (size_t)num_bins) {
+            const double r = row[b * 3 + 0], c = row[b * 3 + 1], bb = row[b * 3 + 2];
+            v = (float)(c * exp(bb - r));
+        }
+        k32[(size_t)slot * row_stride + b] = v;
+    }
+}
+
+// self-test: RN(1/r) by Newton == IEEE division for every r in [1, 2^31]
+__global__ __launch_bounds__(256) void k_selftest_rcp(unsigned long long *mismatches) {
+    unsigned bad = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; r <= 0x80000000ull;
+         r += (uint64_t)gridDim.x * blockDim.x) {
+        const double a = rcp_exact_u31((uint32_t)r);
+        const double b = 1.0 / (double)(uint32_t)r;
+        bad += (a != b);
+        bad += (quot31_exact((uint32_t)r) != 0x1p31 / (double)(uint32_t)r);
+    }
+    for (int off = 32; off; off >>= 1) bad += __shfl_xor(bad, off);
+    if (lane_id() == 0 && bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+__global__ void k_fill_f32(float *p, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- host wrappers
+hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
+                           int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
+                           const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
+                           unsigned long long *d_visited, double drift_dw) {
+    const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    const int chunks = (ntiles + 7) / 8;
+    if (d_kmin32)
+        hipLaunchKernelGGL(k_rcp_extrema, dim3(ntiles, fb.count), dim3(256), 0, s, d_rcp32, d_rext, ntiles, row_stride, st, fb);
+    hipLaunchKernelGGL(k_cws_scan, dim3((unsigned)(chunks * 8 * groups)), dim3(256), 0, s, d_k32, d_rcp32,
+                       d_tilemin, slots, ntiles, row_stride, st, fb, d_kmin32, d_rext, d_weights, slot_begin, d_visited, drift_dw);
+    return hipGetLastError();
+}
+
+hipError_t launch_slot_kmin(hipStream_t s, const float *d_kmin32, float *d_kminslot, int slots, int ntiles) {
+    hipLaunchKernelGGL(k_slot_kmin, dim3(slots), dim3(256), 0, s, d_kmin32, d_kminslot, ntiles * 4);
+    return hipGetLastError();
+}
+
+hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, int ncounters, const float *d_kminslot,
+                               const double *d_weights, int slots, int slot_begin, DevState *st, const FlushBatch &fb,
+                               int enable) {
+    hipLaunchKernelGGL(k_flush_decide, dim3(1), dim3(1024), 0, s, d_ctr, ncounters, d_kminslot, d_weights, slots,
+                       slot_begin, st, fb, enable);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_kmin(hipStream_t s, const float *d_k32, float *d_kmin32, int slots, int ntiles, size_t row_stride) {
+    hipLaunchKernelGGL(k_tile_kmin, dim3(ntiles, slots), dim3(256), 0, s, d_k32, d_kmin32, ntiles, row_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,
+                              const float *d_tilemin, double *d_candA, int32_t *d_candB,
+                              unsigned long long *d_mins, double *d_weights,
+                              int slots, int slot_begin, int ntiles, DevState *st, const FlushBatch &fb) {
+    hipLaunchKernelGGL(k_cws_resolve, dim3(slots, fb.count), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
+                       d_rcb, d_f64, d_tilemin, d_candA, d_candB, slots, ntiles, st, fb);
+    hipLaunchKernelGGL(k_cws_apply, dim3((slots + 255) / 256), dim3(256), 0, s, d_candA, d_candB, d_mins,
+                       d_weights, slots, slot_begin, st, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const double *d_f64,
+                                    const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
+                                    int slots, int slot_begin, int ntiles, double decay_weight,
+                                    DevState *st, const FlushBatch &fb) {
+    hipLaunchKernelGGL(k_cws_resolve_drift, dim3(slots), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
+                       d_rcb, d_f64, d_tilemin, d_mins, d_weights, slots, slot_begin, ntiles, decay_weight, st, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_cws_chunk(hipStream_t s, const uint64_t *d_pairs, uint64_t n_attempts, double *d_val,
+                            uint32_t *d_blkcnt, unsigned long long *d_gamma_total, unsigned long long *d_chunk_base,
+                            double *d_rcb, uint64_t num_bins, uint64_t slot_begin, uint64_t slots,
+                            uint64_t sketch_size, double ainv, double bbb, double ccc, double magic,
+                            const uint64_t *d_raw, uint64_t first_attempt, const uint64_t *d_ev, uint32_t n_ev) {
+    const uint32_t nblk = (uint32_t)((n_attempts + CWS_BLOCK - 1) / CWS_BLOCK);
+    hipLaunchKernelGGL(k_cws_eval, dim3(nblk), dim3(256), 0, s, d_pairs, n_attempts, d_val, d_blkcnt, ainv, bbb, ccc, magic,
+                       d_raw, first_attempt, d_ev, n_ev);
+    hipLaunchKernelGGL(k_cws_scan_blocks, dim3(1), dim3(1024), 0, s, d_blkcnt, nblk, d_gamma_total, d_chunk_base);
+    hipLaunchKernelGGL(k_cws_scatter, dim3(nblk), dim3(256), 0, s, d_val, n_attempts, d_blkcnt, d_chunk_base, d_rcb,
+                       num_bins, slot_begin, slots, sketch_size);
+    return hipGetLastError();
+}
+
+hipError_t launch_alfg(hipStream_t s, const uint64_t *d_coef, uint64_t *d_windows, uint64_t *d_raw, uint32_t first_chunk,
+                       uint32_t n_chunks, uint64_t chunk_len) {
+    // windows[first_chunk] is valid; produces windows[first_chunk + 1 .. first_chunk + n_chunks) and the chunks themselves
+    hipLaunchKernelGGL(k_alfg_jump, dim3(1), dim3(640), 0, s, d_coef, d_windows, first_chunk, n_chunks);
+    hipLaunchKernelGGL(k_alfg_fill, dim3(n_chunks), dim3(256), 0, s, d_windows, d_raw, first_chunk, chunk_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_rng_candidates(hipStream_t s, const uint64_t *d_raw, uint64_t n, uint64_t *d_list, uint32_t cap,
+                                 unsigned int *d_count) {
+    hipLaunchKernelGGL(k_rng_candidates, dim3(4096), dim3(256), 0, s, d_raw, n, d_list, cap, d_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_cws_beta(hipStream_t s, const uint64_t *d_uraw, uint64_t first_entry, uint64_t n, double *d_rcb,
+                           uint64_t num_bins, uint64_t slot_begin, uint64_t slots) {
+    hipLaunchKernelGGL(k_cws_beta, dim3(2048), dim3(256), 0, s, d_uraw, first_entry, n, d_rcb, num_bins, slot_begin, slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_smash(hipStream_t s, const unsigned long long *d_mins, const double *d_weights, uint32_t N, uint32_t S,
+                        int metric, double *d_out) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_smash, dim3((N + SMASH_T - 1) / SMASH_T, (N + SMASH_T - 1) / SMASH_T), dim3(256), 0, s, d_mins,
+                       d_weights, N, S, metric, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_k32(hipStream_t s, const double *d_rcb, float *d_k32, int slots,
+                            int32_t num_bins, size_t row_stride) {
+    if (slots == 0) return hipSuccess;
+    int bx = (int)((row_stride + 255) / 256); if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_build_k32, dim3(bx, slots), dim3(256), 0, s, d_rcb, d_k32, num_bins, row_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_rcp(hipStream_t s, unsigned long long *d_mismatches) {
+    hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(256), 0, s, d_mismatches);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_f32(hipStream_t s, float *p, size_t n, float v) {
+    hipLaunchKernelGGL(k_fill_f32, dim3(256), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+}  // namespace hulk
