@@ -136,7 +136,12 @@ class Sketcher:
     def close(self):
         if getattr(self, "_p", None):
             lib().orc_free(self._p); self._p = None
-    __del__ = close
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: the module globals may be gone already
+            pass
 
     def _chk(self, rc):
         if rc != 0:
