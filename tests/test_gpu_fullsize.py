@@ -135,3 +135,24 @@ def test_drift_pruning_against_oracle_many_intervals(decay):
     assert np.allclose(w, wo, rtol=1e-7, atol=0)
     assert (wo < 0).all()                      # the regime the drift pruning relies on
     o.close()
+
+
+def test_host_buffers_in_chunks_equal_device_path():
+    """hulk_add_reads with 1.3 M reads in ONE call: three chunks through the two pinned staging sets (chunk borders
+    inside intervals) — same sketch and counters as the device-resident path."""
+    from hulk_amd import synth
+    n = 1_300_000
+    m, w, c = _run_stream(21, 64, 100_000, 1.0, n, 1_300_000, 16)
+    os.environ["HULK_BATCH"] = "16"
+    try:
+        g = gpu().GpuSketcher(21, 9, 64, 100_000, 1.0)
+    finally:
+        os.environ.pop("HULK_BATCH", None)
+    bases, offsets = synth.reads_numpy(0, n, L)
+    g.add_reads(bases, offsets)
+    bases[:] = 0                                   # the call has copied the buffers: scribbling over them changes nothing
+    g.finish()
+    m2, w2 = g.sketch()
+    assert g.counters() == c
+    assert np.array_equal(m, m2) and np.array_equal(w, w2)
+    g.close()
