@@ -87,6 +87,20 @@ int main(int argc, char **argv) {
             if (decode(*d, cut, piece, opiece, n, r2, e2) && r2 != src) { bad++; printf("FAIL truncated it=%d accepted\n", it); }
         }
     }
-    printf("%d cases, %d bad\n", cases, bad);
+    // mangled streams: any outcome but a crash or an out-of-bounds access is fine (build with -fsanitize=address to see those)
+    int rejected = 0;
+    for (int it = 0; it < cases; it++) {
+        const size_t n = 1 + rand() % 50000;
+        std::vector<uint8_t> src(n);
+        for (size_t i = 0; i < n; i++) src[i] = (i % 97 < 60) ? "ACGT"[rand() & 3] : (uint8_t)('A' + rand() % 40);
+        std::vector<uint8_t> comp = deflate_raw(src, rand() % 10, rand() % 3 ? Z_DEFAULT_STRATEGY : Z_FIXED);
+        for (int f = 1 + rand() % 4; f > 0; f--) comp[(size_t)rand() % comp.size()] ^= (uint8_t)(1u << (rand() % 8));
+        if (rand() % 5 == 0) comp.resize(1 + (size_t)rand() % comp.size());
+        std::vector<uint8_t> res; std::string err;
+        // the output window is sized for 4x the original: a mangled stream may inflate to more than that
+        if (!decode(*d, comp, rand() % 2 ? 1 + rand() % 300 : (size_t)1 << 20, (size_t)1 << 22, 4 * n + 70000, res, err)) rejected++;
+    }
+    printf("%d cases, %d bad; %d mangled streams, %d rejected\n", cases, bad, cases, rejected);
+    delete d;
     return bad != 0;
 }
