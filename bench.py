@@ -34,7 +34,7 @@ BATCH = int(os.environ.get("HULK_BENCH_BATCH", "16"))   # sketching intervals pe
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(sample_intervals=5):
+def cpu_baseline(sample_intervals=8):
     """The CPU oracle (oracle/hulk_oracle.c, a literal port of the Go algorithm) timed on this
     box's host cores on a bounded sample of the same workload.  Single thread."""
     from oracle import pyorc
