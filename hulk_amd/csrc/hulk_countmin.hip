@@ -262,12 +262,32 @@ __global__ __launch_bounds__(512) void k_cmsd_segsum(const uint32_t *__restrict_
     const uint32_t e1 = b1 < (int64_t)B ? ei[b1] : etot[t];
     const double lnw = log(omega);                                // w^x = exp(x ln w): |x ln w| * 2^-53 relative, far below the tolerance
     if (tid == 0) { segfac[(size_t)t * CMS_SEGS + seg] = exp((double)(e1 - e0) * lnw); sege0[(size_t)t * CMS_SEGS + seg] = e0; }
-    for (int64_t b = b0 + tid; b < b1 && b < (int64_t)B; b += blockDim.x) {
-        const uint32_t h = hist[b];
-        if (h) {
-            const double wgt = (double)h * exp((double)(e1 - 1u - ei[b]) * lnw);
-            for (int d = 0; d < depth; d++) atomicAdd(&ladd[d * width + pos16[(size_t)d * B + b]], wgt);
+    // four bins per thread and step, every global load of the step (count, element index, the rows' counter
+    // positions) requested before the first is used: with one workgroup per CU their latency was the kernel's time
+    const int64_t bend = b1 < (int64_t)B ? b1 : (int64_t)B;
+    constexpr int U = 4;
+    for (int64_t bb = b0 + tid; bb < bend; bb += (int64_t)U * blockDim.x) {
+        uint32_t h[U], e[U]; uint16_t pp[U][8];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t b = bb + (int64_t)u * blockDim.x;
+            const bool ok = b < bend;
+            h[u] = ok ? hist[b] : 0u; e[u] = ok ? ei[b] : 0u;
+#pragma unroll
+            for (int d = 0; d < 8; d++) pp[u][d] = (ok && d < depth) ? pos16[(size_t)d * B + b] : (uint16_t)0;
         }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (h[u]) {
+                const double wgt = (double)h[u] * exp((double)(e1 - 1u - e[u]) * lnw);
+                if (depth <= 8) {
+#pragma unroll
+                    for (int d = 0; d < 8; d++) if (d < depth) atomicAdd(&ladd[d * width + pp[u][d]], wgt);
+                } else {
+                    const int64_t b = bb + (int64_t)u * blockDim.x;
+                    for (int d = 0; d < depth; d++) atomicAdd(&ladd[d * width + pos16[(size_t)d * B + b]], wgt);
+                }
+            }
     }
     __syncthreads();
     for (int i = tid; i < depth * width; i += blockDim.x) {
