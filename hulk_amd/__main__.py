@@ -1,8 +1,8 @@
-"""`python -m hulk_amd sketch ...` — the `hulk sketch` flag surface (cmd/root.go:62-66,
-cmd/sketch.go:50-59) over the GPU path, writing the reference's JSON sketch.
+"""`python -m hulk_amd sketch|smash ...` — the `hulk sketch` / `hulk smash` flag surface (cmd/root.go:62-66,
+cmd/sketch.go:50-59, cmd/smash.go) over the GPU path, writing the reference's JSON sketch / similarity matrix.
 
-Flag handling, log lines and the JSON writer only: the line pump (src/pipeline/sketch.go:40-161) and
-every numeric step run in libhulkhip.  `smash`, --khf/--kmv and --profiling are not provided.
+Flag handling, log lines and the writers only: the line pump (src/pipeline/sketch.go:40-161) and
+every numeric step run in libhulkhip.  --khf/--kmv (never fed in the reference) and --profiling are not provided.
 """
 import argparse
 import os
