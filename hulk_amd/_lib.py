@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhulkhip.so")
 HULK_OK = 0
 HULK_CWS_GO_COMPAT = 0
 HULK_CWS_EXTERNAL = 1
+HULK_FLAG_GAMMA_CPYTHON, HULK_FLAG_NO_PRUNE, HULK_FLAG_NO_SKIP = 1, 2, 4
+HULK_MAX_BINS = 1 << 20
 
 # every symbol include/hulk_hip.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = (
@@ -33,7 +35,7 @@ class HulkParams(ctypes.Structure):
         ("num_bins", ctypes.c_int32), ("decay_ratio", ctypes.c_double),
         ("interval", ctypes.c_uint32), ("device", ctypes.c_int32),
         ("slot_begin", ctypes.c_uint32), ("slot_count", ctypes.c_uint32),
-        ("cws_source", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 5),
+        ("cws_source", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 4),
     ]
 
 

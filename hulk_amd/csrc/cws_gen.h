@@ -70,9 +70,11 @@ class GoRandSource {
 // (k_cws_eval / k_cws_scatter in hulk_cws.hip).
 struct CwsConstants {
     double ainv, bbb, ccc, magic;            // alpha = 2, beta = 1 (histosketch.go:112-113)
-    CwsConstants() {
+    // cpython_squeeze: 1 + ln 4.5 (CPython's SG_MAGICCONST) instead of go_rng's recalled 4*exp(-0.5)/sqrt(2) — see
+    // HULK_FLAG_GAMMA_CPYTHON in include/hulk_hip.h
+    explicit CwsConstants(bool cpython_squeeze = false) {
         const double alpha = 2.0;
-        magic = 4 * std::exp(-0.5) / std::sqrt(2.0);
+        magic = cpython_squeeze ? 1.0 + std::log(4.5) : 4 * std::exp(-0.5) / std::sqrt(2.0);
         ainv = std::sqrt(2.0 * alpha - 1.0);
         bbb = alpha - std::log(4.0);
         ccc = alpha + ainv;

@@ -319,7 +319,10 @@ inline uint8_t *Decoder::run(uint8_t *out, uint8_t *out_limit, const uint8_t *hi
                     while (dst < out) *dst++ = *src++;
                 }
             }
-            bitbuf = bb; bitcnt = bc; in = ip;
+            // The refill above leaves up to 7 real look-ahead bits of *ip above `bc`; harmless while the next reader ORs the
+            // same byte over them, wrong once a stored block has taken its bytes straight from `in` in between: hand the
+            // state back with exactly `bc` bits.
+            bitbuf = bc < 64 ? bb & ((1ull << bc) - 1) : bb; bitcnt = bc; in = ip;
             if (leave == 1) { state = last_block ? DONE : HEADER; continue; }
             if (leave == 2) { state = ERROR; return out; }
         }

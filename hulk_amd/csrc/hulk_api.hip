@@ -98,7 +98,7 @@ struct hulk_ctx {
     double *d_f64 = nullptr, *d_weights = nullptr, *d_rcb = nullptr;
     float *d_rcp32 = nullptr, *d_k32 = nullptr, *d_tilemin = nullptr;
     float *d_kmin32 = nullptr, *d_rext = nullptr, *d_kminslot = nullptr;          // bound test of k_cws_scan (no concept drift only)
-    unsigned long long *d_visited = nullptr; uint64_t scan_tiles_total = 0; bool prune = false;
+    unsigned long long *d_visited = nullptr; uint64_t scan_tiles_total = 0; bool prune = false, no_skip = false;
     double *d_candA = nullptr; int32_t *d_candB = nullptr;
     // staging for host reads
     // hulk_add_reads (host buffers): two sets of pinned + device staging; the copy of chunk i+1 into pinned memory
@@ -117,6 +117,7 @@ struct hulk_ctx {
     // host-side run state
     uint64_t seq_count = 0, flush_index = 0;
     uint32_t T = 16, ring_n = 17, ring_base = 0;   // interval batch size and spectrum ring
+    uint32_t bin_spectra = 0;                      // spectra hulk_bin_reads_device filled that no flush has taken yet
     bool tables_ready = false, finished = false, hist_hook_used = false;
     int sticky = HULK_OK;
     std::string last_error;
@@ -198,7 +199,7 @@ int generate_tables_host(hulk_ctx *c) {
     if (need_entries == 0) { c->tables_ready = true; return HULK_OK; }
     const uint64_t need_gammas = 2 * need_entries;
     const size_t CH = (size_t)1 << 22;                                        // attempts (or uniforms) per chunk
-    const CwsConstants K;
+    const CwsConstants K((c->p.flags & HULK_FLAG_GAMMA_CPYTHON) != 0);
     uint64_t *h_buf[2] = {nullptr, nullptr}; uint64_t *d_pairs[2] = {nullptr, nullptr};
     double *d_val = nullptr; uint32_t *d_blkcnt = nullptr; unsigned long long *d_tot = nullptr;
     hipEvent_t done[2] = {nullptr, nullptr};
@@ -282,7 +283,7 @@ int generate_tables_device(hulk_ctx *c) {
     const uint64_t need_gammas = 2 * need_entries;
     const uint64_t C = 1ull << GO_RNG_JUMP_LOG2;
     const size_t CH = (size_t)1 << 22;                                        // attempts per evaluation chunk
-    const CwsConstants K;
+    const CwsConstants K((c->p.flags & HULK_FLAG_GAMMA_CPYTHON) != 0);
     // Cheng's sampler accepts ~77 % of the attempts at alpha = 2; the stream is sized with a wide margin
     const uint64_t max_attempts = (uint64_t)((double)need_gammas / 0.66) + (1u << 20);
     const uint64_t n_chunks = (2 * max_attempts + 4096 + C - 1) / C;
@@ -583,9 +584,8 @@ int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, b
     uint32_t *hist = ring_hist(c);
     HIPCHK(c, launch_count_used(s, hist, c->d_state, fb));
     {   // whole-batch bound on the counters as they stand BEFORE this batch is added (see k_flush_decide)
-        static const bool no_skip = getenv("HULK_NO_SKIP") != nullptr;
         HIPCHK(c, launch_flush_decide(s, c->d_ctr, c->cms_depth * c->cms_width, c->d_kminslot, c->d_weights, (int)c->slots,
-                                      (int)c->slot_begin, c->d_state, fb, (c->prune && !c->drift && !no_skip && c->slots) ? 1 : 0));
+                                      (int)c->slot_begin, c->d_state, fb, (c->prune && !c->drift && !c->no_skip && c->slots) ? 1 : 0));
     }
     if (c->scaling) {
         HIPCHK(c, launch_elem_index(s, hist, c->d_blkcnt, c->d_eidx, c->d_etot, fb));
@@ -653,6 +653,10 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     if (p.decay_ratio < 0.0 || p.decay_ratio > 1.0 || p.decay_ratio != p.decay_ratio) return fail(nullptr, HULK_ERR_DECAY);
     if (bins < 2) return fail(nullptr, HULK_ERR_BINS);
     if (p.k < 1) return fail(nullptr, HULK_ERR_K);
+    // the binning kernels pack (spectrum slot << 20 | bin) into a dword (hulk_spectrum.hip); k^4 <= 31^4 < 2^20
+    if (bins > (int64_t)HULK_MAX_BINS)
+        return fail(nullptr, HULK_ERR_ARG, "num_bins " + std::to_string(bins) + " exceeds HULK_MAX_BINS (2^20; k^4 at k = 31 is 923521)");
+    if (p.flags & ~(HULK_FLAG_GAMMA_CPYTHON | HULK_FLAG_NO_PRUNE | HULK_FLAG_NO_SKIP)) return fail(nullptr, HULK_ERR_ARG, "unknown flags");
     if (p.slot_count == 0) { p.slot_begin = 0; p.slot_count = p.sketch_size; }
     if ((uint64_t)p.slot_begin + p.slot_count > p.sketch_size) return fail(nullptr, HULK_ERR_ARG, "slot shard outside sketch");
     if (p.cws_source > HULK_CWS_EXTERNAL) return fail(nullptr, HULK_ERR_ARG, "cws_source");
@@ -719,7 +723,8 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(hipMemsetAsync(c->d_visited, 0, (size_t)MIN_SLOTS * 8, c->stream));
     // exact pruning of the K scan: without drift weights only fall; with drift (curMin = w / decayWeight) that still
     // holds for negative weights, which is what k_cws_scan tests then; decayRatio == 0 (decayWeight 0) is left alone
-    c->prune = !(c->drift && c->decay_weight <= 0.0) && !getenv("HULK_NO_PRUNE");
+    c->prune = !(c->drift && c->decay_weight <= 0.0) && !getenv("HULK_NO_PRUNE") && !(p.flags & HULK_FLAG_NO_PRUNE);
+    c->no_skip = getenv("HULK_NO_SKIP") != nullptr || (p.flags & HULK_FLAG_NO_SKIP) != 0;
     if (c->scaling) {
         const size_t NC = (size_t)c->cms_depth * c->cms_width;
         CHK_CREATE(dalloc(&c->d_blkcnt, T * (size_t)elem_index_blocks(c->B)));
@@ -855,6 +860,10 @@ int hulk_bin_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d
         if (rc != HULK_OK) return rc;
     }
     c->seq_count += n;
+    {
+        const uint32_t filled = reads_per_spectrum ? (uint32_t)((n + reads_per_spectrum - 1) / reads_per_spectrum) : (n ? 1u : 0u);
+        if (filled > c->bin_spectra) c->bin_spectra = filled;
+    }
     return HULK_OK;
 }
 
@@ -862,8 +871,9 @@ int hulk_flush_batch(hulk_ctx *c, uint32_t count) {
     if (!c) return HULK_ERR_ARG;
     if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
     if (count > c->T || c->ring_base != 0) return fail(c, HULK_ERR_ARG, "batch count");
+    if (count < c->bin_spectra) return fail(c, HULK_ERR_ARG, "fewer spectra flushed than hulk_bin_reads_device filled");
     int rc = flush_batch(c, count);
-    if (rc == HULK_OK && count) c->cur_ring ^= 1;      // the next batch is binned into the other ring meanwhile
+    if (rc == HULK_OK && count) { c->cur_ring ^= 1; c->bin_spectra = 0; }   // the next batch is binned into the other ring meanwhile
     return rc;
 }
 
@@ -871,8 +881,9 @@ int hulk_flush_batch_after(hulk_ctx *c, uint32_t count, void *dep_stream) {
     if (!c) return HULK_ERR_ARG;
     if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
     if (count > c->T || c->ring_base != 0) return fail(c, HULK_ERR_ARG, "batch count");
+    if (count < c->bin_spectra) return fail(c, HULK_ERR_ARG, "fewer spectra flushed than hulk_bin_reads_device filled");
     int rc = flush_batch(c, count, (hipStream_t)dep_stream, true);
-    if (rc == HULK_OK && count) c->cur_ring ^= 1;
+    if (rc == HULK_OK && count) { c->cur_ring ^= 1; c->bin_spectra = 0; }
     return rc;
 }
 
@@ -972,8 +983,11 @@ int hulk_flush(hulk_ctx *c) {
 int hulk_finish(hulk_ctx *c) {
     if (!c) return HULK_ERR_ARG;
     if (!c->finished) {
-        int rc = do_flush(c);                          // pipeline/sketch.go:219-221
+        // pipeline/sketch.go:219-221; a tail batch of hulk_bin_reads_device may span several spectra (ragged last
+        // batch of a multi-GPU run): all of them are flushed, in order
+        int rc = flush_batch(c, c->bin_spectra > 1 ? c->bin_spectra : 1u);
         if (rc != HULK_OK) return rc;
+        c->bin_spectra = 0;
         c->finished = true;
     }
     int rc = check_device_error(c);

@@ -45,12 +45,12 @@ class GpuSketcher:
 
     def __init__(self, k=21, w=9, sketch_size=50, interval=0, decay_ratio=1.0, num_bins=0,
                  device=0, slot_begin=0, slot_count=0, cws_source=_lib.HULK_CWS_GO_COMPAT,
-                 stream=None):
+                 stream=None, flags=0):
         self._L = _lib.load()
         self._ctx = ctypes.c_void_p()
         p = HulkParams(k=k, w=w, sketch_size=sketch_size, num_bins=num_bins,
                        decay_ratio=decay_ratio, interval=interval, device=device,
-                       slot_begin=slot_begin, slot_count=slot_count, cws_source=cws_source)
+                       slot_begin=slot_begin, slot_count=slot_count, cws_source=cws_source, flags=flags)
         rc = self._L.hulk_create(ctypes.byref(p), ctypes.byref(self._ctx))
         if rc != 0:
             self._ctx = None

@@ -73,6 +73,21 @@ extern "C" {
 #define HULK_CWS_GO_COMPAT 0     /* go_rng Gamma/Uniform over Go math/rand, seed 1 (default) */
 #define HULK_CWS_EXTERNAL 1      /* caller supplies them with hulk_set_cws_tables (e.g. dumped by a Go program) */
 
+/* hulk_params.flags.  None of the NO_* switches changes a result; they only remove an exact shortcut so that
+ * its effect can be measured (bench.py --no-prune) and tested (tests/test_gpu_parity.py). */
+#define HULK_FLAG_GAMMA_CPYTHON 1u /* go_rng's Gamma (third-party, github.com/leesper/go_rng @ a612b043e353, not vendored by
+                                    * the reference: histosketch.go:103,112-113) is restated from memory as CPython's
+                                    * gammavariate with the squeeze constant 4*exp(-0.5)/sqrt(2) (the default here); this flag
+                                    * selects CPython's own SG_MAGICCONST = 1 + ln 4.5.  Any valid squeeze only short-cuts the
+                                    * real test r >= ln z, so the tables are the same either way (tested); the flag exists so
+                                    * that a pin against a real Go run can be reproduced literally */
+#define HULK_FLAG_NO_PRUNE 2u      /* CWS scan reads the whole table for every interval (no per-tile bound, no whole-batch bound) */
+#define HULK_FLAG_NO_SKIP 4u       /* keep the per-tile bound, drop the whole-batch bound */
+
+/* Largest k-mer spectrum this build bins: the binning kernels pack (spectrum slot << 20 | bin) into one dword
+ * (k^4 = 923,521 < 2^20 at the reference's maximum k = 31; cmd/sketch.go:118). */
+#define HULK_MAX_BINS (1 << 20)
+
 typedef struct hulk_ctx hulk_ctx;
 
 typedef struct hulk_params {
@@ -86,7 +101,8 @@ typedef struct hulk_params {
     uint32_t slot_begin;   /* this context owns sketch slots [slot_begin, slot_begin+slot_count) */
     uint32_t slot_count;   /* 0 => all slots (single-GPU) */
     uint32_t cws_source;   /* HULK_CWS_* */
-    uint32_t reserved[5];
+    uint32_t flags;        /* HULK_FLAG_* (0 = defaults) */
+    uint32_t reserved[4];
 } hulk_params;
 
 /* Version of this ABI (HULK_ABI_VERSION). */

@@ -235,8 +235,17 @@ void orc_gosrc_free(orc_gosrc *s) { free(s); }
 double orc_go_uniform_range(orc_gosrc *s, double a, double b) {
     return a + orc_gosrc_float64(s) * (b - a);
 }
+/* The squeeze constant is the one uncertain recollection of go_rng: go_rng is believed to define
+ * MAGIC_CONST = 4*exp(-0.5)/sqrt(2) (variant 0, default); CPython's gammavariate uses SG_MAGICCONST = 1 + ln 4.5
+ * (variant 1); variant 2 has no squeeze at all.  It turns out NOT to matter: `r + M - 4.5z >= 0` is only a shortcut
+ * that implies `r >= ln z` for every M <= 1 + ln 4.5 (tangent bound ln z <= 4.5z - 1 - ln 4.5), so the accept/reject
+ * decision — and with it the whole parameter stream — is the same for all three (tests/test_oracle_reference_vectors.py
+ * ::test_gamma_squeeze_constant_is_immaterial checks 10^6 draws).  Product counterpart: HULK_FLAG_GAMMA_CPYTHON. */
+static int g_gamma_variant = 0;
+void orc_set_gamma_variant(int v) { g_gamma_variant = v; }
+int orc_get_gamma_variant(void) { return g_gamma_variant; }
 double orc_go_gamma(orc_gosrc *s, double alpha, double beta) {
-    const double MAGIC_CONST = 4 * exp(-0.5) / sqrt(2.0);
+    const double MAGIC_CONST = g_gamma_variant == 2 ? -HUGE_VAL : g_gamma_variant == 1 ? 1.0 + log(4.5) : 4 * exp(-0.5) / sqrt(2.0);
     /* only the alpha > 1 branch is reachable from HULK (Gamma(2,1)) */
     const double ainv = sqrt(2.0 * alpha - 1.0);
     const double bbb = alpha - log(4.0);

@@ -52,6 +52,8 @@ def lib():
         L.orc_gosrc_float64.restype = dbl; L.orc_gosrc_float64.argtypes = [vp]
         L.orc_go_gamma.restype = dbl; L.orc_go_gamma.argtypes = [vp, dbl, dbl]
         L.orc_go_uniform_range.restype = dbl; L.orc_go_uniform_range.argtypes = [vp, dbl, dbl]
+        L.orc_set_gamma_variant.argtypes = [ctypes.c_int]
+        L.orc_get_gamma_variant.restype = ctypes.c_int
         L.orc_cws_fill.restype = ctypes.c_int; L.orc_cws_fill.argtypes = [u32, i32, vp, vp, vp]
         L.orc_cms_geometry.argtypes = [vp, vp]
         L.orc_new.restype = ctypes.c_int; L.orc_new.argtypes = [u32, u32, u32, i32, dbl, u32, vp]
@@ -94,6 +96,12 @@ def minimizers(seq: bytes, k: int, w: int):
     if n < 0:
         raise OracleError(n)
     return out[:n].copy()
+
+
+def set_gamma_variant(v):
+    """0 = go_rng's recalled squeeze constant 4*exp(-0.5)/sqrt(2) (default), 1 = CPython's 1 + ln 4.5, 2 = no squeeze.
+    Applies to tables generated afterwards (cws_tables, Sketcher).  All three give the same stream (see hulk_oracle.c)."""
+    lib().orc_set_gamma_variant(int(v))
 
 
 def cms_geometry():

@@ -1,5 +1,6 @@
 // Differential test of hulk::inflate (hulk_amd/csrc/fast_inflate.h) against zlib: random inputs of several kinds,
-// every compression level and strategy (fixed / dynamic / stored blocks, Huffman-only, RLE), fed in random input
+// every compression level and strategy (fixed / dynamic / stored blocks, Huffman-only, RLE; one stream in three mixes
+// block kinds: independently compressed chunks joined at Z_FULL_FLUSH points), fed in random input
 // pieces (down to 1 byte) with random output pieces, so that every resume point of the decoder is exercised.
 // usage: inflate_fuzz [cases] [seed]      exit code 0 = all equal
 #include "../../hulk_amd/csrc/fast_inflate.h"
@@ -20,6 +21,62 @@ static std::vector<uint8_t> deflate_raw(const std::vector<uint8_t> &src, int lev
     out.resize(z.total_out);
     deflateEnd(&z);
     return out;
+}
+
+// One raw stream made of several chunks, each compressed on its own (level, strategy) and closed with Z_FULL_FLUSH —
+// a byte-aligned empty stored block, after which no match reaches back — so the chunks concatenate into ONE valid
+// stream in which Huffman, fixed and stored (level 0) blocks follow each other in every order; in particular a non-final
+// block after a non-empty stored block after a Huffman block.  (deflateParams would do the same inside one z_stream, but
+// zlib 1.2.11's level-0 switch reads out of bounds.)
+static std::vector<uint8_t> deflate_mixed(const std::vector<uint8_t> &src) {
+    std::vector<uint8_t> all;
+    size_t pos = 0;
+    do {
+        const size_t n = std::min(src.size() - pos, (size_t)(rand() % 3 == 0 ? 1 + rand() % 64 : 1 + rand() % 20000));
+        const int level = rand() % 3 == 0 ? 0 : rand() % 10;
+        const int strat = rand() % 3 == 0 ? Z_FIXED : (rand() % 4 == 0 ? Z_HUFFMAN_ONLY : Z_DEFAULT_STRATEGY);
+        const bool last = pos + n >= src.size();
+        z_stream z{};
+        deflateInit2(&z, level, Z_DEFLATED, -15, 8, strat);
+        std::vector<uint8_t> out(deflateBound(&z, n) + 64);
+        z.next_in = (Bytef *)src.data() + pos; z.avail_in = (uInt)n; z.next_out = out.data(); z.avail_out = (uInt)out.size();
+        deflate(&z, last ? Z_FINISH : Z_FULL_FLUSH);
+        all.insert(all.end(), out.begin(), out.begin() + (long)z.total_out);
+        deflateEnd(&z);
+        pos += n;
+    } while (pos < src.size());
+    return all;
+}
+
+// Hand-made stream: fixed-Huffman blocks of literals and stored blocks in random order, joined at BIT boundaries (no
+// flush marker in between) — the shape zlib only produces through deflateParams: a Huffman block whose end-of-block
+// code is followed directly by a non-empty stored block and then by another non-final block.
+struct BitWriter {
+    std::vector<uint8_t> out; uint64_t acc = 0; int n = 0;
+    void bits(uint32_t v, int c) { acc |= (uint64_t)v << n; n += c; while (n >= 8) { out.push_back((uint8_t)acc); acc >>= 8; n -= 8; } }
+    void huff(uint32_t code, int len) { uint32_t r = 0; for (int i = 0; i < len; i++) r |= ((code >> i) & 1u) << (len - 1 - i); bits(r, len); }
+    void align() { if (n) { out.push_back((uint8_t)acc); acc = 0; n = 0; } }
+};
+static std::vector<uint8_t> deflate_handmade(const std::vector<uint8_t> &src) {
+    BitWriter w;
+    size_t pos = 0;
+    do {
+        const size_t n = std::min(src.size() - pos, (size_t)(rand() % 2 ? rand() % 40 : rand() % 30000));
+        const bool last = pos + n >= src.size();
+        w.bits(last ? 1u : 0u, 1);
+        if (rand() % 2) {                                        // stored: LEN, NLEN after the byte boundary
+            w.bits(0, 2); w.align();
+            w.bits((uint32_t)n, 16); w.bits((uint32_t)n ^ 0xffffu, 16);
+            w.out.insert(w.out.end(), src.begin() + (long)pos, src.begin() + (long)(pos + n));
+        } else {                                                 // fixed Huffman, literals only (RFC 1951 3.2.6)
+            w.bits(1, 2);
+            for (size_t i = 0; i < n; i++) { const uint32_t c = src[pos + i]; if (c < 144) w.huff(0x30 + c, 8); else w.huff(0x190 + (c - 144), 9); }
+            w.huff(0, 7);
+        }
+        pos += n;
+    } while (pos < src.size());
+    w.align();
+    return w.out;
 }
 
 static bool decode(Decoder &d, const std::vector<uint8_t> &comp, size_t piece, size_t opiece, size_t n_expected,
@@ -70,15 +127,16 @@ int main(int argc, char **argv) {
         }
         const int level = rand() % 10;
         const int strat = (rand() % 4 == 0) ? Z_FIXED : (rand() % 5 == 0 ? Z_HUFFMAN_ONLY : (rand() % 7 == 0 ? Z_RLE : Z_DEFAULT_STRATEGY));
-        const std::vector<uint8_t> comp = deflate_raw(src, level, strat);
+        const bool mixed = it % 3 == 2;                      // every third case: blocks of different kinds in one stream
+        const std::vector<uint8_t> comp = mixed ? (it % 2 ? deflate_handmade(src) : deflate_mixed(src)) : deflate_raw(src, level, strat);
         const size_t piece = rand() % 3 == 0 ? 1 + rand() % 40 : (rand() % 2 ? (size_t)1 << 20 : 1 + rand() % 5000);
         const size_t opiece = rand() % 3 == 0 ? 1 + rand() % 600 : (size_t)1 << 22;
         std::vector<uint8_t> res; std::string err;
         const bool ok = decode(*d, comp, piece, opiece, n, res, err);
         if (!ok || res != src) {
             bad++;
-            if (bad < 10) printf("FAIL it=%d n=%zu kind=%d level=%d strat=%d piece=%zu opiece=%zu ok=%d err=%s got=%zu\n",
-                                 it, n, kind, level, strat, piece, opiece, (int)ok, err.c_str(), res.size());
+            if (bad < 10) printf("FAIL it=%d mixed=%d n=%zu kind=%d level=%d strat=%d piece=%zu opiece=%zu ok=%d err=%s got=%zu\n",
+                                 it, (int)mixed, n, kind, level, strat, piece, opiece, (int)ok, err.c_str(), res.size());
         }
         // a truncated stream must end in an error, never in DONE with wrong data
         if (comp.size() > 8 && it % 7 == 0) {

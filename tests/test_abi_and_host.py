@@ -38,7 +38,12 @@ def test_params_struct_layout_matches_header():
     from hulk_amd._lib import HulkParams
     assert ctypes.sizeof(HulkParams) == 64
     assert HulkParams.decay_ratio.offset == 16 and HulkParams.interval.offset == 24
-    assert HulkParams.cws_source.offset == 40
+    assert HulkParams.cws_source.offset == 40 and HulkParams.flags.offset == 44
+    hdr = open(os.path.join(ROOT, "include", "hulk_hip.h")).read()
+    from hulk_amd import _lib
+    for name in ("HULK_FLAG_GAMMA_CPYTHON", "HULK_FLAG_NO_PRUNE", "HULK_FLAG_NO_SKIP"):
+        assert int(re.search(rf"#define {name} (\d+)u", hdr).group(1)) == getattr(_lib, name)
+    assert "#define HULK_MAX_BINS (1 << 20)" in hdr and _lib.HULK_MAX_BINS == 1 << 20
 
 
 def test_create_without_gpu_fails_loudly():
@@ -61,6 +66,11 @@ def test_parameter_errors_before_device_probe():
         hulk_amd.GpuSketcher(1, 9, 8)
     with pytest.raises(hulk_amd.HulkError, match="negative value used for number of k-mer spectrum bins"):
         hulk_amd.GpuSketcher(21, 9, 8, num_bins=-3)
+    # more bins than the binning kernels' (slot << 20 | bin) keys can hold: refused, never aliased
+    with pytest.raises(hulk_amd.HulkError, match="HULK_MAX_BINS"):
+        hulk_amd.GpuSketcher(21, 9, 8, num_bins=(1 << 20) + 1)
+    with pytest.raises(hulk_amd.HulkError, match="unknown flags"):
+        hulk_amd.GpuSketcher(21, 9, 8, flags=1 << 9)
 
 
 def test_go_float_formatting():

@@ -118,6 +118,24 @@ def test_c3_shape_drift_batch_invariance():
     assert m1.max() < 31 ** 4 and np.all(np.isfinite(w1))
 
 
+def test_c3_full_size_50m_reads():
+    """BASELINE config C3 as stated: 50 M reads x 150 bp, k = 31, sketchSize = 1024, concept drift on (decay 0.02),
+    interval 100k = 500 sketching intervals over 22.7 GB of CWS tables.  The oracle would need days, so the run is
+    checked through size-independent properties: counters, value ranges, and bit-identical sketches under a different
+    interval-batch size and different call boundaries (the batch changes which intervals share a pass over the table
+    and a count-min replay; the decay path is the order-dependent one)."""
+    n = 50_000_000
+    m1, w1, c1 = _run_stream(31, 1024, 100_000, 0.02, n, 1_600_000, 16)
+    assert c1["n_reads"] == n and c1["total_len"] == n * L
+    assert 24.6 * n < c1["n_minimizers"] < 25.6 * n           # SURVEY.md §8: ~25.1 distinct minimizers per read at k = 31
+    assert m1.max() < 31 ** 4 and np.all(np.isfinite(w1))
+    assert (w1 < 0).all()                                     # every slot has been taken by a negative weight long since
+    assert len(np.unique(m1)) > 900                           # slots are independent samples of the spectrum
+    m2, w2, c2 = _run_stream(31, 1024, 100_000, 0.02, n, 2_345_678, 7)
+    assert c1 == c2
+    assert np.array_equal(m1, m2) and np.array_equal(w1, w2)
+
+
 @pytest.mark.parametrize("decay", [0.02, 0.5])
 def test_drift_pruning_against_oracle_many_intervals(decay):
     """Concept drift with the scan pruned against w_start/decayWeight (negative weights only): 10 intervals of

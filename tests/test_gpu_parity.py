@@ -471,3 +471,115 @@ def test_two_groups_per_read(k, w, lens, n):
     assert np.array_equal(g.cms(), o.cms())
     assert_same_sketch(o, g)
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("batch", [1, 3, 16])
+@pytest.mark.parametrize("decay", [0.02, 0.5])
+def test_k31_concept_drift_against_oracle(decay, batch, monkeypatch):
+    """BASELINE config C3's mode at its k: k = 31 (923,521 bins, minimizer values use all 64 bits: integer minima,
+    rolling k-mers) WITH concept drift — count-min uniform scaling (countmin.go:141-147) and the
+    `A < w/decayWeight` update (histosketch.go:139-153) — against the oracle, for three interval-batch sizes."""
+    monkeypatch.setenv("HULK_BATCH", str(batch))
+    rng = np.random.default_rng(31_000 + int(decay * 100))
+    seqs = random_reads(rng, 30_000, 150)
+    o, g = run_both(seqs, 31, 9, 4, interval=5_000, batches=3, decay=decay)
+    assert g.batch_size == batch
+    o.finish(); g.finish()
+    om, ow = o.sketch(); gm, gw = g.sketch()
+    assert o.counters()["n_minimizers"] == g.counters()["n_minimizers"]
+    assert np.array_equal(om, gm), f"{(om != gm).sum()} of {len(om)} mins differ"
+    assert np.allclose(gw, ow, rtol=DRIFT_RTOL, atol=0)
+    assert np.allclose(g.cms(), o.cms(), rtol=1e-9, atol=1e-300)
+    g.close(); o.close()
+
+
+def _numpy_histosketch(hist, r, c, b):
+    """One flush of a histogram through count-min (countmin.go:103-147, no decay) and AddElement
+    (histosketch.go:129-155) for ARBITRARY tables r, c, b [S][B] — a numpy restatement for the external-table test."""
+    S, B = r.shape
+    ctr = np.zeros((7, 2000))
+    pos = np.array([[pyorc.jump((x + d * x) & 0xFFFFFFFFFFFFFFFF, 2000) for x in range(B)] for d in range(7)])
+    mins = np.zeros(S, dtype=np.uint64); wts = np.full(S, np.finfo(np.float64).max)
+    for x in np.nonzero(hist)[0]:
+        f = np.inf
+        for d in range(7):
+            ctr[d, pos[d, x]] += float(hist[x]); f = min(f, ctr[d, pos[d, x]])
+        A = c[:, x] / (np.exp(np.log(f) - b[:, x]) * np.exp(r[:, x]))
+        upd = A < wts
+        mins[upd] = x; wts[upd] = A[upd]
+    return mins, wts
+
+
+def test_external_cws_tables_are_what_the_sketch_follows():
+    """hulk_set_cws_tables / HULK_CWS_EXTERNAL (include/hulk_hip.h) — the hook that takes r, c, b dumped by a real Go
+    run of newCWS (histosketch.go:95-126; tools/go/dump_cws):
+      * fed the oracle's tables it reproduces the default (device-generated) sketch bit for bit;
+      * fed DIFFERENT tables (a slot permutation of the oracle's; tables drawn by numpy) the sketch follows the
+        supplied ones and differs from the default;
+      * HULK_FLAG_GAMMA_CPYTHON generates the same tables as the default (the squeeze constant is immaterial);
+      * a context created EXTERNAL refuses to sketch before the tables are set."""
+    h = gpu()
+    from hulk_amd import _lib
+    k, w, S, B = 11, 5, 24, 11 ** 4
+    rng = np.random.default_rng(77)
+    seqs = random_reads(rng, 4000, 150)
+    bases, offsets = pack_reads(seqs)
+
+    def gpu_sketch(tables=None, flags=0):
+        g = h.GpuSketcher(k, w, S, 1000, cws_source=_lib.HULK_CWS_EXTERNAL if tables is not None else _lib.HULK_CWS_GO_COMPAT,
+                          flags=flags)
+        if tables is not None:
+            g.set_cws_tables(*tables)
+        g.add_reads(bases, offsets); g.finish()
+        out = g.sketch(); g.close()
+        return out
+
+    o = pyorc.Sketcher(k, w, S, 0, 1.0, 1000)
+    t0 = pyorc.cws_tables(S, B)
+    o.add_reads(bases, offsets); o.finish()
+    m0, w0 = o.sketch(); o.close()
+    gm, gw = gpu_sketch()                                         # default: generated on the device
+    assert np.array_equal(gm, m0) and np.allclose(gw, w0, rtol=WEIGHT_RTOL, atol=0)
+    em, ew = gpu_sketch(t0)                                       # the same tables through the hook
+    assert np.array_equal(em, gm) and np.allclose(ew, gw, rtol=1e-12, atol=0)
+    fm, fw = gpu_sketch(flags=_lib.HULK_FLAG_GAMMA_CPYTHON)       # CPython's squeeze constant: same tables
+    assert np.array_equal(fm, gm) and np.array_equal(fw, gw)
+    perm = np.roll(np.arange(S), 5)                               # slot i gets the parameters of slot perm[i]
+    pm, pw = gpu_sketch(tuple(np.ascontiguousarray(a[perm]) for a in t0))
+    assert np.array_equal(pm, m0[perm]) and np.allclose(pw, w0[perm], rtol=WEIGHT_RTOL, atol=0)
+    assert not np.array_equal(pm, m0)
+    g = h.GpuSketcher(k, w, S, 1000, cws_source=_lib.HULK_CWS_EXTERNAL)
+    with pytest.raises(h.HulkError, match="hulk_set_cws_tables"):
+        g.add_reads(bases, offsets); g.finish()
+    g.close()
+    # tables that no generator of this repository produced: numpy's gamma / uniform, one histogram, numpy restatement
+    k2, S2 = 7, 16
+    B2 = k2 ** 4
+    r = rng.gamma(2.0, 1.0, size=(S2, B2)); c = np.log(rng.gamma(2.0, 1.0, size=(S2, B2))); b = rng.random((S2, B2)) * r
+    hist = ((rng.random(B2) < 0.6) * rng.integers(1, 30, size=B2)).astype(np.uint32)
+    g = h.GpuSketcher(k2, 3, S2, cws_source=_lib.HULK_CWS_EXTERNAL)
+    g.set_cws_tables(r, c, b)
+    g.add_histogram(hist); g.flush()
+    xm, xw = g.sketch(); g.close()
+    nm, nw = _numpy_histosketch(hist, r, c, b)
+    assert np.array_equal(xm, nm) and np.allclose(xw, nw, rtol=WEIGHT_RTOL, atol=0)
+    d = h.GpuSketcher(k2, 3, S2)                                  # ... and the default tables give another sketch
+    d.add_histogram(hist); d.flush()
+    assert not np.array_equal(d.sketch()[0], xm)
+    d.close()
+
+
+def test_num_bins_limit():
+    """The binning kernels pack (spectrum slot << 20 | bin): 2^20 bins is the largest spectrum (k^4 at k = 31 is
+    923,521); one more is refused at hulk_create instead of aliasing bins silently.  Parity at the limit."""
+    h = gpu()
+    from hulk_amd import _lib
+    with pytest.raises(h.HulkError, match="HULK_MAX_BINS"):
+        h.GpuSketcher(15, 9, 2, num_bins=_lib.HULK_MAX_BINS + 1)
+    rng = np.random.default_rng(20)
+    seqs = random_reads(rng, 3000, 150)
+    o, g = run_both(seqs, 15, 9, 2, interval=1500, num_bins=_lib.HULK_MAX_BINS)
+    assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32))
+    o.finish(); g.finish()
+    assert_same_sketch(o, g)
+    g.close(); o.close()

@@ -83,3 +83,21 @@ def test_smash_cli_end_to_end(tmp_path):
         assert line == ",".join(str(int(v)) for v in mins[names.index(f)]) + ",blank"
     assert main(["smash", "-d", str(d), "-m", "euclidean", "-o", out]) == 1     # not in availMetrics
     assert main(["smash", "-d", str(d), "-k", "21", "-o", out]) == 1            # no sketch with that k
+
+
+def test_c5_full_size_sampled_against_oracle():
+    """BASELINE config C5 at its stated size: 1024 sketches x sketchSize 2048, both metrics (cmd/smash.go:183-226,
+    sketchio.go:259-306).  A pair's distance depends on its two sketches only, so the oracle's matrix of 64 random
+    sketches must equal the corresponding 64 x 64 sub-matrix of the GPU's 1024 x 1024 one, bit for bit."""
+    from hulk_amd.smash import distance_matrix
+    rng = np.random.default_rng(1024)
+    N, S = 1024, 2048
+    mins, weights = make_sketches(rng, N, S)
+    idx = np.sort(rng.choice(N, size=64, replace=False))
+    for metric in ("weightedjaccard", "jaccard"):
+        full = distance_matrix(mins, weights, metric)
+        assert full.shape == (N, N)
+        want = pyorc.smash_matrix(mins[idx], weights[idx], metric)
+        assert np.array_equal(full[np.ix_(idx, idx)], want), metric
+        if metric == "jaccard":
+            assert np.array_equal(full, full.T) and np.all(np.diag(full) == 0)

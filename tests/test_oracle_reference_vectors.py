@@ -204,3 +204,22 @@ def test_golden_sketch_reproduced_by_oracle(fq_reads):
     m, w = o.sketch()
     assert np.array_equal(m, g.mins) and np.array_equal(w, g.weights)     # JSON floats round-trip exactly
     assert g.concept_drift is True and g.num_histogram_bins == 50625
+
+
+def test_gamma_squeeze_constant_is_immaterial():
+    """SURVEY.md App. B flags go_rng's squeeze constant as its one uncertain recollection (4*exp(-0.5)/sqrt(2) vs
+    CPython's 1 + ln 4.5).  The squeeze `r + M - 4.5 z >= 0` is only a shortcut that implies the real test
+    `r >= ln z` for any M <= 1 + ln 4.5, so the accepted variates — hence r, c, b of newCWS — do not depend on it:
+    both constants, and no squeeze at all, give the identical stream over 10^6 draws."""
+    def draws(variant, n):
+        pyorc.set_gamma_variant(variant)
+        try:
+            g = pyorc.GoRand(1)
+            return np.array([g.gamma(2.0, 1.0) for _ in range(n)])
+        finally:
+            pyorc.set_gamma_variant(0)
+    n = 1_000_000
+    a = draws(0, n)
+    assert abs(a.mean() - 2.0) < 0.01 and abs(a.var() - 2.0) < 0.03      # Gamma(2, 1)
+    assert np.array_equal(a, draws(1, n))
+    assert np.array_equal(a, draws(2, n))
