@@ -3,25 +3,32 @@
 
 Workload at N=1 (BASELINE configs[1], "C2"): synthetic 150 bp reads, k=21, w=9, sketchSize=512,
 interval=100k reads; reads are resident in HBM before the timed region.  One *step* = one batch of
-T=16 sketching intervals (1.6 M reads): one launch chain bins the reads of the 16 intervals into 16
-k-mer spectra (minimizers -> jump hash -> spectrum), the spectra go through the count-min update,
-and ONE pass over the CWS table applies all 16 histosketch updates in interval order —
+T=16 sketching intervals (1.6 M reads of the global stream): one launch chain bins the reads of the 16
+intervals into 16 k-mer spectra (minimizers -> jump hash -> spectrum), the spectra go through the
+count-min update, and ONE pass over the CWS table applies all 16 histosketch updates in interval order —
 bit-identical to flushing after every 100k reads (tests/test_gpu_parity.py).  The flush of step n
 runs on a second stream under the minimizer kernels of step n+1.  Default K=20 steps = 32 M reads
-(C2's 10 M reads = 6.25 steps).
+(C2's 10 M reads = 6.25 steps; `value_cold` is C2 exactly as stated: 10 M reads, fresh context, no warm-up).
 
-N>1 (one process per GPU, launched by torch.distributed.run): every interval's reads are split
-into N contiguous slices, the 16 spectra of a step are merged with ONE RCCL all-reduce, the CWS
-update is slot-sharded (hulk_amd/distributed.py).  Per-rank work per step is kept fixed as N
-grows (each rank bins 100k reads per interval => the global interval is N x 100k): "weak" scaling.
+N>1: one process per GPU over RCCL.  Launched by torch.distributed.run (RANK/WORLD_SIZE in the environment) this
+process is one rank; launched as plain `python bench.py --gpus N` it spawns the N ranks itself and relays their line.
+  --scaling strong (default; SURVEY.md §8e, the reference's rule pipeline/sketch.go:211-215): the sketching interval
+      stays 100k reads of the GLOBAL stream; rank g bins reads [g*I/N, (g+1)*I/N) of every interval, ONE all-reduce
+      merges the 16 spectra of a step, count-min is replicated, the CWS update is slot-sharded.  The sketch is the
+      one a single GPU computes (same `sketch_md5`); total work is fixed as N grows.
+  --scaling weak: every rank bins 100k reads per interval, i.e. the global interval is N x 100k — fixed work per rank,
+      but a different sketch than C2's.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,25 +38,98 @@ sys.path.insert(0, ROOT)
 
 K, W, S, READ_LEN, INTERVAL = 21, 9, 512, 150, 100_000
 BATCH = int(os.environ.get("HULK_BENCH_BATCH", "16"))   # sketching intervals per step (one pass over the CWS table)
+C2_READS = 10_000_000        # BASELINE configs[1]
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+SIMDS, CLOCK_GHZ, VALU_CYCLES = 256 * 4, 2.4, 2   # MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op issues over 2 cycles
+PMC_PROFILE = os.path.join("profiles", "r02_pmc.json")
 
 
-def cpu_baseline(sample_intervals=8):
-    """The CPU oracle (oracle/hulk_oracle.c, a literal port of the Go algorithm) timed on this
-    box's host cores on a bounded sample of the same workload.  Single thread."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sample_intervals=4):
+    """The CPU oracle (oracle/hulk_oracle.c, a literal port of the Go algorithm) timed on this box's host cores on a
+    bounded sample of the same workload (SURVEY.md §8d "CPU baseline beside it"):
+      leg (i)  everything on one thread;
+      leg (ii) the minimizer + jump-hash stage of every interval on all host cores (one private k-mer spectrum per
+               thread, summed), the count-min + histosketch update single-threaded as in the Go reference (one
+               Sketcher goroutine, pipeline/sketch.go:271-301).
+    Both legs sketch the first `sample_intervals` intervals of the bench stream on a fresh sketch, so they include the
+    one interval (the first) in which most slots still change; per-interval cost does not depend on that (AddElement
+    evaluates every slot for every bin either way), so the rate scales linearly to any number of reads."""
     from oracle import pyorc
     from hulk_amd import synth
-    o = pyorc.Sketcher(K, W, S, 0, 1.0, INTERVAL)          # CWS table generation: not timed
-    bases, offsets = synth.reads_numpy(0, sample_intervals * INTERVAL, READ_LEN)
+    n = sample_intervals * INTERVAL
+    bases, offsets = synth.reads_numpy(0, n, READ_LEN)
+    nproc = os.cpu_count() or 1
+    # ---- leg (i): one thread
+    o = pyorc.Sketcher(K, W, S, 0, 1.0, INTERVAL)          # CWS table generation: not timed (one-off, as in the GPU figure)
     t0 = time.perf_counter()
     o.add_reads(bases, offsets)
-    dt = time.perf_counter() - t0
-    n = sample_intervals * INTERVAL
-    o.close()
-    return {"value": n / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": f"{n} reads = {sample_intervals} intervals of {INTERVAL} "
-                      f"(k={K}, sketchSize={S}), single-threaded C port of the Go path, "
-                      f"CWS table generation excluded; {dt:.1f} s"}
+    dt1 = time.perf_counter() - t0
+    m1, _ = o.sketch()
+    # ---- leg (ii): binning on all cores, histosketch on one
+    o2 = pyorc.Sketcher(K, W, S, 0, 1.0, 0)
+    workers = [pyorc.Sketcher(K, W, 1, 0, 1.0, 0) for _ in range(nproc)]       # S=1: only their k-mer spectrum is used
+    t0 = time.perf_counter()
+    for t in range(sample_intervals):
+        cuts = np.linspace(t * INTERVAL, (t + 1) * INTERVAL, nproc + 1).astype(np.int64)
+        hists = [None] * nproc
+
+        def work(i):
+            a, b = int(cuts[i]), int(cuts[i + 1])
+            if b > a:
+                lo = int(offsets[a])
+                workers[i].add_reads(bases[lo:int(offsets[b])], offsets[a:b + 1] - offsets[a])   # ctypes releases the GIL
+            hists[i] = workers[i].histogram()
+            workers[i].wipe()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nproc)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        o2.add_histogram(np.sum(hists, axis=0).astype(np.uint32))
+        o2.flush()
+    dt2 = time.perf_counter() - t0
+    m2, _ = o2.sketch()
+    assert np.array_equal(m1, m2), "all-cores CPU leg disagrees with the single-threaded one"
+    o.close(); o2.close()
+    for x in workers:
+        x.close()
+    what = (f"{n} reads = {sample_intervals} intervals of {INTERVAL} (k={K}, sketchSize={S}), fresh sketch (includes the "
+            f"first interval), C port of the Go path (oracle/hulk_oracle.c), CWS table generation excluded")
+    return {"value": n / dt2, "unit": "reads/s", "cores": nproc, "kind": "port",
+            "sample": what + f"; minimizer + jump-hash stage on {nproc} threads, count-min + histosketch on 1 (as the "
+                             f"reference's single Sketcher goroutine); {dt2:.1f} s",
+            "nproc": nproc, "cpu_model": cpu_model(),
+            "single_thread": {"value": n / dt1, "unit": "reads/s", "cores": 1, "seconds": dt1},
+            "reference_binary": "unavailable: no Go toolchain on this box, the reference's modules are not vendored"}
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) and relay their JSON line."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(p.stdout)
+        raise SystemExit(p.returncode or 1)
+    print(lines[0], flush=True)
+    raise SystemExit(0)
 
 
 def main():
@@ -57,12 +137,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--no-prune", action="store_true",
+                    help="the timed pass itself runs with the exact bounds of the CWS stage off (HULK_FLAG_NO_PRUNE): every "
+                         "interval is evaluated against the whole table (profiling aid; implies --single-pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="skip the value_cold pass (C2 exactly: 10 M reads, no warm-up)")
     ap.add_argument("--single-pass", action="store_true",
                     help="skip the second timed pass (CWS-scan pruning disabled) that fills value_unpruned")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the all-reduce path even at world size 1 (test aid)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        self_spawn(args)
 
     # RCCL / the HIP runtime print banners on stdout; the contract is ONE JSON line there.
     sys.stdout.flush()
@@ -72,29 +162,34 @@ def main():
     import torch
     import torch.distributed as dist
     import hulk_amd
-    from hulk_amd import synth
-    from hulk_amd.distributed import GpuEngine, ShardedSketcher, slot_shard
+    from hulk_amd import _lib, synth
+    from hulk_amd.distributed import GpuEngine, ShardedSketcher, interval_slice, slot_shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     use_dist = world > 1 or args.force_collective
+    rccl_ranks = 0
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(device))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        rccl_ranks = dist.get_world_size()
+        assert dist.get_backend() == "nccl" and rccl_ranks == world
 
     steps, warmup = args.steps, args.warmup
     total_steps = steps + warmup
-    # global interval = world * INTERVAL; this rank bins its contiguous INTERVAL-read slice of each
-    reads_per_rank_step = INTERVAL * BATCH
+    scaling = args.scaling
+    _, per_interval = interval_slice(scaling, 0, INTERVAL, rank, world)       # reads of an interval this rank bins
+    reads_per_rank_step = per_interval * BATCH
+    global_interval = INTERVAL if scaling == "strong" else INTERVAL * world
+    reads_per_step = global_interval * BATCH
     sb, sc = slot_shard(S, rank, world)
 
     os.environ["HULK_BATCH"] = str(BATCH)
@@ -104,32 +199,27 @@ def main():
     coll_stream = torch.cuda.Stream(device=device) if use_dist else None
     torch.cuda.set_stream(stream)
 
-    # synthetic reads, resident in HBM.  Interval t of step s = global reads
-    # [(s*BATCH+t)*world*INTERVAL, +world*INTERVAL); this rank owns the slice [rank*INTERVAL, +INTERVAL)
-    # of it, so an N-rank run sketches the same global stream as a 1-rank run with interval N*100k.
+    # synthetic reads, resident in HBM: this rank's slice of every interval of every step (hulk_amd.distributed.
+    # interval_slice), so an N-rank run sketches the same global stream as ONE rank with interval = global_interval
     n_buf = min(total_steps, 24)          # distinct steps kept in HBM (reused cyclically beyond that)
-    step_bases, offsets = [], None
+    step_bases = []
     for s_ in range(n_buf):
         parts = []
         for t in range(BATCH):
-            first = ((s_ * BATCH + t) * world + rank) * INTERVAL
-            b, _ = synth.reads_torch(first, INTERVAL, READ_LEN, device=device)
-            parts.append(b[:INTERVAL * READ_LEN])
+            first, cnt = interval_slice(scaling, s_ * BATCH + t, INTERVAL, rank, world)
+            b, _ = synth.reads_torch(first, cnt, READ_LEN, device=device)
+            parts.append(b[:cnt * READ_LEN])
         pad = torch.zeros(16, dtype=torch.uint8, device=device)
         step_bases.append(torch.cat(parts + [pad]))
     offsets = torch.arange(reads_per_rank_step + 1, dtype=torch.int64, device=device) * READ_LEN
     torch.cuda.synchronize()
 
-
     def run_pass(prune):
-        """warm-up + the timed K steps on a fresh context; prune=False disables the exact bound test of the
-        CWS scan (HULK_NO_PRUNE), so that every interval streams the whole table like the reference does."""
-        if prune:
-            os.environ.pop("HULK_NO_PRUNE", None)
-        else:
-            os.environ["HULK_NO_PRUNE"] = "1"
+        """warm-up + the timed K steps on a fresh context; prune=False disables the exact bounds of the CWS stage
+        (HULK_FLAG_NO_PRUNE), so that every interval streams the whole table like the reference does."""
         sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=local_rank,
-                                  slot_begin=sb, slot_count=sc, stream=stream.cuda_stream)
+                                  slot_begin=sb, slot_count=sc, stream=stream.cuda_stream,
+                                  flags=0 if prune else _lib.HULK_FLAG_NO_PRUNE)
         assert sk.batch_size == BATCH
         eng = GpuEngine(sk, device, n_spectra=BATCH)
         sh = ShardedSketcher(eng, S, rank, world if use_dist else 1, dist if use_dist else None)
@@ -137,7 +227,7 @@ def main():
         def one_step(t):
             b = step_bases[t % n_buf]
             sk.bin_reads_device(b.data_ptr(), offsets.data_ptr(), reads_per_rank_step, READ_LEN, b.numel(),
-                                reads_per_spectrum=INTERVAL)
+                                reads_per_spectrum=per_interval)
             if use_dist:
                 h = eng.histogram_tensor()                 # view of the ring the reads were just binned into
                 coll_stream.wait_stream(stream)
@@ -164,8 +254,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         tiles1 = sk.scan_stats()
-        n_launch, scan_ms = sk.get_profile("k_cws_scan")
-        n_k1, k1_ms = sk.get_profile("k_minimizer_fast")
+        prof = {k: sk.get_profile(k) for k in ("k_cws_scan", "k_minimizer_fast", "k_jump_bin")}
         sk.set_profiling(False)
         if use_dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -175,36 +264,89 @@ def main():
         sk.finish()
         counters = sk.counters()
         mins, weights = sh.gather_sketch() if (use_dist and world > 1) else sk.sketch()
-
         sk.close()
-        return dict(elapsed=elapsed, n_launch=n_launch, scan_ms=scan_ms, n_k1=n_k1, k1_ms=k1_ms, counters=counters,
-                    mins=mins, weights=weights, tiles0=tiles0, tiles1=tiles1)
+        return dict(elapsed=elapsed, prof=prof, counters=counters, mins=mins, weights=weights, tiles0=tiles0, tiles1=tiles1)
 
-    full = run_pass(False) if not args.single_pass else None
-    main_pass = run_pass(True)
-    elapsed, n_launch, scan_ms, n_k1, k1_ms = (main_pass[k] for k in ("elapsed", "n_launch", "scan_ms", "n_k1", "k1_ms"))
-    counters, mins, weights, tiles0, tiles1 = (main_pass[k] for k in ("counters", "mins", "weights", "tiles0", "tiles1"))
+    def run_cold():
+        """C2 exactly as BASELINE.json states it: 10 M reads, interval 100k, through the interval rule of
+        hulk_add_reads_device on a FRESH context (the first batch evaluates the whole CWS table), no warm-up; the clock
+        stops after hulk_finish (final flush + device error check).  Context creation (CWS table generation, the
+        reference pays it once at pipeline/sketch.go:277) is timed separately."""
+        chunk = INTERVAL * BATCH
+        chunks = []
+        for first in range(0, C2_READS, chunk):
+            n = min(chunk, C2_READS - first)
+            b, off = synth.reads_torch(first, n, READ_LEN, device=device)
+            chunks.append((b, off, n))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=local_rank, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for b, off, n in chunks:
+            sk.add_reads_device(b.data_ptr(), off.data_ptr(), n, READ_LEN, b.numel())
+        sk.finish()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        mins, _ = sk.sketch()
+        sk.close()
+        return {"value_cold": C2_READS / (t2 - t1), "cold_seconds": t2 - t1, "cold_create_seconds": t1 - t0,
+                "cold_reads": C2_READS, "cold_sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()}
+
+    single = args.single_pass or args.no_prune
+    full = run_pass(False) if not single else None
+    main_pass = run_pass(not args.no_prune)
+    elapsed, prof, counters = main_pass["elapsed"], main_pass["prof"], main_pass["counters"]
+    mins, weights, tiles0, tiles1 = (main_pass[k] for k in ("mins", "weights", "tiles0", "tiles1"))
     if full is not None and rank == 0:
         assert np.array_equal(full["mins"], mins) and np.array_equal(full["weights"], weights), "pruning changed the sketch"
+    cold = run_cold() if (world == 1 and rank == 0 and not args.no_cold and not use_dist) else None
 
     if rank == 0:
-        total_reads = steps * reads_per_rank_step * world
+        total_reads = steps * reads_per_step
         value = total_reads / elapsed
-        # Per-launch durations measured live with HIP events on the work stream (hulk_set_profiling).
-        # Dominant kernel by time = k_minimizer_fast (minimizers + jump hash + spectrum atomics): its
-        # algorithmic HBM bytes are the bases (1 B/base) + the read offsets (8 B/read); it is bound by
-        # VALU issue (integer hashing, fp64 jump hash), not by HBM — frac is reported against the HBM
-        # peak as the contract asks, the VALU-busy fraction from rocprofv3 PMC is in profiles/.
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
+        except Exception:
+            pass
+
+        def from_profile(kernel, key):
+            return pmc.get(kernel, {}).get(key) if world == 1 else None
+
+        # Per-launch durations measured live with HIP events on the stream each kernel is launched on (hulk_set_profiling).
+        # Dominant kernel by time = k_minimizer_fast (K1a: bases -> distinct minimizers per read).  Its algorithmic
+        # bytes are SURVEY.md §8(d)'s per-read figure for the bin side, L + 8 (one ASCII byte per base + the read's
+        # offset), x the reads of one launch.  The minimizer list it hands to k_jump_bin (8 B value + 1 B spectrum slot
+        # per distinct minimizer) is an artefact of this implementation: reported as intermediate_bytes, not priced.
+        n_k1, k1_ms = prof["k_minimizer_fast"]
         k1_avg_s = (k1_ms / 1e3) / max(n_k1, 1)
-        # algorithmic bytes of k_minimizer_fast: bases + offsets in, (value u64 + slot u8) per distinct
-        # minimizer out (the list k_jump_bin consumes)
-        per_read_min = counters["n_minimizers"] / float(counters["n_reads"])
-        k1_bytes = float(reads_per_rank_step) * (READ_LEN + 8 + 9.0 * per_read_min)
+        per_read_min = counters["n_minimizers"] / float(max(counters["n_reads"], 1))
+        k1_bytes = float(reads_per_rank_step) * (READ_LEN + 8)
         k1_ach = k1_bytes / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
+        n_kj, kj_ms = prof["k_jump_bin"]
+        kj_avg_s = (kj_ms / 1e3) / max(n_kj, 1)
+
+        def valu_roofline(kernel, avg_s):
+            """VALU-issue floor of a launch: (VALU wave-instructions of the launch, SQ_INSTS_VALU from the rocprofv3 PMC
+            pass of this command) / 1024 SIMDs x 2 cycles per wave64 instruction / 2.4 GHz.  frac = floor / measured."""
+            insts = from_profile(kernel, "SQ_INSTS_VALU")
+            if not insts or avg_s <= 0:
+                return None
+            scale = reads_per_rank_step / float(pmc.get("reads_per_launch", INTERVAL * BATCH))
+            floor_us = insts * scale / SIMDS * VALU_CYCLES / (CLOCK_GHZ * 1e3)
+            return {"kernel": kernel, "wave_instr_per_read": insts / float(pmc.get("reads_per_launch", INTERVAL * BATCH)),
+                    "cycles_per_instr_assumed": VALU_CYCLES, "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
+                    "floor_us": floor_us, "avg_launch_us": avg_s * 1e6, "frac": floor_us / (avg_s * 1e6),
+                    "instr_from_profile": PMC_PROFILE,
+                    "formula": "SQ_INSTS_VALU per launch / 1024 SIMDs * 2 cycles / 2.4 GHz; every instruction priced at "
+                               "the full rate (v_mad_u64_u32, v_mul_lo_u32 and fp64 ops issue slower: the true floor is higher)"}
+
         # The HBM-streaming kernel of the path = k_cws_scan.  Unpruned it makes ONE fp32 pass over this rank's
         # slice of K per launch (4*slots*k^4 bytes, SURVEY.md §8d) + the BATCH reciprocal vectors; with the exact
         # bound test (no concept drift) it only reads the 8-slot x 256-bin tiles that can still lower a weight,
         # so the bytes it is priced on are the tiles it actually read (hulk_get_scan_stats) + the small tables.
+        n_launch, scan_ms = prof["k_cws_scan"]
         wtiles = ((K ** 4 + 1023) // 1024) * 4
         full_bytes = 4.0 * sc * (K ** 4) + 4.0 * BATCH * (K ** 4)
         visited = (tiles1[0] - tiles0[0]) / max(n_launch, 1)
@@ -215,53 +357,60 @@ def main():
         out = {
             "metric": "reads/sec (150bp, k=21, sketch=512)", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "C2: synthetic 150bp reads, k=21, w=9, sketchSize=512, "
-                                   f"interval=100k reads per rank, {BATCH} intervals per step, HBM-resident input",
-                       "reads_per_step": reads_per_rank_step * world, "total_reads": total_reads,
-                       "intervals_per_step": BATCH,
-                       "parallelism": f"read-shard x{world}, slot-sharded CWS"},
+                                   f"interval={global_interval} reads of the global stream ({per_interval} per rank), "
+                                   f"{BATCH} intervals per step, HBM-resident input"
+                                   + (", CWS-scan bounds OFF (--no-prune)" if args.no_prune else ""),
+                       "reads_per_step": reads_per_step, "reads_per_rank_step": reads_per_rank_step,
+                       "total_reads": total_reads, "intervals_per_step": BATCH, "global_interval": global_interval,
+                       "parallelism": f"read-shard x{world}, replicated count-min, slot-sharded CWS"},
+            "rccl_ranks": rccl_ranks,
             "roofline": {"bound": "hbm", "kernel": "k_minimizer_fast", "achieved": k1_ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_ach / HBM_PEAK_GBS,
-                         "traffic": None, "launches": int(n_k1), "avg_launch_us": k1_avg_s * 1e6,
-                         "alg_bytes_per_launch": k1_bytes,
-                         "note": "dominant by time; VALU-issue bound (SQ_ACTIVE_INST_VALU = 100% of SIMD cycles, "
-                                 "profiles/r01_pmc.json), not HBM bound"},
+                         "traffic": None, "traffic_from_profile": from_profile("k_minimizer_fast", "hbm_bytes_per_launch"),
+                         "traffic_profile": PMC_PROFILE if pmc else None,
+                         "launches": int(n_k1), "avg_launch_us": k1_avg_s * 1e6,
+                         "alg_bytes_per_launch": k1_bytes, "alg_bytes_per_read": READ_LEN + 8,
+                         "intermediate_bytes": float(reads_per_rank_step) * 9.0 * per_read_min,
+                         "note": "dominant kernel by time; bound by VALU issue, not by HBM (see roofline_valu): its "
+                                 "fraction of the HBM peak is small by construction"},
+            "roofline_valu": valu_roofline("k_minimizer_fast", k1_avg_s),
+            "roofline_valu_jump": valu_roofline("k_jump_bin", kj_avg_s),
+            "k_jump_bin": {"launches": int(n_kj), "avg_launch_us": kj_avg_s * 1e6,
+                           "note": "k_jump_bin + k_jump_left: jump hash of the minimizer list, second by time"},
             "roofline_cws_scan": {"bound": "hbm", "kernel": "k_cws_scan", "achieved": achieved,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                  "traffic": None, "launches": int(n_launch),
+                                  "traffic": None, "traffic_from_profile": from_profile("k_cws_scan", "hbm_bytes_per_launch"),
+                                  "launches": int(n_launch),
                                   "avg_launch_us": avg_s * 1e6, "alg_bytes_per_launch": alg_bytes,
                                   "intervals_per_launch": BATCH, "tiles_read_per_launch": visited,
                                   "tiles_covered_per_launch": covered, "unpruned_bytes_per_launch": full_bytes,
                                   "note": "exact branch-and-bound: a batch whose smallest count-min counter already rules "
                                           "out every slot skips the estimates/scan/resolve, otherwise only tiles whose "
                                           "lower bound can beat a slot's current weight are read (identical sketch; "
-                                          "HULK_NO_PRUNE=1 disables both = value_unpruned)"},
-            "path_bytes_per_read": READ_LEN + 4.0 * S * (K ** 4) / (INTERVAL * world),
-            "sketch_md5": __import__("hashlib").md5(mins.astype("<u8").tobytes()).hexdigest(),
+                                          "--no-prune / HULK_FLAG_NO_PRUNE disables both = value_unpruned)"},
+            "sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest(),
             # same K steps with the exact pruning of the CWS scan switched off: every interval streams the whole
             # table, as the reference's algorithm does (sketch asserted identical)
-            "value_unpruned": (total_reads / full["elapsed"]) if full is not None else None,
+            "value_unpruned": (total_reads / full["elapsed"]) if full is not None else (value if args.no_prune else None),
             "ms_per_step_unpruned": (full["elapsed"] / steps * 1e3) if full is not None else None,
             "n_minimizers_rank0": counters["n_minimizers"],
         }
-        # HBM traffic per launch from rocprofv3 PMC (FETCH_SIZE/WRITE_SIZE, separate passes of this same
-        # command, gfx950 correction applied — see profiles/r01_pmc.json); cannot be collected live.
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            if world == 1:
-                out["roofline"]["traffic"] = pmc["k_minimizer_fast"]["hbm_bytes_per_launch"]
-                out["roofline_cws_scan"]["traffic"] = pmc["k_cws_scan"]["hbm_bytes_per_launch"]   # PMC run, same command
-        except Exception:
-            pass
-        # SURVEY.md §8(d) prices the path at L + 4*S*k^4/I bytes per read (one K pass per interval) => a roofline of
-        # 1.94e9 reads/s/GPU at C2; this is value / that rate.  The path itself moves far fewer bytes (one K pass
-        # per BATCH intervals, and only the tiles that can still change a slot).
-        out["path_hbm_frac"] = value * out["path_bytes_per_read"] / 1e9 / (HBM_PEAK_GBS * world)
+        # SURVEY.md §8(d) prices the path at L + 4*S*k^4/I bytes per read (one K pass per interval): a MODEL of the
+        # reference's data movement, not traffic this implementation generates (one K pass serves BATCH intervals and
+        # the exact bounds skip most of it) — kept for comparison with the survey's 1.94e9 reads/s/GPU figure only.
+        model_bytes = READ_LEN + 4.0 * S * (K ** 4) / global_interval
+        out["survey_model"] = {"bytes_per_read": model_bytes, "reads_per_s_at_hbm_peak": HBM_PEAK_GBS * 1e9 * world / model_bytes,
+                               "value_over_model": value * model_bytes / 1e9 / (HBM_PEAK_GBS * world)}
+        if cold is not None:
+            out.update(cold)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+            if cold is not None:
+                out["speedup_vs_cpu_cold"] = cold["value_cold"] / out["cpu_baseline"]["value"]
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

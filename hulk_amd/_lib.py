@@ -3,8 +3,10 @@
 The library is built in-tree (hulk_amd/csrc/Makefile).  There is NO fallback: if the shared
 object is missing or no gfx950 GPU is usable, importing/creating fails loudly.
 
-A process that also uses torch must `import torch` BEFORE the first hulk_amd call: torch bundles its
-own libamdhip64, and two HIP runtimes in one process leave the second without devices.
+One HIP runtime per process: torch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's, which
+libhulkhip.so is linked against).  Whichever is loaded first serves both, and torch on top of /opt/rocm's runtime finds
+no device — so when torch is installed, load() maps torch's copy first (without importing torch) and libhulkhip binds
+to it; `import torch` may then come before or after the first hulk_amd call.  Without torch /opt/rocm's is used.
 """
 import ctypes
 import os
@@ -59,6 +61,27 @@ class HulkError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """Map torch's bundled HIP runtime before libhulkhip.so pulls in /opt/rocm's (see the module docstring)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                                   # torch is loaded: its runtime already owns the SONAME
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError as e:
+            raise ImportError(f"torch is installed but its HIP runtime {path} does not load ({e}); importing torch "
+                              "before hulk_amd is the work-around") from e
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -67,6 +90,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C hulk_amd/csrc` (or "
             "`python -c 'import __graft_entry__ as g; g.build()'`). hulk_amd has no CPU fallback.")
+    _preload_torch_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     vp, u64, u32, i32, dbl = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.c_double
     L.hulk_abi_version.restype = ctypes.c_int

@@ -68,7 +68,7 @@ int32_t jump_host(uint64_t key, int64_t n) {
 
 constexpr uint64_t MAX_READS_PER_LAUNCH = 4u << 20;   // 4 Mi reads -> <= ~7 GB of minimizer list at w = 9
 
-struct ProfileRec { hipEvent_t a, b; int which; };   // which: 0 = k_cws_scan, 1 = k_minimizer_fast
+struct ProfileRec { hipEvent_t a, b; int which; };   // which: 0 = k_cws_scan, 1 = k_minimizer_fast, 2 = k_jump_bin + k_jump_left
 
 }  // namespace
 
@@ -547,7 +547,10 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
         HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->ml, c->d_state,
                                         c->d_min_slots, c->d_slow_list, slow_cnt));
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
-        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist, slow_cnt_next));
+        ProfileRec pj{}; pj.which = 2;
+        if (c->profiling) { HIPCHK(c, hipEventCreate(&pj.a)); HIPCHK(c, hipEventCreate(&pj.b)); }
+        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist, slow_cnt_next, pj.a, pj.b));
+        if (c->profiling) c->prof.push_back(pj);
         pick_config(c->p.k, max_len, P, threads);      // (fast_ok implies max_len <= 256: always fits)
         const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(128, (n + 3) / 4);   // the list is normally empty or short
         HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, hist, c->d_state,
@@ -1120,8 +1123,9 @@ int hulk_get_profile(hulk_ctx *c, const char *kernel, uint64_t *launches, double
     if (!c || !launches || !total_ms) return fail(c, HULK_ERR_ARG, "NULL");
     int which = 0;
     if (kernel && strcmp(kernel, "k_minimizer_fast") == 0) which = 1;
+    else if (kernel && strcmp(kernel, "k_jump_bin") == 0) which = 2;
     else if (kernel && strcmp(kernel, "k_cws_scan") != 0)
-        return fail(c, HULK_ERR_ARG, "instrumented kernels: k_cws_scan, k_minimizer_fast");
+        return fail(c, HULK_ERR_ARG, "instrumented kernels: k_cws_scan, k_minimizer_fast, k_jump_bin");
     { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
     double tot = 0; uint64_t n = 0;
     std::vector<ProfileRec> keep;

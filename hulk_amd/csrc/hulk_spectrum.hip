@@ -403,7 +403,7 @@ __global__ void k_add_hist(uint32_t *hist, const uint32_t *add, int32_t n) {
 // ---------------------------------------------------------------------------- host wrappers
 // K1b: jump hash of the list (dense key array); K1c: spectrum ranges in LDS, merged without atomics
 hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
-                                 uint32_t *d_hists, uint32_t *d_zero_word) {
+                                 uint32_t *d_hists, uint32_t *d_zero_word, hipEvent_t jump_begin, hipEvent_t jump_end) {
     if (n_reads == 0) return hipSuccess;
     hipError_t e = hipSuccess;
     const uint32_t n_regions = (uint32_t)((n_reads + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE);
@@ -419,8 +419,10 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     static int jump_cut = -1;
     if (jump_cut < 0) { const char *ec = getenv("HULK_JUMP_CUT"); jump_cut = ec ? atoi(ec) : 10; }
     const uint32_t cut = (jump_c || !ml.lo) ? 0u : (uint32_t)jump_cut;
+    if (jump_begin) { e = hipEventRecord(jump_begin, s); if (e != hipSuccess) return e; }      // bench.py: k_jump_bin + k_jump_left
     hipLaunchKernelGGL(k_jump_bin, dim3((n_regions + 3) / 4), dim3(256), (size_t)jump_lds, s, ml, n_regions, P.num_bins, jump_c, cut);
     if (cut) hipLaunchKernelGGL(k_jump_left, dim3((n_regions + 3) / 4), dim3(256), 0, s, ml, n_regions, P.num_bins);
+    if (jump_end) { e = hipEventRecord(jump_end, s); if (e != hipSuccess) return e; }
     const uint32_t n_spectra = P.interval ? (uint32_t)((P.fill + n_reads + P.interval - 1) / P.interval) : 1u;
     const int nranges = (P.num_bins + HIST_RANGE - 1) / HIST_RANGE;
     static int parts_target = -1;

@@ -28,6 +28,22 @@ def read_shard(interval_reads: int, rank: int, world: int):
     return (interval_reads * rank) // world, (interval_reads * (rank + 1)) // world
 
 
+def interval_slice(scaling: str, t: int, interval: int, rank: int, world: int):
+    """(first global read, count) of the part of sketching interval `t` that `rank` bins.
+
+    "strong" is SURVEY.md §8(e) / the reference's rule (pipeline/sketch.go:211-215: a flush every `interval` reads of
+    the GLOBAL stream): interval t = global reads [t*I, (t+1)*I), rank g takes the contiguous slice
+    [t*I + g*I/G, t*I + (g+1)*I/G) — the sketch is the one a single GPU computes with the same interval.
+    "weak" keeps the per-rank work fixed instead: the global interval is G*I reads and rank g takes its g-th block of
+    I — the sketch of a single-GPU run with interval G*I."""
+    if scaling == "strong":
+        lo, hi = read_shard(interval, rank, world)
+        return t * interval + lo, hi - lo
+    if scaling == "weak":
+        return (t * world + rank) * interval, interval
+    raise ValueError("scaling must be 'strong' or 'weak'")
+
+
 class ShardedSketcher:
     """Drives one rank of a G-rank run.
 

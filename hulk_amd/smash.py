@@ -106,7 +106,12 @@ def smash(sketch_dir, out_file, ksize=21, algo="histosketch", metric="jaccard", 
         if len(a.mins) != size:
             raise HulkError(-30, f"sketch length mismatch: {size} vs {len(a.mins)}\n")
     mins = np.stack([a.mins for a in sk])
-    weights = np.stack([a.weights for a in sk])
+    if algo == "histosketch":
+        weights = np.stack([a.weights for a in sk])
+    elif metric == "weightedjaccard":                           # sketchio.go:287-293
+        raise HulkError(-30, "weighted jaccard is only supported for histosketches")
+    else:
+        weights = np.zeros(mins.shape)                          # MinHash signatures carry no weights (khf.go:12-16)
     dist = distance_matrix(mins, weights, metric, device)
     od = os.path.dirname(out_file)
     if od and od != "." and not os.path.exists(od):

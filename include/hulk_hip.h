@@ -225,8 +225,8 @@ int hulk_selftest_reciprocal(hulk_ctx *ctx, uint64_t *mismatches);
  * Reports how many tiles the scans read out of how many they covered (both cumulative). */
 int hulk_get_scan_stats(hulk_ctx *ctx, uint64_t *tiles_visited, uint64_t *tiles_total);
 
-/* Per-kernel timing for bench.py: when enabled, hipEvents bracket every launch of the two heavy
- * kernels ("k_minimizer_fast", "k_cws_scan") on the work stream. */
+/* Per-kernel timing for bench.py: when enabled, hipEvents bracket every launch of the heavy kernels
+ * ("k_minimizer_fast", "k_jump_bin" = k_jump_bin + k_jump_left, "k_cws_scan") on the stream they are launched on. */
 int hulk_set_profiling(hulk_ctx *ctx, int enabled);
 /* Number of timed launches of `kernel` and their summed duration (synchronises; clears that log). */
 int hulk_get_profile(hulk_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);

@@ -428,6 +428,13 @@ int orc_flush(orc_sketcher *o) {
     return ORC_OK;
 }
 
+/* KmerSpectrum.Wipe alone (kmerspectrum.go:53-64): used by bench.py's all-cores CPU leg, whose worker threads only
+ * bin reads and hand their spectrum to the one sketching thread */
+void orc_wipe(orc_sketcher *o) {
+    for (int32_t i = 0; i < o->B; i++) o->bins[i] = 0;
+    o->used = 0;
+}
+
 /* one iteration of SeqMinimizer.Run's loop (pipeline/sketch.go:197-215) +
  * Minion (minion.go:45-57) + collector (boss.go:90-95) */
 int orc_add_read(orc_sketcher *o, const uint8_t *seq, int32_t len) {

@@ -63,6 +63,7 @@ def lib():
         L.orc_add_element.argtypes = [vp, u64, dbl]
         L.orc_add_histogram.restype = ctypes.c_int; L.orc_add_histogram.argtypes = [vp, vp]
         L.orc_flush.restype = ctypes.c_int; L.orc_flush.argtypes = [vp]
+        L.orc_wipe.argtypes = [vp]
         L.orc_finish.restype = ctypes.c_int; L.orc_finish.argtypes = [vp]
         L.orc_get_sketch.argtypes = [vp, vp, vp]
         L.orc_get_histogram.argtypes = [vp, vp]
@@ -168,6 +169,7 @@ class Sketcher:
         self._chk(lib().orc_add_histogram(self._p, hist.ctypes.data))
 
     def flush(self): self._chk(lib().orc_flush(self._p))
+    def wipe(self): lib().orc_wipe(self._p)
     def finish(self): self._chk(lib().orc_finish(self._p))
 
     def sketch(self):

@@ -127,3 +127,28 @@ def test_spectrum_size_is_int32_pow():
     from hulk_amd import spectrum_size
     assert spectrum_size(21) == 194481 and spectrum_size(31) == 923521
     assert spectrum_size(216) < 0          # int32 wrap, as int32(helpers.Pow(k,4))
+
+
+def test_khf_signature_layout_and_kmv_is_fatal(tmp_path):
+    """`hulk sketch --khf / --kmv` observable behaviour (cmd/sketch.go:58-59, pipeline/boss.go:70-71,
+    pipeline/sketch.go:226-234, sketchio.go:56-75): the secondary MinHash sketches are constructed but never fed, so
+    KHF is a signature of math.MaxUint64 values (fields ksize, md5sum, mins, num) after the histosketch, and KMV — an
+    empty sketch — makes HULKdata.Add fail with the reference's message."""
+    from hulk_amd import HistoSketch
+    from hulk_amd.sketchio import HULKdata, KHFSketch, KMVSketch, load_hulk_data, md5sum
+    d = HULKdata()
+    d.add(HistoSketch(21, np.array([3, 9], dtype=np.uint64), np.array([-0.5, -0.25]), 194481, False))
+    d.add(KHFSketch(21, 2))
+    d.filename, d.banner_label = "x.fq,", "blank"
+    obj = json.loads(d.dumps())
+    assert [s["Algorithm"] for s in obj["signatures"]] == ["histosketch", "khf"]
+    khf = obj["signatures"][1]["Sketch"]
+    assert list(khf) == ["ksize", "md5sum", "mins", "num"]
+    assert khf["mins"] == [18446744073709551615] * 2 and khf["num"] == 2 and khf["ksize"] == 21
+    assert khf["md5sum"] == hashlib.md5(b"\xff" * 16).hexdigest() == md5sum(np.full(2, 2 ** 64 - 1, dtype=np.uint64))
+    assert '                "num": 2\n            }\n        }\n    ],' in d.dumps()
+    p = tmp_path / "k.json"; d.write_json(p)
+    back = load_hulk_data(p)                                       # LoadHULKdata accepts khf signatures (sketchio.go:154-157)
+    assert [a for a, _ in back.signatures] == ["histosketch", "khf"]
+    with pytest.raises(ValueError, match="no sketch was generated by the kmv algorithm"):
+        d.add(KMVSketch(21, 2))

@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from hulk_amd import synth
-from hulk_amd.distributed import ShardedSketcher, read_shard, slot_shard
+from hulk_amd.distributed import ShardedSketcher, interval_slice, read_shard, slot_shard
 
 K, W, S, I, NI, L = 9, 4, 10, 600, 3, 80
 
@@ -55,8 +55,8 @@ def _worker(rank, world, port, q):
     eng = OracleEngine(rank, world)
     sh = ShardedSketcher(eng, S, rank, world, dist)
     for t in range(NI):
-        lo, hi = read_shard(I, rank, world)
-        bases, offsets = synth.reads_numpy(t * I + lo, hi - lo, L)
+        first, cnt = interval_slice("strong", t, I, rank, world)     # a slice of the GLOBAL interval
+        bases, offsets = synth.reads_numpy(first, cnt, L)
         eng.bin_reads(bases, offsets)
         sh.end_interval()
     sh.finish()
@@ -79,6 +79,33 @@ def test_shard_helpers():
         for r in range(world):
             lo, hi = read_shard(100000, r, world); cov += [(lo, hi)]
         assert cov[0][0] == 0 and cov[-1][1] == 100000 and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
+
+
+def test_interval_slices_partition_the_global_stream():
+    """strong: the ranks' slices tile interval t = [t*I, (t+1)*I) of the global stream (pipeline/sketch.go:211-215 with
+    the reference's interval); weak: they tile [t*G*I, (t+1)*G*I) — a G-times longer interval."""
+    for world in (1, 2, 3, 8):
+        for t in (0, 1, 7):
+            for mode, span in (("strong", 100000), ("weak", 100000 * world)):
+                sl = [interval_slice(mode, t, 100000, r, world) for r in range(world)]
+                assert sl[0][0] == t * span and sum(c for _, c in sl) == span
+                assert all(a[0] + a[1] == b[0] for a, b in zip(sl, sl[1:]))
+    with pytest.raises(ValueError):
+        interval_slice("sideways", 0, 10, 0, 1)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` without a launcher spawns the N ranks itself; it must never quietly time one GPU.
+    Here (no GPU) it has to exit non-zero with a message and print no JSON line."""
+    import subprocess, sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "GPU(s) visible" in p.stderr and "{" not in p.stdout
 
 
 @pytest.mark.timeout(300)

@@ -28,10 +28,43 @@ def test_bench_json_contract_and_collective_path():
     for k in REQUIRED:
         assert k in a, k
     assert a["n_gpus"] == 1 and a["steps"] == 3 and a["warmup"] == 1 and a["vs_baseline"] is None
-    assert a["unit"] == "reads/s" and a["higher_is_better"] is True and a["scaling"] == "weak"
+    assert a["unit"] == "reads/s" and a["higher_is_better"] is True and a["scaling"] == "strong"
     assert "workload" in a["config"] and "model" not in a["config"]
     r = a["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # algorithmic bytes = SURVEY.md §8(d)'s per-read figure (L + 8) x the reads of one launch; nothing else priced in
+    assert r["alg_bytes_per_launch"] == a["config"]["reads_per_rank_step"] * (150 + 8) and r["traffic"] is None
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
     assert a["value"] > 1e7 and abs(a["ms_per_step"] * a["value"] / 1e3 - a["config"]["reads_per_step"]) < 1.0
-    b = _run(["--no-cpu-baseline", "--force-collective"])
+    assert a["rccl_ranks"] == 0
+    # C2 exactly as BASELINE states it: 10 M reads on a fresh context; below the steady-state rate, above 1e8
+    assert a["cold_reads"] == 10_000_000 and 1e8 < a["value_cold"] < 1.2 * a["value"]
+    assert a["value_unpruned"] is not None and a["value_unpruned"] <= 1.2 * a["value"]
+    b = _run(["--no-cpu-baseline", "--no-cold", "--force-collective"])
     assert b["sketch_md5"] == a["sketch_md5"]           # all-reduce over one rank is the identity
+    assert b["rccl_ranks"] == 1                         # dist.get_world_size() on the nccl (= RCCL) backend
+    # the real unpruned switch: the timed pass itself reads the whole table for every interval, same sketch
+    c = _run(["--no-cpu-baseline", "--no-cold", "--no-prune"])
+    assert c["sketch_md5"] == a["sketch_md5"]
+    sc, sa = c["roofline_cws_scan"], a["roofline_cws_scan"]
+    assert sc["tiles_read_per_launch"] == sc["tiles_covered_per_launch"] > 0
+    assert sa["tiles_read_per_launch"] < sc["tiles_read_per_launch"]
+    assert sc["avg_launch_us"] > sa["avg_launch_us"]
+    # weak scaling is identical to strong at one rank
+    d = _run(["--no-cpu-baseline", "--no-cold", "--single-pass", "--scaling", "weak"])
+    assert d["scaling"] == "weak" and d["sketch_md5"] == a["sketch_md5"]
+
+
+def test_bench_gpus_2_spawns_or_refuses():
+    """Invoked the way the driver invokes it (`python bench.py --gpus 2`, no launcher): on a one-GPU box it must refuse
+    with a non-zero exit — never print an n_gpus: 1 line; with two GPUs it spawns two RCCL ranks."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    if torch.cuda.device_count() < 2:
+        assert p.returncode != 0 and "GPU(s) visible" in p.stderr and "{" not in p.stdout
+    else:
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+        assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "strong"

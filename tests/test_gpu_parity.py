@@ -583,3 +583,56 @@ def test_num_bins_limit():
     o.finish(); g.finish()
     assert_same_sketch(o, g)
     g.close(); o.close()
+
+
+def test_cli_khf_kmv_stream_flags(tmp_path):
+    """`hulk sketch --khf / --kmv / --stream` observable behaviour (cmd/sketch.go:56-59,75-86,121-122;
+    pipeline/sketch.go:226-234; sketchio.go:56-75): --khf appends the never-fed KHF signature (all math.MaxUint64),
+    --kmv is fatal after the reads were processed and leaves no JSON, --stream sends the log to <outFile>.log."""
+    import json, os
+    from conftest import GOLDEN
+    from hulk_amd.__main__ import main
+    from hulk_amd.sketchio import load_hulk_data
+    fq = os.path.join(GOLDEN, "test-reads-small.fq.gz")
+    out = str(tmp_path / "a")
+    assert main(["sketch", "-f", fq, "-s", "16", "--khf", "-o", out]) == 0
+    doc = json.load(open(out + ".json"))
+    assert [s["Algorithm"] for s in doc["signatures"]] == ["histosketch", "khf"]
+    assert doc["signatures"][1]["Sketch"] == {"ksize": 21, "md5sum": hashlib.md5(b"\xff" * 128).hexdigest(),
+                                              "mins": [2 ** 64 - 1] * 16, "num": 16}
+    load_hulk_data(out + ".json")
+    plain = str(tmp_path / "p")
+    assert main(["sketch", "-f", fq, "-s", "16", "-o", plain]) == 0
+    assert json.load(open(plain + ".json"))["signatures"][0] == doc["signatures"][0]
+    bad = str(tmp_path / "b")
+    assert main(["sketch", "-f", fq, "-s", "16", "--kmv", "--khf", "-o", bad]) == 1
+    assert not os.path.exists(bad + ".json")
+    st = str(tmp_path / "logs" / "s")
+    assert main(["sketch", "-f", fq, "-s", "16", "--stream", "-o", st]) == 0
+    log = open(st + ".log").read()
+    assert "\tstreaming: enabled" in log and "\tadding KHF sketch: false" in log and "written sketch to disk" in log
+    assert json.load(open(st + ".json"))["signatures"][0] == doc["signatures"][0]
+
+
+def test_import_order_does_not_matter():
+    """hulk_amd first, torch afterwards, in a fresh process: both must see the GPU (one HIP runtime per process;
+    hulk_amd/_lib.py maps torch's bundled runtime before libhulkhip.so binds to /opt/rocm's)."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, hulk_amd\n"
+            "assert 'torch' not in sys.modules\n"
+            "from hulk_amd import synth\n"
+            "g = hulk_amd.GpuSketcher(15, 9, 8)\n"
+            "b, o = synth.reads_numpy(0, 2000, 150)\n"
+            "g.add_reads(b, o); g.finish(); m0 = g.sketch()[0]\n"
+            "import torch\n"
+            "assert torch.cuda.is_available()\n"
+            "x = torch.arange(10, device='cuda').sum().item(); assert x == 45\n"
+            "bt, ot = synth.reads_torch(0, 2000, 150); torch.cuda.synchronize()\n"
+            "h = hulk_amd.GpuSketcher(15, 9, 8)\n"
+            "h.add_reads_device(bt.data_ptr(), ot.data_ptr(), 2000, 150, bt.numel()); h.finish()\n"
+            "assert np.array_equal(h.sketch()[0], m0)\n"
+            "print('ok')\n") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-2000:]

@@ -1,7 +1,12 @@
 """Two ranks of the PRODUCT multi-GPU path (GpuSketcher + GpuEngine + ShardedSketcher, the protocol of
 bench.py) on ONE MI355X: both processes use cuda:0 and exchange over gloo (RCCL refuses two ranks on
 one device; the collective is the only thing swapped).  The gathered sketch must equal a single-rank
-GPU run over the same global read stream with interval = 2 x the per-rank interval, and the oracle.
+GPU run over the same global read stream, and the oracle:
+  * "strong" (bench.py's default): each rank bins its half of every interval of I reads — the single-rank
+    run has the SAME interval I (the reference's rule, pipeline/sketch.go:211-215);
+  * "weak": each rank bins I reads per interval — the single-rank run has interval 2 x I.
+The stream ends in a ragged tail (TAIL < BATCH intervals binned, then finish() without a flush_batch): the final flush
+must take every spectrum of the tail batch.
 """
 import os
 import socket
@@ -11,7 +16,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-K, W, S, I, BATCH, STEPS, L = 15, 9, 64, 3000, 4, 3, 150
+K, W, S, I, BATCH, STEPS, TAIL, L = 15, 9, 64, 3000, 4, 3, 2, 150
 
 
 def _free_port():
@@ -19,14 +24,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, overlap):
+def _worker(rank, world, port, q, overlap, scaling):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["HULK_BATCH"] = str(BATCH)
     import hulk_amd
     from hulk_amd import synth
-    from hulk_amd.distributed import GpuEngine, ShardedSketcher, slot_shard
+    from hulk_amd.distributed import GpuEngine, ShardedSketcher, interval_slice, slot_shard
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     stream = torch.cuda.Stream()
@@ -38,19 +43,27 @@ def _worker(rank, world, port, q, overlap):
     assert sk.batch_size == BATCH
     eng = GpuEngine(sk, "cuda:0", n_spectra=BATCH)
     sh = ShardedSketcher(eng, S, rank, world, dist)
-    n = I * BATCH
-    offsets = torch.arange(n + 1, dtype=torch.int64, device="cuda:0") * L
+    per = interval_slice(scaling, 0, I, rank, world)[1]     # reads of an interval this rank bins
+    offsets = torch.arange(per * BATCH + 1, dtype=torch.int64, device="cuda:0") * L
     keep = []
-    for s_ in range(STEPS):
+    for s_ in range(STEPS + 1):
+        nt = BATCH if s_ < STEPS else TAIL                  # the last batch is a ragged tail
         parts = []
-        for t in range(BATCH):
-            first = ((s_ * BATCH + t) * world + rank) * I
-            b, _ = synth.reads_torch(first, I, L, device="cuda:0")
-            parts.append(b[:I * L])
+        for t in range(nt):
+            first, cnt = interval_slice(scaling, s_ * BATCH + t, I, rank, world)
+            b, _ = synth.reads_torch(first, cnt, L, device="cuda:0")
+            parts.append(b[:cnt * L])
         bases = torch.cat(parts + [torch.zeros(16, dtype=torch.uint8, device="cuda:0")])
         keep.append(bases)
-        sk.bin_reads_device(bases.data_ptr(), offsets.data_ptr(), n, L, bases.numel(), reads_per_spectrum=I)
+        sk.bin_reads_device(bases.data_ptr(), offsets.data_ptr(), per * nt, L, bases.numel(), reads_per_spectrum=per)
         h = eng.histogram_tensor()
+        if s_ == STEPS:                                     # tail: all-reduce the whole view, then finish() flushes it
+            torch.cuda.synchronize()
+            hc = h.cpu()
+            dist.all_reduce(hc, op=dist.ReduceOp.SUM)
+            h.copy_(hc)
+            torch.cuda.synchronize()
+            break
         if overlap:                                     # bench.py's shape: collective + flush on a second stream
             coll.wait_stream(stream)
             with torch.cuda.stream(coll):
@@ -72,8 +85,8 @@ def _worker(rank, world, port, q, overlap):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_two_ranks_one_gpu_match_single_rank(overlap):
+@pytest.mark.parametrize("overlap,scaling", [(False, "weak"), (True, "weak"), (False, "strong"), (True, "strong")])
+def test_two_ranks_one_gpu_match_single_rank(overlap, scaling):
     import torch
     import torch.multiprocessing as mp
     import hulk_amd
@@ -85,24 +98,25 @@ def test_two_ranks_one_gpu_match_single_rank(overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, overlap)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, overlap, scaling)) for r in range(world)]
     for p in procs:
         p.start()
     mins, weights, _ = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # single rank, same global stream: interval = world * I
-    total = STEPS * BATCH * world * I
+    # single rank, same global stream: interval = I (strong: the reference's rule) or world * I (weak)
+    gi = I if scaling == "strong" else world * I
+    total = (STEPS * BATCH + TAIL) * gi
     bases, offsets = synth.reads_numpy(0, total, L)
-    g = hulk_amd.GpuSketcher(K, W, S, interval=world * I)
+    g = hulk_amd.GpuSketcher(K, W, S, interval=gi)
     g.add_reads(bases, offsets)
     g.finish()
     m1, w1 = g.sketch()
     g.close()
     assert np.array_equal(mins, m1)
     assert np.array_equal(weights, w1)                  # same kernels, same order: bit-identical
-    o = pyorc.Sketcher(K, W, S, 0, 1.0, world * I)
+    o = pyorc.Sketcher(K, W, S, 0, 1.0, gi)
     o.add_reads(bases, offsets)
     o.finish()
     mo, wo = o.sketch()
