@@ -1,22 +1,15 @@
-# PMC passes for the bench (separate runs, --kernel-trace only): HBM traffic + VALU activity
+# PMC passes for the bench (separate runs, --kernel-trace only — never combined with other trace domains):
+# HBM traffic, VALU activity, LDS activity / bank conflicts, L2 hits.  Results -> gpurun_out/pmc/<pass>/
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc; rm -rf $OUT; mkdir -p $OUT
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-cold --single-pass --steps 5 --warmup 1 $BENCH_ARGS"
 cd /tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --single-pass --steps 5 --warmup 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --single-pass --steps 5 --warmup 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/sq -o s --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --single-pass --steps 5 --warmup 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/tcc -o t --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --single-pass --steps 5 --warmup 1 > /dev/null 2>&1
-python - <<'PY'
-import csv,glob,collections,os
-OUT=os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/pmc'
-for f in sorted(glob.glob(OUT+'/**/*counter_collection.csv', recursive=True)):
-    agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
-    for row in csv.DictReader(open(f)):
-        k=row['Kernel_Name']
-        if 'hulk' not in k: continue
-        import re
-        k=re.search(r'(k_\w+)',k).group(1)
-        agg[k][row['Counter_Name']]+=float(row['Counter_Value']); n[(k,row['Counter_Name'])]+=1
-    for k,v in sorted(agg.items()):
-        print(k, {a:(round(b/max(n[(k,a)],1),1), n[(k,a)]) for a,b in v.items()})
-PY
+pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o p --output-format csv -- $BENCH > /dev/null 2> $OUT/$name.err; }
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
+pass valu SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_WAIT_ANY
+pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_ATOMIC_RETURN SQ_INSTS_LDS SQ_INSTS_SMEM
+pass tcc TCC_HIT_sum TCC_MISS_sum
+pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
+ls $OUT
