@@ -329,19 +329,31 @@ def main():
         kj_avg_s = (kj_ms / 1e3) / max(n_kj, 1)
 
         def valu_roofline(kernel, avg_s):
-            """VALU-issue floor of a launch: (VALU wave-instructions of the launch, SQ_INSTS_VALU from the rocprofv3 PMC
-            pass of this command) / 1024 SIMDs x 2 cycles per wave64 instruction / 2.4 GHz.  frac = floor / measured."""
-            insts = from_profile(kernel, "SQ_INSTS_VALU")
+            """VALU-issue roofline of a launch from the rocprofv3 PMC pass of this command (profiles/r02_pmc.json):
+            floor_us        = SQ_INSTS_VALU / 1024 SIMDs x 2 cycles / 2.4 GHz — every wave64 VALU instruction at the
+                              2-cycle rate MI355X_MICROARCH.md quotes (v_fma_f32-class ops);
+            floor_us_issue  = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz — the cycles the VALU pipes were
+                              actually occupied (the counter ticks in quad-cycles).  Integer, 64-bit, fp64 and VOP3 ops
+                              issue at ~4.5 cycles per wave64 instruction on this chip, v_rcp_f64 at 16
+                              (tools/ubench/op_cost.hip, profiles/r02_op_cost.txt), which is what these kernels are made of.
+            frac / frac_issue = floor / the launch duration measured live in this run."""
+            insts, active = from_profile(kernel, "SQ_INSTS_VALU"), from_profile(kernel, "SQ_ACTIVE_INST_VALU")
             if not insts or avg_s <= 0:
                 return None
-            scale = reads_per_rank_step / float(pmc.get("reads_per_launch", INTERVAL * BATCH))
+            per_launch = float(pmc.get("reads_per_launch", INTERVAL * BATCH))
+            scale = reads_per_rank_step / per_launch
             floor_us = insts * scale / SIMDS * VALU_CYCLES / (CLOCK_GHZ * 1e3)
-            return {"kernel": kernel, "wave_instr_per_read": insts / float(pmc.get("reads_per_launch", INTERVAL * BATCH)),
+            out_ = {"kernel": kernel, "wave_instr_per_read": insts / per_launch,
                     "cycles_per_instr_assumed": VALU_CYCLES, "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
                     "floor_us": floor_us, "avg_launch_us": avg_s * 1e6, "frac": floor_us / (avg_s * 1e6),
                     "instr_from_profile": PMC_PROFILE,
-                    "formula": "SQ_INSTS_VALU per launch / 1024 SIMDs * 2 cycles / 2.4 GHz; every instruction priced at "
-                               "the full rate (v_mad_u64_u32, v_mul_lo_u32 and fp64 ops issue slower: the true floor is higher)"}
+                    "formula": "floor_us = SQ_INSTS_VALU / 1024 SIMDs * 2 cycles / 2.4 GHz; floor_us_issue = "
+                               "SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / 1024 / 2.4 GHz; frac = floor / avg_launch_us"}
+            if active:
+                fi = active * scale * 4.0 / SIMDS / (CLOCK_GHZ * 1e3)
+                out_.update({"cycles_per_instr_measured": 4.0 * active / insts, "floor_us_issue": fi,
+                             "frac_issue": fi / (avg_s * 1e6)})
+            return out_
 
         # The HBM-streaming kernel of the path = k_cws_scan.  Unpruned it makes ONE fp32 pass over this rank's
         # slice of K per launch (4*slots*k^4 bytes, SURVEY.md §8d) + the BATCH reciprocal vectors; with the exact
