@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--no-prune", action="store_true",
                     help="the timed pass itself runs with the exact bounds of the CWS stage off (HULK_FLAG_NO_PRUNE): every "
                          "interval is evaluated against the whole table (profiling aid; implies --single-pass)")
+    ap.add_argument("--n-frac", type=float, default=0.0,
+                    help="variant workload: this fraction of the reads gets one 'N' at a pseudo-random position (real Illumina "
+                         "data has such reads; they leave the table-free fast path of the minimizer kernel).  Not the headline.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the value_cold pass (C2 exactly: 10 M reads, no warm-up)")
     ap.add_argument("--single-pass", action="store_true",
@@ -211,7 +214,13 @@ def main():
             b, _ = synth.reads_torch(first, cnt, READ_LEN, device=device)
             parts.append(b[:cnt * READ_LEN])
         pad = torch.zeros(16, dtype=torch.uint8, device=device)
-        step_bases.append(torch.cat(parts + [pad]))
+        sbuf = torch.cat(parts + [pad])
+        if args.n_frac > 0:                   # one 'N' in a deterministic pseudo-random subset of the reads
+            idx = torch.arange(reads_per_rank_step, dtype=torch.int64, device=device)
+            hsh = ((idx + s_ * 1_000_003) * 0x9E3779B1) & 0xFFFFFFFF
+            sel = idx[(hsh.double() / 4294967296.0) < args.n_frac]
+            sbuf[sel * READ_LEN + (hsh[sel] >> 8) % READ_LEN] = ord("N")
+        step_bases.append(sbuf)
     offsets = torch.arange(reads_per_rank_step + 1, dtype=torch.int64, device=device) * READ_LEN
     torch.cuda.synchronize()
 
@@ -375,7 +384,8 @@ def main():
             "config": {"workload": "C2: synthetic 150bp reads, k=21, w=9, sketchSize=512, "
                                    f"interval={global_interval} reads of the global stream ({per_interval} per rank), "
                                    f"{BATCH} intervals per step, HBM-resident input"
-                                   + (", CWS-scan bounds OFF (--no-prune)" if args.no_prune else ""),
+                                   + (", CWS-scan bounds OFF (--no-prune)" if args.no_prune else "")
+                                   + (f", VARIANT: {args.n_frac:g} of the reads carry one N" if args.n_frac > 0 else ""),
                        "reads_per_step": reads_per_step, "reads_per_rank_step": reads_per_rank_step,
                        "total_reads": total_reads, "intervals_per_step": BATCH, "global_interval": global_interval,
                        "parallelism": f"read-shard x{world}, replicated count-min, slot-sharded CWS"},

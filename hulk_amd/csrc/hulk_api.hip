@@ -108,8 +108,7 @@ struct hulk_ctx {
         size_t cap_bases = 0, cap_off = 0; hipEvent_t ev = nullptr; bool busy = false;
     } hstage[2];
     int hstage_cur = 0;
-    uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;   // d_slow_count[2]: alternate per launch
-    uint32_t slow_parity = 0;
+    uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;   // reads the fast kernel deferred (built by k_region_offsets)
     MinimizerList ml{}; uint64_t ml_regions = 0;
     uint64_t *d_long_xs = nullptr, *d_long_table = nullptr; uint8_t *d_long_valid = nullptr;   // long-sequence scratch
     void *d_long_desc = nullptr; uint64_t long_desc_cap = 0;
@@ -501,17 +500,13 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             HIPCHK(c, hipMalloc((void **)&c->d_slow_list, (size_t)(n + n / 4 + 1024) * 4));
             c->d_slow_cap = n + n / 4 + 1024;
         }
-        // the slow-list counter alternates between two words; the launch zeroes the one the NEXT launch will use
-        // (in k_region_offsets), so no memset sits in front of the minimizer kernel
-        uint32_t *slow_cnt = c->d_slow_count + c->slow_parity, *slow_cnt_next = c->d_slow_count + (c->slow_parity ^ 1u);
-        c->slow_parity ^= 1u;
         const uint64_t regions = (n + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE;
         // (a region never shrinks again: calls with and without reads of two groups may alternate)
         const uint64_t rcap = std::max<uint64_t>(minimizer_list_rcap(c->p.w, pair_ok), c->ml.rcap);
         if (regions > c->ml_regions || c->ml.rcap != rcap) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum);
-            hipFree(c->ml.lo); hipFree(c->ml.lo_cnt);
+            hipFree(c->ml.lo); hipFree(c->ml.lo_cnt); hipFree(c->ml.dmask); hipFree(c->ml.dsum);
             uint32_t *keep_partial = c->ml.partial; const uint32_t keep_parts = c->ml.max_parts;
             uint32_t *keep_nib = c->ml.nib, *keep_over = c->ml.nib_over; const uint32_t keep_np = c->ml.nib_parts;
             c->ml = MinimizerList{}; c->ml_regions = 0;
@@ -526,6 +521,8 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             HIPCHK(c, hipMalloc((void **)&c->ml.bsum, (cap / 1024 + 2) * 4));
             HIPCHK(c, hipMalloc((void **)&c->ml.lo, cap * JUMP_LO_CAP * sizeof(uint4)));
             HIPCHK(c, hipMalloc((void **)&c->ml.lo_cnt, cap * 4));
+            HIPCHK(c, hipMalloc((void **)&c->ml.dmask, cap * 4));
+            HIPCHK(c, hipMalloc((void **)&c->ml.dsum, (cap / 1024 + 2) * 4));
             if (!c->ml.nib) {
                 const size_t nr = ((size_t)c->B + 262143) / 262144;
                 c->ml.nib_parts = 48;
@@ -544,17 +541,19 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             HIPCHK(c, hipEventCreate(&pr.a)); HIPCHK(c, hipEventCreate(&pr.b));
             HIPCHK(c, hipEventRecord(pr.a, c->stream));
         }
-        HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->ml, c->d_state,
-                                        c->d_min_slots, c->d_slow_list, slow_cnt));
+        HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->ml, c->d_state, c->d_min_slots));
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
         ProfileRec pj{}; pj.which = 2;
         if (c->profiling) { HIPCHK(c, hipEventCreate(&pj.a)); HIPCHK(c, hipEventCreate(&pj.b)); }
-        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist, slow_cnt_next, pj.a, pj.b));
+        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist, c->d_slow_list, c->d_slow_count, pj.a, pj.b));
         if (c->profiling) c->prof.push_back(pj);
         pick_config(c->p.k, max_len, P, threads);      // (fast_ok implies max_len <= 256: always fits)
-        const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(128, (n + 3) / 4);   // the list is normally empty or short
+        // the list is normally empty or short; its length is only known on the device, so the grid is fixed: enough
+        // workgroups that 1 % of deferred reads (reads with N) do not queue behind 512 waves (blocks past the list exit at once)
+        static const uint32_t slow_blocks = [] { const char *e = getenv("HULK_SLOW_BLOCKS"); const long v = e ? atol(e) : 2048; return (uint32_t)(v < 1 ? 1 : v > 8192 ? 8192 : v); }();
+        const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(slow_blocks, (n + 3) / 4);
         HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, hist, c->d_state,
-                                       c->d_min_slots, c->d_slow_list, slow_cnt, list_blocks));
+                                       c->d_min_slots, c->d_slow_list, c->d_slow_count, list_blocks));
         return HULK_OK;
     }
     const bool fits = pick_config(c->p.k, max_len, P, threads);
@@ -782,7 +781,7 @@ void hulk_destroy(hulk_ctx *c) {
         hipFree(hs.d_bases); hipFree(hs.d_off);
     }
     hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
-    hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial); hipFree(c->ml.nib); hipFree(c->ml.nib_over); hipFree(c->ml.lo); hipFree(c->ml.lo_cnt);
+    hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial); hipFree(c->ml.nib); hipFree(c->ml.nib_over); hipFree(c->ml.lo); hipFree(c->ml.lo_cnt); hipFree(c->ml.dmask); hipFree(c->ml.dsum);
     hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;

@@ -38,6 +38,8 @@ struct MinimizerList {
     uint8_t *slot;      // [regions][rcap] spectrum (ring slot) of the read each value came from
     uint32_t *key;      // dense (regions back to back): slot << 20 | bin, written by k_jump_bin
     uint32_t *cnt;      // [regions]
+    uint32_t *dmask;    // [regions] bit i: read i of the region is deferred to the generic kernel (N, too long, too repetitive)
+    uint32_t *dsum;     // [regions / 1024 + 1] per-block sums of popcount(dmask) for the deferred-read list
     uint32_t *off;      // [regions + 1] exclusive prefix of cnt
     uint32_t *bsum;     // [regions / 1024 + 1] per-block sums for the prefix
     uint32_t *partial;  // [max_parts][ring_n][num_bins] per-part spectra of k_range_hist
@@ -87,11 +89,10 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
                                 uint32_t list_blocks);
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
                                  uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
-                                 DevState *d_state, unsigned long long *d_min_slots, uint32_t *d_slow_list,
-                                 uint32_t *d_slow_count);
+                                 DevState *d_state, unsigned long long *d_min_slots);
 hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
-                                 uint32_t *d_hists, uint32_t *d_zero_word, hipEvent_t jump_begin = nullptr,
-                                 hipEvent_t jump_end = nullptr);
+                                 uint32_t *d_hists, uint32_t *d_slow_list, uint32_t *d_slow_count,
+                                 hipEvent_t jump_begin = nullptr, hipEvent_t jump_end = nullptr);
 uint32_t minimizer_list_rcap(uint32_t w, bool pair);
 hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSeqDesc *d_desc, uint32_t n_seqs,
                              uint64_t max_npos, MinimizerParams P, uint64_t *d_xs, uint8_t *d_valid, uint64_t *d_table,

@@ -20,6 +20,7 @@ namespace {
 //                tab[tab_size] u64  open-addressing set = the per-read golang-set
 //                q[128] u64     distinct minimizers waiting for a full-wave jump-hash pass
 //                pk[...] u8     2-bit packed bases, base p at bits 2(p%4) of byte p/4
+//                pkn[...] u8    "code 4" flag of base p at bit 2(p%4) of byte p/4 (reads with N and the like)
 // LDS per block: lut[256]       seq_nt4_table (minimizer.go:13-30)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint8_t nt4_of(unsigned c) {
@@ -41,7 +42,10 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
                                                        const uint32_t *__restrict__ read_list_count) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint8_t *lut = smem;
-    if (read_list) n_reads = *read_list_count;      // second pass over the reads the fast kernel deferred
+    if (read_list) {                                // second pass over the reads the fast kernel deferred
+        n_reads = *read_list_count;
+        if ((uint64_t)blockIdx.x * (blockDim.x >> 6) >= n_reads) return;   // the grid is sized for a long list: most blocks have nothing to do
+    }
     for (int t = threadIdx.x; t < 256; t += blockDim.x) lut[t] = nt4_of((unsigned)t);
     __syncthreads();
 
@@ -57,11 +61,13 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
     uint32_t *qs = (uint32_t *)(q + 128);                      // spectrum slot of each queued value
     uint8_t *pk8 = (uint8_t *)(q + 128 + 64);
     const uint32_t *pk32 = (const uint32_t *)pk8;
+    const size_t pkbytes = ((((size_t)xcap + 32 + 3) / 4 + 16) + 7) & ~(size_t)7;
+    uint8_t *pkn8 = pk8 + pkbytes;                             // "code 4" flags, same layout as pk (low bit of a base's pair)
+    const uint32_t *pkn32 = (const uint32_t *)pkn8;
 
     const int32_t k = (int32_t)P.k, w = (int32_t)P.w;
     const int32_t wwin = w > 0 ? w : 1;   // w == 0: the deque is emptied every step, same window as w == 1
     const uint64_t mask = (1ull << (2 * k)) - 1;
-    const uint64_t shift = (uint64_t)(2 * (k - 1));
 
     for (uint32_t s = lane; s < tabn; s += 64) tab[s] = TAB_EMPTY;
     wave_sync();
@@ -101,13 +107,14 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
                 if (sh && al + 8 <= (uintptr_t)bases + P.bases_bytes) hi = *(const uint32_t *)(al + 4);
                 const uint32_t by = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
                 const int nv = left < 4 ? (int)left : 4;
-                unsigned pack = 0;
+                unsigned pack = 0, npack = 0;
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     unsigned c = lut[(by >> (8 * t)) & 0xff];
-                    if (t < nv) { sawN |= (c > 3); pack |= (c & 3u) << (2 * t); }
+                    if (t < nv) { sawN |= (c > 3); pack |= (c & 3u) << (2 * t); npack |= (c >> 2) << (2 * t); }
                 }
                 pk8[p >> 2] = (uint8_t)pack;
+                pkn8[p >> 2] = (uint8_t)npack;
             }
         }
         const bool hasN = __ballot(sawN) != 0ull;
@@ -121,24 +128,30 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
             bool valid = false;
             if (j < npos) {
                 uint64_t f, r;
-                if (!hasN) {
+                {
                     const uint32_t bo = 2u * (uint32_t)j, d = bo >> 5, o = bo & 31u;
                     const uint64_t lo = (uint64_t)pk32[d] | ((uint64_t)pk32[d + 1] << 32);
                     uint64_t W = o ? (lo >> o) | ((uint64_t)pk32[d + 2] << (64 - o)) : lo;
                     W &= mask;                    // base j at bits 0..1, base i at bits 2(k-1)..
-                    uint64_t rev = __brevll(W) >> (64 - 2 * k);
-                    f = ((rev >> 1) & 0x5555555555555555ull) | ((rev & 0x5555555555555555ull) << 1);
                     r = (~W) & mask;
-                } else {
-                    // literal recurrence; bases before i-k cannot reach bit positions that
-                    // survive (f is masked every step, r loses 2 bits per step)
-                    f = 0; r = 0;
-                    int32_t p0 = i - k; if (p0 < 0) p0 = 0;
-                    for (int32_t p = p0; p <= i; p++) {
-                        const uint64_t c = lut[bases[o0 + (uint64_t)p]];
-                        f = (f << 2 | c) & mask;
-                        r = (r >> 2) | ((3ull ^ c) << shift);
+                    if (hasN) {
+                        // The reference does not special-case code 4 (minimizer.go:118-122): `f = (f<<2 | c) & mask` ORs bit 2
+                        // into the PREVIOUS base's pair, `r = r>>2 | (3^c) << shift` (r is never masked) puts 7 at the top —
+                        // complement 3 for the base itself, and bit 2k, which one step later is the low bit of the NEXT
+                        // base's pair.  So with N(p) = "base p has code 4" and code 0 stored for such a base:
+                        //   f: pair of base p |= N(p+1) for every base of the k-mer but its last;
+                        //   r: pair of base p |= N(p-1) for every base of the k-mer (p-1 may lie in front of it), and
+                        //      bit 2k is set when the k-mer's last base is an N.
+                        // X = the flags of bases j-1 .. j+k-1 at bits 0, 2, ..., 2k.
+                        const uint32_t nbo = j > 0 ? bo - 2u : 0u, nd = nbo >> 5, no = nbo & 31u;
+                        const uint64_t nlo = (uint64_t)pkn32[nd] | ((uint64_t)pkn32[nd + 1] << 32);
+                        uint64_t X = no ? (nlo >> no) | ((uint64_t)pkn32[nd + 2] << (64 - no)) : nlo;
+                        if (j == 0) X <<= 2;
+                        W |= (X >> 4) & (mask >> 2);
+                        r |= X & ((mask << 1) | 1ull);
                     }
+                    const uint64_t rev = __brevll(W) >> (64 - 2 * k);
+                    f = ((rev >> 1) & 0x5555555555555555ull) | ((rev & 0x5555555555555555ull) << 1);
                 }
                 if (f != r) {
                     const uint64_t canon = f > r ? r : f;
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
 // Per-read set semantics: a 128-entry open-addressing set per group; all run-start values of a
 // lane are inserted with back-to-back LDS compare-and-swaps (one round trip), collisions probe on.
 // Eligible reads: no code-4 base, 1 <= w <= WM <= 16, k-mer positions <= 16*w, length <= 256,
-// <= 64 run starts.  Anything else is appended to slow_list and handled by k_minimizer_bin.
+// <= 64 run starts.  Anything else is marked in the region's deferred mask and handled by k_minimizer_bin.
 //
 // LDS per group: tab[128] u64 | pk[20] u32      per wave: q[192] u64      per block: lut[256]
 // ------------------------------------------------------------------------------------------
@@ -347,9 +360,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                                                         const uint64_t *__restrict__ offsets,
                                                         uint64_t n_reads, MinimizerParams P,
                                                         MinimizerList ml, DevState *st,
-                                                        unsigned long long *__restrict__ min_slots,
-                                                        uint32_t *__restrict__ slow_list,
-                                                        uint32_t *__restrict__ slow_count) {
+                                                        unsigned long long *__restrict__ min_slots) {
     extern __shared__ __align__(16) unsigned char smem[];
     // (the first 2 KB of LDS held ASCII -> 2-bit tables once; the layout behind them is unchanged)
 
@@ -382,6 +393,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     uint64_t *xl = ml.x + region * ml.rcap;
     uint8_t *sl8 = ml.slot + region * ml.rcap;
     uint32_t wcount = 0;              // wave-uniform: values written to the region so far
+    uint32_t dmask = 0;               // wave-uniform: reads of the region handed to the generic kernel
     // ablation switches (tools/k1_ablate.py) exist only in the DBG instantiation: in the production kernel they
     // cost a branch per k-mer position and SGPRs the compiler then spills to VGPR lanes
     const uint32_t dbg = DBG ? P.debug : 0u;
@@ -689,9 +701,15 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     if ((startbits >> t) & 1u) cs[at++] = X[t];
             }
         }
-        if (act && defer) {
-            if (gl == 0 && half == 0) { const uint32_t at = atomicAdd(slow_count, 1u); slow_list[at] = (uint32_t)(wave_first + idx); }
-            act = false;
+        {
+            // deferred reads are marked in the region's mask (one store per wave at the end): a compact list is built by
+            // k_region_offsets.  (An atomicAdd on ONE list counter per deferred read serialised at ~12 ns each: 5 % of
+            // reads with an N doubled this kernel's time.)
+            const uint64_t dbal = __ballot(act && defer && gl == 0 && half == 0);
+            if (PAIR) dmask |= ((uint32_t)(dbal & 1u) | ((uint32_t)(dbal >> 32) & 1u) << 1) << (RPI * it);
+            else dmask |= ((uint32_t)(dbal & 1u) | ((uint32_t)(dbal >> 16) & 1u) << 1 | ((uint32_t)(dbal >> 32) & 1u) << 2 |
+                           ((uint32_t)(dbal >> 48) & 1u) << 3) << (RPI * it);
+            if (act && defer) act = false;
         }
         wave_sync();
 
@@ -736,7 +754,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             if ((newmask >> rnd) & 1u) tab[myslot[rnd]] = TAB_EMPTY;
         wave_sync();
     }
-    if (lane == 0 && wave_first < n_reads) ml.cnt[region] = wcount;
+    if (lane == 0 && wave_first < n_reads) { ml.cnt[region] = wcount; ml.dmask[region] = dmask; }
     if (dbg && sink == 0xdeadbeefu) xl[0] = sink;
     __shared__ unsigned long long blk_nmin[4];
     if (lane == 0) blk_nmin[wid] = wcount;
@@ -885,7 +903,7 @@ size_t minimizer_lds_per_wave(uint32_t xcap, uint32_t tab_size) {
     size_t words = (size_t)xcap + (xcap + 63) / 64 + tab_size + 128 + 64;
     size_t pk = ((size_t)xcap + 32 + 3) / 4 + 16;          // packed bases + slack for 3-dword reads
     pk = (pk + 7) & ~(size_t)7;
-    return words * 8 + pk;
+    return words * 8 + 2 * pk;                              // ... and the code-4 flags in the same layout
 }
 
 size_t minimizer_lds_per_block(uint32_t xcap, uint32_t tab_size, int waves) {
@@ -921,8 +939,7 @@ size_t minimizer_fast_lds(uint32_t, bool pair) {
 
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
                                  uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
-                                 DevState *d_state, unsigned long long *d_min_slots, uint32_t *d_slow_list,
-                                 uint32_t *d_slow_count) {
+                                 DevState *d_state, unsigned long long *d_min_slots) {
     if (n_reads == 0) return hipSuccess;
     const bool pair = P.pair != 0;
     const size_t lds = minimizer_fast_lds(P.w, pair);
@@ -933,7 +950,7 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
     const bool fm = P.k <= 27 && !no_fmin;
 #define HULK_LAUNCH_FAST3(WM, FMv, DBGv, WEQv, KCv, PAIRv)                                                           \
     hipLaunchKernelGGL((k_minimizer_fast<WM, FMv, DBGv, WEQv, KCv, PAIRv>), g, b, lds, s, d_bases, d_offsets, n_reads, \
-                       P, ml, d_state, d_min_slots, d_slow_list, d_slow_count)
+                       P, ml, d_state, d_min_slots)
 #define HULK_LAUNCH_FAST2(WM, FMv, DBGv, WEQv, KCv)                                                                  \
     do { if (pair) HULK_LAUNCH_FAST3(WM, FMv, DBGv, WEQv, KCv, true); else HULK_LAUNCH_FAST3(WM, FMv, DBGv, WEQv, KCv, false); } while (0)
 #define HULK_LAUNCH_FAST(WM)                                                                                         \

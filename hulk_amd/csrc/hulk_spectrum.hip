@@ -18,7 +18,8 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // The step loop of k_jump_bin in assembly (fixed registers v40..v57, s60..s63): hipcc's version of the same loop
 // carries two v_mov_b64 and a dozen scalar mask instructions per pair of steps; this one is the 17 VALU
-// instructions of a step plus v_cmp / s_and and the exit test, the LCG state ping-ponging between v[40:41] and
+// instructions of a step (16 since r * 2^-31 = ((key >> 33) + 1) * 2^-31 is ONE fma(float64(key >> 33), 2^-31, 2^-31) instead of an
+// integer add before the conversion and an exponent adjustment after it) plus v_cmp / s_and and the exit test, the LCG state ping-ponging between v[40:41] and
 // v[42:43].  Lanes that reach p >= n leave the exec mask and keep their t.  The loop ends when at most `cut`
 // lanes are still running (cut = 0: when none is): chains take 12.8 +- 3.5 steps, so the last few lanes of a round
 // of 64 would keep the whole wave busy for ~24 — they are handed over instead (`left` = their mask, key/t = their
@@ -36,9 +37,8 @@ __device__ __forceinline__ double jump_steps_asm(uint32_t &klo, uint32_t &khi, d
     "v_mul_lo_u32 v55, " KS_HI ", %[alo]\n\t"                                        \
     "v_add3_u32 " KD_HI ", v55, " KD_HI ", v54\n\t"                                  \
     "v_lshrrev_b32 v54, 1, " KD_HI "\n\t"                                            \
-    "v_add_u32 v54, 1, v54\n\t"                                                      \
     "v_cvt_f64_u32 v[46:47], v54\n\t"                                                \
-    "v_add_u32 v47, 0xfe100000, v47\n\t"                                             \
+    "v_fma_f64 v[46:47], v[46:47], %[p31], %[p31]\n\t"                               \
     "v_rcp_f64 v[48:49], v[46:47]\n\t"                                               \
     "s_nop 0\n\t"                                                                    \
     "v_fma_f64 v[50:51], -v[46:47], v[48:49], 1.0\n\t"                               \
@@ -77,7 +77,7 @@ __device__ __forceinline__ double jump_steps_asm(uint32_t &klo, uint32_t &khi, d
         "v_mov_b32 %[ohi], v41\n\t"
         : [tlo] "=v"(tlo), [thi] "=v"(thi), [olo] "=v"(olo), [ohi] "=v"(ohi), [mlo] "=s"(mlo), [mhi] "=s"(mhi)
         : [klo] "v"(klo), [khi] "v"(khi), [flo] "v"(flo), [fhi] "v"(fhi), [t0lo] "v"(t0lo), [t0hi] "v"(t0hi),
-          [alo] "s"(0x87B0B0FDu), [ahi] "s"(0x27BB2EE6u), [cut] "s"(cut)
+          [alo] "s"(0x87B0B0FDu), [ahi] "s"(0x27BB2EE6u), [cut] "s"(cut), [p31] "s"(0x3E00000000000000ull /* 2^-31 */)
         : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
           "v56", "v57", "s60", "s61", "s62", "s63", "vcc", "scc", "memory");
 #undef HULK_JSTEP
@@ -173,34 +173,51 @@ __global__ __launch_bounds__(256) void k_jump_left(MinimizerList ml, uint32_t n_
 // ------------------------------------------------------------------------------------------
 constexpr int HIST_RANGE = 32768;     // bins per workgroup (128 KB of LDS)
 
-// exclusive prefix sum of the region counts: per-block sums, then one block per 1024 regions
+// exclusive prefix sum of the region counts: per-block sums, then one block per 1024 regions.  The same two kernels
+// scan the number of deferred reads per region (popcount of dmask) and write the compact deferred-read list the
+// generic kernel works through, in read order.
 __global__ __launch_bounds__(1024) void k_region_bsum(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ bsum,
+                                                      const uint32_t *__restrict__ dmask, uint32_t *__restrict__ dsum,
                                                       uint32_t n_regions) {
-    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t wsum[16], wdsum[16];
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
     uint32_t v = i < n_regions ? cnt[i] : 0u;
-    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    uint32_t dv = i < n_regions ? (uint32_t)__popc(dmask[i]) : 0u;
+    for (int off = 32; off; off >>= 1) { v += __shfl_xor(v, off); dv += __shfl_xor(dv, off); }
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = v; wdsum[threadIdx.x >> 6] = dv; }
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t t = 0; for (int x = 0; x < 16; x++) t += wsum[x]; bsum[blockIdx.x] = t; }
+    if (threadIdx.x == 0) {
+        uint32_t t = 0, d = 0;
+        for (int x = 0; x < 16; x++) { t += wsum[x]; d += wdsum[x]; }
+        bsum[blockIdx.x] = t; dsum[blockIdx.x] = d;
+    }
 }
 __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ bsum,
                                                          uint32_t *__restrict__ off, uint32_t n_regions,
-                                                         uint32_t *__restrict__ nib_over, uint32_t *__restrict__ zero_word) {
+                                                         uint32_t *__restrict__ nib_over, const uint32_t *__restrict__ dmask,
+                                                         const uint32_t *__restrict__ dsum, uint32_t *__restrict__ slow_list,
+                                                         uint32_t *__restrict__ slow_count) {
     if (nib_over && blockIdx.x == 0 && threadIdx.x < RING_MAX) nib_over[threadIdx.x] = 0;
-    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;      // the next launch's slow-list counter
-    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t wsum[16], wdsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t i = blockIdx.x * 1024u + (uint32_t)tid;
-    uint32_t before = 0;
-    for (uint32_t b = 0; b < blockIdx.x; b++) before += bsum[b];       // same address for the whole block: broadcast
+    uint32_t before = 0, dbefore = 0;
+    for (uint32_t b = 0; b < blockIdx.x; b++) { before += bsum[b]; dbefore += dsum[b]; }   // same address for the whole block: broadcast
     const uint32_t v = i < n_regions ? cnt[i] : 0u;
-    const uint32_t incl = wave_scan_incl(v);
-    if (lane == 63) wsum[wid] = incl;
+    uint32_t m = i < n_regions ? dmask[i] : 0u;
+    const uint32_t dv = (uint32_t)__popc(m);
+    const uint32_t incl = wave_scan_incl(v), dincl = wave_scan_incl(dv);
+    if (lane == 63) { wsum[wid] = incl; wdsum[wid] = dincl; }
     __syncthreads();
-    for (int x = 0; x < wid; x++) before += wsum[x];
+    for (int x = 0; x < wid; x++) { before += wsum[x]; dbefore += wdsum[x]; }
     if (i < n_regions) off[i] = before + incl - v;
-    if (i + 1 == n_regions) off[n_regions] = before + incl;
+    if (i + 1 == n_regions) { off[n_regions] = before + incl; *slow_count = dbefore + dincl; }
+    uint32_t at = dbefore + dincl - dv;
+    while (m) {                                                   // rare: the reads of this region the fast kernel deferred
+        const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+        slow_list[at++] = i * FAST_READS_PER_WAVE + b;
+        m &= m - 1u;
+    }
 }
 
 // workgroup (r, t, part): LDS spectrum of bins [r*RANGE, (r+1)*RANGE) over part `part` of interval t's keys
@@ -403,13 +420,15 @@ __global__ void k_add_hist(uint32_t *hist, const uint32_t *add, int32_t n) {
 // ---------------------------------------------------------------------------- host wrappers
 // K1b: jump hash of the list (dense key array); K1c: spectrum ranges in LDS, merged without atomics
 hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
-                                 uint32_t *d_hists, uint32_t *d_zero_word, hipEvent_t jump_begin, hipEvent_t jump_end) {
+                                 uint32_t *d_hists, uint32_t *d_slow_list, uint32_t *d_slow_count, hipEvent_t jump_begin,
+                                 hipEvent_t jump_end) {
     if (n_reads == 0) return hipSuccess;
     hipError_t e = hipSuccess;
     const uint32_t n_regions = (uint32_t)((n_reads + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE);
     const uint32_t nblk = (n_regions + 1023) / 1024;
-    hipLaunchKernelGGL(k_region_bsum, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, n_regions);
-    hipLaunchKernelGGL(k_region_offsets, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.off, n_regions, ml.nib_over, d_zero_word);
+    hipLaunchKernelGGL(k_region_bsum, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.dmask, ml.dsum, n_regions);
+    hipLaunchKernelGGL(k_region_offsets, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.off, n_regions, ml.nib_over, ml.dmask,
+                       ml.dsum, d_slow_list, d_slow_count);
     // k_jump_bin needs no LDS; a dummy allocation caps its occupancy so that the flush kernels of the
     // previous batch (other stream) find free wave slots next to it
     static int jump_lds = -1;

@@ -50,6 +50,10 @@ def test_bench_json_contract_and_collective_path():
     assert sc["tiles_read_per_launch"] == sc["tiles_covered_per_launch"] > 0
     assert sa["tiles_read_per_launch"] < sc["tiles_read_per_launch"]
     assert sc["avg_launch_us"] > sa["avg_launch_us"]
+    # variant: 1 % of the reads carry an N (they leave the fast minimizer kernel): measured -2 %, must stay within 15 % here
+    e = _run(["--no-cpu-baseline", "--no-cold", "--single-pass", "--n-frac", "0.01"])
+    assert e["sketch_md5"] != a["sketch_md5"] and e["value"] > 0.85 * a["value"]
+    assert "VARIANT" in e["config"]["workload"]
     # weak scaling is identical to strong at one rank
     d = _run(["--no-cpu-baseline", "--no-cold", "--single-pass", "--scaling", "weak"])
     assert d["scaling"] == "weak" and d["sketch_md5"] == a["sketch_md5"]
