@@ -240,7 +240,6 @@ __device__ __forceinline__ double poww(const double *tab, long long x, double ln
     const uint32_t u = (uint32_t)x;
     return tab[u & 127u] * tab[128u + ((u >> 7) & 127u)] * tab[256u + (u >> 14)];
 }
-constexpr int CMSD_GROUP = 2;         // chunks staged per barrier (LDS: 112 KB values + 28 KB times + 14 KB stage)
 
 __global__ __launch_bounds__(512) void k_cmsd_segsum(const uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
                                                      const uint32_t *__restrict__ eidx, const uint32_t *__restrict__ etot,
@@ -316,6 +315,15 @@ __global__ __launch_bounds__(256) void k_cmsd_base(const double *__restrict__ se
     ctrd[i] = C;
 }
 
+// Replay with decay.  Workgroup (segment, spectrum): wave d < depth replays row d of the count-min sketch over the
+// segment's bins in order (lazily decayed LDS counters {value, time}); the estimate of a bin is the minimum over the
+// rows, which the row waves form with ONE 64-bit LDS atomic minimum per (row, bin) on a small staging array (the
+// estimates are non-negative doubles, whose bit patterns order like unsigned integers; +inf = "bin not in the stream") —
+// so the staging array is 8 bytes per bin instead of 8 per (row, bin), a barrier covers CMSD_FG = 8 chunks of 64 bins
+// instead of 2, and the combiner wave (d == depth) reads one value per bin: it writes f (fp64), 1/f (fp32), wipes the
+// spectrum and resets the staging slot while the row waves are one group ahead.  (The first version staged every row's
+// value and synchronised every 128 bins: 520 us per 16 spectra of 923,521 bins, almost all of it barrier and combiner time.)
+constexpr int CMSD_FG = 8;            // chunks per barrier group of k_cmsd_freq
 __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
                                                    const uint8_t *__restrict__ meta8, const uint32_t *__restrict__ eidx,
                                                    const uint32_t *__restrict__ sege0, const double *__restrict__ cstart,
@@ -323,9 +331,11 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
                                                    int width, int seg_chunks, size_t row_stride, double omega,
                                                    DevState *st, FlushBatch fb) {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int GB = CMSD_FG * 64;
+    constexpr unsigned long long INF_BITS = 0x7FF0000000000000ull;
     double *lval = (double *)smem;                                               // [depth][width] counter value ...
-    double *stage = lval + (size_t)depth * width;                                // [2][depth][CMSD_GROUP*64]
-    uint16_t *ltime = (uint16_t *)(stage + (size_t)2 * depth * CMSD_GROUP * 64); // ... as of element e0 - 1 + ltime
+    unsigned long long *smin = (unsigned long long *)(lval + (size_t)depth * width);   // [2][GB] min over the rows, as bits
+    uint16_t *ltime = (uint16_t *)(smin + 2 * GB);                               // ... as of element e0 - 1 + ltime
     const int seg = blockIdx.x, t = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;
     const uint32_t gomask = batch_gomask(st, fb);
@@ -345,16 +355,15 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
             lval[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];
             ltime[i] = 0;
         }
+        for (int i = tid; i < 2 * GB; i += blockDim.x) smin[i] = INF_BITS;
     }
-    __syncthreads();
     uint32_t *hist = hists + (size_t)slot * B;
     const uint32_t *ei = eidx + (size_t)t * B;
     double *ft = f64 + (size_t)t * B;
     float *rt = rcp32 + (size_t)t * row_stride;
     const int64_t b0 = (int64_t)seg * seg_chunks * 64;
     const long long tref = (long long)sege0[(size_t)t * CMS_SEGS + seg] - 1;     // time of ltime == 0
-    const int ngroups = (seg_chunks + CMSD_GROUP - 1) / CMSD_GROUP;
-    constexpr int GB = CMSD_GROUP * 64;
+    const int ngroups = (seg_chunks + CMSD_FG - 1) / CMSD_FG;
     const double lnw = log(omega);
     __shared__ double pw[64];                                     // w^x for the gaps inside one 64-bin chunk
     __shared__ double pwt[POWW_N];                                // ... and for any gap (poww)
@@ -363,37 +372,35 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
     __syncthreads();
     const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
     const uint8_t *md = meta8 + (size_t)(d < depth ? d : 0) * B;
-    // the four per-bin inputs of group g+1 are requested before group g is computed: with one workgroup per CU
-    // (LDS) and a barrier per group, their latency was the kernel's time
-    uint32_t nh[CMSD_GROUP], np_[CMSD_GROUP], nm[CMSD_GROUP], nj[CMSD_GROUP];
+    double *rv = lval + (size_t)(d < depth ? d : 0) * width;
+    uint16_t *rtm = ltime + (size_t)(d < depth ? d : 0) * width;
+    // row waves: the four per-bin inputs of the WHOLE next group (8 chunks = 32 loads per lane) are requested before the
+    // current group is computed: with one workgroup per CU nothing else hides their latency (requesting one chunk
+    // ahead left ~1900 cycles per chunk, most of it waiting for these loads)
+    uint32_t nh[CMSD_FG], np_[CMSD_FG], nm[CMSD_FG], nj[CMSD_FG];
     auto fetch = [&](int g) {
 #pragma unroll
-        for (int c = 0; c < CMSD_GROUP; c++) {
-            const int ch = g * CMSD_GROUP + c;
+        for (int c = 0; c < CMSD_FG; c++) {
+            const int ch = g * CMSD_FG + c;
             const int64_t b = b0 + (int64_t)ch * 64 + lane;
             nh[c] = 0; np_[c] = 0; nm[c] = 64u | 0x80u; nj[c] = 0;
-            if (d <= depth && ch < seg_chunks && b < (int64_t)B) {
-                nh[c] = hist[b];                                   // (the combiner wave, d == depth, needs only this one)
-                if (d < depth) { np_[c] = pd[b]; nm[c] = md[b]; nj[c] = ei[b]; }
-            }
+            if (d < depth && ch < seg_chunks && b < (int64_t)B) { nh[c] = hist[b]; np_[c] = pd[b]; nm[c] = md[b]; nj[c] = ei[b]; }
         }
     };
     fetch(0);
-    uint32_t ch_[CMSD_GROUP] = {}, cp[CMSD_GROUP], cm[CMSD_GROUP], cj[CMSD_GROUP], ph[CMSD_GROUP];
+    uint32_t chh[CMSD_FG], cp[CMSD_FG], cm[CMSD_FG], cj[CMSD_FG];
     for (int g = 0; g <= ngroups; g++) {
 #pragma unroll
-        for (int c = 0; c < CMSD_GROUP; c++) { ph[c] = ch_[c]; ch_[c] = nh[c]; cp[c] = np_[c]; cm[c] = nm[c]; cj[c] = nj[c]; }
+        for (int c = 0; c < CMSD_FG; c++) { chh[c] = nh[c]; cp[c] = np_[c]; cm[c] = nm[c]; cj[c] = nj[c]; }
         if (g + 1 < ngroups) fetch(g + 1);
         if (d < depth && g < ngroups) {
-            double *my = stage + ((size_t)(g & 1) * depth + d) * GB;
-            double *rv = lval + (size_t)d * width;
-            uint16_t *rtm = ltime + (size_t)d * width;
+            unsigned long long *my = smin + (size_t)(g & 1) * GB;
 #pragma unroll
-            for (int c = 0; c < CMSD_GROUP; c++) {
-                const int ch = g * CMSD_GROUP + c;
+            for (int c = 0; c < CMSD_FG; c++) {
+                const int ch = g * CMSD_FG + c;
                 if (ch >= seg_chunks) break;
                 const int64_t b = b0 + (int64_t)ch * 64 + lane;
-                const uint32_t h = ch_[c], p = cp[c], m = cm[c]; const long long j = (long long)cj[c];
+                const uint32_t h = chh[c], p = cp[c], m = cm[c]; const long long j = (long long)cj[c];
                 // resolve the lanes in same-counter order: a lane is computed once its predecessor is
                 const uint32_t prev = m & 0x7fu;
                 bool ready = false; double C = 0.0; long long tj = 0;
@@ -411,23 +418,24 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
                         ready = true;
                     }
                 }
-                my[c * 64 + lane] = C;
+                if (h) atomicMin(&my[c * 64 + lane], (unsigned long long)__double_as_longlong(C));
                 if ((m & 0x80u) && b < (int64_t)B) { rv[p] = C; rtm[p] = (uint16_t)(tj - tref); }
             }
         }
         if (d == depth && g > 0) {
-            const double *src = stage + ((size_t)((g - 1) & 1) * depth) * GB;
-            for (int c = 0; c < CMSD_GROUP; c++) {
-                const int ch = (g - 1) * CMSD_GROUP + c;
-                if (ch >= seg_chunks) break;
+            unsigned long long *src = smin + (size_t)((g - 1) & 1) * GB;
+#pragma unroll
+            for (int c = 0; c < CMSD_FG; c++) {
+                const int ch = (g - 1) * CMSD_FG + c;
                 const int64_t b = b0 + (int64_t)ch * 64 + lane;
-                if (b < (int64_t)B) {
-                    if (ph[c]) {                                   // hist[b], fetched two groups ago
-                        double mn = INFINITY;
-                        for (int dd = 0; dd < depth; dd++) { const double e = src[(size_t)dd * GB + c * 64 + lane]; mn = e < mn ? e : mn; }
+                if (ch < seg_chunks && b < (int64_t)B) {
+                    const unsigned long long bits = src[c * 64 + lane];
+                    src[c * 64 + lane] = INF_BITS;
+                    if (bits != INF_BITS) {
+                        const double mn = __longlong_as_double((long long)bits);
                         ft[b] = mn; rt[b] = (float)(1.0 / mn);
-                        hist[b] = 0;
                     } else { ft[b] = 0.0; rt[b] = __builtin_nanf(""); }
+                    hist[b] = 0;
                 }
             }
         }
@@ -537,7 +545,7 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
     const int chunks = (fb.num_bins + 63) / 64;
     const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
     const size_t lds1 = (size_t)depth * width * 8;
-    const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * depth * CMSD_GROUP * 64 * 8 + (size_t)depth * width * 2;
+    const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * CMSD_FG * 64 * 8 + (size_t)depth * width * 2;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_cmsd_segsum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);

@@ -336,6 +336,30 @@ __global__ void k_cws_apply(const double *__restrict__ candA, const int32_t *__r
     weights[gs] = w; mins[gs] = m;
 }
 
+// Minimum of a slot's tile minima per interval: slotmin[t][slot] = min over the wave tiles of tilemin[t][group][tile][row].
+// One coalesced pass over tilemin, so that k_cws_resolve_drift can pass over the (slot, interval) pairs that hold no
+// candidate without touching their rows (it used to stage every row — 8-float strides — behind two barriers per interval).
+__global__ __launch_bounds__(256) void k_slot_tmin(const float *__restrict__ tilemin, float *__restrict__ slotmin, int wtiles,
+                                                   int ngroups, const DevState *st, FlushBatch fb) {
+    __shared__ float red[4][8];
+    const int grp = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const floatx4 *src = (const floatx4 *)(tilemin + (((size_t)t * ngroups + grp) * wtiles) * SCAN_ROWS);
+    const int n4 = wtiles * SCAN_ROWS / 4;                       // float4 i holds rows 4 (i & 1) .. 4 (i & 1) + 3
+    floatx4 m = (floatx4)(INFINITY);
+    for (int i = tid; i < n4; i += 256) {                        // 256 is even: a thread always sees the same half of the rows
+        const floatx4 v = src[i];
+        m.x = fminf(m.x, v.x); m.y = fminf(m.y, v.y); m.z = fminf(m.z, v.z); m.w = fminf(m.w, v.w);
+    }
+    for (int off = 32; off >= 2; off >>= 1) {                    // lanes of equal parity
+        m.x = fminf(m.x, __shfl_xor(m.x, off)); m.y = fminf(m.y, __shfl_xor(m.y, off));
+        m.z = fminf(m.z, __shfl_xor(m.z, off)); m.w = fminf(m.w, __shfl_xor(m.w, off));
+    }
+    if (lane < 2) { red[wid][4 * lane] = m.x; red[wid][4 * lane + 1] = m.y; red[wid][4 * lane + 2] = m.z; red[wid][4 * lane + 3] = m.w; }
+    __syncthreads();
+    if (tid < 8) slotmin[((size_t)t * ngroups + grp) * SCAN_ROWS + tid] = fminf(fminf(red[0][tid], red[1][tid]), fminf(red[2][tid], red[3][tid]));
+    (void)st;
+}
+
 // AddElement with concept drift, per slot, in stream order:  if A < w/decayWeight { w = A; min = bin }
 // (histosketch.go:139-153).  Not a minimum: w may move either way, so elements are taken in order,
 // but a wave tile whose fp32 minimum is not below the current threshold (with the fp32 band) cannot
@@ -346,6 +370,7 @@ __global__ __launch_bounds__(256) void k_cws_resolve_drift(const double *__restr
                                                            unsigned long long *__restrict__ mins,
                                                            double *__restrict__ weights, int slots,
                                                            int slot_begin, int ntiles, double decay_weight,
+                                                           const float *__restrict__ slotmin,
                                                            const DevState *st, FlushBatch fb) {
     extern __shared__ __align__(16) unsigned char smem[];
     float *tm = (float *)smem;                       // [wtiles]
@@ -364,6 +389,12 @@ __global__ __launch_bounds__(256) void k_cws_resolve_drift(const double *__restr
 
     for (int t = 0; t < (int)fb.count; t++) {
         if (!((gomask >> t) & 1u)) continue;
+        {   // no tile of this interval can hold a trigger for the current threshold (same screen as below): next interval
+            const double thr0 = w / decay_weight;
+            if (thr0 != thr0) continue;
+            const double lim0 = thr0 + 1e-5 * fabs(thr0) + 1e-37;
+            if (lim0 < INFINITY && !((double)slotmin[(size_t)t * ngroups * SCAN_ROWS + slot] <= lim0)) continue;   // block-uniform
+        }
         __syncthreads();
         const float *tmin_t = tilemin + (((size_t)t * ngroups + slot / SCAN_ROWS) * wtiles) * SCAN_ROWS + (slot % SCAN_ROWS);
         const double *ft = f64 + (size_t)t * (size_t)num_bins;
@@ -713,10 +744,12 @@ hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *
 
 hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const double *d_f64,
                                     const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
-                                    int slots, int slot_begin, int ntiles, double decay_weight,
+                                    int slots, int slot_begin, int ntiles, double decay_weight, float *d_slotmin,
                                     DevState *st, const FlushBatch &fb) {
+    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    hipLaunchKernelGGL(k_slot_tmin, dim3(ngroups, fb.count), dim3(256), 0, s, d_tilemin, d_slotmin, ntiles * 4, ngroups, st, fb);
     hipLaunchKernelGGL(k_cws_resolve_drift, dim3(slots), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
-                       d_rcb, d_f64, d_tilemin, d_mins, d_weights, slots, slot_begin, ntiles, decay_weight, st, fb);
+                       d_rcb, d_f64, d_tilemin, d_mins, d_weights, slots, slot_begin, ntiles, decay_weight, d_slotmin, st, fb);
     return hipGetLastError();
 }
 

@@ -125,7 +125,7 @@ hipError_t launch_elem_index(hipStream_t s, const uint32_t *d_hists, uint32_t *d
 int elem_index_blocks(int32_t num_bins);
 hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const double *d_f64,
                                     const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
-                                    int slots, int slot_begin, int ntiles, double decay_weight,
+                                    int slots, int slot_begin, int ntiles, double decay_weight, float *d_slotmin,
                                     DevState *st, const FlushBatch &fb);
 hipError_t launch_cws_chunk(hipStream_t s, const uint64_t *d_pairs, uint64_t n_attempts, double *d_val,
                             uint32_t *d_blkcnt, unsigned long long *d_gamma_total, unsigned long long *d_chunk_base,
