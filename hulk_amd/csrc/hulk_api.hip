@@ -97,6 +97,7 @@ struct hulk_ctx {
     double *d_segadd = nullptr, *d_segfac = nullptr, *d_cstart = nullptr; uint32_t *d_sege0 = nullptr; // ... with decay
     double *d_f64 = nullptr, *d_weights = nullptr, *d_rcb = nullptr;
     float *d_rcp32 = nullptr, *d_k32 = nullptr, *d_tilemin = nullptr;
+    unsigned long long *d_scanmap = nullptr;                                       // [slot groups][wave tiles / 64]: k_scan_test's verdicts
     float *d_slotmin = nullptr;                                                    // [T][slot groups][8]: k_slot_tmin (concept drift only)
     float *d_kmin32 = nullptr, *d_rext = nullptr, *d_kminslot = nullptr;          // bound test of k_cws_scan (no concept drift only)
     unsigned long long *d_visited = nullptr; uint64_t scan_tiles_total = 0; bool prune = false, no_skip = false;
@@ -607,15 +608,15 @@ int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, b
         }
         HIPCHK(c, launch_cws_scan(s, c->d_k32, c->d_rcp32, c->d_tilemin, (int)c->slots, c->ntiles,
                                   c->row_stride, c->d_state, fb, c->prune ? c->d_kmin32 : nullptr, c->d_rext,
-                                  c->d_weights, (int)c->slot_begin, c->d_visited, c->drift ? c->decay_weight : 0.0));
+                                  c->d_weights, (int)c->slot_begin, c->d_visited, c->drift ? c->decay_weight : 0.0, c->d_scanmap));
         c->scan_tiles_total += (uint64_t)((c->slots + SCAN_ROWS - 1) / SCAN_ROWS) * (uint64_t)c->ntiles * 4u;
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
         if (c->drift)
             HIPCHK(c, launch_cws_resolve_drift(s, c->d_rcb, c->d_f64, c->d_tilemin, c->d_mins, c->d_weights, (int)c->slots,
-                                               (int)c->slot_begin, c->ntiles, c->decay_weight, c->d_slotmin, c->d_state, fb));
+                                               (int)c->slot_begin, c->ntiles, c->decay_weight, c->d_slotmin, c->d_scanmap, c->d_state, fb));
         else
         HIPCHK(c, launch_cws_resolve(s, c->d_rcb, c->d_f64, c->d_tilemin, c->d_candA, c->d_candB, c->d_mins, c->d_weights,
-                                     (int)c->slots, (int)c->slot_begin, c->ntiles, c->d_state, fb));
+                                     (int)c->slots, (int)c->slot_begin, c->ntiles, c->d_scanmap, c->d_state, fb));
     }
     HIPCHK(c, hipEventRecord(c->ev_flushed[c->cur_ring], s));
     c->pending_flush[c->cur_ring] = true;
@@ -722,6 +723,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_kmin32, (SL ? SL : 1) * (size_t)c->ntiles * 4));
     CHK_CREATE(dalloc(&c->d_rext, T * (size_t)c->ntiles * 4 * 2));
     CHK_CREATE(dalloc(&c->d_kminslot, (SL ? SL : 1)));
+    CHK_CREATE(dalloc(&c->d_scanmap, ((SL + SCAN_ROWS - 1) / SCAN_ROWS + 1) * (((size_t)c->ntiles * 4 + 63) / 64)));
     CHK_CREATE(dalloc(&c->d_slotmin, T * ((SL + SCAN_ROWS - 1) / SCAN_ROWS) * SCAN_ROWS));
     CHK_CREATE(dalloc(&c->d_visited, (size_t)MIN_SLOTS));
     CHK_CREATE(hipMemsetAsync(c->d_visited, 0, (size_t)MIN_SLOTS * 8, c->stream));
@@ -775,7 +777,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_ctr); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
     hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd);
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
-    hipFree(c->d_slotmin); hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited); hipFree(c->d_kminslot);
+    hipFree(c->d_scanmap); hipFree(c->d_slotmin); hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited); hipFree(c->d_kminslot);
     for (auto &hs : c->hstage) {
         if (hs.ev) hipEventDestroy(hs.ev);
         if (hs.h_bases) hipHostFree(hs.h_bases);

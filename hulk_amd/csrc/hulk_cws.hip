@@ -129,92 +129,120 @@ __global__ __launch_bounds__(256) void k_rcp_extrema(const float *__restrict__ r
 
 // ------------------------------------------------------------------------------------------
 // K4a: the HBM-bound pass.  A[t][slot][bin] = K[slot][bin] * (1/f_t[bin]); minimum per
-// (interval t, slot, 256-bin wave tile).  A workgroup streams SCAN_ROWS rows x SCAN_TILE bins of K
-// exactly once (16 B per lane per row, SCAN_ROWS independent loads in flight) and re-uses the
-// registers for every interval of the batch, so the table is read once per BATCH, not per interval.
+// (interval t, slot, 256-bin wave tile).  A wave streams SCAN_ROWS rows x 256 bins of K exactly once (16 B per lane per
+// row, SCAN_ROWS independent loads in flight) and re-uses the registers for every interval of the batch, so the table
+// is read once per BATCH, not per interval.
+//
+// Branch and bound first (k_scan_test): AddElement only ever replaces a slot's weight by a SMALLER A, and over a wave
+// tile A = K * (1/f) >= min(K) * max(1/f) (min(K) < 0; min(K) * min(1/f) otherwise).  A wave tile whose bound cannot
+// get below the current weight of any of its 8 slots for any interval of the batch is not read at all — after the first
+// intervals of a stream that is nearly every tile, because count-min estimates only grow.  The weights at batch start
+// are used (they only fall during the batch), with the same 1e-5 relative band the fp64 resolve uses around fp32 values.
+// The verdicts are ONE BIT per (slot group, wave tile): scanmap[group][tile / 64].  k_cws_scan and everything behind it
+// (k_slot_tmin, k_cws_resolve, k_cws_resolve_drift) only touch tiles whose bit is set; tilemin entries of other tiles are
+// never written nor read.  (The first version tested inside the scan, one wave per tile, and wrote +inf for every
+// pruned tile: at k = 31, sketchSize 1024 that was 462 k waves and 236 MB of +inf per flush — 350 us to read 33 tiles.)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cws_scan(const float *__restrict__ k32,
-                                                  const float *__restrict__ rcp32,
-                                                  float *__restrict__ tilemin, int slots, int ntiles,
-                                                  size_t row_stride, const DevState *st, FlushBatch fb,
-                                                  const float *__restrict__ kmin32, const float *__restrict__ rext,
-                                                  const double *__restrict__ weights, int slot_begin,
-                                                  unsigned long long *__restrict__ visited, double drift_dw) {
-    // XCD-aware order (workgroup b lands on XCD b % 8): XCD x works through column tile 8*chunk + x for
-    // ALL slot groups before moving on, so a column's reciprocal vectors (T x 4 KB) are fetched into
-    // that XCD's L2 once and re-used by the other groups; the 8 XCDs stream 8 adjacent 4 KB pieces of
-    // the same K rows at the same time (32 KB contiguous per row).
+__global__ __launch_bounds__(256) void k_scan_test(const float *__restrict__ kmin32, const float *__restrict__ rext,
+                                                   const double *__restrict__ weights, int slot_begin, int slots,
+                                                   int wtiles, int wwords, double drift_dw, const DevState *st,
+                                                   FlushBatch fb, unsigned long long *__restrict__ scanmap,
+                                                   unsigned long long *__restrict__ visited) {
     if (st->skip_exact[fb.parity]) return;                       // k_flush_decide: nothing in this batch can matter
-    const int ngrp = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
-    const int chunk = blockIdx.x / (8 * ngrp), rem = blockIdx.x % (8 * ngrp);
-    const int grp = rem / 8, tile = chunk * 8 + (rem % 8);
-    if (tile >= ntiles) return;
-    const int tid = threadIdx.x, wid = tid >> 6;
-    const size_t col = (size_t)tile * SCAN_TILE + (size_t)tid * 4;
-    const int wtiles = ntiles * 4;                               // 256-bin wave tiles per row
+    const int grp = blockIdx.y, lane = threadIdx.x & 63;
+    const int word = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (word >= wwords) return;
+    const int wt = word * 64 + lane;
     const uint32_t gomask = batch_gomask(st, fb);
-    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
-    const int lane = tid & 63;
-    // ---- branch and bound (no concept drift): AddElement only ever replaces a slot's weight by a SMALLER
-    // A, and A = K * (1/f) >= min(K) * max(1/f) over a tile (min(K) < 0; min(K) * min(1/f) otherwise).  A wave
-    // tile whose bound cannot get below the slot's current weight for any row and interval of the batch is
-    // not read at all — after the first intervals of a stream that is nearly every tile, because count-min
-    // estimates only grow.  The weights at batch start are used (they only fall during the batch), with the
-    // same 1e-5 relative band the fp64 resolve uses around fp32 values; skipped tiles report +inf.
-    if (kmin32) {
-        const int wt = tile * 4 + wid, row = lane & 7, slot = grp * SCAN_ROWS + row;
-        bool pass = false;
-        if (slot < slots) {
-            const double km = (double)kmin32[(size_t)slot * wtiles + wt];
-            double w = weights[slot_begin + slot];
-            // concept drift (drift_dw = decayWeight > 0): the update test is A < w / decayWeight and w may move either
-            // way — but a NEGATIVE weight can only be replaced by a smaller one (A < w/dw < w), so its threshold of
-            // the whole batch is at most w_start / dw; a slot whose weight is not negative is simply never pruned
-            bool never = false;
-            if (drift_dw > 0.0) { if (w < 0.0) w = w / drift_dw; else never = true; }
-            const double thr = w + 1e-5 * fabs(w) + 1e-37;
-            if (never) pass = true;
-            for (int t = lane >> 3; t < (int)fb.count; t += 8) {
-                if (!((gomask >> t) & 1u)) continue;
-                const float rmax = rext[((size_t)t * wtiles + wt) * 2], rmin = rext[((size_t)t * wtiles + wt) * 2 + 1];
-                if (!(rmax > 0.f)) continue;                     // no element of this interval falls into the tile
-                const double bound = km < 0.0 ? km * (double)rmax : km * (double)rmin;
-                if (bound <= thr) pass = true;
+    bool pass = false;
+    if (wt < wtiles) {
+        if (!kmin32) pass = true;                                // pruning off: every tile is read
+        else {
+            float rmax[SCAN_BATCH_MAX], rmin[SCAN_BATCH_MAX];
+#pragma unroll
+            for (int t = 0; t < SCAN_BATCH_MAX; t++) {
+                rmax[t] = 0.f; rmin[t] = 0.f;
+                if (t < (int)fb.count && ((gomask >> t) & 1u)) {
+                    const floatx2 v = *(const floatx2 *)(rext + ((size_t)t * wtiles + wt) * 2);
+                    rmax[t] = v.x; rmin[t] = v.y;
+                }
+            }
+            for (int row = 0; row < SCAN_ROWS; row++) {
+                const int slot = grp * SCAN_ROWS + row;
+                if (slot >= slots) break;
+                const double km = (double)kmin32[(size_t)slot * wtiles + wt];
+                double w = weights[slot_begin + slot];
+                // concept drift (drift_dw = decayWeight > 0): the update test is A < w / decayWeight and w may move either
+                // way — but a NEGATIVE weight can only be replaced by a smaller one (A < w/dw < w), so its threshold of
+                // the whole batch is at most w_start / dw; a slot whose weight is not negative is simply never pruned
+                if (drift_dw > 0.0) { if (w < 0.0) w = w / drift_dw; else pass = true; }
+                const double thr = w + 1e-5 * fabs(w) + 1e-37;
+#pragma unroll
+                for (int t = 0; t < SCAN_BATCH_MAX; t++) {
+                    if (!(rmax[t] > 0.f)) continue;              // interval not flushed, or none of its elements falls into the tile
+                    const double bound = km < 0.0 ? km * (double)rmax[t] : km * (double)rmin[t];
+                    if (bound <= thr) pass = true;
+                }
             }
         }
-        if (!__ballot(pass)) {
-            for (int t = lane >> 3; t < (int)fb.count; t += 8)
-                tilemin[(((size_t)t * ngroups + grp) * wtiles + (size_t)wt) * SCAN_ROWS + row] = INFINITY;
-            return;
+    }
+    const unsigned long long mask = __ballot(pass);
+    if (lane == 0) {
+        scanmap[(size_t)grp * wwords + word] = mask;
+        if (mask) atomicAdd(&visited[(blockIdx.x + blockIdx.y * gridDim.x) & (MIN_SLOTS - 1)], (unsigned long long)__popcll(mask));
+    }
+}
+
+// workgroup of 16 waves = (quarter of a column word = 16 wave tiles, slot group); wave w takes wave tile 64 cw + 16 quarter + w
+__global__ __launch_bounds__(1024) void k_cws_scan(const float *__restrict__ k32,
+                                                   const float *__restrict__ rcp32,
+                                                   float *__restrict__ tilemin, int slots, int ntiles,
+                                                   size_t row_stride, const DevState *st, FlushBatch fb,
+                                                   const unsigned long long *__restrict__ scanmap, int wwords) {
+    // XCD-aware order (workgroup b lands on XCD b % 8): XCD x works through column unit 8*chunk + x (16 wave tiles) for
+    // ALL slot groups before moving on, so a column's reciprocal vectors (T x 16 KB) are fetched into
+    // that XCD's L2 once and re-used by the other groups; the 8 XCDs stream 8 adjacent 16 KB pieces of
+    // the same K rows at the same time.
+    if (st->skip_exact[fb.parity]) return;
+    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    const int r = (int)(blockIdx.x >> 3), grp = r % ngroups, unit = (r / ngroups) * 8 + (int)(blockIdx.x & 7);
+    const int cw = unit >> 2, quarter = unit & 3;                // unit = 16 wave tiles: fine enough to balance the 8 XCDs
+    if (cw >= wwords) return;
+    const unsigned long long mask = scanmap[(size_t)grp * wwords + cw];
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    if (!((mask >> (16 * quarter + wid)) & 1ull)) return;        // wave-uniform: this tile cannot change the sketch
+    const int wtiles = ntiles * 4;                               // 256-bin wave tiles per row
+    const uint32_t gomask = batch_gomask(st, fb);
+    {
+        const int wt = cw * 64 + quarter * 16 + wid;
+        const size_t col = (size_t)wt * 256 + (size_t)lane * 4;
+        floatx4 kv[SCAN_ROWS];
+#pragma unroll
+        for (int r = 0; r < SCAN_ROWS; r++) {
+            const int slot = grp * SCAN_ROWS + r;
+            if (slot < slots)
+                kv[r] = __builtin_nontemporal_load((const floatx4 *)(k32 + (size_t)slot * row_stride + col));
+            else
+                kv[r] = (floatx4)(0.f);
         }
-        if (lane == 0) atomicAdd(&visited[blockIdx.x & (MIN_SLOTS - 1)], 1ull);
-    }
-    floatx4 kv[SCAN_ROWS];
+        floatx4 rc_next = *(const floatx4 *)(rcp32 + col);
+        for (int t = 0; t < (int)fb.count; t++) {
+            const floatx4 rc = rc_next;
+            if (t + 1 < (int)fb.count) rc_next = *(const floatx4 *)(rcp32 + (size_t)(t + 1) * row_stride + col);
+            if (!((gomask >> t) & 1u)) continue;
+            float m[SCAN_ROWS];
+            // v_mul_f32 x4 + v_min3_f32 x2 per row.  (v_pk_mul_f32 halves the multiplies but runs this loop 2x
+            // SLOWER on MI355X — measured 304 vs 150 us — so the products stay scalar.)  NaN (bin not in the
+            // stream) loses every v_min; INFINITY keeps an all-NaN lane out of the reduction.
 #pragma unroll
-    for (int r = 0; r < SCAN_ROWS; r++) {
-        const int slot = grp * SCAN_ROWS + r;
-        if (slot < slots)
-            kv[r] = __builtin_nontemporal_load((const floatx4 *)(k32 + (size_t)slot * row_stride + col));
-        else
-            kv[r] = (floatx4)(0.f);
-    }
-    floatx4 rc_next = *(const floatx4 *)(rcp32 + col);
-    for (int t = 0; t < (int)fb.count; t++) {
-        const floatx4 rc = rc_next;
-        if (t + 1 < (int)fb.count) rc_next = *(const floatx4 *)(rcp32 + (size_t)(t + 1) * row_stride + col);
-        if (!((gomask >> t) & 1u)) continue;
-        float m[SCAN_ROWS];
-        // v_mul_f32 x4 + v_min3_f32 x2 per row.  (v_pk_mul_f32 halves the multiplies but runs this loop 2x
-        // SLOWER on MI355X — measured 304 vs 150 us — so the products stay scalar.)  NaN (bin not in the
-        // stream) loses every v_min; INFINITY keeps an all-NaN lane out of the reduction.
-#pragma unroll
-        for (int r = 0; r < SCAN_ROWS; r++)
-            m[r] = fminf(fminf(fminf(fminf(kv[r].x * rc.x, kv[r].y * rc.y), kv[r].z * rc.z), kv[r].w * rc.w), INFINITY);
-        static_assert(SCAN_ROWS == 8, "wave_min8_by_row reduces exactly 8 rows");
-        const float mine = wave_min8_by_row(m);                    // lane l: minimum of row l / 8 over the wave
-        // tilemin[t][slot group][wave tile][row]: 8 lanes write the 8 rows of a wave tile (32 contiguous bytes)
-        if ((lane & 7) == 0)
-            tilemin[(((size_t)t * ngroups + grp) * wtiles + (size_t)(tile * 4 + wid)) * SCAN_ROWS + (lane >> 3)] = mine;
+            for (int r = 0; r < SCAN_ROWS; r++)
+                m[r] = fminf(fminf(fminf(fminf(kv[r].x * rc.x, kv[r].y * rc.y), kv[r].z * rc.z), kv[r].w * rc.w), INFINITY);
+            static_assert(SCAN_ROWS == 8, "wave_min8_by_row reduces exactly 8 rows");
+            const float mine = wave_min8_by_row(m);                // lane l: minimum of row l / 8 over the wave
+            // tilemin[t][slot group][wave tile][row]: 8 lanes write the 8 rows of a wave tile (32 contiguous bytes)
+            if ((lane & 7) == 0)
+                tilemin[(((size_t)t * ngroups + grp) * wtiles + (size_t)wt) * SCAN_ROWS + (lane >> 3)] = mine;
+        }
     }
 }
 
@@ -230,8 +258,8 @@ __global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ 
                                                      const double *__restrict__ f64,
                                                      const float *__restrict__ tilemin,
                                                      double *__restrict__ candA, int32_t *__restrict__ candB,
-                                                     int slots, int ntiles, const DevState *st,
-                                                     FlushBatch fb) {
+                                                     int slots, int ntiles, const unsigned long long *__restrict__ scanmap,
+                                                     int wwords, const DevState *st, FlushBatch fb) {
     extern __shared__ __align__(16) unsigned char smem[];
     float *tm = (float *)smem;                       // [wtiles]
     __shared__ float redf[4];
@@ -251,9 +279,10 @@ __global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ 
         const float *tmin_t = tilemin + (((size_t)t * ngroups + slot / SCAN_ROWS) * wtiles) * SCAN_ROWS + (slot % SCAN_ROWS);
         const double *ft = f64 + (size_t)t * (size_t)num_bins;
         if (tid == 0) ncand = 0;
+        const unsigned long long *smap = scanmap + (size_t)(slot / SCAN_ROWS) * wwords;   // tiles the scan read
         float g = INFINITY;
         for (int x = tid; x < wtiles; x += blockDim.x) {
-            const float v = tmin_t[(size_t)x * SCAN_ROWS];
+            const float v = ((smap[x >> 6] >> (x & 63)) & 1ull) ? tmin_t[(size_t)x * SCAN_ROWS] : INFINITY;
             tm[x] = v;
             g = fminf(g, v);
         }
@@ -340,21 +369,25 @@ __global__ void k_cws_apply(const double *__restrict__ candA, const int32_t *__r
 // One coalesced pass over tilemin, so that k_cws_resolve_drift can pass over the (slot, interval) pairs that hold no
 // candidate without touching their rows (it used to stage every row — 8-float strides — behind two barriers per interval).
 __global__ __launch_bounds__(256) void k_slot_tmin(const float *__restrict__ tilemin, float *__restrict__ slotmin, int wtiles,
-                                                   int ngroups, const DevState *st, FlushBatch fb) {
+                                                   int ngroups, const unsigned long long *__restrict__ scanmap, int wwords,
+                                                   const DevState *st, FlushBatch fb) {
     __shared__ float red[4][8];
     const int grp = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const floatx4 *src = (const floatx4 *)(tilemin + (((size_t)t * ngroups + grp) * wtiles) * SCAN_ROWS);
-    const int n4 = wtiles * SCAN_ROWS / 4;                       // float4 i holds rows 4 (i & 1) .. 4 (i & 1) + 3
-    floatx4 m = (floatx4)(INFINITY);
-    for (int i = tid; i < n4; i += 256) {                        // 256 is even: a thread always sees the same half of the rows
-        const floatx4 v = src[i];
-        m.x = fminf(m.x, v.x); m.y = fminf(m.y, v.y); m.z = fminf(m.z, v.z); m.w = fminf(m.w, v.w);
+    const unsigned long long *smap = scanmap + (size_t)grp * wwords;
+    floatx4 lo = (floatx4)(INFINITY), hi = (floatx4)(INFINITY);   // rows 0..3 / 4..7
+    for (int x = tid; x < wtiles; x += 256) {
+        if (!((smap[x >> 6] >> (x & 63)) & 1ull)) continue;       // the scan did not read this tile
+        const floatx4 a = src[2 * x], b = src[2 * x + 1];
+        lo.x = fminf(lo.x, a.x); lo.y = fminf(lo.y, a.y); lo.z = fminf(lo.z, a.z); lo.w = fminf(lo.w, a.w);
+        hi.x = fminf(hi.x, b.x); hi.y = fminf(hi.y, b.y); hi.z = fminf(hi.z, b.z); hi.w = fminf(hi.w, b.w);
     }
-    for (int off = 32; off >= 2; off >>= 1) {                    // lanes of equal parity
-        m.x = fminf(m.x, __shfl_xor(m.x, off)); m.y = fminf(m.y, __shfl_xor(m.y, off));
-        m.z = fminf(m.z, __shfl_xor(m.z, off)); m.w = fminf(m.w, __shfl_xor(m.w, off));
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        for (int off = 32; off; off >>= 1) v[r] = fminf(v[r], __shfl_xor(v[r], off));
+        if (lane == 0) red[wid][r] = v[r];
     }
-    if (lane < 2) { red[wid][4 * lane] = m.x; red[wid][4 * lane + 1] = m.y; red[wid][4 * lane + 2] = m.z; red[wid][4 * lane + 3] = m.w; }
     __syncthreads();
     if (tid < 8) slotmin[((size_t)t * ngroups + grp) * SCAN_ROWS + tid] = fminf(fminf(red[0][tid], red[1][tid]), fminf(red[2][tid], red[3][tid]));
     (void)st;
@@ -371,6 +404,7 @@ __global__ __launch_bounds__(256) void k_cws_resolve_drift(const double *__restr
                                                            double *__restrict__ weights, int slots,
                                                            int slot_begin, int ntiles, double decay_weight,
                                                            const float *__restrict__ slotmin,
+                                                           const unsigned long long *__restrict__ scanmap, int wwords,
                                                            const DevState *st, FlushBatch fb) {
     extern __shared__ __align__(16) unsigned char smem[];
     float *tm = (float *)smem;                       // [wtiles]
@@ -398,7 +432,11 @@ __global__ __launch_bounds__(256) void k_cws_resolve_drift(const double *__restr
         __syncthreads();
         const float *tmin_t = tilemin + (((size_t)t * ngroups + slot / SCAN_ROWS) * wtiles) * SCAN_ROWS + (slot % SCAN_ROWS);
         const double *ft = f64 + (size_t)t * (size_t)num_bins;
-        for (int x = tid; x < wtiles; x += blockDim.x) tm[x] = tmin_t[(size_t)x * SCAN_ROWS];
+        {
+            const unsigned long long *smap = scanmap + (size_t)(slot / SCAN_ROWS) * wwords;       // tiles the scan read
+            for (int x = tid; x < wtiles; x += blockDim.x)
+                tm[x] = ((smap[x >> 6] >> (x & 63)) & 1ull) ? tmin_t[(size_t)x * SCAN_ROWS] : INFINITY;
+        }
         __syncthreads();
         int from = 0;                                 // first tile not yet passed
         for (;;) {
@@ -703,13 +741,16 @@ __global__ void k_fill_f32(float *p, size_t n, float v) {
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
-                           unsigned long long *d_visited, double drift_dw) {
+                           unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap) {
     const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
-    const int chunks = (ntiles + 7) / 8;
+    const int wtiles = ntiles * 4, wwords = (wtiles + 63) / 64;
     if (d_kmin32)
         hipLaunchKernelGGL(k_rcp_extrema, dim3(ntiles, fb.count), dim3(256), 0, s, d_rcp32, d_rext, ntiles, row_stride, st, fb);
-    hipLaunchKernelGGL(k_cws_scan, dim3((unsigned)(chunks * 8 * groups)), dim3(256), 0, s, d_k32, d_rcp32,
-                       d_tilemin, slots, ntiles, row_stride, st, fb, d_kmin32, d_rext, d_weights, slot_begin, d_visited, drift_dw);
+    hipLaunchKernelGGL(k_scan_test, dim3((wwords + 3) / 4, groups), dim3(256), 0, s, d_kmin32, d_rext, d_weights, slot_begin,
+                       slots, wtiles, wwords, drift_dw, st, fb, d_scanmap, d_visited);
+    const int chunks = (wwords * 4 + 7) / 8;                     // units of 16 wave tiles, 8 (one per XCD) side by side
+    hipLaunchKernelGGL(k_cws_scan, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rcp32,
+                       d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
     return hipGetLastError();
 }
 
@@ -734,9 +775,10 @@ hipError_t launch_tile_kmin(hipStream_t s, const float *d_k32, float *d_kmin32, 
 hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,
                               const float *d_tilemin, double *d_candA, int32_t *d_candB,
                               unsigned long long *d_mins, double *d_weights,
-                              int slots, int slot_begin, int ntiles, DevState *st, const FlushBatch &fb) {
+                              int slots, int slot_begin, int ntiles, const unsigned long long *d_scanmap, DevState *st,
+                              const FlushBatch &fb) {
     hipLaunchKernelGGL(k_cws_resolve, dim3(slots, fb.count), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
-                       d_rcb, d_f64, d_tilemin, d_candA, d_candB, slots, ntiles, st, fb);
+                       d_rcb, d_f64, d_tilemin, d_candA, d_candB, slots, ntiles, d_scanmap, (ntiles * 4 + 63) / 64, st, fb);
     hipLaunchKernelGGL(k_cws_apply, dim3((slots + 255) / 256), dim3(256), 0, s, d_candA, d_candB, d_mins,
                        d_weights, slots, slot_begin, st, fb);
     return hipGetLastError();
@@ -745,11 +787,13 @@ hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *
 hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const double *d_f64,
                                     const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
                                     int slots, int slot_begin, int ntiles, double decay_weight, float *d_slotmin,
-                                    DevState *st, const FlushBatch &fb) {
-    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
-    hipLaunchKernelGGL(k_slot_tmin, dim3(ngroups, fb.count), dim3(256), 0, s, d_tilemin, d_slotmin, ntiles * 4, ngroups, st, fb);
+                                    const unsigned long long *d_scanmap, DevState *st, const FlushBatch &fb) {
+    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS, wwords = (ntiles * 4 + 63) / 64;
+    hipLaunchKernelGGL(k_slot_tmin, dim3(ngroups, fb.count), dim3(256), 0, s, d_tilemin, d_slotmin, ntiles * 4, ngroups,
+                       d_scanmap, wwords, st, fb);
     hipLaunchKernelGGL(k_cws_resolve_drift, dim3(slots), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
-                       d_rcb, d_f64, d_tilemin, d_mins, d_weights, slots, slot_begin, ntiles, decay_weight, d_slotmin, st, fb);
+                       d_rcb, d_f64, d_tilemin, d_mins, d_weights, slots, slot_begin, ntiles, decay_weight, d_slotmin,
+                       d_scanmap, wwords, st, fb);
     return hipGetLastError();
 }
 

@@ -110,7 +110,7 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
-                           unsigned long long *d_visited, double drift_dw);
+                           unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap);
 hipError_t launch_tile_kmin(hipStream_t s, const float *d_k32, float *d_kmin32, int slots, int ntiles, size_t row_stride);
 hipError_t launch_slot_kmin(hipStream_t s, const float *d_kmin32, float *d_kminslot, int slots, int ntiles);
 hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, int ncounters, const float *d_kminslot,
@@ -119,14 +119,15 @@ hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, i
 hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,
                               const float *d_tilemin, double *d_candA, int32_t *d_candB,
                               unsigned long long *d_mins, double *d_weights,
-                              int slots, int slot_begin, int ntiles, DevState *st, const FlushBatch &fb);
+                              int slots, int slot_begin, int ntiles, const unsigned long long *d_scanmap, DevState *st,
+                              const FlushBatch &fb);
 hipError_t launch_elem_index(hipStream_t s, const uint32_t *d_hists, uint32_t *d_blkcnt, uint32_t *d_eidx,
                              uint32_t *d_etot, const FlushBatch &fb);
 int elem_index_blocks(int32_t num_bins);
 hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const double *d_f64,
                                     const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
                                     int slots, int slot_begin, int ntiles, double decay_weight, float *d_slotmin,
-                                    DevState *st, const FlushBatch &fb);
+                                    const unsigned long long *d_scanmap, DevState *st, const FlushBatch &fb);
 hipError_t launch_cws_chunk(hipStream_t s, const uint64_t *d_pairs, uint64_t n_attempts, double *d_val,
                             uint32_t *d_blkcnt, unsigned long long *d_gamma_total, unsigned long long *d_chunk_base,
                             double *d_rcb, uint64_t num_bins, uint64_t slot_begin, uint64_t slots,

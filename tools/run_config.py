@@ -30,9 +30,10 @@ while done < a.reads:
     sk.add_reads_device(b.data_ptr(), o.data_ptr(), step, a.len, b.numel()); done += step; i += 1
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
+tiles = sk.scan_stats()
 sk.finish()
 mins, w = sk.sketch()
 print(json.dumps({"k": a.k, "S": a.S, "decay": a.decay, "interval": a.interval, "batch": a.batch,
                   "reads_timed": done - step, "ms": ms, "reads_per_s": (done - step) / ms * 1e3,
                   "create_s": t_create, "mem_GB": torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9,
-                  "distinct_mins": int(len(set(mins.tolist()))), "neg_weights": int((w < 0).sum())}))
+                  "scan_tiles_read": tiles[0], "scan_tiles_covered": tiles[1], "distinct_mins": int(len(set(mins.tolist()))), "neg_weights": int((w < 0).sum())}))
