@@ -222,25 +222,10 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
 //     C(e1-1) = w^(e1-e0) * C(e0-1) + sum{ v_j * w^(e1-1-j) : hits }
 //   k_cmsd_segsum : the sum (one w^x per element, LDS fp64 atomics) and the factor per segment
 //   k_cmsd_base   : C in front of every (spectrum, segment), advancing the persistent fp64 counters
-//   k_cmsd_freq   : replay in bin order with lazily decayed LDS counters {value, time}; zero bins are
+//   k_cmsd_freq   : replay in bin order with LDS counters normalised to a moving base element; zero bins are
 //                   transparent; same-counter lanes of a 64-bin chunk resolve in lane order
 // (fp64 sums are re-associated w.r.t. the reference's step-by-step scaling: ~1e-13 relative)
 // ------------------------------------------------------------------------------------------
-// w^x for an element gap 0 <= x < 2^21 (a spectrum has < 2^20 elements): three 128-entry tables in LDS
-// (w^a, w^(128 b), w^(16384 c)) and two multiplications instead of an fp64 exp() per counter update — 3 ulp.
-constexpr int POWW_N = 384;
-__device__ __forceinline__ void poww_build(double *tab, double lnw, int tid, int nthreads) {
-    for (int i = tid; i < POWW_N; i += nthreads) {
-        const int lvl = i >> 7, a = i & 127;
-        tab[i] = exp((double)a * (lvl == 0 ? 1.0 : lvl == 1 ? 128.0 : 16384.0) * lnw);
-    }
-}
-__device__ __forceinline__ double poww(const double *tab, long long x, double lnw) {
-    if ((unsigned long long)x >= (1ull << 21)) return exp((double)x * lnw);
-    const uint32_t u = (uint32_t)x;
-    return tab[u & 127u] * tab[128u + ((u >> 7) & 127u)] * tab[256u + (u >> 14)];
-}
-
 __global__ __launch_bounds__(512) void k_cmsd_segsum(const uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
                                                      const uint32_t *__restrict__ eidx, const uint32_t *__restrict__ etot,
                                                      double *__restrict__ segadd, double *__restrict__ segfac,
@@ -316,13 +301,21 @@ __global__ __launch_bounds__(256) void k_cmsd_base(const double *__restrict__ se
 }
 
 // Replay with decay.  Workgroup (segment, spectrum): wave d < depth replays row d of the count-min sketch over the
-// segment's bins in order (lazily decayed LDS counters {value, time}); the estimate of a bin is the minimum over the
-// rows, which the row waves form with ONE 64-bit LDS atomic minimum per (row, bin) on a small staging array (the
-// estimates are non-negative doubles, whose bit patterns order like unsigned integers; +inf = "bin not in the stream") —
-// so the staging array is 8 bytes per bin instead of 8 per (row, bin), a barrier covers CMSD_FG = 8 chunks of 64 bins
-// instead of 2, and the combiner wave (d == depth) reads one value per bin: it writes f (fp64), 1/f (fp32), wipes the
-// spectrum and resets the staging slot while the row waves are one group ahead.  (The first version staged every row's
-// value and synchronised every 128 bins: 520 us per 16 spectra of 923,521 bins, almost all of it barrier and combiner time.)
+// segment's bins in order; the estimate of a bin is the minimum over the rows, which the row waves form with ONE 64-bit
+// LDS atomic minimum per (row, bin) on a small staging array (the estimates are non-negative doubles, whose bit patterns
+// order like unsigned integers; +inf = "bin not in the stream").  A barrier covers CMSD_FG = 8 chunks of 64 bins; the
+// combiner wave (d == depth) reads one value per bin, writes f (fp64), 1/f (fp32), wipes the spectrum and resets the
+// staging slot while the row waves are one group ahead.
+//
+// The row waves are a chain of dependent LDS round trips, one workgroup per CU (112 KB of counters), so the number of
+// round trips per chunk IS the kernel's time.  Counters are therefore kept NORMALISED to a base element index:
+// S = C * w^-(t - base) for a counter last touched at element t, so that its value at element j is S * w^(j - base) —
+// a factor that depends on j alone (two small tables, requested together with the counter itself) instead of on the
+// counter's own time (a second, dependent look-up), and a lane that follows another lane of its chunk on the same
+// counter takes that lane's S from a register exchange without any look-up.  One round trip per chunk plus one per
+// level of same-counter chains inside it (was five); every CMSD_PERIOD elements the base moves on and the row's 2000
+// counters are rescaled by w^PERIOD (the period keeps w^-(j - base) far below the fp64 range for any decay < 1).
+// 517 -> 450 (staging) -> see DESIGN.md us per 16 spectra of 923,521 bins.
 constexpr int CMSD_FG = 8;            // chunks per barrier group of k_cmsd_freq
 __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
                                                    const uint8_t *__restrict__ meta8, const uint32_t *__restrict__ eidx,
@@ -333,9 +326,9 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int GB = CMSD_FG * 64;
     constexpr unsigned long long INF_BITS = 0x7FF0000000000000ull;
-    double *lval = (double *)smem;                                               // [depth][width] counter value ...
+    double *lval = (double *)smem;                                               // [depth][width] normalised counters
     unsigned long long *smin = (unsigned long long *)(lval + (size_t)depth * width);   // [2][GB] min over the rows, as bits
-    uint16_t *ltime = (uint16_t *)(smin + 2 * GB);                               // ... as of element e0 - 1 + ltime
+    __shared__ double tabf_lo[64], tabi_lo[64], tabf_hi[66], tabi_hi[66];        // w^x, w^-x for x = lo + 64 hi
     const int seg = blockIdx.x, t = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;
     const uint32_t gomask = batch_gomask(st, fb);
@@ -348,35 +341,38 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
     }
     if (!go) return;
     const size_t B = (size_t)fb.num_bins;
+    const double lnw = log(omega);                               // < 0
+    // elements per base: |ln w| * (period + 64) <= 600  =>  w^-(j - base) <= e^600 (counters stay below ~1e270)
+    int period = 4032;
+    if (-lnw * (double)(period + 64) > 600.0) period = (int)(600.0 / -lnw) - 64;
+    period &= ~63;
+    if (period < 64) period = 64;
     {
         const double *bt = cstart + (((size_t)t * depth) * CMS_SEGS) * width;
         for (int i = tid; i < depth * width; i += blockDim.x) {
             const int dd = i / width, p = i - dd * width;
-            lval[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];
-            ltime[i] = 0;
+            lval[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];       // value as of element e0 - 1: see `base` below
         }
         for (int i = tid; i < 2 * GB; i += blockDim.x) smin[i] = INF_BITS;
+        if (tid < 64) { tabf_lo[tid] = exp((double)tid * lnw); tabi_lo[tid] = exp(-(double)tid * lnw); }
+        if (tid >= 64 && tid < 64 + 66) { const int x = tid - 64; tabf_hi[x] = exp((double)(64 * x) * lnw); tabi_hi[x] = exp(-(double)(64 * x) * lnw); }
     }
+    __syncthreads();
     uint32_t *hist = hists + (size_t)slot * B;
     const uint32_t *ei = eidx + (size_t)t * B;
     double *ft = f64 + (size_t)t * B;
     float *rt = rcp32 + (size_t)t * row_stride;
     const int64_t b0 = (int64_t)seg * seg_chunks * 64;
-    const long long tref = (long long)sege0[(size_t)t * CMS_SEGS + seg] - 1;     // time of ltime == 0
+    // counters are as of element `base`: a counter holding S stands for the value S * w^(j - base) just before element j
+    // adds to it (cstart = value right after element e0 - 1, i.e. at j = e0 it has been scaled once: j - base = 1)
+    long long base = (long long)sege0[(size_t)t * CMS_SEGS + seg] - 1;
+    const double wperiod = exp((double)period * lnw);
     const int ngroups = (seg_chunks + CMSD_FG - 1) / CMSD_FG;
-    const double lnw = log(omega);
-    __shared__ double pw[64];                                     // w^x for the gaps inside one 64-bin chunk
-    __shared__ double pwt[POWW_N];                                // ... and for any gap (poww)
-    if (tid < 64) pw[tid] = exp((double)tid * lnw);
-    poww_build(pwt, lnw, tid, (int)blockDim.x);
-    __syncthreads();
     const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
     const uint8_t *md = meta8 + (size_t)(d < depth ? d : 0) * B;
     double *rv = lval + (size_t)(d < depth ? d : 0) * width;
-    uint16_t *rtm = ltime + (size_t)(d < depth ? d : 0) * width;
     // row waves: the four per-bin inputs of the WHOLE next group (8 chunks = 32 loads per lane) are requested before the
-    // current group is computed: with one workgroup per CU nothing else hides their latency (requesting one chunk
-    // ahead left ~1900 cycles per chunk, most of it waiting for these loads)
+    // current group is computed: with one workgroup per CU nothing else hides their latency
     uint32_t nh[CMSD_FG], np_[CMSD_FG], nm[CMSD_FG], nj[CMSD_FG];
     auto fetch = [&](int g) {
 #pragma unroll
@@ -401,25 +397,36 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
                 if (ch >= seg_chunks) break;
                 const int64_t b = b0 + (int64_t)ch * 64 + lane;
                 const uint32_t h = chh[c], p = cp[c], m = cm[c]; const long long j = (long long)cj[c];
+                // move the base on when the chunk's elements would leave the tables (wave-uniform: element indices
+                // ascend with the lane; lane 0 holds the chunk's first)
+                {
+                    const long long jfirst = (long long)__builtin_amdgcn_readfirstlane((int)cj[c]);
+                    while (jfirst - base > (long long)period) {
+                        for (int i = lane; i < width; i += 64) rv[i] *= wperiod;
+                        base += period;
+                    }
+                }
+                const uint32_t x = h ? (uint32_t)(j - base) : 0u;                // 1 .. period + 64 (unused for bins not in the stream)
+                const double wf = tabf_lo[x & 63u] * tabf_hi[x >> 6], wi = tabi_lo[x & 63u] * tabi_hi[x >> 6];
                 // resolve the lanes in same-counter order: a lane is computed once its predecessor is
                 const uint32_t prev = m & 0x7fu;
-                bool ready = false; double C = 0.0; long long tj = 0;
+                bool ready = false; double Sn = 0.0;
                 if (prev >= 64u) {                                  // first lane of the chunk on this counter: LDS state
-                    const double C0 = rv[p]; const long long t0 = tref + (long long)rtm[p];
-                    if (h) { C = C0 * poww(pwt, j - t0, lnw) + (double)h; tj = j; } else { C = C0; tj = t0; }
+                    const double S0 = rv[p];
+                    if (h) { const double C = S0 * wf + (double)h; Sn = C * wi; atomicMin(&my[c * 64 + lane], (unsigned long long)__double_as_longlong(C)); }
+                    else Sn = S0;
                     ready = true;
                 }
                 while (__any((int)!ready)) {
-                    const double pc = __shfl(C, (int)(prev & 63u));
-                    const long long pt = __shfl(tj, (int)(prev & 63u));
+                    const double ps = __shfl(Sn, (int)(prev & 63u));
                     const int pr = __shfl((int)ready, (int)(prev & 63u));
                     if (!ready && pr) {
-                        if (h) { C = pc * pw[(int)(j - pt) & 63] + (double)h; tj = j; } else { C = pc; tj = pt; }   // gap < 64 inside a chunk
+                        if (h) { const double C = ps * wf + (double)h; Sn = C * wi; atomicMin(&my[c * 64 + lane], (unsigned long long)__double_as_longlong(C)); }
+                        else Sn = ps;
                         ready = true;
                     }
                 }
-                if (h) atomicMin(&my[c * 64 + lane], (unsigned long long)__double_as_longlong(C));
-                if ((m & 0x80u) && b < (int64_t)B) { rv[p] = C; rtm[p] = (uint16_t)(tj - tref); }
+                if ((m & 0x80u) && b < (int64_t)B) rv[p] = Sn;
             }
         }
         if (d == depth && g > 0) {
@@ -545,7 +552,7 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
     const int chunks = (fb.num_bins + 63) / 64;
     const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
     const size_t lds1 = (size_t)depth * width * 8;
-    const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * CMSD_FG * 64 * 8 + (size_t)depth * width * 2;
+    const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * CMSD_FG * 64 * 8;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_cmsd_segsum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
