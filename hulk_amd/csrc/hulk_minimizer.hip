@@ -614,7 +614,8 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     r = (r >> 2) | ((3ull ^ c) << shift);
                 }
                 if (t < w) {
-                    const uint64_t canon = umin64<FM>(f, r);
+                    // (a canonical k-mer has 2k <= 62 bits for every legal k: the f64 minimum is exact whatever FM says)
+                    const uint64_t canon = umin64<true>(f, r);
                     int32_t span = span0 + t;
                     if (span >= k) span = k;
                     uint64_t x;
