@@ -259,7 +259,14 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
 //
 // LDS per group: tab[128] u64 | pk[20] u32      per wave: q[192] u64      per block: lut[256]
 // ------------------------------------------------------------------------------------------
-constexpr int FAST_TAB = 128;
+#ifndef HULK_FAST_TAB
+#define HULK_FAST_TAB 128
+#endif
+#ifndef HULK_FAST_PAD
+#define HULK_FAST_PAD 2048
+#endif
+constexpr int FAST_TAB = HULK_FAST_TAB;       // set slots per 16-lane group (a pair of groups sharing a read uses both tables)
+constexpr int FAST_PAD = HULK_FAST_PAD;
 constexpr int FAST_CAND = 64;          // max run starts per read on the fast path
 constexpr int FAST_RAW = 3072 + 64;    // raw ASCII of the wave's 16 reads, staged once (bytes per wave)
 constexpr int FAST_RAW_PAIR = 5120 + 64;   // ... when two groups share a read (reads of up to ~300 bases)
@@ -379,10 +386,10 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     const int half = PAIR ? (grp & 1) : 0;                         // which half of the read this group takes
     const int sub = PAIR ? ((grp & 3) >> 1) : (grp & 3);           // read of the iteration
     const int32_t posoff = half ? 16 * w - (w - 1) : 0;            // first k-mer position of this group
-    uint64_t *tab = (uint64_t *)(smem + 2048) + (size_t)(PAIR ? (grp & ~1) : grp) * FAST_TAB;   // the per-read set
-    uint32_t *pk32 = (uint32_t *)(smem + 2048 + 16 * FAST_TAB * 8) + grp * 20;
-    uint32_t *raw32 = (uint32_t *)(smem + 2048 + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * (RAWB / 4);
-    uint64_t *cs = (uint64_t *)(smem + 2048 + 16 * FAST_TAB * 8 + 16 * 20 * 4 + 4 * RAWB) + (size_t)grp * FAST_CAND;
+    uint64_t *tab = (uint64_t *)(smem + FAST_PAD) + (size_t)(PAIR ? (grp & ~1) : grp) * FAST_TAB;   // the per-read set
+    uint32_t *pk32 = (uint32_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8) + grp * 20;
+    uint32_t *raw32 = (uint32_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * (RAWB / 4);
+    uint64_t *cs = (uint64_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8 + 16 * 20 * 4 + 4 * RAWB) + (size_t)grp * FAST_CAND;
 #pragma unroll
     for (int x = 0; x < FAST_TAB / 16; x++) tab[gl + 16 * x] = TAB_EMPTY;
     __syncthreads();
@@ -727,11 +734,12 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             bool isnew = false; uint64_t x = 0;
             if (c < total) {
                 x = cs[c];
-                uint32_t sl = ((uint32_t)(x >> 8) ^ (uint32_t)(x >> 37)) & (FAST_TAB - 1);
+                constexpr uint32_t TABM = (PAIR ? 2 * FAST_TAB : FAST_TAB) - 1;    // a pair owns two neighbouring tables
+                uint32_t sl = ((uint32_t)(x >> 8) ^ (uint32_t)(x >> 37)) & TABM;
                 unsigned long long o = (dbg & 4u) ? (unsigned long long)TAB_EMPTY
                                                   : atomicCAS((unsigned long long *)&tab[sl], (unsigned long long)TAB_EMPTY, (unsigned long long)x);
                 while (o != TAB_EMPTY && o != x) {                 // occupied by another value: probe on
-                    sl = (sl + 1) & (FAST_TAB - 1);
+                    sl = (sl + 1) & TABM;
                     o = atomicCAS((unsigned long long *)&tab[sl], (unsigned long long)TAB_EMPTY, (unsigned long long)x);
                 }
                 isnew = (o == TAB_EMPTY);
@@ -935,7 +943,7 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
 }
 
 size_t minimizer_fast_lds(uint32_t, bool pair) {
-    return 2048 + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)(pair ? FAST_RAW_PAIR : FAST_RAW) + 16 * (size_t)FAST_CAND * 8;
+    return FAST_PAD + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)(pair ? FAST_RAW_PAIR : FAST_RAW) + 16 * (size_t)FAST_CAND * 8;
 }
 
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,

@@ -369,31 +369,34 @@ __global__ __launch_bounds__(256) void k_nibble_merge(MinimizerList ml, uint32_t
     const uint32_t slot = P.interval ? (uint32_t)(((uint64_t)t + P.ring_base) % P.ring_n) : P.ring_base;
     uint32_t *hist = hists + (size_t)slot * (size_t)P.num_bins;
     const int total_words = nranges * NIB_WORDS;
+    const size_t pstride = (size_t)n_spectra * (size_t)nranges * NIB_WORDS;
     for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < total_words; w += gridDim.x * blockDim.x) {
         const int r = w / NIB_WORDS, wi = w - r * NIB_WORDS;
         const int32_t b0 = r * NIB_BINS + wi * 8;
         if (b0 >= P.num_bins) continue;
-        uint32_t even = 0, odd = 0, c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t pending = 0;
-        const size_t pstride = (size_t)n_spectra * (size_t)nranges * NIB_WORDS;
+        uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const uint32_t *src = ml.nib + ((size_t)t * (size_t)nranges + r) * NIB_WORDS + wi;
-        for (uint32_t p = 0; p < n_parts; p++) {
-            uint32_t v = src[(size_t)p * pstride];
-            if ((p & 3u) == 0 && p + 3 < n_parts) {                           // four independent loads in flight
-                const uint32_t v1 = src[(size_t)(p + 1) * pstride], v2 = src[(size_t)(p + 2) * pstride], v3 = src[(size_t)(p + 3) * pstride];
-                even += (v & 0x0F0F0F0Fu) + (v1 & 0x0F0F0F0Fu) + (v2 & 0x0F0F0F0Fu);
-                odd += ((v >> 4) & 0x0F0F0F0Fu) + ((v1 >> 4) & 0x0F0F0F0Fu) + ((v2 >> 4) & 0x0F0F0F0Fu);
-                v = v3; p += 3; pending += 3;
-            }
-            even += v & 0x0F0F0F0Fu; odd += (v >> 4) & 0x0F0F0F0Fu;          // byte lanes: at most 17 parts before widening
-            if (++pending >= 14u || p + 1 == n_parts) {
+        // eight parts per step, all eight loads in flight (the kernel is nothing but these strided loads); byte-lane SWAR
+        // sums of the even / odd nibbles: 8 x 15 = 120 fits a byte
+        for (uint32_t p = 0; p < n_parts; p += 8) {
+            uint32_t v[8];
 #pragma unroll
-                for (int q = 0; q < 4; q++) { c[2 * q] += (even >> (8 * q)) & 0xFFu; c[2 * q + 1] += (odd >> (8 * q)) & 0xFFu; }
-                even = odd = 0; pending = 0;
-            }
+            for (int x = 0; x < 8; x++) v[x] = p + x < n_parts ? src[(size_t)(p + x) * pstride] : 0u;
+            uint32_t even = 0, odd = 0;
+#pragma unroll
+            for (int x = 0; x < 8; x++) { even += v[x] & 0x0F0F0F0Fu; odd += (v[x] >> 4) & 0x0F0F0F0Fu; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { c[2 * q] += (even >> (8 * q)) & 0xFFu; c[2 * q + 1] += (odd >> (8 * q)) & 0xFFu; }
         }
+        if (b0 + 8 <= P.num_bins && (((uintptr_t)(hist + b0)) & 15u) == 0) {        // two 16-byte read-modify-writes
+            uint4 *h4 = (uint4 *)(hist + b0);
+            uint4 a0 = h4[0], a1 = h4[1];
+            a0.x += c[0]; a0.y += c[1]; a0.z += c[2]; a0.w += c[3]; a1.x += c[4]; a1.y += c[5]; a1.z += c[6]; a1.w += c[7];
+            h4[0] = a0; h4[1] = a1;
+        } else {
 #pragma unroll
-        for (int q = 0; q < 8; q++) if (c[q] && b0 + q < P.num_bins) hist[b0 + q] += c[q];
+            for (int q = 0; q < 8; q++) if (c[q] && b0 + q < P.num_bins) hist[b0 + q] += c[q];
+        }
     }
 }
 
@@ -481,7 +484,7 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
         const unsigned pg = (n_spectra * np + 7) / 8;
         hipLaunchKernelGGL(k_nibble_hist, dim3(8u * (unsigned)nr * pg), dim3(1024), (size_t)words * 4, s, ml, n_regions, P,
                            n_spectra, np, n_reads, nr);
-        int nb = (nr * NIB_WORDS + 255) / 256; if (nb > 256) nb = 256;
+        int nb = (nr * NIB_WORDS + 255) / 256; if (nb > 512) nb = 512;      // one word (8 bins) per thread up to 131072 words
         hipLaunchKernelGGL(k_nibble_merge, dim3(nb, n_spectra), dim3(256), 0, s, ml, d_hists, P, n_spectra, np, nr);
         only_if = ml.nib_over;                              // the exact kernels only recount flagged spectra
     }
