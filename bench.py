@@ -249,6 +249,7 @@ def main():
 
         for t in range(warmup):
             one_step(t)
+        sk.synchronize()
         torch.cuda.synchronize()
         sk.set_profiling(True)
         tiles0 = sk.scan_stats()
@@ -258,6 +259,7 @@ def main():
         t0 = time.perf_counter()
         for t in range(warmup, total_steps):
             one_step(t)
+        sk.synchronize()                       # (queues the last step's flush, which otherwise waits for a next batch)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()

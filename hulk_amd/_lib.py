@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "hulk_batch_size", "hulk_bin_reads_device", "hulk_histogram_device", "hulk_flush_batch", "hulk_flush_batch_after", "hulk_add_histogram", "hulk_flush",
     "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
     "hulk_get_cws_tables", "hulk_smash", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
-    "hulk_parse_files", "hulk_sketch_files", "hulk_get_scan_stats",
+    "hulk_parse_files", "hulk_sketch_files", "hulk_get_scan_stats", "hulk_synchronize",
 )
 
 
@@ -111,6 +111,7 @@ def load():
     L.hulk_add_histogram.restype = ctypes.c_int; L.hulk_add_histogram.argtypes = [vp, vp]
     L.hulk_flush.restype = ctypes.c_int; L.hulk_flush.argtypes = [vp]
     L.hulk_finish.restype = ctypes.c_int; L.hulk_finish.argtypes = [vp]
+    L.hulk_synchronize.restype = ctypes.c_int; L.hulk_synchronize.argtypes = [vp]
     L.hulk_get_sketch.restype = ctypes.c_int; L.hulk_get_sketch.argtypes = [vp, vp, vp]
     L.hulk_get_counters.restype = ctypes.c_int; L.hulk_get_counters.argtypes = [vp, vp, vp, vp]
     L.hulk_get_histogram.restype = ctypes.c_int; L.hulk_get_histogram.argtypes = [vp, vp]

@@ -88,6 +88,7 @@ struct hulk_ctx {
     hipEvent_t ev_binned = nullptr, ev_flushed[2] = {nullptr, nullptr};
     bool pending_flush[2] = {false, false};
     int cur_ring = 0;
+    struct DeferredFlush { bool armed = false; FlushBatch fb{}; int ring = 0; } deferred;   // a flush between flush_batch's two halves
     // device state
     DevState *d_state = nullptr;
     uint32_t *d_hist = nullptr, *d_hist_tmp = nullptr;
@@ -387,15 +388,27 @@ int ensure_tables(hulk_ctx *c) {
 uint32_t *ring_hist(hulk_ctx *c) { return c->d_hist + (size_t)c->cur_ring * (size_t)c->ring_n * (size_t)c->B; }
 
 // the work stream may only write spectra of the current ring once the flush that last read them is done
+int issue_flush(hulk_ctx *c, hipEvent_t gate);
+// a flush prepared on the current ring has to be queued before anything may wait for it (a partial interval keeps the
+// next batch in the same ring)
+int ring_issue_own_flush(hulk_ctx *c) {
+    if (c->deferred.armed && c->deferred.ring == c->cur_ring) return issue_flush(c, nullptr);
+    return HULK_OK;
+}
+// the event the work stream has to pass before it writes spectra of the current ring (null: nothing to wait for)
+hipEvent_t ring_write_event(hulk_ctx *c) {
+    if (!c->pending_flush[c->cur_ring]) return nullptr;
+    c->pending_flush[c->cur_ring] = false;
+    return c->ev_flushed[c->cur_ring];
+}
 int ring_ready_for_writes(hulk_ctx *c) {
-    if (c->pending_flush[c->cur_ring]) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_flushed[c->cur_ring], 0));
-        c->pending_flush[c->cur_ring] = false;
-    }
+    { const int rc = ring_issue_own_flush(c); if (rc != HULK_OK) return rc; }
+    if (hipEvent_t e = ring_write_event(c)) HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
     return HULK_OK;
 }
 
 int sync_all(hulk_ctx *c) {
+    { const int rc = issue_flush(c, nullptr); if (rc != HULK_OK) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->flush_stream));
     return HULK_OK;
@@ -480,7 +493,7 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
     P.k = c->p.k; P.w = c->p.w; P.num_bins = c->B; P.bases_bytes = bases_bytes;
     P.interval = interval; P.fill = fill; P.ring_base = c->ring_base; P.ring_n = c->ring_n;
     if (const char *e = getenv("HULK_K1_DEBUG")) P.debug = (uint32_t)atoi(e);
-    { int rcw = ring_ready_for_writes(c); if (rcw != HULK_OK) return rcw; }
+    { int rcw = ring_issue_own_flush(c); if (rcw != HULK_OK) return rcw; }
     uint32_t *hist = ring_hist(c);
     int threads = 256;
     // the short-read kernel takes reads of <= 16*w k-mer positions and <= 256 bases; when the batch's
@@ -547,7 +560,10 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
         if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
         ProfileRec pj{}; pj.which = 2;
         if (c->profiling) { HIPCHK(c, hipEventCreate(&pj.a)); HIPCHK(c, hipEventCreate(&pj.b)); }
-        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist, c->d_slow_list, c->d_slow_count, pj.a, pj.b));
+        // (the minimizer and jump-hash kernels do not touch the spectra: only the histogram kernels behind them wait for
+        // the flush that last read this ring)
+        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist, c->d_slow_list, c->d_slow_count, pj.a, pj.b,
+                                        ring_write_event(c)));
         if (c->profiling) c->prof.push_back(pj);
         pick_config(c->p.k, max_len, P, threads);      // (fast_ok implies max_len <= 256: always fits)
         // the list is normally empty or short; its length is only known on the device, so the grid is fixed: enough
@@ -558,6 +574,8 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
                                        c->d_min_slots, c->d_slow_list, c->d_slow_count, list_blocks));
         return HULK_OK;
     }
+    { const int rcf = issue_flush(c, nullptr); if (rcf != HULK_OK) return rcf; }
+    if (hipEvent_t e = ring_write_event(c)) HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
     const bool fits = pick_config(c->p.k, max_len, P, threads);
     P.skip_long = fits ? 0u : 1u;
     HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, hist, c->d_state,
@@ -567,25 +585,19 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
 }
 
 // Flush `count` consecutive spectra of the ring (starting at ring_base) through count-min + CWS.
-int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, bool use_dep = false) {
-    if (count == 0) return HULK_OK;
-    int rc = ensure_tables(c);
-    if (rc != HULK_OK) return rc;
-    FlushBatch fb{};
-    fb.ring_base = c->ring_base; fb.ring_n = c->ring_n; fb.count = count;
-    fb.parity = (int)(c->flush_index & 1); fb.num_bins = c->B;
-    // everything binned so far (and e.g. the caller's all-reduce) is on the work stream: the flush
-    // stream waits for it, then runs on its own
+// queue the kernels of a prepared flush on the flush stream; `gate` (may be null): an event on the work stream they wait for
+int issue_flush(hulk_ctx *c, hipEvent_t gate = nullptr) {
+    if (!c->deferred.armed) return HULK_OK;
+    c->deferred.armed = false;
+    const FlushBatch fb = c->deferred.fb;
+    const int ring = c->deferred.ring;
     static const bool no_overlap = getenv("HULK_NO_OVERLAP") != nullptr;   // profiling aid: one stream, kernels back to back
     hipStream_t s = no_overlap ? c->stream : c->flush_stream;
-    if (use_dep) {            // e.g. the stream the caller's all-reduce of the spectra was issued on
-        HIPCHK(c, hipEventRecord(c->ev_binned, dep_stream));
+    if (!no_overlap) {
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
-    } else if (!no_overlap) {
-        HIPCHK(c, hipEventRecord(c->ev_binned, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
+        if (gate) HIPCHK(c, hipStreamWaitEvent(s, gate, 0));
     }
-    uint32_t *hist = ring_hist(c);
+    uint32_t *hist = c->d_hist + (size_t)ring * (size_t)c->ring_n * (size_t)c->B;
     HIPCHK(c, launch_count_used(s, hist, c->d_state, fb));
     {   // whole-batch bound on the counters as they stand BEFORE this batch is added (see k_flush_decide)
         HIPCHK(c, launch_flush_decide(s, c->d_ctr, c->cms_depth * c->cms_width, c->d_kminslot, c->d_weights, (int)c->slots,
@@ -618,10 +630,30 @@ int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, b
         HIPCHK(c, launch_cws_resolve(s, c->d_rcb, c->d_f64, c->d_tilemin, c->d_candA, c->d_candB, c->d_mins, c->d_weights,
                                      (int)c->slots, (int)c->slot_begin, c->ntiles, c->d_scanmap, c->d_state, fb));
     }
-    HIPCHK(c, hipEventRecord(c->ev_flushed[c->cur_ring], s));
-    c->pending_flush[c->cur_ring] = true;
-    c->flush_index++;
+    HIPCHK(c, hipEventRecord(c->ev_flushed[ring], s));
+    c->pending_flush[ring] = true;
     return HULK_OK;
+}
+
+// Flush `count` consecutive spectra of the ring (starting at ring_base) through count-min + CWS.
+int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, bool use_dep = false) {
+    if (count == 0) return HULK_OK;
+    int rc = ensure_tables(c);
+    if (rc != HULK_OK) return rc;
+    rc = issue_flush(c);                                        // (at most one flush is ever waiting)
+    if (rc != HULK_OK) return rc;
+    FlushBatch fb{};
+    fb.ring_base = c->ring_base; fb.ring_n = c->ring_n; fb.count = count;
+    fb.parity = (int)(c->flush_index & 1); fb.num_bins = c->B;
+    // everything binned so far (or the caller's all-reduce on dep_stream) ends where this event is recorded
+    HIPCHK(c, hipEventRecord(c->ev_binned, use_dep ? dep_stream : c->stream));
+    c->deferred.armed = true; c->deferred.fb = fb; c->deferred.ring = c->cur_ring;
+    c->flush_index++;
+    // Queued at once.  (Holding the flush back until the NEXT batch's minimizer kernel had run — so that its LDS-heavy
+    // count-min kernels would meet k_jump_bin, which needs no LDS, instead of k_minimizer_fast — was measured: C3-shaped
+    // 8.9e8 vs 9.8e8 reads/s without the delay.  What does pay is that the next batch's minimizer and jump-hash kernels
+    // no longer wait for this flush: only the histogram kernels behind them do, see bin_reads.)
+    return issue_flush(c);
 }
 
 int do_flush(hulk_ctx *c) { return flush_batch(c, 1); }
@@ -1114,6 +1146,11 @@ int hulk_get_scan_stats(hulk_ctx *c, uint64_t *tiles_visited, uint64_t *tiles_to
     if (tiles_visited) *tiles_visited = c->prune ? sum : c->scan_tiles_total;
     if (tiles_total) *tiles_total = c->scan_tiles_total;
     return HULK_OK;
+}
+
+int hulk_synchronize(hulk_ctx *c) {
+    if (!c) return HULK_ERR_ARG;
+    return sync_all(c);
 }
 
 int hulk_set_profiling(hulk_ctx *c, int enabled) {

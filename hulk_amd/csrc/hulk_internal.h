@@ -92,7 +92,8 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
                                  DevState *d_state, unsigned long long *d_min_slots);
 hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
                                  uint32_t *d_hists, uint32_t *d_slow_list, uint32_t *d_slow_count,
-                                 hipEvent_t jump_begin = nullptr, hipEvent_t jump_end = nullptr);
+                                 hipEvent_t jump_begin = nullptr, hipEvent_t jump_end = nullptr,
+                                 hipEvent_t wait_before_spectra = nullptr);
 uint32_t minimizer_list_rcap(uint32_t w, bool pair);
 hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSeqDesc *d_desc, uint32_t n_seqs,
                              uint64_t max_npos, MinimizerParams P, uint64_t *d_xs, uint8_t *d_valid, uint64_t *d_table,

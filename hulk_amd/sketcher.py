@@ -160,6 +160,10 @@ class GpuSketcher:
         """theBoss.Flush (boss.go:34-36)."""
         self._chk(self._L.hulk_flush(self._ctx))
 
+    def synchronize(self):
+        """Wait for everything queued so far (copies, binning kernels, flushes)."""
+        self._chk(self._L.hulk_synchronize(self._ctx))
+
     def stop_work(self):
         """Final flush + theBoss.StopWork (pipeline/sketch.go:219-224)."""
         self._chk(self._L.hulk_finish(self._ctx))

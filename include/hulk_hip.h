@@ -34,7 +34,7 @@
  * hulk_last_error()/hulk_strerror().  The library never aborts the process.  A context is
  * single-caller (the reference's SeqMinimizer.Run is one goroutine).  Caller owns every
  * buffer it passes; host buffers may be released as soon as the call returns.  Work is
- * asynchronous on one HIP stream; hulk_finish / hulk_get_* are the synchronisation points and
+ * asynchronous on one HIP stream; hulk_finish / hulk_synchronize / hulk_get_* are the synchronisation points and
  * the place where device-side errors (short read, <1% bins used) surface.
  */
 #ifndef HULK_HIP_H
@@ -195,6 +195,9 @@ int hulk_add_histogram(hulk_ctx *ctx, const uint32_t *bins);
 int hulk_flush(hulk_ctx *ctx);
 /* Final flush + StopWork; synchronises and reports any deferred device-side error. */
 int hulk_finish(hulk_ctx *ctx);
+
+/* Wait until everything queued so far — copies, binning kernels, flushes — has run (the getters below do the same). */
+int hulk_synchronize(hulk_ctx *ctx);
 
 /* Outputs (each synchronises the stream).  mins/weights are full length sketch_size; slots not
  * owned by this context keep their initial values (0 / MaxFloat64). */
