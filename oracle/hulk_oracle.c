@@ -24,7 +24,12 @@
  *     source NOT available offline, and the reference has NO test that pins any CWS
  *     value, sketch `mins` or `weights`  =>  **CWS parity with Go-produced sketches is
  *     UNPINNED** (everything upstream of it — minimizers, bins, histogram, CMS — is
- *     integer-exact and pinned as above).
+ *     integer-exact and pinned as above).  What IS pinned: the restatement equals CPython's
+ *     own random.gammavariate bit for bit when both are fed Go's math/rand Float64 stream
+ *     (tests/test_oracle_reference_vectors.py::test_gamma_matches_cpython_gammavariate_on_the_go_stream),
+ *     and the squeeze constant — go_rng's one doubtful detail — cannot change the stream
+ *     (::test_gamma_squeeze_constant_is_immaterial).  What remains an assumption is that
+ *     go_rng IS that port, call for call (u1 range test, u2 = 1 - U(), one shared source).
  *   - The reference cannot be built here (no Go toolchain, deps not vendored), so there
  *     is no oracle/_ref.
  */

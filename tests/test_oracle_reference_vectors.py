@@ -223,3 +223,37 @@ def test_gamma_squeeze_constant_is_immaterial():
     assert abs(a.mean() - 2.0) < 0.01 and abs(a.var() - 2.0) < 0.03      # Gamma(2, 1)
     assert np.array_equal(a, draws(1, n))
     assert np.array_equal(a, draws(2, n))
+
+
+def test_gamma_matches_cpython_gammavariate_on_the_go_stream():
+    """go_rng's Gamma is (recalled) a port of CPython's random.gammavariate — Cheng's algorithm GB.
+    CPython's own implementation is available here, so the restatement in oracle/hulk_oracle.c is pinned against it: the
+    stdlib routine, fed the SAME uniform stream (Go math/rand Float64, seed 1) through a Random subclass, must return the
+    oracle's variates bit for bit, rejections included (the stream position after N draws is compared too)."""
+    import random
+
+    class GoStream(random.Random):
+        def __init__(self):
+            super().__init__(0)
+            self.src = pyorc.GoRand(1)
+            self.calls = 0
+
+        def random(self):
+            self.calls += 1
+            return self.src.float64()
+
+    ref = GoStream()
+    want = [ref.gammavariate(2.0, 1.0) for _ in range(200_000)]
+    g = pyorc.GoRand(1)
+    got = [g.gamma(2.0, 1.0) for _ in range(200_000)]
+    assert got == want
+    assert g.float64() == ref.src.float64()              # both consumed the same number of uniforms
+    assert ref.calls > 2 * 200_000                        # ... and some attempts were rejected on the way
+    # the first CWS parameters of HistoSketch.newCWS (histosketch.go:107-118) from that routine: r, c = ln(gamma), b = U * r
+    r, c, b = pyorc.cws_tables(2, 16)
+    ref2, uni = GoStream(), pyorc.GoRand(1)
+    import math
+    for i in range(2):
+        for j in range(16):
+            rr = ref2.gammavariate(2.0, 1.0); cc = math.log(ref2.gammavariate(2.0, 1.0)); bb = (0.0 + uni.float64() * 1.0) * rr
+            assert r[i, j] == rr and c[i, j] == cc and b[i, j] == bb
