@@ -668,7 +668,8 @@ constexpr int SMASH_T = 16, SMASH_CH = 64;
 __global__ __launch_bounds__(256) void k_smash(const unsigned long long *__restrict__ mins,
                                                const double *__restrict__ weights, uint32_t N, uint32_t S,
                                                int metric, double *__restrict__ out) {
-    __shared__ unsigned long long ma[SMASH_T][SMASH_CH + 1], mb[SMASH_T][SMASH_CH + 1];
+    // the reference compares the `mins` as float64 (sketchio.go:271-277): converted once, when a chunk is staged
+    __shared__ double ma[SMASH_T][SMASH_CH + 1], mb[SMASH_T][SMASH_CH + 1];
     __shared__ double wa[SMASH_T][SMASH_CH + 1];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;        // query, subject inside the tile
     const uint32_t s = blockIdx.y * SMASH_T + ty, q = blockIdx.x * SMASH_T + tx;
@@ -678,9 +679,9 @@ __global__ __launch_bounds__(256) void k_smash(const unsigned long long *__restr
             const int r = i / SMASH_CH, c = i % SMASH_CH;
             const uint32_t sa = blockIdx.y * SMASH_T + r, qb = blockIdx.x * SMASH_T + r, col = c0 + c;
             const bool okc = col < S;
-            ma[r][c] = (okc && sa < N) ? mins[(size_t)sa * S + col] : 0ull;
+            ma[r][c] = (okc && sa < N) ? (double)mins[(size_t)sa * S + col] : 0.0;
             wa[r][c] = (okc && sa < N) ? weights[(size_t)sa * S + col] : 0.0;
-            mb[r][c] = (okc && qb < N) ? mins[(size_t)qb * S + col] : 0ull;
+            mb[r][c] = (okc && qb < N) ? (double)mins[(size_t)qb * S + col] : 0.0;
         }
         __syncthreads();
         const uint32_t lim = S - c0 < (uint32_t)SMASH_CH ? S - c0 : (uint32_t)SMASH_CH;
@@ -688,11 +689,11 @@ __global__ __launch_bounds__(256) void k_smash(const unsigned long long *__restr
             for (uint32_t c = 0; c < lim; c++) {
                 // math.Max(math.Max(w,0), math.Max(-w,0)) == |w| (NaN stays NaN); weightB == weightA
                 const double wgt = fabs(wa[ty][c]);
-                if ((double)ma[ty][c] == (double)mb[tx][c]) { intersect += wgt; uni += wgt; }
+                if (ma[ty][c] == mb[tx][c]) { intersect += wgt; uni += wgt; }
                 else uni += wgt;
             }
         } else {
-            for (uint32_t c = 0; c < lim; c++) if ((double)ma[ty][c] == (double)mb[tx][c]) intersect += 1.0;
+            for (uint32_t c = 0; c < lim; c++) if (ma[ty][c] == mb[tx][c]) intersect += 1.0;
         }
         __syncthreads();
     }
