@@ -658,3 +658,22 @@ def test_concept_drift_many_seeds_mins_exact():
         assert np.array_equal(gm2, gm) and np.allclose(gw2, gw, rtol=1e-12, atol=0)
         for x in (o, g, o2, g2):
             x.close()
+
+
+@pytest.mark.parametrize("S", [2048, 1001])
+def test_large_and_ragged_sketch_sizes(S):
+    """sketchSize 2048 is what BASELINE C5's sketches have; 1001 is not a multiple of the 8-slot scan groups (the last
+    group's bound test, slot minima and resolve see 1 live row of 8).  k = 15, 4 intervals, against the oracle."""
+    rng = np.random.default_rng(S)
+    seqs = random_reads(rng, 20_000, 150)
+    o, g = run_both(seqs, 15, 9, S, interval=5_000, batches=3)
+    o.finish(); g.finish()
+    assert_same_sketch(o, g)
+    assert np.array_equal(g.cms(), o.cms())
+    g.close(); o.close()
+    if S == 1001:                                   # ... and with concept drift
+        o, g = run_both(seqs[:8000], 15, 9, S, interval=2_000, batches=2, decay=0.05)
+        o.finish(); g.finish()
+        om, ow = o.sketch(); gm, gw = g.sketch()
+        assert np.array_equal(om, gm) and np.allclose(gw, ow, rtol=DRIFT_RTOL, atol=0)
+        g.close(); o.close()
