@@ -299,7 +299,7 @@ int generate_tables_device(hulk_ctx *c) {
 #define GEN_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = fail_hip(c, e_, #call); cleanup(); return rc; } } while (0)
     if (hipMalloc((void **)&d_raw, total_raw * 8) != hipSuccess) { (void)hipGetLastError(); cleanup(); return 1; }   // not enough HBM: host walk
     GEN_CHK(hipMalloc((void **)&d_win, n_chunks * 607 * 8));
-    GEN_CHK(hipMalloc((void **)&d_coef, 607 * 8));
+    GEN_CHK(hipMalloc((void **)&d_coef, 2 * 607 * 8));                         // x^(2^20) and x^(2^26)
     GEN_CHK(hipMalloc((void **)&d_list, (size_t)LIST_CAP * 8));
     GEN_CHK(hipMalloc((void **)&d_cnt, 4));
     GEN_CHK(hipMalloc((void **)&d_val, CH * 8));
@@ -310,11 +310,14 @@ int generate_tables_device(hulk_ctx *c) {
         GoRandSource(1).initial_window(w0);
         GEN_CHK(hipMemcpyAsync(d_win, w0, sizeof w0, hipMemcpyHostToDevice, c->stream));
         GEN_CHK(hipMemcpyAsync(d_coef, GO_RNG_JUMP, 607 * 8, hipMemcpyHostToDevice, c->stream));
+        GEN_CHK(hipMemcpyAsync(d_coef + 607, GO_RNG_JUMP_FAR, 607 * 8, hipMemcpyHostToDevice, c->stream));
         GEN_CHK(hipMemsetAsync(d_cnt, 0, 4, c->stream));
         GEN_CHK(hipMemsetAsync(d_tot, 0, 16, c->stream));
         GEN_CHK(hipStreamSynchronize(c->stream));                              // w0 is a stack buffer
     }
-    GEN_CHK(launch_alfg(c->stream, d_coef, d_win, d_raw, 0, (uint32_t)n_chunks, C));
+    static const bool one_level = getenv("HULK_ALFG_ONE_LEVEL") != nullptr;      // A/B aid: the single walk over all chunks
+    GEN_CHK(launch_alfg(c->stream, d_coef, one_level ? nullptr : d_coef + 607, 1u << (GO_RNG_JUMP_FAR_LOG2 - GO_RNG_JUMP_LOG2),
+                        d_win, d_raw, 0, (uint32_t)n_chunks, C));
     GEN_CHK(launch_rng_candidates(c->stream, d_raw, total_raw, d_list, LIST_CAP, d_cnt));
     unsigned int n_cand = 0;
     GEN_CHK(hipMemcpyAsync(&n_cand, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));

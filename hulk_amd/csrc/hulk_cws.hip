@@ -500,21 +500,29 @@ __global__ __launch_bounds__(256) void k_cws_resolve_drift(const double *__restr
 // jump polynomial (go_rng_jump.h: y[n + C + j] = sum_i coef[i] * y[n + i + j]), k_alfg_fill expands every chunk in
 // parallel, 256 values per step (the shorter lag is 273).  windows[c] = the 607 values that end where chunk c begins.
 __global__ __launch_bounds__(640) void k_alfg_jump(const uint64_t *__restrict__ coef, uint64_t *__restrict__ windows,
-                                                   uint32_t first_chunk, uint32_t n_chunks) {
+                                                   uint32_t first_chunk, uint32_t n_chunks, uint32_t stride,
+                                                   uint32_t span, uint32_t steps) {
+    // workgroup b starts from windows[first_chunk + b * span] (valid) and takes `steps` jumps of `stride` chunks with
+    // the polynomial `coef` (= x^(stride * 2^20)), storing every window it reaches — as far as the chunks go.
+    // Two levels: ONE workgroup walks every 64th chunk with the far polynomial, then one workgroup per 64 chunks fills
+    // in the 63 between (a single walk over all chunks was 130 ms at k = 31, sketchSize 1024: 5.5 k dependent jumps).
     __shared__ uint64_t E[1216], C[608];
     const int tid = threadIdx.x;
-    if (tid < 607) { C[tid] = coef[tid]; E[tid] = windows[(size_t)first_chunk * 607 + tid]; }
+    const uint32_t last = first_chunk + n_chunks;                 // one past the last chunk
+    uint32_t c = first_chunk + blockIdx.x * span;
+    if (c >= last) return;
+    if (tid < 607) { C[tid] = coef[tid]; E[tid] = windows[(size_t)c * 607 + tid]; }
     __syncthreads();
-    for (uint32_t c = first_chunk; c + 1 < first_chunk + n_chunks; c++) {
+    for (uint32_t i = 0; i < steps && c + stride < last; i++, c += stride) {
         for (int base = 607; base < 1213; base += 273) {          // extend the window by 606 values, 273 at a time
             const int j = base + tid;
             if (tid < 273 && j < 1213) E[j] = E[j - 607] + E[j - 273];
             __syncthreads();
         }
         uint64_t acc = 0;
-        if (tid < 607) for (int i = 0; i < 607; i++) acc += C[i] * E[i + tid];
+        if (tid < 607) for (int x = 0; x < 607; x++) acc += C[x] * E[x + tid];
         __syncthreads();
-        if (tid < 607) { E[tid] = acc; windows[(size_t)(c + 1) * 607 + tid] = acc; }
+        if (tid < 607) { E[tid] = acc; windows[(size_t)(c + stride) * 607 + tid] = acc; }
         __syncthreads();
     }
 }
@@ -812,10 +820,17 @@ hipError_t launch_cws_chunk(hipStream_t s, const uint64_t *d_pairs, uint64_t n_a
     return hipGetLastError();
 }
 
-hipError_t launch_alfg(hipStream_t s, const uint64_t *d_coef, uint64_t *d_windows, uint64_t *d_raw, uint32_t first_chunk,
-                       uint32_t n_chunks, uint64_t chunk_len) {
+hipError_t launch_alfg(hipStream_t s, const uint64_t *d_coef, const uint64_t *d_coef_far, uint32_t far_chunks,
+                       uint64_t *d_windows, uint64_t *d_raw, uint32_t first_chunk, uint32_t n_chunks, uint64_t chunk_len) {
     // windows[first_chunk] is valid; produces windows[first_chunk + 1 .. first_chunk + n_chunks) and the chunks themselves
-    hipLaunchKernelGGL(k_alfg_jump, dim3(1), dim3(640), 0, s, d_coef, d_windows, first_chunk, n_chunks);
+    if (d_coef_far && far_chunks > 1 && n_chunks > far_chunks) {
+        hipLaunchKernelGGL(k_alfg_jump, dim3(1), dim3(640), 0, s, d_coef_far, d_windows, first_chunk, n_chunks, far_chunks,
+                           0u, (n_chunks - 1) / far_chunks);
+        hipLaunchKernelGGL(k_alfg_jump, dim3((n_chunks + far_chunks - 1) / far_chunks), dim3(640), 0, s, d_coef, d_windows,
+                           first_chunk, n_chunks, 1u, far_chunks, far_chunks - 1);
+    } else {
+        hipLaunchKernelGGL(k_alfg_jump, dim3(1), dim3(640), 0, s, d_coef, d_windows, first_chunk, n_chunks, 1u, 0u, n_chunks);
+    }
     hipLaunchKernelGGL(k_alfg_fill, dim3(n_chunks), dim3(256), 0, s, d_windows, d_raw, first_chunk, chunk_len);
     return hipGetLastError();
 }

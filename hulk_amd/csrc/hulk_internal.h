@@ -134,8 +134,8 @@ hipError_t launch_cws_chunk(hipStream_t s, const uint64_t *d_pairs, uint64_t n_a
                             double *d_rcb, uint64_t num_bins, uint64_t slot_begin, uint64_t slots,
                             uint64_t sketch_size, double ainv, double bbb, double ccc, double magic,
                             const uint64_t *d_raw, uint64_t first_attempt, const uint64_t *d_ev, uint32_t n_ev);
-hipError_t launch_alfg(hipStream_t s, const uint64_t *d_coef, uint64_t *d_windows, uint64_t *d_raw, uint32_t first_chunk,
-                       uint32_t n_chunks, uint64_t chunk_len);
+hipError_t launch_alfg(hipStream_t s, const uint64_t *d_coef, const uint64_t *d_coef_far, uint32_t far_chunks,
+                       uint64_t *d_windows, uint64_t *d_raw, uint32_t first_chunk, uint32_t n_chunks, uint64_t chunk_len);
 hipError_t launch_rng_candidates(hipStream_t s, const uint64_t *d_raw, uint64_t n, uint64_t *d_list, uint32_t cap,
                                  unsigned int *d_count);
 hipError_t launch_cws_beta(hipStream_t s, const uint64_t *d_uraw, uint64_t first_entry, uint64_t n, double *d_rcb,
