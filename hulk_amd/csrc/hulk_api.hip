@@ -88,7 +88,7 @@ struct hulk_ctx {
     hipEvent_t ev_binned = nullptr, ev_flushed[2] = {nullptr, nullptr};
     bool pending_flush[2] = {false, false};
     int cur_ring = 0;
-    struct DeferredFlush { bool armed = false; FlushBatch fb{}; int ring = 0; } deferred;   // a flush between flush_batch's two halves
+    struct PreparedFlush { bool armed = false; FlushBatch fb{}; int ring = 0; } deferred;   // a flush between its preparation (ev_binned recorded) and the queueing of its kernels
     // device state
     DevState *d_state = nullptr;
     uint32_t *d_hist = nullptr, *d_hist_tmp = nullptr;
