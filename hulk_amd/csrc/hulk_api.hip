@@ -17,6 +17,26 @@
 
 using namespace hulk;
 
+// Debug aid: HULK_POISON=<byte> fills every device / pinned allocation of this file with that byte, so that a read of
+// memory nothing has written shows up the same way in every process (tools/fuzz_parity.py found one such read by its
+// dependence on what earlier contexts had left behind).
+static int poison_byte() {
+    static const int v = [] { const char *e = getenv("HULK_POISON"); return e ? (int)(strtol(e, nullptr, 0) & 0xff) : -1; }();
+    return v;
+}
+static hipError_t poison_malloc(void **p, size_t n) {
+    hipError_t e = (hipMalloc)(p, n);
+    if (e == hipSuccess && poison_byte() >= 0 && n) { e = hipMemset(*p, poison_byte(), n); if (e == hipSuccess) e = hipDeviceSynchronize(); }
+    return e;
+}
+static hipError_t poison_host_malloc(void **p, size_t n, unsigned flags) {
+    hipError_t e = (hipHostMalloc)(p, n, flags);
+    if (e == hipSuccess && poison_byte() >= 0 && n) memset(*p, poison_byte(), n);
+    return e;
+}
+#define hipMalloc(p, n) poison_malloc((void **)(p), (n))
+#define hipHostMalloc(p, n, f) poison_host_malloc((void **)(p), (n), (f))
+
 namespace {
 
 thread_local std::string g_create_error;

@@ -371,7 +371,13 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     extern __shared__ __align__(16) unsigned char smem[];
     // (the first 2 KB of LDS held ASCII -> 2-bit tables once; the layout behind them is unchanged)
 
-    constexpr uint64_t XN = FM ? 0x7FF0000000000000ull : X_NONE;   // "no value": above every minimizer value
+    // KEY5 (the k = 31 instance): minimizer values use all 64 bits there (hash << 8 wraps), so they are not comparable as
+    // doubles — but X = (hash mod 2^56) << 8 | span with 1 <= span <= 31 is order-isomorphic to the 61-bit key
+    // (hash mod 2^56) << 5 | span, which is.  The window minima, run starts and the candidate list work on keys (one
+    // v_min_f64 per minimum instead of v_cmp_lt_u64 + two v_cndmask); a key becomes its X again when it enters the set.
+    constexpr bool KEY5 = !FM && WEQ && KC == 31;
+    constexpr bool FMM = FM || KEY5;                               // 64-bit minima through v_min_f64
+    constexpr uint64_t XN = FMM ? 0x7FF0000000000000ull : X_NONE;  // "no value": above every minimizer value / key
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, gsh = lane & 48;
     // WEQ: the window size equals the block size WM (w = 9 is the reference's default): every `t < w` test and
@@ -390,8 +396,11 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     uint32_t *pk32 = (uint32_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8) + grp * 20;
     uint32_t *raw32 = (uint32_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * (RAWB / 4);
     uint64_t *cs = (uint64_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8 + 16 * 20 * 4 + 4 * RAWB) + (size_t)grp * FAST_CAND;
+    {   // every group empties its OWN table (a pair's set spans both of its groups' tables)
+        uint64_t *own = (uint64_t *)(smem + FAST_PAD) + (size_t)grp * FAST_TAB;
 #pragma unroll
-    for (int x = 0; x < FAST_TAB / 16; x++) tab[gl + 16 * x] = TAB_EMPTY;
+        for (int x = 0; x < FAST_TAB / 16; x++) own[gl + 16 * x] = TAB_EMPTY;
+    }
     __syncthreads();
 
     // this wave owns FAST_READS_PER_WAVE consecutive reads and one region of the minimizer list
@@ -627,6 +636,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     if (span >= k) span = k;
                     uint64_t x;
                     if (HP && !(dbg & 16u)) x = hash64_pack_kc<HP ? KC : 21>(canon, (uint32_t)span);
+                    else if (KEY5) x = (hash64(canon, mask) & 0x00FFFFFFFFFFFFFFull) << 5 | (uint64_t)(uint32_t)span;
                     else x = ((dbg & 16u) ? canon * 0x9E3779B97F4A7C15ull : hash64_fm<FM>(canon, mask)) << 8 | (uint64_t)(int64_t)span;
                     // f == r (a k-mer that is its own reverse complement: even k only, reads with N never get
                     // here) is skipped by the reference: the position neither reports nor takes part in a window
@@ -651,7 +661,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                 uint64_t h = XN;
 #pragma unroll
                 for (int t = WM - 1; t >= 0; t--) {
-                    if (t < w) h = umin64<FM>(X[t], h);
+                    if (t < w) h = umin64<FMM>(X[t], h);
                     hp[t] = h;                                 // h[t]
                 }
             }
@@ -662,7 +672,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
 #pragma unroll
             for (int t = 0; t < WM - 1; t++) {
                 const uint64_t v = dpp_row_shr1_u64(hp[t + 1]);
-                hp[t] = FM ? (v | (xnfix & 0xffffffff00000000ull)) : (v | xnfix);
+                hp[t] = FMM ? (v | (xnfix & 0xffffffff00000000ull)) : (v | xnfix);
             }
             hp[WM - 1] = XN;
             const uint32_t pv = dpp_row_shr1(validbits);
@@ -671,9 +681,9 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             uint64_t g = XN, pm = whole;
 #pragma unroll
             for (int t = 0; t < WM; t++) {
-                g = umin64<FM>(X[t], g);
+                g = umin64<FMM>(X[t], g);
                 const uint64_t hpt = (t + 1 < w) ? hp[t] : XN;
-                const uint64_t m = umin64<FM>(hpt, g);
+                const uint64_t m = umin64<FMM>(hpt, g);
                 if (t < w) { eqbits |= (m == pm) ? (1u << t) : 0u; pm = m; }
                 X[t] = m;
             }
@@ -734,6 +744,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             bool isnew = false; uint64_t x = 0;
             if (c < total) {
                 x = cs[c];
+                if (KEY5) x = (x & ~31ull) << 3 | (x & 31ull);              // key -> X = hash << 8 | span
                 constexpr uint32_t TABM = (PAIR ? 2 * FAST_TAB : FAST_TAB) - 1;    // a pair owns two neighbouring tables
                 uint32_t sl = ((uint32_t)(x >> 8) ^ (uint32_t)(x >> 37)) & TABM;
                 unsigned long long o = (dbg & 4u) ? (unsigned long long)TAB_EMPTY

@@ -677,3 +677,25 @@ def test_large_and_ragged_sketch_sizes(S):
         om, ow = o.sketch(); gm, gw = g.sketch()
         assert np.array_equal(om, gm) and np.allclose(gw, ow, rtol=DRIFT_RTOL, atol=0)
         g.close(); o.close()
+
+
+def test_pair_sets_start_empty_low_complexity_reads():
+    """Regression (found by tools/fuzz_parity.py, 12,000 cases): when two 16-lane groups share a read their per-read set spans
+    BOTH groups' LDS tables; each group must empty its own at kernel start (for a while both emptied the first, and stale LDS
+    in the second made some values look already seen — dropped minimizers, depending on what ran before).  Low-complexity
+    reads over {A, C} (many repeats per read) in the two-groups shape (k = 5, w = 5, 150 bp), after other batches."""
+    h = gpu()
+    rng = np.random.default_rng(2298)
+    for trial in range(6):
+        k, w = 5, 5
+        g = h.GpuSketcher(k, w, 1); o = pyorc.Sketcher(k, w, 1, 0, 1.0, 0)
+        parts = [random_reads(rng, int(rng.integers(60, 300)), int(rng.integers(165, 250))),       # generic kernel
+                 random_reads(rng, int(rng.integers(60, 300)), int(rng.integers(165, 250))),
+                 random_reads(rng, int(rng.integers(20, 80)), 150, alphabet=b"AC") + [b"A" * 150, b"C" * 150, b"AC" * 75],
+                 random_reads(rng, 7, 150, alphabet=b"AC")]
+        for p in parts:
+            b, off = pack_reads(p)
+            g.add_reads(b, off); o.add_reads(b, off)
+        assert g.counters()["n_minimizers"] == o.counters()["n_minimizers"], trial
+        assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32)), trial
+        g.close(); o.close()

@@ -15,6 +15,7 @@ from hulk_amd._lib import HulkError
 from oracle import pyorc
 from conftest import pack_reads
 
+only = int(os.environ["FUZZ_ONLY"]) if "FUZZ_ONLY" in os.environ else None      # run just this case (the others only draw their random numbers)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
@@ -58,6 +59,13 @@ for case in range(n_cases):
     desc = f"case {case}: k={k} w={w} S={S} decay={decay} I={interval} batch={batch} alph={alph!r} reads={len(seqs)} shape={shape}"
     os.environ["HULK_BATCH"] = str(batch)
     oerr = gerr = None
+    if os.environ.get("FUZZ_DUMP") == str(case):           # write the case's reads (no GPU needed) and stop
+        np.save(os.environ.get("FUZZ_DUMP_FILE", "fuzz_case.npy"), np.array(seqs, dtype=object), allow_pickle=True)
+        print("dumped", desc)
+        sys.exit(0)
+    if (only is not None and case != only) or case < int(os.environ.get("FUZZ_FROM", "0")):
+        rng.integers(0, len(seqs) + 1, size=3)
+        continue
     o = pyorc.Sketcher(k, w, S, 0, decay, interval)
     bases, offsets = pack_reads(seqs)
     try:
@@ -88,6 +96,42 @@ for case in range(n_cases):
     if not ok:
         bad += 1
         print("MISMATCH", desc, "::", why, flush=True)
+        if only is not None or "FUZZ_FROM" in os.environ:      # diagnosis: which reads disagree on their number of distinct minimizers
+            print("cuts", cuts, "oracle", o.counters(), "gpu", g.counters())
+            for variant in ("same cuts", "one call", "NO_FAST"):
+                if variant == "NO_FAST":
+                    os.environ["HULK_NO_FAST_K1"] = "1"
+                g2 = hulk_amd.GpuSketcher(k, w, S, interval, decay)
+                try:
+                    cc = cuts if variant == "same cuts" else [0, len(seqs)]
+                    for x, y in zip(cc[:-1], cc[1:]):
+                        g2.add_reads(bases, offsets[x:y + 1])
+                    g2.finish()
+                    print(" rerun", variant, g2.counters())
+                except HulkError as e:
+                    print(" rerun", variant, "error", e.message)
+                g2.close()
+                os.environ.pop("HULK_NO_FAST_K1", None)
+            for x, y in zip(cuts[:-1], cuts[1:]):          # which call's reads disagree
+                oo = pyorc.Sketcher(k, w, 1, 0, 1.0, 0); g3 = hulk_amd.GpuSketcher(k, w, 1)
+                try:
+                    oo.add_reads(bases, offsets[x:y + 1]); g3.add_reads(bases, offsets[x:y + 1])
+                    ho, hg = oo.histogram(), g3.histogram()
+                    print(" call", x, y, "maxlen", max(len(q) for q in seqs[x:y]) if y > x else 0, "oracle", oo.counters()["n_minimizers"], "gpu", g3.counters()["n_minimizers"], "hist equal", bool(np.array_equal(ho.astype(np.uint32), hg)))
+                except Exception as e:
+                    print(" call", x, y, "error", e)
+                oo.close(); g3.close()
+            for i, sq in enumerate(seqs):
+                try:
+                    no = len(pyorc.minimizers(sq, k, w))
+                except pyorc.OracleError:
+                    continue
+                gg = hulk_amd.GpuSketcher(k, w, 1)
+                gg.add_seq(sq)
+                ng = gg.counters()["n_minimizers"]
+                gg.close()
+                if no != ng:
+                    print("read", i, "len", len(sq), "oracle", no, "gpu alone", ng, sq[:80])
     g.close(); o.close()
 print(f"{n_cases} cases ({n_cases - n_err} sketches compared, {n_err} agreed on an error: {errs}), {bad} mismatches, "
       f"{time.time() - t_start:.1f} s (seed {seed})")
