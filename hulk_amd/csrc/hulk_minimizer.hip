@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
     __syncthreads();
 
     const int lane = lane_id();
-    const int wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     const uint32_t xcap = P.xcap, tabn = P.tab_size, tabmask = P.tab_size - 1;
     const size_t per_wave = P.lds_per_wave;
     unsigned char *wbase = smem + 256 + (size_t)wid * per_wave;
@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     constexpr bool KEY5 = !FM && WEQ && KC == 31;
     constexpr bool FMM = FM || KEY5;                               // 64-bit minima through v_min_f64
     constexpr uint64_t XN = FMM ? 0x7FF0000000000000ull : X_NONE;  // "no value": above every minimizer value / key
-    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    // (wid is wave-uniform: keeping it in an SGPR also keeps it out of the register allocator's way — hipcc 7.2 lost the
+    // VGPR copy across the main loop in the <16, false, false, false, 0, true> instance)
+    const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, gsh = lane & 48;
     // WEQ: the window size equals the block size WM (w = 9 is the reference's default): every `t < w` test and
     // every multiple of w becomes a compile-time constant

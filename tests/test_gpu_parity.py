@@ -699,3 +699,31 @@ def test_pair_sets_start_empty_low_complexity_reads():
         assert g.counters()["n_minimizers"] == o.counters()["n_minimizers"], trial
         assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32)), trial
         g.close(); o.close()
+
+
+@pytest.mark.parametrize("w", [3, 4, 7, 9, 12, 16])
+@pytest.mark.parametrize("k", [21, 24, 28, 31])
+def test_every_short_read_kernel_instance(k, w):
+    """One case per instantiation of k_minimizer_fast (block size 4 / 9 / 16 x {w equal to it or not} x {k = 21, k <= 27,
+    k >= 28, k = 31} x {one group per read, two}), with and without sketching intervals: minimizer count, k-mer spectrum
+    and sketch against the oracle.  Regression for a code-generation accident found by tools/fuzz_parity.py (FUZZ_BIG_K):
+    in the <16, k >= 28, w != 16, two groups> instance hipcc lost the wave index across the main loop, the block's
+    minimizer count went to no LDS address at all and `n_minimizers` came back as stale LDS contents (spectrum and sketch
+    were right, so tests that compared only those passed)."""
+    rng = np.random.default_rng(100 * k + w)
+    shapes = [(max(k + w - 1, min(256, k + 16 * w - 1) - 40), min(256, k + 16 * w - 1))]
+    if 16 * w + k - 1 <= 256:
+        shapes.append((k + 16 * w, min(512, k + 31 * w)))
+    for lens in shapes:
+        seqs = random_reads(rng, 700, lens)
+        seqs[3] = seqs[3][:40] + b"N" + seqs[3][41:]                  # one deferred read
+        for interval in (0, 250):
+            o, g = run_both(seqs, k, w, 4, interval=interval, num_bins=4096, batches=2 if interval else 1)
+            if not interval:
+                assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32)), (lens, interval)
+            o.finish(); g.finish()
+            oc, gc = o.counters(), g.counters()
+            assert all(oc[key] == gc[key] for key in ("n_reads", "n_minimizers", "total_len")), (lens, interval, oc, gc)
+            assert np.array_equal(g.cms(), o.cms()), (lens, interval)
+            assert_same_sketch(o, g)
+            g.close(); o.close()

@@ -25,11 +25,13 @@ n_err = 0
 errs = {}
 t_start = time.time()
 for case in range(n_cases):
-    k = int(rng.choice([3, 5, 7, 8, 9, 11, 12, 13, 15, 16, 17, 21, 21, 21]))   # k^4 bins and S*k^4 tables stay small; 21 = the compiled-in default
+    k = int(rng.choice([3, 5, 7, 8, 9, 11, 12, 13, 15, 16, 17, 21, 21, 21] + ([27, 28, 31] if os.environ.get("FUZZ_BIG_K") else [])))   # k^4 bins and S*k^4 tables stay small; 21 = the compiled-in default
     w = int(rng.choice([1, 2, 3, 4, 5, 9, 9, 9, 10, 16, 17, 25, 40]))
     S = int(rng.choice([1, 2, 7, 8, 9, 16, 31, 50]))
     if k == 21:
         S = min(S, 16)
+    if k > 21:
+        S = min(S, 2)                  # (FUZZ_BIG_K) 923,521 bins at k = 31: tables of 3 x S x k^4 doubles on both sides
     decay = float(rng.choice([1.0, 1.0, 1.0, 0.0, 0.02, 0.3, 0.97]))
     interval = int(rng.choice([0, 0, 1, 7, 50, 333]))
     batch = int(rng.choice([1, 2, 5, 8, 16]))
@@ -68,8 +70,12 @@ for case in range(n_cases):
         continue
     o = pyorc.Sketcher(k, w, S, 0, decay, interval)
     bases, offsets = pack_reads(seqs)
+    ohist = ghist = None
     try:
-        o.add_reads(bases, offsets); o.finish()
+        o.add_reads(bases, offsets)
+        if interval == 0:
+            ohist = o.histogram().astype(np.uint32)          # the whole k-mer spectrum, before the final flush wipes it
+        o.finish()
     except pyorc.OracleError as e:
         oerr = str(e)
     g = hulk_amd.GpuSketcher(k, w, S, interval, decay)
@@ -77,11 +83,15 @@ for case in range(n_cases):
         cuts = sorted(set([0, len(seqs)] + [int(x) for x in rng.integers(0, len(seqs) + 1, size=3)]))
         for x, y in zip(cuts[:-1], cuts[1:]):
             g.add_reads(bases, offsets[x:y + 1])
+        if interval == 0:
+            ghist = g.histogram()
         g.finish()
     except HulkError as e:
         gerr = e.message
     ok = True
-    if (oerr is None) != (gerr is None) or (oerr is not None and oerr != gerr):
+    if ohist is not None and ghist is not None and not np.array_equal(ohist, ghist):
+        ok = False; why = f"spectra differ in {int((ohist != ghist).sum())} bins"
+    elif (oerr is None) != (gerr is None) or (oerr is not None and oerr != gerr):
         ok = False; why = f"errors differ: oracle={oerr!r} gpu={gerr!r}"
     elif oerr is None:
         om, ow = o.sketch(); gm, gw = g.sketch()
