@@ -167,6 +167,12 @@ template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((voi
 // position g = jump(bin*(d+1), width) (countmin.go:122-125), ascending bin inside a group.
 int build_chains(hulk_ctx *c) {
     const int D = c->cms_depth, W = c->cms_width; const int32_t B = c->B;
+    if (!getenv("HULK_CHAINS_HOST")) {          // (the host loop below is kept as the A/B check of k_build_chains)
+        HIPCHK(c, dalloc(&c->d_meta8, (size_t)D * B));
+        HIPCHK(c, dalloc(&c->d_pos16, (size_t)D * B));
+        HIPCHK(c, launch_build_chains(c->stream, c->d_pos16, c->d_meta8, B, D, W));
+        return HULK_OK;
+    }
     std::vector<uint32_t> pos(B);
     std::vector<uint16_t> pos16((size_t)D * B);
     std::vector<uint8_t> meta8((size_t)D * B);       // bits 0-6: previous lane of the 64-bin chunk on the same counter (64 = none); bit 7: last one

@@ -579,4 +579,37 @@ hipError_t launch_elem_index(hipStream_t s, const uint32_t *d_hists, uint32_t *d
 
 int elem_index_blocks(int32_t num_bins) { return (num_bins + EIDX_BLOCK - 1) / EIDX_BLOCK; }
 
+// Static chain tables of the bin-order count-min kernels (built once per context): for row d the counter position
+// g = jump(bin + d*bin, width) of every bin (countmin.go:122-125), and per 64-bin chunk which earlier lane of the chunk
+// hits the same counter (bits 0-6, 64 = none) and whether the bin is the last one of the chunk on its counter (bit 7).
+// One wave per (row, chunk).  (A host loop did this until round 2: 7 * k^4 jump hashes, 70 ms of every hulk_create at k = 21.)
+namespace {
+__global__ __launch_bounds__(256) void k_build_chains(uint16_t *__restrict__ pos16, uint8_t *__restrict__ meta8, int32_t B, int width) {
+    const int lane = lane_id();
+    const int32_t chunk = (int32_t)blockIdx.x * 4 + (int32_t)(threadIdx.x >> 6);
+    const int d = (int)blockIdx.y;
+    const int32_t b = chunk * 64 + lane;
+    if (chunk * 64 >= B) return;
+    const bool valid = b < B;
+    const uint32_t pos = valid ? (uint32_t)jump_hash((uint64_t)b + (uint64_t)d * (uint64_t)b, width) : 0xffffffffu;
+    int prev = 64; bool later = false;
+#pragma unroll
+    for (int j = 0; j < 64; j++) {
+        const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)pos, j);
+        if (pj == pos && j < lane) prev = j;
+        if (pj == pos && j > lane) later = true;
+    }
+    if (valid) {
+        pos16[(size_t)d * (size_t)B + (size_t)b] = (uint16_t)pos;
+        meta8[(size_t)d * (size_t)B + (size_t)b] = (uint8_t)prev | (later ? 0u : 0x80u);
+    }
+}
+}  // namespace
+
+hipError_t launch_build_chains(hipStream_t s, uint16_t *d_pos16, uint8_t *d_meta8, int32_t num_bins, int depth, int width) {
+    const int chunks = (num_bins + 63) / 64;
+    hipLaunchKernelGGL(k_build_chains, dim3((chunks + 3) / 4, depth), dim3(256), 0, s, d_pos16, d_meta8, num_bins, width);
+    return hipGetLastError();
+}
+
 }  // namespace hulk

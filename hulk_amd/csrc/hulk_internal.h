@@ -99,6 +99,7 @@ hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSe
                              uint64_t max_npos, MinimizerParams P, uint64_t *d_xs, uint8_t *d_valid, uint64_t *d_table,
                              uint64_t table_total, uint32_t *d_hists, unsigned long long *d_min_slots);
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb);
+hipError_t launch_build_chains(hipStream_t s, uint16_t *d_pos16, uint8_t *d_meta8, int32_t num_bins, int depth, int width);
 hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
                                unsigned long long *d_ctr, uint32_t *d_segsum, unsigned long long *d_base,
                                double *d_f64, float *d_rcp32, int depth, int width, size_t row_stride,
