@@ -205,26 +205,34 @@ def main():
 
     # synthetic reads, resident in HBM: this rank's slice of every interval of every step (hulk_amd.distributed.
     # interval_slice), so an N-rank run sketches the same global stream as ONE rank with interval = global_interval
-    n_buf = min(total_steps, 24)          # distinct steps kept in HBM (reused cyclically beyond that)
-    step_bases = []
-    for s_ in range(n_buf):
-        parts = []
-        for t in range(BATCH):
-            first, cnt = interval_slice(scaling, s_ * BATCH + t, INTERVAL, rank, world)
-            b, _ = synth.reads_torch(first, cnt, READ_LEN, device=device)
-            parts.append(b[:cnt * READ_LEN])
-        pad = torch.zeros(16, dtype=torch.uint8, device=device)
-        sbuf = torch.cat(parts + [pad])
-        if args.n_frac > 0:                   # one 'N' in a deterministic pseudo-random subset of the reads
-            idx = torch.arange(reads_per_rank_step, dtype=torch.int64, device=device)
-            hsh = ((idx + s_ * 1_000_003) * 0x9E3779B1) & 0xFFFFFFFF
-            sel = idx[(hsh.double() / 4294967296.0) < args.n_frac]
-            sbuf[sel * READ_LEN + (hsh[sel] >> 8) % READ_LEN] = ord("N")
-        step_bases.append(sbuf)
-    offsets = torch.arange(reads_per_rank_step + 1, dtype=torch.int64, device=device) * READ_LEN
+    def make_input(mode, max_buf):
+        """this rank's slice of every interval of every step under the scaling rule `mode`, resident in HBM"""
+        nb = min(total_steps, max_buf)        # distinct steps kept in HBM (reused cyclically beyond that)
+        per = interval_slice(mode, 0, INTERVAL, rank, world)[1]
+        bufs = []
+        for s_ in range(nb):
+            parts = []
+            for t in range(BATCH):
+                first, cnt = interval_slice(mode, s_ * BATCH + t, INTERVAL, rank, world)
+                b, _ = synth.reads_torch(first, cnt, READ_LEN, device=device)
+                parts.append(b[:cnt * READ_LEN])
+            pad = torch.zeros(16, dtype=torch.uint8, device=device)
+            sbuf = torch.cat(parts + [pad])
+            if args.n_frac > 0:                   # one 'N' in a deterministic pseudo-random subset of the reads
+                idx = torch.arange(per * BATCH, dtype=torch.int64, device=device)
+                hsh = ((idx + s_ * 1_000_003) * 0x9E3779B1) & 0xFFFFFFFF
+                sel = idx[(hsh.double() / 4294967296.0) < args.n_frac]
+                sbuf[sel * READ_LEN + (hsh[sel] >> 8) % READ_LEN] = ord("N")
+            bufs.append(sbuf)
+        offs = torch.arange(per * BATCH + 1, dtype=torch.int64, device=device) * READ_LEN
+        return bufs, offs, per
+
+    step_bases, offsets, _per = make_input(scaling, 24)
+    assert _per == per_interval
+    n_buf = len(step_bases)
     torch.cuda.synchronize()
 
-    def run_pass(prune):
+    def run_pass(prune, bufs=None, offs=None, per=None):
         """warm-up + the timed K steps on a fresh context; prune=False disables the exact bounds of the CWS stage
         (HULK_FLAG_NO_PRUNE), so that every interval streams the whole table like the reference does."""
         sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=local_rank,
@@ -233,11 +241,12 @@ def main():
         assert sk.batch_size == BATCH
         eng = GpuEngine(sk, device, n_spectra=BATCH)
         sh = ShardedSketcher(eng, S, rank, world if use_dist else 1, dist if use_dist else None)
+        if bufs is None:
+            bufs, offs, per = step_bases, offsets, per_interval
 
         def one_step(t):
-            b = step_bases[t % n_buf]
-            sk.bin_reads_device(b.data_ptr(), offsets.data_ptr(), reads_per_rank_step, READ_LEN, b.numel(),
-                                reads_per_spectrum=per_interval)
+            b = bufs[t % len(bufs)]
+            sk.bin_reads_device(b.data_ptr(), offs.data_ptr(), per * BATCH, READ_LEN, b.numel(), reads_per_spectrum=per)
             if use_dist:
                 h = eng.histogram_tensor()                 # view of the ring the reads were just binned into
                 coll_stream.wait_stream(stream)
@@ -313,6 +322,19 @@ def main():
     if full is not None and rank == 0:
         assert np.array_equal(full["mins"], mins) and np.array_equal(full["weights"], weights), "pruning changed the sketch"
     cold = run_cold() if (world == 1 and rank == 0 and not args.no_cold and not use_dist) else None
+    # N > 1: the same K steps under the OTHER scaling rule too (strong: the global interval is split over the ranks,
+    # SURVEY.md §8e, the headline; weak: every rank bins a whole interval of its own), so one driver run yields both
+    other = None
+    if use_dist and not args.single_pass and not args.no_prune:      # (world 1 only with --force-collective: a test of this path)
+        other_mode = "weak" if scaling == "strong" else "strong"
+        del step_bases[:]
+        torch.cuda.empty_cache()
+        ob, oo, oper = make_input(other_mode, 8)
+        op = run_pass(True, ob, oo, oper)
+        other_reads = steps * (INTERVAL if other_mode == "strong" else INTERVAL * world) * BATCH
+        other = {"scaling": other_mode, "value": other_reads / op["elapsed"], "ms_per_step": op["elapsed"] / steps * 1e3,
+                 "reads_per_rank_step": oper * BATCH}
+        del ob
 
     if rank == 0:
         total_reads = steps * reads_per_step
@@ -431,6 +453,8 @@ def main():
                                "value_over_model": value * model_bytes / 1e9 / (HBM_PEAK_GBS * world)}
         if cold is not None:
             out.update(cold)
+        if other is not None:
+            out["other_scaling"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]

@@ -43,6 +43,11 @@ def test_bench_json_contract_and_collective_path():
     b = _run(["--no-cpu-baseline", "--no-cold", "--force-collective"])
     assert b["sketch_md5"] == a["sketch_md5"]           # all-reduce over one rank is the identity
     assert b["rccl_ranks"] == 1                         # dist.get_world_size() on the nccl (= RCCL) backend
+    # with a collective the same steps are also timed under the other scaling rule (at one rank: the same work)
+    o = b["other_scaling"]
+    assert o["scaling"] == "weak" and o["reads_per_rank_step"] == b["config"]["reads_per_rank_step"]
+    assert 0.5 * b["value"] < o["value"] < 2.0 * b["value"]
+    assert "other_scaling" not in a
     # the real unpruned switch: the timed pass itself reads the whole table for every interval, same sketch
     c = _run(["--no-cpu-baseline", "--no-cold", "--no-prune"])
     assert c["sketch_md5"] == a["sketch_md5"]
