@@ -474,6 +474,10 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
         if (keys_per_part < 0) { const char *ek = getenv("HULK_NIB_KEYS"); keys_per_part = ek ? atoi(ek) : 131072; }
         uint32_t np = (uint32_t)((rps * 20 + (uint64_t)keys_per_part - 1) / (uint64_t)keys_per_part);
         if (np < 1) np = 1;
+        // short intervals (a rank's slice of a strong-scaling run): still ~128 workgroups, one per CU would leave half the chip idle
+        static int min_blocks = -1;
+        if (min_blocks < 0) { const char *em = getenv("HULK_NIB_MIN_BLOCKS"); min_blocks = em ? atoi(em) : 128; }
+        if (rps >= 4096 && (uint64_t)np * n_spectra * nr < (uint64_t)min_blocks) np = (uint32_t)(((uint64_t)min_blocks + (uint64_t)n_spectra * nr - 1) / ((uint64_t)n_spectra * nr));
         if (np > ml.nib_parts) np = ml.nib_parts;
         while (np > 1 && (uint64_t)np * n_spectra * nr > 2048) np--;
         const int words = ((std::min<int32_t>(P.num_bins, NIB_BINS) + 7) >> 3);
