@@ -139,6 +139,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--split", choices=("interval", "slice"), default="interval",
+                    help="how the strong rule shares a batch of intervals among N ranks: 'interval' = whole intervals "
+                         "(batch/N each, hulk_amd.distributed.batch_share), 'slice' = 1/N of every interval (SURVEY.md 8e); "
+                         "same global stream, same interval, same sketch")
     ap.add_argument("--no-prune", action="store_true",
                     help="the timed pass itself runs with the exact bounds of the CWS stage off (HULK_FLAG_NO_PRUNE): every "
                          "interval is evaluated against the whole table (profiling aid; implies --single-pass)")
@@ -167,7 +171,7 @@ def main():
     import torch.distributed as dist
     import hulk_amd
     from hulk_amd import _lib, synth
-    from hulk_amd.distributed import GpuEngine, ShardedSketcher, interval_slice, slot_shard
+    from hulk_amd.distributed import GpuEngine, ShardedSketcher, batch_share, interval_slice, slot_shard
 
     world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
     rank = int(os.environ.get("RANK", "0")) if launched else 0
@@ -190,8 +194,20 @@ def main():
     steps, warmup = args.steps, args.warmup
     total_steps = steps + warmup
     scaling = args.scaling
-    _, per_interval = interval_slice(scaling, 0, INTERVAL, rank, world)       # reads of an interval this rank bins
-    reads_per_rank_step = per_interval * BATCH
+    # mode = the scaling rule + (strong only) how a batch is shared: "strong-interval" | "strong" (slices) | "weak"
+    mode = scaling
+    if scaling == "strong" and args.split == "interval" and BATCH % world == 0:
+        mode = "strong-interval"
+
+    def share(m):
+        """(reads per spectrum, reads per step, first spectrum) of this rank under mode m"""
+        if m == "strong-interval":
+            _, n, first_spec = batch_share(0, BATCH, INTERVAL, rank, world)
+            return INTERVAL, n, first_spec
+        per = interval_slice(m, 0, INTERVAL, rank, world)[1]
+        return per, per * BATCH, 0
+
+    per_interval, reads_per_rank_step, first_spectrum = share(mode)
     global_interval = INTERVAL if scaling == "strong" else INTERVAL * world
     reads_per_step = global_interval * BATCH
     sb, sc = slot_shard(S, rank, world)
@@ -205,34 +221,38 @@ def main():
 
     # synthetic reads, resident in HBM: this rank's slice of every interval of every step (hulk_amd.distributed.
     # interval_slice), so an N-rank run sketches the same global stream as ONE rank with interval = global_interval
-    def make_input(mode, max_buf):
-        """this rank's slice of every interval of every step under the scaling rule `mode`, resident in HBM"""
+    def make_input(m, max_buf):
+        """this rank's share of every batch under mode `m`, resident in HBM: (buffers, offsets, reads per spectrum,
+        reads per step, first spectrum)"""
         nb = min(total_steps, max_buf)        # distinct steps kept in HBM (reused cyclically beyond that)
-        per = interval_slice(mode, 0, INTERVAL, rank, world)[1]
+        per, n_step, first_spec = share(m)
         bufs = []
         for s_ in range(nb):
             parts = []
-            for t in range(BATCH):
-                first, cnt = interval_slice(mode, s_ * BATCH + t, INTERVAL, rank, world)
+            if m == "strong-interval":
+                first, cnt, _ = batch_share(s_, BATCH, INTERVAL, rank, world)
                 b, _ = synth.reads_torch(first, cnt, READ_LEN, device=device)
                 parts.append(b[:cnt * READ_LEN])
+            else:
+                for t in range(BATCH):
+                    first, cnt = interval_slice(m, s_ * BATCH + t, INTERVAL, rank, world)
+                    b, _ = synth.reads_torch(first, cnt, READ_LEN, device=device)
+                    parts.append(b[:cnt * READ_LEN])
             pad = torch.zeros(16, dtype=torch.uint8, device=device)
             sbuf = torch.cat(parts + [pad])
             if args.n_frac > 0:                   # one 'N' in a deterministic pseudo-random subset of the reads
-                idx = torch.arange(per * BATCH, dtype=torch.int64, device=device)
+                idx = torch.arange(n_step, dtype=torch.int64, device=device)
                 hsh = ((idx + s_ * 1_000_003) * 0x9E3779B1) & 0xFFFFFFFF
                 sel = idx[(hsh.double() / 4294967296.0) < args.n_frac]
                 sbuf[sel * READ_LEN + (hsh[sel] >> 8) % READ_LEN] = ord("N")
             bufs.append(sbuf)
-        offs = torch.arange(per * BATCH + 1, dtype=torch.int64, device=device) * READ_LEN
-        return bufs, offs, per
+        offs = torch.arange(n_step + 1, dtype=torch.int64, device=device) * READ_LEN
+        return bufs, offs, per, n_step, first_spec
 
-    step_bases, offsets, _per = make_input(scaling, 24)
-    assert _per == per_interval
-    n_buf = len(step_bases)
+    main_input = make_input(mode, 24)
     torch.cuda.synchronize()
 
-    def run_pass(prune, bufs=None, offs=None, per=None):
+    def run_pass(prune, inp=None):
         """warm-up + the timed K steps on a fresh context; prune=False disables the exact bounds of the CWS stage
         (HULK_FLAG_NO_PRUNE), so that every interval streams the whole table like the reference does."""
         sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=local_rank,
@@ -241,12 +261,12 @@ def main():
         assert sk.batch_size == BATCH
         eng = GpuEngine(sk, device, n_spectra=BATCH)
         sh = ShardedSketcher(eng, S, rank, world if use_dist else 1, dist if use_dist else None)
-        if bufs is None:
-            bufs, offs, per = step_bases, offsets, per_interval
+        bufs, offs, per, n_step, first_spec = inp if inp is not None else main_input
 
         def one_step(t):
             b = bufs[t % len(bufs)]
-            sk.bin_reads_device(b.data_ptr(), offs.data_ptr(), per * BATCH, READ_LEN, b.numel(), reads_per_spectrum=per)
+            sk.bin_reads_device(b.data_ptr(), offs.data_ptr(), n_step, READ_LEN, b.numel(), reads_per_spectrum=per,
+                                first_spectrum=first_spec)
             if use_dist:
                 h = eng.histogram_tensor()                 # view of the ring the reads were just binned into
                 coll_stream.wait_stream(stream)
@@ -326,15 +346,21 @@ def main():
     # SURVEY.md §8e, the headline; weak: every rank bins a whole interval of its own), so one driver run yields both
     other = None
     if use_dist and not args.single_pass and not args.no_prune:      # (world 1 only with --force-collective: a test of this path)
-        other_mode = "weak" if scaling == "strong" else "strong"
-        del step_bases[:]
+        other = []
+        del main_input[0][:]
         torch.cuda.empty_cache()
-        ob, oo, oper = make_input(other_mode, 8)
-        op = run_pass(True, ob, oo, oper)
-        other_reads = steps * (INTERVAL if other_mode == "strong" else INTERVAL * world) * BATCH
-        other = {"scaling": other_mode, "value": other_reads / op["elapsed"], "ms_per_step": op["elapsed"] / steps * 1e3,
-                 "reads_per_rank_step": oper * BATCH}
-        del ob
+        for om in ("strong-interval", "strong", "weak"):
+            if om == mode or (om == "strong-interval" and BATCH % world):
+                continue
+            oin = make_input(om, 8)
+            op = run_pass(True, oin)
+            other_reads = steps * (INTERVAL * world if om == "weak" else INTERVAL) * BATCH
+            other.append({"mode": om, "scaling": "weak" if om == "weak" else "strong",
+                          "split": "interval" if om == "strong-interval" else "slice",
+                          "value": other_reads / op["elapsed"], "ms_per_step": op["elapsed"] / steps * 1e3,
+                          "reads_per_rank_step": oin[3]})
+            del oin[0][:]
+            torch.cuda.empty_cache()
 
     if rank == 0:
         total_reads = steps * reads_per_step
@@ -412,6 +438,7 @@ def main():
                                    + (f", VARIANT: {args.n_frac:g} of the reads carry one N" if args.n_frac > 0 else ""),
                        "reads_per_step": reads_per_step, "reads_per_rank_step": reads_per_rank_step,
                        "total_reads": total_reads, "intervals_per_step": BATCH, "global_interval": global_interval,
+                       "split": ("whole intervals per rank" if mode == "strong-interval" else "a slice of every interval per rank"),
                        "parallelism": f"read-shard x{world}, replicated count-min, slot-sharded CWS"},
             "rccl_ranks": rccl_ranks,
             "roofline": {"bound": "hbm", "kernel": "k_minimizer_fast", "achieved": k1_ach,

@@ -24,7 +24,7 @@ HULK_MAX_BINS = 1 << 20
 ABI_SYMBOLS = (
     "hulk_abi_version", "hulk_strerror", "hulk_last_error", "hulk_create", "hulk_destroy",
     "hulk_set_stream", "hulk_set_private_stream", "hulk_set_cws_tables", "hulk_add_reads", "hulk_add_reads_device",
-    "hulk_batch_size", "hulk_bin_reads_device", "hulk_histogram_device", "hulk_flush_batch", "hulk_flush_batch_after", "hulk_add_histogram", "hulk_flush",
+    "hulk_batch_size", "hulk_bin_reads_device", "hulk_bin_reads_device_at", "hulk_histogram_device", "hulk_flush_batch", "hulk_flush_batch_after", "hulk_add_histogram", "hulk_flush",
     "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
     "hulk_get_cws_tables", "hulk_smash", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
     "hulk_parse_files", "hulk_sketch_files", "hulk_get_scan_stats", "hulk_synchronize",
@@ -104,6 +104,7 @@ def load():
     L.hulk_add_reads.restype = ctypes.c_int; L.hulk_add_reads.argtypes = [vp, vp, vp, u64]
     L.hulk_add_reads_device.restype = ctypes.c_int; L.hulk_add_reads_device.argtypes = [vp, vp, vp, u64, u32, u64]
     L.hulk_bin_reads_device.restype = ctypes.c_int; L.hulk_bin_reads_device.argtypes = [vp, vp, vp, u64, u32, u64, u64]
+    L.hulk_bin_reads_device_at.restype = ctypes.c_int; L.hulk_bin_reads_device_at.argtypes = [vp, vp, vp, u64, u32, u64, u64, u32]
     L.hulk_batch_size.restype = u32; L.hulk_batch_size.argtypes = [vp]
     L.hulk_flush_batch.restype = ctypes.c_int; L.hulk_flush_batch.argtypes = [vp, u32]
     L.hulk_flush_batch_after.restype = ctypes.c_int; L.hulk_flush_batch_after.argtypes = [vp, u32, vp]

@@ -521,6 +521,9 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
     MinimizerParams P{};
     P.k = c->p.k; P.w = c->p.w; P.num_bins = c->B; P.bases_bytes = bases_bytes;
     P.interval = interval; P.fill = fill; P.ring_base = c->ring_base; P.ring_n = c->ring_n;
+    // whole intervals in front of this launch move the first spectrum, not the fill: the kernels then see a launch that
+    // starts inside spectrum ring_base (hist_slot() is unchanged by this) and build no empty spectra in front of it
+    if (P.interval && P.fill >= P.interval) { P.ring_base = (uint32_t)((P.ring_base + P.fill / P.interval) % P.ring_n); P.fill %= P.interval; }
     if (const char *e = getenv("HULK_K1_DEBUG")) P.debug = (uint32_t)atoi(e);
     { int rcw = ring_issue_own_flush(c); if (rcw != HULK_OK) return rcw; }
     uint32_t *hist = ring_hist(c);
@@ -913,25 +916,29 @@ int hulk_add_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d
     return HULK_OK;
 }
 
-int hulk_bin_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
-                          uint32_t max_read_len, uint64_t bases_bytes, uint64_t reads_per_spectrum) {
+int hulk_bin_reads_device_at(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
+                             uint32_t max_read_len, uint64_t bases_bytes, uint64_t reads_per_spectrum, uint32_t first_spectrum) {
     if (!c) return HULK_ERR_ARG;
     if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
     if (n && (!d_bases || !d_offsets)) return fail(c, HULK_ERR_ARG, "NULL buffer");
     if (c->ring_base != 0) return fail(c, HULK_ERR_STATE, "a partial interval is pending");
-    if (reads_per_spectrum && (n + reads_per_spectrum - 1) / reads_per_spectrum > c->T)
-        return fail(c, HULK_ERR_ARG, "more spectra than the batch size");
+    if (first_spectrum && !reads_per_spectrum) return fail(c, HULK_ERR_ARG, "first_spectrum needs reads_per_spectrum");
+    const uint64_t count = reads_per_spectrum ? (n + reads_per_spectrum - 1) / reads_per_spectrum : (n ? 1u : 0u);
+    if ((uint64_t)first_spectrum + count > c->T) return fail(c, HULK_ERR_ARG, "more spectra than the batch size");
+    const uint64_t skip = (uint64_t)first_spectrum * reads_per_spectrum;       // as if that many reads had been binned before
     for (uint64_t pos = 0; pos < n; pos += MAX_READS_PER_LAUNCH) {
         const uint64_t chunk = std::min<uint64_t>(MAX_READS_PER_LAUNCH, n - pos);
-        int rc = bin_reads(c, d_bases, d_offsets + pos, chunk, max_read_len, bases_bytes, reads_per_spectrum, pos);
+        int rc = bin_reads(c, d_bases, d_offsets + pos, chunk, max_read_len, bases_bytes, reads_per_spectrum, skip + pos);
         if (rc != HULK_OK) return rc;
     }
     c->seq_count += n;
-    {
-        const uint32_t filled = reads_per_spectrum ? (uint32_t)((n + reads_per_spectrum - 1) / reads_per_spectrum) : (n ? 1u : 0u);
-        if (filled > c->bin_spectra) c->bin_spectra = filled;
-    }
+    if (n && first_spectrum + (uint32_t)count > c->bin_spectra) c->bin_spectra = first_spectrum + (uint32_t)count;
     return HULK_OK;
+}
+
+int hulk_bin_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
+                          uint32_t max_read_len, uint64_t bases_bytes, uint64_t reads_per_spectrum) {
+    return hulk_bin_reads_device_at(c, d_bases, d_offsets, n, max_read_len, bases_bytes, reads_per_spectrum, 0);
 }
 
 int hulk_flush_batch(hulk_ctx *c, uint32_t count) {

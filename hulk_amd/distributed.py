@@ -44,6 +44,17 @@ def interval_slice(scaling: str, t: int, interval: int, rank: int, world: int):
     raise ValueError("scaling must be 'strong' or 'weak'")
 
 
+def batch_share(step: int, batch: int, interval: int, rank: int, world: int):
+    """The other way to split the SAME global stream with the SAME interval (so: the same sketch as "strong"): inside a
+    batch of `batch` consecutive intervals rank g bins the WHOLE intervals [g*batch/G, (g+1)*batch/G) — one contiguous
+    chunk of reads per batch, batch/G spectra to build instead of `batch` slices, and the all-reduce over the ring is a
+    gather.  Returns (first global read, number of reads, first spectrum of the batch); needs batch % world == 0."""
+    if batch % world:
+        raise ValueError("batch_share needs the batch size to be a multiple of the number of ranks")
+    per = batch // world
+    return (step * batch + rank * per) * interval, per * interval, rank * per
+
+
 class ShardedSketcher:
     """Drives one rank of a G-rank run.
 

@@ -126,10 +126,11 @@ class GpuSketcher:
                                                 max_read_len, bases_bytes))
 
     def bin_reads_device(self, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes,
-                         reads_per_spectrum=0):
-        """Multi-GPU step 1: bin this rank's reads, no interval rule (see hulk_hip.h)."""
-        self._chk(self._L.hulk_bin_reads_device(self._ctx, bases_ptr, offsets_ptr, n_reads,
-                                                max_read_len, bases_bytes, reads_per_spectrum))
+                         reads_per_spectrum=0, first_spectrum=0):
+        """Multi-GPU step 1: bin this rank's reads, no interval rule (see hulk_hip.h); first_spectrum: the spectrum of
+        the batch the first read belongs to (a rank that bins whole intervals of a batch)."""
+        self._chk(self._L.hulk_bin_reads_device_at(self._ctx, bases_ptr, offsets_ptr, n_reads,
+                                                   max_read_len, bases_bytes, reads_per_spectrum, first_spectrum))
 
     def flush_batch(self, n_spectra, after_stream=None):
         """Flush n_spectra spectra; with after_stream (a hipStream_t handle) the flush waits for that

@@ -180,6 +180,12 @@ uint32_t hulk_batch_size(const hulk_ctx *ctx);
 int hulk_bin_reads_device(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets,
                           uint64_t n_reads, uint32_t max_read_len, uint64_t bases_bytes,
                           uint64_t reads_per_spectrum);
+/* The same with the first read going to spectrum `first_spectrum` instead of 0 (needs reads_per_spectrum > 0): a rank
+ * that bins WHOLE intervals of a batch — intervals [first_spectrum, first_spectrum + n_reads / reads_per_spectrum) —
+ * while the other ranks bin the others; the all-reduce over the ring then is a gather (the other spectra are zero here). */
+int hulk_bin_reads_device_at(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets,
+                             uint64_t n_reads, uint32_t max_read_len, uint64_t bases_bytes,
+                             uint64_t reads_per_spectrum, uint32_t first_spectrum);
 uint32_t *hulk_histogram_device(hulk_ctx *ctx);
 int hulk_flush_batch(hulk_ctx *ctx, uint32_t n_spectra);
 /* Same, but the flush waits for the work queued so far on `dep_stream` (the stream the all-reduce

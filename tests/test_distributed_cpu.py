@@ -94,6 +94,21 @@ def test_interval_slices_partition_the_global_stream():
         interval_slice("sideways", 0, 10, 0, 1)
 
 
+def test_batch_shares_partition_a_batch_by_whole_intervals():
+    """batch_share: the ranks' chunks tile the `batch` intervals of a step in rank order, each a whole number of
+    intervals that starts at the spectrum it reports; a batch that does not divide among the ranks is refused."""
+    from hulk_amd.distributed import batch_share
+    I, batch = 100000, 16
+    for world in (1, 2, 4, 8, 16):
+        for step in (0, 3):
+            sh = [batch_share(step, batch, I, r, world) for r in range(world)]
+            assert sh[0][0] == step * batch * I and sum(n for _, n, _ in sh) == batch * I
+            assert all(a[0] + a[1] == b[0] for a, b in zip(sh, sh[1:]))
+            assert all(n % I == 0 and first == (step * batch + spec) * I for first, n, spec in sh)
+    with pytest.raises(ValueError):
+        batch_share(0, 16, I, 0, 3)
+
+
 def test_bench_refuses_more_gpus_than_visible():
     """`python bench.py --gpus N` without a launcher spawns the N ranks itself; it must never quietly time one GPU.
     Here (no GPU) it has to exit non-zero with a message and print no JSON line."""

@@ -727,3 +727,32 @@ def test_every_short_read_kernel_instance(k, w):
             assert np.array_equal(g.cms(), o.cms()), (lens, interval)
             assert_same_sketch(o, g)
             g.close(); o.close()
+
+
+def test_bin_reads_at_first_spectrum_any_order():
+    """hulk_bin_reads_device_at: the spectra of a batch filled by separate calls, out of order (what a rank that bins whole
+    intervals of a batch does for its own ones), then one flush of the batch — the sketch of the interval rule over the
+    same reads, and refusals for spectra past the batch."""
+    import torch
+    h = gpu()
+    k, w, S, I, L = 15, 9, 16, 700, 120
+    rng = np.random.default_rng(5)
+    seqs = random_reads(rng, 4 * I, L)
+    bases, offsets = pack_reads(seqs)
+    o = pyorc.Sketcher(k, w, S, 0, 1.0, I); o.add_reads(bases, offsets); o.finish()
+    g = h.GpuSketcher(k, w, S, interval=0)
+    db = torch.from_numpy(np.concatenate([bases, np.zeros(16, np.uint8)])).cuda()
+    for first_spec, n_spec in ((2, 2), (0, 1), (1, 1)):
+        lo = first_spec * I
+        off = torch.from_numpy((offsets[lo:lo + n_spec * I + 1]).astype(np.int64)).cuda()
+        g.bin_reads_device(db.data_ptr(), off.data_ptr(), n_spec * I, L, db.numel(), reads_per_spectrum=I, first_spectrum=first_spec)
+    with pytest.raises(h.HulkError):
+        g.bin_reads_device(db.data_ptr(), off.data_ptr(), I, L, db.numel(), reads_per_spectrum=I, first_spectrum=g.batch_size)
+    with pytest.raises(h.HulkError):
+        g.flush_batch(3)                                   # four spectra were filled
+    g.flush_batch(4)
+    g.finish()
+    assert g.counters()["n_minimizers"] == o.counters()["n_minimizers"]
+    assert np.array_equal(g.cms(), o.cms())
+    assert_same_sketch(o, g)
+    g.close(); o.close()

@@ -4,7 +4,9 @@ one device; the collective is the only thing swapped).  The gathered sketch must
 GPU run over the same global read stream, and the oracle:
   * "strong" (bench.py's default): each rank bins its half of every interval of I reads — the single-rank
     run has the SAME interval I (the reference's rule, pipeline/sketch.go:211-215);
-  * "weak": each rank bins I reads per interval — the single-rank run has interval 2 x I.
+  * "weak": each rank bins I reads per interval — the single-rank run has interval 2 x I;
+  * "strong-interval": the strong rule split the other way (distributed.batch_share): each rank bins WHOLE intervals of a
+    batch through hulk_bin_reads_device_at(first_spectrum), the all-reduce over the ring is a gather.
 The stream ends in a ragged tail (TAIL < BATCH intervals binned, then finish() without a flush_batch): the final flush
 must take every spectrum of the tail batch.
 """
@@ -31,7 +33,7 @@ def _worker(rank, world, port, q, overlap, scaling):
     os.environ["HULK_BATCH"] = str(BATCH)
     import hulk_amd
     from hulk_amd import synth
-    from hulk_amd.distributed import GpuEngine, ShardedSketcher, interval_slice, slot_shard
+    from hulk_amd.distributed import GpuEngine, ShardedSketcher, batch_share, interval_slice, slot_shard
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     stream = torch.cuda.Stream()
@@ -43,19 +45,30 @@ def _worker(rank, world, port, q, overlap, scaling):
     assert sk.batch_size == BATCH
     eng = GpuEngine(sk, "cuda:0", n_spectra=BATCH)
     sh = ShardedSketcher(eng, S, rank, world, dist)
-    per = interval_slice(scaling, 0, I, rank, world)[1]     # reads of an interval this rank bins
+    by_interval = scaling == "strong-interval"              # whole intervals of a batch per rank (distributed.batch_share)
+    per = I if by_interval else interval_slice(scaling, 0, I, rank, world)[1]     # reads of an interval this rank bins
     offsets = torch.arange(per * BATCH + 1, dtype=torch.int64, device="cuda:0") * L
     keep = []
     for s_ in range(STEPS + 1):
         nt = BATCH if s_ < STEPS else TAIL                  # the last batch is a ragged tail
         parts = []
-        for t in range(nt):
-            first, cnt = interval_slice(scaling, s_ * BATCH + t, I, rank, world)
+        first_spectrum = 0
+        if by_interval:
+            first, cnt, first_spectrum = batch_share(0, nt, I, rank, world)     # this rank's intervals of a batch of nt ...
+            first += s_ * BATCH * I                                             # ... that starts at interval s_ * BATCH
             b, _ = synth.reads_torch(first, cnt, L, device="cuda:0")
             parts.append(b[:cnt * L])
+            n_mine = cnt
+        else:
+            for t in range(nt):
+                first, cnt = interval_slice(scaling, s_ * BATCH + t, I, rank, world)
+                b, _ = synth.reads_torch(first, cnt, L, device="cuda:0")
+                parts.append(b[:cnt * L])
+            n_mine = per * nt
         bases = torch.cat(parts + [torch.zeros(16, dtype=torch.uint8, device="cuda:0")])
         keep.append(bases)
-        sk.bin_reads_device(bases.data_ptr(), offsets.data_ptr(), per * nt, L, bases.numel(), reads_per_spectrum=per)
+        sk.bin_reads_device(bases.data_ptr(), offsets.data_ptr(), n_mine, L, bases.numel(), reads_per_spectrum=per,
+                            first_spectrum=first_spectrum)
         h = eng.histogram_tensor()
         if s_ == STEPS:                                     # tail: all-reduce the whole view, then finish() flushes it
             torch.cuda.synchronize()
@@ -85,7 +98,8 @@ def _worker(rank, world, port, q, overlap, scaling):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,scaling", [(False, "weak"), (True, "weak"), (False, "strong"), (True, "strong")])
+@pytest.mark.parametrize("overlap,scaling", [(False, "weak"), (True, "weak"), (False, "strong"), (True, "strong"),
+                                             (False, "strong-interval"), (True, "strong-interval")])
 def test_two_ranks_one_gpu_match_single_rank(overlap, scaling):
     import torch
     import torch.multiprocessing as mp
@@ -106,7 +120,7 @@ def test_two_ranks_one_gpu_match_single_rank(overlap, scaling):
         p.join(timeout=60)
         assert p.exitcode == 0
     # single rank, same global stream: interval = I (strong: the reference's rule) or world * I (weak)
-    gi = I if scaling == "strong" else world * I
+    gi = world * I if scaling == "weak" else I
     total = (STEPS * BATCH + TAIL) * gi
     bases, offsets = synth.reads_numpy(0, total, L)
     g = hulk_amd.GpuSketcher(K, W, S, interval=gi)
