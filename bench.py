@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 K, W, S, READ_LEN, INTERVAL = 21, 9, 512, 150, 100_000
+NUM_BINS = K ** 4        # cmd/sketch.go:118
 BATCH = int(os.environ.get("HULK_BENCH_BATCH", "16"))   # sketching intervals per step (one pass over the CWS table)
 C2_READS = 10_000_000        # BASELINE configs[1]
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
@@ -247,10 +248,30 @@ def main():
                 sbuf[sel * READ_LEN + (hsh[sel] >> 8) % READ_LEN] = ord("N")
             bufs.append(sbuf)
         offs = torch.arange(n_step + 1, dtype=torch.int64, device=device) * READ_LEN
-        return bufs, offs, per, n_step, first_spec
+        return bufs, offs, per, n_step, first_spec, m
 
     main_input = make_input(mode, 24)
     torch.cuda.synchronize()
+
+    def inplace_gather_works():
+        """With whole intervals per rank the exchange is a gather: every rank owns BATCH/N consecutive spectra of the ring and
+        ncclAllGather runs in place on it (send buffer = the rank's slice of the receive buffer), half the traffic of the
+        all-reduce.  Checked once on a small tensor; all ranks agree on the verdict (all-reduce otherwise)."""
+        ok = False
+        try:
+            t = torch.full((world * 4,), -1, dtype=torch.int32, device=device)
+            t[rank * 4:(rank + 1) * 4] = rank
+            dist.all_gather_into_tensor(t, t[rank * 4:(rank + 1) * 4])
+            torch.cuda.synchronize()
+            want = torch.arange(world, dtype=torch.int32, device=device).repeat_interleave(4)
+            ok = bool(torch.equal(t, want))
+        except Exception as e:                      # noqa: BLE001 — any refusal means: use the all-reduce
+            sys.stderr.write(f"bench.py: in-place all-gather unavailable ({e}); using all-reduce\n")
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item())
+
+    use_gather = use_dist and not os.environ.get("HULK_BENCH_ALLREDUCE") and inplace_gather_works()
 
     def run_pass(prune, inp=None):
         """warm-up + the timed K steps on a fresh context; prune=False disables the exact bounds of the CWS stage
@@ -261,7 +282,9 @@ def main():
         assert sk.batch_size == BATCH
         eng = GpuEngine(sk, device, n_spectra=BATCH)
         sh = ShardedSketcher(eng, S, rank, world if use_dist else 1, dist if use_dist else None)
-        bufs, offs, per, n_step, first_spec = inp if inp is not None else main_input
+        bufs, offs, per, n_step, first_spec, in_mode = inp if inp is not None else main_input
+        own = (first_spec * NUM_BINS, (first_spec + BATCH // world) * NUM_BINS)      # this rank's spectra of the ring ("strong-interval")
+        gather = use_gather and in_mode == "strong-interval"
 
         def one_step(t):
             b = bufs[t % len(bufs)]
@@ -271,7 +294,10 @@ def main():
                 h = eng.histogram_tensor()                 # view of the ring the reads were just binned into
                 coll_stream.wait_stream(stream)
                 with torch.cuda.stream(coll_stream):
-                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    if gather:
+                        dist.all_gather_into_tensor(h, h[own[0]:own[1]])
+                    else:
+                        dist.all_reduce(h, op=dist.ReduceOp.SUM)
                 sk.flush_batch(BATCH, after_stream=coll_stream.cuda_stream)
             else:
                 sk.flush_batch(BATCH)
@@ -441,6 +467,8 @@ def main():
                        "split": ("whole intervals per rank" if mode == "strong-interval" else "a slice of every interval per rank"),
                        "parallelism": f"read-shard x{world}, replicated count-min, slot-sharded CWS"},
             "rccl_ranks": rccl_ranks,
+            "collective": (None if not use_dist else "all_gather in place over the ring (each rank owns BATCH/N spectra)"
+                           if (use_gather and mode == "strong-interval") else "all_reduce (sum) over the ring"),
             "roofline": {"bound": "hbm", "kernel": "k_minimizer_fast", "achieved": k1_ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_ach / HBM_PEAK_GBS,
                          "traffic": None, "traffic_from_profile": from_profile("k_minimizer_fast", "hbm_bytes_per_launch"),

@@ -43,14 +43,16 @@ def test_bench_json_contract_and_collective_path():
     b = _run(["--no-cpu-baseline", "--no-cold", "--force-collective"])
     assert b["sketch_md5"] == a["sketch_md5"]           # all-reduce over one rank is the identity
     assert b["rccl_ranks"] == 1                         # dist.get_world_size() on the nccl (= RCCL) backend
+    assert "all_gather" in b["collective"] and a["collective"] is None     # whole intervals per rank: the exchange is a gather
     # with a collective the same steps are also timed under the other scaling rule (at one rank: the same work)
     assert [o["mode"] for o in b["other_scaling"]] == ["strong", "weak"]      # the headline splits a batch by whole intervals
     for o in b["other_scaling"]:
         assert o["reads_per_rank_step"] == b["config"]["reads_per_rank_step"] and 0.5 * b["value"] < o["value"] < 2.0 * b["value"]
     assert "other_scaling" not in a
     # the slice split of SURVEY.md 8(e) as the headline: same stream, same interval, same sketch
-    f = _run(["--no-cpu-baseline", "--no-cold", "--single-pass", "--split", "slice"])
+    f = _run(["--no-cpu-baseline", "--no-cold", "--single-pass", "--split", "slice", "--force-collective"])
     assert f["sketch_md5"] == a["sketch_md5"] and "slice" in f["config"]["split"] and "whole" in a["config"]["split"]
+    assert "all_reduce" in f["collective"]
     # the real unpruned switch: the timed pass itself reads the whole table for every interval, same sketch
     c = _run(["--no-cpu-baseline", "--no-cold", "--no-prune"])
     assert c["sketch_md5"] == a["sketch_md5"]
