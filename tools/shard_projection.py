@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import torch
 import hulk_amd
 from hulk_amd import synth
-from hulk_amd.distributed import interval_slice, slot_shard
+from hulk_amd.distributed import GpuEngine, interval_slice, slot_shard
 
 K, W, S, INTERVAL, BATCH, READ_LEN = 21, 9, 512, 100_000, 16, 150
 
@@ -43,9 +43,17 @@ def run(world, steps, warmup=3, split="slice"):
     sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=0, slot_begin=sb, slot_count=sc,
                               stream=stream.cuda_stream)
 
+    eng = GpuEngine(sk, dev, n_spectra=BATCH)
+    own = BATCH // world
+
     def step(t):
         b = bufs[t % n_buf]
         sk.bin_reads_device(b.data_ptr(), offsets.data_ptr(), n_step, READ_LEN, b.numel(), reads_per_spectrum=per)
+        if split == "interval" and world > 1:
+            # what the gather would bring: the other ranks' spectra (copies of this rank's first one stand in for them), so
+            # that the flush sees BATCH non-empty spectra as it does in an N-rank run
+            h = eng.histogram_tensor().view(BATCH, -1)
+            h[own:] = h[0]                                    # (~10 us on the work stream; the real gather runs on its own)
         sk.flush_batch(BATCH)
     for t in range(warmup):
         step(t)
