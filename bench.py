@@ -360,8 +360,17 @@ def main():
         return {"value_cold": C2_READS / (t2 - t1), "cold_seconds": t2 - t1, "cold_create_seconds": t1 - t0,
                 "cold_reads": C2_READS, "cold_sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()}
 
+    # The first pass of a process measures ~7 % low whatever runs before it short of a pass itself (1.08 vs 1.00-1.01 ms per
+    # step, HULK_BENCH_REPEAT below; 40 untimed steps on a throwaway context do not help, a whole discarded pass does: the
+    # transient is worth ~1.5 ms at the start of the first context that is timed, profiled and finished).  So one pass is
+    # run and discarded before the timed ones; neither timed pass then depends on being the second.
+    run_pass(not args.no_prune)
     single = args.single_pass or args.no_prune
     full = run_pass(False) if not single else None
+    if os.environ.get("HULK_BENCH_REPEAT"):           # diagnosis: the same pass several times, ms per step of each on stderr
+        for i in range(int(os.environ["HULK_BENCH_REPEAT"])):
+            r = run_pass(not args.no_prune)
+            sys.stderr.write(f"repeat {i}: {r['elapsed'] / steps * 1e3:.4f} ms/step, k1a {r['prof']['k_minimizer_fast'][1] / max(r['prof']['k_minimizer_fast'][0], 1) * 1e3:.1f} us\n")
     main_pass = run_pass(not args.no_prune)
     elapsed, prof, counters = main_pass["elapsed"], main_pass["prof"], main_pass["counters"]
     mins, weights, tiles0, tiles1 = (main_pass[k] for k in ("mins", "weights", "tiles0", "tiles1"))
