@@ -13,12 +13,17 @@ runs on a second stream under the minimizer kernels of step n+1.  Default K=20 s
 N>1: one process per GPU over RCCL.  Launched by torch.distributed.run (RANK/WORLD_SIZE in the environment) this
 process is one rank; launched as plain `python bench.py --gpus N` it spawns the N ranks itself and relays their line.
   --scaling strong (default; SURVEY.md §8e, the reference's rule pipeline/sketch.go:211-215): the sketching interval
-      stays 100k reads of the GLOBAL stream; rank g bins reads [g*I/N, (g+1)*I/N) of every interval, ONE all-reduce
-      merges the 16 spectra of a step, count-min is replicated, the CWS update is slot-sharded.  The sketch is the
-      one a single GPU computes (same `sketch_md5`); total work is fixed as N grows.
+      stays 100k reads of the GLOBAL stream, count-min is replicated, the CWS update is slot-sharded.  The sketch is
+      the one a single GPU computes (same `sketch_md5`); total work is fixed as N grows.  How the 16 intervals of a step
+      are shared:  --split interval (default when 16 % N == 0): rank g bins the WHOLE intervals [16g/N, 16(g+1)/N) into
+      their spectra of the ring and ONE in-place all-gather completes it;  --split slice (§8e to the letter): rank g bins
+      reads [g*I/N, (g+1)*I/N) of every interval and ONE all-reduce sums the 16 spectra.
   --scaling weak: every rank bins 100k reads per interval, i.e. the global interval is N x 100k — fixed work per rank,
       but a different sketch than C2's.
+  At N > 1 the modes not used for the headline are timed too (`other_scaling`).
 
+Passes, in order: one discarded (the first pass of a process measures low), `value_unpruned`, the headline (W warm-up +
+K timed steps between barriers), at N = 1 `value_cold` and the CPU baseline, at N > 1 the other modes.
 Prints ONE JSON line on rank 0.
 """
 import argparse
