@@ -143,7 +143,7 @@ struct hulk_ctx {
     bool tables_ready = false, finished = false, hist_hook_used = false;
     int sticky = HULK_OK;
     std::string last_error;
-    bool profiling = false;
+    int profiling = 0;   /* bit 0 k_cws_scan, bit 1 k_minimizer_fast, bit 2 k_jump_bin (hulk_set_profiling) */
     std::vector<ProfileRec> prof;
 };
 
@@ -584,19 +584,19 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             c->ml.rcap = rcap; c->ml_regions = cap;
         }
         ProfileRec pr{}; pr.which = 1;
-        if (c->profiling) {
+        if ((c->profiling & 2)) {
             HIPCHK(c, hipEventCreate(&pr.a)); HIPCHK(c, hipEventCreate(&pr.b));
             HIPCHK(c, hipEventRecord(pr.a, c->stream));
         }
         HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->ml, c->d_state, c->d_min_slots));
-        if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
+        if ((c->profiling & 2)) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
         ProfileRec pj{}; pj.which = 2;
-        if (c->profiling) { HIPCHK(c, hipEventCreate(&pj.a)); HIPCHK(c, hipEventCreate(&pj.b)); }
+        if ((c->profiling & 4)) { HIPCHK(c, hipEventCreate(&pj.a)); HIPCHK(c, hipEventCreate(&pj.b)); }
         // (the minimizer and jump-hash kernels do not touch the spectra: only the histogram kernels behind them wait for
         // the flush that last read this ring)
         HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist, c->d_slow_list, c->d_slow_count, pj.a, pj.b,
                                         ring_write_event(c)));
-        if (c->profiling) c->prof.push_back(pj);
+        if ((c->profiling & 4)) c->prof.push_back(pj);
         pick_config(c->p.k, max_len, P, threads);      // (fast_ok implies max_len <= 256: always fits)
         // the list is normally empty or short; its length is only known on the device, so the grid is fixed: enough
         // workgroups that 1 % of deferred reads (reads with N) do not queue behind 512 waves (blocks past the list exit at once)
@@ -646,7 +646,7 @@ int issue_flush(hulk_ctx *c, hipEvent_t gate = nullptr) {
     }
     if (c->slots) {
         ProfileRec pr{};
-        if (c->profiling) {
+        if ((c->profiling & 1)) {
             HIPCHK(c, hipEventCreate(&pr.a)); HIPCHK(c, hipEventCreate(&pr.b));
             HIPCHK(c, hipEventRecord(pr.a, s));
         }
@@ -654,7 +654,7 @@ int issue_flush(hulk_ctx *c, hipEvent_t gate = nullptr) {
                                   c->row_stride, c->d_state, fb, c->prune ? c->d_kmin32 : nullptr, c->d_rext,
                                   c->d_weights, (int)c->slot_begin, c->d_visited, c->drift ? c->decay_weight : 0.0, c->d_scanmap));
         c->scan_tiles_total += (uint64_t)((c->slots + SCAN_ROWS - 1) / SCAN_ROWS) * (uint64_t)c->ntiles * 4u;
-        if (c->profiling) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
+        if ((c->profiling & 1)) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
         if (c->drift)
             HIPCHK(c, launch_cws_resolve_drift(s, c->d_rcb, c->d_f64, c->d_tilemin, c->d_mins, c->d_weights, (int)c->slots,
                                                (int)c->slot_begin, c->ntiles, c->decay_weight, c->d_slotmin, c->d_scanmap, c->d_state, fb));
@@ -1191,7 +1191,8 @@ int hulk_synchronize(hulk_ctx *c) {
 
 int hulk_set_profiling(hulk_ctx *c, int enabled) {
     if (!c) return HULK_ERR_ARG;
-    c->profiling = enabled != 0;
+    // 1 (the on/off switch) = every instrumented kernel; otherwise a mask: 2 k_minimizer_fast, 4 k_jump_bin, 8 k_cws_scan
+    c->profiling = enabled == 1 ? 7 : ((enabled & 6) | ((enabled & 8) ? 1 : 0));
     return HULK_OK;
 }
 

@@ -235,7 +235,9 @@ int hulk_selftest_reciprocal(hulk_ctx *ctx, uint64_t *mismatches);
 int hulk_get_scan_stats(hulk_ctx *ctx, uint64_t *tiles_visited, uint64_t *tiles_total);
 
 /* Per-kernel timing for bench.py: when enabled, hipEvents bracket every launch of the heavy kernels
- * ("k_minimizer_fast", "k_jump_bin" = k_jump_bin + k_jump_left, "k_cws_scan") on the stream they are launched on. */
+ * ("k_minimizer_fast", "k_jump_bin" = k_jump_bin + k_jump_left, "k_cws_scan") on the stream they are launched on.
+ * enabled: 0 off, 1 all three, otherwise a mask (2 k_minimizer_fast, 4 k_jump_bin, 8 k_cws_scan) — every bracketed
+ * launch costs the stream two event records (all three: ~3 % of a C2 step), so a timed run brackets what it reports. */
 int hulk_set_profiling(hulk_ctx *ctx, int enabled);
 /* Number of timed launches of `kernel` and their summed duration (synchronises; clears that log). */
 int hulk_get_profile(hulk_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);
