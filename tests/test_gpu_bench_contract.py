@@ -14,7 +14,7 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def _run(extra):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HULK_BENCH_PREWARM_S="0")   # (no need to warm the GPU for a contract test)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"] + extra,
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
