@@ -375,7 +375,16 @@ def main():
     # ... and PREWARM_S seconds of discarded passes on top: on a box whose GPU has been idle (a fresh lease) the first process
     # otherwise measures 2-4 % below the ones after it (1.025 vs 0.988 ms per step; with 3 s of load first: 1.000 vs 0.990)
     t_pw = time.perf_counter() + PREWARM_S
-    while time.perf_counter() < t_pw:
+
+    def more_prewarm():
+        go = time.perf_counter() < t_pw
+        if use_dist:                                   # every rank must run the same number of passes (they hold collectives)
+            f = torch.tensor([1 if go else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            go = bool(f.item())
+        return go
+
+    while more_prewarm():
         run_pass(not args.no_prune)
     single = args.single_pass or args.no_prune
     full = run_pass(False, brackets=2) if not single else None
