@@ -436,6 +436,11 @@ int ring_ready_for_writes(hulk_ctx *c) {
     return HULK_OK;
 }
 
+// The profile events only measure time (hulk_get_profile synchronises the streams before it reads them): without the
+// system-scope fence a default event carries, a bracket no longer writes back and invalidates the caches around the kernel
+// (k_minimizer_fast's bracket cost 2 % of a C2 step that way, mostly in the kernel behind it)
+constexpr unsigned PROFILE_EVENT_FLAGS = hipEventDisableSystemFence;
+
 int sync_all(hulk_ctx *c) {
     { const int rc = issue_flush(c, nullptr); if (rc != HULK_OK) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -585,13 +590,13 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
         }
         ProfileRec pr{}; pr.which = 1;
         if ((c->profiling & 2)) {
-            HIPCHK(c, hipEventCreate(&pr.a)); HIPCHK(c, hipEventCreate(&pr.b));
+            HIPCHK(c, hipEventCreateWithFlags(&pr.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pr.b, PROFILE_EVENT_FLAGS));
             HIPCHK(c, hipEventRecord(pr.a, c->stream));
         }
         HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->ml, c->d_state, c->d_min_slots));
         if ((c->profiling & 2)) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
         ProfileRec pj{}; pj.which = 2;
-        if ((c->profiling & 4)) { HIPCHK(c, hipEventCreate(&pj.a)); HIPCHK(c, hipEventCreate(&pj.b)); }
+        if ((c->profiling & 4)) { HIPCHK(c, hipEventCreateWithFlags(&pj.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pj.b, PROFILE_EVENT_FLAGS)); }
         // (the minimizer and jump-hash kernels do not touch the spectra: only the histogram kernels behind them wait for
         // the flush that last read this ring)
         HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist, c->d_slow_list, c->d_slow_count, pj.a, pj.b,
@@ -647,7 +652,7 @@ int issue_flush(hulk_ctx *c, hipEvent_t gate = nullptr) {
     if (c->slots) {
         ProfileRec pr{};
         if ((c->profiling & 1)) {
-            HIPCHK(c, hipEventCreate(&pr.a)); HIPCHK(c, hipEventCreate(&pr.b));
+            HIPCHK(c, hipEventCreateWithFlags(&pr.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pr.b, PROFILE_EVENT_FLAGS));
             HIPCHK(c, hipEventRecord(pr.a, s));
         }
         HIPCHK(c, launch_cws_scan(s, c->d_k32, c->d_rcp32, c->d_tilemin, (int)c->slots, c->ntiles,
