@@ -152,3 +152,17 @@ def test_khf_signature_layout_and_kmv_is_fatal(tmp_path):
     assert [a for a, _ in back.signatures] == ["histosketch", "khf"]
     with pytest.raises(ValueError, match="no sketch was generated by the kmv algorithm"):
         d.add(KMVSketch(21, 2))
+
+
+def test_cgo_binding_file_is_the_block_of_integration_md():
+    """tools/go/gpusketch/gpusketch.go (reviewable source, no Go toolchain here) = INTEGRATION.md's first Go block, and every
+    C.hulk_* it calls is an entry point the header declares."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    body = re.search(r"```go\n(.*?)\n```", doc, re.S).group(1)
+    src = open(os.path.join(root, "tools", "go", "gpusketch", "gpusketch.go")).read()
+    assert src.endswith(body + "\n")
+    header = open(os.path.join(root, "include", "hulk_hip.h")).read()
+    called = set(re.findall(r"C\.(hulk_[a-z_]+)\(", body))
+    assert called and all(re.search(r"\b%s\s*\(" % name, header) for name in called), called

@@ -1,0 +1,107 @@
+// The cgo binding a maintainer of will-rowe/hulk would add to call libhulkhip (include/hulk_hip.h) from src/pipeline:
+// reviewable source, NOT built or run in this repository (no Go toolchain in the image).  It is the first Go block of
+// INTEGRATION.md §2, word for word (tests/test_abi_and_host.py keeps the two identical).
+
+// Package gpusketch binds libhulkhip.so (include/hulk_hip.h).
+package gpusketch
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../third_party/hulk_hip/include
+#cgo LDFLAGS: -L${SRCDIR}/../../third_party/hulk_hip/lib -lhulkhip
+#include <stdlib.h>
+#include "hulk_hip.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"unsafe"
+)
+
+// Sketcher plays the role of theBoss + the Sketcher's HistoSketch for one run.
+type Sketcher struct {
+	ctx     *C.hulk_ctx
+	k, s    uint
+	bins    int32
+	bases   []byte   // batch staging: sequences are copied here (no Go pointer is retained by C)
+	offsets []uint64
+	batch   int
+}
+
+// New = findMinimizers (boss.go:54) + histosketch.NewHistoSketch (histosketch.go:50).
+func New(k, w, sketchSize uint, bins int32, decay float64, interval uint, device int) (*Sketcher, error) {
+	p := C.hulk_params{k: C.uint32_t(k), w: C.uint32_t(w), sketch_size: C.uint32_t(sketchSize),
+		num_bins: C.int32_t(bins), decay_ratio: C.double(decay), interval: C.uint32_t(interval),
+		device: C.int32_t(device)}
+	var ctx *C.hulk_ctx
+	if rc := C.hulk_create(&p, &ctx); rc != C.HULK_OK {
+		return nil, errors.New(C.GoString(C.hulk_last_error(nil))) // same text the reference logs
+	}
+	return &Sketcher{ctx: ctx, k: k, s: sketchSize, bins: bins, offsets: []uint64{0}, batch: 1 << 16}, nil
+}
+
+// AddSeq = theBoss.AddSeq (boss.go:24-26); sequences are batched before crossing into C.
+func (g *Sketcher) AddSeq(seq []byte) error {
+	g.bases = append(g.bases, seq...)
+	g.offsets = append(g.offsets, uint64(len(g.bases)))
+	if len(g.offsets) > g.batch {
+		return g.push()
+	}
+	return nil
+}
+
+func (g *Sketcher) push() error {
+	n := len(g.offsets) - 1
+	if n == 0 {
+		return nil
+	}
+	rc := C.hulk_add_reads(g.ctx, (*C.uint8_t)(unsafe.Pointer(&g.bases[0])),
+		(*C.uint64_t)(unsafe.Pointer(&g.offsets[0])), C.uint64_t(n))
+	g.bases, g.offsets = g.bases[:0], g.offsets[:1]
+	return g.err(rc)
+}
+
+// Flush = theBoss.Flush (boss.go:34-36).  With params.interval set, the library applies the
+// interval rule of sketch.go:211-215 itself and this is only needed for the final flush.
+func (g *Sketcher) Flush() error {
+	if err := g.push(); err != nil {
+		return err
+	}
+	return g.err(C.hulk_flush(g.ctx))
+}
+
+// StopWork = final Flush + theBoss.StopWork (sketch.go:219-224).
+func (g *Sketcher) StopWork() error {
+	if err := g.push(); err != nil {
+		return err
+	}
+	return g.err(C.hulk_finish(g.ctx))
+}
+
+// GetMinimizerCount = theBoss.GetMinimizerCount (boss.go:39-41).
+func (g *Sketcher) GetMinimizerCount() int {
+	var reads, mins, length C.uint64_t
+	C.hulk_get_counters(g.ctx, &reads, &mins, &length)
+	return int(mins)
+}
+
+// Sketch fills the exported fields sketchio needs (histosketch.go:40-41).
+func (g *Sketcher) Sketch() (mins []uint, weights []float64, err error) {
+	m := make([]uint64, g.s)
+	weights = make([]float64, g.s)
+	rc := C.hulk_get_sketch(g.ctx, (*C.uint64_t)(unsafe.Pointer(&m[0])), (*C.double)(unsafe.Pointer(&weights[0])))
+	mins = make([]uint, g.s)
+	for i, v := range m {
+		mins[i] = uint(v)
+	}
+	return mins, weights, g.err(rc)
+}
+
+func (g *Sketcher) Close() { C.hulk_destroy(g.ctx); g.ctx = nil }
+
+func (g *Sketcher) err(rc C.int) error {
+	if rc == C.HULK_OK {
+		return nil
+	}
+	return errors.New(C.GoString(C.hulk_last_error(g.ctx)))
+}
