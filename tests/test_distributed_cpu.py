@@ -142,3 +142,73 @@ def test_two_ranks_equal_single_process():
     for rank, mins, weights in outs:
         assert np.array_equal(mins, rm), f"rank {rank}"
         assert np.array_equal(weights, rw), f"rank {rank}"
+
+
+NB = 2          # batches of BatchOracleEngine.T intervals in the whole-interval test
+
+
+class BatchOracleEngine(OracleEngine):
+    """Test double of a batched engine (hulk_bin_reads_device_at): T spectra per exchange, a rank fills the ones it owns."""
+    T = 2
+
+    def __init__(self, rank, world):
+        super().__init__(rank, world)
+        self.hist = torch.zeros(self.T * K ** 4, dtype=torch.int32)
+
+    def bin_reads_at(self, bases, offsets, reads_per_spectrum, first_spectrum):
+        B = K ** 4
+        for i in range(len(offsets) - 1):
+            seq = bytes(bases[int(offsets[i]):int(offsets[i + 1])])
+            t = first_spectrum + i // reads_per_spectrum
+            for x in self.pyorc.minimizers(seq, K, W):
+                self.hist[t * B + self.pyorc.jump(int(x), B)] += 1
+
+    def flush(self):
+        B = K ** 4
+        for t in range(self.T):                         # the spectra of the batch, in interval order
+            self.o.add_histogram(self.hist[t * B:(t + 1) * B].numpy().astype(np.uint32))
+            self.o.flush()
+        self.hist.zero_()
+
+    def finish(self):
+        pass                                            # (every batch of this test is complete)
+
+
+def _worker_whole_intervals(rank, world, port, q):
+    from hulk_amd.distributed import batch_share
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = BatchOracleEngine(rank, world)
+    sh = ShardedSketcher(eng, S, rank, world, dist)
+    for step in range(NB):
+        first, cnt, first_spec = batch_share(step, eng.T, I, rank, world)    # whole intervals of the batch
+        bases, offsets = synth.reads_numpy(first, cnt, L)
+        eng.bin_reads_at(bases, offsets, I, first_spec)
+        sh.end_interval()                               # ONE all-reduce over the T spectra (a gather here), then the flush
+    sh.finish()
+    mins, weights = sh.gather_sketch()
+    q.put((rank, mins, weights))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_whole_intervals_equal_single_process():
+    """The strong rule shared by whole intervals (distributed.batch_share): rank g fills the spectra of ITS intervals of a
+    batch, one all-reduce over the batch's spectra gathers them, the flush takes them in interval order — the sketch of one
+    process with the same interval."""
+    from oracle import pyorc
+    ref = pyorc.Sketcher(K, W, S, 0, 1.0, I)
+    bases, offsets = synth.reads_numpy(0, NB * BatchOracleEngine.T * I, L)
+    ref.add_reads(bases, offsets); ref.finish()
+    rm, rw = ref.sketch()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_whole_intervals, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    outs = [q.get(timeout=240) for _ in range(world)]
+    for p in procs: p.join(60)
+    for rank, mins, weights in outs:
+        assert np.array_equal(mins, rm), f"rank {rank}"
+        assert np.array_equal(weights, rw), f"rank {rank}"
