@@ -4,7 +4,6 @@ Reference: cmd/smash.go:60-226 (parameter checks, CollectJSONs, makeMatrix), HUL
 (src/sketchio/sketchio.go:259-306), distances.GetDistance/GetWJD (src/distances/distances.go).
 The N x N x S comparison runs in libhulkhip (hulk_smash); this module only loads, orders and writes.
 """
-import ctypes
 import fnmatch
 import glob
 import os

@@ -1,7 +1,7 @@
 """PCIe-inclusive rate: reads handed over as HOST buffers through hulk_add_reads (pageable numpy)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, hulk_amd
+import hulk_amd
 from hulk_amd import synth
 n = 1_000_000
 sk = hulk_amd.GpuSketcher(21, 9, 512, interval=100_000)

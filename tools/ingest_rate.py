@@ -10,7 +10,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 from hulk_amd import ingest, synth
 
 ap = argparse.ArgumentParser()
