@@ -3,29 +3,37 @@
 
 Workload at N=1 (BASELINE configs[1], "C2"): synthetic 150 bp reads, k=21, w=9, sketchSize=512,
 interval=100k reads; reads are resident in HBM before the timed region.  One *step* = one batch of
-T=16 sketching intervals (1.6 M reads of the global stream): one launch chain bins the reads of the 16
+T=16 sketching intervals per rank (1.6 M reads): one launch chain bins the reads of the 16
 intervals into 16 k-mer spectra (minimizers -> jump hash -> spectrum), the spectra go through the
 count-min update, and ONE pass over the CWS table applies all 16 histosketch updates in interval order —
 bit-identical to flushing after every 100k reads (tests/test_gpu_parity.py).  The flush of step n
 runs on a second stream under the minimizer kernels of step n+1.  Default K=20 steps = 32 M reads
 (C2's 10 M reads = 6.25 steps; `value_cold` is C2 exactly as stated: 10 M reads, fresh context, no warm-up).
 
-N>1: one process per GPU over RCCL.  Launched by torch.distributed.run (RANK/WORLD_SIZE in the environment) this
-process is one rank; launched as plain `python bench.py --gpus N` it spawns the N ranks itself and relays their line.
-  --scaling strong (default; SURVEY.md §8e, the reference's rule pipeline/sketch.go:211-215): the sketching interval
-      stays 100k reads of the GLOBAL stream, count-min is replicated, the CWS update is slot-sharded.  The sketch is
-      the one a single GPU computes (same `sketch_md5`); total work is fixed as N grows.  How the 16 intervals of a step
-      are shared:  --split interval (default when 16 % N == 0): rank g bins the WHOLE intervals [16g/N, 16(g+1)/N) into
-      their spectra of the ring and ONE in-place all-gather completes it;  --split slice (§8e to the letter): rank g bins
-      reads [g*I/N, (g+1)*I/N) of every interval and ONE all-reduce sums the 16 spectra.
-  --scaling weak: every rank bins 100k reads per interval, i.e. the global interval is N x 100k — fixed work per rank,
-      but a different sketch than C2's.
-  At N > 1 the modes not used for the headline are timed too (`other_scaling`).
+N>1: one process per GPU; the exchange between the ranks is INSIDE libhulkhip.so (hulk_comm_init: RCCL over xGMI;
+hulk_step_sharded / hulk_step_sliced, include/hulk_hip.h) — torch.distributed only carries the rendezvous (the 128-byte
+RCCL id), the barriers around the timed region and the MAX over the ranks' clocks.  Launched by torch.distributed.run
+(RANK/WORLD_SIZE in the environment) this process is one rank; launched as plain `python bench.py --gpus N` it spawns the
+N ranks itself and relays their line.  The sketching interval is always 100k reads of the GLOBAL stream (the reference's
+rule, pipeline/sketch.go:211-215), so every mode but `sliced-weak` computes the sketch ONE GPU computes over the same stream:
+  sharded (headline): a step = N x 16 intervals of the global stream, rank g bins the WHOLE intervals [16g, 16g+16) of it
+      (1.6 M reads per rank per step at every N: `scaling` is "weak" in the driver's sense — the stream an N-rank run gets
+      through in K steps is N times longer — while the sketch stays the single-GPU one, `sketch_md5` of the same stream);
+      count-min is replicated, the CWS update slot-sharded; per step ONE all-gather: of the spectra while an element can
+      still change a weight (the first step), of the count-min increments (56 KB per interval) afterwards.
+  sliced-strong (SURVEY.md 8e to the letter): a step = 16 intervals, rank g bins reads [g*I/N, (g+1)*I/N) of every interval,
+      ONE all-reduce (uint32 sum) of the 16 spectra per step; total work fixed as N grows.
+  sliced-weak: every rank bins 100k reads per interval, i.e. the global interval is N x 100k — another sketch than C2's.
+  At N > 1 the modes not used for the headline are timed too (`other_scaling`), and `value_c4` is BASELINE configs[3]:
+  50 M reads per rank (400 M at N = 8) through the sharded steps on fresh contexts, ragged last step, the clock stopped
+  after the EOF gather of the sketch.
+HULK_BENCH_TRANSPORT=gloo (test aid): the ranks share GPU 0 and the library's HOST transport carries the exchange over gloo
+(RCCL refuses two ranks on one device) — same protocol, same kernels; tests/test_gpu_bench_contract.py runs world 2 this way.
 
 Passes, in order: discarded ones (the first pass of a process measures low, and a GPU fresh from idle for seconds: one
 pass + HULK_BENCH_PREWARM_S = 2 s of them), `value_unpruned`, the headline (W warm-up +
-K timed steps between barriers), at N = 1 `value_cold` and the CPU baseline, at N > 1 the other modes.
-Prints ONE JSON line on rank 0.
+K timed steps between barriers), at N = 1 `value_cold`, the end-to-end file figures and the CPU baseline, at N > 1 the other
+modes and `value_c4`.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import hashlib
@@ -47,6 +55,7 @@ NUM_BINS = K ** 4        # cmd/sketch.go:118
 PREWARM_S = float(os.environ.get("HULK_BENCH_PREWARM_S", "2"))   # seconds of discarded passes before the timed ones
 BATCH = int(os.environ.get("HULK_BENCH_BATCH", "16"))   # sketching intervals per step (one pass over the CWS table)
 C2_READS = 10_000_000        # BASELINE configs[1]
+C4_READS_PER_RANK = int(os.environ.get("HULK_BENCH_C4_READS_PER_RANK", "50000000"))   # BASELINE configs[3]: 400 M reads on 8 GPUs
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 SIMDS, CLOCK_GHZ, VALU_CYCLES = 256 * 4, 2.4, 2   # MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op issues over 2 cycles
 PMC_PROFILE = os.path.join("profiles", "r02_pmc.json")
@@ -126,7 +135,7 @@ def self_spawn(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) and relay their JSON line."""
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("HULK_BENCH_TRANSPORT") != "gloo":      # (gloo: test aid, the ranks share GPU 0)
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -141,16 +150,58 @@ def self_spawn(args):
     raise SystemExit(0)
 
 
+def e2e_file_rates(n_reads=2_000_000):
+    """End to end, FASTQ file -> sketch (the reference's DataStreamer/FastqHandler/AddSeq loop, pipeline/sketch.go:40-217,
+    in native code: hulk_sketch_files): a synthetic FASTQ of `n_reads` 150 bp reads on /dev/shm, plain and .gz, C2 parameters,
+    wall clock from the first byte read to hulk_finish, on a context whose tables exist (the second of two runs, so the
+    pinned staging is allocated too).  Host-bound (parse / inflate), reported beside the kernel-path figure, never as it."""
+    import gzip
+    import shutil
+    import tempfile
+    import hulk_amd
+    from hulk_amd import synth
+    d = tempfile.mkdtemp(prefix="hulk_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    out = {"reads": n_reads, "note": "hulk_sketch_files on a page-cached file, wall clock incl. parse, PCIe and hulk_finish"}
+    try:
+        plain = os.path.join(d, "reads.fq")
+        qual = b"I" * READ_LEN
+        with open(plain, "wb") as fh:
+            for first in range(0, n_reads, 100_000):
+                n = min(100_000, n_reads - first)
+                bases, _ = synth.reads_numpy(first, n, READ_LEN)
+                bb = bases[:n * READ_LEN].tobytes()
+                fh.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (first + i, bb[i * READ_LEN:(i + 1) * READ_LEN], qual) for i in range(n)))
+        gz = plain + ".gz"
+        with open(plain, "rb") as fi, gzip.open(gz, "wb", compresslevel=1) as fo:
+            shutil.copyfileobj(fi, fo, 1 << 24)
+        for label, path in (("plain", plain), ("gz", gz)):
+            best = None
+            for _ in range(2):
+                g = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL)
+                t0 = time.perf_counter()
+                st = g.sketch_files([path])
+                g.finish()
+                dt = time.perf_counter() - t0
+                mins, _ = g.sketch()
+                g.close()
+                assert st["n_seqs"] == n_reads
+                best = dt if best is None else min(best, dt)
+            out[label] = {"value": n_reads / best, "unit": "reads/s", "seconds": best, "file_bytes": os.path.getsize(path),
+                          "sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()}
+        assert out["plain"]["sketch_md5"] == out["gz"]["sketch_md5"]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
-    ap.add_argument("--split", choices=("interval", "slice"), default="interval",
-                    help="how the strong rule shares a batch of intervals among N ranks: 'interval' = whole intervals "
-                         "(batch/N each, hulk_amd.distributed.batch_share), 'slice' = 1/N of every interval (SURVEY.md 8e); "
-                         "same global stream, same interval, same sketch")
+    ap.add_argument("--mode", choices=("sharded", "sliced-strong", "sliced-weak"), default="sharded",
+                    help="N > 1: how the global stream is shared (see the module docstring); at N = 1 all three are the same "
+                         "work and the plain single-GPU calls are used unless --force-collective")
     ap.add_argument("--no-prune", action="store_true",
                     help="the timed pass itself runs with the exact bounds of the CWS stage off (HULK_FLAG_NO_PRUNE): every "
                          "interval is evaluated against the whole table (profiling aid; implies --single-pass)")
@@ -159,10 +210,15 @@ def main():
                          "data has such reads; they leave the table-free fast path of the minimizer kernel).  Not the headline.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the value_cold pass (C2 exactly: 10 M reads, no warm-up)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the FASTQ file -> sketch figures (N = 1 only)")
+    ap.add_argument("--no-c4", action="store_true", help="N > 1: skip value_c4 (50 M reads per rank on fresh contexts)")
     ap.add_argument("--single-pass", action="store_true",
                     help="skip the second timed pass (CWS-scan pruning disabled) that fills value_unpruned")
     ap.add_argument("--force-collective", action="store_true",
-                    help="run the all-reduce path even at world size 1 (test aid)")
+                    help="run the sharded-step path (RCCL communicator, exchange inside the library) even at world size 1 (test aid)")
+    ap.add_argument("--loopback", type=int, default=0, metavar="G",
+                    help="projection aid at N = 1: time rank 0's share of a G-rank sharded step on this GPU, the other ranks' "
+                         "contributions stood in for by copies of its own (hulk_comm_init_loopback); not a headline")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -179,7 +235,7 @@ def main():
     import torch.distributed as dist
     import hulk_amd
     from hulk_amd import _lib, synth
-    from hulk_amd.distributed import GpuEngine, ShardedSketcher, batch_share, interval_slice, slot_shard
+    from hulk_amd.distributed import gloo_exchange, interval_slice, num_steps, slot_shard, step_share
 
     world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
     rank = int(os.environ.get("RANK", "0")) if launched else 0
@@ -188,62 +244,66 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    transport = os.environ.get("HULK_BENCH_TRANSPORT", "rccl")         # "gloo": test aid, all ranks on GPU 0 (module docstring)
+    if transport not in ("rccl", "gloo"):
+        raise SystemExit("HULK_BENCH_TRANSPORT must be rccl or gloo")
+    dev_index = 0 if transport == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     use_dist = world > 1 or args.force_collective
+    loop_world = args.loopback if (args.loopback > 1 and world == 1) else 0
     rccl_ranks = 0
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
-        rccl_ranks = dist.get_world_size()
-        assert dist.get_backend() == "nccl" and rccl_ranks == world
+        if transport == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+            assert dist.get_backend() == "nccl"
+            rccl_ranks = dist.get_world_size()
+        assert dist.get_world_size() == world
+
+    def host_tensor(vals, dtype):
+        return torch.tensor(vals, dtype=dtype, device="cpu" if transport == "gloo" else device)
 
     steps, warmup = args.steps, args.warmup
     total_steps = steps + warmup
-    scaling = args.scaling
-    # mode = the scaling rule + (strong only) how a batch is shared: "strong-interval" | "strong" (slices) | "weak"
-    mode = scaling
-    if scaling == "strong" and args.split == "interval" and BATCH % world == 0:
-        mode = "strong-interval"
+    mode = args.mode
+    shard_world = loop_world or world                  # ranks a sharded step is laid out for
 
     def share(m):
-        """(reads per spectrum, reads per step, first spectrum) of this rank under mode m"""
-        if m == "strong-interval":
-            _, n, first_spec = batch_share(0, BATCH, INTERVAL, rank, world)
-            return INTERVAL, n, first_spec
-        per = interval_slice(m, 0, INTERVAL, rank, world)[1]
-        return per, per * BATCH, 0
+        """(reads per spectrum, reads of this rank per step, reads of the global stream per step) under mode m"""
+        if m == "sharded":
+            return INTERVAL, BATCH * INTERVAL, shard_world * BATCH * INTERVAL
+        sc_ = "strong" if m == "sliced-strong" else "weak"
+        per = interval_slice(sc_, 0, INTERVAL, rank, world)[1]
+        return per, per * BATCH, (INTERVAL if sc_ == "strong" else INTERVAL * world) * BATCH
 
-    per_interval, reads_per_rank_step, first_spectrum = share(mode)
-    global_interval = INTERVAL if scaling == "strong" else INTERVAL * world
-    reads_per_step = global_interval * BATCH
-    sb, sc = slot_shard(S, rank, world)
+    per_interval, reads_per_rank_step, reads_per_step = share(mode)
+    global_interval = INTERVAL * world if mode == "sliced-weak" else INTERVAL
+    sb, sc = slot_shard(S, rank if not loop_world else 0, shard_world)
 
     os.environ["HULK_BATCH"] = str(BATCH)
-    # work stream (minimizer kernels) and, for N > 1, a second stream for the collective: the all-reduce
-    # of step n and the flush behind it run under the minimizer kernels of step n+1
-    stream = torch.cuda.Stream(device=device)
-    coll_stream = torch.cuda.Stream(device=device) if use_dist else None
+    stream = torch.cuda.Stream(device=device)          # the work stream (the library flushes and exchanges on its own second one)
     torch.cuda.set_stream(stream)
 
-    # synthetic reads, resident in HBM: this rank's slice of every interval of every step (hulk_amd.distributed.
-    # interval_slice), so an N-rank run sketches the same global stream as ONE rank with interval = global_interval
     def make_input(m, max_buf):
-        """this rank's share of every batch under mode `m`, resident in HBM: (buffers, offsets, reads per spectrum,
-        reads per step, first spectrum)"""
+        """this rank's share of every step under mode `m`, resident in HBM: (buffers, offsets, reads per spectrum, reads per
+        step of this rank, mode) — `sharded`: its whole intervals of the step (distributed.step_share), `sliced-*`: its slice
+        of every interval (distributed.interval_slice) — so an N-rank run sketches the same global stream as ONE rank"""
         nb = min(total_steps, max_buf)        # distinct steps kept in HBM (reused cyclically beyond that)
-        per, n_step, first_spec = share(m)
+        per, n_step, _ = share(m)
         bufs = []
         for s_ in range(nb):
             parts = []
-            if m == "strong-interval":
-                first, cnt, _ = batch_share(s_, BATCH, INTERVAL, rank, world)
+            if m == "sharded":
+                first, cnt, _ = step_share(s_, BATCH, INTERVAL, rank, shard_world)
                 b, _ = synth.reads_torch(first, cnt, READ_LEN, device=device)
                 parts.append(b[:cnt * READ_LEN])
             else:
                 for t in range(BATCH):
-                    first, cnt = interval_slice(m, s_ * BATCH + t, INTERVAL, rank, world)
+                    first, cnt = interval_slice("strong" if m == "sliced-strong" else "weak", s_ * BATCH + t, INTERVAL, rank, world)
                     b, _ = synth.reads_torch(first, cnt, READ_LEN, device=device)
                     parts.append(b[:cnt * READ_LEN])
             pad = torch.zeros(16, dtype=torch.uint8, device=device)
@@ -255,58 +315,44 @@ def main():
                 sbuf[sel * READ_LEN + (hsh[sel] >> 8) % READ_LEN] = ord("N")
             bufs.append(sbuf)
         offs = torch.arange(n_step + 1, dtype=torch.int64, device=device) * READ_LEN
-        return bufs, offs, per, n_step, first_spec, m
+        return bufs, offs, per, n_step, m
 
     main_input = make_input(mode, 24)
     torch.cuda.synchronize()
 
-    def inplace_gather_works():
-        """With whole intervals per rank the exchange is a gather: every rank owns BATCH/N consecutive spectra of the ring and
-        ncclAllGather runs in place on it (send buffer = the rank's slice of the receive buffer), half the traffic of the
-        all-reduce.  Checked once on a small tensor; all ranks agree on the verdict (all-reduce otherwise)."""
-        ok = False
-        try:
-            t = torch.full((world * 4,), -1, dtype=torch.int32, device=device)
-            t[rank * 4:(rank + 1) * 4] = rank
-            dist.all_gather_into_tensor(t, t[rank * 4:(rank + 1) * 4])
-            torch.cuda.synchronize()
-            want = torch.arange(world, dtype=torch.int32, device=device).repeat_interleave(4)
-            ok = bool(torch.equal(t, want))
-        except Exception as e:                      # noqa: BLE001 — any refusal means: use the all-reduce
-            sys.stderr.write(f"bench.py: in-place all-gather unavailable ({e}); using all-reduce\n")
-        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
-        dist.all_reduce(f, op=dist.ReduceOp.MIN)
-        return bool(f.item())
-
-    use_gather = use_dist and not os.environ.get("HULK_BENCH_ALLREDUCE") and inplace_gather_works()
+    def connect(sk):
+        """the context's communicator: RCCL (rank 0's id travels over torch.distributed), the host transport over gloo
+        (test aid), or the loopback stand-in (--loopback)"""
+        if loop_world:
+            sk.comm_init_loopback(0, loop_world)
+        elif transport == "gloo":
+            sk.comm_init_host(rank, world, gloo_exchange(dist))
+        else:
+            ids = [hulk_amd.GpuSketcher.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            sk.comm_init(ids[0], rank, world)
 
     def run_pass(prune, inp=None, brackets=1):
         """warm-up + the timed K steps on a fresh context; prune=False disables the exact bounds of the CWS stage
         (HULK_FLAG_NO_PRUNE), so that every interval streams the whole table like the reference does."""
-        sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=local_rank,
+        bufs, offs, per, n_step, in_mode = inp if inp is not None else main_input
+        comm = use_dist or loop_world
+        sharded = comm and in_mode == "sharded"
+        sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL if sharded else 0, decay_ratio=1.0, device=dev_index,
                                   slot_begin=sb, slot_count=sc, stream=stream.cuda_stream,
                                   flags=0 if prune else _lib.HULK_FLAG_NO_PRUNE)
         assert sk.batch_size == BATCH
-        eng = GpuEngine(sk, device, n_spectra=BATCH)
-        sh = ShardedSketcher(eng, S, rank, world if use_dist else 1, dist if use_dist else None)
-        bufs, offs, per, n_step, first_spec, in_mode = inp if inp is not None else main_input
-        own = (first_spec * NUM_BINS, (first_spec + BATCH // world) * NUM_BINS)      # this rank's spectra of the ring ("strong-interval")
-        gather = use_gather and in_mode == "strong-interval"
+        if comm:
+            connect(sk)
 
         def one_step(t):
             b = bufs[t % len(bufs)]
-            sk.bin_reads_device(b.data_ptr(), offs.data_ptr(), n_step, READ_LEN, b.numel(), reads_per_spectrum=per,
-                                first_spectrum=first_spec)
-            if use_dist:
-                h = eng.histogram_tensor()                 # view of the ring the reads were just binned into
-                coll_stream.wait_stream(stream)
-                with torch.cuda.stream(coll_stream):
-                    if gather:
-                        dist.all_gather_into_tensor(h, h[own[0]:own[1]])
-                    else:
-                        dist.all_reduce(h, op=dist.ReduceOp.SUM)
-                sk.flush_batch(BATCH, after_stream=coll_stream.cuda_stream)
+            if sharded:
+                sk.step_sharded(b.data_ptr(), offs.data_ptr(), n_step, READ_LEN, b.numel(), shard_world * BATCH)
+            elif comm:
+                sk.step_sliced(b.data_ptr(), offs.data_ptr(), n_step, READ_LEN, b.numel(), per, BATCH)
             else:
+                sk.bin_reads_device(b.data_ptr(), offs.data_ptr(), n_step, READ_LEN, b.numel(), reads_per_spectrum=per)
                 sk.flush_batch(BATCH)
 
         for t in range(warmup):
@@ -328,18 +374,20 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         tiles1 = sk.scan_stats()
-        prof = {k: sk.get_profile(k) for k in ("k_cws_scan", "k_minimizer_fast", "k_jump_bin")}
+        prof = {k: sk.get_profile(k) for k in ("k_cws_scan", "k_minimizer_fast", "k_jump_bin", "k_jump_left")}
         sk.set_profiling(False)
         if use_dist:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            tt = host_tensor([elapsed], torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
 
         sk.finish()
         counters = sk.counters()
-        mins, weights = sh.gather_sketch() if (use_dist and world > 1) else sk.sketch()
+        mins, weights = sk.gather_sketch() if (comm and not loop_world) else sk.sketch()
+        cstats = sk.comm_stats() if comm else None
         sk.close()
-        return dict(elapsed=elapsed, prof=prof, counters=counters, mins=mins, weights=weights, tiles0=tiles0, tiles1=tiles1)
+        return dict(elapsed=elapsed, prof=prof, counters=counters, mins=mins, weights=weights, tiles0=tiles0, tiles1=tiles1,
+                    comm=cstats)
 
     def run_cold():
         """C2 exactly as BASELINE.json states it: 10 M reads, interval 100k, through the interval rule of
@@ -354,7 +402,7 @@ def main():
             chunks.append((b, off, n))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=local_rank, stream=stream.cuda_stream)
+        sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=dev_index, stream=stream.cuda_stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for b, off, n in chunks:
@@ -366,6 +414,47 @@ def main():
         sk.close()
         return {"value_cold": C2_READS / (t2 - t1), "cold_seconds": t2 - t1, "cold_create_seconds": t1 - t0,
                 "cold_reads": C2_READS, "cold_sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()}
+
+    def run_c4():
+        """BASELINE configs[3] ("C4"), scaled to the ranks present: C4_READS_PER_RANK (50 M) x N reads of the global stream
+        — 400 M at N = 8 — through hulk_step_sharded on FRESH contexts: no warm-up, the first step exchanges and evaluates
+        the spectra against the whole CWS table, the last step is ragged, and the clock stops after hulk_finish and the
+        EOF all-gather of the sketch (hulk_gather_sketch).  Context + communicator creation are timed separately."""
+        total = C4_READS_PER_RANK * world
+        ns = num_steps(total, BATCH, INTERVAL, world)
+        chunks = []
+        for s_ in range(ns):
+            first, n, si = step_share(s_, BATCH, INTERVAL, rank, world, total)
+            b, off = synth.reads_torch(first, max(n, 1), READ_LEN, device=device)
+            chunks.append((b, off, n, si))
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=dev_index, slot_begin=sb, slot_count=sc,
+                                  stream=stream.cuda_stream)
+        connect(sk)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for b, off, n, si in chunks:
+            sk.step_sharded(b.data_ptr(), off.data_ptr(), n, READ_LEN, b.numel(), si)
+        sk.finish()
+        mins, _ = sk.gather_sketch()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t2 = time.perf_counter()
+        tt = host_tensor([t2 - t1], torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        cs = sk.comm_stats()
+        sk.close()
+        del chunks
+        torch.cuda.empty_cache()
+        return {"value_c4": total / dt, "c4_seconds": dt, "c4_create_seconds": t1 - t0, "c4_reads": total, "c4_steps": ns,
+                "c4_workload": f"C4: {total} synthetic 150bp reads sharded by whole intervals over {world} rank(s), k=21, w=9, "
+                               f"sketchSize=512, interval={INTERVAL} of the global stream, fresh contexts, ragged last step, "
+                               "clock stopped after the EOF gather",
+                "c4_exchange": cs, "c4_sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()}
 
     # The first pass of a process measures ~7 % low whatever runs before it short of a pass itself (1.08 vs 1.00-1.01 ms per
     # step, HULK_BENCH_REPEAT below; 40 untimed steps on a throwaway context do not help, a whole discarded pass does: the
@@ -379,7 +468,7 @@ def main():
     def more_prewarm():
         go = time.perf_counter() < t_pw
         if use_dist:                                   # every rank must run the same number of passes (they hold collectives)
-            f = torch.tensor([1 if go else 0], dtype=torch.int32, device=device)
+            f = host_tensor([1 if go else 0], torch.int32)
             dist.all_reduce(f, op=dist.ReduceOp.MIN)
             go = bool(f.item())
         return go
@@ -393,37 +482,39 @@ def main():
             r = run_pass(not args.no_prune)
             sys.stderr.write(f"repeat {i}: {r['elapsed'] / steps * 1e3:.4f} ms/step, k1a {r['prof']['k_minimizer_fast'][1] / max(r['prof']['k_minimizer_fast'][0], 1) * 1e3:.1f} us\n")
     # The timed pass brackets only the dominant kernel (the launch durations the `roofline` object needs, measured over the
-    # timed region): every bracket costs the stream two event records — k_minimizer_fast's 2 % of a step, all three
-    # instrumented kernels 3.2 % (per-step timings in DESIGN.md §6).  The figures of the other two kernels come from
+    # timed region): every bracket costs the stream two event records — k_minimizer_fast's 2 % of a step, all
+    # instrumented kernels 3.2 % (per-step timings in DESIGN.md §6).  The figures of the other kernels come from
     # one more pass of the same steps, after the timed one.
     main_pass = run_pass(not args.no_prune, brackets=2)
     instr_pass = run_pass(not args.no_prune, brackets=1)
     elapsed, prof, counters = main_pass["elapsed"], main_pass["prof"], main_pass["counters"]
     mins, weights = main_pass["mins"], main_pass["weights"]
     tiles0, tiles1 = instr_pass["tiles0"], instr_pass["tiles1"]
-    prof = dict(prof, k_jump_bin=instr_pass["prof"]["k_jump_bin"], k_cws_scan=instr_pass["prof"]["k_cws_scan"])
+    prof = dict(prof, k_jump_bin=instr_pass["prof"]["k_jump_bin"], k_jump_left=instr_pass["prof"]["k_jump_left"],
+                k_cws_scan=instr_pass["prof"]["k_cws_scan"])
     if full is not None and rank == 0:
         assert np.array_equal(full["mins"], mins) and np.array_equal(full["weights"], weights), "pruning changed the sketch"
-    cold = run_cold() if (world == 1 and rank == 0 and not args.no_cold and not use_dist) else None
-    # N > 1: the same K steps under the OTHER scaling rule too (strong: the global interval is split over the ranks,
-    # SURVEY.md §8e, the headline; weak: every rank bins a whole interval of its own), so one driver run yields both
+    plain_single = world == 1 and rank == 0 and not use_dist and not loop_world
+    cold = run_cold() if (plain_single and not args.no_cold) else None
+    # N > 1: the same K steps under the other modes too, so one driver run yields all of them
     other = None
+    c4 = None
     if use_dist and not args.single_pass and not args.no_prune:      # (world 1 only with --force-collective: a test of this path)
         other = []
         del main_input[0][:]
         torch.cuda.empty_cache()
-        for om in ("strong-interval", "strong", "weak"):
-            if om == mode or (om == "strong-interval" and BATCH % world):
+        for om in ("sharded", "sliced-strong", "sliced-weak"):
+            if om == mode:
                 continue
             oin = make_input(om, 8)
             op = run_pass(True, oin, brackets=2)
-            other_reads = steps * (INTERVAL * world if om == "weak" else INTERVAL) * BATCH
-            other.append({"mode": om, "scaling": "weak" if om == "weak" else "strong",
-                          "split": "interval" if om == "strong-interval" else "slice",
-                          "value": other_reads / op["elapsed"], "ms_per_step": op["elapsed"] / steps * 1e3,
-                          "reads_per_rank_step": oin[3]})
+            other.append({"mode": om, "value": steps * share(om)[2] / op["elapsed"], "ms_per_step": op["elapsed"] / steps * 1e3,
+                          "reads_per_rank_step": oin[3], "reads_per_step": share(om)[2],
+                          "sketch_md5": hashlib.md5(op["mins"].astype("<u8").tobytes()).hexdigest(), "exchange": op["comm"]})
             del oin[0][:]
             torch.cuda.empty_cache()
+        if not args.no_c4:
+            c4 = run_c4()
 
     if rank == 0:
         total_reads = steps * reads_per_step
@@ -449,6 +540,18 @@ def main():
         k1_ach = k1_bytes / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
         n_kj, kj_ms = prof["k_jump_bin"]
         kj_avg_s = (kj_ms / 1e3) / max(n_kj, 1)
+        n_kl, kl_ms = prof["k_jump_left"]
+        kl_avg_s = (kl_ms / 1e3) / max(n_kl, 1)
+        longest = "k_minimizer_fast" if k1_avg_s >= kj_avg_s else "k_jump_bin"
+        scaling = "strong" if mode == "sliced-strong" else "weak"
+        comm_desc = None
+        if use_dist or loop_world:
+            how = ("loopback stand-in (no peers)" if loop_world else "RCCL (ncclAllGather / ncclAllReduce, bound by hulk_comm_init)"
+                   if transport == "rccl" else "host transport over gloo (test aid: all ranks on GPU 0)")
+            what = ("one all-gather per step: k-mer spectra while an element can still lower a weight, count-min increments after"
+                    if mode == "sharded" else "one all-reduce (uint32 sum) of the step's spectra")
+            comm_desc = {"inside": "libhulkhip.so (hulk_step_sharded / hulk_step_sliced)", "transport": how, "per_step": what,
+                         "timed_pass": main_pass["comm"]}
 
         def valu_roofline(kernel, avg_s):
             """VALU-issue roofline of a launch from the rocprofv3 PMC pass of this command (profiles/r02_pmc.json):
@@ -495,17 +598,23 @@ def main():
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "C2: synthetic 150bp reads, k=21, w=9, sketchSize=512, "
-                                   f"interval={global_interval} reads of the global stream ({per_interval} per rank), "
-                                   f"{BATCH} intervals per step, HBM-resident input"
+                                   f"interval={global_interval} reads of the global stream, "
+                                   f"{BATCH} intervals per rank and step ({reads_per_rank_step} reads; {reads_per_step} of the "
+                                   "global stream per step), HBM-resident input"
+                                   + (f", LOOPBACK: rank 0's share of a {loop_world}-rank sharded step, no peers" if loop_world else "")
                                    + (", CWS-scan bounds OFF (--no-prune)" if args.no_prune else "")
                                    + (f", VARIANT: {args.n_frac:g} of the reads carry one N" if args.n_frac > 0 else ""),
                        "reads_per_step": reads_per_step, "reads_per_rank_step": reads_per_rank_step,
                        "total_reads": total_reads, "intervals_per_step": BATCH, "global_interval": global_interval,
-                       "split": ("whole intervals per rank" if mode == "strong-interval" else "a slice of every interval per rank"),
+                       "mode": mode,
+                       "split": ("whole intervals per rank" if mode == "sharded" else "a slice of every interval per rank"),
                        "parallelism": f"read-shard x{world}, replicated count-min, slot-sharded CWS"},
+            "scaling_note": ("per-rank work per step is fixed (16 whole intervals = 1.6 M reads), the global interval stays the "
+                             "reference's 100k reads: the sketch is the single-GPU sketch of the same (N times longer) stream"
+                             if mode == "sharded" else "total work per step fixed" if mode == "sliced-strong" else
+                             "per-rank work fixed, global interval N x 100k: another sketch than C2's"),
             "rccl_ranks": rccl_ranks, "prewarm_seconds": PREWARM_S,
-            "collective": (None if not use_dist else "all_gather in place over the ring (each rank owns BATCH/N spectra)"
-                           if (use_gather and mode == "strong-interval") else "all_reduce (sum) over the ring"),
+            "collective": comm_desc,
             "roofline": {"bound": "hbm", "kernel": "k_minimizer_fast", "achieved": k1_ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_ach / HBM_PEAK_GBS,
                          "traffic": None, "traffic_from_profile": from_profile("k_minimizer_fast", "hbm_bytes_per_launch"),
@@ -513,13 +622,19 @@ def main():
                          "launches": int(n_k1), "avg_launch_us": k1_avg_s * 1e6,
                          "alg_bytes_per_launch": k1_bytes, "alg_bytes_per_read": READ_LEN + 8,
                          "intermediate_bytes": float(reads_per_rank_step) * 9.0 * per_read_min,
-                         "note": "dominant kernel by time; bound by VALU issue, not by HBM (see roofline_valu): its "
-                                 "fraction of the HBM peak is small by construction"},
+                         "longest_kernel": longest,
+                         "note": f"single kernels by measured time: k_minimizer_fast {k1_avg_s * 1e6:.1f} us, k_jump_bin "
+                                 f"{kj_avg_s * 1e6:.1f} us, k_jump_left {kl_avg_s * 1e6:.1f} us per launch (stage K1b = the last "
+                                 "two; it has no SURVEY 8(d) bytes — the minimizer list is an artefact of this implementation, "
+                                 "see intermediate_bytes).  Both stages are bound by VALU issue, not by HBM (roofline_valu, "
+                                 "roofline_valu_jump): the fraction of the HBM peak is small by construction"},
             "roofline_valu": valu_roofline("k_minimizer_fast", k1_avg_s),
             "roofline_valu_jump": valu_roofline("k_jump_bin", kj_avg_s),
             "k_jump_bin": {"launches": int(n_kj), "avg_launch_us": kj_avg_s * 1e6,
-                           "note": "k_jump_bin + k_jump_left: jump hash of the minimizer list, second by time; bracketed "
-                                   "in a separate pass of the same steps after the timed one (as k_cws_scan below)"},
+                           "note": "jump hash of the minimizer list, alone; bracketed in a separate pass of the same steps "
+                                   "after the timed one (as k_jump_left and k_cws_scan)"},
+            "k_jump_left": {"launches": int(n_kl), "avg_launch_us": kl_avg_s * 1e6,
+                            "note": "the chains k_jump_bin handed over (at most 10 lanes of a round still running)"},
             "roofline_cws_scan": {"bound": "hbm", "kernel": "k_cws_scan", "achieved": achieved,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                   "traffic": None, "traffic_from_profile": from_profile("k_cws_scan", "hbm_bytes_per_launch"),
@@ -548,6 +663,10 @@ def main():
             out.update(cold)
         if other is not None:
             out["other_scaling"] = other
+        if c4 is not None:
+            out.update(c4)
+        if plain_single and not args.no_e2e:
+            out["e2e"] = e2e_file_rates()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]

@@ -15,6 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhulkhip.so")
 
 HULK_OK = 0
+HULK_ABI_VERSION = 2            # include/hulk_hip.h; load() refuses a libhulkhip.so built from another version of the header
+HULK_UNIQUE_ID_BYTES = 128
+HULK_XCHG_ALLGATHER, HULK_XCHG_ALLREDUCE_U32 = 0, 1
 HULK_CWS_GO_COMPAT = 0
 HULK_CWS_EXTERNAL = 1
 HULK_FLAG_GAMMA_CPYTHON, HULK_FLAG_NO_PRUNE, HULK_FLAG_NO_SKIP = 1, 2, 4
@@ -28,6 +31,8 @@ ABI_SYMBOLS = (
     "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
     "hulk_get_cws_tables", "hulk_smash", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
     "hulk_parse_files", "hulk_sketch_files", "hulk_get_scan_stats", "hulk_synchronize",
+    "hulk_comm_unique_id", "hulk_comm_init", "hulk_comm_init_host", "hulk_comm_init_loopback", "hulk_step_sharded",
+    "hulk_step_sliced", "hulk_gather_sketch", "hulk_get_comm_stats",
 )
 
 
@@ -48,6 +53,8 @@ class IngestStats(ctypes.Structure):
 
 BATCH_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8),
                             ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64)
+# hulk_exchange_fn: (user, op, send, recv, bytes) -> 0 on success
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
 
 
 class HulkError(RuntimeError):
@@ -61,11 +68,47 @@ class HulkError(RuntimeError):
 _lib = None
 
 
+def _soname(path):
+    """DT_SONAME of an ELF shared object (None if it cannot be read)."""
+    import subprocess
+    try:
+        out = subprocess.run(["readelf", "-d", path], capture_output=True, text=True, timeout=20).stdout
+    except (OSError, subprocess.SubprocessError):
+        return None
+    for line in out.splitlines():
+        if "(SONAME)" in line and "[" in line:
+            return line.split("[", 1)[1].split("]", 1)[0]
+    return None
+
+
+def _needed(path, prefix):
+    import subprocess
+    try:
+        out = subprocess.run(["readelf", "-d", path], capture_output=True, text=True, timeout=20).stdout
+    except (OSError, subprocess.SubprocessError):
+        return None
+    for line in out.splitlines():
+        if "(NEEDED)" in line and "[" + prefix in line:
+            return line.split("[", 1)[1].split("]", 1)[0]
+    return None
+
+
+HIP_RUNTIME_BOUND = None        # which HIP runtime load() mapped first: "torch:<path>", "system" or "already loaded (torch)"
+
+
 def _preload_torch_hip_runtime():
-    """Map torch's bundled HIP runtime before libhulkhip.so pulls in /opt/rocm's (see the module docstring)."""
+    """Map torch's bundled HIP runtime before libhulkhip.so pulls in /opt/rocm's (see the module docstring).
+    HULK_NO_TORCH_PRELOAD=1 opts out; a bundled runtime whose SONAME is not the one libhulkhip.so was linked against
+    is left alone (both would end up loaded, and the second one sees no device) with a warning."""
+    global HIP_RUNTIME_BOUND
     import importlib.util
     import sys
+    import warnings
+    HIP_RUNTIME_BOUND = "system"
+    if os.environ.get("HULK_NO_TORCH_PRELOAD"):
+        return
     if "torch" in sys.modules:
+        HIP_RUNTIME_BOUND = "already loaded (torch)"
         return                                   # torch is loaded: its runtime already owns the SONAME
     try:
         spec = importlib.util.find_spec("torch")
@@ -75,8 +118,15 @@ def _preload_torch_hip_runtime():
         return
     path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
     if os.path.exists(path):
+        want, have = _needed(LIB_PATH, "libamdhip64"), _soname(path)
+        if want and have and want != have:
+            warnings.warn(f"hulk_amd: torch bundles HIP runtime {have} but libhulkhip.so is linked against {want}; not "
+                          "preloading it — import torch AFTER the first hulk_amd call will find no device "
+                          "(rebuild libhulkhip.so against torch's ROCm, or set HULK_NO_TORCH_PRELOAD=1 to silence)")
+            return
         try:
             ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            HIP_RUNTIME_BOUND = "torch:" + path
         except OSError as e:
             raise ImportError(f"torch is installed but its HIP runtime {path} does not load ({e}); importing torch "
                               "before hulk_amd is the work-around") from e
@@ -94,6 +144,9 @@ def load():
     L = ctypes.CDLL(LIB_PATH)
     vp, u64, u32, i32, dbl = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.c_double
     L.hulk_abi_version.restype = ctypes.c_int
+    if L.hulk_abi_version() != HULK_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} reports ABI version {L.hulk_abi_version()}, this binding is written for "
+                          f"{HULK_ABI_VERSION}: rebuild it (`make -C hulk_amd/csrc`)")
     L.hulk_strerror.restype = ctypes.c_char_p; L.hulk_strerror.argtypes = [ctypes.c_int]
     L.hulk_last_error.restype = ctypes.c_char_p; L.hulk_last_error.argtypes = [vp]
     L.hulk_create.restype = ctypes.c_int; L.hulk_create.argtypes = [ctypes.POINTER(HulkParams), ctypes.POINTER(vp)]
@@ -129,5 +182,13 @@ def load():
     L.hulk_sketch_files.restype = ctypes.c_int
     L.hulk_sketch_files.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), u32, ctypes.c_int, u32,
                                     ctypes.POINTER(IngestStats)]
+    L.hulk_comm_unique_id.restype = ctypes.c_int; L.hulk_comm_unique_id.argtypes = [vp]
+    L.hulk_comm_init.restype = ctypes.c_int; L.hulk_comm_init.argtypes = [vp, vp, u32, u32]
+    L.hulk_comm_init_host.restype = ctypes.c_int; L.hulk_comm_init_host.argtypes = [vp, u32, u32, EXCHANGE_FN, vp]
+    L.hulk_comm_init_loopback.restype = ctypes.c_int; L.hulk_comm_init_loopback.argtypes = [vp, u32, u32]
+    L.hulk_step_sharded.restype = ctypes.c_int; L.hulk_step_sharded.argtypes = [vp, vp, vp, u64, u32, u64, u32]
+    L.hulk_step_sliced.restype = ctypes.c_int; L.hulk_step_sliced.argtypes = [vp, vp, vp, u64, u32, u64, u64, u32]
+    L.hulk_gather_sketch.restype = ctypes.c_int; L.hulk_gather_sketch.argtypes = [vp, vp, vp]
+    L.hulk_get_comm_stats.restype = ctypes.c_int; L.hulk_get_comm_stats.argtypes = [vp, vp, vp, vp]
     _lib = L
     return L

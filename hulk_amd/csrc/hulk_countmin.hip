@@ -612,4 +612,104 @@ hipError_t launch_build_chains(hipStream_t s, uint16_t *d_pos16, uint8_t *d_meta
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// hulk_step_sharded, delta exchange.  In the steady state of a stream (no element of the step can lower any weight on
+// any rank: k_flush_decide's whole-batch bound, evaluated one step earlier) all a flush still changes is the count-min
+// counters (countmin.go:122-127), the element count and the 1 % rule (kmerspectrum.go:84-96) — then it wipes the spectra
+// (kmerspectrum.go:58-64).  A rank therefore reduces each of ITS intervals to the increments it causes:
+//   k_shard_local : workgroup (bin segment, interval): waves 0..6 add the segment's counts to their row's 2000 counters
+//                   in LDS (as k_cms_segsum), wave 7 counts the used bins; the workgroup adds its sums to the interval's
+//                   delta vector (consecutive addresses: coalesced atomics) and wipes the segment.  One pass, one launch.
+//   k_shard_apply : after the all-gather of every rank's {header, deltas}: thread per counter walks the intervals of the
+//                   step in stream order — rank 0's, rank 1's, ... — applies flush_go()'s rule to each and adds.
+// Unsigned integer sums: the counters equal those of the spectra exchange bit for bit.
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(512) void k_shard_local(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
+                                                     uint32_t *__restrict__ hdr, uint32_t *__restrict__ delta, int depth,
+                                                     int width, int seg_chunks, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *lctr = (uint32_t *)smem;                           // [depth][width]
+    const int seg = blockIdx.x, t = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;  // waves 0..depth-1: rows; wave depth: used bins
+    for (int i = tid; i < depth * width; i += blockDim.x) lctr[i] = 0;
+    __syncthreads();
+    const size_t B = (size_t)fb.num_bins;
+    uint32_t *hist = hists + (size_t)ring_slot(fb, t) * B;
+    const int64_t b0 = (int64_t)seg * seg_chunks * 64;
+    if (d < depth) {
+        const uint16_t *pd = pos16 + (size_t)d * B;
+        for (int c0 = 0; c0 < seg_chunks; c0 += 8) {              // 8 chunks of loads in flight
+            uint32_t h[8]; uint32_t p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int64_t b = b0 + (int64_t)(c0 + u) * 64 + lane;
+                const bool ok = (c0 + u < seg_chunks) && b < (int64_t)B;
+                h[u] = ok ? hist[b] : 0u; p[u] = ok ? pd[b] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (h[u]) atomicAdd(&lctr[d * width + p[u]], h[u]);
+        }
+    } else if (d == depth) {
+        unsigned cnt = 0;
+        for (int c0 = 0; c0 < seg_chunks; c0++) {
+            const int64_t b = b0 + (int64_t)c0 * 64 + lane;
+            if (b < (int64_t)B) cnt += hist[b] != 0;
+        }
+        for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (lane == 0 && cnt) atomicAdd(&hdr[2 + t], cnt);
+    }
+    __syncthreads();
+    uint32_t *out = delta + (size_t)t * depth * width;
+    for (int i = tid; i < depth * width; i += blockDim.x) { const uint32_t v = lctr[i]; if (v) atomicAdd(&out[i], v); }
+    const int64_t w1 = b0 + (int64_t)seg_chunks * 64;
+    for (int64_t b = b0 + tid; b < w1 && b < (int64_t)B; b += blockDim.x) hist[b] = 0;      // Wipe
+}
+
+__global__ __launch_bounds__(256) void k_shard_apply(const uint32_t *__restrict__ hdr_all, const uint32_t *__restrict__ delta_all,
+                                                     unsigned long long *__restrict__ ctr, int ncounters, uint32_t world,
+                                                     uint32_t T, uint32_t step_intervals, int32_t num_bins, DevState *st) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncounters) return;
+    unsigned long long run = ctr[i], elems = 0;
+    bool few = false;
+    for (uint32_t r = 0; r < world; r++) {
+        const uint32_t *h = hdr_all + (size_t)r * SHARD_HDR;
+        const uint32_t lo = r * T;                                             // rank r holds intervals [r*T, r*T + cnt) of the step
+        const uint32_t cnt = step_intervals <= lo ? 0u : (step_intervals - lo < T ? step_intervals - lo : T);
+        for (uint32_t t = 0; t < cnt; t++) {
+            const uint32_t used = h[2 + t];
+            if (used == 0) continue;                                           // boss.go:118: nothing to flush
+            if ((double)used / (double)num_bins < 0.01) { few = true; continue; }  // kmerspectrum.go:88-96 ("not used yet")
+            run += delta_all[((size_t)r * T + t) * (size_t)ncounters + i];
+            elems += used;
+        }
+    }
+    ctr[i] = run;
+    if (i == 0) {
+        if (few) set_error(st, -5);
+        if (elems) atomicAdd(&st->n_elements, elems);
+    }
+}
+}  // namespace
+
+hipError_t launch_shard_local(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, uint32_t *d_hdr, uint32_t *d_delta,
+                              int depth, int width, const FlushBatch &fb) {
+    if (fb.count == 0) return hipSuccess;
+    const int chunks = (fb.num_bins + 63) / 64;
+    const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
+    hipLaunchKernelGGL(k_shard_local, dim3(CMS_SEGS, fb.count), dim3(512), (size_t)depth * width * 4, s, d_hists, d_pos16, d_hdr,
+                       d_delta, depth, width, seg_chunks, fb);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_apply(hipStream_t s, const uint32_t *d_hdr_all, const uint32_t *d_delta_all, unsigned long long *d_ctr,
+                              int depth, int width, uint32_t world, uint32_t T, uint32_t step_intervals, int32_t num_bins,
+                              DevState *st) {
+    const int nc = depth * width;
+    hipLaunchKernelGGL(k_shard_apply, dim3((nc + 255) / 256), dim3(256), 0, s, d_hdr_all, d_delta_all, d_ctr, nc, world, T,
+                       step_intervals, num_bins, st);
+    return hipGetLastError();
+}
+
 }  // namespace hulk

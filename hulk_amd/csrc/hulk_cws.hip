@@ -63,7 +63,8 @@ __device__ __forceinline__ float wave_min8_by_row(float (&m)[8]) {
 __global__ __launch_bounds__(1024) void k_flush_decide(const unsigned long long *__restrict__ ctr, int ncounters,
                                                        const float *__restrict__ kminslot,
                                                        const double *__restrict__ weights, int slots, int slot_begin,
-                                                       DevState *st, FlushBatch fb, int enable) {
+                                                       DevState *st, FlushBatch fb, int enable,
+                                                       uint32_t *need_full) {
     __shared__ unsigned long long red[16];
     __shared__ int anypass;
     const int tid = threadIdx.x;
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(1024) void k_flush_decide(const unsigned long long 
     }
     if (pass) atomicOr(&anypass, 1);
     __syncthreads();
-    if (tid == 0) st->skip_exact[fb.parity] = anypass ? 0u : 1u;
+    // need_full: the verdict goes to a rank's exchange header instead (hulk_step_sharded: it governs the NEXT step)
+    if (tid == 0) { if (need_full) *need_full = anypass ? 1u : 0u; else st->skip_exact[fb.parity] = anypass ? 0u : 1u; }
 }
 __global__ __launch_bounds__(256) void k_slot_kmin(const float *__restrict__ kmin32, float *__restrict__ kminslot, int wtiles) {
     __shared__ float red[4];
@@ -770,9 +772,9 @@ hipError_t launch_slot_kmin(hipStream_t s, const float *d_kmin32, float *d_kmins
 
 hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, int ncounters, const float *d_kminslot,
                                const double *d_weights, int slots, int slot_begin, DevState *st, const FlushBatch &fb,
-                               int enable) {
+                               int enable, uint32_t *d_need_full) {
     hipLaunchKernelGGL(k_flush_decide, dim3(1), dim3(1024), 0, s, d_ctr, ncounters, d_kminslot, d_weights, slots,
-                       slot_begin, st, fb, enable);
+                       slot_begin, st, fb, enable, d_need_full);
     return hipGetLastError();
 }
 

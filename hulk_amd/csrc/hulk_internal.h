@@ -93,7 +93,8 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
 hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
                                  uint32_t *d_hists, uint32_t *d_slow_list, uint32_t *d_slow_count,
                                  hipEvent_t jump_begin = nullptr, hipEvent_t jump_end = nullptr,
-                                 hipEvent_t wait_before_spectra = nullptr);
+                                 hipEvent_t wait_before_spectra = nullptr, hipEvent_t left_begin = nullptr,
+                                 hipEvent_t left_end = nullptr);
 uint32_t minimizer_list_rcap(uint32_t w, bool pair);
 hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSeqDesc *d_desc, uint32_t n_seqs,
                              uint64_t max_npos, MinimizerParams P, uint64_t *d_xs, uint8_t *d_valid, uint64_t *d_table,
@@ -117,7 +118,15 @@ hipError_t launch_tile_kmin(hipStream_t s, const float *d_k32, float *d_kmin32, 
 hipError_t launch_slot_kmin(hipStream_t s, const float *d_kmin32, float *d_kminslot, int slots, int ntiles);
 hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, int ncounters, const float *d_kminslot,
                                const double *d_weights, int slots, int slot_begin, DevState *st, const FlushBatch &fb,
-                               int enable);
+                               int enable, uint32_t *d_need_full = nullptr);
+// hulk_step_sharded's delta exchange (hulk_countmin.hip): a rank's exchange block is SHARD_HDR header words
+// {-, need_full, used bins per interval ...} and [T][depth * width] count-min increments
+constexpr int SHARD_HDR = 32;
+hipError_t launch_shard_local(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, uint32_t *d_hdr, uint32_t *d_delta,
+                              int depth, int width, const FlushBatch &fb);
+hipError_t launch_shard_apply(hipStream_t s, const uint32_t *d_hdr_all, const uint32_t *d_delta_all, unsigned long long *d_ctr,
+                              int depth, int width, uint32_t world, uint32_t T, uint32_t step_intervals, int32_t num_bins,
+                              DevState *st);
 hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,
                               const float *d_tilemin, double *d_candA, int32_t *d_candB,
                               unsigned long long *d_mins, double *d_weights,

@@ -424,7 +424,7 @@ __global__ void k_add_hist(uint32_t *hist, const uint32_t *add, int32_t n) {
 // K1b: jump hash of the list (dense key array); K1c: spectrum ranges in LDS, merged without atomics
 hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParams P, const MinimizerList &ml,
                                  uint32_t *d_hists, uint32_t *d_slow_list, uint32_t *d_slow_count, hipEvent_t jump_begin,
-                                 hipEvent_t jump_end, hipEvent_t wait_before_spectra) {
+                                 hipEvent_t jump_end, hipEvent_t wait_before_spectra, hipEvent_t left_begin, hipEvent_t left_end) {
     if (n_reads == 0) return hipSuccess;
     hipError_t e = hipSuccess;
     const uint32_t n_regions = (uint32_t)((n_reads + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE);
@@ -441,10 +441,12 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     static int jump_cut = -1;
     if (jump_cut < 0) { const char *ec = getenv("HULK_JUMP_CUT"); jump_cut = ec ? atoi(ec) : 10; }
     const uint32_t cut = (jump_c || !ml.lo) ? 0u : (uint32_t)jump_cut;
-    if (jump_begin) { e = hipEventRecord(jump_begin, s); if (e != hipSuccess) return e; }      // bench.py: k_jump_bin + k_jump_left
+    if (jump_begin) { e = hipEventRecord(jump_begin, s); if (e != hipSuccess) return e; }      // bench.py: k_jump_bin alone ...
     hipLaunchKernelGGL(k_jump_bin, dim3((n_regions + 3) / 4), dim3(256), (size_t)jump_lds, s, ml, n_regions, P.num_bins, jump_c, cut);
-    if (cut) hipLaunchKernelGGL(k_jump_left, dim3((n_regions + 3) / 4), dim3(256), 0, s, ml, n_regions, P.num_bins);
     if (jump_end) { e = hipEventRecord(jump_end, s); if (e != hipSuccess) return e; }
+    if (left_begin) { e = hipEventRecord(left_begin, s); if (e != hipSuccess) return e; }      // ... and k_jump_left alone
+    if (cut) hipLaunchKernelGGL(k_jump_left, dim3((n_regions + 3) / 4), dim3(256), 0, s, ml, n_regions, P.num_bins);
+    if (left_end) { e = hipEventRecord(left_end, s); if (e != hipSuccess) return e; }
     // the kernels below write the spectra of the ring: the flush that last read them has to be done
     if (wait_before_spectra) { e = hipStreamWaitEvent(s, wait_before_spectra, 0); if (e != hipSuccess) return e; }
     const uint32_t n_spectra = P.interval ? (uint32_t)((P.fill + n_reads + P.interval - 1) / P.interval) : 1u;

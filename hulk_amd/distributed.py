@@ -1,17 +1,17 @@
-"""Multi-GPU sharding of the sketch path: one process per GPU.
+"""Multi-GPU sharding of the sketch path: one process per GPU, the exchange inside libhulkhip.so
+(include/hulk_hip.h: hulk_comm_init + hulk_step_sharded / hulk_step_sliced + hulk_gather_sketch; RCCL over xGMI, or a
+transport of the host).  This module is what a host needs besides those calls: which reads a rank takes, which sketch
+slots it owns, and — for hosts whose ranks are connected by torch.distributed rather than RCCL (the test suite: two ranks on
+one GPU over gloo) — the exchange function hulk_comm_init_host wants.
 
-Per interval t (global reads [tI, (t+1)I)):
-  1. rank g bins its contiguous slice [tI + gI/G, tI + (g+1)I/G) into a private uint32 histogram
-  2. ONE exchange: all-reduce(sum) of the histogram (k^4 uint32; RCCL over xGMI on GPUs) — every
-     rank needs every bin because count-min collisions couple bins.  Intervals are processed in
-     batches of T (hulk_batch_size): T spectra are merged by ONE all-reduce of T*k^4 uint32, which
-     turns T latency-bound 0.8 MB messages into one bandwidth-bound message
-  3. the count-min update is replicated (cheap, deterministic); the CWS update is slot-sharded:
-     rank g owns sketch slots [gS/G, (g+1)S/G) and only that slice of the CWS tables
-  4. at EOF one all-gather of the per-rank (mins, weights) slices
-
-The class is engine-agnostic: the product engine is `GpuSketcher` (libhulkhip); the CPU test
-suite drives the same logic with a test double over gloo (tests/test_distributed_cpu.py).
+The interval rule is the reference's throughout (pipeline/sketch.go:211-215: a flush every `interval` reads of the GLOBAL
+stream), so an N-rank run computes the sketch of ONE rank over the same stream:
+  * whole intervals per rank (hulk_step_sharded, `step_share`): step s covers the global intervals [s*G*T, (s+1)*G*T),
+    rank g bins [s*G*T + g*T, s*G*T + (g+1)*T) — one contiguous chunk of T*interval reads.  Count-min is replicated, the CWS
+    update is slot-sharded (`slot_shard`); per step ONE all-gather: of the k-mer spectra while an element can still change
+    a weight somewhere, of the count-min increments (7 x 2000 integers per interval) once none can;
+  * a slice of every interval per rank (hulk_step_sliced, `interval_slice`; SURVEY.md §8e to the letter): ONE all-reduce
+    (uint32 sum) of the T spectra of a step.
 """
 import numpy as np
 
@@ -45,99 +45,53 @@ def interval_slice(scaling: str, t: int, interval: int, rank: int, world: int):
 
 
 def batch_share(step: int, batch: int, interval: int, rank: int, world: int):
-    """The other way to split the SAME global stream with the SAME interval (so: the same sketch as "strong"): inside a
-    batch of `batch` consecutive intervals rank g bins the WHOLE intervals [g*batch/G, (g+1)*batch/G) — one contiguous
-    chunk of reads per batch, batch/G spectra to build instead of `batch` slices, and the all-reduce over the ring is a
-    gather.  Returns (first global read, number of reads, first spectrum of the batch); needs batch % world == 0."""
+    """Whole intervals of ONE batch of `batch` intervals shared among the ranks (hulk_bin_reads_device_at): rank g bins
+    the intervals [g*batch/G, (g+1)*batch/G) of batch `step`.  Returns (first global read, number of reads, first spectrum
+    of the batch); needs batch % world == 0.  (hulk_step_sharded gives every rank a whole batch instead: step_share.)"""
     if batch % world:
         raise ValueError("batch_share needs the batch size to be a multiple of the number of ranks")
     per = batch // world
     return (step * batch + rank * per) * interval, per * interval, rank * per
 
 
-class ShardedSketcher:
-    """Drives one rank of a G-rank run.
-
-    engine must provide: bin_reads(first_read_in_interval_slice...) is left to the caller; this
-    class needs only
-        engine.histogram_tensor() -> tensor viewing the engine's histogram (summed in place)
-        engine.flush()
-        engine.finish()
-        engine.sketch() -> (mins uint64[S], weights float64[S])  (own slots filled)
-    and a torch.distributed-like module `dist` (all_reduce, all_gather_object / all_gather).
-    """
-
-    def __init__(self, engine, sketch_size, rank, world, dist=None, group=None):
-        self.engine, self.S, self.rank, self.world = engine, sketch_size, rank, world
-        self.dist, self.group = dist, group
-        self.slot_begin, self.slot_count = slot_shard(sketch_size, rank, world)
-
-    def end_interval(self):
-        """Steps 2+3 for the interval whose reads the caller has just binned."""
-        if self.world > 1:
-            h = self.engine.histogram_tensor()
-            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
-        self.engine.flush()
-
-    def finish(self):
-        if self.world > 1:
-            h = self.engine.histogram_tensor()
-            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
-        self.engine.finish()
-
-    def gather_sketch(self):
-        """Step 4: full (mins, weights) on every rank."""
-        mins, weights = self.engine.sketch()
-        if self.world == 1:
-            return mins, weights
-        import torch
-        lo, n = self.slot_begin, self.slot_count
-        # fixed-size payload per rank: pad to the largest shard
-        cap = max(slot_shard(self.S, r, self.world)[1] for r in range(self.world))
-        pay = np.zeros(2 * cap, dtype=np.int64)
-        pay[:n] = mins[lo:lo + n].view(np.int64)
-        pay[cap:cap + n] = weights[lo:lo + n].view(np.int64)
-        t = torch.from_numpy(pay)
-        dev = getattr(self.engine, "collective_device", None)
-        if dev is not None:
-            t = t.to(dev)
-        outs = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(outs, t, group=self.group)
-        full_m = np.zeros(self.S, dtype=np.uint64)
-        full_w = np.zeros(self.S, dtype=np.float64)
-        for r, o in enumerate(outs):
-            b, c = slot_shard(self.S, r, self.world)
-            a = o.cpu().numpy()
-            full_m[b:b + c] = a[:c].view(np.uint64)
-            full_w[b:b + c] = a[cap:cap + c].view(np.float64)
-        return full_m, full_w
+def num_steps(total_reads: int, batch: int, interval: int, world: int) -> int:
+    """Steps of hulk_step_sharded a stream of `total_reads` reads takes (a step = world * batch intervals)."""
+    per_step = world * batch * interval
+    return (total_reads + per_step - 1) // per_step
 
 
-class GpuEngine:
-    """Adapter: GpuSketcher + a torch view of its device histogram for the collective."""
+def step_share(step: int, batch: int, interval: int, rank: int, world: int, total_reads=None):
+    """hulk_step_sharded's layout: step `step` covers the global intervals [step*G*T, (step+1)*G*T) (T = `batch` =
+    hulk_batch_size), rank g holds [step*G*T + g*T, step*G*T + (g+1)*T).  Returns (first global read, number of reads,
+    step_intervals): the rank's contiguous chunk and the number of intervals of the global stream in this step — the same
+    on every rank.  With `total_reads` the stream ends there: the last step is ragged (a rank may hold fewer intervals
+    or none, the stream's last interval may be partial — the reference's EOF flush, pipeline/sketch.go:219-221)."""
+    per_step = world * batch * interval
+    lo = step * per_step
+    hi = lo + per_step if total_reads is None else min(lo + per_step, total_reads)
+    if hi <= lo:
+        return lo, 0, 0
+    step_intervals = (hi - lo + interval - 1) // interval
+    first = min(lo + rank * batch * interval, hi)
+    last = min(first + batch * interval, hi)
+    return first, last - first, step_intervals
 
-    def __init__(self, sketcher, device, n_spectra=1):
-        import torch
-        self.sk = sketcher
-        self.collective_device = torch.device(device)
-        self.n_spectra = n_spectra          # spectra (intervals) merged per collective
-        self._views = {}                    # the library alternates between two spectrum rings
 
-    def histogram_tensor(self):
-        """torch view of the spectra the NEXT flush will consume (int32: counts < 2^31, sum bit-identical)."""
-        import torch
-        ptr = self.sk.histogram_device_ptr()
-        t = self._views.get(ptr)
-        if t is None:
-            nb = self.sk.num_bins * self.n_spectra
+def gloo_exchange(dist, group=None):
+    """The exchange function hulk_comm_init_host wants, over a torch.distributed process group on HOST tensors (gloo):
+    exchange(op, send, recv) with numpy uint8 views of the library's pinned staging."""
+    import torch
 
-            class _View:  # __cuda_array_interface__ v2
-                __cuda_array_interface__ = {"shape": (nb,), "typestr": "<i4", "data": (ptr, False),
-                                            "version": 2, "strides": None}
-            t = torch.as_tensor(_View(), device=self.collective_device)
-            self._views[ptr] = t
-        return t
-
-    def flush(self): self.sk.flush_batch(self.n_spectra)
-    def finish(self): self.sk.finish()
-    def sketch(self): return self.sk.sketch()
+    def exchange(op, send, recv):
+        if op == 0:                                           # HULK_XCHG_ALLGATHER: world * bytes, rank order
+            world = dist.get_world_size(group)
+            t = torch.from_numpy(send)
+            out = torch.from_numpy(recv)
+            dist.all_gather(list(out.view(world, -1).unbind(0)), t, group=group)
+        elif op == 1:                                         # HULK_XCHG_ALLREDUCE_U32: uint32 sum (int32 adds wrap alike)
+            t = torch.from_numpy(send.view(np.int32).copy())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            recv.view(np.int32)[:] = t.numpy()
+        else:
+            raise ValueError(f"unknown exchange op {op}")
+    return exchange

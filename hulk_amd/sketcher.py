@@ -140,6 +140,70 @@ class GpuSketcher:
         else:
             self._chk(self._L.hulk_flush_batch_after(self._ctx, n_spectra, ctypes.c_void_p(after_stream)))
 
+    # ---- multi-GPU: the exchange inside the library (include/hulk_hip.h)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId: called by one rank, handed to the others by the host."""
+        L = _lib.load()
+        buf = ctypes.create_string_buffer(_lib.HULK_UNIQUE_ID_BYTES)
+        rc = L.hulk_comm_unique_id(buf)
+        if rc != 0:
+            raise HulkError(rc, L.hulk_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """RCCL communicator of this rank (collective call)."""
+        if len(unique_id) != _lib.HULK_UNIQUE_ID_BYTES:
+            raise ValueError("unique_id must be HULK_UNIQUE_ID_BYTES long")
+        self._chk(self._L.hulk_comm_init(self._ctx, ctypes.c_char_p(unique_id), rank, world))
+        self.rank, self.world = rank, world
+
+    def comm_init_host(self, rank: int, world: int, exchange):
+        """The same protocol over a transport of the host: exchange(op, send: np.uint8[bytes], recv: np.uint8[...]) fills
+        `recv` (op 0: all-gather, world * bytes in rank order; op 1: uint32 sum, bytes)."""
+        def thunk(_user, op, send, recv, nbytes):
+            try:
+                n = int(nbytes)
+                s_ = np.ctypeslib.as_array(ctypes.cast(send, ctypes.POINTER(ctypes.c_uint8)), shape=(n,))
+                r_ = np.ctypeslib.as_array(ctypes.cast(recv, ctypes.POINTER(ctypes.c_uint8)),
+                                           shape=(n * world if op == _lib.HULK_XCHG_ALLGATHER else n,))
+                exchange(int(op), s_, r_)
+                return 0
+            except Exception as e:  # noqa: BLE001 — reported through the ABI's status code
+                import sys
+                sys.stderr.write(f"hulk_amd: exchange callback failed: {e!r}\n")
+                return 1
+        self._exchange_thunk = _lib.EXCHANGE_FN(thunk)           # keep the callback alive as long as the context
+        self._chk(self._L.hulk_comm_init_host(self._ctx, rank, world, self._exchange_thunk, None))
+        self.rank, self.world = rank, world
+
+    def comm_init_loopback(self, rank: int, world: int):
+        """Projection aid: one rank's share of a `world`-rank step on one GPU, no peers."""
+        self._chk(self._L.hulk_comm_init_loopback(self._ctx, rank, world))
+        self.rank, self.world = rank, world
+
+    def step_sharded(self, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes, step_intervals):
+        """One step of this rank: its whole intervals of the step -> exchange -> flush (hulk_step_sharded)."""
+        self._chk(self._L.hulk_step_sharded(self._ctx, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes,
+                                            step_intervals))
+
+    def step_sliced(self, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes, reads_per_spectrum, n_spectra):
+        """SURVEY.md 8(e) to the letter: a slice of every interval per rank, one all-reduce of the spectra, flush."""
+        self._chk(self._L.hulk_step_sliced(self._ctx, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes,
+                                           reads_per_spectrum, n_spectra))
+
+    def gather_sketch(self):
+        """(mins, weights) of the whole sketch on every rank."""
+        mins = np.zeros(self.sketch_size, dtype=np.uint64)
+        weights = np.zeros(self.sketch_size, dtype=np.float64)
+        self._chk(self._L.hulk_gather_sketch(self._ctx, mins.ctypes.data, weights.ctypes.data))
+        return mins, weights
+
+    def comm_stats(self):
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._chk(self._L.hulk_get_comm_stats(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"steps_delta": a.value, "steps_full": b.value, "bytes_received": c.value}
+
     @property
     def batch_size(self):
         return self._L.hulk_batch_size(self._ctx)

@@ -28,6 +28,9 @@
  *   DataStreamer.Run + FastqHandler.Run (lines -> reads)          hulk_parse_files (host only),
  *       src/pipeline/sketch.go:40-79, 99-161; seqio.go:38-40        hulk_sketch_files (+ the AddSeq
  *                                                                   loop of sketch.go:196-217)
+ *   SeqMinimizer.Run's AddSeq / Flush loop when the read stream   hulk_comm_init + hulk_step_sharded
+ *       is sharded over several GPUs                                (+ hulk_gather_sketch for
+ *       src/pipeline/sketch.go:182-250, boss.go:24-41               Sketcher.Run's result, sketch.go:271-301)
  *
  * Conventions: every call returns HULK_OK (0) or a negative HULK_ERR_*; the message the
  * reference would have passed to log.Fatalf("ERROR---> %v") is available from
@@ -46,7 +49,9 @@
 extern "C" {
 #endif
 
-#define HULK_ABI_VERSION 1
+/* 2: hulk_params.reserved[0] became `flags` (unknown bits are refused), hulk_set_profiling takes a mask, the multi-GPU
+ * entry points (hulk_comm_*, hulk_step_*, hulk_gather_sketch).  Bindings compare it with the value they were written for. */
+#define HULK_ABI_VERSION 2
 
 #define HULK_OK 0
 #define HULK_ERR_W (-1)          /* "w must be: 0 < w < 257"                  minimizer.go:63 */
@@ -68,6 +73,7 @@ extern "C" {
 #define HULK_ERR_STATE (-34)     /* call not valid in this state (e.g. add after finish) */
 #define HULK_ERR_IO (-35)        /* open/read/gzip failure; the message is the one Go's os/gzip error carries */
 #define HULK_ERR_FASTA_HEADER (-36) /* --fasta input without any '>' line (the reference panics on l1[0] = 64, sketch.go:127) */
+#define HULK_ERR_COMM (-37)      /* RCCL (or the host's exchange function) failed; hulk_last_error has the detail */
 
 /* How the CWS parameter matrices r, c, b (histosketch.go:95-126) are produced. */
 #define HULK_CWS_GO_COMPAT 0     /* go_rng Gamma/Uniform over Go math/rand, seed 1 (default) */
@@ -194,6 +200,60 @@ int hulk_flush_batch(hulk_ctx *ctx, uint32_t n_spectra);
  * (event / wait_stream) before the collective. */
 int hulk_flush_batch_after(hulk_ctx *ctx, uint32_t n_spectra, void *dep_stream);
 
+/* ---- multi-GPU with the exchange INSIDE the library (one context = one rank = one GPU) -------------------------
+ * The seam is still SeqMinimizer.Run (src/pipeline/sketch.go:182-250) driving theBoss (boss.go:24-41): a host that
+ * shards the read stream over G processes calls hulk_comm_init once and then hulk_step_sharded instead of
+ * hulk_add_reads_device; the interval rule stays the reference's (a flush every `interval` reads of the GLOBAL stream,
+ * sketch.go:211-215) and the sketch is the one a single GPU computes over the same stream.
+ *
+ * Step s of a G-rank run covers the global sketching intervals [s*G*T, (s+1)*G*T), T = hulk_batch_size(); rank g owns
+ * the WHOLE intervals [s*G*T + g*T, s*G*T + (g+1)*T) — one contiguous chunk of T*interval reads — and the sketch
+ * slots [slot_begin, slot_begin + slot_count) given at hulk_create (count-min is replicated, the CWS update is
+ * slot-sharded).  Per step the library picks one of two exact exchanges on its flush stream:
+ *   full   (the first step of a stream, concept drift / decay, or while any rank's whole-step bound says an element
+ *           could still lower one of its slots' weights): all-gather of the G*T k-mer spectra, then the ordinary flush
+ *           of every rank's T intervals in stream order on every rank;
+ *   delta  (steady state: count-min counters only grow and AddElement only replaces a weight by a smaller one,
+ *           countmin.go:103-138, histosketch.go:139-153, so once every rank's bound min_row(K)/min(counter) cannot get
+ *           below any of its weights, no element can change the sketch): each rank reduces ITS intervals to the
+ *           count-min increments they cause (7 x 2000 integers per interval) and their used-bin counts (the 1 % rule,
+ *           kmerspectrum.go:84-96), ONE all-gather of those (G*T*56 KB instead of G*T*k^4*4 B), every rank adds them in
+ *           stream order.  The bound is evaluated at the start of step s on every rank and travels with step s's
+ *           exchange; it governs step s+1 (counters and weights are monotone, so a bound that held one step earlier
+ *           still holds).  Integer sums: bit-identical to the full exchange (tested on both paths).
+ * The last step of a stream may be ragged: `step_intervals` (the same value on every rank) is the number of intervals
+ * of the global stream in this step, rank g holds min(T, max(0, step_intervals - g*T)) of them and the last one may
+ * be partial (the reference's EOF flush, sketch.go:219-221).  hulk_finish afterwards only synchronises. */
+#define HULK_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId: called by ONE rank; the host hands the 128 bytes to the other ranks over any channel it has. */
+int hulk_comm_unique_id(void *unique_id);
+/* ncclCommInitRank (RCCL over xGMI; librccl.so.1 is bound when this is first called).  Collective call. */
+int hulk_comm_init(hulk_ctx *ctx, const void *unique_id, uint32_t rank, uint32_t world);
+/* The same protocol over a transport the HOST provides (hosts without RCCL between their ranks; the test suite runs two
+ * ranks on one GPU this way, which RCCL refuses): the library stages the buffers through pinned host memory and calls
+ * `fn` synchronously.  op HULK_XCHG_ALLGATHER: send = this rank's `bytes`, recv = world * bytes, rank order;
+ * op HULK_XCHG_ALLREDUCE_U32: element-wise uint32 sum of `bytes` / 4 words over the ranks, send -> recv. */
+#define HULK_XCHG_ALLGATHER 0
+#define HULK_XCHG_ALLREDUCE_U32 1
+typedef int (*hulk_exchange_fn)(void *user, int op, const void *send, void *recv, uint64_t bytes);
+int hulk_comm_init_host(hulk_ctx *ctx, uint32_t rank, uint32_t world, hulk_exchange_fn fn, void *user);
+/* Projection aid (tools/shard_projection.py): no peer at all — the other ranks' contributions to an all-gather are
+ * copies of this rank's own, an all-reduce is the identity.  One GPU then runs exactly one rank's share of a G-rank
+ * step, which bounds the G-GPU rate from above. */
+int hulk_comm_init_loopback(hulk_ctx *ctx, uint32_t rank, uint32_t world);
+/* One step of this rank: bin its whole intervals of the step (n_reads <= T * interval reads, resident in HBM as for
+ * hulk_add_reads_device), exchange, flush.  Asynchronous; the next step's binning runs under this step's exchange. */
+int hulk_step_sharded(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                      uint32_t max_read_len, uint64_t bases_bytes, uint32_t step_intervals);
+/* SURVEY.md 8(e) to the letter, for comparison: every rank bins `reads_per_spectrum` reads of each of `n_spectra`
+ * intervals (its slice of every interval), ONE all-reduce (uint32 sum) of the n_spectra spectra, flush. */
+int hulk_step_sliced(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                     uint32_t max_read_len, uint64_t bases_bytes, uint64_t reads_per_spectrum, uint32_t n_spectra);
+/* Sketcher.Run's result on every rank (src/pipeline/sketch.go:271-301): all-gather of the ranks' slot shards. */
+int hulk_gather_sketch(hulk_ctx *ctx, uint64_t *mins, double *weights);
+/* Steps taken by each exchange and the bytes this rank received through the transport (cumulative). */
+int hulk_get_comm_stats(hulk_ctx *ctx, uint64_t *steps_delta, uint64_t *steps_full, uint64_t *bytes_received);
+
 /* Test hook: add counts to the current k-mer spectrum directly (host uint32[num_bins]). */
 int hulk_add_histogram(hulk_ctx *ctx, const uint32_t *bins);
 
@@ -235,8 +295,8 @@ int hulk_selftest_reciprocal(hulk_ctx *ctx, uint64_t *mismatches);
 int hulk_get_scan_stats(hulk_ctx *ctx, uint64_t *tiles_visited, uint64_t *tiles_total);
 
 /* Per-kernel timing for bench.py: when enabled, hipEvents bracket every launch of the heavy kernels
- * ("k_minimizer_fast", "k_jump_bin" = k_jump_bin + k_jump_left, "k_cws_scan") on the stream they are launched on.
- * enabled: 0 off, 1 all three, otherwise a mask (2 k_minimizer_fast, 4 k_jump_bin, 8 k_cws_scan) — every bracketed
+ * ("k_minimizer_fast", "k_jump_bin", "k_jump_left", "k_cws_scan"; each alone) on the stream they are launched on.
+ * enabled: 0 off, 1 all of them, otherwise a mask (2 k_minimizer_fast, 4 k_jump_bin and k_jump_left, 8 k_cws_scan) — every bracketed
  * launch costs the stream two event records (all three: ~3 % of a C2 step), so a timed run brackets what it reports. */
 int hulk_set_profiling(hulk_ctx *ctx, int enabled);
 /* Number of timed launches of `kernel` and their summed duration (synchronises; clears that log). */

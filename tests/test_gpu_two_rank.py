@@ -1,14 +1,15 @@
-"""Two ranks of the PRODUCT multi-GPU path (GpuSketcher + GpuEngine + ShardedSketcher, the protocol of
-bench.py) on ONE MI355X: both processes use cuda:0 and exchange over gloo (RCCL refuses two ranks on
-one device; the collective is the only thing swapped).  The gathered sketch must equal a single-rank
-GPU run over the same global read stream, and the oracle:
-  * "strong" (bench.py's default): each rank bins its half of every interval of I reads — the single-rank
-    run has the SAME interval I (the reference's rule, pipeline/sketch.go:211-215);
-  * "weak": each rank bins I reads per interval — the single-rank run has interval 2 x I;
-  * "strong-interval": the strong rule split the other way (distributed.batch_share): each rank bins WHOLE intervals of a
-    batch through hulk_bin_reads_device_at(first_spectrum), the all-reduce over the ring is a gather.
-The stream ends in a ragged tail (TAIL < BATCH intervals binned, then finish() without a flush_batch): the final flush
-must take every spectrum of the tail batch.
+"""Two ranks of the PRODUCT multi-GPU path on ONE MI355X: both processes use cuda:0, every step goes through
+hulk_step_sharded / hulk_step_sliced (the exchange inside libhulkhip.so) and the ranks are connected by the library's HOST
+transport over gloo (hulk_comm_init_host + distributed.gloo_exchange) — RCCL refuses two ranks on one device; the transport
+is the only thing swapped, the protocol (which exchange a step takes, the kernels, the order) is the one RCCL ranks run.
+The gathered sketch must equal a single-rank GPU run over the same global read stream, and the oracle:
+  * "sharded":       whole intervals per rank (distributed.step_share); the first step exchanges spectra, later ones the
+                     count-min increments — both exchanges must have been taken;
+  * "sharded-full":  the same with HULK_SHARD_FULL=1 (every step exchanges spectra): the delta exchange changes nothing;
+  * "sliced-strong": SURVEY.md §8(e) to the letter — each rank bins its half of every interval, one all-reduce per step;
+  * "sliced-weak":   each rank bins I reads per interval — the single-rank run has interval 2 x I.
+The stream ends in a ragged step (rank 0: a whole and a partial interval, rank 1: nothing) / a ragged tail batch.
+RCCL itself runs at world size 1 (test_rccl_world_one_is_the_single_rank_sketch; tests/test_gpu_cpp_host.py from C++).
 """
 import os
 import socket
@@ -18,7 +19,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-K, W, S, I, BATCH, STEPS, TAIL, L = 15, 9, 64, 3000, 4, 3, 2, 150
+K, W, S, I, BATCH, L = 15, 9, 64, 3000, 4, 150
+WORLD = 2
+TOTAL = 4 * WORLD * BATCH * I + I + 1100      # four whole steps + a ragged one
+STEPS, TAIL = 3, 2                            # sliced modes: whole batches + a tail batch of TAIL intervals
 
 
 def _free_port():
@@ -26,81 +30,60 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, overlap, scaling):
-    import torch
-    import torch.distributed as dist
+def _worker(rank, world, port, q, overlap, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["HULK_BATCH"] = str(BATCH)
+    if not overlap:
+        os.environ["HULK_NO_OVERLAP"] = "1"
+    if mode == "sharded-full":
+        os.environ["HULK_SHARD_FULL"] = "1"
+    import torch
+    import torch.distributed as dist
     import hulk_amd
     from hulk_amd import synth
-    from hulk_amd.distributed import GpuEngine, ShardedSketcher, batch_share, interval_slice, slot_shard
+    from hulk_amd.distributed import gloo_exchange, interval_slice, num_steps, slot_shard, step_share
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    stream = torch.cuda.Stream()
-    coll = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
     sb, sc = slot_shard(S, rank, world)
-    sk = hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, device=0, slot_begin=sb, slot_count=sc,
-                              stream=stream.cuda_stream)
+    sharded = mode.startswith("sharded")
+    sk = hulk_amd.GpuSketcher(K, W, S, interval=I if sharded else 0, decay_ratio=1.0, device=0, slot_begin=sb, slot_count=sc)
     assert sk.batch_size == BATCH
-    eng = GpuEngine(sk, "cuda:0", n_spectra=BATCH)
-    sh = ShardedSketcher(eng, S, rank, world, dist)
-    by_interval = scaling == "strong-interval"              # whole intervals of a batch per rank (distributed.batch_share)
-    per = I if by_interval else interval_slice(scaling, 0, I, rank, world)[1]     # reads of an interval this rank bins
-    offsets = torch.arange(per * BATCH + 1, dtype=torch.int64, device="cuda:0") * L
+    sk.comm_init_host(rank, world, gloo_exchange(dist))
     keep = []
-    for s_ in range(STEPS + 1):
-        nt = BATCH if s_ < STEPS else TAIL                  # the last batch is a ragged tail
-        parts = []
-        first_spectrum = 0
-        if by_interval:
-            first, cnt, first_spectrum = batch_share(0, nt, I, rank, world)     # this rank's intervals of a batch of nt ...
-            first += s_ * BATCH * I                                             # ... that starts at interval s_ * BATCH
-            b, _ = synth.reads_torch(first, cnt, L, device="cuda:0")
-            parts.append(b[:cnt * L])
-            n_mine = cnt
-        else:
+    if sharded:
+        for s_ in range(num_steps(TOTAL, BATCH, I, world)):
+            first, n, step_intervals = step_share(s_, BATCH, I, rank, world, TOTAL)
+            b, off = synth.reads_torch(first, max(n, 1), L, device="cuda:0")
+            keep.append((b, off))
+            torch.cuda.synchronize()
+            sk.step_sharded(b.data_ptr(), off.data_ptr(), n, L, b.numel(), step_intervals)
+    else:
+        scaling = mode.split("-")[1]
+        per = interval_slice(scaling, 0, I, rank, world)[1]
+        offsets = torch.arange(per * BATCH + 1, dtype=torch.int64, device="cuda:0") * L
+        for s_ in range(STEPS + 1):
+            nt = BATCH if s_ < STEPS else TAIL
+            parts = []
             for t in range(nt):
                 first, cnt = interval_slice(scaling, s_ * BATCH + t, I, rank, world)
                 b, _ = synth.reads_torch(first, cnt, L, device="cuda:0")
                 parts.append(b[:cnt * L])
-            n_mine = per * nt
-        bases = torch.cat(parts + [torch.zeros(16, dtype=torch.uint8, device="cuda:0")])
-        keep.append(bases)
-        sk.bin_reads_device(bases.data_ptr(), offsets.data_ptr(), n_mine, L, bases.numel(), reads_per_spectrum=per,
-                            first_spectrum=first_spectrum)
-        h = eng.histogram_tensor()
-        if s_ == STEPS:                                     # tail: all-reduce the whole view, then finish() flushes it
+            bases = torch.cat(parts + [torch.zeros(16, dtype=torch.uint8, device="cuda:0")])
+            keep.append(bases)
             torch.cuda.synchronize()
-            hc = h.cpu()
-            dist.all_reduce(hc, op=dist.ReduceOp.SUM)
-            h.copy_(hc)
-            torch.cuda.synchronize()
-            break
-        if overlap:                                     # bench.py's shape: collective + flush on a second stream
-            coll.wait_stream(stream)
-            with torch.cuda.stream(coll):
-                hc = h.cpu()                            # gloo: host-staged all-reduce of the int32 spectra
-                dist.all_reduce(hc, op=dist.ReduceOp.SUM)
-                h.copy_(hc)
-            sk.flush_batch(BATCH, after_stream=coll.cuda_stream)
-        else:
-            hc = h.cpu()
-            dist.all_reduce(hc, op=dist.ReduceOp.SUM)
-            h.copy_(hc)
-            sk.flush_batch(BATCH)
+            sk.step_sliced(bases.data_ptr(), offsets.data_ptr(), per * nt, L, bases.numel(), per, nt)
     sk.finish()
-    eng.collective_device = None                        # gloo gather on host tensors
-    mins, weights = sh.gather_sketch()
+    mins, weights = sk.gather_sketch()
+    stats = sk.comm_stats()
     if rank == 0:
-        q.put((mins, weights, sk.counters()))
+        q.put((mins, weights, sk.cms(), stats))
     sk.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,scaling", [(False, "weak"), (True, "weak"), (False, "strong"), (True, "strong"),
-                                             (False, "strong-interval"), (True, "strong-interval")])
-def test_two_ranks_one_gpu_match_single_rank(overlap, scaling):
+@pytest.mark.parametrize("overlap,mode", [(True, "sharded"), (False, "sharded"), (True, "sharded-full"),
+                                          (True, "sliced-strong"), (False, "sliced-strong"), (True, "sliced-weak")])
+def test_two_ranks_one_gpu_match_single_rank(overlap, mode):
     import torch
     import torch.multiprocessing as mp
     import hulk_amd
@@ -108,32 +91,99 @@ def test_two_ranks_one_gpu_match_single_rank(overlap, scaling):
     from oracle import pyorc
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    world = 2
+    world = WORLD
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, overlap, scaling)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, overlap, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    mins, weights, _ = q.get(timeout=240)
+    mins, weights, cms, stats = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # single rank, same global stream: interval = I (strong: the reference's rule) or world * I (weak)
-    gi = world * I if scaling == "weak" else I
-    total = (STEPS * BATCH + TAIL) * gi
+    if mode == "sharded":
+        assert stats["steps_full"] >= 1 and stats["steps_delta"] >= 1, stats      # both exchanges were taken
+    elif mode == "sharded-full":
+        assert stats["steps_delta"] == 0
+    # single rank, same global stream: interval = I (the reference's rule) or world * I (weak)
+    gi = world * I if mode == "sliced-weak" else I
+    total = TOTAL if mode.startswith("sharded") else (STEPS * BATCH + TAIL) * gi
     bases, offsets = synth.reads_numpy(0, total, L)
     g = hulk_amd.GpuSketcher(K, W, S, interval=gi)
     g.add_reads(bases, offsets)
     g.finish()
     m1, w1 = g.sketch()
+    c1 = g.cms()
     g.close()
     assert np.array_equal(mins, m1)
     assert np.array_equal(weights, w1)                  # same kernels, same order: bit-identical
+    assert np.array_equal(cms, c1)                      # count-min counters: integer sums, whichever exchange moved them
     o = pyorc.Sketcher(K, W, S, 0, 1.0, gi)
     o.add_reads(bases, offsets)
     o.finish()
     mo, wo = o.sketch()
+    assert np.array_equal(o.cms(), cms)
     o.close()
     assert np.array_equal(mins, mo)
     assert np.allclose(weights, wo, rtol=1e-12, atol=0)
+
+
+def test_rccl_world_one_is_the_single_rank_sketch():
+    """hulk_comm_unique_id + hulk_comm_init bind librccl.so.1 and build a communicator (world size 1 on this box); the
+    sharded step over it — spectra exchange first, increments later — gives the sketch of hulk_add_reads."""
+    import torch
+    import hulk_amd
+    from hulk_amd import synth
+    from hulk_amd.distributed import num_steps, step_share
+    os.environ["HULK_BATCH"] = str(BATCH)
+    total = 5 * BATCH * I + 700
+    sk = hulk_amd.GpuSketcher(K, W, S, interval=I)
+    sk.comm_init(hulk_amd.GpuSketcher.comm_unique_id(), 0, 1)
+    keep = []
+    for s_ in range(num_steps(total, BATCH, I, 1)):
+        first, n, si = step_share(s_, BATCH, I, 0, 1, total)
+        b, off = synth.reads_torch(first, n, L, device="cuda:0")
+        keep.append((b, off))
+        torch.cuda.synchronize()
+        sk.step_sharded(b.data_ptr(), off.data_ptr(), n, L, b.numel(), si)
+    sk.finish()
+    mins, weights = sk.gather_sketch()
+    stats = sk.comm_stats()
+    cms, cnt = sk.cms(), sk.counters()
+    sk.close()
+    assert stats["steps_full"] >= 1 and stats["steps_delta"] >= 1, stats
+    bases, offsets = synth.reads_numpy(0, total, L)
+    g = hulk_amd.GpuSketcher(K, W, S, interval=I)
+    g.add_reads(bases, offsets)
+    g.finish()
+    m1, w1 = g.sketch()
+    assert np.array_equal(mins, m1) and np.array_equal(weights, w1) and np.array_equal(cms, g.cms())
+    assert cnt == g.counters()
+    g.close()
+
+
+def test_sharded_step_reports_too_few_used_bins():
+    """The 1 % rule (kmerspectrum.go:84-96, "not used yet") must fire on the delta exchange too: an interval of identical
+    reads uses a handful of bins."""
+    import torch
+    import hulk_amd
+    from hulk_amd import synth
+    from hulk_amd._lib import HulkError
+    os.environ["HULK_BATCH"] = str(BATCH)
+    sk = hulk_amd.GpuSketcher(K, W, S, interval=I)
+    sk.comm_init_loopback(0, 1)
+    keep = []
+    for s_ in range(4):
+        b, off = synth.reads_torch(s_ * BATCH * I, BATCH * I, L, device="cuda:0")
+        if s_ == 3:
+            b = b.clone()
+            b[:BATCH * I * L] = b[:L].repeat(BATCH * I)            # every read of the step = the first one
+        keep.append((b, off))
+        torch.cuda.synchronize()
+        sk.step_sharded(b.data_ptr(), off.data_ptr(), BATCH * I, L, b.numel(), BATCH)
+    assert sk.comm_stats()["steps_delta"] >= 1
+    with pytest.raises(HulkError) as e:
+        sk.finish()
+    assert "not used yet" in str(e.value)
+    sk.close()
