@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
     "hulk_get_cws_tables", "hulk_smash", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
     "hulk_parse_files", "hulk_sketch_files", "hulk_get_scan_stats", "hulk_synchronize",
-    "hulk_comm_unique_id", "hulk_comm_init", "hulk_comm_init_host", "hulk_comm_init_loopback", "hulk_step_sharded",
+    "hulk_comm_unique_id", "hulk_comm_init", "hulk_comm_init_host", "hulk_comm_init_loopback", "hulk_step_sharded", "hulk_step_sharded_host",
     "hulk_step_sliced", "hulk_gather_sketch", "hulk_get_comm_stats",
 )
 
@@ -187,6 +187,7 @@ def load():
     L.hulk_comm_init_host.restype = ctypes.c_int; L.hulk_comm_init_host.argtypes = [vp, u32, u32, EXCHANGE_FN, vp]
     L.hulk_comm_init_loopback.restype = ctypes.c_int; L.hulk_comm_init_loopback.argtypes = [vp, u32, u32]
     L.hulk_step_sharded.restype = ctypes.c_int; L.hulk_step_sharded.argtypes = [vp, vp, vp, u64, u32, u64, u32]
+    L.hulk_step_sharded_host.restype = ctypes.c_int; L.hulk_step_sharded_host.argtypes = [vp, vp, vp, u64, u32]
     L.hulk_step_sliced.restype = ctypes.c_int; L.hulk_step_sliced.argtypes = [vp, vp, vp, u64, u32, u64, u64, u32]
     L.hulk_gather_sketch.restype = ctypes.c_int; L.hulk_gather_sketch.argtypes = [vp, vp, vp]
     L.hulk_get_comm_stats.restype = ctypes.c_int; L.hulk_get_comm_stats.argtypes = [vp, vp, vp, vp]

@@ -1027,6 +1027,69 @@ int ctx_fail(hulk_ctx *c, int code, const char *full_message) {
 }
 }  // namespace hulk
 
+
+namespace {
+// reads [i0, i1) of the caller's host buffers -> the next of the two pinned + device staging sets: host copy (several
+// threads: one core copies ~10 GB/s, a PCIe 5 x16 link moves ~50) and hipMemcpyAsync on the context's stream.  The caller
+// queues its kernels behind the copies, then records hs.ev and sets hs.busy (the set is reused when that event has passed).
+int stage_host_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t i0, uint64_t i1,
+                     hulk_ctx::HostStage **out) {
+    const uint64_t cn = i1 - i0, lo = offsets[i0];
+    const size_t nbytes = (size_t)(offsets[i1] - lo);
+    hulk_ctx::HostStage &hs = c->hstage[c->hstage_cur];
+    if (!hs.ev) HIPCHK(c, hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
+    if (hs.busy) { HIPCHK(c, hipEventSynchronize(hs.ev)); hs.busy = false; }     // its copies and kernels are done
+    if (nbytes + 32 > hs.cap_bases) {
+        if (hs.h_bases) hipHostFree(hs.h_bases);
+        hipFree(hs.d_bases); hs.h_bases = hs.d_bases = nullptr;
+        hs.cap_bases = (nbytes + 32) + (nbytes + 32) / 4;
+        HIPCHK(c, hipHostMalloc((void **)&hs.h_bases, hs.cap_bases, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void **)&hs.d_bases, hs.cap_bases));
+    }
+    if (cn + 2 > hs.cap_off) {
+        if (hs.h_off) hipHostFree(hs.h_off);
+        hipFree(hs.d_off); hs.h_off = hs.d_off = nullptr;
+        hs.cap_off = (cn + 2) + (cn + 2) / 4;
+        HIPCHK(c, hipHostMalloc((void **)&hs.h_off, hs.cap_off * 8, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void **)&hs.d_off, hs.cap_off * 8));
+    }
+    {
+        static const unsigned tmax = [] { const char *e = getenv("HULK_HOST_COPY_THREADS"); const long v = e ? atol(e) : 4; return (unsigned)(v < 1 ? 1 : v > 32 ? 32 : v); }();
+        const unsigned T = nbytes >= (8u << 20) ? tmax : 1u;
+        const size_t piece = (nbytes / T + 63) & ~(size_t)63;
+        std::vector<std::thread> th;
+        auto work = [&](unsigned t) {
+            const size_t at = (size_t)t * piece;
+            if (at < nbytes) memcpy(hs.h_bases + at, bases + lo + at, std::min(piece, nbytes - at));
+        };
+        for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (uint64_t i = 0; i <= cn; i++) hs.h_off[i] = offsets[i0 + i] - lo;
+        for (auto &x : th) x.join();
+    }
+    HIPCHK(c, hipMemcpyAsync(hs.d_bases, hs.h_bases, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs.d_off, hs.h_off, (cn + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    c->hstage_cur ^= 1;
+    *out = &hs;
+    return HULK_OK;
+}
+// NewMinimizerSketch's checks run per read in the reference (minimizer.go:70-76)
+int check_host_reads(hulk_ctx *c, const uint64_t *offsets, uint64_t n, uint64_t *max_len_out) {
+    uint64_t max_len = 0;
+    const uint64_t need = (uint64_t)c->p.w + c->p.k - 1;
+    for (uint64_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(c, HULK_ERR_ARG, "offsets not monotone");
+        const uint64_t L = offsets[i + 1] - offsets[i];
+        if (L < 1) return fail(c, HULK_ERR_EMPTY_SEQ);
+        if (L < need) return fail(c, HULK_ERR_SHORT_SEQ);
+        if (L > max_len) max_len = L;
+    }
+    if (max_len > 0xffffffffull) return fail(c, HULK_ERR_READ_TOO_LONG);
+    *max_len_out = max_len;
+    return HULK_OK;
+}
+}  // namespace
+
 extern "C" {
 int hulk_add_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
                           uint32_t max_read_len, uint64_t bases_bytes) {
@@ -1110,17 +1173,8 @@ int hulk_add_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, u
     if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
     if (n == 0) return HULK_OK;
     if (!bases || !offsets) return fail(c, HULK_ERR_ARG, "NULL buffer");
-    // NewMinimizerSketch's checks run per read in the reference (minimizer.go:70-76)
     uint64_t max_len = 0;
-    const uint64_t need = (uint64_t)c->p.w + c->p.k - 1;
-    for (uint64_t i = 0; i < n; i++) {
-        if (offsets[i + 1] < offsets[i]) return fail(c, HULK_ERR_ARG, "offsets not monotone");
-        const uint64_t L = offsets[i + 1] - offsets[i];
-        if (L < 1) return fail(c, HULK_ERR_EMPTY_SEQ);
-        if (L < need) return fail(c, HULK_ERR_SHORT_SEQ);
-        if (L > max_len) max_len = L;
-    }
-    if (max_len > 0xffffffffull) return fail(c, HULK_ERR_READ_TOO_LONG);
+    { const int rcv = check_host_reads(c, offsets, n, &max_len); if (rcv != HULK_OK) return rcv; }
     // Chunks of <= 2^19 reads / 96 MB go through two pinned staging sets: host copy (several threads: one core
     // copies ~10 GB/s, a PCIe 5 x16 link moves ~50) -> hipMemcpyAsync -> kernels, all queued on the context's
     // stream; the call returns when the caller's buffers have been read, not when the kernels have run.
@@ -1133,46 +1187,14 @@ int hulk_add_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, u
             if (L > cmax) cmax = L;
             i1++;
         }
-        const uint64_t cn = i1 - i0, lo = offsets[i0];
-        const size_t nbytes = (size_t)(offsets[i1] - lo);
-        hulk_ctx::HostStage &hs = c->hstage[c->hstage_cur];
-        if (!hs.ev) HIPCHK(c, hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
-        if (hs.busy) { HIPCHK(c, hipEventSynchronize(hs.ev)); hs.busy = false; }     // its copies and kernels are done
-        if (nbytes + 32 > hs.cap_bases) {
-            if (hs.h_bases) hipHostFree(hs.h_bases);
-            hipFree(hs.d_bases); hs.h_bases = hs.d_bases = nullptr;
-            hs.cap_bases = (nbytes + 32) + (nbytes + 32) / 4;
-            HIPCHK(c, hipHostMalloc((void **)&hs.h_bases, hs.cap_bases, hipHostMallocDefault));
-            HIPCHK(c, hipMalloc((void **)&hs.d_bases, hs.cap_bases));
-        }
-        if (cn + 2 > hs.cap_off) {
-            if (hs.h_off) hipHostFree(hs.h_off);
-            hipFree(hs.d_off); hs.h_off = hs.d_off = nullptr;
-            hs.cap_off = (cn + 2) + (cn + 2) / 4;
-            HIPCHK(c, hipHostMalloc((void **)&hs.h_off, hs.cap_off * 8, hipHostMallocDefault));
-            HIPCHK(c, hipMalloc((void **)&hs.d_off, hs.cap_off * 8));
-        }
-        {
-            static const unsigned tmax = [] { const char *e = getenv("HULK_HOST_COPY_THREADS"); const long v = e ? atol(e) : 4; return (unsigned)(v < 1 ? 1 : v > 32 ? 32 : v); }();
-            const unsigned T = nbytes >= (8u << 20) ? tmax : 1u;
-            const size_t piece = (nbytes / T + 63) & ~(size_t)63;
-            std::vector<std::thread> th;
-            auto work = [&](unsigned t) {
-                const size_t at = (size_t)t * piece;
-                if (at < nbytes) memcpy(hs.h_bases + at, bases + lo + at, std::min(piece, nbytes - at));
-            };
-            for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
-            work(0);
-            for (uint64_t i = 0; i <= cn; i++) hs.h_off[i] = offsets[i0 + i] - lo;
-            for (auto &x : th) x.join();
-        }
-        HIPCHK(c, hipMemcpyAsync(hs.d_bases, hs.h_bases, nbytes, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hs.d_off, hs.h_off, (cn + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        const uint64_t cn = i1 - i0;
+        hulk_ctx::HostStage *hsp = nullptr;
+        { const int rcs = stage_host_reads(c, bases, offsets, i0, i1, &hsp); if (rcs != HULK_OK) return rcs; }
+        hulk_ctx::HostStage &hs = *hsp;
         const int rc = hulk_add_reads_device(c, hs.d_bases, hs.d_off, cn, (uint32_t)cmax, hs.cap_bases);
         if (rc != HULK_OK) return rc;
         HIPCHK(c, hipEventRecord(hs.ev, c->stream));
         hs.busy = true;
-        c->hstage_cur ^= 1;
         i0 = i1;
     }
     return HULK_OK;
@@ -1522,6 +1544,20 @@ int hulk_step_sharded(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_off
     m.step++;
     c->cur_ring ^= 1;
     return HULK_OK;
+}
+
+int hulk_step_sharded_host(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n, uint32_t step_intervals) {
+    if (!c) return HULK_ERR_ARG;
+    if (n && (!bases || !offsets)) return fail(c, HULK_ERR_ARG, "NULL buffer");
+    if (n == 0) return hulk_step_sharded(c, nullptr, nullptr, 0, 0, 0, step_intervals);
+    uint64_t max_len = 0;
+    { const int rcv = check_host_reads(c, offsets, n, &max_len); if (rcv != HULK_OK) return rcv; }
+    hulk_ctx::HostStage *hs = nullptr;
+    { const int rcs = stage_host_reads(c, bases, offsets, 0, n, &hs); if (rcs != HULK_OK) return rcs; }
+    const int rc = hulk_step_sharded(c, hs->d_bases, hs->d_off, n, (uint32_t)max_len, hs->cap_bases, step_intervals);
+    HIPCHK(c, hipEventRecord(hs->ev, c->stream));               // (the binning kernels are on the work stream)
+    hs->busy = true;
+    return rc;
 }
 
 int hulk_step_sliced(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, uint32_t max_read_len,

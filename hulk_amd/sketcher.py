@@ -187,6 +187,13 @@ class GpuSketcher:
         self._chk(self._L.hulk_step_sharded(self._ctx, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes,
                                             step_intervals))
 
+    def step_sharded_host(self, bases, offsets, step_intervals):
+        """hulk_step_sharded for reads held in host memory (numpy): read i = bases[offsets[i]:offsets[i+1]]."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._chk(self._L.hulk_step_sharded_host(self._ctx, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                                 step_intervals))
+
     def step_sliced(self, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes, reads_per_spectrum, n_spectra):
         """SURVEY.md 8(e) to the letter: a slice of every interval per rank, one all-reduce of the spectra, flush."""
         self._chk(self._L.hulk_step_sliced(self._ctx, bases_ptr, offsets_ptr, n_reads, max_read_len, bases_bytes,

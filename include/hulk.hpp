@@ -9,11 +9,14 @@
 //   histosketch.HistoSketch (exported fields)  histosketch.go:36-47       hulk::HistoSketch
 //   DataStreamer + FastqHandler + AddSeq loop  pipeline/sketch.go:40-217  hulk::Boss::SketchFiles
 //   log.Fatalf("ERROR---> %v") via helpers.ErrorCheck   helpers.go:31-35  hulk::Error (what() = %v)
+//   SeqMinimizer.Run's loop with the read stream sharded over GPUs        hulk::Boss::Shard + AddSeq + StopWorkSharded
+//       pipeline/sketch.go:182-250                                          (RCCL inside libhulkhip.so)
 //
 // Header only; link with -lhulkhip.  A Boss is single-caller, like SeqMinimizer.Run's goroutine.
 #ifndef HULK_HPP
 #define HULK_HPP
 
+#include <array>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -41,7 +44,10 @@ struct SketchInfo {
     double DecayRatio = 1.0;       // -x
     int32_t SpectrumSize = 0;      // 0 = Pow(KmerSize, 4)  (cmd/sketch.go:118)
     int Device = 0;
+    unsigned Rank = 0, World = 1;  // multi-GPU: this process is rank Rank of World (one GPU each); it owns the sketch
+                                   // slots [S*Rank/World, S*(Rank+1)/World) and Boss::Shard connects it to the others
 };
+using UniqueId = std::array<uint8_t, HULK_UNIQUE_ID_BYTES>;
 
 // histosketch.HistoSketch as sketchio consumes it (exported fields only)
 struct HistoSketch {
@@ -60,17 +66,41 @@ class Boss {
     // findMinimizers + NewHistoSketch: throws hulk::Error with the reference's message
     static Boss FindMinimizers(const SketchInfo &info) { return Boss(info); }
 
-    Boss(Boss &&o) noexcept : ctx_(o.ctx_), info_(o.info_), bins_(o.bins_), bases_(std::move(o.bases_)),
+    Boss(Boss &&o) noexcept : ctx_(o.ctx_), info_(o.info_), bins_(o.bins_), sharded_(o.sharded_), bases_(std::move(o.bases_)),
                               offsets_(std::move(o.offsets_)) { o.ctx_ = nullptr; }
     Boss(const Boss &) = delete;
     Boss &operator=(const Boss &) = delete;
     ~Boss() { if (ctx_) hulk_destroy(ctx_); }
 
+    // ---- the read stream sharded over World GPUs (include/hulk_hip.h, hulk_step_sharded): rank 0 draws an id
+    // (CommUniqueId), the host hands it to the other ranks, every rank calls Shard — then AddSeq takes THIS RANK's reads:
+    // of every step of World * T sketching intervals of the global stream (T = hulk_batch_size) the whole intervals
+    // [Rank * T, (Rank + 1) * T), in stream order.  A full share (T * Interval reads) is pushed as one step.
+    static UniqueId CommUniqueId() {
+        UniqueId id{};
+        const int rc = hulk_comm_unique_id(id.data());
+        if (rc != HULK_OK) throw Error(rc, hulk_last_error(nullptr));
+        return id;
+    }
+    void Shard(const UniqueId &id) {
+        if (info_.Interval == 0) throw Error(HULK_ERR_ARG, "a sharded run needs Interval > 0");
+        check(hulk_comm_init(ctx_, id.data(), info_.Rank, info_.World));
+        sharded_ = true;
+    }
+    // End of the stream: `lastStepIntervals` = sketching intervals of the GLOBAL stream in the last, ragged step (the same
+    // value on every rank, 0 if the stream ended on a step border); this rank's remaining reads are its share of it.
+    void StopWorkSharded(uint32_t lastStepIntervals) {
+        if (lastStepIntervals) push_step(lastStepIntervals);
+        check(hulk_finish(ctx_));
+    }
+
     // theBoss.AddSeq (boss.go:24-26); sequences are staged and cross the ABI in batches
     void AddSeq(const uint8_t *seq, size_t len) {
         bases_.insert(bases_.end(), seq, seq + len);
         offsets_.push_back(bases_.size());
-        if (offsets_.size() > kBatchReads || bases_.size() > kBatchBytes) push();
+        if (sharded_) {
+            if (offsets_.size() - 1 == (size_t)hulk_batch_size(ctx_) * info_.Interval) push_step(info_.World * hulk_batch_size(ctx_));
+        } else if (offsets_.size() > kBatchReads || bases_.size() > kBatchBytes) push();
     }
     void AddSeq(const std::string &seq) { AddSeq(reinterpret_cast<const uint8_t *>(seq.data()), seq.size()); }
 
@@ -107,7 +137,8 @@ class Boss {
         hs.KmerSize = info_.KmerSize; hs.SketchSize = info_.SketchSize; hs.Dimensions = bins_;
         hs.ApplyConceptDrift = info_.DecayRatio != 1.0;
         hs.Sketch.resize(info_.SketchSize); hs.SketchWeights.resize(info_.SketchSize);
-        check(hulk_get_sketch(ctx_, hs.Sketch.data(), hs.SketchWeights.data()));
+        check(sharded_ ? hulk_gather_sketch(ctx_, hs.Sketch.data(), hs.SketchWeights.data())
+                       : hulk_get_sketch(ctx_, hs.Sketch.data(), hs.SketchWeights.data()));
         return hs;
     }
 
@@ -119,6 +150,10 @@ class Boss {
         hulk_params p{};
         p.k = info.KmerSize; p.w = info.WindowSize; p.sketch_size = info.SketchSize; p.num_bins = info.SpectrumSize;
         p.decay_ratio = info.DecayRatio; p.interval = info.Interval; p.device = info.Device;
+        if (info.World > 1) {
+            p.slot_begin = (uint32_t)((uint64_t)info.SketchSize * info.Rank / info.World);
+            p.slot_count = (uint32_t)((uint64_t)info.SketchSize * (info.Rank + 1) / info.World) - p.slot_begin;
+        }
         const int rc = hulk_create(&p, &ctx_);
         if (rc != HULK_OK) throw Error(rc, hulk_last_error(nullptr));
         bins_ = info.SpectrumSize;
@@ -132,11 +167,18 @@ class Boss {
         bases_.clear(); offsets_.assign(1, 0);
         check(rc);
     }
+    void push_step(uint32_t stepIntervals) {
+        const uint64_t n = offsets_.size() - 1;
+        const int rc = hulk_step_sharded_host(ctx_, bases_.data(), offsets_.data(), n, stepIntervals);
+        bases_.clear(); offsets_.assign(1, 0);
+        check(rc);
+    }
     void check(int rc) { if (rc != HULK_OK) throw Error(rc, hulk_last_error(ctx_)); }
 
     hulk_ctx *ctx_ = nullptr;
     SketchInfo info_;
     int32_t bins_ = 0;
+    bool sharded_ = false;
     std::vector<uint8_t> bases_;
     std::vector<uint64_t> offsets_;
 };

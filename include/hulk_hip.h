@@ -245,6 +245,10 @@ int hulk_comm_init_loopback(hulk_ctx *ctx, uint32_t rank, uint32_t world);
  * hulk_add_reads_device), exchange, flush.  Asynchronous; the next step's binning runs under this step's exchange. */
 int hulk_step_sharded(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                       uint32_t max_read_len, uint64_t bases_bytes, uint32_t step_intervals);
+/* The same for reads in HOST memory (a Go host's slices): validated as hulk_add_reads does, copied into pinned staging
+ * before the call returns (the cgo rule), PCIe copy and kernels queued on the context's stream. */
+int hulk_step_sharded_host(hulk_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                           uint32_t step_intervals);
 /* SURVEY.md 8(e) to the letter, for comparison: every rank bins `reads_per_spectrum` reads of each of `n_spectra`
  * intervals (its slice of every interval), ONE all-reduce (uint32 sum) of the n_spectra spectra, flush. */
 int hulk_step_sliced(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,

@@ -2,6 +2,8 @@
 // objects; prints one JSON line that tests/test_gpu_cpp_host.py compares with the Python/ctypes path.
 //   boss_driver addseq <reads.txt> k w S interval decay      one sequence per line -> AddSeq
 //   boss_driver files  <path>      k w S interval decay      SketchFiles (native ingest)
+//   boss_driver sharded <reads.txt> k w S interval decay     the same stream through Shard (RCCL, world size 1) + AddSeq +
+//                                                             StopWorkSharded: hulk_step_sharded_host per full share
 //   boss_driver errors                                         the reference's fatal messages
 #include <cstdio>
 #include <cstdlib>
@@ -39,13 +41,24 @@ int main(int argc, char **argv) {
             catch (const hulk::Error &e) { std::printf("%d|%s\n", e.code(), e.what()); }
             return 0;
         }
-        if (argc < 8) { std::fprintf(stderr, "usage: boss_driver addseq|files <path> k w S interval decay\n"); return 2; }
+        if (argc < 8) { std::fprintf(stderr, "usage: boss_driver addseq|files|sharded <path> k w S interval decay\n"); return 2; }
         hulk::SketchInfo info;
         info.KmerSize = (unsigned)std::atoi(argv[3]); info.WindowSize = (unsigned)std::atoi(argv[4]);
         info.SketchSize = (unsigned)std::atoi(argv[5]); info.Interval = (unsigned)std::atoi(argv[6]);
         info.DecayRatio = std::atof(argv[7]);
         hulk::Boss theBoss = hulk::Boss::FindMinimizers(info);
         uint64_t seqCount = 0;
+        if (mode == "sharded") {
+            theBoss.Shard(hulk::Boss::CommUniqueId());                                // one rank: the id needs no other host
+            std::ifstream in(argv[2]);
+            std::string line;
+            while (std::getline(in, line)) { theBoss.AddSeq(line); seqCount++; }
+            const uint64_t perStep = (uint64_t)hulk_batch_size(theBoss.handle()) * info.Interval;
+            const uint64_t rest = seqCount % perStep;
+            theBoss.StopWorkSharded((uint32_t)((rest + info.Interval - 1) / info.Interval));
+            print_sketch(theBoss, seqCount);
+            return 0;
+        }
         if (mode == "addseq") {
             std::ifstream in(argv[2]);
             std::string line;

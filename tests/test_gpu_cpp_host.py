@@ -40,7 +40,10 @@ def test_cpp_boss_matches_python_and_oracle(tmp_path, fq_reads):
         g.add_reads(*pack_reads(fq_reads))
         g.finish()
         m, w = g.sketch()
-        for mode, path in (("addseq", str(txt)), ("files", os.path.join(GOLDEN, "test-reads-small.fq.gz"))):
+        modes = [("addseq", str(txt)), ("files", os.path.join(GOLDEN, "test-reads-small.fq.gz"))]
+        if interval:                                    # hulk::Boss::Shard: RCCL communicator (world size 1) from C++,
+            modes.append(("sharded", str(txt)))         # hulk_step_sharded_host per full share, ragged last step
+        for mode, path in modes:
             p = subprocess.run([exe, mode, path, str(k), "9", str(S), str(interval), repr(decay)],
                                capture_output=True, text=True, timeout=300)
             assert p.returncode == 0, p.stdout + p.stderr
