@@ -677,13 +677,22 @@ __global__ __launch_bounds__(256) void k_shard_apply(const uint32_t *__restrict_
         const uint32_t *h = hdr_all + (size_t)r * SHARD_HDR;
         const uint32_t lo = r * T;                                             // rank r holds intervals [r*T, r*T + cnt) of the step
         const uint32_t cnt = step_intervals <= lo ? 0u : (step_intervals - lo < T ? step_intervals - lo : T);
+        if (!cnt) break;
+        // flush_go()'s rule per interval first (wave-uniform header words), then all of the rank's loads in flight at once
+        uint32_t gomask = 0;
         for (uint32_t t = 0; t < cnt; t++) {
             const uint32_t used = h[2 + t];
             if (used == 0) continue;                                           // boss.go:118: nothing to flush
             if ((double)used / (double)num_bins < 0.01) { few = true; continue; }  // kmerspectrum.go:88-96 ("not used yet")
-            run += delta_all[((size_t)r * T + t) * (size_t)ncounters + i];
+            gomask |= 1u << t;
             elems += used;
         }
+        const uint32_t *dr = delta_all + (size_t)r * T * (size_t)ncounters + i;
+        uint32_t v[SCAN_BATCH_MAX];
+#pragma unroll
+        for (uint32_t t = 0; t < (uint32_t)SCAN_BATCH_MAX; t++) v[t] = (t < T && ((gomask >> t) & 1u)) ? dr[(size_t)t * ncounters] : 0u;
+#pragma unroll
+        for (uint32_t t = 0; t < (uint32_t)SCAN_BATCH_MAX; t++) run += v[t];
     }
     ctr[i] = run;
     if (i == 0) {
