@@ -59,6 +59,8 @@ C4_READS_PER_RANK = int(os.environ.get("HULK_BENCH_C4_READS_PER_RANK", "50000000
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 SIMDS, CLOCK_GHZ, VALU_CYCLES = 256 * 4, 2.4, 2   # MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op issues over 2 cycles
 PMC_PROFILE = os.path.join("profiles", "r02_pmc.json")
+ISA_MIX = os.path.join("profiles", "r03_isa_mix.json")      # tools/isa_mix.py over the production kernels, priced by profiles/r03_op_cost.txt
+CLOCK_MEASURED_GHZ = 2.3    # shader clock under VALU load: s_memtime ticks per ns of HIP-event time, tools/ubench/op_cost2.hip (2.1-2.35)
 
 
 def cpu_model():
@@ -553,16 +555,26 @@ def main():
             comm_desc = {"inside": "libhulkhip.so (hulk_step_sharded / hulk_step_sliced)", "transport": how, "per_step": what,
                          "timed_pass": main_pass["comm"]}
 
+        isa_mix = {}
+        try:
+            isa_mix = json.load(open(os.path.join(ROOT, ISA_MIX)))
+        except Exception:
+            pass
+
         def valu_roofline(kernel, avg_s):
-            """VALU-issue roofline of a launch from the rocprofv3 PMC pass of this command (profiles/r02_pmc.json):
-            floor_us        = SQ_INSTS_VALU / 1024 SIMDs x 2 cycles / 2.4 GHz — every wave64 VALU instruction at the
-                              2-cycle rate MI355X_MICROARCH.md quotes (v_fma_f32-class ops);
-            floor_us_issue  = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz — the cycles the VALU pipes were
-                              actually occupied (the counter ticks in quad-cycles).  Integer, 64-bit, fp64 and VOP3 ops
-                              issue at ~4.5 cycles per wave64 instruction on this chip, v_rcp_f64 at 16
-                              (tools/ubench/op_cost.hip, profiles/r02_op_cost.txt), which is what these kernels are made of.
-            frac / frac_issue = floor / the launch duration measured live in this run."""
-            insts, active = from_profile(kernel, "SQ_INSTS_VALU"), from_profile(kernel, "SQ_ACTIVE_INST_VALU")
+            """VALU-issue roofline of a launch.  SQ_INSTS_VALU (wave64 VALU instructions per launch) comes from the rocprofv3 PMC
+            pass of this command (profiles/r02_pmc.json); what an instruction costs was measured two independent ways
+            (profiles/r03_op_cost.txt: whole launches by HIP events at the nominal clock, tools/ubench/op_cost.hip; every wave
+            timing its own block with s_memtime — shader-clock ticks — grouped by the SIMD it ran on, op_cost2.hip):
+            simple VOP2 ops (v_add/sub_u32, v_and/or/xor_b32, v_mov_b32, v_lshrrev_b32, v_mul/add_f32) issue in 2.35 cycles,
+            everything else these kernels use (VOP3 integer ops, v_lshlrev_b32, min/max, DPP, cmp/cndmask, every 64-bit, fp64
+            and packed op) in 4.4, v_rcp_f64 in 16.5.  MI355X_MICROARCH.md's 2 cycles is the first class only.
+            floor_us      = SQ_INSTS_VALU / 1024 SIMDs x 2 cycles / 2.4 GHz   (every instruction priced as the fast class at the
+                            nominal clock: an optimistic bound, kept for comparison with round 2)
+            floor_us_mix  = SQ_INSTS_VALU x (mean cycles of the kernel's own static instruction mix, tools/isa_mix.py ->
+                            profiles/r03_isa_mix.json) / 1024 / the measured shader clock under load (2.3 GHz)
+            frac / frac_mix = floor / the launch duration measured live in this run."""
+            insts = from_profile(kernel, "SQ_INSTS_VALU")
             if not insts or avg_s <= 0:
                 return None
             per_launch = float(pmc.get("reads_per_launch", INTERVAL * BATCH))
@@ -572,12 +584,15 @@ def main():
                     "cycles_per_instr_assumed": VALU_CYCLES, "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
                     "floor_us": floor_us, "avg_launch_us": avg_s * 1e6, "frac": floor_us / (avg_s * 1e6),
                     "instr_from_profile": PMC_PROFILE,
-                    "formula": "floor_us = SQ_INSTS_VALU / 1024 SIMDs * 2 cycles / 2.4 GHz; floor_us_issue = "
-                               "SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / 1024 / 2.4 GHz; frac = floor / avg_launch_us"}
-            if active:
-                fi = active * scale * 4.0 / SIMDS / (CLOCK_GHZ * 1e3)
-                out_.update({"cycles_per_instr_measured": 4.0 * active / insts, "floor_us_issue": fi,
-                             "frac_issue": fi / (avg_s * 1e6)})
+                    "formula": "floor_us = SQ_INSTS_VALU / 1024 SIMDs * 2 cycles / 2.4 GHz; floor_us_mix = SQ_INSTS_VALU * "
+                               "mean_cycles_of_the_static_mix / 1024 / 2.3 GHz (measured clock); frac = floor / avg_launch_us"}
+            mixk = isa_mix.get(kernel)
+            if mixk and mixk.get("mean_cycles_loop"):
+                mc = float(mixk["mean_cycles_loop"])
+                fm = insts * scale * mc / SIMDS / (CLOCK_MEASURED_GHZ * 1e3)
+                out_.update({"cycles_per_instr_mix": mc, "mix": mixk.get("mix_loop"), "mix_from": ISA_MIX,
+                             "op_costs_from": "profiles/r03_op_cost.txt", "clock_measured_ghz": CLOCK_MEASURED_GHZ,
+                             "floor_us_mix": fm, "frac_mix": fm / (avg_s * 1e6)})
             return out_
 
         # The HBM-streaming kernel of the path = k_cws_scan.  Unpruned it makes ONE fp32 pass over this rank's

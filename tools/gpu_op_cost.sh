@@ -1,5 +1,5 @@
-# VALU issue cost by two methods (tools/ubench/op_cost.hip: HIP events / nominal clock; op_cost2.hip: in-kernel s_memtime /
-# clock measured from an s_nop block) + the clock a third way: GRBM_GUI_ACTIVE per kernel of the same binary (rocprofv3 --pmc,
+# VALU issue cost by two methods (tools/ubench/op_cost.hip: HIP events / nominal clock; op_cost2.hip: in-kernel s_memtime per wave,
+# grouped by the SIMD the wave ran on — cycles, no clock assumed) + the clock another way: GRBM_GUI_ACTIVE per kernel of the same binary (rocprofv3 --pmc,
 # its own pass) over the kernel's duration from the kernel trace.   gpurun -- 'bash tools/gpu_op_cost.sh'
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 make -C tools/ubench op_cost op_cost2 > /dev/null
@@ -8,7 +8,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out/op_cost; rm -rf $O; mkdir -p $O
 echo "== method 1: whole launches by HIP events, cycles at a NOMINAL 2.4 GHz (tools/ubench/op_cost.hip)"
 tools/ubench/op_cost
 echo
-echo "== method 2: every wave times its own block with s_memtime; clock measured by an s_nop block (tools/ubench/op_cost2.hip)"
+echo "== method 2: every wave times its own block with s_memtime (shader-clock ticks) and reports its SIMD (tools/ubench/op_cost2.hip)"
 tools/ubench/op_cost2
 } > $O/op_cost.txt 2>&1
 cd /tmp && rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $O/pmc -o p --output-format csv -- $GRAFT_REPO_ROOT/tools/ubench/op_cost2 > /dev/null 2> $O/pmc.err
@@ -19,7 +19,7 @@ O = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "op_cost")
 cnt = glob.glob(O + "/pmc/**/*counter_collection.csv", recursive=True)
 trc = glob.glob(O + "/pmc/**/*kernel_trace.csv", recursive=True)
 print()
-print("== clock a third way: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel duration, rocprofv3 --pmc pass over op_cost2")
+print("== clock another way: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel duration, rocprofv3 --pmc pass over op_cost2")
 if not cnt or not trc:
     print("no counter output", cnt, trc)
 else:
