@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
 // K3 with uniform scaling (0 < decay < 1), bin-order form.  Counter (d,p) right after stream element j
 // is C(j) = w*C(j-1) + (v_j if element j hits it).  Over a bin segment holding elements [e0,e1):
 //     C(e1-1) = w^(e1-e0) * C(e0-1) + sum{ v_j * w^(e1-1-j) : hits }
-//   k_cmsd_segsum : the sum (one w^x per element, LDS fp64 atomics) and the factor per segment
+//   k_cmsd_segsum : the sum (one w^x per element; wave d owns row d: ascending bin order, reproducible) and the factor per segment
 //   k_cmsd_base   : C in front of every (spectrum, segment), advancing the persistent fp64 counters
 //   k_cmsd_freq   : replay in bin order with LDS counters normalised to a moving base element; zero bins are
 //                   transparent; same-counter lanes of a 64-bin chunk resolve in lane order
@@ -246,32 +246,35 @@ __global__ __launch_bounds__(512) void k_cmsd_segsum(const uint32_t *__restrict_
     const uint32_t e1 = b1 < (int64_t)B ? ei[b1] : etot[t];
     const double lnw = log(omega);                                // w^x = exp(x ln w): |x ln w| * 2^-53 relative, far below the tolerance
     if (tid == 0) { segfac[(size_t)t * CMS_SEGS + seg] = exp((double)(e1 - e0) * lnw); sege0[(size_t)t * CMS_SEGS + seg] = e0; }
-    // four bins per thread and step, every global load of the step (count, element index, the rows' counter
-    // positions) requested before the first is used: with one workgroup per CU their latency was the kernel's time
+    // Deterministic sums (round 3; before, every thread added its bins' terms to all rows with fp64 LDS atomics, in an order
+    // that depended on the timing of the 8 waves: weights reproducible to ~1e-13, not to the bit).  Now the terms of a group of
+    // 512 bins are computed once, one per thread, into an LDS staging array, and row d's counters are touched by wave d ONLY:
+    // it walks the group's 8 chunks in order and adds lane l's term to its counter with one LDS atomic per chunk — same-address
+    // lanes of one instruction resolve in the hardware's fixed lane order, successive instructions of a wave in program order,
+    // so every counter receives its terms in ascending bin order, the same in every run.  Zero bins are transparent.
+    double *stage = ladd + (size_t)depth * width;                 // [2][512]
+    const int d = tid >> 6, lane = tid & 63;
+    const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
     const int64_t bend = b1 < (int64_t)B ? b1 : (int64_t)B;
-    constexpr int U = 4;
-    for (int64_t bb = b0 + tid; bb < bend; bb += (int64_t)U * blockDim.x) {
-        uint32_t h[U], e[U]; uint16_t pp[U][8];
+    const int ngroups = (int)((bend - b0 + 511) / 512);
+    uint32_t nh = 0, ne = 0;
+    { const int64_t b = b0 + tid; if (b < bend) { nh = hist[b]; ne = ei[b]; } }
+    for (int g = 0; g < ngroups; g++) {
+        const uint32_t h = nh, e = ne;
+        const int64_t gb = b0 + (int64_t)g * 512;
+        { const int64_t b = gb + 512 + tid; nh = 0; ne = 0; if (b < bend) { nh = hist[b]; ne = ei[b]; } }   // next group's loads in flight
+        uint16_t pp[8];
+        if (d < depth) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int64_t b = bb + (int64_t)u * blockDim.x;
-            const bool ok = b < bend;
-            h[u] = ok ? hist[b] : 0u; e[u] = ok ? ei[b] : 0u;
-#pragma unroll
-            for (int d = 0; d < 8; d++) pp[u][d] = (ok && d < depth) ? pos16[(size_t)d * B + b] : (uint16_t)0;
+            for (int c = 0; c < 8; c++) { const int64_t b = gb + c * 64 + lane; pp[c] = b < bend ? pd[b] : (uint16_t)0; }
         }
+        stage[(g & 1) * 512 + tid] = h ? (double)h * exp((double)(e1 - 1u - e) * lnw) : 0.0;
+        __syncthreads();                                          // (one barrier per group: the other half is written next)
+        if (d < depth) {
+            const double *sg = stage + (g & 1) * 512;
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            if (h[u]) {
-                const double wgt = (double)h[u] * exp((double)(e1 - 1u - e[u]) * lnw);
-                if (depth <= 8) {
-#pragma unroll
-                    for (int d = 0; d < 8; d++) if (d < depth) atomicAdd(&ladd[d * width + pp[u][d]], wgt);
-                } else {
-                    const int64_t b = bb + (int64_t)u * blockDim.x;
-                    for (int d = 0; d < depth; d++) atomicAdd(&ladd[d * width + pos16[(size_t)d * B + b]], wgt);
-                }
-            }
+            for (int c = 0; c < 8; c++) { const double wv = sg[c * 64 + lane]; if (wv != 0.0) atomicAdd(&ladd[d * width + pp[c]], wv); }
+        }
     }
     __syncthreads();
     for (int i = tid; i < depth * width; i += blockDim.x) {
@@ -551,7 +554,8 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
                                 int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb) {
     const int chunks = (fb.num_bins + 63) / 64;
     const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
-    const size_t lds1 = (size_t)depth * width * 8;
+    if (depth > 8) return hipErrorInvalidValue;                     // k_cmsd_segsum: one wave per row, 8 waves
+    const size_t lds1 = (size_t)depth * width * 8 + (size_t)2 * 512 * 8;
     const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * CMSD_FG * 64 * 8;
     static bool attr_set = false;
     if (!attr_set) {

@@ -493,6 +493,27 @@ def test_k31_concept_drift_against_oracle(decay, batch, monkeypatch):
     g.close(); o.close()
 
 
+def test_concept_drift_is_reproducible_to_the_bit():
+    """Drift mode (k = 31, decay 0.02: fp64 count-min counters with uniform scaling, countmin.go:141-147) gives the same
+    `mins`, `weights` AND counters bit for bit in repeated runs: the segment sums of k_cmsd_segsum are formed in a fixed
+    order (one wave per count-min row, ascending bins) — until round 3 fp64 LDS atomics of eight waves added in whatever
+    order they arrived (~1e-13 between runs)."""
+    from hulk_amd import synth
+    bases, offsets = synth.reads_numpy(0, 60_000, 150)
+    outs = []
+    for _ in range(5):
+        g = gpu().GpuSketcher(31, 9, 64, interval=20_000, decay_ratio=0.02)
+        g.add_reads(bases, offsets)
+        g.finish()
+        m, w = g.sketch()
+        outs.append((m, w, g.cms()))
+        g.close()
+    for m, w, c in outs[1:]:
+        assert np.array_equal(m, outs[0][0])
+        assert np.array_equal(w.view(np.uint64), outs[0][1].view(np.uint64))
+        assert np.array_equal(c.view(np.uint64), outs[0][2].view(np.uint64))
+
+
 def _numpy_histosketch(hist, r, c, b):
     """One flush of a histogram through count-min (countmin.go:103-147, no decay) and AddElement
     (histosketch.go:129-155) for ARBITRARY tables r, c, b [S][B] — a numpy restatement for the external-table test."""
