@@ -58,7 +58,7 @@ C2_READS = 10_000_000        # BASELINE configs[1]
 C4_READS_PER_RANK = int(os.environ.get("HULK_BENCH_C4_READS_PER_RANK", "50000000"))   # BASELINE configs[3]: 400 M reads on 8 GPUs
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 SIMDS, CLOCK_GHZ, VALU_CYCLES = 256 * 4, 2.4, 2   # MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op issues over 2 cycles
-PMC_PROFILE = os.path.join("profiles", "r02_pmc.json")
+PMC_PROFILE = os.path.join("profiles", "r03_pmc.json")
 ISA_MIX = os.path.join("profiles", "r03_isa_mix.json")      # tools/isa_mix.py over the production kernels, priced by profiles/r03_op_cost.txt
 CLOCK_MEASURED_GHZ = 2.3    # shader clock under VALU load: s_memtime ticks per ns of HIP-event time, tools/ubench/op_cost2.hip (2.1-2.35)
 
@@ -563,7 +563,7 @@ def main():
 
         def valu_roofline(kernel, avg_s):
             """VALU-issue roofline of a launch.  SQ_INSTS_VALU (wave64 VALU instructions per launch) comes from the rocprofv3 PMC
-            pass of this command (profiles/r02_pmc.json); what an instruction costs was measured two independent ways
+            pass of this command (profiles/r03_pmc.json); what an instruction costs was measured two independent ways
             (profiles/r03_op_cost.txt: whole launches by HIP events at the nominal clock, tools/ubench/op_cost.hip; every wave
             timing its own block with s_memtime — shader-clock ticks — grouped by the SIMD it ran on, op_cost2.hip):
             simple VOP2 ops (v_add/sub_u32, v_and/or/xor_b32, v_mov_b32, v_lshrrev_b32, v_mul/add_f32) issue in 2.35 cycles,

@@ -1,7 +1,7 @@
 # everything: GPU test suite, bench line, C3-shaped rate
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/full
 python -m pytest tests -m gpu -q -rf --timeout=900 > gpurun_out/full/pytest.txt 2>&1; tail -8 gpurun_out/full/pytest.txt
-python bench.py --no-cpu-baseline > gpurun_out/full/bench.json 2> gpurun_out/full/bench.err
+python bench.py --no-cpu-baseline --no-e2e > gpurun_out/full/bench.json 2> gpurun_out/full/bench.err
 python - <<'PY'
 import json
 d=json.load(open('gpurun_out/full/bench.json'))
