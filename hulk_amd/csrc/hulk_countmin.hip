@@ -257,24 +257,39 @@ __global__ __launch_bounds__(512) void k_cmsd_segsum(const uint32_t *__restrict_
     const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
     const int64_t bend = b1 < (int64_t)B ? b1 : (int64_t)B;
     const int ngroups = (int)((bend - b0 + 511) / 512);
+    // software pipeline: the terms of group g+1 are computed (VALU: one exp per thread) behind the LDS atomics of group g
+    // (issued first, fire and forget), one barrier per group
+    auto term = [&](uint32_t h, uint32_t e) { return h ? (double)h * exp((double)(e1 - 1u - e) * lnw) : 0.0; };
     uint32_t nh = 0, ne = 0;
     { const int64_t b = b0 + tid; if (b < bend) { nh = hist[b]; ne = ei[b]; } }
-    for (int g = 0; g < ngroups; g++) {
-        const uint32_t h = nh, e = ne;
-        const int64_t gb = b0 + (int64_t)g * 512;
-        { const int64_t b = gb + 512 + tid; nh = 0; ne = 0; if (b < bend) { nh = hist[b]; ne = ei[b]; } }   // next group's loads in flight
-        uint16_t pp[8];
-        if (d < depth) {
+    if (ngroups > 0) stage[tid] = term(nh, ne);
+    { const int64_t b = b0 + 512 + tid; nh = 0; ne = 0; if (b < bend) { nh = hist[b]; ne = ei[b]; } }
+    uint16_t pn[8];
+    auto fetch_pos = [&](int g) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) { const int64_t b = gb + c * 64 + lane; pp[c] = b < bend ? pd[b] : (uint16_t)0; }
-        }
-        stage[(g & 1) * 512 + tid] = h ? (double)h * exp((double)(e1 - 1u - e) * lnw) : 0.0;
-        __syncthreads();                                          // (one barrier per group: the other half is written next)
+        for (int c = 0; c < 8; c++) { const int64_t b = b0 + (int64_t)g * 512 + c * 64 + lane; pn[c] = (d < depth && b < bend) ? pd[b] : (uint16_t)0; }
+    };
+    fetch_pos(0);
+    __syncthreads();
+    for (int g = 0; g < ngroups; g++) {
+        uint16_t pp[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) pp[c] = pn[c];
+        if (g + 1 < ngroups) fetch_pos(g + 1);
         if (d < depth) {
             const double *sg = stage + (g & 1) * 512;
+            double wv[8];
 #pragma unroll
-            for (int c = 0; c < 8; c++) { const double wv = sg[c * 64 + lane]; if (wv != 0.0) atomicAdd(&ladd[d * width + pp[c]], wv); }
+            for (int c = 0; c < 8; c++) wv[c] = sg[c * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 8; c++) if (wv[c] != 0.0) atomicAdd(&ladd[d * width + pp[c]], wv[c]);
         }
+        if (g + 1 < ngroups) {
+            const uint32_t h = nh, e = ne;
+            { const int64_t b = b0 + (int64_t)(g + 2) * 512 + tid; nh = 0; ne = 0; if (b < bend) { nh = hist[b]; ne = ei[b]; } }
+            stage[((g + 1) & 1) * 512 + tid] = term(h, e);
+        }
+        __syncthreads();
     }
     __syncthreads();
     for (int i = tid; i < depth * width; i += blockDim.x) {
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
     constexpr unsigned long long INF_BITS = 0x7FF0000000000000ull;
     double *lval = (double *)smem;                                               // [depth][width] normalised counters
     unsigned long long *smin = (unsigned long long *)(lval + (size_t)depth * width);   // [2][GB] min over the rows, as bits
-    __shared__ double tabf_lo[64], tabi_lo[64], tabf_hi[66], tabi_hi[66];        // w^x, w^-x for x = lo + 64 hi
+    __shared__ double tabf_lo[64], tabf_hi[66];                                   // w^x for x = lo + 64 hi
     const int seg = blockIdx.x, t = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;
     const uint32_t gomask = batch_gomask(st, fb);
@@ -357,8 +372,8 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
             lval[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];       // value as of element e0 - 1: see `base` below
         }
         for (int i = tid; i < 2 * GB; i += blockDim.x) smin[i] = INF_BITS;
-        if (tid < 64) { tabf_lo[tid] = exp((double)tid * lnw); tabi_lo[tid] = exp(-(double)tid * lnw); }
-        if (tid >= 64 && tid < 64 + 66) { const int x = tid - 64; tabf_hi[x] = exp((double)(64 * x) * lnw); tabi_hi[x] = exp(-(double)(64 * x) * lnw); }
+        if (tid < 64) tabf_lo[tid] = exp((double)tid * lnw);
+        if (tid >= 64 && tid < 64 + 66) { const int x = tid - 64; tabf_hi[x] = exp((double)(64 * x) * lnw); }
     }
     __syncthreads();
     uint32_t *hist = hists + (size_t)slot * B;
@@ -410,8 +425,18 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
                     }
                 }
                 const uint32_t x = h ? (uint32_t)(j - base) : 0u;                // 1 .. period + 64 (unused for bins not in the stream)
-                const double wf = tabf_lo[x & 63u] * tabf_hi[x >> 6], wi = tabi_lo[x & 63u] * tabi_hi[x >> 6];
-                // resolve the lanes in same-counter order: a lane is computed once its predecessor is
+                // w^x from the two tables; w^-x as its reciprocal on the VALU (the kernel is bound by the LDS pipe: the two
+                // table reads this replaces were 2 of its ~11 LDS instructions per row and chunk — any pair with wf * wi = 1
+                // to rounding serves, the counter is only ever kept as S = C * wi and used as S * wf')
+                const double wf = tabf_lo[x & 63u] * tabf_hi[x >> 6];
+                double wi;
+                {
+                    double y = __builtin_amdgcn_rcp(wf), e = __builtin_fma(-wf, y, 1.0);
+                    y = __builtin_fma(y, e, y); e = __builtin_fma(-wf, y, 1.0);
+                    wi = __builtin_fma(y, e, y);
+                }
+                // resolve the lanes in same-counter order: a lane is computed once its predecessor is (whether it is comes
+                // from the wave's ballot of finished lanes, not from a second register exchange)
                 const uint32_t prev = m & 0x7fu;
                 bool ready = false; double Sn = 0.0;
                 if (prev >= 64u) {                                  // first lane of the chunk on this counter: LDS state
@@ -420,14 +445,16 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
                     else Sn = S0;
                     ready = true;
                 }
-                while (__any((int)!ready)) {
+                unsigned long long done = __ballot(ready);
+                while (done != ~0ull) {
                     const double ps = __shfl(Sn, (int)(prev & 63u));
-                    const int pr = __shfl((int)ready, (int)(prev & 63u));
+                    const bool pr = (done >> (prev & 63u)) & 1ull;
                     if (!ready && pr) {
                         if (h) { const double C = ps * wf + (double)h; Sn = C * wi; atomicMin(&my[c * 64 + lane], (unsigned long long)__double_as_longlong(C)); }
                         else Sn = ps;
                         ready = true;
                     }
+                    done = __ballot(ready);
                 }
                 if ((m & 0x80u) && b < (int64_t)B) rv[p] = Sn;
             }
