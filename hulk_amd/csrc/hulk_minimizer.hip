@@ -5,6 +5,8 @@
 // All kernels are wave64 code for CDNA4; none of them has a CPU or library fallback.
 #include "hulk_device.h"
 
+#include <type_traits>
+
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -257,13 +259,13 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
 // Eligible reads: no code-4 base, 1 <= w <= WM <= 16, k-mer positions <= 16*w, length <= 256,
 // <= 64 run starts.  Anything else is marked in the region's deferred mask and handled by k_minimizer_bin.
 //
-// LDS per group: tab[128] u64 | pk[20] u32      per wave: q[192] u64      per block: lut[256]
+// LDS per group: tab[128] u64 | pk[20] u32 | pkn[20] u32 (code-4 flags)      per wave: raw ASCII of its 16 reads      per group: cs[64] u64
 // ------------------------------------------------------------------------------------------
 #ifndef HULK_FAST_TAB
 #define HULK_FAST_TAB 128
 #endif
 #ifndef HULK_FAST_PAD
-#define HULK_FAST_PAD 2048
+#define HULK_FAST_PAD 0
 #endif
 constexpr int FAST_TAB = HULK_FAST_TAB;       // set slots per 16-lane group (a pair of groups sharing a read uses both tables)
 constexpr int FAST_PAD = HULK_FAST_PAD;
@@ -391,13 +393,23 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     constexpr int RPI = PAIR ? 2 : 4;                              // reads per iteration of a wave
     constexpr bool DX = KC != 0 && WEQ && 2 * (KC + WM - 1) <= 64;     // direct k-mer extraction (phase A)
     constexpr bool HP = FM && WEQ && KC >= 17 && KC <= 27;                    // hash + packing in explicit dword form
+    // NV: reads with `N` (code 4, minimizer.go:118-122) stay in this kernel.  The reference does not special-case code 4:
+    // `f = (f<<2 | c) & mask` ORs bit 2 into the PREVIOUS base's pair, `r = r>>2 | (3^c) << shift` (never masked) puts 7 at the
+    // top.  With code 0 stored for such a base and N(p) = "base p has code 4" this is closed form (derived for k_minimizer_bin,
+    // which checks it against the literal recurrence): in f the pair of base p gets |= N(p+1) for every base of the k-mer but
+    // its last, in r the pair of base p gets |= N(p-1) for every base of the k-mer, bit 2k of r is set when the k-mer's last
+    // base is an N, and f == r has to be tested for odd k too.  An iteration of the wave takes this variant of phase A only
+    // when one of its 4 reads has an N (wave-uniform branch): +13 instructions per k-mer position there, nothing elsewhere.
+    // Any other byte outside ACGTacgt still defers the read to k_minimizer_bin and its full seq_nt4_table.
+    constexpr bool NV = DX && HP && !PAIR && 2 * (KC + WM) <= 64;
     const int half = PAIR ? (grp & 1) : 0;                         // which half of the read this group takes
     const int sub = PAIR ? ((grp & 3) >> 1) : (grp & 3);           // read of the iteration
     const int32_t posoff = half ? 16 * w - (w - 1) : 0;            // first k-mer position of this group
     uint64_t *tab = (uint64_t *)(smem + FAST_PAD) + (size_t)(PAIR ? (grp & ~1) : grp) * FAST_TAB;   // the per-read set
     uint32_t *pk32 = (uint32_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8) + grp * 20;
-    uint32_t *raw32 = (uint32_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8 + 16 * 20 * 4) + (size_t)wid * (RAWB / 4);
-    uint64_t *cs = (uint64_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8 + 16 * 20 * 4 + 4 * RAWB) + (size_t)grp * FAST_CAND;
+    uint32_t *pkn32 = (uint32_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8 + 16 * 20 * 4) + grp * 20;   // "code 4" flags, pk's layout
+    uint32_t *raw32 = (uint32_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8 + 2 * 16 * 20 * 4) + (size_t)wid * (RAWB / 4);
+    uint64_t *cs = (uint64_t *)(smem + FAST_PAD + 16 * FAST_TAB * 8 + 2 * 16 * 20 * 4 + 4 * RAWB) + (size_t)grp * FAST_CAND;
     {   // every group empties its OWN table (a pair's set spans both of its groups' tables)
         uint64_t *own = (uint64_t *)(smem + FAST_PAD) + (size_t)grp * FAST_TAB;
 #pragma unroll
@@ -505,10 +517,10 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
         const int32_t nposg = npos - posoff < 0 ? 0 : (npos - posoff > 16 * w ? 16 * w : npos - posoff);
         if (dbg & 64u) { sink += a32 + (uint32_t)npos + hslot; continue; }   // ablation: per-iteration bookkeeping only
         // ---- stage 16 bases per lane: ASCII -> 2-bit pack (one dword per lane), detect code 4
-        bool sawN = false;
+        bool sawN = false, softN = false;                      // sawN: a byte this kernel cannot take; softN (NV): an `N`
         if (act && !defer) {
             const int32_t p = 16 * gl;
-            uint32_t pack = 0;
+            uint32_t pack = 0, npack = 0;
             if (p < Lg) {
                 const uint32_t ro = a32 + (uint32_t)posoff + (uint32_t)p;     // first of the lane's bytes, from the wave's first base
                 unsigned sh;
@@ -528,8 +540,8 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                 }
                 // ASCII -> 2-bit, four bases per dword, no table: fold the case, code = (c >> 1 ^ c >> 2) & 3
                 // (A 0, C 1, G 2, T 3), and prove it by mapping the codes back to letters with one v_perm_b32:
-                // any byte that does not come back (N, U, 0..3, anything else) defers the read to the generic
-                // kernel, which has the full nt4 table.  (c * 0x01041040) >> 24 gathers the four codes of a dword
+                // any byte that does not come back (N, U, 0..3, anything else) is looked at below.
+                // (c * 0x01041040) >> 24 gathers the four codes of a dword
                 // into one byte.  Bytes past the read's end are the next read's (or zero): they only reach k-mer
                 // positions that are not reported, and at worst defer a read that did not need it.
                 uint32_t bad = 0;
@@ -542,29 +554,45 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     bad |= __builtin_amdgcn_perm(0u, 0x54474341u, c) ^ up;
                     pack |= ((c * 0x01041040u) >> 24) << (8 * x);
                 }
-                if (Lg - p < 16 && lastwave && idx + 1 == nrd) {
-                    // the last read of the call: what follows it is not a read; test its own bytes only
-                    const int nv = (int)(Lg - p);
-                    bad = 0;
+                // the last read of the call: what follows it is not a read; only its own bytes count
+                const bool lastread = Lg - p < 16 && lastwave && idx + 1 == nrd;
+                if (bad != 0 || lastread) {                        // rare: look at the bytes one by one
+                    const int nv = lastread ? (int)(Lg - p) : 16;
+                    uint32_t hard = 0;
 #pragma unroll
                     for (int x = 0; x < 4; x++) {
-                        const uint32_t by = __builtin_amdgcn_alignbit(d[x + 1], d[x], sh);   // (sh = 0: d[x])
+                        const uint32_t by = __builtin_amdgcn_alignbit(d[x + 1], d[x], sh);
                         const uint32_t up = by & 0xDFDFDFDFu, e = up >> 1, c = (e ^ (e >> 1)) & 0x03030303u;
                         const int nb = nv - 4 * x;
                         const uint32_t m = nb >= 4 ? ~0u : nb <= 0 ? 0u : (1u << (8 * nb)) - 1u;
-                        bad |= (__builtin_amdgcn_perm(0u, 0x54474341u, c) ^ up) & m;
+                        const uint32_t mm = (__builtin_amdgcn_perm(0u, 0x54474341u, c) ^ up) & m;      // bytes that did not come back
+                        if (NV) {
+                            // 0x80 per byte: it is an N / n (which the code formula maps to 0, the code stored for a code-4
+                            // base) — or it is something else this kernel does not take
+                            const uint32_t tN = up ^ 0x4E4E4E4Eu;
+                            const uint32_t isN = ~(((tN & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | tN | 0x7F7F7F7Fu) & m;
+                            const uint32_t nz = (((mm & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | mm) & 0x80808080u;
+                            hard |= nz & ~isN;
+                            const uint32_t b4 = isN >> 7;                                  // bits 0, 8, 16, 24
+                            const uint32_t fl = (b4 & 1u) | ((b4 >> 6) & 4u) | ((b4 >> 12) & 16u) | ((b4 >> 18) & 64u);   // -> bits 0, 2, 4, 6
+                            npack |= fl << (8 * x);
+                        } else hard |= mm;
                     }
+                    sawN = hard != 0;
+                    softN = NV && npack != 0;
                 }
-                sawN = bad != 0;
             }
             pk32[gl] = pack;
             if (gl < 4) pk32[16 + gl] = 0;                     // slack for 3-dword window reads
+            if (NV) { pkn32[gl] = npack; if (gl < 4) pkn32[16 + gl] = 0; }
         }
         {
-            // code 4 anywhere in the read defers it as a whole (both groups of a pair must agree)
+            // a byte the kernel cannot take anywhere in the read defers it as a whole (both groups of a pair must agree)
             const uint32_t gN = PAIR ? (uint32_t)(__ballot(sawN) >> (lane & 32)) : (uint32_t)(__ballot(sawN) >> gsh) & 0xffffu;
             if (gN) defer = true;
         }
+        // NV: does any read of this iteration carry an N?  (wave-uniform; reads deferred for another reason do not count)
+        const bool waveN = NV && __ballot(softN && !defer) != 0ull;
         wave_sync();
         if (dbg & 32u) { sink += pk32[gl]; wave_sync(); continue; }      // ablation: staging only
 
@@ -613,6 +641,22 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     nb = (uint32_t)(lo >> o);
                 }
             }
+            // NV: the flag windows of the N variant.  Xn = flags of bases p0-1 .. p0+NBW-1 at bits 0, 2, 4, ... (for r, bit 2k
+            // included); Hb = flags of bases p0+1 .. in the forward (first base on top) layout of Bb, one pair down (for f).
+            uint64_t Xn = 0, Hb = 0;
+            if (NV && waveN) {
+                constexpr int NBW = KC + WM - 1;
+                const uint32_t bo = 2u * (uint32_t)p0, nbo = p0 > 0 ? bo - 2u : 0u, d = nbo >> 5, o = nbo & 31u;
+                const uint64_t lo = (uint64_t)pkn32[d] | ((uint64_t)pkn32[d + 1] << 32);
+                Xn = o ? (lo >> o) | ((uint64_t)pkn32[d + 2] << (64 - o)) : lo;
+                if (p0 == 0) Xn <<= 2;
+                Xn &= (NBW + 1 < 32) ? ((1ull << (2 * (NBW + 1))) - 1) : ~0ull;
+                const uint64_t Fn = (Xn >> 4) & ((1ull << (2 * (NBW - 1))) - 1);      // pair u: N(p0 + u + 1), u < NBW - 1
+                const uint64_t rv = __brevll(Fn) >> (64 - 2 * NBW);
+                Hb = ((rv >> 1) & 0x5555555555555555ull) | ((rv & 0x5555555555555555ull) << 1);
+            }
+            auto phaseA = [&](auto nvx_tag) {
+            constexpr bool NVX = decltype(nvx_tag)::value;
 #pragma unroll
             for (int t = 0; t < WM; t++) {
                 if (DX) {
@@ -622,8 +666,17 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     const uint32_t bl = (uint32_t)Bb, cl = (uint32_t)Cl;
                     uint32_t bh = (uint32_t)(Bb >> 32), ch = (uint32_t)(Cl >> 32);
                     asm("" : "+v"(bh), "+v"(ch));   // opaque: or hipcc re-fuses the dwords into 64-bit shifts + masks
-                    const uint32_t fl = sf ? __builtin_amdgcn_alignbit(bh, bl, sf) : bl, fh = __builtin_amdgcn_ubfe(bh, sf, HB);
-                    const uint32_t rl = sr ? __builtin_amdgcn_alignbit(ch, cl, sr) : cl, rh = __builtin_amdgcn_ubfe(ch, sr, HB);
+                    uint32_t fl = sf ? __builtin_amdgcn_alignbit(bh, bl, sf) : bl, fh = __builtin_amdgcn_ubfe(bh, sf, HB);
+                    uint32_t rl = sr ? __builtin_amdgcn_alignbit(ch, cl, sr) : cl, rh = __builtin_amdgcn_ubfe(ch, sr, HB);
+                    if (NVX) {
+                        // f: pair of base p |= N(p+1) for every base but the k-mer's last (the bottom pair);
+                        // r: pair of base p |= N(p-1), and bit 2k = N(last base)
+                        const uint32_t hl = (uint32_t)Hb, xl = (uint32_t)Xn;
+                        uint32_t hh = (uint32_t)(Hb >> 32), xh = (uint32_t)(Xn >> 32);
+                        asm("" : "+v"(hh), "+v"(xh));
+                        fl |= (sf ? __builtin_amdgcn_alignbit(hh, hl, sf) : hl) & ~3u; fh |= __builtin_amdgcn_ubfe(hh, sf, HB);
+                        rl |= sr ? __builtin_amdgcn_alignbit(xh, xl, sr) : xl; rh |= __builtin_amdgcn_ubfe(xh, sr, HB + 1);
+                    }
                     f = ((uint64_t)fh << 32) | fl;
                     r = ((uint64_t)rh << 32) | rl;
                 } else if (t) {
@@ -632,7 +685,8 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     r = (r >> 2) | ((3ull ^ c) << shift);
                 }
                 if (t < w) {
-                    // (a canonical k-mer has 2k <= 62 bits for every legal k: the f64 minimum is exact whatever FM says)
+                    // (a canonical k-mer has 2k <= 62 bits for every legal k: the f64 minimum is exact whatever FM says;
+                    //  with an N as its last base r carries bit 2k: still far below 2^62, and then f is the minimum)
                     const uint64_t canon = umin64<true>(f, r);
                     int32_t span = span0 + t;
                     if (span >= k) span = k;
@@ -640,12 +694,14 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     if (HP && !(dbg & 16u)) x = hash64_pack_kc<HP ? KC : 21>(canon, (uint32_t)span);
                     else if (KEY5) x = (hash64(canon, mask) & 0x00FFFFFFFFFFFFFFull) << 5 | (uint64_t)(uint32_t)span;
                     else x = ((dbg & 16u) ? canon * 0x9E3779B97F4A7C15ull : hash64_fm<FM>(canon, mask)) << 8 | (uint64_t)(int64_t)span;
-                    // f == r (a k-mer that is its own reverse complement: even k only, reads with N never get
-                    // here) is skipped by the reference: the position neither reports nor takes part in a window
-                    if (!(k & 1) && f == r) { x = XN; validbits &= ~(1u << t); }
+                    // f == r (a k-mer that is its own reverse complement: even k only — or any k once code-4 flags are in
+                    // play) is skipped by the reference: the position neither reports nor takes part in a window
+                    if ((NVX || !(k & 1)) && f == r) { x = XN; validbits &= ~(1u << t); }
                     X[t] = x;
                 }
             }
+            };
+            if (NV && waveN) phaseA(std::true_type{}); else phaseA(std::false_type{});
         }
         if (dbg & 8u) {
 #pragma unroll
@@ -956,7 +1012,7 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
 }
 
 size_t minimizer_fast_lds(uint32_t, bool pair) {
-    return FAST_PAD + 16 * (size_t)FAST_TAB * 8 + 16 * 20 * 4 + 4 * (size_t)(pair ? FAST_RAW_PAIR : FAST_RAW) + 16 * (size_t)FAST_CAND * 8;
+    return FAST_PAD + 16 * (size_t)FAST_TAB * 8 + 2 * 16 * 20 * 4 + 4 * (size_t)(pair ? FAST_RAW_PAIR : FAST_RAW) + 16 * (size_t)FAST_CAND * 8;
 }
 
 hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,

@@ -112,6 +112,42 @@ def test_n_lowercase_and_min_length():
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("w", [9, 4])
+def test_fast_kernel_instance_with_n_bases(w):
+    """Reads with `N` stay in the short-read kernel's k = 21 instance (code 4 in closed form: minimizer.go:118-122 does not
+    special-case it — bit 2 of the code spills into the neighbouring base's pair of f, r keeps bit 2k): one N at every
+    position of a 150 bp read, lower-case n, runs of N, N at both ends, several N per read, an N in the first bases of the
+    NEXT read (the kernel stages past a read's end), reads of the minimum length, and reads that carry an N next to a byte
+    the kernel does not take (those still go to the generic kernel) — spectrum, minimizer count and sketch against the oracle."""
+    rng = np.random.default_rng(2100 + w)
+    k, L = 21, 150
+    base = random_reads(rng, 1, L)[0]
+    seqs = []
+    for p in range(L):                                   # one N at every position
+        b = bytearray(random_reads(rng, 1, L)[0]); b[p] = ord("N" if p % 3 else "n"); seqs.append(bytes(b))
+    for _ in range(400):                                 # several N, runs of N
+        b = bytearray(random_reads(rng, 1, L)[0])
+        for q in rng.integers(0, L, size=int(rng.integers(1, 6))):
+            b[q] = ord("N")
+        if rng.random() < 0.3:
+            a = int(rng.integers(0, L - 12)); b[a:a + int(rng.integers(2, 12))] = b"N" * 11
+        seqs.append(bytes(b[:L]))
+    seqs += [b"N" + base[1:], base[:-1] + b"N", b"N" + base[1:-1] + b"N", b"N" * L, base, b"NN" + base[2:]]
+    seqs += random_reads(rng, 300, (w + k - 1, 80), b"ACGTN")          # short and ragged, 20 % N
+    seqs += random_reads(rng, 300, L, b"ACGTacgtNn")
+    for _ in range(100):                                 # an N and a byte outside ACGTN in the same read
+        b = bytearray(random_reads(rng, 1, L)[0]); b[int(rng.integers(0, L))] = ord("N"); b[int(rng.integers(0, L))] = ord("R"); seqs.append(bytes(b))
+    seqs += random_reads(rng, 500, L)                    # clean reads in between: waves with and without an N
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    o, g = run_both(seqs, k, w, 8, batches=3)
+    assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32))
+    assert o.counters()["n_minimizers"] == g.counters()["n_minimizers"]
+    o.finish(); g.finish()
+    assert_same_sketch(o, g)
+    g.close(); o.close()
+
+
 def test_even_k_symmetric_kmers_skipped():
     """even k: palindromic k-mers (f == r) are skipped (minimizer.go:145)."""
     rng = np.random.default_rng(3)
