@@ -88,7 +88,8 @@ def cpu_baseline(sample_intervals=4):
     n = sample_intervals * INTERVAL
     bases, offsets = synth.reads_numpy(0, n, READ_LEN)
     nproc = os.cpu_count() or 1
-    nthreads = min(nproc, 32)       # the minimizer stage is < 5 % of the CPU time; more threads only add start-up cost
+    nthreads = min(nproc, 64)       # every host core up to 64 threads: the minimizer stage is < 5 % of the CPU time, and a thread
+                                    # per logical core of a 256-thread box only adds start-up cost (32 -> 64 threads: no change)
     # ---- leg (i): one thread
     o = pyorc.Sketcher(K, W, S, 0, 1.0, INTERVAL)          # CWS table generation: not timed (one-off, as in the GPU figure)
     t0 = time.perf_counter()
