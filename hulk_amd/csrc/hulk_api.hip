@@ -122,6 +122,9 @@ struct hulk_ctx {
         uint32_t rank = 0, world = 1;
         ncclComm_t nccl = nullptr;
         hulk_exchange_fn fn = nullptr; void *user = nullptr;
+        // the collectives run on a stream of their own at the HIGHEST priority: a few workgroups that must not queue behind the
+        // thousands of pending minimizer workgroups of the next step (the flush stream around them has the lowest)
+        hipStream_t stream = nullptr; hipEvent_t ev_ready = nullptr, ev_done = nullptr;
         uint32_t *d_hdr = nullptr;                      // [world][SHARD_HDR]: {-, need_full, used bins per interval ...}
         uint32_t *d_delta = nullptr;                    // [world][T][depth * width] count-min increments per interval
         uint32_t *d_gather = nullptr; size_t gather_words = 0;   // [world][T][num_bins] spectra of a full exchange
@@ -736,6 +739,18 @@ int comm_allreduce_u32(hulk_ctx *c, hipStream_t s, uint32_t *d_buf, size_t words
     return HULK_OK;                                             // loopback / no peers: the identity
 }
 
+// what stream s has queued so far -> the collectives' stream, and back
+int comm_enter(hulk_ctx *c, hipStream_t s) {
+    HIPCHK(c, hipEventRecord(c->comm.ev_ready, s));
+    HIPCHK(c, hipStreamWaitEvent(c->comm.stream, c->comm.ev_ready, 0));
+    return HULK_OK;
+}
+int comm_leave(hulk_ctx *c, hipStream_t s) {
+    HIPCHK(c, hipEventRecord(c->comm.ev_done, c->comm.stream));
+    HIPCHK(c, hipStreamWaitEvent(s, c->comm.ev_done, 0));
+    return HULK_OK;
+}
+
 // The kernels of one flush: `fb.count` consecutive spectra of `hist` (starting at fb.ring_base) through count-min + CWS, on stream s.
 int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &fb) {
     HIPCHK(c, launch_count_used(s, hist, c->d_state, fb));
@@ -790,7 +805,9 @@ int issue_flush(hulk_ctx *c, hipEvent_t gate = nullptr) {
     if (!no_overlap_mode() && gate) HIPCHK(c, hipStreamWaitEvent(s, gate, 0));
     uint32_t *hist = c->d_hist + (size_t)ring * (size_t)c->ring_n * (size_t)c->B;
     if (c->deferred.allreduce) {                                 // hulk_step_sliced: sum the ranks' spectra first
-        const int rc = comm_allreduce_u32(c, s, hist + (size_t)fb.ring_base * (size_t)c->B, (size_t)fb.count * (size_t)c->B);
+        int rc = comm_enter(c, s);
+        if (rc == HULK_OK) rc = comm_allreduce_u32(c, c->comm.stream, hist + (size_t)fb.ring_base * (size_t)c->B, (size_t)fb.count * (size_t)c->B);
+        if (rc == HULK_OK) rc = comm_leave(c, s);
         if (rc != HULK_OK) return rc;
     }
     { const int rc = flush_kernels(c, s, hist, fb); if (rc != HULK_OK) return rc; }
@@ -990,6 +1007,9 @@ void hulk_destroy(hulk_ctx *c) {
         hipFree(m.d_hdr); hipFree(m.d_delta); hipFree(m.d_gather); hipFree(m.d_sk);
         for (int i = 0; i < 2; i++) { if (m.h_hdr[i]) hipHostFree(m.h_hdr[i]); if (m.ev_hdr[i]) hipEventDestroy(m.ev_hdr[i]); }
         if (m.h_stage) hipHostFree(m.h_stage);
+        if (m.ev_ready) hipEventDestroy(m.ev_ready);
+        if (m.ev_done) hipEventDestroy(m.ev_done);
+        if (m.stream) { hipStreamSynchronize(m.stream); hipStreamDestroy(m.stream); }
     }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -1400,6 +1420,13 @@ int comm_setup(hulk_ctx *c, int kind, uint32_t rank, uint32_t world) {
     HIPCHK(c, dalloc(&m.d_delta, (size_t)world * c->T * NC));
     HIPCHK(c, dalloc(&m.d_sk, (size_t)world * (2 + 2 * (size_t)c->S)));
     HIPCHK(c, hipMemset(m.d_hdr, 0, (size_t)world * SHARD_HDR * 4));
+    {
+        int lo = 0, hi = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(c, hipStreamCreateWithPriority(&m.stream, hipStreamNonBlocking, hi));   // `hi` = greatest priority
+        HIPCHK(c, hipEventCreateWithFlags(&m.ev_ready, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&m.ev_done, hipEventDisableTiming));
+    }
     for (int i = 0; i < 2; i++) {
         HIPCHK(c, hipHostMalloc((void **)&m.h_hdr[i], (size_t)world * SHARD_HDR * 4, hipHostMallocDefault));
         HIPCHK(c, hipEventCreateWithFlags(&m.ev_hdr[i], hipEventDisableTiming));
@@ -1504,10 +1531,14 @@ int hulk_step_sharded(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_off
         HIPCHK(c, launch_shard_local(s, hist, c->d_pos16, own_hdr, own_delta, c->cms_depth, c->cms_width, fb));
         HIPCHK(c, hipEventRecord(c->ev_flushed[ring], s));          // the ring is wiped: the work stream may fill it again
         c->pending_flush[ring] = true;
+        rc = comm_enter(c, s);
+        if (rc != HULK_OK) return rc;
         if (m.kind == 1) NCCLCHK(c, rccl()->GroupStart());
-        rc = comm_allgather(c, s, own_hdr, m.d_hdr, SHARD_HDR * 4);
-        if (rc == HULK_OK) rc = comm_allgather(c, s, own_delta, m.d_delta, (size_t)c->T * NC * 4);
-        if (m.kind == 1) NCCLCHK(c, rccl()->GroupEnd());
+        rc = comm_allgather(c, m.stream, own_hdr, m.d_hdr, SHARD_HDR * 4);
+        const int rc2 = rc == HULK_OK ? comm_allgather(c, m.stream, own_delta, m.d_delta, (size_t)c->T * NC * 4) : rc;
+        if (m.kind == 1) NCCLCHK(c, rccl()->GroupEnd());                 // (closed whatever the calls inside it returned)
+        if (rc2 != HULK_OK) return rc2;
+        rc = comm_leave(c, s);
         if (rc != HULK_OK) return rc;
         HIPCHK(c, launch_shard_apply(s, m.d_hdr, m.d_delta, c->d_ctr, c->cms_depth, c->cms_width, m.world, c->T,
                                      step_intervals, c->B, c->d_state));
@@ -1520,8 +1551,10 @@ int hulk_step_sharded(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_off
             HIPCHK(c, hipMalloc((void **)&m.d_gather, need * 4));
             m.gather_words = need;
         }
-        rc = comm_allgather(c, s, own_hdr, m.d_hdr, SHARD_HDR * 4);
-        if (rc == HULK_OK) rc = comm_allgather(c, s, hist, m.d_gather, (size_t)c->T * B * 4);
+        rc = comm_enter(c, s);
+        if (rc == HULK_OK) rc = comm_allgather(c, m.stream, own_hdr, m.d_hdr, SHARD_HDR * 4);
+        if (rc == HULK_OK) rc = comm_allgather(c, m.stream, hist, m.d_gather, (size_t)c->T * B * 4);
+        if (rc == HULK_OK) rc = comm_leave(c, s);
         if (rc != HULK_OK) return rc;
         if (own) HIPCHK(c, hipMemsetAsync(hist, 0, (size_t)own * B * 4, s));    // Wipe of the rank's own copy
         HIPCHK(c, hipEventRecord(c->ev_flushed[ring], s));
