@@ -753,13 +753,13 @@ int comm_leave(hulk_ctx *c, hipStream_t s) {
 
 // The kernels of one flush: `fb.count` consecutive spectra of `hist` (starting at fb.ring_base) through count-min + CWS, on stream s.
 int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &fb) {
-    HIPCHK(c, launch_count_used(s, hist, c->d_state, fb));
+    if (!c->scaling) HIPCHK(c, launch_count_used(s, hist, c->d_state, fb));    // (with decay k_elem_index delivers the count)
     {   // whole-batch bound on the counters as they stand BEFORE this batch is added (see k_flush_decide)
         HIPCHK(c, launch_flush_decide(s, c->d_ctr, c->cms_depth * c->cms_width, c->d_kminslot, c->d_weights, (int)c->slots,
                                       (int)c->slot_begin, c->d_state, fb, (c->prune && !c->drift && !c->no_skip && c->slots) ? 1 : 0));
     }
     if (c->scaling) {
-        HIPCHK(c, launch_elem_index(s, hist, c->d_blkcnt, c->d_eidx, c->d_etot, fb));
+        HIPCHK(c, launch_elem_index(s, hist, c->d_blkcnt, c->d_eidx, c->d_etot, fb, c->d_state));
         HIPCHK(c, launch_cmsd_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_eidx, c->d_etot, c->d_ctrd, c->d_segadd,
                                        c->d_segfac, c->d_sege0, c->d_cstart, c->d_f64, c->d_rcp32, c->cms_depth,
                                        c->cms_width, c->row_stride, c->decay_weight, c->d_state, fb));

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void k_elem_count(const uint32_t *__restrict__
 __global__ __launch_bounds__(256) void k_elem_index(const uint32_t *__restrict__ hists,
                                                     const uint32_t *__restrict__ blkcnt,
                                                     uint32_t *__restrict__ eidx, uint32_t *__restrict__ etot,
-                                                    int nblk, FlushBatch fb) {
+                                                    int nblk, FlushBatch fb, DevState *st) {
     __shared__ unsigned red[4];
     __shared__ unsigned wsum[4];
     const int t = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -526,7 +526,13 @@ __global__ __launch_bounds__(256) void k_elem_index(const uint32_t *__restrict__
     if (lane == 0) { red[wid] = off; wsum[wid] = all; }
     __syncthreads();
     off = red[0] + red[1] + red[2] + red[3];
-    if (blk == 0 && tid == 0) etot[t] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (blk == 0 && tid == 0) {
+        const unsigned total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        etot[t] = total;
+        // the number of elements IS KmerSpectrum.Cardinality() (kmerspectrum.go:53-55): with decay the flush takes the 1 %
+        // rule's count from here instead of a k_count_used pass of its own (26 us per 16 spectra at k = 31)
+        st->used[fb.parity][ring_slot(fb, t)] = total;
+    }
     __syncthreads();
     // 8 consecutive bins per thread
     const int32_t b0 = blk * EIDX_BLOCK + tid * 8;
@@ -601,10 +607,10 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
 }
 
 hipError_t launch_elem_index(hipStream_t s, const uint32_t *d_hists, uint32_t *d_blkcnt, uint32_t *d_eidx,
-                             uint32_t *d_etot, const FlushBatch &fb) {
+                             uint32_t *d_etot, const FlushBatch &fb, DevState *st) {
     const int nblk = (fb.num_bins + EIDX_BLOCK - 1) / EIDX_BLOCK;
     hipLaunchKernelGGL(k_elem_count, dim3(nblk, fb.count), dim3(256), 0, s, d_hists, d_blkcnt, nblk, fb);
-    hipLaunchKernelGGL(k_elem_index, dim3(nblk, fb.count), dim3(256), 0, s, d_hists, d_blkcnt, d_eidx, d_etot, nblk, fb);
+    hipLaunchKernelGGL(k_elem_index, dim3(nblk, fb.count), dim3(256), 0, s, d_hists, d_blkcnt, d_eidx, d_etot, nblk, fb, st);
     return hipGetLastError();
 }
 

@@ -133,7 +133,7 @@ hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *
                               int slots, int slot_begin, int ntiles, const unsigned long long *d_scanmap, DevState *st,
                               const FlushBatch &fb);
 hipError_t launch_elem_index(hipStream_t s, const uint32_t *d_hists, uint32_t *d_blkcnt, uint32_t *d_eidx,
-                             uint32_t *d_etot, const FlushBatch &fb);
+                             uint32_t *d_etot, const FlushBatch &fb, DevState *st);
 int elem_index_blocks(int32_t num_bins);
 hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const double *d_f64,
                                     const float *d_tilemin, unsigned long long *d_mins, double *d_weights,
