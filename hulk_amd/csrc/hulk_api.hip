@@ -739,6 +739,20 @@ int comm_allreduce_u32(hulk_ctx *c, hipStream_t s, uint32_t *d_buf, size_t words
     return HULK_OK;                                             // loopback / no peers: the identity
 }
 
+// frees everything hulk_comm_init* set up (also after a failed ncclCommInitRank, so that the call can be repeated)
+void comm_teardown(hulk_ctx *c) {
+    hulk_ctx::Comm &m = c->comm;
+    if (m.stream) hipStreamSynchronize(m.stream);                 // no collective in flight when the communicator goes
+    if (m.nccl && rccl()->CommDestroy) rccl()->CommDestroy(m.nccl);
+    hipFree(m.d_hdr); hipFree(m.d_delta); hipFree(m.d_gather); hipFree(m.d_sk);
+    for (int i = 0; i < 2; i++) { if (m.h_hdr[i]) hipHostFree(m.h_hdr[i]); if (m.ev_hdr[i]) hipEventDestroy(m.ev_hdr[i]); }
+    if (m.h_stage) hipHostFree(m.h_stage);
+    if (m.ev_ready) hipEventDestroy(m.ev_ready);
+    if (m.ev_done) hipEventDestroy(m.ev_done);
+    if (m.stream) hipStreamDestroy(m.stream);
+    m = hulk_ctx::Comm{};
+}
+
 // what stream s has queued so far -> the collectives' stream, and back
 int comm_enter(hulk_ctx *c, hipStream_t s) {
     HIPCHK(c, hipEventRecord(c->comm.ev_ready, s));
@@ -1001,16 +1015,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
     hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial); hipFree(c->ml.nib); hipFree(c->ml.nib_over); hipFree(c->ml.lo); hipFree(c->ml.lo_cnt); hipFree(c->ml.dmask); hipFree(c->ml.dsum);
     hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);
-    {
-        hulk_ctx::Comm &m = c->comm;
-        if (m.nccl && rccl()->CommDestroy) rccl()->CommDestroy(m.nccl);
-        hipFree(m.d_hdr); hipFree(m.d_delta); hipFree(m.d_gather); hipFree(m.d_sk);
-        for (int i = 0; i < 2; i++) { if (m.h_hdr[i]) hipHostFree(m.h_hdr[i]); if (m.ev_hdr[i]) hipEventDestroy(m.ev_hdr[i]); }
-        if (m.h_stage) hipHostFree(m.h_stage);
-        if (m.ev_ready) hipEventDestroy(m.ev_ready);
-        if (m.ev_done) hipEventDestroy(m.ev_done);
-        if (m.stream) { hipStreamSynchronize(m.stream); hipStreamDestroy(m.stream); }
-    }
+    comm_teardown(c);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1458,7 +1463,7 @@ int hulk_comm_init(hulk_ctx *c, const void *unique_id, uint32_t rank, uint32_t w
     { const int rc = comm_setup(c, 1, rank, world); if (rc != HULK_OK) return rc; }
     ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
     const ncclResult_t r = R->CommInitRank(&c->comm.nccl, (int)world, id, (int)rank);
-    if (r != ncclSuccess) { c->comm.kind = 0; return fail_nccl(c, r, "ncclCommInitRank"); }
+    if (r != ncclSuccess) { const int rc = fail_nccl(c, r, "ncclCommInitRank"); c->comm.nccl = nullptr; comm_teardown(c); return rc; }
     return HULK_OK;
 }
 

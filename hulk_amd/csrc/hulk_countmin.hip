@@ -706,36 +706,37 @@ __global__ __launch_bounds__(512) void k_shard_local(uint32_t *__restrict__ hist
 __global__ __launch_bounds__(256) void k_shard_apply(const uint32_t *__restrict__ hdr_all, const uint32_t *__restrict__ delta_all,
                                                      unsigned long long *__restrict__ ctr, int ncounters, uint32_t world,
                                                      uint32_t T, uint32_t step_intervals, int32_t num_bins, DevState *st) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ncounters) return;
-    unsigned long long run = ctr[i], elems = 0;
-    bool few = false;
-    for (uint32_t r = 0; r < world; r++) {
-        const uint32_t *h = hdr_all + (size_t)r * SHARD_HDR;
-        const uint32_t lo = r * T;                                             // rank r holds intervals [r*T, r*T + cnt) of the step
-        const uint32_t cnt = step_intervals <= lo ? 0u : (step_intervals - lo < T ? step_intervals - lo : T);
-        if (!cnt) break;
-        // flush_go()'s rule per interval first (wave-uniform header words), then all of the rank's loads in flight at once
-        uint32_t gomask = 0;
-        for (uint32_t t = 0; t < cnt; t++) {
-            const uint32_t used = h[2 + t];
-            if (used == 0) continue;                                           // boss.go:118: nothing to flush
-            if ((double)used / (double)num_bins < 0.01) { few = true; continue; }  // kmerspectrum.go:88-96 ("not used yet")
-            gomask |= 1u << t;
-            elems += used;
-        }
-        const uint32_t *dr = delta_all + (size_t)r * T * (size_t)ncounters + i;
-        uint32_t v[SCAN_BATCH_MAX];
-#pragma unroll
-        for (uint32_t t = 0; t < (uint32_t)SCAN_BATCH_MAX; t++) v[t] = (t < T && ((gomask >> t) & 1u)) ? dr[(size_t)t * ncounters] : 0u;
-#pragma unroll
-        for (uint32_t t = 0; t < (uint32_t)SCAN_BATCH_MAX; t++) run += v[t];
+    // grid = (counters / 256, ranks): a workgroup adds ONE rank's intervals to its 256 counters (integer sums: the order of
+    // the ranks' atomic adds does not matter); the rank's header words come in with one load per lane
+    __shared__ uint32_t h[SHARD_HDR];
+    const uint32_t r = blockIdx.y;
+    if (threadIdx.x < SHARD_HDR) h[threadIdx.x] = hdr_all[(size_t)r * SHARD_HDR + threadIdx.x];
+    __syncthreads();
+    const uint32_t lo = r * T;                                                 // rank r holds intervals [r*T, r*T + cnt) of the step
+    const uint32_t cnt = step_intervals <= lo ? 0u : (step_intervals - lo < T ? step_intervals - lo : T);
+    // flush_go()'s rule per interval
+    uint32_t gomask = 0; unsigned long long elems = 0; bool few = false;
+    for (uint32_t t = 0; t < cnt; t++) {
+        const uint32_t used = h[2 + t];
+        if (used == 0) continue;                                               // boss.go:118: nothing to flush
+        if ((double)used / (double)num_bins < 0.01) { few = true; continue; }  // kmerspectrum.go:88-96 ("not used yet")
+        gomask |= 1u << t;
+        elems += used;
     }
-    ctr[i] = run;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         if (few) set_error(st, -5);
         if (elems) atomicAdd(&st->n_elements, elems);
     }
+    if (i >= ncounters || !gomask) return;
+    const uint32_t *dr = delta_all + (size_t)r * T * (size_t)ncounters + i;
+    uint32_t v[SCAN_BATCH_MAX];
+#pragma unroll
+    for (uint32_t t = 0; t < (uint32_t)SCAN_BATCH_MAX; t++) v[t] = (t < T && ((gomask >> t) & 1u)) ? dr[(size_t)t * ncounters] : 0u;   // all loads in flight
+    unsigned long long sum = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < (uint32_t)SCAN_BATCH_MAX; t++) sum += v[t];
+    if (sum) atomicAdd(&ctr[i], sum);
 }
 }  // namespace
 
@@ -753,8 +754,9 @@ hipError_t launch_shard_apply(hipStream_t s, const uint32_t *d_hdr_all, const ui
                               int depth, int width, uint32_t world, uint32_t T, uint32_t step_intervals, int32_t num_bins,
                               DevState *st) {
     const int nc = depth * width;
-    hipLaunchKernelGGL(k_shard_apply, dim3((nc + 255) / 256), dim3(256), 0, s, d_hdr_all, d_delta_all, d_ctr, nc, world, T,
-                       step_intervals, num_bins, st);
+    const uint32_t ranks = std::min<uint32_t>(world, (step_intervals + T - 1) / T);      // ranks that hold intervals of this step
+    hipLaunchKernelGGL(k_shard_apply, dim3((nc + 255) / 256, ranks ? ranks : 1), dim3(256), 0, s, d_hdr_all, d_delta_all, d_ctr, nc,
+                       world, T, step_intervals, num_bins, st);
     return hipGetLastError();
 }
 

@@ -400,8 +400,9 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     // its last, in r the pair of base p gets |= N(p-1) for every base of the k-mer, bit 2k of r is set when the k-mer's last
     // base is an N, and f == r has to be tested for odd k too.  An iteration of the wave takes this variant of phase A only
     // when one of its 4 reads has an N (wave-uniform branch): +13 instructions per k-mer position there, nothing elsewhere.
-    // Any other byte outside ACGTacgt still defers the read to k_minimizer_bin and its full seq_nt4_table.
-    constexpr bool NV = DX && HP && !PAIR && 2 * (KC + WM) <= 64;
+    // Any other byte outside ACGTacgt still defers the read to k_minimizer_bin and its full seq_nt4_table.  (PAIR: the second
+    // group's first k-mer needs N(posoff - 1), a base only its partner staged: read from the partner's flag dwords.)
+    constexpr bool NV = DX && HP && 2 * (KC + WM) <= 64;
     const int half = PAIR ? (grp & 1) : 0;                         // which half of the read this group takes
     const int sub = PAIR ? ((grp & 3) >> 1) : (grp & 3);           // read of the iteration
     const int32_t posoff = half ? 16 * w - (w - 1) : 0;            // first k-mer position of this group
@@ -649,7 +650,13 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                 const uint32_t bo = 2u * (uint32_t)p0, nbo = p0 > 0 ? bo - 2u : 0u, d = nbo >> 5, o = nbo & 31u;
                 const uint64_t lo = (uint64_t)pkn32[d] | ((uint64_t)pkn32[d + 1] << 32);
                 Xn = o ? (lo >> o) | ((uint64_t)pkn32[d + 2] << (64 - o)) : lo;
-                if (p0 == 0) Xn <<= 2;
+                if (p0 == 0) {
+                    Xn <<= 2;
+                    if (PAIR && half) {                              // base posoff - 1 lies in the partner group's part of the read
+                        const uint32_t q = (uint32_t)(posoff - 1);
+                        Xn |= (uint64_t)(((pkn32 - 20)[q >> 4] >> (2u * (q & 15u))) & 1u);
+                    }
+                }
                 Xn &= (NBW + 1 < 32) ? ((1ull << (2 * (NBW + 1))) - 1) : ~0ull;
                 const uint64_t Fn = (Xn >> 4) & ((1ull << (2 * (NBW - 1))) - 1);      // pair u: N(p0 + u + 1), u < NBW - 1
                 const uint64_t rv = __brevll(Fn) >> (64 - 2 * NBW);

@@ -112,13 +112,15 @@ def test_n_lowercase_and_min_length():
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("w", [9, 4])
-def test_fast_kernel_instance_with_n_bases(w):
+@pytest.mark.parametrize("w,long_reads", [(9, False), (4, False), (9, True), (4, True)])
+def test_fast_kernel_instance_with_n_bases(w, long_reads):
     """Reads with `N` stay in the short-read kernel's k = 21 instance (code 4 in closed form: minimizer.go:118-122 does not
     special-case it — bit 2 of the code spills into the neighbouring base's pair of f, r keeps bit 2k): one N at every
     position of a 150 bp read, lower-case n, runs of N, N at both ends, several N per read, an N in the first bases of the
     NEXT read (the kernel stages past a read's end), reads of the minimum length, and reads that carry an N next to a byte
-    the kernel does not take (those still go to the generic kernel) — spectrum, minimizer count and sketch against the oracle."""
+    the kernel does not take (those still go to the generic kernel); long_reads: a call whose reads take two 16-lane groups
+    each (the second group's first k-mer needs the flag of a base its partner staged) — spectrum, minimizer count and
+    sketch against the oracle."""
     rng = np.random.default_rng(2100 + w)
     k, L = 21, 150
     base = random_reads(rng, 1, L)[0]
@@ -138,6 +140,18 @@ def test_fast_kernel_instance_with_n_bases(w):
     for _ in range(100):                                 # an N and a byte outside ACGTN in the same read
         b = bytearray(random_reads(rng, 1, L)[0]); b[int(rng.integers(0, L))] = ord("N"); b[int(rng.integers(0, L))] = ord("R"); seqs.append(bytes(b))
     seqs += random_reads(rng, 500, L)                    # clean reads in between: waves with and without an N
+    if long_reads:                                       # reads of two 16-lane groups (250-300 bp): an N at every 3rd position,
+        L2 = 16 * w + 100 if w == 9 else 16 * w + 30     # around the seam between the groups (position 16w - (w-1)) densely
+        seqs = seqs[:600]
+        seam = 16 * w - (w - 1)
+        for p in list(range(0, L2, 3)) + list(range(seam - 3, seam + k + 3)):
+            b = bytearray(random_reads(rng, 1, L2)[0]); b[p] = ord("N"); seqs.append(bytes(b))
+        for _ in range(200):
+            b = bytearray(random_reads(rng, 1, int(rng.integers(16 * w + k, L2 + 1)))[0])
+            for q in rng.integers(0, len(b), size=int(rng.integers(1, 5))):
+                b[q] = ord("N")
+            seqs.append(bytes(b))
+        seqs += random_reads(rng, 200, L2)
     order = rng.permutation(len(seqs))
     seqs = [seqs[i] for i in order]
     o, g = run_both(seqs, k, w, 8, batches=3)

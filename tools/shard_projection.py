@@ -81,6 +81,7 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--mode", choices=("sharded", "sliced"), default="sharded")
     a = ap.parse_args()
+    run(1, 8)              # (discarded: the first context of a process runs well below the ones after it)
     base = None
     for w in [int(x) for x in a.worlds.split(",")]:
         r = run(w, a.steps, mode=a.mode)
