@@ -187,3 +187,36 @@ def test_sharded_step_reports_too_few_used_bins():
         sk.finish()
     assert "not used yet" in str(e.value)
     sk.close()
+
+
+def test_sharded_step_from_host_slices():
+    """hulk_step_sharded_host (a Go host's byte slices: validated like hulk_add_reads, staged through pinned memory) gives the
+    sketch of the device-pointer call; a read shorter than w + k - 1 is refused with the reference's text before anything runs."""
+    import hulk_amd
+    from hulk_amd import synth
+    from hulk_amd._lib import HulkError
+    from hulk_amd.distributed import num_steps, step_share
+    os.environ["HULK_BATCH"] = str(BATCH)
+    total = 3 * BATCH * I + 2 * I + 500
+    sk = hulk_amd.GpuSketcher(K, W, S, interval=I)
+    sk.comm_init_loopback(0, 1)
+    for s_ in range(num_steps(total, BATCH, I, 1)):
+        first, n, si = step_share(s_, BATCH, I, 0, 1, total)
+        bases, offsets = synth.reads_numpy(first, n, L)
+        sk.step_sharded_host(bases, offsets, si)
+    sk.finish()
+    mins, weights = sk.gather_sketch()
+    cms = sk.cms()
+    sk.close()
+    bases, offsets = synth.reads_numpy(0, total, L)
+    g = hulk_amd.GpuSketcher(K, W, S, interval=I)
+    g.add_reads(bases, offsets)
+    g.finish()
+    m1, w1 = g.sketch()
+    assert np.array_equal(mins, m1) and np.array_equal(weights, w1) and np.array_equal(cms, g.cms())
+    g.close()
+    bad = hulk_amd.GpuSketcher(K, W, S, interval=I)
+    bad.comm_init_loopback(0, 1)
+    with pytest.raises(HulkError, match="sequence length must be >= w \\+ k - 1"):
+        bad.step_sharded_host(np.frombuffer(b"ACGTACGTAC", dtype=np.uint8), np.array([0, 10], dtype=np.uint64), 1)
+    bad.close()
