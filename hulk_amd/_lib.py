@@ -25,7 +25,7 @@ HULK_MAX_BINS = 1 << 20
 
 # every symbol include/hulk_hip.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = (
-    "hulk_abi_version", "hulk_strerror", "hulk_last_error", "hulk_create", "hulk_destroy",
+    "hulk_abi_version", "hulk_build_info", "hulk_strerror", "hulk_last_error", "hulk_create", "hulk_destroy",
     "hulk_set_stream", "hulk_set_private_stream", "hulk_set_cws_tables", "hulk_add_reads", "hulk_add_reads_device",
     "hulk_batch_size", "hulk_bin_reads_device", "hulk_bin_reads_device_at", "hulk_histogram_device", "hulk_flush_batch", "hulk_flush_batch_after", "hulk_add_histogram", "hulk_flush",
     "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
@@ -132,6 +132,20 @@ def _preload_torch_hip_runtime():
                               "before hulk_amd is the work-around") from e
 
 
+def source_hash():
+    """First 16 hex digits of the SHA-256 over hulk_amd/csrc's sources and headers, in the Makefile's order — what
+    hulk_build_info() of a library built from this tree reports."""
+    import hashlib
+    import re
+    csrc = os.path.join(_HERE, "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    names = re.search(r"^SRCS = (.*)$", mk, re.M).group(1).split() + re.search(r"^HDRS = (.*)$", mk, re.M).group(1).split()
+    h = hashlib.sha256()
+    for n in names:
+        h.update(open(os.path.join(csrc, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -147,6 +161,7 @@ def load():
     if L.hulk_abi_version() != HULK_ABI_VERSION:
         raise ImportError(f"{LIB_PATH} reports ABI version {L.hulk_abi_version()}, this binding is written for "
                           f"{HULK_ABI_VERSION}: rebuild it (`make -C hulk_amd/csrc`)")
+    L.hulk_build_info.restype = ctypes.c_char_p
     L.hulk_strerror.restype = ctypes.c_char_p; L.hulk_strerror.argtypes = [ctypes.c_int]
     L.hulk_last_error.restype = ctypes.c_char_p; L.hulk_last_error.argtypes = [vp]
     L.hulk_create.restype = ctypes.c_int; L.hulk_create.argtypes = [ctypes.POINTER(HulkParams), ctypes.POINTER(vp)]

@@ -868,6 +868,13 @@ int check_device_error(hulk_ctx *c) {
 extern "C" {
 
 int hulk_abi_version(void) { return HULK_ABI_VERSION; }
+#ifndef HULK_SOURCE_HASH
+#define HULK_SOURCE_HASH "unknown"
+#endif
+#ifndef HULK_HIPCC_VERSION
+#define HULK_HIPCC_VERSION "unknown"
+#endif
+const char *hulk_build_info(void) { return "abi=2 arch=gfx950 sources=" HULK_SOURCE_HASH " hipcc=" HULK_HIPCC_VERSION; }
 const char *hulk_strerror(int status) { return err_text(status); }
 const char *hulk_last_error(const hulk_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
 

@@ -113,6 +113,9 @@ typedef struct hulk_params {
 
 /* Version of this ABI (HULK_ABI_VERSION). */
 int hulk_abi_version(void);
+/* "abi=2 arch=gfx950 sources=<first 16 hex digits of the SHA-256 over hulk_amd/csrc's sources and headers, in the Makefile's
+ * order> hipcc=<version>": which tree and compiler this .so was built from (a binding or a test can refuse a stale one). */
+const char *hulk_build_info(void);
 /* Reference error text for a status code. */
 const char *hulk_strerror(int status);
 /* Message of the last failure on this context ("" if none). NULL ctx => last hulk_create failure. */

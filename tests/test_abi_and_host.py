@@ -154,6 +154,15 @@ def test_khf_signature_layout_and_kmv_is_fatal(tmp_path):
         d.add(KMVSketch(21, 2))
 
 
+def test_library_is_built_from_this_tree():
+    """hulk_build_info(): the .so in the tree reports the hash of the sources in the tree (a stale build — sources edited, `make`
+    not run — fails here, on CPU, before any GPU test trusts it) and the compiler it came from."""
+    L = _lib.load()
+    info = L.hulk_build_info().decode()
+    assert "abi=%d " % _lib.HULK_ABI_VERSION in info and "arch=gfx950" in info and "hipcc=" in info
+    assert "sources=" + _lib.source_hash() in info, (info, _lib.source_hash())
+
+
 def test_cgo_binding_file_is_the_block_of_integration_md():
     """tools/go/gpusketch/gpusketch.go (reviewable source, no Go toolchain here) = INTEGRATION.md's first Go block, and every
     C.hulk_* it calls is an entry point the header declares."""
