@@ -157,6 +157,7 @@ def test_khf_signature_layout_and_kmv_is_fatal(tmp_path):
 def test_library_is_built_from_this_tree():
     """hulk_build_info(): the .so in the tree reports the hash of the sources in the tree (a stale build — sources edited, `make`
     not run — fails here, on CPU, before any GPU test trusts it) and the compiler it came from."""
+    from hulk_amd import _lib
     L = _lib.load()
     info = L.hulk_build_info().decode()
     assert "abi=%d " % _lib.HULK_ABI_VERSION in info and "arch=gfx950" in info and "hipcc=" in info
