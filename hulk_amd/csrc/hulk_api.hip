@@ -132,6 +132,7 @@ struct hulk_ctx {
         uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;      // host transport: pinned staging
         unsigned long long *d_sk = nullptr;             // hulk_gather_sketch: [world][2 + 2 S]
         uint64_t step = 0, steps_delta = 0, steps_full = 0, bytes_rx = 0;
+        uint64_t global_intervals = 0;                  // intervals of the GLOBAL stream the steps so far covered
     } comm;
     // device state
     DevState *d_state = nullptr;
@@ -1265,8 +1266,9 @@ int hulk_finish(hulk_ctx *c) {
     }
     int rc = check_device_error(c);
     if (rc != HULK_OK) return rc;
-    // "no sequences received" (pipeline/sketch.go:237-239); the histogram test hook is exempt
-    if (c->seq_count == 0 && !c->hist_hook_used) return fail(c, HULK_ERR_NO_SEQ);
+    // "no sequences received" (pipeline/sketch.go:237-239); the histogram test hook is exempt — and so is a rank of a sharded
+    // run that happened to hold none of a short stream's intervals: the reference's count is over the global stream
+    if (c->seq_count == 0 && !c->hist_hook_used && c->comm.global_intervals == 0) return fail(c, HULK_ERR_NO_SEQ);
     return HULK_OK;
 }
 
@@ -1587,6 +1589,7 @@ int hulk_step_sharded(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_off
     HIPCHK(c, hipEventRecord(m.ev_hdr[cur], s));
     m.hdr_pending[cur] = true;
     m.step++;
+    m.global_intervals += step_intervals;
     c->cur_ring ^= 1;
     return HULK_OK;
 }
