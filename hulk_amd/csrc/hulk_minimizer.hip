@@ -402,7 +402,8 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     // when one of its 4 reads has an N (wave-uniform branch): +13 instructions per k-mer position there, nothing elsewhere.
     // Any other byte outside ACGTacgt still defers the read to k_minimizer_bin and its full seq_nt4_table.  (PAIR: the second
     // group's first k-mer needs N(posoff - 1), a base only its partner staged: read from the partner's flag dwords.)
-    constexpr bool NV = DX && HP && 2 * (KC + WM) <= 64;
+    constexpr bool NV = (DX && HP && 2 * (KC + WM) <= 64) || (!DX && WM <= 9);   // one-window form, or the rolling form (the
+                                                                                   // 16-position instances are at 128 VGPRs already)
     const int half = PAIR ? (grp & 1) : 0;                         // which half of the read this group takes
     const int sub = PAIR ? ((grp & 3) >> 1) : (grp & 3);           // read of the iteration
     const int32_t posoff = half ? 16 * w - (w - 1) : 0;            // first k-mer position of this group
@@ -612,8 +613,22 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
             validbits = (1u << (nposg - p0 < w ? nposg - p0 : w)) - 1u;
             const int32_t span0 = ap0 + k - 1 - w + 2;
             uint64_t f = 0, r = 0;
-            uint32_t nb = 0;                                    // next <=15 bases, 2 bits each
+            uint32_t nb = 0, nn = 0;                            // next <=15 bases, 2 bits each; their code-4 flags (N variant)
             uint64_t Bb = 0, Cl = 0;
+            // NV: Xn = the code-4 flags of bases p0-1, p0, p0+1, ... at bits 0, 2, 4, ... (p0 - 1 may be the partner group's)
+            uint64_t Xn = 0, Hb = 0;
+            if (NV && waveN) {
+                const uint32_t bo = 2u * (uint32_t)p0, nbo = p0 > 0 ? bo - 2u : 0u, d = nbo >> 5, o = nbo & 31u;
+                const uint64_t lo = (uint64_t)pkn32[d] | ((uint64_t)pkn32[d + 1] << 32);
+                Xn = o ? (lo >> o) | ((uint64_t)pkn32[d + 2] << (64 - o)) : lo;
+                if (p0 == 0) {
+                    Xn <<= 2;
+                    if (PAIR && half) {                              // base posoff - 1 lies in the partner group's part of the read
+                        const uint32_t q = (uint32_t)(posoff - 1);
+                        Xn |= (uint64_t)(((pkn32 - 20)[q >> 4] >> (2u * (q & 15u))) & 1u);
+                    }
+                }
+            }
             if (DX) {
                 // the block's w+k-1 bases fit one 64-bit window: every k-mer of the block is a shift + mask of the
                 // window in the forward (first base on top: Bb) or the complemented (first base at the bottom: Cl)
@@ -632,31 +647,31 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     const uint64_t lo = (uint64_t)pk32[d] | ((uint64_t)pk32[d + 1] << 32);
                     uint64_t W = o ? (lo >> o) | ((uint64_t)pk32[d + 2] << (64 - o)) : lo;
                     W &= mask;
+                    r = (~W) & mask;
+                    if (NV && waveN) {
+                        // the block's first k-mer in closed form (as k_minimizer_bin): f's pairs |= N(p+1) but the last base's,
+                        // r's pairs |= N(p-1) and bit 2k = N(last base); the positions behind it roll the literal recurrence
+                        const uint64_t X0 = (2 * k + 2 < 64) ? (Xn & ((1ull << (2 * k + 2)) - 1)) : Xn;
+                        W |= (X0 >> 4) & (mask >> 2);
+                        r |= X0 & ((mask << 1) | 1ull);
+                    }
                     const uint64_t rev = __brevll(W) >> (64 - 2 * k);
                     f = ((rev >> 1) & 0x5555555555555555ull) | ((rev & 0x5555555555555555ull) << 1);
-                    r = (~W) & mask;
                 }
                 {
                     const uint32_t bo = 2u * (uint32_t)(p0 + k), d = bo >> 5, o = bo & 31u;
                     const uint64_t lo = (uint64_t)pk32[d] | ((uint64_t)pk32[d + 1] << 32);
                     nb = (uint32_t)(lo >> o);
-                }
-            }
-            // NV: the flag windows of the N variant.  Xn = flags of bases p0-1 .. p0+NBW-1 at bits 0, 2, 4, ... (for r, bit 2k
-            // included); Hb = flags of bases p0+1 .. in the forward (first base on top) layout of Bb, one pair down (for f).
-            uint64_t Xn = 0, Hb = 0;
-            if (NV && waveN) {
-                constexpr int NBW = KC + WM - 1;
-                const uint32_t bo = 2u * (uint32_t)p0, nbo = p0 > 0 ? bo - 2u : 0u, d = nbo >> 5, o = nbo & 31u;
-                const uint64_t lo = (uint64_t)pkn32[d] | ((uint64_t)pkn32[d + 1] << 32);
-                Xn = o ? (lo >> o) | ((uint64_t)pkn32[d + 2] << (64 - o)) : lo;
-                if (p0 == 0) {
-                    Xn <<= 2;
-                    if (PAIR && half) {                              // base posoff - 1 lies in the partner group's part of the read
-                        const uint32_t q = (uint32_t)(posoff - 1);
-                        Xn |= (uint64_t)(((pkn32 - 20)[q >> 4] >> (2u * (q & 15u))) & 1u);
+                    if (NV && waveN) {
+                        const uint64_t ln = (uint64_t)pkn32[d] | ((uint64_t)pkn32[d + 1] << 32);
+                        nn = (uint32_t)(ln >> o);
                     }
                 }
+            }
+            // NV, one-window form: Xn cut to the window (for r, bit 2k included); Hb = the flags of bases p0+1 .. in the forward
+            // (first base on top) layout of Bb, one pair down (for f)
+            if (NV && DX && waveN) {
+                constexpr int NBW = KC + WM - 1;
                 Xn &= (NBW + 1 < 32) ? ((1ull << (2 * (NBW + 1))) - 1) : ~0ull;
                 const uint64_t Fn = (Xn >> 4) & ((1ull << (2 * (NBW - 1))) - 1);      // pair u: N(p0 + u + 1), u < NBW - 1
                 const uint64_t rv = __brevll(Fn) >> (64 - 2 * NBW);
@@ -687,14 +702,17 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     f = ((uint64_t)fh << 32) | fl;
                     r = ((uint64_t)rh << 32) | rl;
                 } else if (t) {
-                    const uint64_t c = nb & 3u; nb >>= 2;
+                    uint64_t c = nb & 3u; nb >>= 2;
+                    if (NVX) { c |= (uint64_t)(nn & 1u) << 2; nn >>= 2; }   // code 4 as the reference rolls it (minimizer.go:118-122)
                     f = (f << 2 | c) & mask;
                     r = (r >> 2) | ((3ull ^ c) << shift);
                 }
                 if (t < w) {
                     // (a canonical k-mer has 2k <= 62 bits for every legal k: the f64 minimum is exact whatever FM says;
                     //  with an N as its last base r carries bit 2k: still far below 2^62, and then f is the minimum)
-                    const uint64_t canon = umin64<true>(f, r);
+                    // (k = 31 with an N as the last base: r carries bit 62, and with A or N in the four bases before it its
+                    //  bit pattern is a signalling NaN, which v_min_f64 does not pass through — integer minimum there)
+                    const uint64_t canon = (NVX && k >= 31) ? (f < r ? f : r) : umin64<true>(f, r);
                     int32_t span = span0 + t;
                     if (span >= k) span = k;
                     uint64_t x;

@@ -112,17 +112,19 @@ def test_n_lowercase_and_min_length():
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("w,long_reads", [(9, False), (4, False), (9, True), (4, True)])
-def test_fast_kernel_instance_with_n_bases(w, long_reads):
+@pytest.mark.parametrize("k,w,long_reads", [(21, 9, False), (21, 4, False), (21, 9, True), (21, 4, True),
+                                            (31, 9, False), (31, 9, True), (17, 5, False), (24, 9, False), (12, 3, True)])
+def test_fast_kernel_instance_with_n_bases(k, w, long_reads):
     """Reads with `N` stay in the short-read kernel's k = 21 instance (code 4 in closed form: minimizer.go:118-122 does not
-    special-case it — bit 2 of the code spills into the neighbouring base's pair of f, r keeps bit 2k): one N at every
+    special-case it — bit 2 of the code spills into the neighbouring base's pair of f, r keeps bit 2k; k = 21: closed form on
+    the one-window extraction, other k: the literal recurrence on the rolling k-mers): one N at every
     position of a 150 bp read, lower-case n, runs of N, N at both ends, several N per read, an N in the first bases of the
     NEXT read (the kernel stages past a read's end), reads of the minimum length, and reads that carry an N next to a byte
     the kernel does not take (those still go to the generic kernel); long_reads: a call whose reads take two 16-lane groups
     each (the second group's first k-mer needs the flag of a base its partner staged) — spectrum, minimizer count and
     sketch against the oracle."""
-    rng = np.random.default_rng(2100 + w)
-    k, L = 21, 150
+    rng = np.random.default_rng(2100 + w + 100 * k)
+    L = 150
     base = random_reads(rng, 1, L)[0]
     seqs = []
     for p in range(L):                                   # one N at every position
