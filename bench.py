@@ -323,17 +323,51 @@ def main():
     main_input = make_input(mode, 24)
     torch.cuda.synchronize()
 
-    def connect(sk):
+    rccl_error = [None]            # set on every rank when RCCL could not be bound / initialised on ANY rank (reported in the line)
+    host_group = [None]
+
+    def connect(sk, remake=None):
         """the context's communicator: RCCL (rank 0's id travels over torch.distributed), the host transport over gloo
-        (test aid), or the loopback stand-in (--loopback)"""
+        (test aid), or the loopback stand-in (--loopback).  Returns the context to use: when hulk_comm_init fails on any
+        rank (librccl.so.1 missing, ncclCommInitRank refusing) all ranks agree on it, say so on stderr and in the JSON line
+        (comm.transport), and the run goes on over the library's HOST transport on a gloo group — same protocol, same
+        kernels, slower exchange — rather than leaving the scaling run without a number."""
         if loop_world:
             sk.comm_init_loopback(0, loop_world)
-        elif transport == "gloo":
+            return sk
+        if transport == "gloo":
             sk.comm_init_host(rank, world, gloo_exchange(dist))
-        else:
-            ids = [hulk_amd.GpuSketcher.comm_unique_id() if rank == 0 else None]
+            return sk
+        if rccl_error[0] is None:
+            uid = err = None
+            if rank == 0:
+                try:
+                    uid = hulk_amd.GpuSketcher.comm_unique_id()
+                except _lib.HulkError as e:
+                    err = str(e)
+            ids = [uid]
             dist.broadcast_object_list(ids, src=0)
-            sk.comm_init(ids[0], rank, world)
+            if ids[0] is None:
+                err = err or "rank 0 could not create an RCCL unique id"
+            else:
+                try:
+                    sk.comm_init(ids[0], rank, world)
+                except _lib.HulkError as e:
+                    err = str(e)
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            bad = [e for e in errs if e]
+            if not bad:
+                return sk
+            rccl_error[0] = bad[0]
+            host_group[0] = dist.new_group(backend="gloo")
+            if rank == 0:
+                print(f"bench.py: RCCL transport unavailable ({bad[0]}); using the library's host transport over gloo", file=sys.stderr)
+            if err is None and remake is not None:             # this rank's context already holds a communicator
+                sk.close()
+                sk = remake()
+        sk.comm_init_host(rank, world, gloo_exchange(dist, host_group[0]))
+        return sk
 
     def run_pass(prune, inp=None, brackets=1):
         """warm-up + the timed K steps on a fresh context; prune=False disables the exact bounds of the CWS stage
@@ -341,12 +375,14 @@ def main():
         bufs, offs, per, n_step, in_mode = inp if inp is not None else main_input
         comm = use_dist or loop_world
         sharded = comm and in_mode == "sharded"
-        sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL if sharded else 0, decay_ratio=1.0, device=dev_index,
-                                  slot_begin=sb, slot_count=sc, stream=stream.cuda_stream,
-                                  flags=0 if prune else _lib.HULK_FLAG_NO_PRUNE)
+        def make():
+            return hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL if sharded else 0, decay_ratio=1.0, device=dev_index,
+                                        slot_begin=sb, slot_count=sc, stream=stream.cuda_stream,
+                                        flags=0 if prune else _lib.HULK_FLAG_NO_PRUNE)
+        sk = make()
         assert sk.batch_size == BATCH
         if comm:
-            connect(sk)
+            sk = connect(sk, make)
 
         def one_step(t):
             b = bufs[t % len(bufs)]
@@ -438,9 +474,10 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=dev_index, slot_begin=sb, slot_count=sc,
-                                  stream=stream.cuda_stream)
-        connect(sk)
+        def make():
+            return hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=dev_index, slot_begin=sb,
+                                        slot_count=sc, stream=stream.cuda_stream)
+        sk = connect(make(), make)
         torch.cuda.synchronize()
         dist.barrier()
         t1 = time.perf_counter()
@@ -554,8 +591,10 @@ def main():
         scaling = "strong" if mode == "sliced-strong" else "weak"
         comm_desc = None
         if use_dist or loop_world:
-            how = ("loopback stand-in (no peers)" if loop_world else "RCCL (ncclAllGather / ncclAllReduce, bound by hulk_comm_init)"
-                   if transport == "rccl" else "host transport over gloo (test aid: all ranks on GPU 0)")
+            how = ("loopback stand-in (no peers)" if loop_world else
+                   f"host transport over gloo (RCCL unavailable: {rccl_error[0]})" if rccl_error[0] else
+                   "RCCL (ncclAllGather / ncclAllReduce, bound by hulk_comm_init)" if transport == "rccl" else
+                   "host transport over gloo (test aid: all ranks on GPU 0)")
             what = ("one all-gather per step: k-mer spectra while an element can still lower a weight, count-min increments after"
                     if mode == "sharded" else "one all-reduce (uint32 sum) of the step's spectra")
             comm_desc = {"inside": "libhulkhip.so (hulk_step_sharded / hulk_step_sliced)", "transport": how, "per_step": what,

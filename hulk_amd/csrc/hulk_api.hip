@@ -669,7 +669,8 @@ Rccl *rccl() {
     static Rccl R = [] {
         Rccl r;
         const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-        for (const char *n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.handle) break; }
+        if (const char *only = getenv("HULK_RCCL_LIB")) r.handle = dlopen(only, RTLD_NOW | RTLD_GLOBAL);      // this build and no other
+        else for (const char *n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.handle) break; }
         if (!r.handle) { const char *e = dlerror(); r.error = std::string("librccl.so.1 not found: ") + (e ? e : ""); return r; }
 #define RCCL_SYM(f) do { r.f = (decltype(r.f))dlsym(r.handle, "nccl" #f); if (!r.f) r.error = "librccl lacks nccl" #f; } while (0)
         RCCL_SYM(GetUniqueId); RCCL_SYM(CommInitRank); RCCL_SYM(CommDestroy); RCCL_SYM(AllGather); RCCL_SYM(AllReduce);

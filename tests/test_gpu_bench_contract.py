@@ -80,6 +80,18 @@ def test_bench_json_contract_and_collective_path():
     assert "LOOPBACK" in g["config"]["workload"] and g["config"]["reads_per_step"] == 8 * g["config"]["reads_per_rank_step"]
 
 
+def test_bench_says_so_when_rccl_cannot_be_bound():
+    """hulk_comm_init failing (here: HULK_RCCL_LIB names a file that is not there) must not leave a scaling run without a
+    line: every rank learns of it, the run goes over the library's host transport on a gloo group and the line says so."""
+    a = _run(["--no-cpu-baseline", "--single-pass", "--no-cold", "--no-e2e", "--no-c4", "--force-collective"], {"HULK_RCCL_LIB": "/nonexistent/librccl.so.1"})
+    t = a["collective"]["transport"]
+    assert "host transport over gloo" in t and "RCCL unavailable" in t and "librccl" in t
+    cs = a["collective"]["timed_pass"]
+    assert cs["steps_full"] >= 1 and cs["steps_delta"] >= 1
+    b = _run(["--no-cpu-baseline", "--single-pass", "--no-cold", "--no-e2e"])
+    assert a["sketch_md5"] == b["sketch_md5"]
+
+
 def test_bench_world_two_end_to_end_on_one_gpu():
     """`python bench.py --gpus 2` the way the driver invokes it (no launcher), both ranks on GPU 0 over the host transport:
     everything bench.py does at N > 1 runs — self_spawn, the pre-warm agreement, all three modes, value_c4 with its ragged

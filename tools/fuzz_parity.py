@@ -24,7 +24,11 @@ bad = 0
 n_err = 0
 errs = {}
 t_start = time.time()
+budget = float(os.environ.get("FUZZ_SECONDS", 0))                    # stop after this many seconds (the summary counts the cases done)
 for case in range(n_cases):
+    if budget and time.time() - t_start > budget:
+        n_cases = case
+        break
     k = int(rng.choice([3, 5, 7, 8, 9, 11, 12, 13, 15, 16, 17, 21, 21, 21] + ([27, 28, 31] if os.environ.get("FUZZ_BIG_K") else [])))   # k^4 bins and S*k^4 tables stay small; 21 = the compiled-in default
     w = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 10, 11, 12, 13, 14, 15, 16, 17, 25, 40] if os.environ.get("FUZZ_WIDE_W") else [1, 2, 3, 4, 5, 9, 9, 9, 10, 16, 17, 25, 40]))   # (FUZZ_WIDE_W: every window size of the short-read kernel; changes what a seed draws)
     S = int(rng.choice([1, 2, 7, 8, 9, 16, 31, 50]))

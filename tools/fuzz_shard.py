@@ -53,7 +53,11 @@ def reads(rng_, n, L, alph):
 
 bad = 0
 t_start = time.time()
+budget = float(os.environ.get("FUZZ_SECONDS", 0))                    # stop after this many seconds (the summary counts the cases done)
 for case in range(n_cases):
+    if budget and time.time() - t_start > budget:
+        n_cases = case
+        break
     k = int(rng.choice([11, 13, 15, 15, 17, 21]))
     w = int(rng.choice([4, 5, 9, 9, 12]))
     S = int(rng.choice([3, 8, 16, 50]))
