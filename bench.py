@@ -52,6 +52,7 @@ sys.path.insert(0, ROOT)
 
 K, W, S, READ_LEN, INTERVAL = 21, 9, 512, 150, 100_000
 NUM_BINS = K ** 4        # cmd/sketch.go:118
+STEPTIMES = int(os.environ.get("HULK_BENCH_STEPTIMES", "0"))     # diagnosis: per-step wall times of every pass on stderr
 PREWARM_S = float(os.environ.get("HULK_BENCH_PREWARM_S", "2"))   # seconds of discarded passes before the timed ones
 BATCH = int(os.environ.get("HULK_BENCH_BATCH", "16"))   # sketching intervals per step (one pass over the CWS table)
 C2_READS = 10_000_000        # BASELINE configs[1]
@@ -404,8 +405,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        stamps = []                            # HULK_BENCH_STEPTIMES (diagnosis): 1 = when each call returned, 2 = with a sync per step
         for t in range(warmup, total_steps):
             one_step(t)
+            if STEPTIMES:
+                if STEPTIMES == 2:
+                    sk.synchronize()
+                stamps.append(time.perf_counter())
+        if STEPTIMES and rank == 0:
+            sys.stderr.write("step times (ms, %s): " % ("synchronised" if STEPTIMES == 2 else "host call returns") +
+                             " ".join("%.3f" % ((b - a) * 1e3) for a, b in zip([t0] + stamps[:-1], stamps)) + "\n")
         sk.synchronize()                       # (queues the last step's flush, which otherwise waits for a next batch)
         torch.cuda.synchronize()
         if use_dist:
@@ -505,6 +514,8 @@ def main():
     # step, HULK_BENCH_REPEAT below; 40 untimed steps on a throwaway context do not help, a whole discarded pass does: the
     # transient is worth ~1.5 ms at the start of the first context that is timed, profiled and finished).  So one pass is
     # run and discarded before the timed ones; neither timed pass then depends on being the second.
+    # (Round 3: it is the clock ramp of a GPU leaving idle — HULK_BENCH_STEPTIMES=2 shows the first pass descending from 1.25 to
+    # 1.11 ms per synchronised step over its 20 steps, later passes from 1.17 over their first 15)
     run_pass(not args.no_prune)
     # ... and PREWARM_S seconds of discarded passes on top: on a box whose GPU has been idle (a fresh lease) the first process
     # otherwise measures 2-4 % below the ones after it (1.025 vs 0.988 ms per step; with 3 s of load first: 1.000 vs 0.990)
