@@ -176,3 +176,28 @@ def test_cgo_binding_file_is_the_block_of_integration_md():
     header = open(os.path.join(root, "include", "hulk_hip.h")).read()
     called = set(re.findall(r"C\.(hulk_[a-z_]+)\(", body))
     assert called and all(re.search(r"\b%s\s*\(" % name, header) for name in called), called
+
+
+def test_header_is_c99_and_a_c_host_links(tmp_path):
+    """cgo compiles the preamble as C: include/hulk_hip.h must be valid C99 (no C++-isms), and a plain C host must link
+    against libhulkhip.so and reach the entry points that need no GPU (ABI version, error strings, build info)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "hulk_amd", "csrc")
+    src = tmp_path / "host.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "hulk_hip.h"\n'
+                   "int main(void) {\n"
+                   "    hulk_params p; memset(&p, 0, sizeof p);\n"
+                   "    if (hulk_abi_version() != HULK_ABI_VERSION) return 2;\n"
+                   "    if (!strstr(hulk_strerror(HULK_ERR_SHORT_SEQ), \"w + k - 1\")) return 3;\n"
+                   '    printf("%s\\n", hulk_build_info());\n'
+                   "    return 0;\n}\n")
+    exe = tmp_path / "host"
+    subprocess.run(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                    str(src), "-o", str(exe), "-L", libdir, "-lhulkhip", "-Wl,-rpath," + libdir], check=True)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.returncode, p.stderr)
+    assert "abi=" in p.stdout and "arch=gfx950" in p.stdout
