@@ -21,10 +21,20 @@ namespace inflate {
 constexpr int LITLEN_BITS = 11, DIST_BITS = 8, PRE_BITS = 7;
 constexpr int LITLEN_ENOUGH = 2342, DIST_ENOUGH = 402;     // table sizes sufficient for any code set (zlib's "enough")
 constexpr size_t OUT_SLACK = 320;                          // bytes a fast-loop step may write past `out_limit`
+constexpr size_t IN_SLACK = 24;                            // input bytes the fast loop wants ahead of every iteration (three 8-byte refills)
 
-// table entry: bits 0-3 code length (bits to drop), 4-6 kind, 8-12 extra bits, 16-31 value
+// table entry: bits 0-5 the bits to drop — code length, plus the extra bits for a length / distance symbol, so that ONE shift
+// by the entry itself (a 6-bit count) moves the reader past the whole symbol and the extra bits' value is cut out of the old
+// buffer off the critical path —, 8-12 extra-bit count, 13-15 kind, 16-31 value
 enum Kind : uint32_t { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_SUB = 3, K_BAD = 4 };
-static inline uint32_t mk(uint32_t len, uint32_t kind, uint32_t extra, uint32_t val) { return len | (kind << 4) | (extra << 8) | (val << 16); }
+constexpr uint32_t KIND_SHIFT = 13, KIND_MASK = 7u << KIND_SHIFT;
+static inline uint32_t mk(uint32_t len, uint32_t kind, uint32_t extra, uint32_t val) {
+    return (len + (kind == K_LEN ? extra : 0u)) | (kind << KIND_SHIFT) | (extra << 8) | (val << 16);
+}
+static inline uint32_t drop_of(uint32_t e) { return e & 63u; }                                  // bits the symbol takes off the reader, extra bits included
+static inline uint32_t codelen_of(uint32_t e) {                                                 // ... its Huffman code alone
+    return ((e >> KIND_SHIFT) & 7u) == K_LEN ? (e & 63u) - ((e >> 8) & 31u) : (e & 63u);
+}
 
 static const uint16_t LEN_BASE[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
 static const uint8_t LEN_EXTRA[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
@@ -101,8 +111,27 @@ static inline bool build_table(const uint8_t *lens, int nsyms, int what, uint32_
         }
         code <<= 1;
     }
+    // Literal pairs (literal/length table only): where a first-level index starts with a literal of l1 bits and its remaining
+    // table_bits - l1 bits hold a whole second literal, the entry delivers both — total length in bits 0-3, kind still K_LIT,
+    // extra field = 1 | l1 << 1 (bit 8: "two bytes", bits 9-12: the first code's length, for the one-symbol-at-a-time loop),
+    // value = lit1 | lit2 << 8.  FASTQ text is mostly literals with 2-6 bit codes: the dependent look-up -> shift -> look-up
+    // chain of the fast loop is then walked once per two bytes.  In place, from the top: the second literal's entry sits at
+    // i >> l1 < i, not yet rewritten.
+    if (what == 0)
+        for (int i = prim - 1; i >= 0; i--) {
+            const uint32_t e = table[i];
+            if ((e & KIND_MASK) != (K_LIT << KIND_SHIFT)) continue;
+            const uint32_t l1 = e & 63u;
+            if ((int)l1 >= table_bits) continue;
+            const uint32_t e2 = table[(uint32_t)i >> l1];
+            if ((e2 & (KIND_MASK | 0x1f00u)) != (K_LIT << KIND_SHIFT) || l1 + (e2 & 63u) > (uint32_t)table_bits) continue;
+            table[i] = mk(l1 + (e2 & 63u), K_LIT, 1u | (l1 << 1), (e >> 16) | ((e2 >> 16) << 8));
+        }
     return true;
 }
+
+// both bytes of a literal entry's value are stored, the second counts only for a pair (else it is 0 and overwritten next)
+static inline void put2(uint8_t *out, uint32_t e) { const uint16_t v = (uint16_t)(e >> 16); memcpy(out, &v, 2); }
 
 struct Decoder {
     // bit reader
@@ -139,6 +168,12 @@ struct Decoder {
     // are ever needed).  Returns the new output position.  Stops when the output piece is full, the input piece is
     // exhausted (state stays resumable) or the final block ended (state == DONE).  `eof` = no more input will come.
     uint8_t *run(uint8_t *out, uint8_t *out_limit, const uint8_t *hist, bool eof);
+    // the one body, compiled twice on x86-64: as it is, and with BMI/BMI2 enabled (shrx/bzhi shorten the shift-and-mask chain
+    // between two table look-ups: +10 % on FASTQ text); run() picks by what the CPU it runs on reports
+    __attribute__((always_inline)) inline uint8_t *run_body(uint8_t *out, uint8_t *out_limit, const uint8_t *hist, bool eof);
+#if defined(__x86_64__)
+    __attribute__((target("bmi,bmi2"))) uint8_t *run_bmi2(uint8_t *out, uint8_t *out_limit, const uint8_t *hist, bool eof);
+#endif
 };
 
 inline void Decoder::load_fixed() {
@@ -174,9 +209,9 @@ inline int Decoder::read_dynamic_header() {
     while (n < total) {
         top_up();
         const uint32_t e = pre[bb & ((1u << PRE_BITS) - 1)];
-        const int cl = (int)(e & 15u);
+        const int cl = (int)(e & 63u);
         if (cl > bc) return 0;
-        if (((e >> 4) & 7u) == K_BAD) { fail("flate: corrupt input (code lengths)"); return -1; }
+        if (((e >> KIND_SHIFT) & 7u) == K_BAD) { fail("flate: corrupt input (code lengths)"); return -1; }
         const uint32_t sym = e >> 16;
         const int xb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
         if (cl + xb > bc) return 0;
@@ -197,7 +232,19 @@ inline int Decoder::read_dynamic_header() {
     return 1;
 }
 
+#if defined(__x86_64__)
+__attribute__((target("bmi,bmi2"))) inline uint8_t *Decoder::run_bmi2(uint8_t *out, uint8_t *out_limit, const uint8_t *hist, bool eof) {
+    return run_body(out, out_limit, hist, eof);
+}
 inline uint8_t *Decoder::run(uint8_t *out, uint8_t *out_limit, const uint8_t *hist, bool eof) {
+    static const bool bmi2 = __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2");
+    return bmi2 ? run_bmi2(out, out_limit, hist, eof) : run_body(out, out_limit, hist, eof);
+}
+#else
+inline uint8_t *Decoder::run(uint8_t *out, uint8_t *out_limit, const uint8_t *hist, bool eof) { return run_body(out, out_limit, hist, eof); }
+#endif
+
+__attribute__((always_inline)) inline uint8_t *Decoder::run_body(uint8_t *out, uint8_t *out_limit, const uint8_t *hist, bool eof) {
     for (;;) {
         if (state == DONE || state == ERROR) return out;
         if (state == HEADER) {
@@ -253,58 +300,74 @@ inline uint8_t *Decoder::run(uint8_t *out, uint8_t *out_limit, const uint8_t *hi
             while (pend_len && out < out_limit) { *out = *(out - pend_dist); out++; pend_len--; }
             if (pend_len) return out;
         }
-        // fast loop: >= 16 input bytes and >= OUT_SLACK output bytes ahead.  The reader state lives in locals here:
+        // fast loop: >= IN_SLACK input bytes and >= OUT_SLACK output bytes ahead.  The reader state lives in locals here:
         // stores through the (byte) output pointer may alias anything, and would force the members to be re-read
-        // after every literal.
-        {
+        // after every literal.  The loop is software-pipelined: every path ends with "refill, look the NEXT symbol's entry
+        // up", and a match does so BEFORE it copies, so that the table load of the next symbol (the head of the dependent
+        // chain look-up -> shift -> look-up) is in flight behind the copy.  DNA text inflates as tens of millions of 4-8 byte
+        // matches (a 4-letter alphabet repeats every 4-mer within any 32 KiB), not as literals: the per-match latency is
+        // what the rate of a FASTQ stream is made of.
+        if (in_left() >= IN_SLACK && (size_t)(out_limit - out) >= OUT_SLACK) {
             uint64_t bb = bitbuf; int bc = bitcnt; const uint8_t *ip = in;
-            const uint8_t *const ip_stop = in_end - 16;
+            const uint8_t *const ip_stop = in_end - IN_SLACK;
             uint8_t *const out_stop = out_limit - OUT_SLACK;
             const uint32_t *const lt = litlen, *const dt = dist;
             int leave = 0;                                          // 1 = end of block, 2 = error (err set)
-            while (ip <= ip_stop && out <= out_stop) {
-                uint64_t w; memcpy(&w, ip, 8);
-                bb |= w << bc; ip += (63 - bc) >> 3; bc |= 56;
-                uint32_t e = lt[bb & ((1u << LITLEN_BITS) - 1)];
-                if (((e >> 4) & 7u) == K_LIT) {
-                    // up to four literals from one refill (each <= 11 bits here: first-level hits)
-                    bb >>= (e & 15u); bc -= (int)(e & 15u); *out++ = (uint8_t)(e >> 16);
+            uint64_t w;
+#define HULK_REFILL() do { memcpy(&w, ip, 8); bb |= w << bc; ip += (63 - bc) >> 3; bc |= 56; } while (0)
+            HULK_REFILL();
+            uint32_t e = lt[bb & ((1u << LITLEN_BITS) - 1)];
+            // every iteration starts refilled (56..63 bits) with `e` = the entry of the symbol at the reader's position, and makes at
+            // most two more refills of <= 7 bytes each: ip <= in_end - IN_SLACK here keeps every 8-byte load inside the piece
+            do {
+                if (((e >> KIND_SHIFT) & 7u) == K_LIT) {
+                    // up to four first-level hits from one refill (each <= 11 bits: one literal or a pair of them)
+                    bb >>= (e & 63u); bc -= (int)(e & 63u); put2(out, e); out += 1 + ((e >> 8) & 1u);
                     e = lt[bb & ((1u << LITLEN_BITS) - 1)];
-                    if (((e >> 4) & 7u) != K_LIT) goto not_literal;
-                    bb >>= (e & 15u); bc -= (int)(e & 15u); *out++ = (uint8_t)(e >> 16);
+                    if (((e >> KIND_SHIFT) & 7u) != K_LIT) goto not_literal;
+                    bb >>= (e & 63u); bc -= (int)(e & 63u); put2(out, e); out += 1 + ((e >> 8) & 1u);
                     e = lt[bb & ((1u << LITLEN_BITS) - 1)];
-                    if (((e >> 4) & 7u) != K_LIT) goto not_literal;
-                    bb >>= (e & 15u); bc -= (int)(e & 15u); *out++ = (uint8_t)(e >> 16);
+                    if (((e >> KIND_SHIFT) & 7u) != K_LIT) goto not_literal;
+                    bb >>= (e & 63u); bc -= (int)(e & 63u); put2(out, e); out += 1 + ((e >> 8) & 1u);
                     e = lt[bb & ((1u << LITLEN_BITS) - 1)];
-                    if (((e >> 4) & 7u) != K_LIT) goto not_literal;
-                    bb >>= (e & 15u); bc -= (int)(e & 15u); *out++ = (uint8_t)(e >> 16);
+                    if (((e >> KIND_SHIFT) & 7u) != K_LIT) goto not_literal;
+                    bb >>= (e & 63u); bc -= (int)(e & 63u); put2(out, e); out += 1 + ((e >> 8) & 1u);
+                    HULK_REFILL();
+                    e = lt[bb & ((1u << LITLEN_BITS) - 1)];
                     continue;
                 not_literal:
-                    // <= 33 bits used, >= 23 left: not enough for a length + distance pair (<= 48): refill first
-                    if (ip > ip_stop) break;
-                    memcpy(&w, ip, 8);
-                    bb |= w << bc; ip += (63 - bc) >> 3; bc |= 56;
+                    // <= 33 bits used, >= 23 left (the look-up above saw 11 real bits): not enough for a length + distance pair
+                    // (<= 48): refill — `e` stays what it is, a refill only adds bits above the ones present
+                    HULK_REFILL();
                 }
-                if (((e >> 4) & 7u) == K_SUB) { bb >>= LITLEN_BITS; bc -= LITLEN_BITS; e = lt[(e >> 16) + (bb & ((1u << ((e >> 8) & 31u)) - 1))]; }
-                bb >>= (e & 15u); bc -= (int)(e & 15u);
-                const uint32_t kind = (e >> 4) & 7u;
-                if (kind == K_LIT) { *out++ = (uint8_t)(e >> 16); continue; }           // (a literal with a long code)
+                if (((e >> KIND_SHIFT) & 7u) == K_SUB) { bb >>= LITLEN_BITS; bc -= LITLEN_BITS; e = lt[(e >> 16) + (bb & ((1u << ((e >> 8) & 31u)) - 1))]; }
+                const uint64_t sl = bb;                                              // (the length's extra bits are cut out of this)
+                bb >>= (e & 63u); bc -= (int)(e & 63u);
+                const uint32_t kind = (e >> KIND_SHIFT) & 7u;
+                if (kind == K_LIT) {                                                      // (a literal with a long code)
+                    *out++ = (uint8_t)(e >> 16);
+                    HULK_REFILL();
+                    e = lt[bb & ((1u << LITLEN_BITS) - 1)];
+                    continue;
+                }
                 if (kind != K_LEN) {
                     if (kind == K_EOB) { leave = 1; break; }
                     err = "flate: corrupt input (literal/length code)"; leave = 2; break;
                 }
                 const uint32_t xb = (e >> 8) & 31u;
-                const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << xb) - 1));
-                bb >>= xb; bc -= (int)xb;
+                const uint32_t len = (e >> 16) + (uint32_t)((sl >> ((e & 63u) - xb)) & ((1u << xb) - 1));
                 // <= 15 + 5 bits of >= 56 used so far; the distance needs <= 15 + 13 more
                 uint32_t d = dt[bb & ((1u << DIST_BITS) - 1)];
-                if (((d >> 4) & 7u) == K_SUB) { bb >>= DIST_BITS; bc -= DIST_BITS; d = dt[(d >> 16) + (bb & ((1u << ((d >> 8) & 31u)) - 1))]; }
-                if (((d >> 4) & 7u) != K_LEN) { err = "flate: corrupt input (distance code)"; leave = 2; break; }
-                bb >>= (d & 15u); bc -= (int)(d & 15u);
+                if (((d >> KIND_SHIFT) & 7u) == K_SUB) { bb >>= DIST_BITS; bc -= DIST_BITS; d = dt[(d >> 16) + (bb & ((1u << ((d >> 8) & 31u)) - 1))]; }
+                if (((d >> KIND_SHIFT) & 7u) != K_LEN) { err = "flate: corrupt input (distance code)"; leave = 2; break; }
+                const uint64_t sd = bb;
+                bb >>= (d & 63u); bc -= (int)(d & 63u);
                 const uint32_t dxb = (d >> 8) & 31u;
-                const uint32_t distance = (d >> 16) + (uint32_t)(bb & ((1u << dxb) - 1));
-                bb >>= dxb; bc -= (int)dxb;
+                const uint32_t distance = (d >> 16) + (uint32_t)((sd >> ((d & 63u) - dxb)) & ((1u << dxb) - 1));
                 if (distance > (size_t)(out - hist)) { err = "flate: corrupt input (distance too far back)"; leave = 2; break; }
+                // the next symbol's entry, requested before the copy
+                HULK_REFILL();
+                e = lt[bb & ((1u << LITLEN_BITS) - 1)];
                 const uint8_t *src = out - distance;
                 uint8_t *dst = out; out += len;
                 if (distance >= 8) {
@@ -318,7 +381,8 @@ inline uint8_t *Decoder::run(uint8_t *out, uint8_t *out_limit, const uint8_t *hi
                 } else {
                     while (dst < out) *dst++ = *src++;
                 }
-            }
+            } while (ip <= ip_stop && out <= out_stop);
+#undef HULK_REFILL
             // The refill above leaves up to 7 real look-ahead bits of *ip above `bc`; harmless while the next reader ORs the
             // same byte over them, wrong once a stored block has taken its bytes straight from `in` in between: hand the
             // state back with exactly `bc` bits.
@@ -333,12 +397,13 @@ inline uint8_t *Decoder::run(uint8_t *out, uint8_t *out_limit, const uint8_t *hi
             // an entry can be trusted iff the bits of its code were all there (missing bits read as zeros)
             uint32_t e = litlen[bitbuf & ((1u << LITLEN_BITS) - 1)];
             int used = 0;
-            if (((e >> 4) & 7u) == K_SUB) {
+            if (((e >> KIND_SHIFT) & 7u) == K_SUB) {
                 e = litlen[(e >> 16) + ((bitbuf >> LITLEN_BITS) & ((1u << ((e >> 8) & 31u)) - 1))];
                 used = LITLEN_BITS;
             }
-            const int cl = used + (int)(e & 15u);
-            const uint32_t kind = (e >> 4) & 7u;
+            int cl = used + (int)codelen_of(e);
+            const uint32_t kind = (e >> KIND_SHIFT) & 7u;
+            if (kind == K_LIT && ((e >> 8) & 1u)) cl = (int)((e >> 9) & 15u);      // a pair entry: its first literal only
             if (cl > bitcnt) { if (eof) fail("unexpected EOF"); return out; }
             if (kind == K_BAD) { fail("flate: corrupt input (literal/length code)"); return out; }
             if (kind == K_LIT) { bitbuf >>= cl; bitcnt -= cl; *out++ = (uint8_t)(e >> 16); continue; }
@@ -355,13 +420,13 @@ inline uint8_t *Decoder::run(uint8_t *out, uint8_t *out_limit, const uint8_t *hi
                 while (bc <= 56 && ip < in_end) { bb |= (uint64_t)(*ip++) << bc; bc += 8; }
                 uint32_t d = dist[bb & ((1u << DIST_BITS) - 1)];
                 int dused = 0;
-                if (((d >> 4) & 7u) == K_SUB) {
+                if (((d >> KIND_SHIFT) & 7u) == K_SUB) {
                     if (bc < DIST_BITS) { if (eof) fail("unexpected EOF"); return out; }
                     d = dist[(d >> 16) + ((bb >> DIST_BITS) & ((1u << ((d >> 8) & 31u)) - 1))];
                     dused = DIST_BITS;
                 }
-                const int dcl = dused + (int)(d & 15u);
-                const uint32_t dk = (d >> 4) & 7u;
+                const int dcl = dused + (int)codelen_of(d);
+                const uint32_t dk = (d >> KIND_SHIFT) & 7u;
                 const uint32_t dxb = (d >> 8) & 31u;
                 if (dk != K_LEN) {
                     if (bc >= dcl || eof) { fail(bc >= dcl ? "flate: corrupt input (distance code)" : "unexpected EOF"); }
@@ -378,7 +443,7 @@ inline uint8_t *Decoder::run(uint8_t *out, uint8_t *out_limit, const uint8_t *hi
                 if (n) { pend_len = n; pend_dist = distance; return out; }
             }
             // back to the fast loop when there is room again
-            if ((size_t)(in_end - in) >= 16 && (size_t)(out_limit - out) >= OUT_SLACK) break;
+            if (in_left() >= IN_SLACK && (size_t)(out_limit - out) >= OUT_SLACK) break;
         }
         continue;
     next_state:;
