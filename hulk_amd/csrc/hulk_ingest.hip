@@ -507,6 +507,14 @@ struct CallbackSink : Sink {
     do { hipError_t e_ = (call); if (e_ != hipSuccess) return err.set(HULK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
 // pinned double-buffered staging in front of hulk_add_reads_device
+// HULK_INGEST_TRACE=1: seconds the calling thread spent in each phase of a run, on stderr when the run ends (diagnosis)
+struct PhaseTrace {
+    double wait_block = 0, parse = 0, stage_wait = 0, alloc = 0, enqueue = 0, add_reads = 0;
+    static bool on() { static const bool v = getenv("HULK_INGEST_TRACE") != nullptr; return v; }
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+static PhaseTrace g_trace;
+
 struct GpuSink : Sink {
     struct Stage {
         uint8_t *h_bases = nullptr, *d_bases = nullptr; uint64_t *h_off = nullptr, *d_off = nullptr;
@@ -527,7 +535,9 @@ struct GpuSink : Sink {
     bool prepare(uint64_t n, uint64_t nbytes, uint8_t **b, uint64_t **l, IngestError &err) override {
         Stage &s = st[cur];
         if (!s.ev) ING_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+        const double tw0 = PhaseTrace::now();
         if (s.busy) { ING_HIP(hipEventSynchronize(s.ev)); s.busy = false; }      // its copies + kernels are done
+        const double tw1 = PhaseTrace::now(); g_trace.stage_wait += tw1 - tw0;
         if (nbytes + 32 > s.cap_bases) {
             if (s.h_bases) hipHostFree(s.h_bases);
             if (s.d_bases) hipFree(s.d_bases);
@@ -545,6 +555,7 @@ struct GpuSink : Sink {
             ING_HIP(hipMalloc((void **)&s.d_off, s.cap_off * 8));
         }
         *b = s.h_bases; *l = s.h_off;
+        g_trace.alloc += PhaseTrace::now() - tw1;
         return true;
     }
     bool commit(uint64_t n, IngestError &err) override {
@@ -557,9 +568,12 @@ struct GpuSink : Sink {
         if (mn < min_len) return err.set(HULK_ERR_SHORT_SEQ, hulk_strerror(HULK_ERR_SHORT_SEQ));
         if (mx > 0xffffffffull) return err.set(HULK_ERR_READ_TOO_LONG, hulk_strerror(HULK_ERR_READ_TOO_LONG));
         hipStream_t stream = hulk::ctx_stream(ctx);
+        const double tc0 = PhaseTrace::now();
         ING_HIP(hipMemcpyAsync(s.d_bases, s.h_bases, tot, hipMemcpyHostToDevice, stream));
         ING_HIP(hipMemcpyAsync(s.d_off, s.h_off, (n + 1) * 8, hipMemcpyHostToDevice, stream));
+        const double tc1 = PhaseTrace::now(); g_trace.enqueue += tc1 - tc0;
         const int rc = hulk_add_reads_device(ctx, s.d_bases, s.d_off, n, (uint32_t)mx, s.cap_bases);
+        g_trace.add_reads += PhaseTrace::now() - tc1;
         if (rc != HULK_OK) return err.set(rc, hulk_last_error(ctx));
         ING_HIP(hipEventRecord(s.ev, stream));
         s.busy = true;
@@ -778,10 +792,14 @@ int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, uint32_t t
     BlockReader reader(paths, n_paths);
     Parser ps(sink, threads, err);
     bool ok = true;
+    g_trace = PhaseTrace{};
     for (;;) {
+        const double tb0 = PhaseTrace::now();
         std::unique_ptr<Block> b = reader.next(err);
+        const double tb1 = PhaseTrace::now(); g_trace.wait_block += tb1 - tb0;
         if (!b) { ok = err.code == HULK_OK; break; }
         ok = fasta ? ps.fasta_block(*b) : ps.fastq_block(*b);
+        g_trace.parse += PhaseTrace::now() - tb1;
         reader.recycle(std::move(b));
         if (!ok || (fasta && ps.fa_stopped)) break;
     }
@@ -792,6 +810,10 @@ int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, uint32_t t
         stats->bytes_in = reader.bytes_in();
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+    if (PhaseTrace::on())
+        fprintf(stderr, "ingest trace (calling thread, s): next block %.3f | parse + sink %.3f, of which: staging wait %.3f, staging "
+                        "alloc %.3f, copies queued %.3f, hulk_add_reads_device %.3f\n", g_trace.wait_block, g_trace.parse,
+                g_trace.stage_wait, g_trace.alloc, g_trace.enqueue, g_trace.add_reads);
     return ok ? HULK_OK : err.code;
 }
 

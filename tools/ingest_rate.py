@@ -47,5 +47,6 @@ if a.gpu:
     st = g.sketch_files([path], threads=a.threads)
     g.finish()
     dt = time.time() - t0
-    print("sketch_files: %d reads in %.3f s -> %.2e reads/s end to end (file %.1f MB on disk)" % (st["n_seqs"], dt, st["n_seqs"] / dt, size / 1e6))
+    print("sketch_files: %d reads in %.3f s (%.3f s inside hulk_sketch_files) -> %.2e reads/s end to end (file %.1f MB on disk)"
+          % (st["n_seqs"], dt, st["seconds"], st["n_seqs"] / dt, size / 1e6))
     g.close()
