@@ -156,7 +156,7 @@ def self_spawn(args):
 
 def e2e_file_rates(n_reads=2_000_000):
     """End to end, FASTQ file -> sketch (the reference's DataStreamer/FastqHandler/AddSeq loop, pipeline/sketch.go:40-217,
-    in native code: hulk_sketch_files): a synthetic FASTQ of `n_reads` 150 bp reads on /dev/shm, plain and .gz, C2 parameters,
+    in native code: hulk_sketch_files): a synthetic FASTQ of `n_reads` 150 bp reads on /dev/shm, plain, .gz (one member) and bgzip'd, C2 parameters,
     wall clock from the first byte read to hulk_finish, on a context whose tables exist (the second of two runs, so the
     pinned staging is allocated too).  Host-bound (parse / inflate), reported beside the kernel-path figure, never as it."""
     import gzip
@@ -178,7 +178,18 @@ def e2e_file_rates(n_reads=2_000_000):
         gz = plain + ".gz"
         with open(plain, "rb") as fi, gzip.open(gz, "wb", compresslevel=1) as fo:
             shutil.copyfileobj(fi, fo, 1 << 24)
-        for label, path in (("plain", plain), ("gz", gz)):
+        import zlib
+        bg = plain + ".bgzf.gz"                  # bgzip's container: 64 KiB members with their size in the header, inflated side by side
+        with open(plain, "rb") as fi, open(bg, "wb") as fo:
+            while True:
+                piece = fi.read(65280)
+                c = zlib.compressobj(1, zlib.DEFLATED, -15)
+                body = c.compress(piece) + c.flush()
+                fo.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\x00BC\x02\x00" + (18 + len(body) + 8 - 1).to_bytes(2, "little") + body +
+                         (zlib.crc32(piece) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little"))
+                if not piece:                    # (the empty member written last is the format's end-of-file marker)
+                    break
+        for label, path in (("plain", plain), ("gz", gz), ("bgzf", bg)):
             best = None
             for _ in range(2):
                 g = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL)
@@ -192,7 +203,7 @@ def e2e_file_rates(n_reads=2_000_000):
                 best = dt if best is None else min(best, dt)
             out[label] = {"value": n_reads / best, "unit": "reads/s", "seconds": best, "file_bytes": os.path.getsize(path),
                           "sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()}
-        assert out["plain"]["sketch_md5"] == out["gz"]["sketch_md5"]
+        assert out["plain"]["sketch_md5"] == out["gz"]["sketch_md5"] == out["bgzf"]["sketch_md5"]
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return out

@@ -48,6 +48,7 @@ def test_bench_json_contract_and_collective_path():
     # end to end from a FASTQ file, plain and .gz: host-bound, far below the kernel-path rate, same sketch both ways
     e2e = a["e2e"]
     assert 1e5 < e2e["gz"]["value"] < e2e["plain"]["value"] < a["value"] and e2e["plain"]["sketch_md5"] == e2e["gz"]["sketch_md5"]
+    assert e2e["gz"]["value"] < e2e["bgzf"]["value"] < a["value"] and e2e["bgzf"]["sketch_md5"] == e2e["plain"]["sketch_md5"]   # members side by side
     # the sharded step at world size 1: RCCL communicator, exchange inside the library, same sketch
     b = _run(["--no-cpu-baseline", "--no-cold", "--force-collective"], {"HULK_BENCH_C4_READS_PER_RANK": "5000000"})
     assert b["sketch_md5"] == a["sketch_md5"]

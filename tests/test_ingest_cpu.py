@@ -334,3 +334,71 @@ def test_inflate_against_zlib(tmp_path):
                    check=True, timeout=300)
     r = subprocess.run([exe, "250", "11"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def _bgzf(data, rng, level=6, eof_marker=True, extra_subfield=False):
+    """bgzip's container: members of <= 64 KiB of text, each header with the 'BC' extra subfield = member size - 1
+    (optionally behind another subfield), and the empty end-of-file member."""
+    import zlib
+    out = bytearray()
+    at = 0
+    pieces = []
+    while at < len(data):
+        n = int(rng.integers(1, 65281)) if rng.random() < 0.3 else 65280
+        pieces.append(data[at:at + n]); at += n
+    if eof_marker:
+        pieces.append(b"")
+    for piece in pieces:
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(piece) + c.flush()
+        pre = b"XY\x03\x00abc" if extra_subfield else b""
+        xlen = len(pre) + 6
+        total = 12 + xlen + len(body) + 8
+        assert total <= 65536
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + xlen.to_bytes(2, "little") + pre + b"BC\x02\x00" + (total - 1).to_bytes(2, "little")
+        out += body + (zlib.crc32(piece) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little")
+    return bytes(out)
+
+
+def test_bgzf_members_are_inflated_side_by_side(tmp_path):
+    """bgzip files go through the parallel member reader (GzBgzf): same reads as the text; an ordinary gzip member, trailing
+    bytes, a lying BSIZE, a bad checksum or a cut file in the middle hand the stream over to the one-thread reader, whose
+    results and messages they must therefore keep; the one-thread reader alone (HULK_GZ_THREADS=1) agrees."""
+    rng = np.random.default_rng(11)
+    seqs, blob = _fastq_blob(rng, 60_000)                       # ~ 17 MB of text: several 8 MB pieces of compressed input? (one or two) and ~270 members
+    assert len(blob) > 16 << 20
+    p = str(tmp_path / "a.fq.gz"); open(p, "wb").write(_bgzf(blob, rng))
+    assert native([p]) == seqs
+    p = str(tmp_path / "sub.fq.gz"); open(p, "wb").write(_bgzf(blob, rng, level=1, extra_subfield=True, eof_marker=False))
+    assert native([p]) == seqs
+    # BGZF, then an ordinary member, then BGZF again, then bytes that are no gzip header
+    cut1, cut2 = blob.index(b"\n@r20000\n") + 1, blob.index(b"\n@r41000\n") + 1
+    mixed = _bgzf(blob[:cut1], rng, eof_marker=False) + gzip.compress(blob[cut1:cut2], 6) + _bgzf(blob[cut2:], rng) + b"\0\0not gzip"
+    p = str(tmp_path / "mixed.fq.gz"); open(p, "wb").write(mixed)
+    assert native([p]) == seqs
+    good = _bgzf(blob, rng)
+    # BSIZE of the third member off by a few bytes: the members cannot be located from there on, the stream itself is fine
+    hdr = [i for i in range(len(good) - 18) if good[i:i + 4] == b"\x1f\x8b\x08\x04" and good[i + 12:i + 16] == b"BC\x02\x00"]
+    lying = bytearray(good); at = hdr[2] + 16
+    lying[at:at + 2] = (int.from_bytes(good[at:at + 2], "little") + 7).to_bytes(2, "little")
+    p = str(tmp_path / "lying.fq.gz"); open(p, "wb").write(bytes(lying))
+    assert native([p]) == seqs
+    # checksum of a member in the middle / a cut file: the reference's messages
+    bad = bytearray(good); bad[hdr[5] - 6] ^= 0x20                # (CRC-32 field of member 4)
+    p = str(tmp_path / "crc.fq.gz"); open(p, "wb").write(bytes(bad))
+    with pytest.raises(HulkError) as e:
+        native([p])
+    assert e.value.message == "gzip: invalid checksum"
+    p = str(tmp_path / "cut.fq.gz"); open(p, "wb").write(good[:hdr[len(hdr) // 2] + 300])
+    with pytest.raises(HulkError) as e:
+        native([p])
+    assert e.value.message == "unexpected EOF"
+    # a file that is only the end-of-file member: no reads, no error
+    p = str(tmp_path / "empty.fq.gz"); open(p, "wb").write(_bgzf(b"", rng))
+    assert native([p]) == []
+    code = ("import sys; sys.path.insert(0, %r)\nfrom hulk_amd import ingest\n"
+            "b, o, st = ingest.parse_files(%r)\nimport hashlib; print(st['n_seqs'], hashlib.md5(b.tobytes()).hexdigest())"
+            % (ROOT, [str(tmp_path / "a.fq.gz"), str(tmp_path / "mixed.fq.gz"), str(tmp_path / "lying.fq.gz")]))
+    outs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **extra)).stdout.strip() for extra in ({}, {"HULK_GZ_THREADS": "1"}, {"HULK_GZ_ZLIB": "1"})]
+    assert outs[0] == outs[1] == outs[2] and outs[0].startswith(str(3 * len(seqs)) + " ")

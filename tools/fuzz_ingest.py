@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential test of the native line pump (hulk_parse_files) against the literal
 restatement of the reference (oracle/linepump.py): random line soups, CR/LF mixes, missing final
-newlines, empty lines everywhere, several inputs, gzip, FASTQ and FASTA mode, small blocks.  CPU only."""
+newlines, empty lines everywhere, several inputs, gzip and bgzip containers, FASTQ and FASTA mode, small blocks.  CPU only."""
 import gzip
 import os
 import sys
@@ -45,6 +45,23 @@ def soup(n_lines, clean):
     return data
 
 
+def bgzf(data, eof_marker=True):
+    import zlib
+    out = bytearray()
+    at, pieces = 0, []
+    while at < len(data):
+        n = int(rng.choice([1, 50, 700, 9000, 65280])); pieces.append(data[at:at + n]); at += n
+    if eof_marker:
+        pieces.append(b"")
+    for piece in pieces:
+        c = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, -15)
+        body = c.compress(piece) + c.flush()
+        total = 18 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\x00BC\x02\x00" + (total - 1).to_bytes(2, "little")
+        out += body + (zlib.crc32(piece) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little")
+    return bytes(out)
+
+
 with tempfile.TemporaryDirectory() as td:
     for case in range(n_cases):
         fasta = bool(rng.random() < 0.3)
@@ -55,8 +72,16 @@ with tempfile.TemporaryDirectory() as td:
             data = soup(n_lines, clean)
             gz = bool(rng.random() < 0.3)
             p = os.path.join(td, "c%d_%d.fq%s" % (case, f, ".gz" if gz else ""))
-            with (gzip.open(p, "wb") if gz else open(p, "wb")) as fh:
-                fh.write(data)
+            if gz and rng.random() < 0.4:                     # bgzip's container (members located by their BC field, inflated side by side),
+                with open(p, "wb") as fh:                        # sometimes with an ordinary member in the middle (hand-over to the one-thread reader)
+                    cut = int(rng.integers(0, len(data) + 1)) if rng.random() < 0.3 else len(data)
+                    fh.write(bgzf(data[:cut], eof_marker=cut == len(data)))
+                    if cut < len(data):
+                        cut2 = int(rng.integers(cut, len(data) + 1))
+                        fh.write(gzip.compress(data[cut:cut2], 1) + bgzf(data[cut2:]))
+            else:
+                with (gzip.open(p, "wb") if gz else open(p, "wb")) as fh:
+                    fh.write(data)
             paths.append(p)
         want = werr = got = gerr = None
         try:

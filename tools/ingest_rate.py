@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host ingest rate: writes a synthetic FASTQ (150 bp reads) under .scratch/ and times
 hulk_parse_files (parse only) and, with --gpu, hulk_sketch_files end to end.
-usage: ingest_rate.py [n_reads] [--gz] [--gpu] [--threads T]"""
+usage: ingest_rate.py [n_reads] [--gz | --bgzf] [--gpu] [--threads T]"""
 import argparse
 import gzip
 import os
@@ -15,14 +15,44 @@ from hulk_amd import ingest, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("n_reads", nargs="?", type=int, default=1_000_000)
 ap.add_argument("--gz", action="store_true")
+ap.add_argument("--bgzf", action="store_true", help="bgzip container (members of 64 KiB inflated side by side) instead of one gzip member")
 ap.add_argument("--gpu", action="store_true")
 ap.add_argument("--threads", type=int, default=0)
 a = ap.parse_args()
 os.makedirs(os.path.join(ROOT, ".scratch"), exist_ok=True)
-path = os.path.join(ROOT, ".scratch", "synth_%d.fq%s" % (a.n_reads, ".gz" if a.gz else ""))
+path = os.path.join(ROOT, ".scratch", "synth_%d.fq%s" % (a.n_reads, ".bgzf.gz" if a.bgzf else ".gz" if a.gz else ""))
+
+
+class BgzfWriter:
+    """bgzip's container, level 1: 65280-byte members with the BC extra subfield, and the empty end-of-file member"""
+    def __init__(self, p):
+        self.fh, self.buf = open(p, "wb"), bytearray()
+
+    def member(self, piece):
+        import zlib
+        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = c.compress(bytes(piece)) + c.flush()
+        self.fh.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\x00BC\x02\x00" + (18 + len(body) + 8 - 1).to_bytes(2, "little") + body +
+                      (zlib.crc32(bytes(piece)) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little"))
+
+    def write(self, data):
+        self.buf += data
+        while len(self.buf) >= 65280:
+            self.member(self.buf[:65280]); del self.buf[:65280]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.buf:
+            self.member(self.buf)
+        self.member(b"")
+        self.fh.close()
+
+
 if not os.path.exists(path):
     L = 150
-    op = (lambda p: gzip.open(p, "wb", compresslevel=1)) if a.gz else (lambda p: open(p, "wb"))
+    op = BgzfWriter if a.bgzf else (lambda p: gzip.open(p, "wb", compresslevel=1)) if a.gz else (lambda p: open(p, "wb"))
     with op(path) as fh:
         qual = b"I" * L
         for first in range(0, a.n_reads, 100000):
