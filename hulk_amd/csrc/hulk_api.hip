@@ -1063,14 +1063,8 @@ int ctx_fail(hulk_ctx *c, int code, const char *full_message) {
 
 
 namespace {
-// reads [i0, i1) of the caller's host buffers -> the next of the two pinned + device staging sets: host copy (several
-// threads: one core copies ~10 GB/s, a PCIe 5 x16 link moves ~50) and hipMemcpyAsync on the context's stream.  The caller
-// queues its kernels behind the copies, then records hs.ev and sets hs.busy (the set is reused when that event has passed).
-int stage_host_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t i0, uint64_t i1,
-                     hulk_ctx::HostStage **out) {
-    const uint64_t cn = i1 - i0, lo = offsets[i0];
-    const size_t nbytes = (size_t)(offsets[i1] - lo);
-    hulk_ctx::HostStage &hs = c->hstage[c->hstage_cur];
+// a staging set that is free again (its last copies and kernels done) and holds nbytes of bases and cn reads
+int stage_ready(hulk_ctx *c, hulk_ctx::HostStage &hs, size_t nbytes, uint64_t cn) {
     if (!hs.ev) HIPCHK(c, hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
     if (hs.busy) { HIPCHK(c, hipEventSynchronize(hs.ev)); hs.busy = false; }     // its copies and kernels are done
     if (nbytes + 32 > hs.cap_bases) {
@@ -1087,6 +1081,17 @@ int stage_host_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets,
         HIPCHK(c, hipHostMalloc((void **)&hs.h_off, hs.cap_off * 8, hipHostMallocDefault));
         HIPCHK(c, hipMalloc((void **)&hs.d_off, hs.cap_off * 8));
     }
+    return HULK_OK;
+}
+// reads [i0, i1) of the caller's host buffers -> the next of the two pinned + device staging sets: host copy (several
+// threads: one core copies ~10 GB/s, a PCIe 5 x16 link moves ~50) and hipMemcpyAsync on the context's stream.  The caller
+// queues its kernels behind the copies, then records hs.ev and sets hs.busy (the set is reused when that event has passed).
+int stage_host_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t i0, uint64_t i1,
+                     hulk_ctx::HostStage **out) {
+    const uint64_t cn = i1 - i0, lo = offsets[i0];
+    const size_t nbytes = (size_t)(offsets[i1] - lo);
+    hulk_ctx::HostStage &hs = c->hstage[c->hstage_cur];
+    { const int rc = stage_ready(c, hs, nbytes, cn); if (rc != HULK_OK) return rc; }
     {
         static const unsigned tmax = [] { const char *e = getenv("HULK_HOST_COPY_THREADS"); const long v = e ? atol(e) : 4; return (unsigned)(v < 1 ? 1 : v > 32 ? 32 : v); }();
         const unsigned T = nbytes >= (8u << 20) ? tmax : 1u;
@@ -1123,6 +1128,23 @@ int check_host_reads(hulk_ctx *c, const uint64_t *offsets, uint64_t n, uint64_t 
     return HULK_OK;
 }
 }  // namespace
+
+namespace hulk {
+int ctx_stage_acquire(hulk_ctx *c, size_t nbytes, uint64_t n, StageSet *out) {
+    hulk_ctx::HostStage &hs = c->hstage[c->hstage_cur];
+    const int rc = stage_ready(c, hs, nbytes, n);
+    if (rc != HULK_OK) return rc;
+    out->h_bases = hs.h_bases; out->d_bases = hs.d_bases; out->h_off = hs.h_off; out->d_off = hs.d_off; out->cap_bases = hs.cap_bases;
+    return HULK_OK;
+}
+int ctx_stage_release(hulk_ctx *c) {
+    hulk_ctx::HostStage &hs = c->hstage[c->hstage_cur];
+    HIPCHK(c, hipEventRecord(hs.ev, c->stream));
+    hs.busy = true;
+    c->hstage_cur ^= 1;
+    return HULK_OK;
+}
+}  // namespace hulk
 
 extern "C" {
 int hulk_add_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,

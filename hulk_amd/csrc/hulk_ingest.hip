@@ -720,82 +720,46 @@ struct CallbackSink : Sink {
 // pinned double-buffered staging in front of hulk_add_reads_device
 // HULK_INGEST_TRACE=1: seconds the calling thread spent in each phase of a run, on stderr when the run ends (diagnosis)
 struct PhaseTrace {
-    double wait_block = 0, parse = 0, stage_wait = 0, alloc = 0, enqueue = 0, add_reads = 0;
+    double wait_block = 0, parse = 0, stage_wait = 0, enqueue = 0, add_reads = 0;
     static bool on() { static const bool v = getenv("HULK_INGEST_TRACE") != nullptr; return v; }
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 };
 static PhaseTrace g_trace;
 
 struct GpuSink : Sink {
-    struct Stage {
-        uint8_t *h_bases = nullptr, *d_bases = nullptr; uint64_t *h_off = nullptr, *d_off = nullptr;
-        size_t cap_bases = 0, cap_off = 0; hipEvent_t ev = nullptr; bool busy = false;
-    };
-    hulk_ctx *ctx; Stage st[2]; int cur = 0; uint64_t min_len;
+    // the staging (two pinned + device sets) is the context's: nothing is allocated or freed per run after the first
+    hulk_ctx *ctx; hulk::StageSet st{}; uint64_t min_len;
     explicit GpuSink(hulk_ctx *c) : ctx(c), min_len(hulk::ctx_min_read_len(c)) {}
-    ~GpuSink() override {
-        for (auto &s : st) {
-            if (s.busy && s.ev) hipEventSynchronize(s.ev);
-            if (s.ev) hipEventDestroy(s.ev);
-            if (s.h_bases) hipHostFree(s.h_bases);
-            if (s.h_off) hipHostFree(s.h_off);
-            if (s.d_bases) hipFree(s.d_bases);
-            if (s.d_off) hipFree(s.d_off);
-        }
-    }
     bool prepare(uint64_t n, uint64_t nbytes, uint8_t **b, uint64_t **l, IngestError &err) override {
-        Stage &s = st[cur];
-        if (!s.ev) ING_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
         const double tw0 = PhaseTrace::now();
-        if (s.busy) { ING_HIP(hipEventSynchronize(s.ev)); s.busy = false; }      // its copies + kernels are done
-        const double tw1 = PhaseTrace::now(); g_trace.stage_wait += tw1 - tw0;
-        if (nbytes + 32 > s.cap_bases) {
-            if (s.h_bases) hipHostFree(s.h_bases);
-            if (s.d_bases) hipFree(s.d_bases);
-            s.h_bases = s.d_bases = nullptr;
-            s.cap_bases = (nbytes + 32) + (nbytes + 32) / 4;
-            ING_HIP(hipHostMalloc((void **)&s.h_bases, s.cap_bases, hipHostMallocDefault));
-            ING_HIP(hipMalloc((void **)&s.d_bases, s.cap_bases));
-        }
-        if (n + 2 > s.cap_off) {
-            if (s.h_off) hipHostFree(s.h_off);
-            if (s.d_off) hipFree(s.d_off);
-            s.h_off = s.d_off = nullptr;
-            s.cap_off = (n + 2) + (n + 2) / 4;
-            ING_HIP(hipHostMalloc((void **)&s.h_off, s.cap_off * 8, hipHostMallocDefault));
-            ING_HIP(hipMalloc((void **)&s.d_off, s.cap_off * 8));
-        }
-        *b = s.h_bases; *l = s.h_off;
-        g_trace.alloc += PhaseTrace::now() - tw1;
+        const int rc = hulk::ctx_stage_acquire(ctx, (size_t)nbytes, n, &st);
+        g_trace.stage_wait += PhaseTrace::now() - tw0;
+        if (rc != HULK_OK) return err.set(rc, hulk_last_error(ctx));
+        *b = st.h_bases; *l = st.h_off;
         return true;
     }
     bool commit(uint64_t n, IngestError &err) override {
         if (n == 0) return true;
-        Stage &s = st[cur];
         uint64_t mn, mx;
-        const uint64_t tot = lens_to_offsets(s.h_off, n, mn, mx);
+        const uint64_t tot = lens_to_offsets(st.h_off, n, mn, mx);
         // NewMinimizerSketch's checks (minimizer.go:70-76), as hulk_add_reads makes them
         if (mn < 1) return err.set(HULK_ERR_EMPTY_SEQ, hulk_strerror(HULK_ERR_EMPTY_SEQ));
         if (mn < min_len) return err.set(HULK_ERR_SHORT_SEQ, hulk_strerror(HULK_ERR_SHORT_SEQ));
         if (mx > 0xffffffffull) return err.set(HULK_ERR_READ_TOO_LONG, hulk_strerror(HULK_ERR_READ_TOO_LONG));
         hipStream_t stream = hulk::ctx_stream(ctx);
         const double tc0 = PhaseTrace::now();
-        ING_HIP(hipMemcpyAsync(s.d_bases, s.h_bases, tot, hipMemcpyHostToDevice, stream));
-        ING_HIP(hipMemcpyAsync(s.d_off, s.h_off, (n + 1) * 8, hipMemcpyHostToDevice, stream));
+        ING_HIP(hipMemcpyAsync(st.d_bases, st.h_bases, tot, hipMemcpyHostToDevice, stream));
+        ING_HIP(hipMemcpyAsync(st.d_off, st.h_off, (n + 1) * 8, hipMemcpyHostToDevice, stream));
         const double tc1 = PhaseTrace::now(); g_trace.enqueue += tc1 - tc0;
-        const int rc = hulk_add_reads_device(ctx, s.d_bases, s.d_off, n, (uint32_t)mx, s.cap_bases);
+        int rc = hulk_add_reads_device(ctx, st.d_bases, st.d_off, n, (uint32_t)mx, st.cap_bases);
         g_trace.add_reads += PhaseTrace::now() - tc1;
         if (rc != HULK_OK) return err.set(rc, hulk_last_error(ctx));
-        ING_HIP(hipEventRecord(s.ev, stream));
-        s.busy = true;
-        cur ^= 1;
+        rc = hulk::ctx_stage_release(ctx);
+        if (rc != HULK_OK) return err.set(rc, hulk_last_error(ctx));
         n_seqs += n; total_len += tot;
         return true;
     }
-    bool finish(IngestError &err) override {
-        for (auto &s : st) if (s.busy) { ING_HIP(hipEventSynchronize(s.ev)); s.busy = false; }
-        return true;
-    }
+    bool finish(IngestError &) override { return true; }      // (the sets stay the context's; whoever takes one next waits for its event)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1022,9 +986,9 @@ int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, uint32_t t
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     if (PhaseTrace::on())
-        fprintf(stderr, "ingest trace (calling thread, s): next block %.3f | parse + sink %.3f, of which: staging wait %.3f, staging "
-                        "alloc %.3f, copies queued %.3f, hulk_add_reads_device %.3f\n", g_trace.wait_block, g_trace.parse,
-                g_trace.stage_wait, g_trace.alloc, g_trace.enqueue, g_trace.add_reads);
+        fprintf(stderr, "ingest trace (calling thread, s): next block %.3f | parse + sink %.3f, of which: staging set (wait / first "
+                        "allocation) %.3f, copies queued %.3f, hulk_add_reads_device %.3f\n", g_trace.wait_block, g_trace.parse,
+                g_trace.stage_wait, g_trace.enqueue, g_trace.add_reads);
     return ok ? HULK_OK : err.code;
 }
 
