@@ -312,7 +312,18 @@ class GzBgzf : public GzStream {
             }
             if (cur_->off < cur_->out_len) {
                 const size_t n = std::min(cap, cur_->out_len - cur_->off);
-                memcpy(dst, cur_->out.data() + cur_->off, n);
+                const uint8_t *src = cur_->out.data() + cur_->off;
+                if (n >= (8u << 20)) {                              // one core copies ~8 GB/s, less than the members inflate at
+                    const unsigned R = 4;
+                    const size_t piece = (n / R + 63) & ~(size_t)63;
+                    std::vector<std::thread> th;
+                    auto work = [&](unsigned i) { const size_t at = (size_t)i * piece; if (at < n) memcpy(dst + at, src + at, std::min(piece, n - at)); };
+                    for (unsigned i = 1; i < R; i++) th.emplace_back(work, i);
+                    work(0);
+                    for (auto &t : th) t.join();
+                } else {
+                    memcpy(dst, src, n);
+                }
                 cur_->off += n;
                 return (long)n;
             }
