@@ -27,6 +27,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -36,6 +37,7 @@
 #include "../../include/hulk_hip.h"
 #include "hulk_internal.h"
 #include "fast_inflate.h"
+#include "par_inflate.h"
 
 namespace {
 
@@ -71,11 +73,17 @@ struct GzStream {
     virtual long read(uint8_t *dst, size_t cap, std::string &msg) = 0;      // up to cap bytes; 0 = end of the stream; -1 = error (msg filled)
 };
 
+// where a reader that inflated the front of a member by other means (GzPar) hands the member over: the descriptor is positioned
+// at the byte that holds the first bit of a block header, `bit` of its bits belong to the block in front; the last <= 32 KiB
+// of text, and the CRC-32 / length of all the member's text so far
+struct GzResume { int bit = 0; std::vector<uint8_t> hist; uint32_t crc = 0, size = 0; };
+
 class GzFast : public GzStream {
  public:
     // `first` = the stream starts here (an invalid first header is an error; after a member it is the clean end)
-    explicit GzFast(int fd, bool first = true) : fd_(fd), first_(first) {
+    explicit GzFast(int fd, bool first = true, const GzResume *resume = nullptr) : fd_(fd), first_(first) {
         for (auto &c : chunks_) { c.buf.resize(HIST + CHUNK + hulk::inflate::OUT_SLACK + 64); free_.push_back(&c); }
+        if (resume) { resume_ = *resume; resuming_ = true; crc_ = resume->crc; size_ = resume->size; }
         th_ = std::thread([this] { produce(); });
     }
     ~GzFast() {
@@ -184,10 +192,22 @@ class GzFast : public GzStream {
             uint8_t *base = c->buf.data() + HIST, *out = base;
             size_t hist_have = 0;
             std::string msg;
-            const int hr = read_header(first, msg);
-            if (hr <= 0) { finish(c, 0, hr < 0 ? msg : io_err_); return; }
-            first = false;
-            dec_.reset();
+            if (resuming_) {
+                // in the middle of a member: no header; the reader starts `bit` bits into the first byte, the window is handed in
+                resuming_ = false; first = false;
+                dec_.reset();
+                refill();
+                dec_.refill_slow();
+                if (dec_.bitcnt < resume_.bit) { finish(c, 0, !io_err_.empty() ? io_err_ : std::string("unexpected EOF")); return; }
+                dec_.bitbuf >>= resume_.bit; dec_.bitcnt -= resume_.bit;
+                hist_have = std::min(HIST, resume_.hist.size());
+                memcpy(base - hist_have, resume_.hist.data() + resume_.hist.size() - hist_have, hist_have);
+            } else {
+                const int hr = read_header(first, msg);
+                if (hr <= 0) { finish(c, 0, hr < 0 ? msg : io_err_); return; }
+                first = false;
+                dec_.reset();
+            }
             for (;;) {
                 uint8_t *lim = base + CHUNK;
                 out = dec_.run(out, lim, base - hist_have, false);
@@ -228,6 +248,8 @@ class GzFast : public GzStream {
 
     int fd_;
     bool first_;
+    GzResume resume_;
+    bool resuming_ = false;
     std::thread th_;
     std::mutex m_;
     std::condition_variable cv_;
@@ -243,6 +265,20 @@ class GzFast : public GzStream {
     Chunk *cur_ = nullptr;
     uint32_t crc_ = 0, size_ = 0;
 };
+
+// One core copies ~8 GB/s out of a buffer another core wrote, less than several inflate threads deliver: large pieces are
+// copied by four threads.  (Pieces of ceil(n / 4) rounded up to 64 bytes: with floor(n / 4), as first written, the last
+// n mod 4 bytes were not copied whenever floor(n / 4) happened to be a multiple of 64.)
+static void copy_wide(uint8_t *dst, const uint8_t *src, size_t n) {
+    if (n < (8u << 20)) { memcpy(dst, src, n); return; }
+    const unsigned R = 4;
+    const size_t piece = ((n + R - 1) / R + 63) & ~(size_t)63;
+    std::vector<std::thread> th;
+    auto work = [&](unsigned i) { const size_t at = (size_t)i * piece; if (at < n) memcpy(dst + at, src + at, std::min(piece, n - at)); };
+    for (unsigned i = 1; i < R; i++) th.emplace_back(work, i);
+    work(0);
+    for (auto &t : th) t.join();
+}
 
 // ------------------------------------------------------------------------------------------
 // BGZF (bgzip / htslib): a gzip file of members of <= 64 KiB of text whose headers carry the member's compressed size in a
@@ -313,17 +349,7 @@ class GzBgzf : public GzStream {
             if (cur_->off < cur_->out_len) {
                 const size_t n = std::min(cap, cur_->out_len - cur_->off);
                 const uint8_t *src = cur_->out.data() + cur_->off;
-                if (n >= (8u << 20)) {                              // one core copies ~8 GB/s, less than the members inflate at
-                    const unsigned R = 4;
-                    const size_t piece = (n / R + 63) & ~(size_t)63;
-                    std::vector<std::thread> th;
-                    auto work = [&](unsigned i) { const size_t at = (size_t)i * piece; if (at < n) memcpy(dst + at, src + at, std::min(piece, n - at)); };
-                    for (unsigned i = 1; i < R; i++) th.emplace_back(work, i);
-                    work(0);
-                    for (auto &t : th) t.join();
-                } else {
-                    memcpy(dst, src, n);
-                }
+                copy_wide(dst, src, n);
                 cur_->off += n;
                 return (long)n;
             }
@@ -455,6 +481,275 @@ class GzBgzf : public GzStream {
 };
 
 // ------------------------------------------------------------------------------------------
+// ONE gzip member inflated by several threads (par_inflate.h has the how and why).  The compressed file is taken in batches
+// of T chunks of 1 MB; a batch starts at a block boundary `q` that is known to the bit, with the 32 KiB of text in front of it.
+// Chunk 0 decodes from q with that window; chunk j > 0 looks for a block header behind byte j MB and decodes from there into
+// symbols, not knowing its window; every chunk runs until the first block boundary at or behind the start its successor
+// found.  Chunk j's work COUNTS only if chunk j-1 counted and ended, at a block boundary, exactly on chunk j's start bit:
+// then its start was a real boundary of the real stream, its unknown symbols are resolved from chunk j-1's last 32 KiB, and
+// the member's CRC-32 is combined from the chunks' (zlib's crc32_combine).  Where the chain breaks — a false candidate, no
+// candidate, a symbol buffer too small, the end of what was read — the next batch simply starts at the last boundary that
+// counted.  Whatever is not the plain middle of a member is not handled here at all: in front of the final block, at a block
+// that does not decode, or when a batch made no progress, the bytes so far are delivered and the one-thread reader (GzFast)
+// takes the member over from that bit with the window, the CRC-32 and the length so far — so the trailer check, further
+// members, trailing bytes, truncation and every message are exactly the one-thread reader's.  Regular files only.
+// HULK_GZ_THREADS as for BGZF; HULK_GZ_PAR=0 switches it off; HULK_GZ_PAR_CHUNK (bytes, >= 8 KiB) for tests.
+// ------------------------------------------------------------------------------------------
+class GzPar : public GzStream {
+ public:
+    static size_t chunk_bytes() {
+        static const size_t v = [] {
+            const char *e = getenv("HULK_GZ_PAR_CHUNK");
+            const size_t b = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(1u << 20);
+            return b < (8u << 10) ? (size_t)(8u << 10) : b;
+        }();
+        return v;
+    }
+    static bool wanted(int fd) {
+        static const bool on = [] { const char *e = getenv("HULK_GZ_PAR"); return !(e && e[0] == '0'); }();
+        struct stat sb;
+        return on && GzBgzf::threads() > 1 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= 4 * chunk_bytes();
+    }
+    explicit GzPar(int fd) : fd_(fd) { th_ = std::thread([this] { produce(); }); }
+    ~GzPar() override {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+        if (getenv("HULK_INGEST_TRACE"))
+            fprintf(stderr, "ingest trace: parallel gzip reader, %llu batches, %llu chunks counted / %llu decoded, %llu bytes of text%s; producer s: "
+                    "wait for a free batch %.3f, input %.3f, decode %.3f, windows %.3f, resolve + crc %.3f\n",
+                    (unsigned long long)n_batches_, (unsigned long long)n_counted_, (unsigned long long)n_decoded_, (unsigned long long)n_bytes_,
+                    tail_ ? ", then handed over to the one-thread reader" : "", t_wait_, t_in_, t_dec_, t_win_, t_res_);
+        if (tail_) tail_.reset();                                  // (owns and closes the descriptor from then on)
+        else if (fd_ > 0) ::close(fd_);
+    }
+    long read(uint8_t *dst, size_t cap, std::string &msg) override {
+        for (;;) {
+            if (tail_) return tail_->read(dst, cap, msg);
+            if (!cur_) {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return !ready_.empty(); });
+                cur_ = ready_.front(); ready_.pop_front();
+            }
+            if (cur_->off < cur_->out_len) {
+                const size_t n = std::min(cap, cur_->out_len - cur_->off);
+                copy_wide(dst, cur_->out.get() + cur_->off, n);
+                cur_->off += n;
+                return (long)n;
+            }
+            if (!cur_->err.empty()) { msg = cur_->err; return -1; }
+            if (cur_->hand) {
+                if (::lseek(fd_, cur_->hand_off, SEEK_SET) < 0) { msg = std::string("lseek: ") + strerror(errno); return -1; }
+                tail_.reset(cur_->mid_member ? new GzFast(fd_, false, &cur_->resume) : new GzFast(fd_, true));
+                continue;
+            }
+            { std::lock_guard<std::mutex> g(m_); free_.push_back(cur_); }
+            cv_.notify_all();
+            cur_ = nullptr;
+        }
+    }
+
+ private:
+    static constexpr size_t W = hulk::inflate::SPEC_WINDOW;
+    static constexpr int64_t PENDING = -1, NONE = -2;
+    struct Batch {
+        std::unique_ptr<uint8_t[]> out; size_t out_cap = 0, out_len = 0, off = 0;
+        bool hand = false, mid_member = false; off_t hand_off = 0; GzResume resume; std::string err;
+    };
+    Batch *get_free() {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return !free_.empty() || stop_; });
+        if (stop_) return nullptr;
+        Batch *b = free_.back(); free_.pop_back();
+        b->out_len = b->off = 0; b->hand = b->mid_member = false; b->err.clear();
+        return b;
+    }
+    void publish(Batch *b) { { std::lock_guard<std::mutex> g(m_); ready_.push_back(b); } cv_.notify_all(); }
+    static long pread_all(int fd, uint8_t *dst, size_t len, off_t at) {
+        size_t got = 0;
+        while (got < len) {
+            const ssize_t m = ::pread(fd, dst + got, len - got, at + (off_t)got);
+            if (m < 0) { if (errno == EINTR) continue; return -1; }
+            if (m == 0) break;
+            got += (size_t)m;
+        }
+        return (long)got;
+    }
+    // length of the gzip header at p (n bytes there), 0 = not all there / not one
+    static size_t header_len(const uint8_t *p, size_t n) {
+        if (n < 10 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8) return 0;
+        const uint8_t flg = p[3];
+        size_t o = 10;
+        if (flg & 4) { if (o + 2 > n) return 0; o += 2 + ((size_t)p[o] | ((size_t)p[o + 1] << 8)); if (o > n) return 0; }
+        if (flg & 8) { while (o < n && p[o]) o++; if (o >= n) return 0; o++; }
+        if (flg & 16) { while (o < n && p[o]) o++; if (o >= n) return 0; o++; }
+        if (flg & 2) { o += 2; }
+        return o <= n ? o : 0;
+    }
+
+    void produce() {
+        using namespace hulk::inflate;
+        const unsigned T = GzBgzf::threads();
+        const size_t C = chunk_bytes(), EXTRA = std::max<size_t>(C, 1u << 20), IN_LEN = (size_t)T * C + EXTRA;
+        // symbols per chunk: FASTQ deflates 3-5x; a block of zlib's is <= 32 Ki symbols of <= 258 bytes.  Where a chunk does not fit
+        // the chain breaks, no more — but a file that keeps breaking it (text that deflates 10x and more) is decoded T times for
+        // nothing: after three batches in a row of which less than half counted, the one-thread reader gets the rest
+        const size_t CAP = std::max<size_t>(10 * C, 2u << 20);
+        unsigned poor = 0;
+        // the gzip header
+        uint64_t q;                                                // bit of the file where the next batch starts (a block boundary)
+        {
+            std::vector<uint8_t> h(1u << 16);
+            const long m = pread_all(fd_, h.data(), h.size(), 0);
+            const size_t hl = m > 0 ? header_len(h.data(), (size_t)m) : 0;
+            if (hl == 0) {                                         // the one-thread reader says what is wrong with it
+                Batch *b = get_free(); if (!b) return;
+                b->hand = true; b->mid_member = false; b->hand_off = 0; publish(b); return;
+            }
+            q = 8 * (uint64_t)hl;
+        }
+        std::unique_ptr<uint8_t[]> inbuf[2] = {std::unique_ptr<uint8_t[]>(new uint8_t[IN_LEN + SPEC_IN_SLACK]), std::unique_ptr<uint8_t[]>(new uint8_t[IN_LEN + SPEC_IN_SLACK])};
+        std::vector<std::unique_ptr<uint16_t[]>> sym(T);
+        for (auto &p : sym) p.reset(new uint16_t[W + CAP + SPEC_OUT_SLACK + 8]);      // (not initialised: pages are touched as far as a chunk gets)
+        std::vector<SpecChunk> ch(T);
+        std::vector<std::atomic<int64_t>> start(T + 1);
+        std::vector<uint8_t> win(W, 0), lut((size_t)T * (256 + W));
+        size_t have = 0; uint32_t crc = 0; uint64_t total = 0;
+        // the next batch's input is read ahead while this one is decoded (its position is a guess: this batch's nominal end)
+        int cur_in = 0;
+        std::thread ahead; off_t ahead_off = -1; long ahead_got = 0;
+        auto join_ahead = [&] { if (ahead.joinable()) ahead.join(); };
+        struct Joiner { std::function<void()> f; ~Joiner() { f(); } } joiner{join_ahead};
+
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        for (;;) {
+            double t0 = now();
+            Batch *b = get_free();
+            if (!b) return;
+            t_wait_ += now() - t0; t0 = now();
+            auto hand_over = [&](uint64_t at_bit) {
+                b->hand = true; b->mid_member = true; b->hand_off = (off_t)(at_bit >> 3);
+                b->resume.bit = (int)(at_bit & 7); b->resume.crc = crc; b->resume.size = (uint32_t)total;
+                b->resume.hist.assign(win.end() - (ptrdiff_t)have, win.end());
+                publish(b);
+            };
+            // input: from the read-ahead when the guess was good, else read now
+            join_ahead();
+            const off_t qb = (off_t)(q >> 3);
+            off_t F; long got;
+            if (ahead_off >= 0 && qb >= ahead_off && (size_t)(qb - ahead_off) < EXTRA / 2) { cur_in ^= 1; F = ahead_off; got = ahead_got; }
+            else { F = qb; got = pread_all(fd_, inbuf[cur_in].get(), IN_LEN, F); }
+            ahead_off = -1;
+            if (got < 0) { b->err = std::string("read: ") + strerror(errno); publish(b); return; }
+            uint8_t *in = inbuf[cur_in].get();
+            memset(in + got, 0, SPEC_IN_SLACK);
+            const uint64_t in_bits = 8 * (uint64_t)got, bit0 = q - 8 * (uint64_t)F;
+            if (in_bits < bit0 + 3) { hand_over(q); return; }
+            if ((size_t)got == IN_LEN) {
+                ahead_off = F + (off_t)((size_t)T * C);
+                uint8_t *dst = inbuf[cur_in ^ 1].get();
+                ahead = std::thread([this, dst, IN_LEN, ahead_off, &ahead_got] { ahead_got = pread_all(fd_, dst, IN_LEN, ahead_off); });
+            }
+            t_in_ += now() - t0; t0 = now();
+            const unsigned n = (unsigned)std::min<size_t>(T, ((size_t)got + C - 1) / C);
+            for (unsigned j = 0; j <= n; j++) start[j].store(j == 0 ? (int64_t)bit0 : PENDING, std::memory_order_relaxed);
+            auto decode = [&](unsigned j) {
+                SpecChunk &c = ch[j];
+                c.in = in; c.in_bits = in_bits; c.base = sym[j].get() + W; c.cap = CAP; c.out_len = 0; c.stop = SPEC_ERROR;
+                uint64_t s = bit0;
+                if (j > 0) {
+                    const uint64_t from = std::max<uint64_t>(8 * (uint64_t)j * C, bit0 + 1);
+                    s = find_block_start(in, in_bits, from, 8 * (uint64_t)j * C + 4 * (uint64_t)C);
+                    start[j].store(s == ~0ull ? NONE : (int64_t)s, std::memory_order_release);
+                    if (s == ~0ull) return;
+                    for (size_t i = 0; i < W; i++) c.base[(ptrdiff_t)i - (ptrdiff_t)W] = (uint16_t)(256 + i);
+                    c.hist_have = W;
+                } else {
+                    for (size_t i = 0; i < W; i++) c.base[(ptrdiff_t)i - (ptrdiff_t)W] = win[i];
+                    c.hist_have = have;
+                }
+                const uint64_t nominal_end = 8 * (uint64_t)(j + 1) * C;
+                spec_run(c, s, [&](uint64_t pos) {
+                    if (pos < nominal_end) return false;
+                    if (j + 1 >= n) return true;
+                    int64_t nx;
+                    while ((nx = start[j + 1].load(std::memory_order_acquire)) == PENDING) std::this_thread::yield();
+                    return nx == NONE || pos >= (uint64_t)nx;
+                });
+            };
+            {
+                std::vector<std::thread> th;
+                for (unsigned j = 1; j < n; j++) th.emplace_back(decode, j);
+                decode(0);
+                for (auto &t : th) t.join();
+            }
+            t_dec_ += now() - t0; t0 = now();
+            // the chain: which chunks count
+            unsigned acc = 0; uint64_t cum = total;
+            for (unsigned j = 0; j < n; j++) {
+                if (j > 0) {
+                    const int64_t sj = start[j].load(std::memory_order_relaxed);
+                    if (sj < 0 || ch[j - 1].stop != SPEC_LINK || ch[j - 1].end_bit != (uint64_t)sj || cum < W) break;
+                }
+                acc++; cum += ch[j].out_len;
+            }
+            n_batches_++; n_counted_ += acc; n_decoded_ += n;
+            const SpecChunk &last = ch[acc - 1];
+            const uint64_t q_new = 8 * (uint64_t)F + last.end_bit;
+            // windows (in order; cheap), then bytes and checksums (side by side)
+            std::vector<size_t> off(acc + 1, 0);
+            for (unsigned j = 0; j < acc; j++) {
+                uint8_t *l = lut.data() + (size_t)j * (256 + W);
+                for (int i = 0; i < 256; i++) l[i] = (uint8_t)i;
+                memcpy(l + 256, win.data(), W);
+                const uint16_t *e = ch[j].base + ch[j].out_len;     // (reaches into the window in front of the symbols when the chunk is short)
+                for (size_t i = 0; i < W; i++) win[i] = l[e[(ptrdiff_t)i - (ptrdiff_t)W]];
+                have = std::min(W, have + ch[j].out_len);
+                off[j + 1] = off[j] + ch[j].out_len;
+            }
+            t_win_ += now() - t0; t0 = now();
+            const size_t out_total = off[acc];
+            if (b->out_cap < out_total) { b->out.reset(new uint8_t[out_total + 64]); b->out_cap = out_total; }
+            std::vector<uint32_t> crcs(acc, 0);
+            auto resolve = [&](unsigned j) {
+                uint8_t *dst = b->out.get() + off[j];
+                spec_resolve(ch[j].base, ch[j].out_len, lut.data() + (size_t)j * (256 + W), dst);
+                uint32_t c = 0;
+                for (size_t at = 0; at < ch[j].out_len; at += 1u << 30) c = (uint32_t)crc32(c, dst + at, (uInt)std::min<size_t>(ch[j].out_len - at, 1u << 30));
+                crcs[j] = c;
+            };
+            {
+                std::vector<std::thread> th;
+                for (unsigned j = 1; j < acc; j++) th.emplace_back(resolve, j);
+                resolve(0);
+                for (auto &t : th) t.join();
+            }
+            for (unsigned j = 0; j < acc; j++) crc = (uint32_t)crc32_combine(crc, crcs[j], (z_off_t)ch[j].out_len);
+            total += out_total; n_bytes_ += out_total;
+            b->out_len = out_total;
+            t_res_ += now() - t0;
+            const bool stuck = q_new == q;
+            q = q_new;
+            poor = 2 * acc < n ? poor + 1 : 0;
+            if (last.stop == SPEC_FINAL || last.stop == SPEC_ERROR || stuck || poor >= 3) { hand_over(q); return; }
+            publish(b);
+        }
+    }
+
+    int fd_;
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    Batch batches_[2];
+    std::deque<Batch *> free_{&batches_[0], &batches_[1]}, ready_;
+    bool stop_ = false;
+    Batch *cur_ = nullptr;
+    std::unique_ptr<GzFast> tail_;
+    uint64_t n_batches_ = 0, n_counted_ = 0, n_decoded_ = 0, n_bytes_ = 0;
+    double t_wait_ = 0, t_in_ = 0, t_dec_ = 0, t_win_ = 0, t_res_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------
 // Sequential byte source over the inputs.  bufio.Scanner is per input: an unterminated last line is
 // a token of THAT input, so a '\n' is supplied at the end of an input that does not end in one.
 // ------------------------------------------------------------------------------------------
@@ -567,6 +862,7 @@ class ByteSource {
             static const bool use_zlib = getenv("HULK_GZ_ZLIB") != nullptr;
             if (!use_zlib) {
                 if (regular_ && GzBgzf::threads() > 1 && GzBgzf::looks_like(fd_)) gzf_.reset(new GzBgzf(fd_));
+                else if (regular_ && GzPar::wanted(fd_)) gzf_.reset(new GzPar(fd_));
                 else gzf_.reset(new GzFast(fd_));
                 return true;
             }

@@ -402,3 +402,83 @@ def test_bgzf_members_are_inflated_side_by_side(tmp_path):
     outs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                            env=dict(os.environ, **extra)).stdout.strip() for extra in ({}, {"HULK_GZ_THREADS": "1"}, {"HULK_GZ_ZLIB": "1"})]
     assert outs[0] == outs[1] == outs[2] and outs[0].startswith(str(3 * len(seqs)) + " ")
+
+
+def _gz_children(paths, **env):
+    """tools/fuzz_gzpar.py --child in a fresh process (the gzip readers read their switches once): {path: [n_seqs, md5(bases),
+    md5(offsets)] or ["error", message]} and the parallel reader's trace lines"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gzpar.py"), "--child"] + paths, capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, HULK_INGEST_TRACE="1", **env))
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("[")]
+    assert len(rows) == len(paths), r.stderr[-2000:]
+    return {row[0]: row[1:] for row in rows}, [l for l in r.stderr.splitlines() if "parallel gzip reader" in l]
+
+
+def test_one_gzip_member_is_inflated_by_several_threads(tmp_path):
+    """An ordinary `.gz` (one member) goes through GzPar: chunks decoded speculatively from block starts found in the stream,
+    counted only when the chunk in front ends exactly there, unknown window bytes resolved afterwards, CRC-32 combined — and the
+    final block, the trailer, further members, trailing bytes and every error are the one-thread reader's.  Same reads as the
+    text at levels 1 / 6 / 9 (small chunks: dozens of them, several batches); a second member and trailing bytes; a wrong
+    CRC-32, a wrong ISIZE, a cut file and a flipped bit give the one-thread reader's messages (HULK_GZ_PAR=0)."""
+    import hashlib
+    import zlib
+    rng = np.random.default_rng(21)
+    seqs, blob = _fastq_blob(rng, 40_000)
+    want = [len(seqs), hashlib.md5(b"".join(seqs)).hexdigest()]
+    paths = []
+    for level in (1, 6, 9):
+        p = str(tmp_path / ("one%d.fq.gz" % level)); open(p, "wb").write(gzip.compress(blob, level)); paths.append(p)
+    cut = blob.index(b"\n@r25000\n") + 1
+    p2 = str(tmp_path / "two.fq.gz"); open(p2, "wb").write(gzip.compress(blob[:cut], 6) + gzip.compress(blob[cut:], 1) + b"\0\0 not gzip")
+    # stored blocks only: no block start is ever found, the chain is one chunk per batch — and the reader gives up
+    c0 = zlib.compressobj(0, zlib.DEFLATED, 31); p0 = str(tmp_path / "stored.fq.gz"); open(p0, "wb").write(c0.compress(blob) + c0.flush())
+    good = gzip.compress(blob, 6)
+    bad = {}
+    for name, f in (("crc", lambda d: d[:-5] + bytes([d[-5] ^ 0x40]) + d[-4:]), ("isize", lambda d: d[:-1] + bytes([d[-1] ^ 1])),
+                    ("cut", lambda d: d[:len(d) // 2]), ("cuttrailer", lambda d: d[:-3]),
+                    ("flip", lambda d: d[:len(d) // 2] + bytes([d[len(d) // 2] ^ 0x10]) + d[len(d) // 2 + 1:])):
+        p = str(tmp_path / (name + ".fq.gz")); open(p, "wb").write(f(good)); bad[name] = p
+    every = paths + [p2, p0] + list(bad.values())
+    par, trace = _gz_children(every, HULK_GZ_PAR_CHUNK="65536", HULK_GZ_THREADS="3")
+    one, none = _gz_children(every, HULK_GZ_PAR="0")
+    assert none == [] and len(trace) == len(every)                          # the parallel reader ran on every file, and only when asked
+    counted = [int(l.split(" chunks counted")[0].split()[-1]) for l in trace]
+    assert min(counted[:4]) >= 20, trace                                       # ... and did the work (dozens of chunks counted per file)
+    for p in paths + [p2, p0]:
+        assert par[p][:2] == want and one[p] == par[p], (p, par[p], one[p])
+    assert par[bad["crc"]] == par[bad["isize"]] == ["error", "gzip: invalid checksum"]
+    assert par[bad["cut"]] == par[bad["cuttrailer"]] == ["error", "unexpected EOF"]
+    for p in bad.values():
+        assert par[p] == one[p], (p, par[p], one[p])
+    # default chunk size (1 MB): a file of fewer than four chunks is the one-thread reader's, a larger one is not
+    big = str(tmp_path / "big.fq.gz"); open(big, "wb").write(gzip.compress(blob * 2, 1))
+    assert os.path.getsize(paths[1]) < 4 << 20 < os.path.getsize(big)
+    dflt, trace = _gz_children([paths[1], big])
+    assert len(trace) == 1 and dflt[paths[1]][:2] == want and dflt[big][0] == 2 * len(seqs)
+
+
+def test_gzpar_fuzz_slice():
+    """tools/fuzz_gzpar.py: both gzip readers on random members (levels, strategies, flush points, several members, flipped
+    bits, truncation, binary stretches) — the same reads or the same message."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gzpar.py"), "12", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_large_piece_copy_covers_its_last_bytes(tmp_path):
+    """A piece of >= 8 MB is copied out of an inflate batch by four threads.  With pieces of floor(n / 4) bytes (as first
+    written) the last n mod 4 bytes stayed uncopied whenever floor(n / 4) was a multiple of 64: here n = 4 * 64 * 40000 + 2,
+    and the two bytes are the last base of a FASTA record and its newline (found by the parallel gzip reader's first test)."""
+    rng = np.random.default_rng(31)
+    n = 4 * 64 * 40000 + 2
+    head = b">contig\n"
+    raw = bytearray(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n - len(head))].tobytes())
+    raw[70::71] = b"\n" * len(raw[70::71])                                     # lines of 70 bases
+    raw[-1:] = b"\n"
+    assert raw[-2:-1] != b"\n"
+    text = head + bytes(raw)
+    body = bytes(raw).replace(b"\n", b"")
+    assert len(text) == n and (n // 4) % 64 == 0 and n % 4 == 2
+    p = str(tmp_path / "exact.fa.gz"); open(p, "wb").write(_bgzf(text, rng, level=1))
+    assert os.path.getsize(p) < 8 << 20                                       # one batch of members, delivered by one read
+    assert native([p], fasta=True) == [body]
