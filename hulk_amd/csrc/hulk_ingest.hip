@@ -38,6 +38,7 @@
 #include "hulk_internal.h"
 #include "fast_inflate.h"
 #include "par_inflate.h"
+#include "crc32_clmul.h"
 
 namespace {
 
@@ -63,7 +64,7 @@ struct IngestError {
 // ------------------------------------------------------------------------------------------
 // gzip reader on hulk::inflate (fast_inflate.h).  A producer thread inflates into 1 MB chunks (each
 // with the previous chunk's last 32 KiB in front of it as match history); the consumer — the block
-// reader's thread — takes the CRC-32 of a chunk (zlib's crc32) while copying it out, so that inflate
+// reader's thread — takes the CRC-32 of a chunk (crc32_clmul.h) while copying it out, so that inflate
 // and checksum run side by side.  Members are concatenated (compress/gzip's multistream default);
 // what follows the last member and is not a gzip header is ignored, as zlib's gzread does.
 // HULK_GZ_ZLIB=1 keeps zlib's inflate (gzread) instead.
@@ -104,7 +105,7 @@ class GzFast : public GzStream {
                 const size_t n = std::min(cap, cur_->len - cur_->off);
                 const uint8_t *src = cur_->buf.data() + HIST + cur_->off;
                 // (zlib's crc32 takes a uInt length)
-                for (size_t at = 0; at < n; at += 1u << 30) crc_ = (uint32_t)crc32(crc_, src + at, (uInt)std::min<size_t>(n - at, 1u << 30));
+                crc_ = hulk::crc32_fast(crc_, src, n);
                 memcpy(dst, src, n);
                 cur_->off += n; size_ += (uint32_t)n;
                 return (long)n;
@@ -393,9 +394,7 @@ class GzBgzf : public GzStream {
         if (d.state != hulk::inflate::Decoder::DONE || o != end) return false;
         d.align_to_byte();
         if (d.in_left() + (size_t)(d.bitcnt >> 3) != 0) return false;           // the deflate stream ends where BSIZE says
-        uint32_t c = 0;
-        for (size_t at = 0; at < m.isize; at += 1u << 30) c = (uint32_t)crc32(c, base + at, (uInt)std::min<size_t>(m.isize - at, 1u << 30));
-        return c == m.crc;
+        return hulk::crc32_fast(0, base, m.isize) == m.crc;
     }
     void produce() {
         off_t pos = 0;
@@ -517,9 +516,9 @@ class GzPar : public GzStream {
         if (th_.joinable()) th_.join();
         if (getenv("HULK_INGEST_TRACE"))
             fprintf(stderr, "ingest trace: parallel gzip reader, %llu batches, %llu chunks counted / %llu decoded, %llu bytes of text%s; producer s: "
-                    "wait for a free batch %.3f, input %.3f, decode %.3f, windows %.3f, resolve + crc %.3f\n",
+                    "input %.3f, decode %.3f, windows %.3f, waiting for the batch in front to become bytes %.3f\n",
                     (unsigned long long)n_batches_, (unsigned long long)n_counted_, (unsigned long long)n_decoded_, (unsigned long long)n_bytes_,
-                    tail_ ? ", then handed over to the one-thread reader" : "", t_wait_, t_in_, t_dec_, t_win_, t_res_);
+                    tail_ ? ", then handed over to the one-thread reader" : "", t_in_, t_dec_, t_win_, t_fin_);
         if (tail_) tail_.reset();                                  // (owns and closes the descriptor from then on)
         else if (fd_ > 0) ::close(fd_);
     }
@@ -590,6 +589,7 @@ class GzPar : public GzStream {
     void produce() {
         using namespace hulk::inflate;
         const unsigned T = GzBgzf::threads();
+        const unsigned HW = std::max(1u, std::thread::hardware_concurrency());
         const size_t C = chunk_bytes(), EXTRA = std::max<size_t>(C, 1u << 20), IN_LEN = (size_t)T * C + EXTRA;
         // symbols per chunk: FASTQ deflates 3-5x; a block of zlib's is <= 32 Ki symbols of <= 258 bytes.  Where a chunk does not fit
         // the chain breaks, no more — but a file that keeps breaking it (text that deflates 10x and more) is decoded T times for
@@ -609,130 +609,163 @@ class GzPar : public GzStream {
             q = 8 * (uint64_t)hl;
         }
         std::unique_ptr<uint8_t[]> inbuf[2] = {std::unique_ptr<uint8_t[]>(new uint8_t[IN_LEN + SPEC_IN_SLACK]), std::unique_ptr<uint8_t[]>(new uint8_t[IN_LEN + SPEC_IN_SLACK])};
-        std::vector<std::unique_ptr<uint16_t[]>> sym(T);
-        for (auto &p : sym) p.reset(new uint16_t[W + CAP + SPEC_OUT_SLACK + 8]);      // (not initialised: pages are touched as far as a chunk gets)
-        std::vector<SpecChunk> ch(T);
+        // Two sets of symbol buffers / tables: while the chunks of batch k+1 are decoded into one, the symbols of batch k are
+        // turned into bytes out of the other (all that batch k+1 needs of batch k is where it ended and its last 32 KiB,
+        // which the cheap window pass delivers).  Not initialised: pages are touched as far as a chunk gets.
+        struct Set { std::vector<std::unique_ptr<uint16_t[]>> sym; std::vector<SpecChunk> ch; std::vector<uint8_t> lut; };
+        Set sets[2];
+        for (auto &st : sets) {
+            st.sym.resize(T); st.ch.resize(T); st.lut.resize((size_t)T * (256 + W));
+            for (auto &p : st.sym) p.reset(new uint16_t[W + CAP + SPEC_OUT_SLACK + 8]);
+        }
         std::vector<std::atomic<int64_t>> start(T + 1);
-        std::vector<uint8_t> win(W, 0), lut((size_t)T * (256 + W));
-        size_t have = 0; uint32_t crc = 0; uint64_t total = 0;
+        std::vector<uint8_t> win(W, 0);
+        size_t have = 0; uint64_t total_ahead = 0;               // (text in front of the batch being decoded)
+        uint32_t crc = 0; uint64_t total = 0;                    // of the text handed to the consumer: the finisher's
         // the next batch's input is read ahead while this one is decoded (its position is a guess: this batch's nominal end)
         int cur_in = 0;
         std::thread ahead; off_t ahead_off = -1; long ahead_got = 0;
-        auto join_ahead = [&] { if (ahead.joinable()) ahead.join(); };
-        struct Joiner { std::function<void()> f; ~Joiner() { f(); } } joiner{join_ahead};
-
+        std::thread finisher;
+        bool gone = false;                                        // the consumer went away while a finisher waited for a free batch
+        struct Joiner { std::thread &a, &b; ~Joiner() { if (a.joinable()) a.join(); if (b.joinable()) b.join(); } } joiner{ahead, finisher};
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        for (;;) {
+
+        for (uint64_t k = 0;; k++) {
+            Set &S = sets[k & 1];
             double t0 = now();
-            Batch *b = get_free();
-            if (!b) return;
-            t_wait_ += now() - t0; t0 = now();
-            auto hand_over = [&](uint64_t at_bit) {
-                b->hand = true; b->mid_member = true; b->hand_off = (off_t)(at_bit >> 3);
-                b->resume.bit = (int)(at_bit & 7); b->resume.crc = crc; b->resume.size = (uint32_t)total;
-                b->resume.hist.assign(win.end() - (ptrdiff_t)have, win.end());
-                publish(b);
-            };
             // input: from the read-ahead when the guess was good, else read now
-            join_ahead();
+            if (ahead.joinable()) ahead.join();
             const off_t qb = (off_t)(q >> 3);
             off_t F; long got;
             if (ahead_off >= 0 && qb >= ahead_off && (size_t)(qb - ahead_off) < EXTRA / 2) { cur_in ^= 1; F = ahead_off; got = ahead_got; }
             else { F = qb; got = pread_all(fd_, inbuf[cur_in].get(), IN_LEN, F); }
             ahead_off = -1;
-            if (got < 0) { b->err = std::string("read: ") + strerror(errno); publish(b); return; }
+            const int read_errno = errno;
             uint8_t *in = inbuf[cur_in].get();
-            memset(in + got, 0, SPEC_IN_SLACK);
-            const uint64_t in_bits = 8 * (uint64_t)got, bit0 = q - 8 * (uint64_t)F;
-            if (in_bits < bit0 + 3) { hand_over(q); return; }
-            if ((size_t)got == IN_LEN) {
+            if (got >= 0) memset(in + got, 0, SPEC_IN_SLACK);
+            const uint64_t in_bits = got > 0 ? 8 * (uint64_t)got : 0, bit0 = q - 8 * (uint64_t)F;
+            const bool no_input = got < 0 || in_bits < bit0 + 3;
+            if (!no_input && (size_t)got == IN_LEN) {
                 ahead_off = F + (off_t)((size_t)T * C);
                 uint8_t *dst = inbuf[cur_in ^ 1].get();
                 ahead = std::thread([this, dst, IN_LEN, ahead_off, &ahead_got] { ahead_got = pread_all(fd_, dst, IN_LEN, ahead_off); });
             }
             t_in_ += now() - t0; t0 = now();
-            const unsigned n = (unsigned)std::min<size_t>(T, ((size_t)got + C - 1) / C);
-            for (unsigned j = 0; j <= n; j++) start[j].store(j == 0 ? (int64_t)bit0 : PENDING, std::memory_order_relaxed);
-            auto decode = [&](unsigned j) {
-                SpecChunk &c = ch[j];
-                c.in = in; c.in_bits = in_bits; c.base = sym[j].get() + W; c.cap = CAP; c.out_len = 0; c.stop = SPEC_ERROR;
-                uint64_t s = bit0;
-                if (j > 0) {
-                    const uint64_t from = std::max<uint64_t>(8 * (uint64_t)j * C, bit0 + 1);
-                    s = find_block_start(in, in_bits, from, 8 * (uint64_t)j * C + 4 * (uint64_t)C);
-                    start[j].store(s == ~0ull ? NONE : (int64_t)s, std::memory_order_release);
-                    if (s == ~0ull) return;
-                    for (size_t i = 0; i < W; i++) c.base[(ptrdiff_t)i - (ptrdiff_t)W] = (uint16_t)(256 + i);
-                    c.hist_have = W;
-                } else {
-                    for (size_t i = 0; i < W; i++) c.base[(ptrdiff_t)i - (ptrdiff_t)W] = win[i];
-                    c.hist_have = have;
+            unsigned n = 0, acc = 0;
+            std::vector<size_t> off(1, 0);
+            uint64_t q_new = q;
+            SpecStop last_stop = SPEC_INPUT;
+            if (!no_input) {
+                n = (unsigned)std::min<size_t>(T, ((size_t)got + C - 1) / C);
+                for (unsigned j = 0; j <= n; j++) start[j].store(j == 0 ? (int64_t)bit0 : PENDING, std::memory_order_relaxed);
+                auto decode = [&](unsigned j) {
+                    SpecChunk &c = S.ch[j];
+                    c.in = in; c.in_bits = in_bits; c.base = S.sym[j].get() + W; c.cap = CAP; c.out_len = 0; c.stop = SPEC_ERROR;
+                    uint64_t s = bit0;
+                    if (j > 0) {
+                        const uint64_t from = std::max<uint64_t>(8 * (uint64_t)j * C, bit0 + 1);
+                        s = find_block_start(in, in_bits, from, 8 * (uint64_t)j * C + 4 * (uint64_t)C);
+                        start[j].store(s == ~0ull ? NONE : (int64_t)s, std::memory_order_release);
+                        if (s == ~0ull) return;
+                        for (size_t i = 0; i < W; i++) c.base[(ptrdiff_t)i - (ptrdiff_t)W] = (uint16_t)(256 + i);
+                        c.hist_have = W;
+                    } else {
+                        for (size_t i = 0; i < W; i++) c.base[(ptrdiff_t)i - (ptrdiff_t)W] = win[i];
+                        c.hist_have = have;
+                    }
+                    const uint64_t nominal_end = 8 * (uint64_t)(j + 1) * C;
+                    spec_run(c, s, [&](uint64_t pos) {
+                        if (pos < nominal_end) return false;
+                        if (j + 1 >= n) return true;
+                        int64_t nx;
+                        while ((nx = start[j + 1].load(std::memory_order_acquire)) == PENDING) std::this_thread::yield();
+                        return nx == NONE || pos >= (uint64_t)nx;
+                    });
+                };
+                {
+                    std::vector<std::thread> th;
+                    for (unsigned j = 1; j < n; j++) th.emplace_back(decode, j);
+                    decode(0);
+                    for (auto &t : th) t.join();
                 }
-                const uint64_t nominal_end = 8 * (uint64_t)(j + 1) * C;
-                spec_run(c, s, [&](uint64_t pos) {
-                    if (pos < nominal_end) return false;
-                    if (j + 1 >= n) return true;
-                    int64_t nx;
-                    while ((nx = start[j + 1].load(std::memory_order_acquire)) == PENDING) std::this_thread::yield();
-                    return nx == NONE || pos >= (uint64_t)nx;
-                });
-            };
-            {
-                std::vector<std::thread> th;
-                for (unsigned j = 1; j < n; j++) th.emplace_back(decode, j);
-                decode(0);
-                for (auto &t : th) t.join();
-            }
-            t_dec_ += now() - t0; t0 = now();
-            // the chain: which chunks count
-            unsigned acc = 0; uint64_t cum = total;
-            for (unsigned j = 0; j < n; j++) {
-                if (j > 0) {
-                    const int64_t sj = start[j].load(std::memory_order_relaxed);
-                    if (sj < 0 || ch[j - 1].stop != SPEC_LINK || ch[j - 1].end_bit != (uint64_t)sj || cum < W) break;
+                t_dec_ += now() - t0; t0 = now();
+                // the chain: which chunks count
+                uint64_t cum = total_ahead;
+                for (unsigned j = 0; j < n; j++) {
+                    if (j > 0) {
+                        const int64_t sj = start[j].load(std::memory_order_relaxed);
+                        if (sj < 0 || S.ch[j - 1].stop != SPEC_LINK || S.ch[j - 1].end_bit != (uint64_t)sj || cum < W) break;
+                    }
+                    acc++; cum += S.ch[j].out_len;
                 }
-                acc++; cum += ch[j].out_len;
+                n_batches_++; n_counted_ += acc; n_decoded_ += n;
+                q_new = 8 * (uint64_t)F + S.ch[acc - 1].end_bit;
+                last_stop = S.ch[acc - 1].stop;
+                // the windows, in order (cheap): table j = identity + the 32 KiB in front of chunk j
+                off.assign(acc + 1, 0);
+                for (unsigned j = 0; j < acc; j++) {
+                    uint8_t *l = S.lut.data() + (size_t)j * (256 + W);
+                    for (int i = 0; i < 256; i++) l[i] = (uint8_t)i;
+                    memcpy(l + 256, win.data(), W);
+                    const uint16_t *e = S.ch[j].base + S.ch[j].out_len;  // (reaches into the window in front of the symbols when the chunk is short)
+                    for (size_t i = 0; i < W; i++) win[i] = l[e[(ptrdiff_t)i - (ptrdiff_t)W]];
+                    have = std::min(W, have + S.ch[j].out_len);
+                    off[j + 1] = off[j] + S.ch[j].out_len;
+                }
+                total_ahead += off[acc];
+                t_win_ += now() - t0; t0 = now();
             }
-            n_batches_++; n_counted_ += acc; n_decoded_ += n;
-            const SpecChunk &last = ch[acc - 1];
-            const uint64_t q_new = 8 * (uint64_t)F + last.end_bit;
-            // windows (in order; cheap), then bytes and checksums (side by side)
-            std::vector<size_t> off(acc + 1, 0);
-            for (unsigned j = 0; j < acc; j++) {
-                uint8_t *l = lut.data() + (size_t)j * (256 + W);
-                for (int i = 0; i < 256; i++) l[i] = (uint8_t)i;
-                memcpy(l + 256, win.data(), W);
-                const uint16_t *e = ch[j].base + ch[j].out_len;     // (reaches into the window in front of the symbols when the chunk is short)
-                for (size_t i = 0; i < W; i++) win[i] = l[e[(ptrdiff_t)i - (ptrdiff_t)W]];
-                have = std::min(W, have + ch[j].out_len);
-                off[j + 1] = off[j] + ch[j].out_len;
-            }
-            t_win_ += now() - t0; t0 = now();
-            const size_t out_total = off[acc];
-            if (b->out_cap < out_total) { b->out.reset(new uint8_t[out_total + 64]); b->out_cap = out_total; }
-            std::vector<uint32_t> crcs(acc, 0);
-            auto resolve = [&](unsigned j) {
-                uint8_t *dst = b->out.get() + off[j];
-                spec_resolve(ch[j].base, ch[j].out_len, lut.data() + (size_t)j * (256 + W), dst);
-                uint32_t c = 0;
-                for (size_t at = 0; at < ch[j].out_len; at += 1u << 30) c = (uint32_t)crc32(c, dst + at, (uInt)std::min<size_t>(ch[j].out_len - at, 1u << 30));
-                crcs[j] = c;
-            };
-            {
-                std::vector<std::thread> th;
-                for (unsigned j = 1; j < acc; j++) th.emplace_back(resolve, j);
-                resolve(0);
-                for (auto &t : th) t.join();
-            }
-            for (unsigned j = 0; j < acc; j++) crc = (uint32_t)crc32_combine(crc, crcs[j], (z_off_t)ch[j].out_len);
-            total += out_total; n_bytes_ += out_total;
-            b->out_len = out_total;
-            t_res_ += now() - t0;
             const bool stuck = q_new == q;
             q = q_new;
             poor = 2 * acc < n ? poor + 1 : 0;
-            if (last.stop == SPEC_FINAL || last.stop == SPEC_ERROR || stuck || poor >= 3) { hand_over(q); return; }
-            publish(b);
+            const bool hand = no_input || last_stop == SPEC_FINAL || last_stop == SPEC_ERROR || stuck || poor >= 3;
+            // the batch in front has to be out of its symbol buffers (the next decode writes them) and its checksum final
+            if (finisher.joinable()) finisher.join();
+            t_fin_ += now() - t0;
+            if (gone) return;
+            GzResume res;
+            if (hand) { res.bit = (int)(q & 7); res.hist.assign(win.end() - (ptrdiff_t)have, win.end()); }
+            const std::string io_err = got < 0 ? std::string("read: ") + strerror(read_errno) : std::string();
+            // bytes and checksums, side by side in pieces of >= 256 KiB, while the next batch is decoded
+            finisher = std::thread([this, &S, &crc, &total, &gone, off = std::move(off), acc, hand, res = std::move(res), io_err, q, HW, T]() mutable {
+                Batch *b = get_free();
+                if (!b) { gone = true; return; }
+                const size_t out_total = off[acc];
+                if (b->out_cap < out_total) { b->out.reset(new uint8_t[out_total + 64]); b->out_cap = out_total; }
+                struct Piece { unsigned j; size_t at, len; uint32_t crc; };
+                std::vector<Piece> pieces;
+                const size_t target = std::max<size_t>(256u << 10, out_total / std::max(1u, std::min(HW, 4 * T)) + 1);
+                for (unsigned j = 0; j < acc; j++) {
+                    const size_t len = S.ch[j].out_len, parts = std::max<size_t>(1, len / target), step = ((len + parts - 1) / parts + 63) & ~(size_t)63;
+                    for (size_t at = 0; at < len; at += step) pieces.push_back({j, at, std::min(step, len - at), 0});
+                }
+                std::atomic<size_t> next{0};
+                auto work = [&] {
+                    for (size_t i; (i = next.fetch_add(1)) < pieces.size();) {
+                        Piece &pc = pieces[i];
+                        uint8_t *dst = b->out.get() + off[pc.j] + pc.at;
+                        hulk::inflate::spec_resolve(S.ch[pc.j].base + pc.at, pc.len, S.lut.data() + (size_t)pc.j * (256 + W), dst);
+                        pc.crc = hulk::crc32_fast(0, dst, pc.len);
+                    }
+                };
+                {
+                    const unsigned nt = (unsigned)std::min<size_t>(pieces.size(), std::min(HW, 4 * T));
+                    std::vector<std::thread> th;
+                    for (unsigned i = 1; i < nt; i++) th.emplace_back(work);
+                    work();
+                    for (auto &t : th) t.join();
+                }
+                for (const Piece &pc : pieces) crc = (uint32_t)crc32_combine(crc, pc.crc, (z_off_t)pc.len);
+                total += out_total; n_bytes_ += out_total;
+                b->out_len = out_total;
+                if (!io_err.empty()) b->err = io_err;
+                else if (hand) {
+                    b->hand = true; b->mid_member = true; b->hand_off = (off_t)(q >> 3);
+                    b->resume = std::move(res); b->resume.crc = crc; b->resume.size = (uint32_t)total;
+                }
+                publish(b);
+            });
+            if (hand || !io_err.empty()) return;                   // (the Joiner waits for the finisher)
         }
     }
 
@@ -740,13 +773,13 @@ class GzPar : public GzStream {
     std::thread th_;
     std::mutex m_;
     std::condition_variable cv_;
-    Batch batches_[2];
-    std::deque<Batch *> free_{&batches_[0], &batches_[1]}, ready_;
+    Batch batches_[3];
+    std::deque<Batch *> free_{&batches_[0], &batches_[1], &batches_[2]}, ready_;
     bool stop_ = false;
     Batch *cur_ = nullptr;
     std::unique_ptr<GzFast> tail_;
     uint64_t n_batches_ = 0, n_counted_ = 0, n_decoded_ = 0, n_bytes_ = 0;
-    double t_wait_ = 0, t_in_ = 0, t_dec_ = 0, t_win_ = 0, t_res_ = 0;
+    double t_in_ = 0, t_dec_ = 0, t_win_ = 0, t_fin_ = 0;
 };
 
 // ------------------------------------------------------------------------------------------
