@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -267,6 +268,28 @@ class GzFast : public GzStream {
     uint32_t crc_ = 0, size_ = 0;
 };
 
+// Large scratch buffers of the gzip readers: anonymous mappings that ask for transparent huge pages (a first touch by 16+
+// threads at once is otherwise 4 KiB page faults queueing on the process's mapping lock).  HULK_GZ_NO_THP=1: plain pages.
+struct BigBuf {
+    void *p = nullptr; size_t n = 0;
+    BigBuf() {}
+    explicit BigBuf(size_t bytes) { reset(bytes); }
+    BigBuf(const BigBuf &) = delete;
+    BigBuf &operator=(const BigBuf &) = delete;
+    ~BigBuf() { release(); }
+    void release() { if (p) ::munmap(p, n); p = nullptr; n = 0; }
+    void reset(size_t bytes) {
+        release();
+        n = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        void *m = ::mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) { p = nullptr; n = 0; throw std::bad_alloc(); }
+        p = m;
+        static const bool thp = getenv("HULK_GZ_NO_THP") == nullptr;
+        if (thp) ::madvise(p, n, MADV_HUGEPAGE);
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
 // One core copies ~8 GB/s out of a buffer another core wrote, less than several inflate threads deliver: large pieces are
 // copied by four threads.  (Pieces of ceil(n / 4) rounded up to 64 bytes: with floor(n / 4), as first written, the last
 // n mod 4 bytes were not copied whenever floor(n / 4) happened to be a multiple of 64.)
@@ -509,11 +532,16 @@ class GzPar : public GzStream {
         struct stat sb;
         return on && GzBgzf::threads() > 1 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= 4 * chunk_bytes();
     }
-    explicit GzPar(int fd) : fd_(fd) { th_ = std::thread([this] { produce(); }); }
+    explicit GzPar(int fd) : fd_(fd), t_start_(clock_s()) { th_ = std::thread([this] { produce(); t_done_ = clock_s() - t_start_; }); }
+    static double clock_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     ~GzPar() override {
         { std::lock_guard<std::mutex> g(m_); stop_ = true; }
         cv_.notify_all();
+        const double t_close = clock_s() - t_start_;
         if (th_.joinable()) th_.join();
+        if (getenv("HULK_INGEST_TRACE"))
+            fprintf(stderr, "ingest trace: parallel gzip reader timeline (s since it was opened): first batch out %.3f, last batch out %.3f, producer gone %.3f, "
+                    "reader closed %.3f\n", t_first_, t_last_, t_done_, t_close);
         if (getenv("HULK_INGEST_TRACE"))
             fprintf(stderr, "ingest trace: parallel gzip reader, %llu batches, %llu chunks counted / %llu decoded, %llu bytes of text%s; producer s: "
                     "input %.3f, decode %.3f, windows %.3f, waiting for the batch in front to become bytes %.3f\n",
@@ -532,7 +560,7 @@ class GzPar : public GzStream {
             }
             if (cur_->off < cur_->out_len) {
                 const size_t n = std::min(cap, cur_->out_len - cur_->off);
-                copy_wide(dst, cur_->out.get() + cur_->off, n);
+                copy_wide(dst, cur_->out.as<uint8_t>() + cur_->off, n);
                 cur_->off += n;
                 return (long)n;
             }
@@ -552,7 +580,7 @@ class GzPar : public GzStream {
     static constexpr size_t W = hulk::inflate::SPEC_WINDOW;
     static constexpr int64_t PENDING = -1, NONE = -2;
     struct Batch {
-        std::unique_ptr<uint8_t[]> out; size_t out_cap = 0, out_len = 0, off = 0;
+        BigBuf out; size_t out_cap = 0, out_len = 0, off = 0;
         bool hand = false, mid_member = false; off_t hand_off = 0; GzResume resume; std::string err;
     };
     Batch *get_free() {
@@ -563,7 +591,10 @@ class GzPar : public GzStream {
         b->out_len = b->off = 0; b->hand = b->mid_member = false; b->err.clear();
         return b;
     }
-    void publish(Batch *b) { { std::lock_guard<std::mutex> g(m_); ready_.push_back(b); } cv_.notify_all(); }
+    void publish(Batch *b) {
+        t_last_ = clock_s() - t_start_; if (t_first_ < 0) t_first_ = t_last_;
+        { std::lock_guard<std::mutex> g(m_); ready_.push_back(b); } cv_.notify_all();
+    }
     static long pread_all(int fd, uint8_t *dst, size_t len, off_t at) {
         size_t got = 0;
         while (got < len) {
@@ -608,15 +639,16 @@ class GzPar : public GzStream {
             }
             q = 8 * (uint64_t)hl;
         }
-        std::unique_ptr<uint8_t[]> inbuf[2] = {std::unique_ptr<uint8_t[]>(new uint8_t[IN_LEN + SPEC_IN_SLACK]), std::unique_ptr<uint8_t[]>(new uint8_t[IN_LEN + SPEC_IN_SLACK])};
+        BigBuf inbuf[2];
+        for (auto &ib : inbuf) ib.reset(IN_LEN + SPEC_IN_SLACK);
         // Two sets of symbol buffers / tables: while the chunks of batch k+1 are decoded into one, the symbols of batch k are
         // turned into bytes out of the other (all that batch k+1 needs of batch k is where it ended and its last 32 KiB,
         // which the cheap window pass delivers).  Not initialised: pages are touched as far as a chunk gets.
-        struct Set { std::vector<std::unique_ptr<uint16_t[]>> sym; std::vector<SpecChunk> ch; std::vector<uint8_t> lut; };
+        struct Set { std::vector<BigBuf> sym; std::vector<SpecChunk> ch; std::vector<uint8_t> lut; };
         Set sets[2];
         for (auto &st : sets) {
-            st.sym.resize(T); st.ch.resize(T); st.lut.resize((size_t)T * (256 + W));
-            for (auto &p : st.sym) p.reset(new uint16_t[W + CAP + SPEC_OUT_SLACK + 8]);
+            st.sym = std::vector<BigBuf>(T); st.ch.resize(T); st.lut.resize((size_t)T * (256 + W));
+            for (auto &p : st.sym) p.reset(2 * (W + CAP + SPEC_OUT_SLACK + 8));
         }
         std::vector<std::atomic<int64_t>> start(T + 1);
         std::vector<uint8_t> win(W, 0);
@@ -638,16 +670,16 @@ class GzPar : public GzStream {
             const off_t qb = (off_t)(q >> 3);
             off_t F; long got;
             if (ahead_off >= 0 && qb >= ahead_off && (size_t)(qb - ahead_off) < EXTRA / 2) { cur_in ^= 1; F = ahead_off; got = ahead_got; }
-            else { F = qb; got = pread_all(fd_, inbuf[cur_in].get(), IN_LEN, F); }
+            else { F = qb; got = pread_all(fd_, inbuf[cur_in].as<uint8_t>(), IN_LEN, F); }
             ahead_off = -1;
             const int read_errno = errno;
-            uint8_t *in = inbuf[cur_in].get();
+            uint8_t *in = inbuf[cur_in].as<uint8_t>();
             if (got >= 0) memset(in + got, 0, SPEC_IN_SLACK);
             const uint64_t in_bits = got > 0 ? 8 * (uint64_t)got : 0, bit0 = q - 8 * (uint64_t)F;
             const bool no_input = got < 0 || in_bits < bit0 + 3;
             if (!no_input && (size_t)got == IN_LEN) {
                 ahead_off = F + (off_t)((size_t)T * C);
-                uint8_t *dst = inbuf[cur_in ^ 1].get();
+                uint8_t *dst = inbuf[cur_in ^ 1].as<uint8_t>();
                 ahead = std::thread([this, dst, IN_LEN, ahead_off, &ahead_got] { ahead_got = pread_all(fd_, dst, IN_LEN, ahead_off); });
             }
             t_in_ += now() - t0; t0 = now();
@@ -660,7 +692,7 @@ class GzPar : public GzStream {
                 for (unsigned j = 0; j <= n; j++) start[j].store(j == 0 ? (int64_t)bit0 : PENDING, std::memory_order_relaxed);
                 auto decode = [&](unsigned j) {
                     SpecChunk &c = S.ch[j];
-                    c.in = in; c.in_bits = in_bits; c.base = S.sym[j].get() + W; c.cap = CAP; c.out_len = 0; c.stop = SPEC_ERROR;
+                    c.in = in; c.in_bits = in_bits; c.base = S.sym[j].as<uint16_t>() + W; c.cap = CAP; c.out_len = 0; c.stop = SPEC_ERROR;
                     uint64_t s = bit0;
                     if (j > 0) {
                         const uint64_t from = std::max<uint64_t>(8 * (uint64_t)j * C, bit0 + 1);
@@ -731,7 +763,7 @@ class GzPar : public GzStream {
                 Batch *b = get_free();
                 if (!b) { gone = true; return; }
                 const size_t out_total = off[acc];
-                if (b->out_cap < out_total) { b->out.reset(new uint8_t[out_total + 64]); b->out_cap = out_total; }
+                if (b->out_cap < out_total) { b->out.reset(out_total + out_total / 16 + 64); b->out_cap = out_total + out_total / 16; }
                 struct Piece { unsigned j; size_t at, len; uint32_t crc; };
                 std::vector<Piece> pieces;
                 const size_t target = std::max<size_t>(256u << 10, out_total / std::max(1u, std::min(HW, 4 * T)) + 1);
@@ -743,7 +775,7 @@ class GzPar : public GzStream {
                 auto work = [&] {
                     for (size_t i; (i = next.fetch_add(1)) < pieces.size();) {
                         Piece &pc = pieces[i];
-                        uint8_t *dst = b->out.get() + off[pc.j] + pc.at;
+                        uint8_t *dst = b->out.as<uint8_t>() + off[pc.j] + pc.at;
                         hulk::inflate::spec_resolve(S.ch[pc.j].base + pc.at, pc.len, S.lut.data() + (size_t)pc.j * (256 + W), dst);
                         pc.crc = hulk::crc32_fast(0, dst, pc.len);
                     }
@@ -780,6 +812,7 @@ class GzPar : public GzStream {
     std::unique_ptr<GzFast> tail_;
     uint64_t n_batches_ = 0, n_counted_ = 0, n_decoded_ = 0, n_bytes_ = 0;
     double t_in_ = 0, t_dec_ = 0, t_win_ = 0, t_fin_ = 0;
+    double t_start_ = 0, t_first_ = -1, t_last_ = 0, t_done_ = 0;
 };
 
 // ------------------------------------------------------------------------------------------
