@@ -289,6 +289,15 @@ struct BigBuf {
     }
     template <class T> T *as() const { return (T *)p; }
 };
+// ... with the few members of std::vector<uint8_t> the block reader uses (growing does NOT keep the contents)
+struct PageBuf {
+    BigBuf m; size_t sz = 0;
+    uint8_t *data() const { return m.as<uint8_t>(); }
+    size_t size() const { return sz; }
+    void resize(size_t n) { if (n > m.n) m.reset(n); sz = n; }
+    uint8_t &operator[](size_t i) const { return data()[i]; }
+    uint8_t *begin() const { return data(); }
+};
 
 // One core copies ~8 GB/s out of a buffer another core wrote, less than several inflate threads deliver: large pieces are
 // copied by four threads.  (Pieces of ceil(n / 4) rounded up to 64 bytes: with floor(n / 4), as first written, the last
@@ -959,7 +968,7 @@ class ByteSource {
 // Reader thread: blocks that end on '\n' (the unterminated tail is carried into the next block).
 // ------------------------------------------------------------------------------------------
 struct Block {
-    std::vector<uint8_t> buf;
+    PageBuf buf;
     size_t len = 0;
     bool tail_too_long = false;   // the line after this block's last '\n' already has >= MAX_TOKEN bytes
 };

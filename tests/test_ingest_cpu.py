@@ -412,7 +412,7 @@ def _gz_children(paths, **env):
                        timeout=900, env=dict(os.environ, HULK_INGEST_TRACE="1", **env))
     rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("[")]
     assert len(rows) == len(paths), r.stderr[-2000:]
-    return {row[0]: row[1:] for row in rows}, [l for l in r.stderr.splitlines() if "parallel gzip reader" in l]
+    return {row[0]: row[1:] for row in rows}, [l for l in r.stderr.splitlines() if "parallel gzip reader," in l]
 
 
 def test_one_gzip_member_is_inflated_by_several_threads(tmp_path):
