@@ -552,10 +552,10 @@ class GzPar : public GzStream {
             fprintf(stderr, "ingest trace: parallel gzip reader timeline (s since it was opened): first batch out %.3f, last batch out %.3f, producer gone %.3f, "
                     "reader closed %.3f\n", t_first_, t_last_, t_done_, t_close);
         if (getenv("HULK_INGEST_TRACE"))
-            fprintf(stderr, "ingest trace: parallel gzip reader, %llu batches, %llu chunks counted / %llu decoded, %llu bytes of text%s; producer s: "
+            fprintf(stderr, "ingest trace: parallel gzip reader, %llu batches, %llu chunks counted / %llu decoded, %llu bytes of text, %llu members ended here%s; producer s: "
                     "input %.3f, decode %.3f, windows %.3f, waiting for the batch in front to become bytes %.3f\n",
                     (unsigned long long)n_batches_, (unsigned long long)n_counted_, (unsigned long long)n_decoded_, (unsigned long long)n_bytes_,
-                    tail_ ? ", then handed over to the one-thread reader" : "", t_in_, t_dec_, t_win_, t_fin_);
+                    (unsigned long long)n_members_, tail_ ? ", then handed over to the one-thread reader" : "", t_in_, t_dec_, t_win_, t_fin_);
         if (tail_) tail_.reset();                                  // (owns and closes the descriptor from then on)
         else if (fd_ > 0) ::close(fd_);
     }
@@ -576,7 +576,7 @@ class GzPar : public GzStream {
             if (!cur_->err.empty()) { msg = cur_->err; return -1; }
             if (cur_->hand) {
                 if (::lseek(fd_, cur_->hand_off, SEEK_SET) < 0) { msg = std::string("lseek: ") + strerror(errno); return -1; }
-                tail_.reset(cur_->mid_member ? new GzFast(fd_, false, &cur_->resume) : new GzFast(fd_, true));
+                tail_.reset(cur_->mid_member ? new GzFast(fd_, false, &cur_->resume) : new GzFast(fd_, cur_->stream_start));
                 continue;
             }
             { std::lock_guard<std::mutex> g(m_); free_.push_back(cur_); }
@@ -590,14 +590,16 @@ class GzPar : public GzStream {
     static constexpr int64_t PENDING = -1, NONE = -2;
     struct Batch {
         BigBuf out; size_t out_cap = 0, out_len = 0, off = 0;
-        bool hand = false, mid_member = false; off_t hand_off = 0; GzResume resume; std::string err;
+        // hand-over to the one-thread reader at byte hand_off: inside a member (resume), or in front of a member's header —
+        // the first of the stream (a bad header is an error) or not (it is the clean end)
+        bool hand = false, mid_member = false, stream_start = false; off_t hand_off = 0; GzResume resume; std::string err;
     };
     Batch *get_free() {
         std::unique_lock<std::mutex> g(m_);
         cv_.wait(g, [this] { return !free_.empty() || stop_; });
         if (stop_) return nullptr;
         Batch *b = free_.back(); free_.pop_back();
-        b->out_len = b->off = 0; b->hand = b->mid_member = false; b->err.clear();
+        b->out_len = b->off = 0; b->hand = b->mid_member = b->stream_start = false; b->err.clear();
         return b;
     }
     void publish(Batch *b) {
@@ -644,7 +646,7 @@ class GzPar : public GzStream {
             const size_t hl = m > 0 ? header_len(h.data(), (size_t)m) : 0;
             if (hl == 0) {                                         // the one-thread reader says what is wrong with it
                 Batch *b = get_free(); if (!b) return;
-                b->hand = true; b->mid_member = false; b->hand_off = 0; publish(b); return;
+                b->hand = true; b->mid_member = false; b->stream_start = true; b->hand_off = 0; publish(b); return;
             }
             q = 8 * (uint64_t)hl;
         }
@@ -668,6 +670,7 @@ class GzPar : public GzStream {
         std::thread ahead; off_t ahead_off = -1; long ahead_got = 0;
         std::thread finisher;
         bool gone = false;                                        // the consumer went away while a finisher waited for a free batch
+        bool at_final = false, give_up_final = false;
         struct Joiner { std::thread &a, &b; ~Joiner() { if (a.joinable()) a.join(); if (b.joinable()) b.join(); } } joiner{ahead, finisher};
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
@@ -692,6 +695,60 @@ class GzPar : public GzStream {
                 ahead = std::thread([this, dst, IN_LEN, ahead_off, &ahead_got] { ahead_got = pread_all(fd_, dst, IN_LEN, ahead_off); });
             }
             t_in_ += now() - t0; t0 = now();
+            if (at_final && !no_input) {
+                // The chain arrived in front of the member's final block.  One block, decoded here with the window that is known now;
+                // then the trailer is checked against the combined CRC-32 and the length, and if a gzip header follows, the next
+                // member is this reader's too.  Anything else about it — the block does not decode or does not end well inside what
+                // was read ), a wrong
+                // trailer — and the one-thread reader gets the member from the bit in front of the block, as if this had not been tried.
+                at_final = false;
+                SpecChunk &c = S.ch[0];
+                // (the zero bytes behind the input count as input for the decoder's look-ahead — a final block at the very end of the file
+                // has only the 8 trailer bytes behind it —: a stream that really goes on into them fails the position test below)
+                c.in = in; c.in_bits = in_bits + 8 * IN_SLACK; c.base = S.sym[0].as<uint16_t>() + W; c.cap = CAP; c.out_len = 0; c.stop = SPEC_ERROR;
+                static_assert(IN_SLACK + 8 <= SPEC_IN_SLACK, "the decoder's look-ahead fits the padding behind the input");
+                for (size_t i = 0; i < W; i++) c.base[(ptrdiff_t)i - (ptrdiff_t)W] = win[i];
+                c.hist_have = have;
+                spec_run(c, bit0, [](uint64_t) { return false; }, true);
+                const uint64_t tr = (c.end_bit + 7) & ~(uint64_t)7;                 // the trailer, behind the next byte boundary
+                bool ok = c.stop == SPEC_LINK && c.blocks == 1 && tr + 64 <= in_bits;
+                if (finisher.joinable()) finisher.join();                            // (crc / total are final now)
+                if (gone) return;
+                Batch *b = nullptr;
+                uint32_t crc_all = 0;
+                if (ok) {
+                    b = get_free();
+                    if (!b) return;
+                    if (b->out_cap < c.out_len) { b->out.reset(c.out_len + 64); b->out_cap = c.out_len; }
+                    uint8_t *l = S.lut.data();
+                    for (int i = 0; i < 256; i++) l[i] = (uint8_t)i;
+                    memcpy(l + 256, win.data(), W);
+                    spec_resolve(c.base, c.out_len, l, b->out.as<uint8_t>());
+                    crc_all = (uint32_t)crc32_combine(crc, hulk::crc32_fast(0, b->out.as<uint8_t>(), c.out_len), (z_off_t)c.out_len);
+                    const uint8_t *t = in + (tr >> 3);
+                    const uint32_t want_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                    const uint32_t want_size = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+                    ok = crc_all == want_crc && (uint32_t)(total + c.out_len) == want_size;
+                    if (!ok) { std::lock_guard<std::mutex> g(m_); free_.push_back(b); b = nullptr; }
+                }
+                if (ok) {
+                    b->out_len = c.out_len; n_bytes_ += c.out_len; n_members_++;
+                    const size_t after = (size_t)(tr >> 3) + 8;                      // first byte behind the trailer, in the buffer
+                    const size_t hl = header_len(in + after, (size_t)got - after);
+                    // a new member: no window, no checksum, no length
+                    crc = 0; total = 0; total_ahead = 0; have = 0;
+                    if (hl == 0) {                                                    // no header, or not all of it here: the one-thread reader's
+                        b->hand = true; b->mid_member = false; b->stream_start = false; b->hand_off = F + (off_t)after;
+                        publish(b);
+                        return;
+                    }
+                    publish(b);
+                    q = 8 * ((uint64_t)F + after + hl);
+                    continue;
+                }
+                // (falls through: the ordinary path finds SPEC_FINAL at once, counts nothing, and hands the member over at q)
+                give_up_final = true;
+            }
             unsigned n = 0, acc = 0;
             std::vector<size_t> off(1, 0);
             uint64_t q_new = q;
@@ -759,7 +816,10 @@ class GzPar : public GzStream {
             const bool stuck = q_new == q;
             q = q_new;
             poor = 2 * acc < n ? poor + 1 : 0;
-            const bool hand = no_input || last_stop == SPEC_FINAL || last_stop == SPEC_ERROR || stuck || poor >= 3;
+            // in front of the final block with everything else in order: the next round of this loop tries the member's end
+            if (!no_input && last_stop == SPEC_FINAL && !give_up_final && !(poor >= 3)) at_final = true;
+            const bool hand = no_input || (last_stop == SPEC_FINAL && !at_final) || last_stop == SPEC_ERROR || (stuck && !at_final) || poor >= 3;
+            give_up_final = false;
             // the batch in front has to be out of its symbol buffers (the next decode writes them) and its checksum final
             if (finisher.joinable()) finisher.join();
             t_fin_ += now() - t0;
@@ -819,7 +879,7 @@ class GzPar : public GzStream {
     bool stop_ = false;
     Batch *cur_ = nullptr;
     std::unique_ptr<GzFast> tail_;
-    uint64_t n_batches_ = 0, n_counted_ = 0, n_decoded_ = 0, n_bytes_ = 0;
+    uint64_t n_batches_ = 0, n_counted_ = 0, n_decoded_ = 0, n_bytes_ = 0, n_members_ = 0;
     double t_in_ = 0, t_dec_ = 0, t_win_ = 0, t_fin_ = 0;
     double t_start_ = 0, t_first_ = -1, t_last_ = 0, t_done_ = 0;
 };

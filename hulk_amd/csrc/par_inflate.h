@@ -14,9 +14,11 @@
 // passes is only a CANDIDATE: the caller accepts a chunk's output only if the decoder of the chunk in front of it arrived,
 // at a block boundary, at exactly that bit (hulk_ingest.hip, GzPar) — a false candidate costs time, never correctness.
 //
-// The final block is never decoded here: a decoder stops in front of it (SPEC_FINAL), and the one-thread reader takes the
-// stream over from that bit with the window, CRC-32 and length so far — so the trailer check, further members, trailing
-// bytes and every error message stay the one-thread reader's.
+// A decoder stops in front of the final block (SPEC_FINAL).  The caller may then decode that one block with the window it
+// knows by then (`through_final`) and check the trailer itself, to go on with a member that follows; whenever anything about
+// that fails, and at the last member's end, the one-thread reader takes the stream over from the bit in front of the final
+// block with the window, CRC-32 and length so far — so every error message, the handling of trailing bytes and of a cut file
+// stay the one-thread reader's.
 #pragma once
 #include "fast_inflate.h"
 
@@ -209,8 +211,9 @@ struct SpecChunk {
 };
 
 // Decode block after block from the boundary at `start_bit`; `should_stop(bit)` is asked at every boundary (the first included).
+// `through_final`: the final block is decoded too and ends the run (SPEC_LINK, end_bit = the bit behind its end-of-block code).
 template <class StopFn>
-static inline void spec_run(SpecChunk &c, uint64_t start_bit, StopFn &&should_stop) {
+static inline void spec_run(SpecChunk &c, uint64_t start_bit, StopFn &&should_stop, bool through_final = false) {
     SpecTables tb;
     uint64_t pos = start_bit;
     uint16_t *out = c.base;
@@ -224,7 +227,8 @@ static inline void spec_run(SpecChunk &c, uint64_t start_bit, StopFn &&should_st
         if (should_stop(pos)) { c.stop = SPEC_LINK; return; }
         if (pos + 3 > c.in_bits) { c.stop = SPEC_INPUT; return; }
         const uint64_t hb = peek_bits(c.in, pos);
-        if (hb & 1u) { c.stop = SPEC_FINAL; return; }
+        const bool is_final = hb & 1u;
+        if (is_final && !through_final) { c.stop = SPEC_FINAL; return; }
         const uint32_t type = (uint32_t)(hb >> 1) & 3u;
         pos += 3;
         if (type == 0) {
@@ -240,6 +244,7 @@ static inline void spec_run(SpecChunk &c, uint64_t start_bit, StopFn &&should_st
             for (uint32_t i = 0; i < len; i++) out[i] = p[i];
             out += len; pos += 8 * (uint64_t)len;
             c.blocks++;
+            if (is_final) { c.end_bit = pos; c.out_len = (size_t)(out - c.base); c.stop = SPEC_LINK; return; }
             continue;
         }
         if (type == 3) { c.stop = SPEC_ERROR; return; }
@@ -254,6 +259,7 @@ static inline void spec_run(SpecChunk &c, uint64_t start_bit, StopFn &&should_st
         const int r = spec_block(c.in, ip_stop, pos, out, out_stop, hist_lo, t->litlen, t->dist);
         if (r != 0) { c.stop = (SpecStop)r; return; }
         c.blocks++;
+        if (is_final) { c.end_bit = pos; c.out_len = (size_t)(out - c.base); c.stop = SPEC_LINK; return; }
     }
 }
 

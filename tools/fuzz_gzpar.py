@@ -2,7 +2,7 @@
 """Randomised differential test of the parallel single-member gzip reader (GzPar, hulk_ingest.hip / par_inflate.h) against
 the one-thread reader (HULK_GZ_PAR=0), which tests/test_ingest_cpu.py and tools/fuzz_ingest.py hold against the restated
 reference: FASTQ-like text of 0.2-6 MB deflated at random levels / strategies / memLevels (block sizes), as one member,
-several members, with stored and fixed blocks, sync-flush points (empty stored blocks, as pigz writes them), trailing bytes,
+several members (the parallel reader ends a member itself and goes on with the next), with stored and fixed blocks, sync-flush points (empty stored blocks, as pigz writes them), trailing bytes,
 truncations and flipped bits — both readers must deliver the same reads or the same message.  Chunks of 32-128 KiB
 (HULK_GZ_PAR_CHUNK; sometimes 8 KiB, less than a block: the chain keeps breaking and the reader gives up) so that every file is
 many chunks and several batches.  CPU only.
@@ -80,7 +80,7 @@ def run(paths, env):
         print("child failed:", r.stderr[-2000:])
         sys.exit(2)
     import re
-    stats = [tuple(map(int, m)) for m in re.findall(r"(\d+) batches, (\d+) chunks counted / (\d+) decoded", r.stderr)]
+    stats = [tuple(map(int, m)) for m in re.findall(r"(\d+) batches, (\d+) chunks counted / (\d+) decoded, \d+ bytes of text, (\d+) members ended", r.stderr)]
     return {row[0]: row[1:] for row in rows}, stats
 
 
@@ -92,9 +92,12 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         r = rng.random()
         if r < 0.5:
             blob, kind = member(text), "one member"
-        elif r < 0.65:
-            cut = text.index(b"\n@", len(text) // 3) + 1
-            blob, kind = member(text[:cut]) + member(text[cut:]) + (b"\0\0junk" if rng.random() < 0.5 else b""), "two members"
+        elif r < 0.65:                                               # 2-4 members (cut anywhere, an empty one now and then), trailing bytes
+            cuts = sorted(int(x) for x in rng.integers(0, len(text) + 1, int(rng.integers(1, 4))))
+            parts = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+            if rng.random() < 0.3:
+                parts.insert(int(rng.integers(0, len(parts) + 1)), b"")
+            blob, kind = b"".join(member(x) for x in parts) + (b"\0\0junk" if rng.random() < 0.5 else b""), "%d members" % len(parts)
         elif r < 0.8:
             blob = bytearray(member(text)); at = int(rng.integers(20, len(blob))); blob[at] ^= 1 << int(rng.integers(0, 8))
             blob, kind = bytes(blob), "flipped bit at %d" % at
@@ -116,5 +119,5 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
             print("MISMATCH", os.path.basename(p), kinds[p], "chunk", chunk, "threads", threads, "::", want[p], "|", got[p], flush=True)
     n_err = sum(1 for p in paths if want[p][0] == "error")
 print(f"{n_cases} cases (seed {seed}, chunk {chunk}, threads {threads}; {n_err} of them end in a message; the parallel reader ran on {len(stats)} files, "
-      f"{sum(s[0] for s in stats)} batches, {sum(s[1] for s in stats)} chunks counted of {sum(s[2] for s in stats)} decoded), {bad} mismatches")
+      f"{sum(s[0] for s in stats)} batches, {sum(s[1] for s in stats)} chunks counted of {sum(s[2] for s in stats)} decoded, {sum(s[3] for s in stats)} members ended in it), {bad} mismatches")
 sys.exit(1 if bad else 0)
