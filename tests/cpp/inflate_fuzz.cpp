@@ -4,6 +4,8 @@
 // pieces (down to 1 byte) with random output pieces, so that every resume point of the decoder is exercised.
 // usage: inflate_fuzz [cases] [seed]      exit code 0 = all equal
 #include "../../hulk_amd/csrc/fast_inflate.h"
+#include "../../hulk_amd/csrc/par_inflate.h"
+#include "../../hulk_amd/csrc/crc32_clmul.h"
 #include <zlib.h>
 #include <algorithm>
 #include <cstdio>
@@ -109,6 +111,60 @@ static bool decode(Decoder &d, const std::vector<uint8_t> &comp, size_t piece, s
     }
 }
 
+
+// par_inflate.h: the symbol decoder on the same streams.  (1) From bit 0 with no window: bytes == the text, no unknown symbol,
+// the run stops in front of the final block and `through_final` takes it to the end.  (2) From a block boundary in the middle
+// (the boundaries are the ones run (1) passed) with an UNKNOWN window: symbols resolved through the table of the true 32 KiB in
+// front == the text from there on.  Any data, not only text: the block search (text only) is not part of this.
+static bool spec_check(const std::vector<uint8_t> &src, const std::vector<uint8_t> &comp_in) {
+    std::vector<uint8_t> comp(comp_in);
+    // (a gzip member has 8 bytes of trailer behind its last block and GzPar lends the decoder IN_SLACK bytes of its zero padding
+    // on top for the look-ahead of the last step: the same here for a bare deflate stream)
+    comp.resize(comp.size() + 8 + SPEC_IN_SLACK, 0);
+    const uint64_t in_bits = 8 * ((uint64_t)comp_in.size() + 8 + IN_SLACK);
+    const size_t cap = src.size() + 1024;
+    std::vector<uint16_t> sym(SPEC_WINDOW + cap + SPEC_OUT_SLACK + 8);
+    std::vector<uint64_t> bounds; std::vector<size_t> outs;
+    SpecChunk c;
+    c.in = comp.data(); c.in_bits = in_bits; c.base = sym.data() + SPEC_WINDOW; c.cap = cap; c.hist_have = 0;
+    spec_run(c, 0, [&](uint64_t pos) { bounds.push_back(pos); outs.push_back((size_t)0); return false; }, true);
+    if (c.stop != SPEC_LINK || c.out_len != src.size()) { printf("spec: stop %d out %zu of %zu\n", (int)c.stop, c.out_len, src.size()); return false; }
+    for (size_t i = 0; i < src.size(); i++) if (c.base[i] != src[i]) { printf("spec: byte %zu differs\n", i); return false; }
+    // where each boundary is in the text: decode again, stopping there
+    if (bounds.size() < 2) return true;
+    const size_t pick = 1 + (size_t)rand() % (bounds.size() - 1);
+    SpecChunk a;
+    a.in = comp.data(); a.in_bits = in_bits; a.base = sym.data() + SPEC_WINDOW; a.cap = cap; a.hist_have = 0;
+    spec_run(a, 0, [&](uint64_t pos) { return pos >= bounds[pick]; }, false);
+    if (a.stop != SPEC_LINK || a.end_bit != bounds[pick]) { printf("spec: no stop at boundary %zu (stop %d)\n", pick, (int)a.stop); return false; }
+    const size_t at = a.out_len;
+    // the true window in front of `at` (right-aligned), as a table
+    std::vector<uint8_t> lut(256 + SPEC_WINDOW, 0);
+    for (int i = 0; i < 256; i++) lut[i] = (uint8_t)i;
+    for (size_t i = 0; i < SPEC_WINDOW; i++) if (at + i >= SPEC_WINDOW) lut[256 + i] = src[at + i - SPEC_WINDOW];
+    for (size_t i = 0; i < SPEC_WINDOW; i++) sym[i] = (uint16_t)(256 + i);
+    SpecChunk b;
+    b.in = comp.data(); b.in_bits = in_bits; b.base = sym.data() + SPEC_WINDOW; b.cap = cap; b.hist_have = SPEC_WINDOW;
+    spec_run(b, bounds[pick], [](uint64_t) { return false; }, true);
+    if (b.stop != SPEC_LINK || at + b.out_len != src.size()) { printf("spec: from boundary %zu: stop %d, %zu + %zu of %zu\n", pick, (int)b.stop, at, b.out_len, src.size()); return false; }
+    std::vector<uint8_t> res(b.out_len);
+    spec_resolve(b.base, b.out_len, lut.data(), res.data());
+    if (memcmp(res.data(), src.data() + at, b.out_len) != 0) { printf("spec: resolved text differs from boundary %zu on\n", pick); return false; }
+    return true;
+}
+
+// crc32_clmul.h against zlib: random lengths, alignments, chained calls
+static bool crc_check() {
+    std::vector<uint8_t> buf(70000);
+    for (auto &x : buf) x = (uint8_t)rand();
+    for (int it = 0; it < 3000; it++) {
+        const size_t off = (size_t)rand() % 64, n = rand() % 4 == 0 ? (size_t)rand() % 200 : (size_t)rand() % (buf.size() - 64);
+        const uint32_t start = it % 2 ? (uint32_t)rand() * 2654435761u : 0;
+        if (hulk::crc32_fast(start, buf.data() + off, n) != (uint32_t)crc32(start, buf.data() + off, (uInt)n)) { printf("crc32_fast differs: off %zu n %zu\n", off, n); return false; }
+    }
+    return true;
+}
+
 int main(int argc, char **argv) {
     const int cases = argc > 1 ? atoi(argv[1]) : 400;
     srand(argc > 2 ? atoi(argv[2]) : 1);
@@ -133,6 +189,7 @@ int main(int argc, char **argv) {
         const size_t opiece = rand() % 3 == 0 ? 1 + rand() % 600 : (size_t)1 << 22;
         std::vector<uint8_t> res; std::string err;
         const bool ok = decode(*d, comp, piece, opiece, n, res, err);
+        if (!spec_check(src, comp)) { bad++; printf("FAIL spec it=%d mixed=%d n=%zu kind=%d level=%d strat=%d\n", it, (int)mixed, n, kind, level, strat); }
         if (!ok || res != src) {
             bad++;
             if (bad < 10) printf("FAIL it=%d mixed=%d n=%zu kind=%d level=%d strat=%d piece=%zu opiece=%zu ok=%d err=%s got=%zu\n",
@@ -157,8 +214,21 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> res; std::string err;
         // the output window is sized for 4x the original: a mangled stream may inflate to more than that
         if (!decode(*d, comp, rand() % 2 ? 1 + rand() % 300 : (size_t)1 << 20, (size_t)1 << 22, 4 * n + 70000, res, err)) rejected++;
+        {   // the symbol decoder on the same mangled stream, from bit 0 and from an arbitrary bit with an unknown window
+            std::vector<uint8_t> padded(comp); padded.resize(comp.size() + SPEC_IN_SLACK, 0);
+            const size_t cap = 4 * n + 70000;
+            std::vector<uint16_t> sym(SPEC_WINDOW + cap + SPEC_OUT_SLACK + 8);
+            for (size_t i = 0; i < SPEC_WINDOW; i++) sym[i] = (uint16_t)(256 + i);
+            SpecChunk c;
+            c.in = padded.data(); c.in_bits = 8 * (uint64_t)comp.size(); c.base = sym.data() + SPEC_WINDOW; c.cap = cap; c.hist_have = 0;
+            spec_run(c, 0, [](uint64_t) { return false; }, true);
+            c.hist_have = SPEC_WINDOW;
+            spec_run(c, (uint64_t)rand() % (8 * comp.size()), [](uint64_t) { return false; }, rand() % 2);
+            (void)find_block_start(padded.data(), c.in_bits, 0, c.in_bits);
+        }
     }
-    printf("%d cases, %d bad; %d mangled streams, %d rejected\n", cases, bad, cases, rejected);
+    if (!crc_check()) bad++;
+    printf("%d cases, %d bad; %d mangled streams, %d rejected; crc32_fast %s\n", cases, bad, cases, rejected, hulk::crc32_fast_usable() ? "folds (PCLMULQDQ)" : "is zlib's");
     delete d;
     return bad != 0;
 }
