@@ -299,6 +299,59 @@ struct PageBuf {
     uint8_t *begin() const { return data(); }
 };
 
+// ------------------------------------------------------------------------------------------
+// A team of workers that stay around.  run(n, f) calls f(0) .. f(n-1), each once, on the caller and the workers, and returns
+// when all are done.  Every parallel step of the ingest path was a fork-join of freshly created threads (two per 32 MB block
+// in the parser, three per batch in the gzip readers, one per large copy): hundreds of creations per second of run, each a
+// stack mapping under the process's mapping lock, at the moment when dozens of other threads take page faults under the same
+// lock.  Indices are handed out one at a time (a task may wait for a LATER index's early result — GzPar's chunks do —, never
+// for an earlier one's: the lowest running task can always finish, so fewer awake threads than tasks cannot deadlock).
+// ------------------------------------------------------------------------------------------
+class Team {
+ public:
+    explicit Team(unsigned workers) { for (unsigned i = 0; i < workers; i++) th_.emplace_back([this] { loop(); }); }
+    ~Team() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    unsigned size() const { return (unsigned)th_.size() + 1; }
+    template <class F> void run(unsigned n, F &&f) {
+        if (n <= 1 || th_.empty()) { for (unsigned i = 0; i < n; i++) f(i); return; }
+        const std::function<void(unsigned)> job(std::ref(f));
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &job; n_ = n; next_.store(0, std::memory_order_relaxed); pending_ = (unsigned)th_.size(); gen_++;
+        }
+        cv_.notify_all();
+        for (unsigned i; (i = next_.fetch_add(1, std::memory_order_relaxed)) < n;) f(i);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+    }
+
+ private:
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> g(m_);
+            cv_.wait(g, [&] { return stop_ || gen_ != seen; });
+            if (stop_) return;
+            seen = gen_;
+            const std::function<void(unsigned)> *job = job_; const unsigned n = n_;
+            g.unlock();
+            for (unsigned i; (i = next_.fetch_add(1, std::memory_order_relaxed)) < n;) (*job)(i);
+            g.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    uint64_t gen_ = 0; bool stop_ = false;
+    const std::function<void(unsigned)> *job_ = nullptr; unsigned n_ = 0, pending_ = 0;
+    std::atomic<unsigned> next_{0};
+};
+
 // One core copies ~8 GB/s out of a buffer another core wrote, less than several inflate threads deliver: large pieces are
 // copied by four threads.  (Pieces of ceil(n / 4) rounded up to 64 bytes: with floor(n / 4), as first written, the last
 // n mod 4 bytes were not copied whenever floor(n / 4) happened to be a multiple of 64.)
@@ -306,11 +359,8 @@ static void copy_wide(uint8_t *dst, const uint8_t *src, size_t n) {
     if (n < (8u << 20)) { memcpy(dst, src, n); return; }
     const unsigned R = 4;
     const size_t piece = ((n + R - 1) / R + 63) & ~(size_t)63;
-    std::vector<std::thread> th;
-    auto work = [&](unsigned i) { const size_t at = (size_t)i * piece; if (at < n) memcpy(dst + at, src + at, std::min(piece, n - at)); };
-    for (unsigned i = 1; i < R; i++) th.emplace_back(work, i);
-    work(0);
-    for (auto &t : th) t.join();
+    static thread_local Team team(R - 1);                      // (the block reader's thread is the only caller; gone with it)
+    team.run(R, [&](unsigned i) { const size_t at = (size_t)i * piece; if (at < n) memcpy(dst + at, src + at, std::min(piece, n - at)); });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -475,10 +525,8 @@ class GzBgzf : public GzStream {
                     }
                 }
             };
-            std::vector<std::thread> th;
-            for (unsigned i = 1; i < T; i++) th.emplace_back(work);
-            work();
-            for (auto &t : th) t.join();
+            if (!team_) team_.reset(new Team(threads() - 1));
+            team_->run(T, [&](unsigned) { work(); });
             const size_t bad = first_bad.load();
             if (bad < b->mem.size()) {
                 // everything in front of the first member that failed a check is good; that member starts the hand-over
@@ -509,6 +557,7 @@ class GzBgzf : public GzStream {
     Batch *cur_ = nullptr;
     std::unique_ptr<GzFast> tail_;
     uint64_t n_members_ = 0;
+    std::unique_ptr<Team> team_;                                  // the producer's
 };
 
 // ------------------------------------------------------------------------------------------
@@ -651,15 +700,20 @@ class GzPar : public GzStream {
             q = 8 * (uint64_t)hl;
         }
         BigBuf inbuf[2];
-        for (auto &ib : inbuf) ib.reset(IN_LEN + SPEC_IN_SLACK);
         // Two sets of symbol buffers / tables: while the chunks of batch k+1 are decoded into one, the symbols of batch k are
         // turned into bytes out of the other (all that batch k+1 needs of batch k is where it ended and its last 32 KiB,
         // which the cheap window pass delivers).  Not initialised: pages are touched as far as a chunk gets.
         struct Set { std::vector<BigBuf> sym; std::vector<SpecChunk> ch; std::vector<uint8_t> lut; };
         Set sets[2];
-        for (auto &st : sets) {
-            st.sym = std::vector<BigBuf>(T); st.ch.resize(T); st.lut.resize((size_t)T * (256 + W));
-            for (auto &p : st.sym) p.reset(2 * (W + CAP + SPEC_OUT_SLACK + 8));
+        try {
+            for (auto &ib : inbuf) ib.reset(IN_LEN + SPEC_IN_SLACK);
+            for (auto &st : sets) {
+                st.sym = std::vector<BigBuf>(T); st.ch.resize(T); st.lut.resize((size_t)T * (256 + W));
+                for (auto &p : st.sym) p.reset(2 * (W + CAP + SPEC_OUT_SLACK + 8));
+            }
+        } catch (const std::bad_alloc &) {                       // no room for the scratch (address space, not pages): one thread needs none
+            Batch *b = get_free(); if (!b) return;
+            b->hand = true; b->mid_member = false; b->stream_start = true; b->hand_off = 0; publish(b); return;
         }
         std::vector<std::atomic<int64_t>> start(T + 1);
         std::vector<uint8_t> win(W, 0);
@@ -667,6 +721,7 @@ class GzPar : public GzStream {
         uint32_t crc = 0; uint64_t total = 0;                    // of the text handed to the consumer: the finisher's
         // the next batch's input is read ahead while this one is decoded (its position is a guess: this batch's nominal end)
         int cur_in = 0;
+        Team decoders(T - 1), resolvers(std::min(HW, 4 * T) - 1);   // (declared in front of the threads that use them: gone after those)
         std::thread ahead; off_t ahead_off = -1; long ahead_got = 0;
         std::thread finisher;
         bool gone = false;                                        // the consumer went away while a finisher waited for a free batch
@@ -780,12 +835,7 @@ class GzPar : public GzStream {
                         return nx == NONE || pos >= (uint64_t)nx;
                     });
                 };
-                {
-                    std::vector<std::thread> th;
-                    for (unsigned j = 1; j < n; j++) th.emplace_back(decode, j);
-                    decode(0);
-                    for (auto &t : th) t.join();
-                }
+                decoders.run(n, decode);
                 t_dec_ += now() - t0; t0 = now();
                 // the chain: which chunks count
                 uint64_t cum = total_ahead;
@@ -828,7 +878,7 @@ class GzPar : public GzStream {
             if (hand) { res.bit = (int)(q & 7); res.hist.assign(win.end() - (ptrdiff_t)have, win.end()); }
             const std::string io_err = got < 0 ? std::string("read: ") + strerror(read_errno) : std::string();
             // bytes and checksums, side by side in pieces of >= 256 KiB, while the next batch is decoded
-            finisher = std::thread([this, &S, &crc, &total, &gone, off = std::move(off), acc, hand, res = std::move(res), io_err, q, HW, T]() mutable {
+            finisher = std::thread([this, &S, &crc, &total, &gone, &resolvers, off = std::move(off), acc, hand, res = std::move(res), io_err, q, HW, T]() mutable {
                 Batch *b = get_free();
                 if (!b) { gone = true; return; }
                 const size_t out_total = off[acc];
@@ -849,13 +899,7 @@ class GzPar : public GzStream {
                         pc.crc = hulk::crc32_fast(0, dst, pc.len);
                     }
                 };
-                {
-                    const unsigned nt = (unsigned)std::min<size_t>(pieces.size(), std::min(HW, 4 * T));
-                    std::vector<std::thread> th;
-                    for (unsigned i = 1; i < nt; i++) th.emplace_back(work);
-                    work();
-                    for (auto &t : th) t.join();
-                }
+                resolvers.run((unsigned)std::min<size_t>(pieces.size(), resolvers.size()), [&](unsigned) { work(); });
                 for (const Piece &pc : pieces) crc = (uint32_t)crc32_combine(crc, pc.crc, (z_off_t)pc.len);
                 total += out_total; n_bytes_ += out_total;
                 b->out_len = out_total;
@@ -959,16 +1003,13 @@ class ByteSource {
         const size_t piece = (cap / R + 4095) & ~(size_t)4095;
         std::vector<long> got(R, 0);
         std::vector<int> errs(R, 0);
-        std::vector<std::thread> th;
-        auto work = [&](unsigned i) {
+        if (!team_) team_.reset(new Team(R - 1));
+        team_->run(R, [&](unsigned i) {
             const size_t at = (size_t)i * piece;
             if (at >= cap) return;
             got[i] = pread_all(fd_, dst + at, std::min(piece, cap - at), pos_ + (off_t)at);
             if (got[i] < 0) errs[i] = errno;
-        };
-        for (unsigned i = 1; i < R; i++) th.emplace_back(work, i);
-        work(0);
-        for (auto &t : th) t.join();
+        });
         size_t total = 0;
         for (unsigned i = 0; i < R; i++) {
             if (got[i] < 0) { errno = errs[i]; return -1; }
@@ -1022,6 +1063,7 @@ class ByteSource {
     gzFile gz_ = nullptr;
     std::unique_ptr<GzStream> gzf_;
     uint8_t last_ = '\n';
+    std::unique_ptr<Team> team_;                                  // read_pieces' readers
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1393,12 +1435,10 @@ struct Parser {
 
     template <class F> void run_parallel(uint32_t P, F f) {
         if (P == 1) { f(0); return; }
-        std::vector<std::thread> th;
-        th.reserve(P - 1);
-        for (uint32_t i = 1; i < P; i++) th.emplace_back([&f, i] { f(i); });
-        f(0);
-        for (auto &t : th) t.join();
+        if (!team_ || team_->size() < P) team_.reset(new Team(P - 1));
+        team_->run(P, [&](unsigned i) { f((uint32_t)i); });
     }
+    std::unique_ptr<Team> team_;
 };
 
 int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads, Sink &sink,

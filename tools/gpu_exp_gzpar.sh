@@ -1,12 +1,16 @@
 #!/bin/bash
-# The e2e leg of bench.py (FASTQ file -> sketch: plain, one gzip member, bgzip'd), huge pages on and off, and the GPU ingest
-# tests.  Writes gpurun_out/e2e_gzpar.txt.
+# Where the calling thread's time goes, file -> sketch, 2 M reads: one gzip member (parallel reader), bgzip'd, plain; parser
+# threads and block size varied for the .gz.  Writes gpurun_out/e2e_gzpar3.txt.
 mkdir -p gpurun_out
+export HULK_INGEST_TRACE=1
+run() { echo "== $*"; env "${@:2}" timeout 100 python tools/ingest_rate.py 2000000 $1 --gpu 2>&1 | grep -v "amdgpu.ids" | tail -5 | cut -c1-330; }
 {
-  cat /sys/kernel/mm/transparent_hugepage/enabled
-  timeout 100 python -c "import bench, json; print(json.dumps(bench.e2e_file_rates(2000000)))" 2>&1 | tail -1
-  echo "== HULK_GZ_NO_THP=1"
-  HULK_GZ_NO_THP=1 timeout 100 python -c "import bench, json; print(json.dumps(bench.e2e_file_rates(2000000)))" 2>&1 | tail -1
-  timeout 60 python -m pytest tests/test_gpu_ingest.py -x -q 2>&1 | tail -2
-} > gpurun_out/e2e_gzpar2.txt 2>&1
-tail -c 4000 gpurun_out/e2e_gzpar2.txt
+  run --gz A=1
+  run "--gz --threads 8" A=1
+  run "--gz --threads 32" A=1
+  run --gz HULK_INGEST_BLOCK=16777216
+  run --gz HULK_INGEST_BLOCK=67108864
+  run --bgzf A=1
+  run "" A=1
+} > gpurun_out/e2e_gzpar3.txt 2>&1
+tail -c 9000 gpurun_out/e2e_gzpar3.txt
