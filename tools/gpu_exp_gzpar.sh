@@ -1,12 +1,10 @@
 #!/bin/bash
-# bench.py's e2e leg (FASTQ file -> sketch: plain, one gzip member, bgzip'd; 2 M reads) and where the calling thread's time
-# goes for each container (tools/ingest_rate.py with HULK_INGEST_TRACE).  Writes gpurun_out/e2e_gzpar4.txt.
+# Block size of the block reader (HULK_INGEST_BLOCK) with the worker teams, file -> sketch, 2 M reads: one gzip member and plain.
+# Writes gpurun_out/e2e_gzpar5.txt.
 mkdir -p gpurun_out
-run() { echo "== $*"; env "${@:2}" HULK_INGEST_TRACE=1 timeout 60 python tools/ingest_rate.py 2000000 $1 --gpu 2>&1 | grep -v "amdgpu.ids" | tail -5 | cut -c1-330; }
+run() { echo "== $*"; env "${@:2}" timeout 40 python tools/ingest_rate.py 2000000 $1 --gpu 2>&1 | grep "^parse\|^sketch_files" | cut -c1-200; }
 {
-  timeout 100 python -c "import bench, json; print(json.dumps(bench.e2e_file_rates(2000000)))" 2>&1 | tail -1
-  run --gz A=1
-  run "" A=1
-  timeout 30 python -m pytest tests/test_gpu_ingest.py -x -q 2>&1 | tail -1
-} > gpurun_out/e2e_gzpar4.txt 2>&1
-tail -c 5000 gpurun_out/e2e_gzpar4.txt
+  for b in 8388608 16777216 33554432 67108864; do run --gz HULK_INGEST_BLOCK=$b; done
+  for b in 8388608 16777216 33554432 67108864; do run "" HULK_INGEST_BLOCK=$b; done
+} > gpurun_out/e2e_gzpar5.txt 2>&1
+cat gpurun_out/e2e_gzpar5.txt
