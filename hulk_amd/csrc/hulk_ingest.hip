@@ -1150,7 +1150,7 @@ class BlockReader {
     std::deque<std::unique_ptr<Block>> q_, pool_;
     bool done_ = false, stop_ = false;
     IngestError err_;
-    uint64_t bytes_in_ = 0;
+    std::atomic<uint64_t> bytes_in_{0};                            // (read by the calling thread for the statistics, also while the reader still runs: an error stops the parser first)
 };
 
 // ------------------------------------------------------------------------------------------
