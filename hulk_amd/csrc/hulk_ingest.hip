@@ -453,7 +453,7 @@ class GzBgzf : public GzStream {
     static constexpr size_t IN_BATCH = 8u << 20, MAX_ISIZE = 1u << 16;
     struct Member { size_t hdr_off, in_off, in_len, out_off; uint32_t crc, isize; };
     struct Batch {
-        std::vector<uint8_t> in, out; std::vector<Member> mem;
+        PageBuf in, out; std::vector<Member> mem;      // (huge-page mappings, not zero-filled by one thread: 16 inflate threads touch them first)
         size_t out_len = 0, off = 0; off_t hand_over = -1; bool eof = false, any_member = false; std::string err;
     };
     Batch *get_free() {
@@ -512,7 +512,7 @@ class GzBgzf : public GzStream {
             // (a member cut by the end of the piece starts the next piece; one cut by the end of the FILE, or not a BGZF member, is
             // then the first thing of a piece: the sequential reader's from there on)
             if (b->mem.empty()) { b->hand_over = pos; publish(b); return; }
-            if (b->out.size() < out_total + 1) b->out.resize(out_total + 1);
+            if (b->out.size() < out_total + 1) b->out.resize(out_total + out_total / 16 + 1);
             const unsigned T = std::min<unsigned>(threads(), (unsigned)b->mem.size());
             std::atomic<size_t> next{0}, first_bad{b->mem.size()};
             auto work = [&]() {
