@@ -731,6 +731,8 @@ class GzPar : public GzStream {
 
         for (uint64_t k = 0;; k++) {
             Set &S = sets[k & 1];
+            // the first batch of a file is a quarter of the others: the parser and the GPU behind this reader start that much sooner
+            const unsigned nmax = k == 0 ? std::max(2u, T / 4) : T;
             double t0 = now();
             // input: from the read-ahead when the guess was good, else read now
             if (ahead.joinable()) ahead.join();
@@ -745,7 +747,7 @@ class GzPar : public GzStream {
             const uint64_t in_bits = got > 0 ? 8 * (uint64_t)got : 0, bit0 = q - 8 * (uint64_t)F;
             const bool no_input = got < 0 || in_bits < bit0 + 3;
             if (!no_input && (size_t)got == IN_LEN) {
-                ahead_off = F + (off_t)((size_t)T * C);
+                ahead_off = F + (off_t)((size_t)nmax * C);
                 uint8_t *dst = inbuf[cur_in ^ 1].as<uint8_t>();
                 ahead = std::thread([this, dst, IN_LEN, ahead_off, &ahead_got] { ahead_got = pread_all(fd_, dst, IN_LEN, ahead_off); });
             }
@@ -809,7 +811,7 @@ class GzPar : public GzStream {
             uint64_t q_new = q;
             SpecStop last_stop = SPEC_INPUT;
             if (!no_input) {
-                n = (unsigned)std::min<size_t>(T, ((size_t)got + C - 1) / C);
+                n = (unsigned)std::min<size_t>(nmax, ((size_t)got + C - 1) / C);
                 for (unsigned j = 0; j <= n; j++) start[j].store(j == 0 ? (int64_t)bit0 : PENDING, std::memory_order_relaxed);
                 auto decode = [&](unsigned j) {
                     SpecChunk &c = S.ch[j];
