@@ -722,7 +722,7 @@ class GzPar : public GzStream {
         // the next batch's input is read ahead while this one is decoded (its position is a guess: this batch's nominal end)
         int cur_in = 0;
         Team decoders(T - 1), resolvers(std::min(HW, 4 * T) - 1);   // (declared in front of the threads that use them: gone after those)
-        std::thread ahead; off_t ahead_off = -1; long ahead_got = 0;
+        std::thread ahead; off_t ahead_off = -1; long ahead_got = 0; int ahead_errno = 0;
         std::thread finisher;
         bool gone = false;                                        // the consumer went away while a finisher waited for a free batch
         bool at_final = false, give_up_final = false;
@@ -738,10 +738,11 @@ class GzPar : public GzStream {
             if (ahead.joinable()) ahead.join();
             const off_t qb = (off_t)(q >> 3);
             off_t F; long got;
-            if (ahead_off >= 0 && qb >= ahead_off && (size_t)(qb - ahead_off) < EXTRA / 2) { cur_in ^= 1; F = ahead_off; got = ahead_got; }
-            else { F = qb; got = pread_all(fd_, inbuf[cur_in].as<uint8_t>(), IN_LEN, F); }
+            // (good = the batch starts in the first half of the first chunk of what was read ahead)
+            int read_errno = 0;
+            if (ahead_off >= 0 && qb >= ahead_off && (size_t)(qb - ahead_off) < std::min(EXTRA, C) / 2) { cur_in ^= 1; F = ahead_off; got = ahead_got; read_errno = ahead_errno; }
+            else { F = qb; got = pread_all(fd_, inbuf[cur_in].as<uint8_t>(), IN_LEN, F); read_errno = errno; }
             ahead_off = -1;
-            const int read_errno = errno;
             uint8_t *in = inbuf[cur_in].as<uint8_t>();
             if (got >= 0) memset(in + got, 0, SPEC_IN_SLACK);
             const uint64_t in_bits = got > 0 ? 8 * (uint64_t)got : 0, bit0 = q - 8 * (uint64_t)F;
@@ -749,15 +750,14 @@ class GzPar : public GzStream {
             if (!no_input && (size_t)got == IN_LEN) {
                 ahead_off = F + (off_t)((size_t)nmax * C);
                 uint8_t *dst = inbuf[cur_in ^ 1].as<uint8_t>();
-                ahead = std::thread([this, dst, IN_LEN, ahead_off, &ahead_got] { ahead_got = pread_all(fd_, dst, IN_LEN, ahead_off); });
+                ahead = std::thread([this, dst, IN_LEN, ahead_off, &ahead_got, &ahead_errno] { ahead_got = pread_all(fd_, dst, IN_LEN, ahead_off); ahead_errno = errno; });
             }
             t_in_ += now() - t0; t0 = now();
             if (at_final && !no_input) {
                 // The chain arrived in front of the member's final block.  One block, decoded here with the window that is known now;
                 // then the trailer is checked against the combined CRC-32 and the length, and if a gzip header follows, the next
-                // member is this reader's too.  Anything else about it — the block does not decode or does not end well inside what
-                // was read ), a wrong
-                // trailer — and the one-thread reader gets the member from the bit in front of the block, as if this had not been tried.
+                // member is this reader's too.  Anything else about it — the block does not decode, does not end inside what was read, a
+                // wrong trailer — and the one-thread reader gets the member from the bit in front of the block, as if this had not been tried.
                 at_final = false;
                 SpecChunk &c = S.ch[0];
                 // (the zero bytes behind the input count as input for the decoder's look-ahead — a final block at the very end of the file
