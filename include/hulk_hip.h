@@ -158,7 +158,10 @@ int hulk_add_reads_device(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t 
  * reads by the reference's slot machine: FASTQ = l1..l3 take the next NON-EMPTY line, l4 takes the
  * next line whatever it is, the read is l2 and its l1 must start with '@' (checked when l4 arrives,
  * so a truncated last record is dropped silently); --fasta = lines of a '>' record concatenated,
- * parsing stops at the first empty line.  `threads` parser threads (0 = one per core, at most 16). */
+ * parsing stops at the first empty line.  `threads` parser threads (0 = one per core, at most 16).
+ * gzip input is inflated by the library itself, multistream as compress/gzip reads it: a regular one-member file of >= 4 MiB
+ * by HULK_GZ_THREADS (default 16) threads at once (about 0.6 GB of scratch mappings while the file is open; HULK_GZ_PAR=0:
+ * one thread), a bgzip'd file member by member on as many; bytes and messages are the same whichever reader runs. */
 typedef struct hulk_ingest_stats {
     uint64_t n_seqs;      /* seqCount of SeqMinimizer.Run */
     uint64_t total_len;   /* lengthTotal */
