@@ -157,8 +157,8 @@ def self_spawn(args):
 def e2e_file_rates(n_reads=2_000_000):
     """End to end, FASTQ file -> sketch (the reference's DataStreamer/FastqHandler/AddSeq loop, pipeline/sketch.go:40-217,
     in native code: hulk_sketch_files): a synthetic FASTQ of `n_reads` 150 bp reads on /dev/shm, plain, .gz (one member) and bgzip'd, C2 parameters,
-    wall clock from the first byte read to hulk_finish, on a context whose tables exist (the second of two runs, so the
-    pinned staging is allocated too).  Host-bound (parse / inflate), reported beside the kernel-path figure, never as it."""
+    wall clock from the first byte read to hulk_finish, on a context whose tables exist (the fastest of four runs, each on a
+    fresh context; all four are in the line).  Host-bound (parse / inflate), reported beside the kernel-path figure, never as it."""
     import gzip
     import shutil
     import tempfile
@@ -189,10 +189,11 @@ def e2e_file_rates(n_reads=2_000_000):
                          (zlib.crc32(piece) & 0xffffffff).to_bytes(4, "little") + len(piece).to_bytes(4, "little"))
                 if not piece:                    # (the empty member written last is the format's end-of-file marker)
                     break
+        from hulk_amd import ingest
         for label, path in (("plain", plain), ("gz", gz), ("bgzf", bg)):
-            best = None
-            for _ in range(2):
-                g = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL)
+            runs = []
+            for _ in range(4):                   # every run on a fresh context; all four listed, the fastest reported (the first of a
+                g = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL)     # process also pays for its first threads and huge pages)
                 t0 = time.perf_counter()
                 st = g.sketch_files([path])
                 g.finish()
@@ -200,8 +201,11 @@ def e2e_file_rates(n_reads=2_000_000):
                 mins, _ = g.sketch()
                 g.close()
                 assert st["n_seqs"] == n_reads
-                best = dt if best is None else min(best, dt)
-            out[label] = {"value": n_reads / best, "unit": "reads/s", "seconds": best, "file_bytes": os.path.getsize(path),
+                runs.append(dt)
+            best = min(runs)
+            _, _, pst = ingest.parse_files([path], collect=False)        # the host side alone: hulk_parse_files, no GPU sink
+            out[label] = {"value": n_reads / best, "unit": "reads/s", "seconds": best, "seconds_all_runs": runs, "file_bytes": os.path.getsize(path),
+                          "parse_only_reads_per_s": pst["n_seqs"] / pst["seconds"] if pst["seconds"] > 0 else None,
                           "sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()}
         assert out["plain"]["sketch_md5"] == out["gz"]["sketch_md5"] == out["bgzf"]["sketch_md5"]
     finally:
