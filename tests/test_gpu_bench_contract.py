@@ -47,8 +47,13 @@ def test_bench_json_contract_and_collective_path():
     assert a["value_unpruned"] is not None and a["value_unpruned"] <= 1.2 * a["value"]
     # end to end from a FASTQ file, plain and .gz: host-bound, far below the kernel-path rate, same sketch both ways
     e2e = a["e2e"]
-    assert 1e5 < e2e["gz"]["value"] < e2e["plain"]["value"] < a["value"] and e2e["plain"]["sketch_md5"] == e2e["gz"]["sketch_md5"]
-    assert e2e["gz"]["value"] < e2e["bgzf"]["value"] < a["value"] and e2e["bgzf"]["sketch_md5"] == e2e["plain"]["sketch_md5"]   # members side by side
+    # (one member inflated by several threads and bgzip'd members side by side: both well above one inflate thread's ~5e6, neither
+    # ordered against the other nor — on a noisy host — strictly against the plain file)
+    for c in ("plain", "gz", "bgzf"):
+        assert 1e5 < e2e[c]["value"] < a["value"] and e2e[c]["sketch_md5"] == e2e["plain"]["sketch_md5"]
+        assert len(e2e[c]["seconds_all_runs"]) == 4 and min(e2e[c]["seconds_all_runs"]) == e2e[c]["seconds"]
+        assert e2e[c]["parse_only_reads_per_s"] > 1e5
+    assert e2e["gz"]["value"] < 1.5 * e2e["plain"]["value"] and e2e["bgzf"]["value"] < 1.5 * e2e["plain"]["value"]
     # the sharded step at world size 1: RCCL communicator, exchange inside the library, same sketch
     b = _run(["--no-cpu-baseline", "--no-cold", "--force-collective"], {"HULK_BENCH_C4_READS_PER_RANK": "5000000"})
     assert b["sketch_md5"] == a["sketch_md5"]
