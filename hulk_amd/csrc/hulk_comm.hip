@@ -1,0 +1,368 @@
+// hulk_comm.hip — multi-GPU with the exchange INSIDE the library (include/hulk_hip.h): RCCL bound at run time, the host
+// and loopback transports, hulk_step_sharded / hulk_step_sliced, hulk_gather_sketch.  Reference seam: SeqMinimizer.Run's
+// AddSeq / Flush loop (src/pipeline/sketch.go:182-250) with the read stream sharded over one process per GPU.
+#include "hulk_ctx.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+
+namespace hulk {
+namespace {
+// ---- RCCL, bound at run time.  libhulkhip.so does not carry a DT_NEEDED for librccl.so.1 (573 MB, half a second to map):
+// a single-GPU host never loads it.  dlopen finds the copy a host process already holds (torch bundles one under the
+// same SONAME) or the one next to the HIP runtime this library is linked against.
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+Rccl *rccl() {
+    static Rccl R = [] {
+        Rccl r;
+        const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        if (const char *only = getenv("HULK_RCCL_LIB")) r.handle = dlopen(only, RTLD_NOW | RTLD_GLOBAL);      // this build and no other
+        else for (const char *n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.handle) break; }
+        if (!r.handle) { const char *e = dlerror(); r.error = std::string("librccl.so.1 not found: ") + (e ? e : ""); return r; }
+#define RCCL_SYM(f) do { r.f = (decltype(r.f))dlsym(r.handle, "nccl" #f); if (!r.f) r.error = "librccl lacks nccl" #f; } while (0)
+        RCCL_SYM(GetUniqueId); RCCL_SYM(CommInitRank); RCCL_SYM(CommDestroy); RCCL_SYM(AllGather); RCCL_SYM(AllReduce);
+        RCCL_SYM(GroupStart); RCCL_SYM(GroupEnd); RCCL_SYM(GetErrorString);
+#undef RCCL_SYM
+        return r;
+    }();
+    return &R;
+}
+int fail_nccl(hulk_ctx *c, ncclResult_t r, const char *what) {
+    return fail(c, HULK_ERR_COMM, std::string(what) + ": " + (rccl()->GetErrorString ? rccl()->GetErrorString(r) : "RCCL error"));
+}
+#define NCCLCHK(c, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return fail_nccl((c), r_, #call); } while (0)
+
+}  // namespace
+
+// host transport: the buffers cross through pinned memory and the caller's function moves them between the ranks
+int comm_host_stage(hulk_ctx *c, size_t bytes) {
+    if (bytes <= c->comm.h_stage_cap) return HULK_OK;
+    if (c->comm.h_stage) hipHostFree(c->comm.h_stage);
+    c->comm.h_stage = nullptr; c->comm.h_stage_cap = 0;
+    HIPCHK(c, hipHostMalloc((void **)&c->comm.h_stage, bytes + bytes / 4, hipHostMallocDefault));
+    c->comm.h_stage_cap = bytes + bytes / 4;
+    return HULK_OK;
+}
+// all-gather of `bytes` per rank on stream s; in place when d_send == d_recv + rank * bytes
+int comm_allgather(hulk_ctx *c, hipStream_t s, const void *d_send, void *d_recv, size_t bytes) {
+    hulk_ctx::Comm &m = c->comm;
+    if (bytes == 0) return HULK_OK;
+    m.bytes_rx += (uint64_t)bytes * (m.world - 1);
+    uint8_t *own = (uint8_t *)d_recv + (size_t)m.rank * bytes;
+    switch (m.kind) {
+        case 1: NCCLCHK(c, rccl()->AllGather(d_send, d_recv, bytes, ncclUint8, m.nccl, s)); return HULK_OK;
+        case 2: {
+            { const int rc = comm_host_stage(c, bytes * (m.world + 1)); if (rc != HULK_OK) return rc; }
+            HIPCHK(c, hipMemcpyAsync(m.h_stage, d_send, bytes, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (m.fn(m.user, HULK_XCHG_ALLGATHER, m.h_stage, m.h_stage + bytes, bytes) != 0)
+                return fail(c, HULK_ERR_COMM, "the host's exchange function failed (all-gather)");
+            HIPCHK(c, hipMemcpyAsync(d_recv, m.h_stage + bytes, bytes * m.world, hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            return HULK_OK;
+        }
+        case 3:
+            for (uint32_t r = 0; r < m.world; r++) {
+                uint8_t *dst = (uint8_t *)d_recv + (size_t)r * bytes;
+                if (dst != (const uint8_t *)d_send) HIPCHK(c, hipMemcpyAsync(dst, d_send, bytes, hipMemcpyDeviceToDevice, s));
+            }
+            return HULK_OK;
+        default: break;
+    }
+    if ((const uint8_t *)d_send != own) HIPCHK(c, hipMemcpyAsync(own, d_send, bytes, hipMemcpyDeviceToDevice, s));
+    return HULK_OK;
+}
+int comm_allreduce_u32(hulk_ctx *c, hipStream_t s, uint32_t *d_buf, size_t words) {
+    hulk_ctx::Comm &m = c->comm;
+    if (words == 0) return HULK_OK;
+    m.bytes_rx += (uint64_t)words * 4 * 2 * (m.world - 1) / m.world;
+    if (m.kind == 1) { NCCLCHK(c, rccl()->AllReduce(d_buf, d_buf, words, ncclUint32, ncclSum, m.nccl, s)); return HULK_OK; }
+    if (m.kind == 2) {
+        const size_t bytes = words * 4;
+        { const int rc = comm_host_stage(c, bytes * 2); if (rc != HULK_OK) return rc; }
+        HIPCHK(c, hipMemcpyAsync(m.h_stage, d_buf, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (m.fn(m.user, HULK_XCHG_ALLREDUCE_U32, m.h_stage, m.h_stage + bytes, bytes) != 0)
+            return fail(c, HULK_ERR_COMM, "the host's exchange function failed (all-reduce)");
+        HIPCHK(c, hipMemcpyAsync(d_buf, m.h_stage + bytes, bytes, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    return HULK_OK;                                             // loopback / no peers: the identity
+}
+
+// frees everything hulk_comm_init* set up (also after a failed ncclCommInitRank, so that the call can be repeated)
+void comm_teardown(hulk_ctx *c) {
+    hulk_ctx::Comm &m = c->comm;
+    if (m.stream) hipStreamSynchronize(m.stream);                 // no collective in flight when the communicator goes
+    if (m.nccl && rccl()->CommDestroy) rccl()->CommDestroy(m.nccl);
+    hipFree(m.d_hdr); hipFree(m.d_delta); hipFree(m.d_gather); hipFree(m.d_sk);
+    for (int i = 0; i < 2; i++) { if (m.h_hdr[i]) hipHostFree(m.h_hdr[i]); if (m.ev_hdr[i]) hipEventDestroy(m.ev_hdr[i]); }
+    if (m.h_stage) hipHostFree(m.h_stage);
+    if (m.ev_ready) hipEventDestroy(m.ev_ready);
+    if (m.ev_done) hipEventDestroy(m.ev_done);
+    if (m.stream) hipStreamDestroy(m.stream);
+    m = hulk_ctx::Comm{};
+}
+
+// what stream s has queued so far -> the collectives' stream, and back
+int comm_enter(hulk_ctx *c, hipStream_t s) {
+    HIPCHK(c, hipEventRecord(c->comm.ev_ready, s));
+    HIPCHK(c, hipStreamWaitEvent(c->comm.stream, c->comm.ev_ready, 0));
+    return HULK_OK;
+}
+int comm_leave(hulk_ctx *c, hipStream_t s) {
+    HIPCHK(c, hipEventRecord(c->comm.ev_done, c->comm.stream));
+    HIPCHK(c, hipStreamWaitEvent(s, c->comm.ev_done, 0));
+    return HULK_OK;
+}
+
+namespace {
+int comm_setup(hulk_ctx *c, int kind, uint32_t rank, uint32_t world) {
+    hulk_ctx::Comm &m = c->comm;
+    if (m.kind != 0) return fail(c, HULK_ERR_STATE, "the context already has a communicator");
+    if (world == 0 || rank >= world) return fail(c, HULK_ERR_ARG, "rank / world");
+    if (c->seq_count || c->flush_index) return fail(c, HULK_ERR_STATE, "hulk_comm_init must precede the first read");
+    HIPCHK(c, hipSetDevice(c->p.device));
+    const size_t NC = (size_t)c->cms_depth * c->cms_width;
+    HIPCHK(c, dalloc(&m.d_hdr, (size_t)world * SHARD_HDR));
+    HIPCHK(c, dalloc(&m.d_delta, (size_t)world * c->T * NC));
+    HIPCHK(c, dalloc(&m.d_sk, (size_t)world * (2 + 2 * (size_t)c->S)));
+    HIPCHK(c, hipMemset(m.d_hdr, 0, (size_t)world * SHARD_HDR * 4));
+    {
+        int lo = 0, hi = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(c, hipStreamCreateWithPriority(&m.stream, hipStreamNonBlocking, hi));   // `hi` = greatest priority
+        HIPCHK(c, hipEventCreateWithFlags(&m.ev_ready, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&m.ev_done, hipEventDisableTiming));
+    }
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(c, hipHostMalloc((void **)&m.h_hdr[i], (size_t)world * SHARD_HDR * 4, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&m.ev_hdr[i], hipEventDisableTiming));
+    }
+    m.rank = rank; m.world = world; m.kind = kind;
+    return HULK_OK;
+}
+// intervals of a step that rank r holds (hulk_hip.h: whole intervals, T per rank, in rank order)
+uint32_t shard_count(const hulk_ctx *c, uint32_t step_intervals, uint32_t r) {
+    const uint64_t lo = (uint64_t)r * c->T;
+    if (step_intervals <= lo) return 0;
+    return (uint32_t)std::min<uint64_t>(c->T, step_intervals - lo);
+}
+}  // namespace
+}  // namespace hulk
+
+using namespace hulk;
+
+extern "C" {
+int hulk_comm_unique_id(void *unique_id) {
+    if (!unique_id) return fail(nullptr, HULK_ERR_ARG, "NULL");
+    Rccl *R = rccl();
+    if (!R->error.empty()) return fail(nullptr, HULK_ERR_COMM, R->error);
+    static_assert(sizeof(ncclUniqueId) == HULK_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    NCCLCHK(nullptr, R->GetUniqueId((ncclUniqueId *)unique_id));
+    return HULK_OK;
+}
+
+int hulk_comm_init(hulk_ctx *c, const void *unique_id, uint32_t rank, uint32_t world) {
+    if (!c || !unique_id) return fail(c, HULK_ERR_ARG, "NULL");
+    Rccl *R = rccl();
+    if (!R->error.empty()) return fail(c, HULK_ERR_COMM, R->error);
+    { const int rc = comm_setup(c, 1, rank, world); if (rc != HULK_OK) return rc; }
+    ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
+    const ncclResult_t r = R->CommInitRank(&c->comm.nccl, (int)world, id, (int)rank);
+    if (r != ncclSuccess) { const int rc = fail_nccl(c, r, "ncclCommInitRank"); c->comm.nccl = nullptr; comm_teardown(c); return rc; }
+    return HULK_OK;
+}
+
+int hulk_comm_init_host(hulk_ctx *c, uint32_t rank, uint32_t world, hulk_exchange_fn fn, void *user) {
+    if (!c || !fn) return fail(c, HULK_ERR_ARG, "NULL");
+    { const int rc = comm_setup(c, 2, rank, world); if (rc != HULK_OK) return rc; }
+    c->comm.fn = fn; c->comm.user = user;
+    return HULK_OK;
+}
+
+int hulk_comm_init_loopback(hulk_ctx *c, uint32_t rank, uint32_t world) {
+    if (!c) return HULK_ERR_ARG;
+    return comm_setup(c, 3, rank, world);
+}
+
+int hulk_step_sharded(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, uint32_t max_read_len,
+                      uint64_t bases_bytes, uint32_t step_intervals) {
+    if (!c) return HULK_ERR_ARG;
+    hulk_ctx::Comm &m = c->comm;
+    if (m.kind == 0) return fail(c, HULK_ERR_STATE, "hulk_step_sharded needs hulk_comm_init");
+    if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
+    if (c->sticky != HULK_OK) return fail(c, c->sticky);
+    const uint64_t I = c->p.interval;
+    if (I == 0) return fail(c, HULK_ERR_ARG, "hulk_step_sharded needs params.interval > 0 (the global sketching interval)");
+    if (c->ring_base != 0 || c->bin_spectra) return fail(c, HULK_ERR_STATE, "a partial interval / an unflushed batch is pending");
+    if (step_intervals == 0 || step_intervals > (uint64_t)m.world * c->T) return fail(c, HULK_ERR_ARG, "step_intervals");
+    const uint32_t own = shard_count(c, step_intervals, m.rank);
+    if ((own == 0) != (n == 0) || n > (uint64_t)own * I || (own && n <= (uint64_t)(own - 1) * I))
+        return fail(c, HULK_ERR_ARG, "n_reads does not match this rank's intervals of the step");
+    if (n && (!d_bases || !d_offsets)) return fail(c, HULK_ERR_ARG, "NULL buffer");
+    int rc = ensure_tables(c);
+    if (rc != HULK_OK) return rc;
+    // 1. bin this rank's intervals into spectra 0 .. own-1 of the current ring (work stream)
+    for (uint64_t pos = 0; pos < n; pos += MAX_READS_PER_LAUNCH) {
+        const uint64_t chunk = std::min<uint64_t>(MAX_READS_PER_LAUNCH, n - pos);
+        rc = bin_reads(c, d_bases, d_offsets + pos, chunk, max_read_len, bases_bytes, I, pos);
+        if (rc != HULK_OK) return rc;
+    }
+    c->seq_count += n;
+    rc = issue_flush(c);
+    if (rc != HULK_OK) return rc;
+    // 2. which exchange: the verdicts of the step before (they travelled with its exchange) — any rank's need_full keeps
+    //    the spectra exchange.  The wait ends when the previous step's exchange has run: this step's binning is queued.
+    bool full = c->drift || c->scaling || !c->prune || c->no_skip || m.step == 0;
+    if (!full) {
+        const int prev = (int)((m.step - 1) & 1);
+        if (m.hdr_pending[prev]) { HIPCHK(c, hipEventSynchronize(m.ev_hdr[prev])); m.hdr_pending[prev] = false; }
+        for (uint32_t r = 0; r < m.world; r++) if (m.h_hdr[prev][(size_t)r * SHARD_HDR + 1]) full = true;
+    }
+    static const bool force_full = getenv("HULK_SHARD_FULL") != nullptr;      // A/B aid: always the spectra exchange
+    if (force_full) full = true;
+    hipStream_t s = flush_stream_of(c);
+    HIPCHK(c, hipEventRecord(c->ev_binned, c->stream));
+    if (!no_overlap_mode()) HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
+    const int ring = c->cur_ring;
+    uint32_t *hist = ring_hist(c);
+    const size_t B = (size_t)c->B, NC = (size_t)c->cms_depth * c->cms_width;
+    uint32_t *own_hdr = m.d_hdr + (size_t)m.rank * SHARD_HDR;
+    FlushBatch fb{};
+    fb.ring_base = 0; fb.ring_n = c->ring_n; fb.count = own; fb.parity = 0; fb.num_bins = c->B;
+    HIPCHK(c, hipMemsetAsync(own_hdr, 0, SHARD_HDR * 4, s));
+    // this rank's verdict for the NEXT step: the whole-batch bound on the counters and weights as they stand now
+    // (a rank without slots has nothing to protect: its verdict stays 0)
+    if (c->slots)
+        HIPCHK(c, launch_flush_decide(s, c->d_ctr, (int)NC, c->d_kminslot, c->d_weights, (int)c->slots, (int)c->slot_begin,
+                                      c->d_state, fb, 1, own_hdr + 1));
+    if (!full) {
+        uint32_t *own_delta = m.d_delta + (size_t)m.rank * c->T * NC;
+        HIPCHK(c, hipMemsetAsync(own_delta, 0, (size_t)c->T * NC * 4, s));
+        HIPCHK(c, launch_shard_local(s, hist, c->d_pos16, own_hdr, own_delta, c->cms_depth, c->cms_width, fb));
+        HIPCHK(c, hipEventRecord(c->ev_flushed[ring], s));          // the ring is wiped: the work stream may fill it again
+        c->pending_flush[ring] = true;
+        rc = comm_enter(c, s);
+        if (rc != HULK_OK) return rc;
+        if (m.kind == 1) NCCLCHK(c, rccl()->GroupStart());
+        rc = comm_allgather(c, m.stream, own_hdr, m.d_hdr, SHARD_HDR * 4);
+        const int rc2 = rc == HULK_OK ? comm_allgather(c, m.stream, own_delta, m.d_delta, (size_t)c->T * NC * 4) : rc;
+        if (m.kind == 1) NCCLCHK(c, rccl()->GroupEnd());                 // (closed whatever the calls inside it returned)
+        if (rc2 != HULK_OK) return rc2;
+        rc = comm_leave(c, s);
+        if (rc != HULK_OK) return rc;
+        HIPCHK(c, launch_shard_apply(s, m.d_hdr, m.d_delta, c->d_ctr, c->cms_depth, c->cms_width, m.world, c->T,
+                                     step_intervals, c->B, c->d_state));
+        m.steps_delta++;
+    } else {
+        const size_t need = (size_t)m.world * c->T * B;
+        if (need > m.gather_words) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            hipFree(m.d_gather); m.d_gather = nullptr; m.gather_words = 0;
+            HIPCHK(c, hipMalloc((void **)&m.d_gather, need * 4));
+            m.gather_words = need;
+        }
+        rc = comm_enter(c, s);
+        if (rc == HULK_OK) rc = comm_allgather(c, m.stream, own_hdr, m.d_hdr, SHARD_HDR * 4);
+        if (rc == HULK_OK) rc = comm_allgather(c, m.stream, hist, m.d_gather, (size_t)c->T * B * 4);
+        if (rc == HULK_OK) rc = comm_leave(c, s);
+        if (rc != HULK_OK) return rc;
+        if (own) HIPCHK(c, hipMemsetAsync(hist, 0, (size_t)own * B * 4, s));    // Wipe of the rank's own copy
+        HIPCHK(c, hipEventRecord(c->ev_flushed[ring], s));
+        c->pending_flush[ring] = true;
+        for (uint32_t r = 0; r < m.world; r++) {                    // the ordinary flush of every rank's intervals, stream order
+            const uint32_t cnt = shard_count(c, step_intervals, r);
+            if (!cnt) break;
+            FlushBatch fr{};
+            fr.ring_base = 0; fr.ring_n = c->T; fr.count = cnt; fr.parity = (int)(c->flush_index & 1); fr.num_bins = c->B;
+            c->flush_index++;
+            rc = flush_kernels(c, s, m.d_gather + (size_t)r * c->T * B, fr);
+            if (rc != HULK_OK) return rc;
+        }
+        m.steps_full++;
+    }
+    const int cur = (int)(m.step & 1);
+    HIPCHK(c, hipMemcpyAsync(m.h_hdr[cur], m.d_hdr, (size_t)m.world * SHARD_HDR * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(m.ev_hdr[cur], s));
+    m.hdr_pending[cur] = true;
+    m.step++;
+    m.global_intervals += step_intervals;
+    c->cur_ring ^= 1;
+    return HULK_OK;
+}
+
+int hulk_step_sharded_host(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n, uint32_t step_intervals) {
+    if (!c) return HULK_ERR_ARG;
+    if (n && (!bases || !offsets)) return fail(c, HULK_ERR_ARG, "NULL buffer");
+    if (n == 0) return hulk_step_sharded(c, nullptr, nullptr, 0, 0, 0, step_intervals);
+    uint64_t max_len = 0;
+    { const int rcv = check_host_reads(c, offsets, n, &max_len); if (rcv != HULK_OK) return rcv; }
+    hulk_ctx::HostStage *hs = nullptr;
+    { const int rcs = stage_host_reads(c, bases, offsets, 0, n, &hs); if (rcs != HULK_OK) return rcs; }
+    const int rc = hulk_step_sharded(c, hs->d_bases, hs->d_off, n, (uint32_t)max_len, hs->cap_bases, step_intervals);
+    HIPCHK(c, hipEventRecord(hs->ev, c->stream));               // (the binning kernels are on the work stream)
+    hs->busy = true;
+    return rc;
+}
+
+int hulk_step_sliced(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, uint32_t max_read_len,
+                     uint64_t bases_bytes, uint64_t reads_per_spectrum, uint32_t n_spectra) {
+    if (!c) return HULK_ERR_ARG;
+    if (c->comm.kind == 0) return fail(c, HULK_ERR_STATE, "hulk_step_sliced needs hulk_comm_init");
+    if (n_spectra == 0 || n_spectra > c->T) return fail(c, HULK_ERR_ARG, "n_spectra");
+    int rc = hulk_bin_reads_device_at(c, d_bases, d_offsets, n, max_read_len, bases_bytes, reads_per_spectrum, 0);
+    if (rc != HULK_OK) return rc;
+    if (c->bin_spectra > n_spectra) return fail(c, HULK_ERR_ARG, "more spectra binned than n_spectra");
+    rc = flush_batch(c, n_spectra, nullptr, false, true);
+    if (rc == HULK_OK) { c->cur_ring ^= 1; c->bin_spectra = 0; }
+    return rc;
+}
+
+int hulk_gather_sketch(hulk_ctx *c, uint64_t *mins, double *weights) {
+    if (!c || !mins || !weights) return fail(c, HULK_ERR_ARG, "NULL");
+    hulk_ctx::Comm &m = c->comm;
+    if (m.kind == 0 || m.world == 1) return hulk_get_sketch(c, mins, weights);
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
+    const size_t S = c->S, blk = 2 + 2 * S;
+    std::vector<unsigned long long> h((size_t)m.world * blk);
+    unsigned long long *own = m.d_sk + (size_t)m.rank * blk;
+    const unsigned long long head[2] = {c->slot_begin, c->slots};
+    HIPCHK(c, hipMemcpyAsync(own, head, 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(own + 2, c->d_mins, S * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(own + 2 + S, c->d_weights, S * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                     // `head` is a stack buffer
+    { const int rc = comm_allgather(c, c->stream, own, m.d_sk, blk * 8); if (rc != HULK_OK) return rc; }
+    HIPCHK(c, hipMemcpyAsync(h.data(), m.d_sk, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < S; i++) { mins[i] = 0; weights[i] = 1.7976931348623157e308; }
+    for (uint32_t r = 0; r < m.world; r++) {
+        const unsigned long long *b = h.data() + (size_t)r * blk;
+        const uint64_t sb = b[0], sc = b[1];
+        if (sb + sc > S) return fail(c, HULK_ERR_COMM, "a rank reported a slot shard outside the sketch");
+        for (uint64_t i = sb; i < sb + sc; i++) { mins[i] = b[2 + i]; memcpy(&weights[i], &b[2 + S + i], 8); }
+    }
+    return HULK_OK;
+}
+
+int hulk_get_comm_stats(hulk_ctx *c, uint64_t *steps_delta, uint64_t *steps_full, uint64_t *bytes_received) {
+    if (!c) return HULK_ERR_ARG;
+    if (steps_delta) *steps_delta = c->comm.steps_delta;
+    if (steps_full) *steps_full = c->comm.steps_full;
+    if (bytes_received) *bytes_received = c->comm.bytes_rx;
+    return HULK_OK;
+}
+
+}  // extern "C"

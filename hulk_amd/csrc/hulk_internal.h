@@ -158,7 +158,7 @@ hipError_t launch_selftest_rcp(hipStream_t s, unsigned long long *d_mismatches);
 hipError_t launch_fill_f32(hipStream_t s, float *p, size_t n, float v);
 hipError_t launch_add_hist(hipStream_t s, uint32_t *d_hist, const uint32_t *d_add, int32_t num_bins);
 
-// context accessors for hulk_ingest.hip (defined in hulk_api.hip; not part of the ABI)
+// context accessors for hulk_ingest.hip (defined in hulk_flush.hip; not part of the ABI)
 }  // namespace hulk
 struct hulk_ctx;
 namespace hulk {

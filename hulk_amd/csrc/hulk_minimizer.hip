@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     // all instructions when done per read); the following 15 reads step from it
     uint32_t slot0 = P.ring_base; uint64_t rem0 = 0;
     if (P.interval) {
-        // a launch covers at most ring_n - 1 intervals (hulk_api.hip), so the quotient is found by a short
+        // a launch covers at most ring_n - 1 intervals (hulk_flush.hip), so the quotient is found by a short
         // scalar loop; the two 64-bit divisions that stood here were ~3 % of the kernel's VALU instructions
         const uint64_t x = P.fill + wave_first;
         uint32_t xl = __builtin_amdgcn_readfirstlane((uint32_t)x), xh = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
