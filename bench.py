@@ -31,9 +31,15 @@ HULK_BENCH_TRANSPORT=gloo (test aid): the ranks share GPU 0 and the library's HO
 (RCCL refuses two ranks on one device) — same protocol, same kernels; tests/test_gpu_bench_contract.py runs world 2 this way.
 
 Passes, in order: discarded ones (the first pass of a process measures low, and a GPU fresh from idle for seconds: one
-pass + HULK_BENCH_PREWARM_S = 2 s of them), `value_unpruned`, the headline (W warm-up +
-K timed steps between barriers), at N = 1 `value_cold`, the end-to-end file figures and the CPU baseline, at N > 1 the other
-modes and `value_c4`.  Prints ONE JSON line on rank 0.
+pass + HULK_BENCH_PREWARM_S = 2 s of them), then the HEADLINE (W warm-up + K timed steps between barriers, no event
+brackets in it), then the secondary legs, each of them fault-isolated: `kernels` (the same steps with every kernel alone on
+one stream and bracketed by HIP events: the durations the roofline objects are computed from), `value_unpruned`,
+`ms_per_step_long` (>= 200 steps), at N = 1 `value_cold`, `c3`, `c5`, the end-to-end file figures and the CPU baseline, at
+N > 1 the other modes and `value_c4`.  A leg that raises leaves `"<leg>_error": "<text>"` in the line and the run goes on;
+a leg that hangs (a rank stuck in a collective) is ended by a watchdog on every rank after HULK_BENCH_LEG_TIMEOUT_S
+(default 300) seconds: rank 0 prints the line with what it has and every rank exits 0.  HULK_BENCH_FAIL=<leg>[,<leg>] makes
+the named legs raise (test aid).  Prints ONE JSON line on rank 0; the exit status is non-zero only if the headline
+itself did not run.
 """
 import argparse
 import hashlib
@@ -59,8 +65,21 @@ C2_READS = 10_000_000        # BASELINE configs[1]
 C4_READS_PER_RANK = int(os.environ.get("HULK_BENCH_C4_READS_PER_RANK", "50000000"))   # BASELINE configs[3]: 400 M reads on 8 GPUs
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 SIMDS, CLOCK_GHZ, VALU_CYCLES = 256 * 4, 2.4, 2   # MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU op issues over 2 cycles
-PMC_PROFILE = os.path.join("profiles", "r03_pmc.json")
-ISA_MIX = os.path.join("profiles", "r03_isa_mix.json")      # tools/isa_mix.py over the production kernels, priced by profiles/r03_op_cost.txt
+def _newest(*names):
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, "profiles", n)):
+            return os.path.join("profiles", n)
+    return os.path.join("profiles", names[-1])
+
+
+PMC_PROFILE = _newest("r04_pmc.json", "r03_pmc.json")
+ISA_MIX = _newest("r04_isa_mix.json", "r03_isa_mix.json")   # tools/isa_mix.py over the production kernels, priced by profiles/r03_op_cost.txt
+LEG_TIMEOUT_S = float(os.environ.get("HULK_BENCH_LEG_TIMEOUT_S", "300"))
+FAIL_LEGS = set(x for x in os.environ.get("HULK_BENCH_FAIL", "").split(",") if x)
+HANG_LEGS = set(x for x in os.environ.get("HULK_BENCH_HANG", "").split(",") if x)      # test aid: the named legs never return
+LONG_STEPS = int(os.environ.get("HULK_BENCH_LONG_STEPS", "200"))
+C3 = dict(k=31, w=9, S=1024, decay=0.02, interval=100_000, reads=8_000_000)     # BASELINE configs[2], HBM-resident sample
+C5 = dict(n=1024, S=2048)                                                         # BASELINE configs[4]
 CLOCK_MEASURED_GHZ = 2.3    # shader clock under VALU load: s_memtime ticks per ns of HIP-event time, tools/ubench/op_cost2.hip (2.1-2.35)
 
 
@@ -213,6 +232,36 @@ def e2e_file_rates(n_reads=2_000_000):
     return out
 
 
+def c5_leg():
+    """BASELINE configs[4] ("C5"): `hulk smash` over 1024 sketches of sketchSize 2048 (cmd/smash.go:183-226), both metrics:
+    end to end through hulk_smash (host arrays in, PCIe both ways) and the distance kernel alone (hulk_smash_ex, HIP events).
+    LDS-pipe fraction of k_smash: every (pair, slot) step is three ds_read_b64 wave-instructions per wave (2 LDS cycles each,
+    MI355X_MICROARCH.md "LDS") -> N^2 * S * 3 / 64 wave-instructions * 2 cycles / 256 CUs / 2.4 GHz over the kernel time."""
+    from hulk_amd.smash import distance_matrix
+    rng = np.random.default_rng(5)
+    N, S_ = C5["n"], C5["S"]
+    base = rng.integers(0, 194481, size=S_).astype(np.uint64)
+    mins = np.where(rng.random((N, S_)) < 0.5, base, rng.integers(0, 194481, size=(N, S_)).astype(np.uint64))
+    w = -rng.gamma(2.0, 1e-3, size=(N, S_))
+    distance_matrix(mins[:8], w[:8], "weightedjaccard")           # module load
+    out = {"workload": f"C5: pairwise matrix over {N} synthetic sketches, sketchSize {S_} (hulk smash, cmd/smash.go:183-226)",
+           "pairs": N * N}
+    lds_cycles = N * N * S_ * 3 / 64.0 * 2 / 256.0
+    for metric in ("weightedjaccard", "jaccard"):
+        best = None
+        for _ in range(3):
+            tm = {}
+            t0 = time.perf_counter()
+            d = distance_matrix(mins, w, metric, timing=tm)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, tm["kernel_ms"], hashlib.md5(np.ascontiguousarray(d).tobytes()).hexdigest())
+        out[metric] = {"ms_end_to_end": best[0] * 1e3, "ms_kernel": best[1], "pairs_per_s": N * N / best[0],
+                       "lds_pipe_frac": (lds_cycles / (CLOCK_GHZ * 1e9)) / (best[1] * 1e-3) if best[1] > 0 else None,
+                       "matrix_md5": best[2]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,12 +276,16 @@ def main():
     ap.add_argument("--n-frac", type=float, default=0.0,
                     help="variant workload: this fraction of the reads gets one 'N' at a pseudo-random position (real Illumina "
                          "data has such reads; they leave the table-free fast path of the minimizer kernel).  Not the headline.")
+    ap.add_argument("--pieces", type=int, default=0, help="hulk_params.bin_pieces of the timed contexts (0 = the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the value_cold pass (C2 exactly: 10 M reads, no warm-up)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the FASTQ file -> sketch figures (N = 1 only)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the C3 leg (k=31, sketchSize=1024, decay; N = 1 only)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 leg (hulk smash 1024 x 2048; N = 1 only)")
     ap.add_argument("--no-c4", action="store_true", help="N > 1: skip value_c4 (50 M reads per rank on fresh contexts)")
+    ap.add_argument("--no-long", action="store_true", help="skip the long pass (ms_per_step_long)")
     ap.add_argument("--single-pass", action="store_true",
-                    help="skip the second timed pass (CWS-scan pruning disabled) that fills value_unpruned")
+                    help="headline and kernel durations only: no value_unpruned, no long pass, no other modes")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the sharded-step path (RCCL communicator, exchange inside the library) even at world size 1 (test aid)")
     ap.add_argument("--loopback", type=int, default=0, metavar="G",
@@ -286,8 +339,72 @@ def main():
     def host_tensor(vals, dtype):
         return torch.tensor(vals, dtype=dtype, device="cpu" if transport == "gloo" else device)
 
+    # ---- the line so far, and the watchdog that prints it if a leg never returns -------------------------------------
+    out = {}                       # rank 0: the JSON line; filled as the legs complete
+    state = {"leg": "headline", "kick": time.monotonic(), "printed": False, "headline_done": False}
+    lock = threading.Lock()
+
+    def print_line():
+        with lock:
+            if state["printed"]:
+                return
+            state["printed"] = True
+            if rank == 0:
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                print(json.dumps(out), flush=True)
+                os.dup2(2, 1)
+
+    def watchdog():
+        while not state["printed"]:
+            time.sleep(1.0)
+            if time.monotonic() - state["kick"] > LEG_TIMEOUT_S:
+                leg_ = state["leg"]
+                sys.stderr.write(f"bench.py rank {rank}: leg '{leg_}' has not returned for {LEG_TIMEOUT_S:.0f} s; giving up on it\n")
+                if not state["headline_done"]:
+                    os._exit(3)                              # nothing to print: the headline itself hangs
+                out[f"{leg_}_error"] = f"timeout: no return within {LEG_TIMEOUT_S:.0f} s (watchdog)"
+                print_line()
+                os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    leg_errors = {}
+    dist_ok = [True]               # collective legs go on only while every rank finished every collective leg so far
+
+    def run_leg(name, fn, collective=False):
+        """fn() fault-isolated: an exception becomes `<name>_error` in the line (and, for a leg that holds collectives, every
+        later collective leg is skipped on every rank: the ranks agree on the outcome after each such leg)."""
+        state["leg"], state["kick"] = name, time.monotonic()
+        if collective and not dist_ok[0]:
+            leg_errors[name] = "skipped: an earlier collective leg failed on some rank"
+            return None
+        res, err = None, None
+        try:
+            if name in FAIL_LEGS:
+                raise RuntimeError(f"HULK_BENCH_FAIL={name} (test aid)")
+            if name in HANG_LEGS:
+                time.sleep(1e9)
+            res = fn()
+        except BaseException as e:                           # noqa: BLE001 — the line must survive anything a leg does
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            err = f"{type(e).__name__}: {e}"[:400]
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+        if collective and use_dist:
+            state["kick"] = time.monotonic()
+            f = host_tensor([0 if err else 1], torch.int32)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            if not bool(f.item()):
+                dist_ok[0] = False
+                err = err or "failed on another rank"
+                res = None
+        if err:
+            leg_errors[name] = err
+        state["kick"] = time.monotonic()
+        return res
+
     steps, warmup = args.steps, args.warmup
-    total_steps = steps + warmup
     mode = args.mode
     shard_world = loop_world or world                  # ranks a sharded step is laid out for
 
@@ -303,15 +420,14 @@ def main():
     global_interval = INTERVAL * world if mode == "sliced-weak" else INTERVAL
     sb, sc = slot_shard(S, rank if not loop_world else 0, shard_world)
 
-    os.environ["HULK_BATCH"] = str(BATCH)
     stream = torch.cuda.Stream(device=device)          # the work stream (the library flushes and exchanges on its own second one)
     torch.cuda.set_stream(stream)
 
-    def make_input(m, max_buf):
+    def make_input(m, max_buf, n_total_steps=None):
         """this rank's share of every step under mode `m`, resident in HBM: (buffers, offsets, reads per spectrum, reads per
         step of this rank, mode) — `sharded`: its whole intervals of the step (distributed.step_share), `sliced-*`: its slice
         of every interval (distributed.interval_slice) — so an N-rank run sketches the same global stream as ONE rank"""
-        nb = min(total_steps, max_buf)        # distinct steps kept in HBM (reused cyclically beyond that)
+        nb = min(n_total_steps or (steps + warmup), max_buf)        # distinct steps kept in HBM (reused cyclically beyond that)
         per, n_step, _ = share(m)
         bufs = []
         for s_ in range(nb):
@@ -385,16 +501,20 @@ def main():
         sk.comm_init_host(rank, world, gloo_exchange(dist, host_group[0]))
         return sk
 
-    def run_pass(prune, inp=None, brackets=1):
+    def run_pass(prune, inp=None, brackets=0, serial=False, n_steps=None):
         """warm-up + the timed K steps on a fresh context; prune=False disables the exact bounds of the CWS stage
-        (HULK_FLAG_NO_PRUNE), so that every interval streams the whole table like the reference does."""
+        (HULK_FLAG_NO_PRUNE), so that every interval streams the whole table like the reference does; serial=True puts the
+        flush on the work stream and bins a batch in one piece (HULK_FLAG_NO_OVERLAP: every kernel alone); brackets: the
+        hulk_set_profiling mask of the timed steps (0 = none)."""
         bufs, offs, per, n_step, in_mode = inp if inp is not None else main_input
+        k_steps = n_steps or steps
         comm = use_dist or loop_world
         sharded = comm and in_mode == "sharded"
+        flags = (0 if prune else _lib.HULK_FLAG_NO_PRUNE) | (_lib.HULK_FLAG_NO_OVERLAP if serial else 0)
         def make():
             return hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL if sharded else 0, decay_ratio=1.0, device=dev_index,
-                                        slot_begin=sb, slot_count=sc, stream=stream.cuda_stream,
-                                        flags=0 if prune else _lib.HULK_FLAG_NO_PRUNE)
+                                        slot_begin=sb, slot_count=sc, stream=stream.cuda_stream, flags=flags, batch=BATCH,
+                                        bin_pieces=args.pieces)
         sk = make()
         assert sk.batch_size == BATCH
         if comm:
@@ -414,15 +534,16 @@ def main():
             one_step(t)
         sk.synchronize()
         torch.cuda.synchronize()
-        sk.set_profiling(brackets)             # hulk_set_profiling: 1 = all instrumented kernels, 2 = k_minimizer_fast only
+        sk.set_profiling(brackets)             # hulk_set_profiling: 0 none, 1 = all instrumented kernels, else a mask
         tiles0 = sk.scan_stats()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         stamps = []                            # HULK_BENCH_STEPTIMES (diagnosis): 1 = when each call returned, 2 = with a sync per step
-        for t in range(warmup, total_steps):
+        for t in range(warmup, warmup + k_steps):
             one_step(t)
+            state["kick"] = time.monotonic()
             if STEPTIMES:
                 if STEPTIMES == 2:
                     sk.synchronize()
@@ -437,7 +558,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         tiles1 = sk.scan_stats()
-        prof = {k: sk.get_profile(k) for k in ("k_cws_scan", "k_minimizer_fast", "k_jump_bin", "k_jump_left")}
+        prof = {k: sk.get_profile(k) for k in ("k_cws_scan", "k_minimizer_fast", "k_jump_bin", "k_jump_left")} if brackets else {}
         sk.set_profiling(False)
         if use_dist:
             tt = host_tensor([elapsed], torch.float64)
@@ -449,8 +570,8 @@ def main():
         mins, weights = sk.gather_sketch() if (comm and not loop_world) else sk.sketch()
         cstats = sk.comm_stats() if comm else None
         sk.close()
-        return dict(elapsed=elapsed, prof=prof, counters=counters, mins=mins, weights=weights, tiles0=tiles0, tiles1=tiles1,
-                    comm=cstats)
+        return dict(elapsed=elapsed, steps=k_steps, prof=prof, counters=counters, mins=mins, weights=weights, tiles0=tiles0,
+                    tiles1=tiles1, comm=cstats)
 
     def run_cold():
         """C2 exactly as BASELINE.json states it: 10 M reads, interval 100k, through the interval rule of
@@ -467,7 +588,8 @@ def main():
         runs = []
         for _ in range(2):            # two complete cold runs, each on its own fresh context; the faster one is reported (both
             t0 = time.perf_counter()  # listed): the timed region is 7 ms, and one host hiccup on a shared box is 100x that
-            sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=dev_index, stream=stream.cuda_stream)
+            sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=dev_index, stream=stream.cuda_stream,
+                                      batch=BATCH, bin_pieces=args.pieces)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for b, off, n in chunks:
@@ -482,6 +604,63 @@ def main():
         best = min(runs)
         return {"value_cold": C2_READS / best[0], "cold_seconds": best[0], "cold_create_seconds": best[1],
                 "cold_seconds_all_runs": [r[0] for r in runs], "cold_reads": C2_READS, "cold_sketch_md5": best[2]}
+
+    def run_c3():
+        """BASELINE configs[2] ("C3") on an HBM-resident sample: k = 31, sketchSize = 1024, concept drift on (decay 0.02),
+        interval 100k — 22.7 GB of fp64 CWS tables + 3.8 GB of K; one warm-up batch, then C3["reads"] reads through the
+        interval rule of hulk_add_reads_device, HIP events on the work stream; then the same again with every kernel alone
+        and k_minimizer_fast / k_cmsd_freq (the count-min replay with decay, countmin.go:141-147) bracketed."""
+        k3, w3, S3, I3 = C3["k"], C3["w"], C3["S"], C3["interval"]
+        stp = I3 * BATCH
+        nbuf = min(4, (C3["reads"] + stp - 1) // stp)
+        bufs = [synth.reads_torch(s_ * stp, stp, READ_LEN, device=device) for s_ in range(nbuf)]
+        torch.cuda.synchronize()
+        res = {"workload": f"C3: synthetic 150bp reads, k={k3}, w={w3}, sketchSize={S3}, decay {C3['decay']} (concept drift), "
+                           f"interval={I3}, {BATCH} intervals per batch, HBM-resident input, {C3['reads']} reads timed after one "
+                           "warm-up batch (BASELINE states 50 M: tests/test_gpu_fullsize.py::test_c3_full_size_50m_reads)"}
+        for label, serial in (("overlapped", False), ("kernels_alone", True)):
+            t0 = time.perf_counter()
+            sk = hulk_amd.GpuSketcher(k3, w3, S3, interval=I3, decay_ratio=C3["decay"], device=dev_index, stream=stream.cuda_stream,
+                                      batch=BATCH, bin_pieces=args.pieces, flags=_lib.HULK_FLAG_NO_OVERLAP if serial else 0)
+            torch.cuda.synchronize()
+            create_s = time.perf_counter() - t0
+            b, o = bufs[0]
+            sk.add_reads_device(b.data_ptr(), o.data_ptr(), stp, READ_LEN, b.numel())
+            sk.synchronize(); torch.cuda.synchronize()
+            if serial:
+                sk.set_profiling(2 | 4 | 16)
+            state["kick"] = time.monotonic()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            done, i = 0, 1
+            while done < C3["reads"]:
+                b, o = bufs[i % nbuf]
+                sk.add_reads_device(b.data_ptr(), o.data_ptr(), stp, READ_LEN, b.numel())
+                done += stp; i += 1
+            sk.synchronize()
+            e1.record(stream); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            if serial:
+                pr = {kk: sk.get_profile(kk) for kk in ("k_minimizer_fast", "k_jump_bin", "k_jump_left", "k_cmsd_freq")}
+                res["kernels_alone"] = {"ms_per_batch": ms / (done / stp), "reads_per_s": done / ms * 1e3,
+                                        **{kk + "_us": (v[1] / max(v[0], 1)) * 1e3 for kk, v in pr.items()},
+                                        "note": "HULK_FLAG_NO_OVERLAP: one stream, one piece per batch, per launch of a 16-interval batch"}
+                sk.set_profiling(0)
+            else:
+                res.update({"value": done / ms * 1e3, "unit": "reads/s", "reads": done, "ms_per_batch": ms / (done / stp),
+                            "create_seconds": create_s})
+            tiles = sk.scan_stats()
+            sk.finish()
+            mins, wts = sk.sketch()
+            if not serial:
+                res.update({"scan_tiles_read": tiles[0], "scan_tiles_covered": tiles[1], "negative_weights": int((wts < 0).sum()),
+                            "sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()})
+            else:
+                res["kernels_alone"]["sketch_md5"] = hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()
+            sk.close()
+            torch.cuda.empty_cache()
+        assert res["sketch_md5"] == res["kernels_alone"]["sketch_md5"], "C3: the one-stream run disagrees"
+        return res
 
     def run_c4():
         """BASELINE configs[3] ("C4"), scaled to the ranks present: C4_READS_PER_RANK (50 M) x N reads of the global stream
@@ -500,13 +679,14 @@ def main():
         t0 = time.perf_counter()
         def make():
             return hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=dev_index, slot_begin=sb,
-                                        slot_count=sc, stream=stream.cuda_stream)
+                                        slot_count=sc, stream=stream.cuda_stream, batch=BATCH, bin_pieces=args.pieces)
         sk = connect(make(), make)
         torch.cuda.synchronize()
         dist.barrier()
         t1 = time.perf_counter()
         for b, off, n, si in chunks:
             sk.step_sharded(b.data_ptr(), off.data_ptr(), n, READ_LEN, b.numel(), si)
+            state["kick"] = time.monotonic()
         sk.finish()
         mins, _ = sk.gather_sketch()
         torch.cuda.synchronize()
@@ -525,13 +705,13 @@ def main():
                                "clock stopped after the EOF gather",
                 "c4_exchange": cs, "c4_sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()}
 
-    # The first pass of a process measures ~7 % low whatever runs before it short of a pass itself (1.08 vs 1.00-1.01 ms per
-    # step, HULK_BENCH_REPEAT below; 40 untimed steps on a throwaway context do not help, a whole discarded pass does: the
-    # transient is worth ~1.5 ms at the start of the first context that is timed, profiled and finished).  So one pass is
-    # run and discarded before the timed ones; neither timed pass then depends on being the second.
-    # (Round 3: it is the clock ramp of a GPU leaving idle — HULK_BENCH_STEPTIMES=2 shows the first pass descending from 1.25 to
-    # 1.11 ms per synchronised step over its 20 steps, later passes from 1.17 over their first 15)
+    # ------------------------------------------------------------------------------------------------------------------
+    # The first pass of a process measures ~7 % low whatever runs before it short of a pass itself: it is the clock ramp of a
+    # GPU leaving idle (HULK_BENCH_STEPTIMES=2 shows the first pass descending from 1.25 to 1.11 ms per synchronised step over
+    # its 20 steps, later passes from 1.17 over their first 15; profiles/r03_firstpass_steps.txt).  So one pass is run and
+    # discarded before the timed one ...
     run_pass(not args.no_prune)
+    state["kick"] = time.monotonic()
     # ... and PREWARM_S seconds of discarded passes on top: on a box whose GPU has been idle (a fresh lease) the first process
     # otherwise measures 2-4 % below the ones after it (1.025 vs 0.988 ms per step; with 3 s of load first: 1.000 vs 0.990)
     t_pw = time.perf_counter() + PREWARM_S
@@ -546,60 +726,87 @@ def main():
 
     while more_prewarm():
         run_pass(not args.no_prune)
-    single = args.single_pass or args.no_prune
-    full = run_pass(False, brackets=2) if not single else None
+        state["kick"] = time.monotonic()
     if os.environ.get("HULK_BENCH_REPEAT"):           # diagnosis: the same pass several times, ms per step of each on stderr
         for i in range(int(os.environ["HULK_BENCH_REPEAT"])):
             r = run_pass(not args.no_prune)
-            sys.stderr.write(f"repeat {i}: {r['elapsed'] / steps * 1e3:.4f} ms/step, k1a {r['prof']['k_minimizer_fast'][1] / max(r['prof']['k_minimizer_fast'][0], 1) * 1e3:.1f} us\n")
-    # The timed pass brackets only the dominant kernel (the launch durations the `roofline` object needs, measured over the
-    # timed region): every bracket costs the stream two event records — k_minimizer_fast's 2 % of a step, all
-    # instrumented kernels 3.2 % (per-step timings in DESIGN.md §6).  The figures of the other kernels come from
-    # one more pass of the same steps, after the timed one.
-    main_pass = run_pass(not args.no_prune, brackets=2)
-    instr_pass = run_pass(not args.no_prune, brackets=1)
-    elapsed, prof, counters = main_pass["elapsed"], main_pass["prof"], main_pass["counters"]
+            sys.stderr.write(f"repeat {i}: {r['elapsed'] / steps * 1e3:.4f} ms/step\n")
+    # ---- the HEADLINE: W warm-up + K timed steps, no event brackets (every bracket costs the stream two event records:
+    # k_minimizer_fast's alone was 2 % of a step)
+    main_pass = run_pass(not args.no_prune, brackets=0)
+    elapsed, counters = main_pass["elapsed"], main_pass["counters"]
     mins, weights = main_pass["mins"], main_pass["weights"]
-    tiles0, tiles1 = instr_pass["tiles0"], instr_pass["tiles1"]
-    prof = dict(prof, k_jump_bin=instr_pass["prof"]["k_jump_bin"], k_jump_left=instr_pass["prof"]["k_jump_left"],
-                k_cws_scan=instr_pass["prof"]["k_cws_scan"])
-    if full is not None and rank == 0:
-        assert np.array_equal(full["mins"], mins) and np.array_equal(full["weights"], weights), "pruning changed the sketch"
-    plain_single = world == 1 and rank == 0 and not use_dist and not loop_world
-    cold = run_cold() if (plain_single and not args.no_cold) else None
-    # N > 1: the same K steps under the other modes too, so one driver run yields all of them
-    other = None
-    c4 = None
-    if use_dist and not args.single_pass and not args.no_prune:      # (world 1 only with --force-collective: a test of this path)
-        other = []
-        del main_input[0][:]
-        torch.cuda.empty_cache()
-        for om in ("sharded", "sliced-strong", "sliced-weak"):
-            if om == mode:
-                continue
-            oin = make_input(om, 8)
-            op = run_pass(True, oin, brackets=2)
-            other.append({"mode": om, "value": steps * share(om)[2] / op["elapsed"], "ms_per_step": op["elapsed"] / steps * 1e3,
-                          "reads_per_rank_step": oin[3], "reads_per_step": share(om)[2],
-                          "sketch_md5": hashlib.md5(op["mins"].astype("<u8").tobytes()).hexdigest(), "exchange": op["comm"]})
-            del oin[0][:]
-            torch.cuda.empty_cache()
-        if not args.no_c4:
-            c4 = run_c4()
+    total_reads = steps * reads_per_step
+    value = total_reads / elapsed
+    scaling = "strong" if mode == "sliced-strong" else "weak"
+    comm_desc = None
+    if use_dist or loop_world:
+        how = ("loopback stand-in (no peers)" if loop_world else
+               f"host transport over gloo (RCCL unavailable: {rccl_error[0]})" if rccl_error[0] else
+               "RCCL (ncclAllGather / ncclAllReduce, bound by hulk_comm_init)" if transport == "rccl" else
+               "host transport over gloo (test aid: all ranks on GPU 0)")
+        what = ("one all-gather per step: k-mer spectra while an element can still lower a weight, count-min increments after"
+                if mode == "sharded" else "one all-reduce (uint32 sum) of the step's spectra")
+        comm_desc = {"inside": "libhulkhip.so (hulk_step_sharded / hulk_step_sliced)", "transport": how, "per_step": what,
+                     "timed_pass": main_pass["comm"]}
+    out.update({
+        "metric": "reads/sec (150bp, k=21, sketch=512)", "value": value, "unit": "reads/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "C2: synthetic 150bp reads, k=21, w=9, sketchSize=512, "
+                               f"interval={global_interval} reads of the global stream, "
+                               f"{BATCH} intervals per rank and step ({reads_per_rank_step} reads; {reads_per_step} of the "
+                               "global stream per step), HBM-resident input"
+                               + (f", LOOPBACK: rank 0's share of a {loop_world}-rank sharded step, no peers" if loop_world else "")
+                               + (", CWS-scan bounds OFF (--no-prune)" if args.no_prune else "")
+                               + (f", VARIANT: {args.n_frac:g} of the reads carry one N" if args.n_frac > 0 else ""),
+                   "reads_per_step": reads_per_step, "reads_per_rank_step": reads_per_rank_step,
+                   "total_reads": total_reads, "intervals_per_step": BATCH, "global_interval": global_interval,
+                   "mode": mode, "bin_pieces": args.pieces or "library default (4)",
+                   "split": ("whole intervals per rank" if mode == "sharded" else "a slice of every interval per rank"),
+                   "parallelism": f"read-shard x{world}, replicated count-min, slot-sharded CWS"},
+        "scaling_note": ("per-rank work per step is fixed (16 whole intervals = 1.6 M reads), the global interval stays the "
+                         "reference's 100k reads: the sketch is the single-GPU sketch of the same (N times longer) stream"
+                         if mode == "sharded" else "total work per step fixed" if mode == "sliced-strong" else
+                         "per-rank work fixed, global interval N x 100k: another sketch than C2's"),
+        "rccl_ranks": rccl_ranks, "prewarm_seconds": PREWARM_S,
+        "collective": comm_desc,
+        "roofline": None,          # (filled by the `kernels` leg)
+        "sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest(),
+        "n_minimizers_rank0": counters["n_minimizers"],
+        "timed_pass_note": "no HIP-event brackets in the timed steps; a batch is binned in pieces on two work streams and flushed "
+                           "on a third (the library's default); per-kernel durations: the `kernels` leg",
+    })
+    # SURVEY.md §8(d) prices the path at L + 4*S*k^4/I bytes per read (one K pass per interval): a MODEL of the
+    # reference's data movement, not traffic this implementation generates (one K pass serves BATCH intervals and
+    # the exact bounds skip most of it) — kept for comparison with the survey's 1.94e9 reads/s/GPU figure only.
+    model_bytes = READ_LEN + 4.0 * S * (K ** 4) / global_interval
+    out["survey_model"] = {"bytes_per_read": model_bytes, "reads_per_s_at_hbm_peak": HBM_PEAK_GBS * 1e9 * world / model_bytes,
+                           "value_over_model": value * model_bytes / 1e9 / (HBM_PEAK_GBS * world)}
+    state["headline_done"] = True
 
-    if rank == 0:
-        total_reads = steps * reads_per_step
-        value = total_reads / elapsed
+    # ---- leg `kernels`: the same steps, every kernel alone (one stream, one piece per batch) and bracketed by HIP events on
+    # the stream it runs on: the launch durations the roofline objects are computed from
+    instr_pass = run_leg("kernels", lambda: run_pass(not args.no_prune, brackets=1, serial=True), collective=True)
+
+    def add_rooflines():
         pmc = {}
         try:
             pmc = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
+        except Exception:
+            pass
+        isa_mix = {}
+        try:
+            isa_mix = json.load(open(os.path.join(ROOT, ISA_MIX)))
         except Exception:
             pass
 
         def from_profile(kernel, key):
             return pmc.get(kernel, {}).get(key) if world == 1 else None
 
-        # Per-launch durations measured live with HIP events on the stream each kernel is launched on (hulk_set_profiling).
+        prof = instr_pass["prof"]
+        tiles0, tiles1 = instr_pass["tiles0"], instr_pass["tiles1"]
         # Dominant kernel by time = k_minimizer_fast (K1a: bases -> distinct minimizers per read).  Its algorithmic
         # bytes are SURVEY.md §8(d)'s per-read figure for the bin side, L + 8 (one ASCII byte per base + the read's
         # offset), x the reads of one launch.  The minimizer list it hands to k_jump_bin (8 B value + 1 B spectrum slot
@@ -614,36 +821,19 @@ def main():
         n_kl, kl_ms = prof["k_jump_left"]
         kl_avg_s = (kl_ms / 1e3) / max(n_kl, 1)
         longest = "k_minimizer_fast" if k1_avg_s >= kj_avg_s else "k_jump_bin"
-        scaling = "strong" if mode == "sliced-strong" else "weak"
-        comm_desc = None
-        if use_dist or loop_world:
-            how = ("loopback stand-in (no peers)" if loop_world else
-                   f"host transport over gloo (RCCL unavailable: {rccl_error[0]})" if rccl_error[0] else
-                   "RCCL (ncclAllGather / ncclAllReduce, bound by hulk_comm_init)" if transport == "rccl" else
-                   "host transport over gloo (test aid: all ranks on GPU 0)")
-            what = ("one all-gather per step: k-mer spectra while an element can still lower a weight, count-min increments after"
-                    if mode == "sharded" else "one all-reduce (uint32 sum) of the step's spectra")
-            comm_desc = {"inside": "libhulkhip.so (hulk_step_sharded / hulk_step_sliced)", "transport": how, "per_step": what,
-                         "timed_pass": main_pass["comm"]}
-
-        isa_mix = {}
-        try:
-            isa_mix = json.load(open(os.path.join(ROOT, ISA_MIX)))
-        except Exception:
-            pass
 
         def valu_roofline(kernel, avg_s):
             """VALU-issue roofline of a launch.  SQ_INSTS_VALU (wave64 VALU instructions per launch) comes from the rocprofv3 PMC
-            pass of this command (profiles/r03_pmc.json); what an instruction costs was measured two independent ways
+            pass of this command (PMC_PROFILE); what an instruction costs was measured two independent ways
             (profiles/r03_op_cost.txt: whole launches by HIP events at the nominal clock, tools/ubench/op_cost.hip; every wave
             timing its own block with s_memtime — shader-clock ticks — grouped by the SIMD it ran on, op_cost2.hip):
             simple VOP2 ops (v_add/sub_u32, v_and/or/xor_b32, v_mov_b32, v_lshrrev_b32, v_mul/add_f32) issue in 2.35 cycles,
             everything else these kernels use (VOP3 integer ops, v_lshlrev_b32, min/max, DPP, cmp/cndmask, every 64-bit, fp64
             and packed op) in 4.4, v_rcp_f64 in 16.5.  MI355X_MICROARCH.md's 2 cycles is the first class only.
             floor_us      = SQ_INSTS_VALU / 1024 SIMDs x 2 cycles / 2.4 GHz   (every instruction priced as the fast class at the
-                            nominal clock: an optimistic bound, kept for comparison with round 2)
+                            nominal clock: an optimistic bound)
             floor_us_mix  = SQ_INSTS_VALU x (mean cycles of the kernel's own static instruction mix, tools/isa_mix.py ->
-                            profiles/r03_isa_mix.json) / 1024 / the measured shader clock under load (2.3 GHz)
+                            ISA_MIX) / 1024 / the measured shader clock under load (2.3 GHz)
             frac / frac_mix = floor / the launch duration measured live in this run."""
             insts = from_profile(kernel, "SQ_INSTS_VALU")
             if not insts or avg_s <= 0:
@@ -678,29 +868,7 @@ def main():
         alg_bytes = visited * 8 * 256 * 4.0 + 4.0 * BATCH * (K ** 4) + 4.0 * sc * wtiles + 8.0 * BATCH * wtiles
         avg_s = (scan_ms / 1e3) / max(n_launch, 1)
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        out = {
-            "metric": "reads/sec (150bp, k=21, sketch=512)", "value": value, "unit": "reads/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2: synthetic 150bp reads, k=21, w=9, sketchSize=512, "
-                                   f"interval={global_interval} reads of the global stream, "
-                                   f"{BATCH} intervals per rank and step ({reads_per_rank_step} reads; {reads_per_step} of the "
-                                   "global stream per step), HBM-resident input"
-                                   + (f", LOOPBACK: rank 0's share of a {loop_world}-rank sharded step, no peers" if loop_world else "")
-                                   + (", CWS-scan bounds OFF (--no-prune)" if args.no_prune else "")
-                                   + (f", VARIANT: {args.n_frac:g} of the reads carry one N" if args.n_frac > 0 else ""),
-                       "reads_per_step": reads_per_step, "reads_per_rank_step": reads_per_rank_step,
-                       "total_reads": total_reads, "intervals_per_step": BATCH, "global_interval": global_interval,
-                       "mode": mode,
-                       "split": ("whole intervals per rank" if mode == "sharded" else "a slice of every interval per rank"),
-                       "parallelism": f"read-shard x{world}, replicated count-min, slot-sharded CWS"},
-            "scaling_note": ("per-rank work per step is fixed (16 whole intervals = 1.6 M reads), the global interval stays the "
-                             "reference's 100k reads: the sketch is the single-GPU sketch of the same (N times longer) stream"
-                             if mode == "sharded" else "total work per step fixed" if mode == "sliced-strong" else
-                             "per-rank work fixed, global interval N x 100k: another sketch than C2's"),
-            "rccl_ranks": rccl_ranks, "prewarm_seconds": PREWARM_S,
-            "collective": comm_desc,
+        out.update({
             "roofline": {"bound": "hbm", "kernel": "k_minimizer_fast", "achieved": k1_ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_ach / HBM_PEAK_GBS,
                          "traffic": None, "traffic_from_profile": from_profile("k_minimizer_fast", "hbm_bytes_per_launch"),
@@ -709,18 +877,24 @@ def main():
                          "alg_bytes_per_launch": k1_bytes, "alg_bytes_per_read": READ_LEN + 8,
                          "intermediate_bytes": float(reads_per_rank_step) * 9.0 * per_read_min,
                          "longest_kernel": longest,
+                         "durations_from": "the `kernels` leg: the timed steps repeated on a fresh context with "
+                                           "HULK_FLAG_NO_OVERLAP (one stream, a batch binned in ONE piece: every kernel runs "
+                                           "alone) and every instrumented kernel bracketed by HIP events on the stream it is "
+                                           "launched on — the headline pass itself carries no brackets and overlaps its kernels, "
+                                           "which stretches each kernel's own duration; rocprofv3 of HULK_NO_OVERLAP=1 bench.py "
+                                           "(profiles/r04_kernel_stats_serial.md) shows the same per-launch figures",
                          "note": f"single kernels by measured time: k_minimizer_fast {k1_avg_s * 1e6:.1f} us, k_jump_bin "
-                                 f"{kj_avg_s * 1e6:.1f} us, k_jump_left {kl_avg_s * 1e6:.1f} us per launch (stage K1b = the last "
-                                 "two; it has no SURVEY 8(d) bytes — the minimizer list is an artefact of this implementation, "
-                                 "see intermediate_bytes).  Both stages are bound by VALU issue, not by HBM (roofline_valu, "
-                                 "roofline_valu_jump): the fraction of the HBM peak is small by construction"},
+                                 f"{kj_avg_s * 1e6:.1f} us, k_jump_left {kl_avg_s * 1e6:.1f} us per launch of {reads_per_rank_step} reads "
+                                 "(stage K1b = the last two; it has no SURVEY 8(d) bytes — the minimizer list is an artefact of "
+                                 "this implementation, see intermediate_bytes).  Both stages are bound by VALU issue, not by HBM "
+                                 "(roofline_valu, roofline_valu_jump): the fraction of the HBM peak is small by construction"},
             "roofline_valu": valu_roofline("k_minimizer_fast", k1_avg_s),
             "roofline_valu_jump": valu_roofline("k_jump_bin", kj_avg_s),
             "k_jump_bin": {"launches": int(n_kj), "avg_launch_us": kj_avg_s * 1e6,
-                           "note": "jump hash of the minimizer list, alone; bracketed in a separate pass of the same steps "
-                                   "after the timed one (as k_jump_left and k_cws_scan)"},
+                           "note": "jump hash of the minimizer list, alone (the `kernels` leg)"},
             "k_jump_left": {"launches": int(n_kl), "avg_launch_us": kl_avg_s * 1e6,
                             "note": "the chains k_jump_bin handed over (at most 10 lanes of a round still running)"},
+            "ms_per_step_kernels_alone": instr_pass["elapsed"] / instr_pass["steps"] * 1e3,
             "roofline_cws_scan": {"bound": "hbm", "kernel": "k_cws_scan", "achieved": achieved,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                   "traffic": None, "traffic_from_profile": from_profile("k_cws_scan", "hbm_bytes_per_launch"),
@@ -732,38 +906,98 @@ def main():
                                           "out every slot skips the estimates/scan/resolve, otherwise only tiles whose "
                                           "lower bound can beat a slot's current weight are read (identical sketch; "
                                           "--no-prune / HULK_FLAG_NO_PRUNE disables both = value_unpruned)"},
-            "sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest(),
-            # same K steps with the exact pruning of the CWS scan switched off: every interval streams the whole
-            # table, as the reference's algorithm does (sketch asserted identical)
-            "value_unpruned": (total_reads / full["elapsed"]) if full is not None else (value if args.no_prune else None),
-            "ms_per_step_unpruned": (full["elapsed"] / steps * 1e3) if full is not None else None,
-            "n_minimizers_rank0": counters["n_minimizers"],
-        }
-        # SURVEY.md §8(d) prices the path at L + 4*S*k^4/I bytes per read (one K pass per interval): a MODEL of the
-        # reference's data movement, not traffic this implementation generates (one K pass serves BATCH intervals and
-        # the exact bounds skip most of it) — kept for comparison with the survey's 1.94e9 reads/s/GPU figure only.
-        model_bytes = READ_LEN + 4.0 * S * (K ** 4) / global_interval
-        out["survey_model"] = {"bytes_per_read": model_bytes, "reads_per_s_at_hbm_peak": HBM_PEAK_GBS * 1e9 * world / model_bytes,
-                               "value_over_model": value * model_bytes / 1e9 / (HBM_PEAK_GBS * world)}
-        if cold is not None:
+        })
+        if rank == 0:
+            assert np.array_equal(instr_pass["mins"], mins) and np.array_equal(instr_pass["weights"], weights), \
+                "the one-stream pass computed another sketch than the timed one"
+
+    if instr_pass is not None and rank == 0:
+        run_leg("rooflines", add_rooflines)
+
+    single = args.single_pass or args.no_prune
+    plain_single = world == 1 and not use_dist and not loop_world
+    # ---- leg `unpruned`: the same K steps with the exact pruning of the CWS scan switched off: every interval streams the
+    # whole table, as the reference's algorithm does (sketch asserted identical)
+    if not single:
+        def unpruned():
+            full = run_pass(False, brackets=0)
+            if rank == 0:
+                assert np.array_equal(full["mins"], mins) and np.array_equal(full["weights"], weights), "pruning changed the sketch"
+            out["value_unpruned"] = total_reads / full["elapsed"]
+            out["ms_per_step_unpruned"] = full["elapsed"] / steps * 1e3
+        run_leg("unpruned", unpruned, collective=True)
+    elif args.no_prune:
+        out["value_unpruned"] = value
+    # ---- leg `long`: the timed pass again with >= 200 steps (the 20 steps of the headline still carry the tail of the clock
+    # ramp of their own pass: --steps 20 / 100 / 400 gave 0.9946 / 0.9863 / 0.9842 ms per step in round 3)
+    if not single and not args.no_long and LONG_STEPS > steps:
+        def long_pass():
+            lp = run_pass(not args.no_prune, brackets=0, n_steps=LONG_STEPS)
+            out["ms_per_step_long"] = lp["elapsed"] / LONG_STEPS * 1e3
+            out["value_long"] = LONG_STEPS * reads_per_step / lp["elapsed"]
+            out["steps_long"] = LONG_STEPS
+            if rank == 0:
+                # (LONG_STEPS steps cycle through the same 22 distinct step buffers: another stream than the headline's, so
+                #  only the counters are compared)
+                assert lp["counters"]["n_reads"] == (LONG_STEPS + warmup) * reads_per_rank_step
+        run_leg("long", long_pass, collective=True)
+    if plain_single and not args.no_cold:
+        cold = run_leg("cold", run_cold)
+        if cold:
             out.update(cold)
-        if other is not None:
-            out["other_scaling"] = other
-        if c4 is not None:
-            out.update(c4)
-        if plain_single and not args.no_e2e:
-            out["e2e"] = e2e_file_rates()
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
-            if cold is not None:
-                out["speedup_vs_cpu_cold"] = cold["value_cold"] / out["cpu_baseline"]["value"]
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
+    # N > 1: the same K steps under the other modes too, so one driver run yields all of them
+    if use_dist and not single:      # (world 1 only with --force-collective: a test of this path)
+        other = []
+        del main_input[0][:]
+        torch.cuda.empty_cache()
+        for om in ("sharded", "sliced-strong", "sliced-weak"):
+            if om == mode:
+                continue
+
+            def other_mode(om=om):
+                oin = make_input(om, 8)
+                op = run_pass(True, oin, brackets=0)
+                other.append({"mode": om, "value": steps * share(om)[2] / op["elapsed"], "ms_per_step": op["elapsed"] / steps * 1e3,
+                              "reads_per_rank_step": oin[3], "reads_per_step": share(om)[2],
+                              "sketch_md5": hashlib.md5(op["mins"].astype("<u8").tobytes()).hexdigest(), "exchange": op["comm"]})
+                del oin[0][:]
+                torch.cuda.empty_cache()
+            run_leg("other_scaling_" + om, other_mode, collective=True)
+        out["other_scaling"] = other
+        if not args.no_c4:
+            c4 = run_leg("c4", run_c4, collective=True)
+            if c4:
+                out.update(c4)
+    if plain_single and not args.no_c3:
+        del main_input[0][:]
+        torch.cuda.empty_cache()
+        c3 = run_leg("c3", run_c3)
+        if c3:
+            out["c3"] = c3
+    if plain_single and rank == 0 and not args.no_c5:
+        c5 = run_leg("c5", c5_leg)
+        if c5:
+            out["c5"] = c5
+    if plain_single and rank == 0 and not args.no_e2e:
+        e2e = run_leg("e2e", e2e_file_rates)
+        if e2e:
+            out["e2e"] = e2e
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cb = run_leg("cpu_baseline", cpu_baseline)
+        if cb:
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu"] = value / cb["value"]
+            if out.get("value_cold"):
+                out["speedup_vs_cpu_cold"] = out["value_cold"] / cb["value"]
+    for name, err in leg_errors.items():
+        out[f"{name}_error"] = err
+    state["leg"], state["kick"] = "exit", time.monotonic()
+    print_line()
     if use_dist:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:             # noqa: BLE001 — the line is out; a rank that left a collective early must not turn that into rc != 0
+            pass
 
 
 if __name__ == "__main__":

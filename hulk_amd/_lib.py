@@ -15,12 +15,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhulkhip.so")
 
 HULK_OK = 0
-HULK_ABI_VERSION = 2            # include/hulk_hip.h; load() refuses a libhulkhip.so built from another version of the header
+HULK_ABI_VERSION = 3            # include/hulk_hip.h; load() refuses a libhulkhip.so built from another version of the header
 HULK_UNIQUE_ID_BYTES = 128
 HULK_XCHG_ALLGATHER, HULK_XCHG_ALLREDUCE_U32 = 0, 1
 HULK_CWS_GO_COMPAT = 0
 HULK_CWS_EXTERNAL = 1
-HULK_FLAG_GAMMA_CPYTHON, HULK_FLAG_NO_PRUNE, HULK_FLAG_NO_SKIP = 1, 2, 4
+HULK_FLAG_GAMMA_CPYTHON, HULK_FLAG_NO_PRUNE, HULK_FLAG_NO_SKIP, HULK_FLAG_SHARD_FULL, HULK_FLAG_NO_OVERLAP = 1, 2, 4, 8, 16
 HULK_MAX_BINS = 1 << 20
 
 # every symbol include/hulk_hip.h declares (tests check the .so exports all of them)
@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "hulk_set_stream", "hulk_set_private_stream", "hulk_set_cws_tables", "hulk_add_reads", "hulk_add_reads_device",
     "hulk_batch_size", "hulk_bin_reads_device", "hulk_bin_reads_device_at", "hulk_histogram_device", "hulk_flush_batch", "hulk_flush_batch_after", "hulk_add_histogram", "hulk_flush",
     "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
-    "hulk_get_cws_tables", "hulk_smash", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
+    "hulk_get_cws_tables", "hulk_smash", "hulk_smash_ex", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
     "hulk_parse_files", "hulk_sketch_files", "hulk_get_scan_stats", "hulk_synchronize",
     "hulk_comm_unique_id", "hulk_comm_init", "hulk_comm_init_host", "hulk_comm_init_loopback", "hulk_step_sharded", "hulk_step_sharded_host",
     "hulk_step_sliced", "hulk_gather_sketch", "hulk_get_comm_stats",
@@ -42,7 +42,8 @@ class HulkParams(ctypes.Structure):
         ("num_bins", ctypes.c_int32), ("decay_ratio", ctypes.c_double),
         ("interval", ctypes.c_uint32), ("device", ctypes.c_int32),
         ("slot_begin", ctypes.c_uint32), ("slot_count", ctypes.c_uint32),
-        ("cws_source", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 4),
+        ("cws_source", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("batch", ctypes.c_uint32), ("bin_pieces", ctypes.c_uint32),
+        ("host_copy_threads", ctypes.c_uint32), ("bin_min_reads", ctypes.c_uint32),
     ]
 
 
@@ -187,6 +188,7 @@ def load():
     L.hulk_get_cms.restype = ctypes.c_int; L.hulk_get_cms.argtypes = [vp, vp]
     L.hulk_get_cws_tables.restype = ctypes.c_int; L.hulk_get_cws_tables.argtypes = [vp, vp, vp, vp]
     L.hulk_smash.restype = ctypes.c_int; L.hulk_smash.argtypes = [ctypes.c_int, vp, vp, u32, u32, ctypes.c_int, vp]
+    L.hulk_smash_ex.restype = ctypes.c_int; L.hulk_smash_ex.argtypes = [ctypes.c_int, vp, vp, u32, u32, ctypes.c_int, vp, vp]
     L.hulk_selftest_reciprocal.restype = ctypes.c_int; L.hulk_selftest_reciprocal.argtypes = [vp, vp]
     L.hulk_set_profiling.restype = ctypes.c_int; L.hulk_set_profiling.argtypes = [vp, ctypes.c_int]
     L.hulk_get_profile.restype = ctypes.c_int; L.hulk_get_profile.argtypes = [vp, ctypes.c_char_p, vp, vp]

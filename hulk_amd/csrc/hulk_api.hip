@@ -68,7 +68,7 @@ int hulk_abi_version(void) { return HULK_ABI_VERSION; }
 #ifndef HULK_HIPCC_VERSION
 #define HULK_HIPCC_VERSION "unknown"
 #endif
-const char *hulk_build_info(void) { return "abi=2 arch=gfx950 sources=" HULK_SOURCE_HASH " hipcc=" HULK_HIPCC_VERSION; }
+const char *hulk_build_info(void) { return "abi=3 arch=gfx950 sources=" HULK_SOURCE_HASH " hipcc=" HULK_HIPCC_VERSION; }
 const char *hulk_strerror(int status) { return err_text(status); }
 const char *hulk_last_error(const hulk_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
 
@@ -89,7 +89,11 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     // the binning kernels pack (spectrum slot << 20 | bin) into a dword (hulk_spectrum.hip); k^4 <= 31^4 < 2^20
     if (bins > (int64_t)HULK_MAX_BINS)
         return fail(nullptr, HULK_ERR_ARG, "num_bins " + std::to_string(bins) + " exceeds HULK_MAX_BINS (2^20; k^4 at k = 31 is 923521)");
-    if (p.flags & ~(HULK_FLAG_GAMMA_CPYTHON | HULK_FLAG_NO_PRUNE | HULK_FLAG_NO_SKIP)) return fail(nullptr, HULK_ERR_ARG, "unknown flags");
+    if (p.flags & ~(HULK_FLAG_GAMMA_CPYTHON | HULK_FLAG_NO_PRUNE | HULK_FLAG_NO_SKIP | HULK_FLAG_SHARD_FULL | HULK_FLAG_NO_OVERLAP))
+        return fail(nullptr, HULK_ERR_ARG, "unknown flags");
+    if (p.batch > (uint32_t)SCAN_BATCH_MAX) return fail(nullptr, HULK_ERR_ARG, "batch must be 0 (default) or 1..16");
+    if (p.bin_pieces > (uint32_t)SCAN_BATCH_MAX) return fail(nullptr, HULK_ERR_ARG, "bin_pieces must be 0 (default) or 1..16");
+    if (p.host_copy_threads > 32) return fail(nullptr, HULK_ERR_ARG, "host_copy_threads must be 0 (default) or 1..32");
     if (p.slot_count == 0) { p.slot_begin = 0; p.slot_count = p.sketch_size; }
     if ((uint64_t)p.slot_begin + p.slot_count > p.sketch_size) return fail(nullptr, HULK_ERR_ARG, "slot shard outside sketch");
     if (p.cws_source > HULK_CWS_EXTERNAL) return fail(nullptr, HULK_ERR_ARG, "cws_source");
@@ -118,7 +122,18 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     c->stream = c->own_stream;
     const size_t B = (size_t)c->B, S = c->S, SL = c->slots;
     CHK_CREATE(dalloc(&c->d_state, 1));
-    if (const char *e = getenv("HULK_BATCH")) { int v = atoi(e); if (v >= 1 && v <= SCAN_BATCH_MAX) c->T = (uint32_t)v; }
+    // (the HULK_* variables read here are overrides for profiling scripts; a host sets the fields)
+    auto knob = [](const char *name, uint32_t field, uint32_t dflt, uint32_t lo, uint32_t hi) {
+        uint32_t v = field ? field : dflt;
+        if (const char *e = getenv(name)) { const long x = atol(e); if (x >= (long)lo && x <= (long)hi) v = (uint32_t)x; }
+        return v;
+    };
+    c->T = knob("HULK_BATCH", p.batch, SCAN_BATCH_MAX, 1, SCAN_BATCH_MAX);
+    c->bin_pieces = knob("HULK_BIN_PIECES", p.bin_pieces, 4, 1, SCAN_BATCH_MAX);
+    c->host_copy_threads = knob("HULK_HOST_COPY_THREADS", p.host_copy_threads, 4, 1, 32);
+    c->bin_min_reads = p.bin_min_reads ? p.bin_min_reads : 65536u;
+    c->no_overlap = (p.flags & HULK_FLAG_NO_OVERLAP) != 0 || getenv("HULK_NO_OVERLAP") != nullptr;
+    c->shard_full = (p.flags & HULK_FLAG_SHARD_FULL) != 0 || getenv("HULK_SHARD_FULL") != nullptr;
     c->ring_n = c->T + 1;
     const size_t T = c->T, RN = c->ring_n;
     CHK_CREATE(dalloc(&c->d_hist, 2 * RN * B));
@@ -135,8 +150,6 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(hipEventCreateWithFlags(&c->ev_flushed[0], hipEventDisableTiming));
     CHK_CREATE(hipEventCreateWithFlags(&c->ev_flushed[1], hipEventDisableTiming));
     CHK_CREATE(dalloc(&c->d_hist_tmp, B));
-    CHK_CREATE(dalloc(&c->d_slow_count, 2));
-    CHK_CREATE(hipMemsetAsync(c->d_slow_count, 0, 8, c->stream));
     CHK_CREATE(dalloc(&c->d_min_slots, (size_t)MIN_SLOTS));
     CHK_CREATE(hipMemsetAsync(c->d_min_slots, 0, (size_t)MIN_SLOTS * 8, c->stream));
     CHK_CREATE(dalloc(&c->d_ctr, (size_t)c->cms_depth * c->cms_width));
@@ -213,8 +226,17 @@ void hulk_destroy(hulk_ctx *c) {
         if (hs.h_off) hipHostFree(hs.h_off);
         hipFree(hs.d_bases); hipFree(hs.d_off);
     }
-    hipFree(c->d_min_slots); hipFree(c->d_slow_list); hipFree(c->d_slow_count);
-    hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum); hipFree(c->ml.partial); hipFree(c->ml.nib); hipFree(c->ml.nib_over); hipFree(c->ml.lo); hipFree(c->ml.lo_cnt); hipFree(c->ml.dmask); hipFree(c->ml.dsum);
+    hipFree(c->d_min_slots);
+    for (auto &ln : c->lane) {
+        if (ln.stream) { hipStreamSynchronize(ln.stream); hipStreamDestroy(ln.stream); }
+        if (ln.ev_k1a) hipEventDestroy(ln.ev_k1a);
+        hipFree(ln.d_slow_list); hipFree(ln.d_slow_count);
+        hulk::MinimizerList &ml = ln.ml;
+        hipFree(ml.x); hipFree(ml.slot); hipFree(ml.key); hipFree(ml.cnt); hipFree(ml.off); hipFree(ml.bsum); hipFree(ml.partial);
+        hipFree(ml.nib); hipFree(ml.nib_over); hipFree(ml.lo); hipFree(ml.lo_cnt); hipFree(ml.dmask); hipFree(ml.dsum);
+    }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);
     comm_teardown(c);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -469,15 +491,16 @@ int hulk_selftest_reciprocal(hulk_ctx *c, uint64_t *mismatches) {
     return HULK_OK;
 }
 
-int hulk_smash(int device, const uint64_t *mins, const double *weights, uint32_t n_sketches, uint32_t sketch_size,
-               int metric, double *distances) {
+int hulk_smash_ex(int device, const uint64_t *mins, const double *weights, uint32_t n_sketches, uint32_t sketch_size,
+                  int metric, double *distances, double *kernel_ms) {
     if (!mins || !weights || !distances) return fail(nullptr, HULK_ERR_ARG, "NULL");
     if (metric != HULK_METRIC_JACCARD && metric != HULK_METRIC_WEIGHTED_JACCARD) return fail(nullptr, HULK_ERR_ARG, "metric");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, HULK_ERR_NO_DEVICE);
     if (device < 0 || device >= ndev) return fail(nullptr, HULK_ERR_ARG, "device ordinal");
-#define SM_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipFree(d_m); hipFree(d_w); hipFree(d_o); return fail_hip(nullptr, e_, #call); } } while (0)
+#define SM_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipFree(d_m); hipFree(d_w); hipFree(d_o); if (ea) hipEventDestroy(ea); if (eb) hipEventDestroy(eb); return fail_hip(nullptr, e_, #call); } } while (0)
     unsigned long long *d_m = nullptr; double *d_w = nullptr, *d_o = nullptr;
+    hipEvent_t ea = nullptr, eb = nullptr;
     const size_t NS = (size_t)n_sketches * sketch_size, NN = (size_t)n_sketches * n_sketches;
     SM_CHK(hipSetDevice(device));
     SM_CHK(hipMalloc((void **)&d_m, (NS ? NS : 1) * 8));
@@ -485,11 +508,19 @@ int hulk_smash(int device, const uint64_t *mins, const double *weights, uint32_t
     SM_CHK(hipMalloc((void **)&d_o, (NN ? NN : 1) * 8));
     SM_CHK(hipMemcpy(d_m, mins, NS * 8, hipMemcpyHostToDevice));
     SM_CHK(hipMemcpy(d_w, weights, NS * 8, hipMemcpyHostToDevice));
+    if (kernel_ms) { SM_CHK(hipEventCreate(&ea)); SM_CHK(hipEventCreate(&eb)); SM_CHK(hipEventRecord(ea, nullptr)); }
     SM_CHK(launch_smash(nullptr, d_m, d_w, n_sketches, sketch_size, metric, d_o));
+    if (kernel_ms) { SM_CHK(hipEventRecord(eb, nullptr)); }
     SM_CHK(hipMemcpy(distances, d_o, NN * 8, hipMemcpyDeviceToHost));
+    if (kernel_ms) { float ms = 0; SM_CHK(hipEventElapsedTime(&ms, ea, eb)); *kernel_ms = ms; hipEventDestroy(ea); hipEventDestroy(eb); }
 #undef SM_CHK
     hipFree(d_m); hipFree(d_w); hipFree(d_o);
     return HULK_OK;
+}
+
+int hulk_smash(int device, const uint64_t *mins, const double *weights, uint32_t n_sketches, uint32_t sketch_size,
+               int metric, double *distances) {
+    return hulk_smash_ex(device, mins, weights, n_sketches, sketch_size, metric, distances, nullptr);
 }
 
 int hulk_get_scan_stats(hulk_ctx *c, uint64_t *tiles_visited, uint64_t *tiles_total) {
@@ -512,8 +543,8 @@ int hulk_synchronize(hulk_ctx *c) {
 
 int hulk_set_profiling(hulk_ctx *c, int enabled) {
     if (!c) return HULK_ERR_ARG;
-    // 1 (the on/off switch) = every instrumented kernel; otherwise a mask: 2 k_minimizer_fast, 4 k_jump_bin, 8 k_cws_scan
-    c->profiling = enabled == 1 ? 7 : ((enabled & 6) | ((enabled & 8) ? 1 : 0));
+    // 1 (the on/off switch) = every instrumented kernel; otherwise a mask: 2 k_minimizer_fast, 4 k_jump_bin, 8 k_cws_scan, 16 k_cmsd_freq
+    c->profiling = enabled == 1 ? 15 : ((enabled & 6) | ((enabled & 8) ? 1 : 0) | ((enabled & 16) ? 8 : 0));
     return HULK_OK;
 }
 
@@ -523,8 +554,9 @@ int hulk_get_profile(hulk_ctx *c, const char *kernel, uint64_t *launches, double
     if (kernel && strcmp(kernel, "k_minimizer_fast") == 0) which = 1;
     else if (kernel && strcmp(kernel, "k_jump_bin") == 0) which = 2;
     else if (kernel && strcmp(kernel, "k_jump_left") == 0) which = 3;
+    else if (kernel && strcmp(kernel, "k_cmsd_freq") == 0) which = 4;
     else if (kernel && strcmp(kernel, "k_cws_scan") != 0)
-        return fail(c, HULK_ERR_ARG, "instrumented kernels: k_cws_scan, k_minimizer_fast, k_jump_bin, k_jump_left");
+        return fail(c, HULK_ERR_ARG, "instrumented kernels: k_cws_scan, k_minimizer_fast, k_jump_bin, k_jump_left, k_cmsd_freq");
     { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
     double tot = 0; uint64_t n = 0;
     std::vector<ProfileRec> keep;

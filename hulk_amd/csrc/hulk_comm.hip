@@ -232,11 +232,10 @@ int hulk_step_sharded(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_off
         if (m.hdr_pending[prev]) { HIPCHK(c, hipEventSynchronize(m.ev_hdr[prev])); m.hdr_pending[prev] = false; }
         for (uint32_t r = 0; r < m.world; r++) if (m.h_hdr[prev][(size_t)r * SHARD_HDR + 1]) full = true;
     }
-    static const bool force_full = getenv("HULK_SHARD_FULL") != nullptr;      // A/B aid: always the spectra exchange
-    if (force_full) full = true;
+    if (c->shard_full) full = true;                                           // HULK_FLAG_SHARD_FULL: always the spectra exchange
     hipStream_t s = flush_stream_of(c);
     HIPCHK(c, hipEventRecord(c->ev_binned, c->stream));
-    if (!no_overlap_mode()) HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
+    if (!no_overlap_mode(c)) HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
     const int ring = c->cur_ring;
     uint32_t *hist = ring_hist(c);
     const size_t B = (size_t)c->B, NC = (size_t)c->cms_depth * c->cms_width;

@@ -584,7 +584,8 @@ size_t cms_binorder_entries(int depth, int width) { return (size_t)depth * CMS_S
 hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
                                 const uint32_t *d_eidx, const uint32_t *d_etot, double *d_ctrd, double *d_segadd,
                                 double *d_segfac, uint32_t *d_sege0, double *d_cstart, double *d_f64, float *d_rcp32,
-                                int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb) {
+                                int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb,
+                                hipEvent_t freq_begin, hipEvent_t freq_end) {
     const int chunks = (fb.num_bins + 63) / 64;
     const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
     if (depth > 8) return hipErrorInvalidValue;                     // k_cmsd_segsum: one wave per row, 8 waves
@@ -601,8 +602,10 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
                        d_segfac, d_sege0, depth, width, seg_chunks, omega, st, fb);
     hipLaunchKernelGGL(k_cmsd_base, dim3((depth * width + 255) / 256), dim3(256), 0, s, d_segadd, d_segfac, d_ctrd, d_cstart,
                        depth, width, st, fb);
+    if (freq_begin) { const hipError_t e = hipEventRecord(freq_begin, s); if (e != hipSuccess) return e; }   // bench.py: k_cmsd_freq alone
     hipLaunchKernelGGL(k_cmsd_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_meta8, d_eidx, d_sege0,
                        d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
+    if (freq_end) { const hipError_t e = hipEventRecord(freq_end, s); if (e != hipSuccess) return e; }
     return hipGetLastError();
 }
 

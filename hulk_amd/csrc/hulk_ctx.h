@@ -39,7 +39,7 @@ static inline hipError_t poison_host_malloc(void **p, size_t n, unsigned flags) 
 
 namespace hulk {
 constexpr uint64_t MAX_READS_PER_LAUNCH = 4u << 20;   // 4 Mi reads -> <= ~7 GB of minimizer list at w = 9
-struct ProfileRec { hipEvent_t a, b; int which; };   // which: 0 = k_cws_scan, 1 = k_minimizer_fast, 2 = k_jump_bin, 3 = k_jump_left
+struct ProfileRec { hipEvent_t a, b; int which; };   // which: 0 = k_cws_scan, 1 = k_minimizer_fast, 2 = k_jump_bin, 3 = k_jump_left, 4 = k_cmsd_freq
 }  // namespace hulk
 
 struct hulk_ctx {
@@ -102,8 +102,21 @@ struct hulk_ctx {
         size_t cap_bases = 0, cap_off = 0; hipEvent_t ev = nullptr; bool busy = false;
     } hstage[2];
     int hstage_cur = 0;
-    uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;   // reads the fast kernel deferred (built by k_region_offsets)
-    hulk::MinimizerList ml{}; uint64_t ml_regions = 0;
+    // Work lanes of the short-read path (hulk_flush.hip, bin_reads): a batch is binned in pieces that alternate between the
+    // context's stream (lane 0) and a second work stream (lane 1, created with the first split batch); a lane owns the
+    // per-launch buffers of the short-read kernels: the minimizer list (grow-only) and the list of reads the fast kernel
+    // deferred (built by k_region_offsets)
+    struct BinLane {
+        hipStream_t stream = nullptr;                   // lane 1 only (lane 0 runs on the context's stream)
+        hipEvent_t ev_k1a = nullptr;                    // behind the lane's latest k_minimizer_fast
+        hulk::MinimizerList ml{}; uint64_t ml_regions = 0;
+        uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;
+    } lane[2];
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;    // context stream -> lane 1 at the start of a split batch, and back
+    uint32_t bin_pieces = 1;                            // pieces a batch is binned in (hulk_params.bin_pieces)
+    uint32_t host_copy_threads = 4;                     // hulk_params.host_copy_threads
+    uint32_t bin_min_reads = 65536;                     // hulk_params.bin_min_reads
+    bool no_overlap = false, shard_full = false;        // HULK_FLAG_NO_OVERLAP, HULK_FLAG_SHARD_FULL
     uint64_t *d_long_xs = nullptr, *d_long_table = nullptr; uint8_t *d_long_valid = nullptr;   // long-sequence scratch
     void *d_long_desc = nullptr; uint64_t long_desc_cap = 0;
     uint64_t long_cap = 0, long_table_cap = 0;   // minimizer list of the short-read kernel (grow-only)
@@ -114,7 +127,7 @@ struct hulk_ctx {
     bool tables_ready = false, finished = false, hist_hook_used = false;
     int sticky = HULK_OK;
     std::string last_error;
-    int profiling = 0;   /* bit 0 k_cws_scan, bit 1 k_minimizer_fast, bit 2 k_jump_bin (hulk_set_profiling) */
+    int profiling = 0;   /* bit 0 k_cws_scan, bit 1 k_minimizer_fast, bit 2 k_jump_bin + k_jump_left, bit 3 k_cmsd_freq (hulk_set_profiling) */
     std::vector<hulk::ProfileRec> prof;
 };
 
@@ -148,7 +161,7 @@ int sync_all(hulk_ctx *c);
 int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
               uint32_t max_len, uint64_t bases_bytes, uint64_t interval, uint64_t fill);
 int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &fb);
-bool no_overlap_mode();
+bool no_overlap_mode(const hulk_ctx *c);
 hipStream_t flush_stream_of(hulk_ctx *c);
 int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream = nullptr, bool use_dep = false, bool allreduce = false);
 int check_device_error(hulk_ctx *c);

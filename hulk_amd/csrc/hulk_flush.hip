@@ -109,8 +109,97 @@ int bin_long_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offset
     return launch_group();
 }
 
-int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
-              uint32_t max_len, uint64_t bases_bytes, uint64_t interval, uint64_t fill) {
+// grow-only buffers of a work lane for a launch of n reads
+static int lane_reserve(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, uint64_t n, bool pair_ok) {
+    if (!ln.d_slow_count) {
+        HIPCHK(c, dalloc(&ln.d_slow_count, 2));
+        HIPCHK(c, hipMemsetAsync(ln.d_slow_count, 0, 8, s));
+    }
+    if (n > ln.d_slow_cap) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        hipFree(ln.d_slow_list); ln.d_slow_list = nullptr; ln.d_slow_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&ln.d_slow_list, (size_t)(n + n / 4 + 1024) * 4));
+        ln.d_slow_cap = n + n / 4 + 1024;
+    }
+    MinimizerList &ml = ln.ml;
+    const uint64_t regions = (n + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE;
+    // (a region never shrinks again: calls with and without reads of two groups may alternate)
+    const uint64_t rcap = std::max<uint64_t>(minimizer_list_rcap(c->p.w, pair_ok), ml.rcap);
+    if (regions > ln.ml_regions || ml.rcap != rcap) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        hipFree(ml.x); hipFree(ml.slot); hipFree(ml.key); hipFree(ml.cnt); hipFree(ml.off); hipFree(ml.bsum);
+        hipFree(ml.lo); hipFree(ml.lo_cnt); hipFree(ml.dmask); hipFree(ml.dsum);
+        uint32_t *keep_partial = ml.partial; const uint32_t keep_parts = ml.max_parts;
+        uint32_t *keep_nib = ml.nib, *keep_over = ml.nib_over; const uint32_t keep_np = ml.nib_parts;
+        ml = MinimizerList{}; ln.ml_regions = 0;
+        ml.partial = keep_partial; ml.max_parts = keep_parts;
+        ml.nib = keep_nib; ml.nib_over = keep_over; ml.nib_parts = keep_np;
+        const uint64_t cap = regions + regions / 8 + 64;
+        HIPCHK(c, hipMalloc((void **)&ml.x, cap * rcap * 8));
+        HIPCHK(c, hipMalloc((void **)&ml.slot, cap * rcap));
+        HIPCHK(c, hipMalloc((void **)&ml.key, cap * rcap * 4));
+        HIPCHK(c, hipMalloc((void **)&ml.cnt, cap * 4));
+        HIPCHK(c, hipMalloc((void **)&ml.off, (cap + 1) * 4));
+        HIPCHK(c, hipMalloc((void **)&ml.bsum, (cap / 1024 + 2) * 4));
+        HIPCHK(c, hipMalloc((void **)&ml.lo, cap * JUMP_LO_CAP * sizeof(uint4)));
+        HIPCHK(c, hipMalloc((void **)&ml.lo_cnt, cap * 4));
+        HIPCHK(c, hipMalloc((void **)&ml.dmask, cap * 4));
+        HIPCHK(c, hipMalloc((void **)&ml.dsum, (cap / 1024 + 2) * 4));
+        if (!ml.nib) {
+            const size_t nr = ((size_t)c->B + 262143) / 262144;
+            ml.nib_parts = 48;
+            HIPCHK(c, hipMalloc((void **)&ml.nib, (size_t)ml.nib_parts * c->ring_n * nr * (262144 / 8) * 4));
+            HIPCHK(c, hipMalloc((void **)&ml.nib_over, RING_MAX * 4));
+            HIPCHK(c, hipMemsetAsync(ml.nib_over, 0, RING_MAX * 4, s));
+        }
+        if (!ml.partial) {
+            ml.max_parts = 8;
+            HIPCHK(c, hipMalloc((void **)&ml.partial, (size_t)ml.max_parts * c->ring_n * (size_t)c->B * 4));
+        }
+        ml.rcap = rcap; ln.ml_regions = cap;
+    }
+    return HULK_OK;
+}
+
+// One piece of a batch through the short-read kernels on stream s with lane ln's buffers: k_minimizer_fast -> region
+// scan -> k_jump_bin / k_jump_left -> spectrum kernels -> the generic kernel over the reads the fast one deferred.
+// after_k1a (may be null): recorded behind k_minimizer_fast;  before_k1a (may be null): waited for in front of it;
+// spectra_gate (may be null): the flush that last read this ring — only the histogram kernels wait for it (the minimizer
+// and jump-hash kernels do not touch the spectra)
+static int bin_fast_piece(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
+                          uint64_t n, uint32_t max_len, MinimizerParams P, uint32_t *hist, hipEvent_t before_k1a,
+                          hipEvent_t after_k1a, hipEvent_t spectra_gate) {
+    { const int rc = lane_reserve(c, ln, s, n, P.pair != 0); if (rc != HULK_OK) return rc; }
+    if (before_k1a) HIPCHK(c, hipStreamWaitEvent(s, before_k1a, 0));
+    ProfileRec pr{}; pr.which = 1;
+    if ((c->profiling & 2)) {
+        HIPCHK(c, hipEventCreateWithFlags(&pr.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pr.b, PROFILE_EVENT_FLAGS));
+        HIPCHK(c, hipEventRecord(pr.a, s));
+    }
+    HIPCHK(c, launch_minimizer_fast(s, d_bases, d_offsets, n, P, ln.ml, c->d_state, c->d_min_slots));
+    if ((c->profiling & 2)) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
+    if (after_k1a) HIPCHK(c, hipEventRecord(after_k1a, s));
+    ProfileRec pj{}; pj.which = 2;
+    ProfileRec pl{}; pl.which = 3;
+    if ((c->profiling & 4)) {
+        HIPCHK(c, hipEventCreateWithFlags(&pj.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pj.b, PROFILE_EVENT_FLAGS));
+        HIPCHK(c, hipEventCreateWithFlags(&pl.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pl.b, PROFILE_EVENT_FLAGS));
+    }
+    HIPCHK(c, launch_minimizer_post(s, n, P, ln.ml, hist, ln.d_slow_list, ln.d_slow_count, pj.a, pj.b, spectra_gate, pl.a, pl.b));
+    if ((c->profiling & 4)) { c->prof.push_back(pj); c->prof.push_back(pl); }
+    int threads = 256;
+    pick_config(c->p.k, max_len, P, threads);      // (the fast path implies max_len <= 512: always fits)
+    // the list is normally empty or short; its length is only known on the device, so the grid is fixed: enough
+    // workgroups that 1 % of deferred reads (reads with N) do not queue behind 512 waves (blocks past the list exit at once)
+    static const uint32_t slow_blocks = [] { const char *e = getenv("HULK_SLOW_BLOCKS"); const long v = e ? atol(e) : 2048; return (uint32_t)(v < 1 ? 1 : v > 8192 ? 8192 : v); }();
+    const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(slow_blocks, (n + 3) / 4);
+    HIPCHK(c, launch_minimizer_bin(s, d_bases, d_offsets, n, P, threads, hist, c->d_state, c->d_min_slots, ln.d_slow_list,
+                                   ln.d_slow_count, list_blocks));
+    return HULK_OK;
+}
+
+// launch parameters of reads [first, ...) of a call that starts `fill` reads into spectrum ring_base
+static MinimizerParams piece_params(const hulk_ctx *c, uint64_t bases_bytes, uint64_t interval, uint64_t fill, bool pair) {
     MinimizerParams P{};
     P.k = c->p.k; P.w = c->p.w; P.num_bins = c->B; P.bases_bytes = bases_bytes;
     P.interval = interval; P.fill = fill; P.ring_base = c->ring_base; P.ring_n = c->ring_n;
@@ -118,9 +207,21 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
     // starts inside spectrum ring_base (hist_slot() is unchanged by this) and build no empty spectra in front of it
     if (P.interval && P.fill >= P.interval) { P.ring_base = (uint32_t)((P.ring_base + P.fill / P.interval) % P.ring_n); P.fill %= P.interval; }
     if (const char *e = getenv("HULK_K1_DEBUG")) P.debug = (uint32_t)atoi(e);
+    P.pair = pair ? 1u : 0u;
+    return P;
+}
+
+// Bins reads [0, n) of a call into the spectra of the current ring (read i -> spectrum (fill + i) / interval).
+// Short reads: the batch is cut at sketching-interval borders into `bin_pieces` pieces that alternate between two work
+// streams (lane 0 = the context's stream, lane 1 = a stream of its own), each with its own minimizer list; a piece's
+// k_minimizer_fast starts when the previous piece's has ended, so that from the second piece on a k_minimizer_fast
+// (VALU + LDS, 4 waves per SIMD) runs beside the k_jump_bin / spectrum kernels of the piece before it (VALU only) and the
+// two fill each other's issue bubbles.  Pieces touch disjoint spectra (their plain read-modify-writes cannot meet) and the
+// context's stream waits for lane 1 before the call returns: to the caller it is still one stream.
+int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
+              uint32_t max_len, uint64_t bases_bytes, uint64_t interval, uint64_t fill) {
     { int rcw = ring_issue_own_flush(c); if (rcw != HULK_OK) return rcw; }
     uint32_t *hist = ring_hist(c);
-    int threads = 256;
     // the short-read kernel takes reads of <= 16*w k-mer positions and <= 256 bases; when the batch's
     // length bound already exceeds that, go straight to the generic kernel
     // ... or, two groups per read, <= 2*16w - (w-1) positions (300 bases at k = 21, w = 9) while a group's own
@@ -130,79 +231,50 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
     const bool pair_ok = !single_ok && !getenv("HULK_NO_PAIR") && 16ull * c->p.w + c->p.k - 1 <= 256 && max_len <= 512 &&
                          (uint64_t)max_len < (uint64_t)c->p.k + 32ull * c->p.w - (c->p.w - 1);
     const bool fast_ok = fast_base && (single_ok || pair_ok);
-    P.pair = pair_ok ? 1u : 0u;
     if (fast_ok) {
         // short-read kernel first; reads it cannot take (N bases, too long for 16 blocks of w
         // positions) are queued on the device and binned by the generic kernel right after
-        if (n > c->d_slow_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            hipFree(c->d_slow_list); c->d_slow_list = nullptr; c->d_slow_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->d_slow_list, (size_t)(n + n / 4 + 1024) * 4));
-            c->d_slow_cap = n + n / 4 + 1024;
+        uint64_t cuts[SCAN_BATCH_MAX + 2]; uint32_t np = 0;
+        cuts[0] = 0;
+        uint32_t want = (no_overlap_mode(c) || !interval) ? 1u : c->bin_pieces;
+        if ((uint64_t)want * c->bin_min_reads > n) want = (uint32_t)(n / c->bin_min_reads);      // (0 or 1: one piece)
+        for (uint32_t p = 1; p < want; p++) {
+            // the interval border nearest to p / want of the reads
+            const uint64_t target = fill + n * p / want;
+            const uint64_t border = (target + interval / 2) / interval * interval;
+            if (border <= fill + cuts[np] || border >= fill + n) continue;
+            cuts[++np] = border - fill;
         }
-        const uint64_t regions = (n + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE;
-        // (a region never shrinks again: calls with and without reads of two groups may alternate)
-        const uint64_t rcap = std::max<uint64_t>(minimizer_list_rcap(c->p.w, pair_ok), c->ml.rcap);
-        if (regions > c->ml_regions || c->ml.rcap != rcap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            hipFree(c->ml.x); hipFree(c->ml.slot); hipFree(c->ml.key); hipFree(c->ml.cnt); hipFree(c->ml.off); hipFree(c->ml.bsum);
-            hipFree(c->ml.lo); hipFree(c->ml.lo_cnt); hipFree(c->ml.dmask); hipFree(c->ml.dsum);
-            uint32_t *keep_partial = c->ml.partial; const uint32_t keep_parts = c->ml.max_parts;
-            uint32_t *keep_nib = c->ml.nib, *keep_over = c->ml.nib_over; const uint32_t keep_np = c->ml.nib_parts;
-            c->ml = MinimizerList{}; c->ml_regions = 0;
-            c->ml.partial = keep_partial; c->ml.max_parts = keep_parts;
-            c->ml.nib = keep_nib; c->ml.nib_over = keep_over; c->ml.nib_parts = keep_np;
-            const uint64_t cap = regions + regions / 8 + 64;
-            HIPCHK(c, hipMalloc((void **)&c->ml.x, cap * rcap * 8));
-            HIPCHK(c, hipMalloc((void **)&c->ml.slot, cap * rcap));
-            HIPCHK(c, hipMalloc((void **)&c->ml.key, cap * rcap * 4));
-            HIPCHK(c, hipMalloc((void **)&c->ml.cnt, cap * 4));
-            HIPCHK(c, hipMalloc((void **)&c->ml.off, (cap + 1) * 4));
-            HIPCHK(c, hipMalloc((void **)&c->ml.bsum, (cap / 1024 + 2) * 4));
-            HIPCHK(c, hipMalloc((void **)&c->ml.lo, cap * JUMP_LO_CAP * sizeof(uint4)));
-            HIPCHK(c, hipMalloc((void **)&c->ml.lo_cnt, cap * 4));
-            HIPCHK(c, hipMalloc((void **)&c->ml.dmask, cap * 4));
-            HIPCHK(c, hipMalloc((void **)&c->ml.dsum, (cap / 1024 + 2) * 4));
-            if (!c->ml.nib) {
-                const size_t nr = ((size_t)c->B + 262143) / 262144;
-                c->ml.nib_parts = 48;
-                HIPCHK(c, hipMalloc((void **)&c->ml.nib, (size_t)c->ml.nib_parts * c->ring_n * nr * (262144 / 8) * 4));
-                HIPCHK(c, hipMalloc((void **)&c->ml.nib_over, RING_MAX * 4));
-                HIPCHK(c, hipMemsetAsync(c->ml.nib_over, 0, RING_MAX * 4, c->stream));
-            }
-            if (!c->ml.partial) {
-                c->ml.max_parts = 8;
-                HIPCHK(c, hipMalloc((void **)&c->ml.partial, (size_t)c->ml.max_parts * c->ring_n * (size_t)c->B * 4));
-            }
-            c->ml.rcap = rcap; c->ml_regions = cap;
+        cuts[++np] = n;
+        hipEvent_t gate = ring_write_event(c);
+        if (np == 1)
+            return bin_fast_piece(c, c->lane[0], c->stream, d_bases, d_offsets, n, max_len,
+                                  piece_params(c, bases_bytes, interval, fill, pair_ok), hist, nullptr, nullptr, gate);
+        hulk_ctx::BinLane &l1 = c->lane[1];
+        if (!l1.stream) {
+            int prio = 0;
+            if (c->stream) (void)hipStreamGetPriority(c->stream, &prio);
+            HIPCHK(c, hipStreamCreateWithPriority(&l1.stream, hipStreamNonBlocking, prio));
+            for (int i = 0; i < 2; i++) HIPCHK(c, hipEventCreateWithFlags(&c->lane[i].ev_k1a, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         }
-        ProfileRec pr{}; pr.which = 1;
-        if ((c->profiling & 2)) {
-            HIPCHK(c, hipEventCreateWithFlags(&pr.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pr.b, PROFILE_EVENT_FLAGS));
-            HIPCHK(c, hipEventRecord(pr.a, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));              // the caller's buffers, everything queued before
+        HIPCHK(c, hipStreamWaitEvent(l1.stream, c->ev_fork, 0));
+        for (uint32_t p = 0; p < np; p++) {
+            const int li = (int)(p & 1);
+            hipStream_t s = li ? l1.stream : c->stream;
+            const int rc = bin_fast_piece(c, c->lane[li], s, d_bases, d_offsets + cuts[p], cuts[p + 1] - cuts[p], max_len,
+                                          piece_params(c, bases_bytes, interval, fill + cuts[p], pair_ok), hist,
+                                          p ? c->lane[li ^ 1].ev_k1a : nullptr, c->lane[li].ev_k1a, gate);
+            if (rc != HULK_OK) return rc;
         }
-        HIPCHK(c, launch_minimizer_fast(c->stream, d_bases, d_offsets, n, P, c->ml, c->d_state, c->d_min_slots));
-        if ((c->profiling & 2)) { HIPCHK(c, hipEventRecord(pr.b, c->stream)); c->prof.push_back(pr); }
-        ProfileRec pj{}; pj.which = 2;
-        ProfileRec pl{}; pl.which = 3;
-        if ((c->profiling & 4)) {
-            HIPCHK(c, hipEventCreateWithFlags(&pj.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pj.b, PROFILE_EVENT_FLAGS));
-            HIPCHK(c, hipEventCreateWithFlags(&pl.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pl.b, PROFILE_EVENT_FLAGS));
-        }
-        // (the minimizer and jump-hash kernels do not touch the spectra: only the histogram kernels behind them wait for
-        // the flush that last read this ring)
-        HIPCHK(c, launch_minimizer_post(c->stream, n, P, c->ml, hist, c->d_slow_list, c->d_slow_count, pj.a, pj.b,
-                                        ring_write_event(c), pl.a, pl.b));
-        if ((c->profiling & 4)) { c->prof.push_back(pj); c->prof.push_back(pl); }
-        pick_config(c->p.k, max_len, P, threads);      // (fast_ok implies max_len <= 256: always fits)
-        // the list is normally empty or short; its length is only known on the device, so the grid is fixed: enough
-        // workgroups that 1 % of deferred reads (reads with N) do not queue behind 512 waves (blocks past the list exit at once)
-        static const uint32_t slow_blocks = [] { const char *e = getenv("HULK_SLOW_BLOCKS"); const long v = e ? atol(e) : 2048; return (uint32_t)(v < 1 ? 1 : v > 8192 ? 8192 : v); }();
-        const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(slow_blocks, (n + 3) / 4);
-        HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, hist, c->d_state,
-                                       c->d_min_slots, c->d_slow_list, c->d_slow_count, list_blocks));
+        HIPCHK(c, hipEventRecord(c->ev_join, l1.stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         return HULK_OK;
     }
+    MinimizerParams P = piece_params(c, bases_bytes, interval, fill, false);
+    int threads = 256;
     { const int rcf = issue_flush(c, nullptr); if (rcf != HULK_OK) return rcf; }
     if (hipEvent_t e = ring_write_event(c)) HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
     const bool fits = pick_config(c->p.k, max_len, P, threads);
@@ -222,9 +294,12 @@ int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &
     }
     if (c->scaling) {
         HIPCHK(c, launch_elem_index(s, hist, c->d_blkcnt, c->d_eidx, c->d_etot, fb, c->d_state));
+        ProfileRec pf{}; pf.which = 4;
+        if ((c->profiling & 8)) { HIPCHK(c, hipEventCreateWithFlags(&pf.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pf.b, PROFILE_EVENT_FLAGS)); }
         HIPCHK(c, launch_cmsd_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_eidx, c->d_etot, c->d_ctrd, c->d_segadd,
                                        c->d_segfac, c->d_sege0, c->d_cstart, c->d_f64, c->d_rcp32, c->cms_depth,
-                                       c->cms_width, c->row_stride, c->decay_weight, c->d_state, fb));
+                                       c->cms_width, c->row_stride, c->decay_weight, c->d_state, fb, pf.a, pf.b));
+        if ((c->profiling & 8)) c->prof.push_back(pf);
     } else {
         HIPCHK(c, launch_cms_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_ctr, c->d_segsum, c->d_cbase, c->d_f64,
                                       c->d_rcp32, c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
@@ -251,8 +326,8 @@ int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &
 }
 
 // the stream flushes run on (HULK_NO_OVERLAP: the work stream itself — profiling aid, every kernel alone)
-bool no_overlap_mode() { static const bool v = getenv("HULK_NO_OVERLAP") != nullptr; return v; }
-hipStream_t flush_stream_of(hulk_ctx *c) { return no_overlap_mode() ? c->stream : c->flush_stream; }
+bool no_overlap_mode(const hulk_ctx *c) { return c->no_overlap; }
+hipStream_t flush_stream_of(hulk_ctx *c) { return c->no_overlap ? c->stream : c->flush_stream; }
 
 // queue the kernels of a prepared flush on the flush stream; `gate` (may be null): an event on the work stream they wait for
 int issue_flush(hulk_ctx *c, hipEvent_t gate) {
@@ -263,8 +338,8 @@ int issue_flush(hulk_ctx *c, hipEvent_t gate) {
     hipStream_t s = flush_stream_of(c);
     // ev_binned orders the flush behind the binning; recorded on a caller's stream (hulk_flush_batch_after: the stream its
     // collective runs on) it has to be waited for even when the flush shares the work stream
-    if (!no_overlap_mode() || c->deferred.use_dep) HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
-    if (!no_overlap_mode() && gate) HIPCHK(c, hipStreamWaitEvent(s, gate, 0));
+    if (!no_overlap_mode(c) || c->deferred.use_dep) HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
+    if (!no_overlap_mode(c) && gate) HIPCHK(c, hipStreamWaitEvent(s, gate, 0));
     uint32_t *hist = c->d_hist + (size_t)ring * (size_t)c->ring_n * (size_t)c->B;
     if (c->deferred.allreduce) {                                 // hulk_step_sliced: sum the ranks' spectra first
         int rc = comm_enter(c, s);
@@ -349,8 +424,7 @@ int stage_host_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets,
     hulk_ctx::HostStage &hs = c->hstage[c->hstage_cur];
     { const int rc = stage_ready(c, hs, nbytes, cn); if (rc != HULK_OK) return rc; }
     {
-        static const unsigned tmax = [] { const char *e = getenv("HULK_HOST_COPY_THREADS"); const long v = e ? atol(e) : 4; return (unsigned)(v < 1 ? 1 : v > 32 ? 32 : v); }();
-        const unsigned T = nbytes >= (8u << 20) ? tmax : 1u;
+        const unsigned T = nbytes >= (8u << 20) ? c->host_copy_threads : 1u;
         // (ceil: with floor(nbytes / T) a multiple of 64 and nbytes % T != 0 the T pieces would end short of the last bytes)
         const size_t piece = ((nbytes + T - 1) / T + 63) & ~(size_t)63;
         std::vector<std::thread> th;

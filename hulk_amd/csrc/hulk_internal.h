@@ -109,7 +109,8 @@ size_t cms_binorder_entries(int depth, int width);   // entries of segsum / base
 hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
                                 const uint32_t *d_eidx, const uint32_t *d_etot, double *d_ctrd, double *d_segadd,
                                 double *d_segfac, uint32_t *d_sege0, double *d_cstart, double *d_f64, float *d_rcp32,
-                                int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb);
+                                int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb,
+                                hipEvent_t freq_begin = nullptr, hipEvent_t freq_end = nullptr);
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,

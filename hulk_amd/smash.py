@@ -33,8 +33,9 @@ def collect_jsons(sketch_dir, recursive=False):
     return found
 
 
-def distance_matrix(mins, weights, metric="jaccard", device=0):
-    """distances[s, q] = GetDistance(subject s, query q) for all pairs, computed on the GPU."""
+def distance_matrix(mins, weights, metric="jaccard", device=0, timing=None):
+    """distances[s, q] = GetDistance(subject s, query q) for all pairs, computed on the GPU.
+    timing: a dict that receives "kernel_ms" (k_smash alone, HIP events; hulk_smash_ex)."""
     mins = np.ascontiguousarray(mins, dtype=np.uint64)
     weights = np.ascontiguousarray(weights, dtype=np.float64)
     if mins.shape != weights.shape or mins.ndim != 2:
@@ -42,8 +43,13 @@ def distance_matrix(mins, weights, metric="jaccard", device=0):
     n, s = mins.shape
     out = np.zeros((n, n), dtype=np.float64)
     L = _lib.load()
-    rc = L.hulk_smash(device, mins.ctypes.data, weights.ctypes.data, n, s,
-                      1 if metric == "weightedjaccard" else 0, out.ctypes.data)
+    import ctypes
+    kms = ctypes.c_double(0.0)
+    rc = L.hulk_smash_ex(device, mins.ctypes.data, weights.ctypes.data, n, s,
+                         1 if metric == "weightedjaccard" else 0, out.ctypes.data,
+                         ctypes.byref(kms) if timing is not None else None)
+    if timing is not None:
+        timing["kernel_ms"] = kms.value
     if rc != 0:
         raise HulkError(rc, L.hulk_last_error(None).decode())
     return out

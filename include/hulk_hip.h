@@ -50,8 +50,13 @@ extern "C" {
 #endif
 
 /* 2: hulk_params.reserved[0] became `flags` (unknown bits are refused), hulk_set_profiling takes a mask, the multi-GPU
- * entry points (hulk_comm_*, hulk_step_*, hulk_gather_sketch).  Bindings compare it with the value they were written for. */
-#define HULK_ABI_VERSION 2
+ * entry points (hulk_comm_*, hulk_step_*, hulk_gather_sketch).
+ * 3: every knob a host may want per context is a field (as SketchCmd carries every flag as a field,
+ *    src/pipeline/pipeline.go:14-30): hulk_params.batch / bin_pieces / host_copy_threads / bin_min_reads (were reserved[0..3], 0 = default),
+ *    HULK_FLAG_SHARD_FULL / HULK_FLAG_NO_OVERLAP, hulk_ingest_opts with hulk_parse_files_opts / hulk_sketch_files_opts.
+ *    The HULK_* environment variables that remain are overrides for profiling scripts, read when a context is created.
+ * Bindings compare it with the value they were written for. */
+#define HULK_ABI_VERSION 3
 
 #define HULK_OK 0
 #define HULK_ERR_W (-1)          /* "w must be: 0 < w < 257"                  minimizer.go:63 */
@@ -89,6 +94,9 @@ extern "C" {
                                     * that a pin against a real Go run can be reproduced literally */
 #define HULK_FLAG_NO_PRUNE 2u      /* CWS scan reads the whole table for every interval (no per-tile bound, no whole-batch bound) */
 #define HULK_FLAG_NO_SKIP 4u       /* keep the per-tile bound, drop the whole-batch bound */
+#define HULK_FLAG_SHARD_FULL 8u    /* hulk_step_sharded always exchanges the k-mer spectra (never the count-min increments) */
+#define HULK_FLAG_NO_OVERLAP 16u   /* one stream: flush kernels on the work stream, a batch binned in one piece (profiling:
+                                    * every kernel runs alone, so its own duration can be read) */
 
 /* Largest k-mer spectrum this build bins: the binning kernels pack (spectrum slot << 20 | bin) into one dword
  * (k^4 = 923,521 < 2^20 at the reference's maximum k = 31; cmd/sketch.go:118). */
@@ -108,7 +116,15 @@ typedef struct hulk_params {
     uint32_t slot_count;   /* 0 => all slots (single-GPU) */
     uint32_t cws_source;   /* HULK_CWS_* */
     uint32_t flags;        /* HULK_FLAG_* (0 = defaults) */
-    uint32_t reserved[4];
+    uint32_t batch;        /* sketching intervals binned by one launch chain and flushed by ONE pass over the CWS table:
+                            * 1..16, 0 = default (16).  Any value gives the same sketch (hulk_batch_size) */
+    uint32_t bin_pieces;   /* a batch of short reads is binned in this many pieces, cut at interval borders, alternating
+                            * between two work streams so that one piece's minimizer kernel runs beside the jump-hash kernel
+                            * of the piece before: 1..16, 0 = default (4), 1 = one piece on the context's stream */
+    uint32_t host_copy_threads; /* threads that copy a chunk of hulk_add_reads' host buffers into pinned staging: 1..32,
+                            * 0 = default (4) */
+    uint32_t bin_min_reads; /* a batch is only cut into pieces of at least this many reads (a piece should fill the chip:
+                            * 256 CUs x 4 workgroups x 64 reads): 0 = default (65536); tests use small values */
 } hulk_params;
 
 /* Version of this ABI (HULK_ABI_VERSION). */
@@ -294,6 +310,9 @@ int hulk_get_cws_tables(hulk_ctx *ctx, double *r, double *c, double *b);
 #define HULK_METRIC_WEIGHTED_JACCARD 1
 int hulk_smash(int device, const uint64_t *mins, const double *weights, uint32_t n_sketches,
                uint32_t sketch_size, int metric, double *distances);
+/* The same; *kernel_ms (may be NULL) receives the duration of the distance kernel alone (HIP events), without the PCIe copies. */
+int hulk_smash_ex(int device, const uint64_t *mins, const double *weights, uint32_t n_sketches,
+                  uint32_t sketch_size, int metric, double *distances, double *kernel_ms);
 
 /* Device self-test: the jump hash replaces the fp64 division 2^31/r by a Newton reciprocal; this
  * checks RN(1/r) against IEEE division for EVERY r in [1, 2^31] and returns the mismatch count. */
@@ -306,9 +325,10 @@ int hulk_selftest_reciprocal(hulk_ctx *ctx, uint64_t *mismatches);
 int hulk_get_scan_stats(hulk_ctx *ctx, uint64_t *tiles_visited, uint64_t *tiles_total);
 
 /* Per-kernel timing for bench.py: when enabled, hipEvents bracket every launch of the heavy kernels
- * ("k_minimizer_fast", "k_jump_bin", "k_jump_left", "k_cws_scan"; each alone) on the stream they are launched on.
- * enabled: 0 off, 1 all of them, otherwise a mask (2 k_minimizer_fast, 4 k_jump_bin and k_jump_left, 8 k_cws_scan) — every bracketed
- * launch costs the stream two event records (all three: ~3 % of a C2 step), so a timed run brackets what it reports. */
+ * ("k_minimizer_fast", "k_jump_bin", "k_jump_left", "k_cws_scan", "k_cmsd_freq"; each alone) on the stream they are launched on.
+ * enabled: 0 off, 1 all of them, otherwise a mask (2 k_minimizer_fast, 4 k_jump_bin and k_jump_left, 8 k_cws_scan, 16 k_cmsd_freq)
+ * — every bracketed launch costs the stream two event records (~3 % of a C2 step for all of them), so the timed pass of
+ * bench.py brackets nothing and the durations come from a separate pass. */
 int hulk_set_profiling(hulk_ctx *ctx, int enabled);
 /* Number of timed launches of `kernel` and their summed duration (synchronises; clears that log). */
 int hulk_get_profile(hulk_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);

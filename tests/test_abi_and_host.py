@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"{s} declared in include/hulk_hip.h but not exported"
     assert sorted(_lib.ABI_SYMBOLS) == syms, "hulk_amd/_lib.py binding list out of sync with the header"
     L.hulk_abi_version.restype = ctypes.c_int
-    assert L.hulk_abi_version() == _lib.HULK_ABI_VERSION == 2
+    assert L.hulk_abi_version() == _lib.HULK_ABI_VERSION == 3
     L.hulk_strerror.restype = ctypes.c_char_p
     assert L.hulk_strerror(-4) == b"sequence length must be >= w + k - 1"
     assert L.hulk_strerror(-5) == b"not used yet"

@@ -1,6 +1,7 @@
-"""bench.py contract on the GPU box: ONE JSON line on stdout with the required keys; the sharded-step path through RCCL
-at world size 1; and `bench.py --gpus 2` END TO END at world 2 — self-spawn, the pre-warm agreement, the other modes, value_c4
-and the JSON relay — with both ranks on this box's one GPU over the library's host transport (HULK_BENCH_TRANSPORT=gloo)."""
+"""bench.py contract on the GPU box: ONE JSON line on stdout with the required keys; every secondary leg fault-isolated; the
+sharded-step path through RCCL at world size 1; and `bench.py --gpus 2` / `--gpus 8` END TO END — self-spawn, the pre-warm
+agreement, the other modes, value_c4 with ranks that hold none of the ragged last step, and the JSON relay — with all ranks
+on this box's one GPU over the library's host transport (HULK_BENCH_TRANSPORT=gloo)."""
 import json
 import os
 import subprocess
@@ -15,8 +16,13 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def _run(extra, env_extra=None, timeout=900):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HULK_BENCH_PREWARM_S="0")   # (no need to warm the GPU for a contract test)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HULK_BENCH_PREWARM_S="0",   # (no need to warm the GPU for a contract test)
+               HULK_BENCH_LONG_STEPS="6")
     env.update(env_extra or {})
+    if "--c3" in extra:                                      # (the C3 / C5 legs only where a test looks at them)
+        extra = [x for x in extra if x != "--c3"]
+    else:
+        extra = extra + ["--no-c3", "--no-c5"]
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"] + extra,
                        capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -26,9 +32,22 @@ def _run(extra, env_extra=None, timeout=900):
 
 
 def test_bench_json_contract_and_collective_path():
-    a = _run(["--no-cpu-baseline"])
+    a = _run(["--no-cpu-baseline", "--c3"])
     for k in REQUIRED:
         assert k in a, k
+    assert not [k for k in a if k.endswith("_error")], [k for k in a if k.endswith("_error")]
+    # the timed pass carries no event brackets; the kernel durations come from the one-stream `kernels` leg
+    assert "no HIP-event brackets" in a["timed_pass_note"] and "HULK_FLAG_NO_OVERLAP" in a["roofline"]["durations_from"]
+    assert a["ms_per_step_kernels_alone"] > 0.8 * a["ms_per_step"]
+    assert a["steps_long"] == 6 and 0.5 * a["ms_per_step"] < a["ms_per_step_long"] < 2.0 * a["ms_per_step"]
+    # BASELINE configs[2] and [4] are in the driver's line
+    c3 = a["c3"]
+    assert "k=31" in c3["workload"] and c3["reads"] >= 8_000_000 and 1e8 < c3["value"] < a["value"]
+    assert c3["negative_weights"] == 1024 and c3["kernels_alone"]["k_cmsd_freq_us"] > 0 and c3["kernels_alone"]["k_minimizer_fast_us"] > 0
+    c5 = a["c5"]
+    for metric in ("weightedjaccard", "jaccard"):
+        assert c5[metric]["ms_kernel"] < c5[metric]["ms_end_to_end"] and 0.0 < c5[metric]["lds_pipe_frac"] < 1.0
+    assert c5["pairs"] == 1024 * 1024
     assert a["n_gpus"] == 1 and a["steps"] == 3 and a["warmup"] == 1 and a["vs_baseline"] is None
     assert a["unit"] == "reads/s" and a["higher_is_better"] is True and a["scaling"] == "weak"
     assert "workload" in a["config"] and "model" not in a["config"]
@@ -86,6 +105,28 @@ def test_bench_json_contract_and_collective_path():
     assert "LOOPBACK" in g["config"]["workload"] and g["config"]["reads_per_step"] == 8 * g["config"]["reads_per_rank_step"]
 
 
+def test_bench_line_survives_any_secondary_leg():
+    """Fault isolation: every secondary leg may raise (HULK_BENCH_FAIL names the legs that do) and the ONE line still comes
+    out with the headline in it, `<leg>_error` for each of them, and exit status 0."""
+    ok = _run(["--no-cpu-baseline", "--single-pass", "--no-cold", "--no-e2e"])
+    legs = "kernels,unpruned,long,cold,c3,c5,e2e,cpu_baseline"
+    a = _run(["--c3"], {"HULK_BENCH_FAIL": legs})
+    for leg in legs.split(","):
+        assert "HULK_BENCH_FAIL" in a[leg + "_error"], leg
+    assert a["value"] > 1e7 and a["sketch_md5"] == ok["sketch_md5"] and a["roofline"] is None
+    for gone in ("value_unpruned", "ms_per_step_long", "value_cold", "c3", "c5", "e2e", "cpu_baseline"):
+        assert gone not in a, gone
+    # at N > 1 (here: world 1 through the collective path) the modes and C4 each on their own; a failed collective leg
+    # makes the ranks skip the collective legs behind it (they may no longer be in step), never the line
+    b = _run(["--no-cpu-baseline", "--no-cold", "--no-e2e", "--force-collective"],
+             {"HULK_BENCH_FAIL": "other_scaling_sliced-weak", "HULK_BENCH_C4_READS_PER_RANK": "3300000"})
+    assert b["sketch_md5"] == ok["sketch_md5"] and "HULK_BENCH_FAIL" in b["other_scaling_sliced-weak_error"]
+    assert [o["mode"] for o in b["other_scaling"]] == ["sliced-strong"] and "skipped" in b["c4_error"] and "value_c4" not in b
+    # a leg that never returns: the watchdog prints the line and ends the process with status 0
+    c = _run(["--no-cpu-baseline", "--single-pass", "--no-cold", "--no-e2e"], {"HULK_BENCH_HANG": "kernels", "HULK_BENCH_LEG_TIMEOUT_S": "8"})
+    assert c["sketch_md5"] == ok["sketch_md5"] and "timeout" in c["kernels_error"] and c["roofline"] is None
+
+
 def test_bench_says_so_when_rccl_cannot_be_bound():
     """hulk_comm_init failing (here: HULK_RCCL_LIB names a file that is not there) must not leave a scaling run without a
     line: every rank learns of it, the run goes over the library's host transport on a gloo group and the line says so."""
@@ -127,6 +168,54 @@ def test_bench_world_two_end_to_end_on_one_gpu():
     strong = [o for o in out["other_scaling"] if o["mode"] == "sliced-strong"][0]
     half = _run(["--no-cpu-baseline", "--no-cold", "--no-e2e", "--single-pass", "--steps", "3", "--warmup", "1"])
     assert strong["sketch_md5"] == half["sketch_md5"]
+
+
+def test_bench_world_eight_end_to_end_on_one_gpu():
+    """`python bench.py --gpus 8` — the driver's N = 8 invocation — with the eight ranks on GPU 0 over the host transport.
+    C4 is laid out so that its ragged last step leaves ranks 2..7 WITHOUT any interval (8 x 1.85 M reads = 148 intervals = one
+    whole step of 128 + one of 20: rank 0 holds 16, rank 1 four), the case that only exists from world 3 up; the sharded
+    sketch must be the single-rank sketch of the same 8 x longer stream, C4's the single-rank sketch of its 14.8 M reads."""
+    import hashlib
+    import numpy as np
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(HULK_BENCH_TRANSPORT="gloo", HULK_BENCH_PREWARM_S="0", HULK_BENCH_C4_READS_PER_RANK="1850000", HULK_BENCH_LONG_STEPS="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=1800, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in out, k
+    assert not [k for k in out if k.endswith("_error")], {k: out[k] for k in out if k.endswith("_error")}
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["mode"] == "sharded"
+    assert out["config"]["reads_per_step"] == 8 * out["config"]["reads_per_rank_step"] == 12_800_000
+    assert abs(out["ms_per_step"] * out["value"] / 1e3 - out["config"]["reads_per_step"]) < 1.0
+    cs = out["collective"]["timed_pass"]
+    assert cs["steps_full"] + cs["steps_delta"] == 3 and cs["steps_full"] >= 1 and cs["steps_delta"] >= 1 and cs["bytes_received"] > 0
+    assert [o["mode"] for o in out["other_scaling"]] == ["sliced-strong", "sliced-weak"]
+    assert out["c4_reads"] == 14_800_000 and out["c4_steps"] == 2
+    ce = out["c4_exchange"]
+    assert ce["steps_full"] + ce["steps_delta"] == 2 and ce["steps_full"] >= 1
+    # the same global stream on ONE rank: 3 steps of 128 intervals = 24 plain steps of 16
+    one = _run(["--no-cpu-baseline", "--no-cold", "--no-e2e", "--single-pass", "--steps", "16", "--warmup", "8"])
+    assert one["config"]["total_reads"] == 16 * 1_600_000
+    assert out["sketch_md5"] == one["sketch_md5"]
+    # C4's stream on one rank through the plain interval rule
+    import torch
+    import hulk_amd
+    from hulk_amd import synth
+    g = hulk_amd.GpuSketcher(21, 9, 512, interval=100_000)
+    for first in range(0, 14_800_000, 1_600_000):
+        n = min(1_600_000, 14_800_000 - first)
+        b, off = synth.reads_torch(first, n, 150)
+        torch.cuda.synchronize()
+        g.add_reads_device(b.data_ptr(), off.data_ptr(), n, 150, b.numel())
+        g.synchronize()
+    g.finish()
+    m, _ = g.sketch()
+    g.close()
+    assert out["c4_sketch_md5"] == hashlib.md5(m.astype("<u8").tobytes()).hexdigest()
 
 
 def test_bench_gpus_2_spawns_or_refuses():

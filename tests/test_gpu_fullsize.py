@@ -22,19 +22,11 @@ def gpu():
     return hulk_amd
 
 
-def _run_stream(k, S, interval, decay, n_reads, chunk, batch):
+def _run_stream(k, S, interval, decay, n_reads, chunk, batch, pieces=0):
     """Sketch synthetic reads [0, n_reads) fed as device-resident chunks of `chunk` reads."""
     import torch
     from hulk_amd import synth
-    old = os.environ.get("HULK_BATCH")
-    os.environ["HULK_BATCH"] = str(batch)
-    try:
-        g = gpu().GpuSketcher(k, 9, S, interval, decay)
-    finally:
-        if old is None:
-            os.environ.pop("HULK_BATCH", None)
-        else:
-            os.environ["HULK_BATCH"] = old
+    g = gpu().GpuSketcher(k, 9, S, interval, decay, batch=batch, bin_pieces=pieces)
     assert g.batch_size == batch
     first = 0
     while first < n_reads:
@@ -61,9 +53,13 @@ def test_c2_full_size_invariances():
     # other batch size, other call boundaries (not multiples of the interval): bit-identical sketch
     m2, w2, c2 = _run_stream(21, 512, 100_000, 1.0, n, 1_234_567, 5)
     assert np.array_equal(m1, m2) and np.array_equal(w1, w2) and c1 == c2
-    # determinism of the two-stream pipeline
+    # determinism of the pipeline (a batch binned in 4 pieces on two work streams, flushed on a third)
     m3, w3, _ = _run_stream(21, 512, 100_000, 1.0, n, 1_600_000, 16)
     assert np.array_equal(m1, m3) and np.array_equal(w1, w3)
+    # ... and the pieces change nothing: one piece on the context's stream, eight, sixteen
+    for pieces in (1, 8, 16):
+        m4, w4, c4 = _run_stream(21, 512, 100_000, 1.0, n, 1_600_000, 16, pieces=pieces)
+        assert np.array_equal(m1, m4) and np.array_equal(w1, w4) and c1 == c4, pieces
 
 
 def test_c2_prefix_against_oracle():
@@ -112,7 +108,7 @@ def test_c3_shape_drift_batch_invariance():
     must not depend on how many intervals are flushed per pass over the table."""
     n = 5_000_000
     m1, w1, c1 = _run_stream(31, 1024, 100_000, 0.02, n, 1_600_000, 16)
-    m2, w2, c2 = _run_stream(31, 1024, 100_000, 0.02, n, 900_001, 3)
+    m2, w2, c2 = _run_stream(31, 1024, 100_000, 0.02, n, 900_001, 3, pieces=1)
     assert c1 == c2 and c1["n_reads"] == n
     assert np.array_equal(m1, m2) and np.array_equal(w1, w2)
     assert m1.max() < 31 ** 4 and np.all(np.isfinite(w1))
@@ -155,17 +151,44 @@ def test_drift_pruning_against_oracle_many_intervals(decay):
     o.close()
 
 
+@pytest.mark.parametrize("extra", [1, 2, 3])
+def test_host_chunk_of_8_mib_and_a_few_bytes_is_copied_whole(extra):
+    """hulk_add_reads copies a chunk of >= 8 MB into pinned staging with four threads.  With pieces of floor(n / 4) bytes
+    rounded up to 64 (as first written) the last n mod 4 bytes never reached the staging buffer whenever floor(n / 4) was a
+    multiple of 64 — n = 8 MiB + 1..3 — and the chunk's last read was sketched with whatever the buffer held before
+    (ADVICE r3).  Both staging sets are dirtied with other reads first; the device-resident path is the comparison."""
+    import torch
+    nbytes = (8 << 20) + extra
+    assert (nbytes // 4) % 64 == 0 and nbytes % 4 == extra
+    rng = np.random.default_rng(80 + extra)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    n = nbytes // 150
+    lens = np.full(n, 150, dtype=np.uint64)
+    lens[-1] += nbytes - int(lens.sum())                          # the last read takes the remainder: its last bases are the bytes at stake
+    offsets = np.zeros(n + 1, dtype=np.uint64); offsets[1:] = np.cumsum(lens)
+    real = acgt[rng.integers(0, 4, nbytes)]
+    filler = acgt[rng.integers(0, 4, nbytes)]
+    filler[-4:] = np.where(real[-4:] == ord("A"), ord("C"), ord("A")).astype(np.uint8)   # what a stale tail would look like
+    g = gpu().GpuSketcher(21, 9, 4)
+    d = gpu().GpuSketcher(21, 9, 4)
+    for data in (filler, filler, real):                           # two staging sets: both hold the filler when `real` arrives
+        g.add_reads(data, offsets)
+        tb, to = torch.from_numpy(data).cuda(), torch.from_numpy(offsets.astype(np.int64)).cuda()
+        torch.cuda.synchronize()
+        d.add_reads_device(tb.data_ptr(), to.data_ptr(), n, int(lens.max()), nbytes)
+        d.synchronize()
+    assert np.array_equal(g.histogram(), d.histogram())
+    assert g.counters() == d.counters()
+    g.close(); d.close()
+
+
 def test_host_buffers_in_chunks_equal_device_path():
     """hulk_add_reads with 1.3 M reads in ONE call: three chunks through the two pinned staging sets (chunk borders
     inside intervals) — same sketch and counters as the device-resident path."""
     from hulk_amd import synth
     n = 1_300_000
     m, w, c = _run_stream(21, 64, 100_000, 1.0, n, 1_300_000, 16)
-    os.environ["HULK_BATCH"] = "16"
-    try:
-        g = gpu().GpuSketcher(21, 9, 64, 100_000, 1.0)
-    finally:
-        os.environ.pop("HULK_BATCH", None)
+    g = gpu().GpuSketcher(21, 9, 64, 100_000, 1.0, batch=16)
     bases, offsets = synth.reads_numpy(0, n, L)
     g.add_reads(bases, offsets)
     bases[:] = 0                                   # the call has copied the buffers: scribbling over them changes nothing

@@ -21,12 +21,12 @@ def test_fuzz_slice():
 
 @pytest.mark.parametrize("full", [False, True])
 def test_fuzz_slice_of_the_multi_rank_protocol(full):
-    """tools/fuzz_shard.py: G = 1..5 ranks as threads of one process on the one GPU, connected by an in-process exchange
+    """tools/fuzz_shard.py: G = 1..8 ranks as threads of one process on the one GPU, connected by an in-process exchange
     function over the library's host transport; hulk_step_sharded (spectra / count-min-increment exchange, ragged last steps,
     ranks without reads, drift) and hulk_step_sliced against the oracle.  full: the spectra exchange on every step."""
     env = dict(os.environ)
     if full:
-        env["HULK_SHARD_FULL"] = "1"
+        env["FUZZ_SHARD_FULL"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_shard.py"), "30", "17" if full else "16"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]

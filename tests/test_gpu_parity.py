@@ -28,9 +28,9 @@ def random_reads(rng, n, length, alphabet=b"ACGT"):
     return [bytes(a[rng.integers(0, len(a), size=l)]) for l in lens]
 
 
-def run_both(seqs, k, w, S, interval=0, num_bins=0, batches=1, decay=1.0):
+def run_both(seqs, k, w, S, interval=0, num_bins=0, batches=1, decay=1.0, batch=0):
     o = pyorc.Sketcher(k, w, S, num_bins, decay, interval)
-    g = gpu().GpuSketcher(k, w, S, interval, decay, num_bins)
+    g = gpu().GpuSketcher(k, w, S, interval, decay, num_bins, batch=batch)
     bases, offsets = pack_reads(seqs)
     o.add_reads(bases, offsets)
     # feed the GPU in several host batches to exercise interval splitting across calls
@@ -249,16 +249,15 @@ def test_jump_hash_many_keys_large_bins():
 
 
 @pytest.mark.parametrize("batch", [1, 3, 16])
-def test_interval_batches_ring_wraparound(batch, monkeypatch):
-    """Intervals are flushed in batches of HULK_BATCH spectra held in a ring; uneven host calls leave
+def test_interval_batches_ring_wraparound(batch):
+    """Intervals are flushed in batches of hulk_params.batch spectra held in a ring; uneven host calls leave
     partial intervals pending across calls and wrap the ring many times.  Must equal the oracle's
     flush-every-interval result bit for bit."""
-    monkeypatch.setenv("HULK_BATCH", str(batch))
     rng = np.random.default_rng(batch)
     k, w, S, interval = 11, 5, 16, 50
     seqs = random_reads(rng, 2113, (60, 150), b"ACGTN" if batch == 3 else b"ACGT")
     o = pyorc.Sketcher(k, w, S, 0, 1.0, interval)
-    g = gpu().GpuSketcher(k, w, S, interval)
+    g = gpu().GpuSketcher(k, w, S, interval, batch=batch)
     assert g.batch_size == batch
     bases, offsets = pack_reads(seqs)
     o.add_reads(bases, offsets)
@@ -273,30 +272,52 @@ def test_interval_batches_ring_wraparound(batch, monkeypatch):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("pieces,piece_min", [(2, 64), (3, 700), (4, 1), (16, 1), (8, 5000)])
+def test_batch_binned_in_pieces_on_two_work_streams(pieces, piece_min):
+    """A batch of short reads is cut at interval borders into hulk_params.bin_pieces pieces that alternate between the
+    context's stream and a second work stream, each with its own minimizer list (hulk_flush.hip, bin_reads).  Uneven host
+    calls (partial intervals pending across calls), reads with N (each lane's deferred-read list) and reads for the
+    generic kernel in between: spectrum, counters, count-min and sketch equal the oracle's, whatever the pieces."""
+    rng = np.random.default_rng(1000 + pieces)
+    k, w, S, interval = 15, 9, 24, 500
+    seqs = random_reads(rng, 14_000, (40, 150), b"ACGTN" if pieces == 3 else b"ACGT")      # (min length w + k - 1 = 23)
+    o = pyorc.Sketcher(k, w, S, 0, 1.0, interval)
+    g = gpu().GpuSketcher(k, w, S, interval, batch=8 if pieces != 16 else 16, bin_pieces=pieces, bin_min_reads=piece_min)
+    bases, offsets = pack_reads(seqs)
+    o.add_reads(bases, offsets)
+    cuts = [0, 3999, 4000, 9001, 9300, 14_000]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        g.add_reads(bases, offsets[a:b + 1])
+    assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32))   # (14,000 = 28 whole intervals: empty)
+    o.finish(); g.finish()
+    oc, gc = o.counters(), g.counters()
+    for key in ("n_reads", "n_minimizers", "total_len"):
+        assert oc[key] == gc[key], key
+    assert np.array_equal(g.cms(), o.cms())
+    assert_same_sketch(o, g)
+    g.close(); o.close()
+
+
 def test_bin_then_flush_batch_equals_interval_rule():
     """The multi-GPU entry points (bin_reads_device + flush_batch) on one GPU = the interval rule."""
     import torch
     from hulk_amd import synth
     k, w, S, interval, T = 13, 7, 12, 300, 5
-    os_env = __import__("os").environ
-    os_env["HULK_BATCH"] = str(T)
-    try:
-        g = gpu().GpuSketcher(k, w, S, 0)
-        o = pyorc.Sketcher(k, w, S, 0, 1.0, interval)
-        for step in range(3):
-            b, off = synth.reads_torch(step * interval * T, interval * T, 120)
-            torch.cuda.synchronize()        # generated on torch's stream; the context runs on its own
-            g.bin_reads_device(b.data_ptr(), off.data_ptr(), interval * T, 120, b.numel(), interval)
-            g.flush_batch(T)
-            hb, ho = synth.reads_numpy(step * interval * T, interval * T, 120)
-            o.add_reads(hb, ho)
-        torch.cuda.synchronize()
-        o.finish(); g.finish()
-        assert_same_sketch(o, g)
-        assert np.array_equal(g.cms(), o.cms())
-        g.close(); o.close()
-    finally:
-        os_env.pop("HULK_BATCH", None)
+    g = gpu().GpuSketcher(k, w, S, 0, batch=T)
+    assert g.batch_size == T
+    o = pyorc.Sketcher(k, w, S, 0, 1.0, interval)
+    for step in range(3):
+        b, off = synth.reads_torch(step * interval * T, interval * T, 120)
+        torch.cuda.synchronize()        # generated on torch's stream; the context runs on its own
+        g.bin_reads_device(b.data_ptr(), off.data_ptr(), interval * T, 120, b.numel(), interval)
+        g.flush_batch(T)
+        hb, ho = synth.reads_numpy(step * interval * T, interval * T, 120)
+        o.add_reads(hb, ho)
+    torch.cuda.synchronize()
+    o.finish(); g.finish()
+    assert_same_sketch(o, g)
+    assert np.array_equal(g.cms(), o.cms())
+    g.close(); o.close()
 
 
 DRIFT_RTOL = 1e-7   # the count-min decay is evaluated in closed form (w^gap) instead of step by step
@@ -444,21 +465,17 @@ def test_many_long_reads_grouped_launches():
     g.close(); o.close()
 
 
-def test_scan_pruning_is_exact_and_effective(monkeypatch):
+def test_scan_pruning_is_exact_and_effective():
     """The bound test of k_cws_scan must not change a single bit of the sketch, and after the first
     intervals of a stream it must skip most of the table (count-min estimates only grow)."""
     from hulk_amd import synth
     bases, offsets = synth.reads_numpy(0, 60000, 150)
     res = {}
+    from hulk_amd import _lib
     for prune in (True, False, "tiles-only"):
-        monkeypatch.delenv("HULK_NO_PRUNE", raising=False)
-        monkeypatch.delenv("HULK_NO_SKIP", raising=False)
-        if prune is False:
-            monkeypatch.setenv("HULK_NO_PRUNE", "1")
-        elif prune == "tiles-only":
-            monkeypatch.setenv("HULK_NO_SKIP", "1")            # per-tile bound only, no whole-batch bound
-        monkeypatch.setenv("HULK_BATCH", "4")
-        g = gpu().GpuSketcher(15, 9, 96, interval=2000)
+        # False: neither bound; "tiles-only": per-tile bound only, no whole-batch bound
+        flags = _lib.HULK_FLAG_NO_PRUNE if prune is False else _lib.HULK_FLAG_NO_SKIP if prune == "tiles-only" else 0
+        g = gpu().GpuSketcher(15, 9, 96, interval=2000, batch=4, flags=flags)
         g.add_reads(bases, offsets)
         g.finish()
         res[prune] = (g.sketch(), g.scan_stats(), g.cms())
@@ -527,14 +544,13 @@ def test_two_groups_per_read(k, w, lens, n):
 
 @pytest.mark.parametrize("batch", [1, 3, 16])
 @pytest.mark.parametrize("decay", [0.02, 0.5])
-def test_k31_concept_drift_against_oracle(decay, batch, monkeypatch):
+def test_k31_concept_drift_against_oracle(decay, batch):
     """BASELINE config C3's mode at its k: k = 31 (923,521 bins, minimizer values use all 64 bits: integer minima,
     rolling k-mers) WITH concept drift — count-min uniform scaling (countmin.go:141-147) and the
     `A < w/decayWeight` update (histosketch.go:139-153) — against the oracle, for three interval-batch sizes."""
-    monkeypatch.setenv("HULK_BATCH", str(batch))
     rng = np.random.default_rng(31_000 + int(decay * 100))
     seqs = random_reads(rng, 30_000, 150)
-    o, g = run_both(seqs, 31, 9, 4, interval=5_000, batches=3, decay=decay)
+    o, g = run_both(seqs, 31, 9, 4, interval=5_000, batches=3, decay=decay, batch=batch)
     assert g.batch_size == batch
     o.finish(); g.finish()
     om, ow = o.sketch(); gm, gw = g.sketch()

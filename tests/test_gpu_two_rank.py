@@ -32,11 +32,6 @@ def _free_port():
 
 def _worker(rank, world, port, q, overlap, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    os.environ["HULK_BATCH"] = str(BATCH)
-    if not overlap:
-        os.environ["HULK_NO_OVERLAP"] = "1"
-    if mode == "sharded-full":
-        os.environ["HULK_SHARD_FULL"] = "1"
     import torch
     import torch.distributed as dist
     import hulk_amd
@@ -46,7 +41,10 @@ def _worker(rank, world, port, q, overlap, mode):
     torch.cuda.set_device(0)
     sb, sc = slot_shard(S, rank, world)
     sharded = mode.startswith("sharded")
-    sk = hulk_amd.GpuSketcher(K, W, S, interval=I if sharded else 0, decay_ratio=1.0, device=0, slot_begin=sb, slot_count=sc)
+    from hulk_amd import _lib
+    flags = (0 if overlap else _lib.HULK_FLAG_NO_OVERLAP) | (_lib.HULK_FLAG_SHARD_FULL if mode == "sharded-full" else 0)
+    sk = hulk_amd.GpuSketcher(K, W, S, interval=I if sharded else 0, decay_ratio=1.0, device=0, slot_begin=sb, slot_count=sc,
+                              batch=BATCH, flags=flags)
     assert sk.batch_size == BATCH
     sk.comm_init_host(rank, world, gloo_exchange(dist))
     keep = []
@@ -136,9 +134,8 @@ def test_rccl_world_one_is_the_single_rank_sketch():
     import hulk_amd
     from hulk_amd import synth
     from hulk_amd.distributed import num_steps, step_share
-    os.environ["HULK_BATCH"] = str(BATCH)
     total = 5 * BATCH * I + 700
-    sk = hulk_amd.GpuSketcher(K, W, S, interval=I)
+    sk = hulk_amd.GpuSketcher(K, W, S, interval=I, batch=BATCH)
     sk.comm_init(hulk_amd.GpuSketcher.comm_unique_id(), 0, 1)
     keep = []
     for s_ in range(num_steps(total, BATCH, I, 1)):
@@ -170,8 +167,7 @@ def test_sharded_step_reports_too_few_used_bins():
     import hulk_amd
     from hulk_amd import synth
     from hulk_amd._lib import HulkError
-    os.environ["HULK_BATCH"] = str(BATCH)
-    sk = hulk_amd.GpuSketcher(K, W, S, interval=I)
+    sk = hulk_amd.GpuSketcher(K, W, S, interval=I, batch=BATCH)
     sk.comm_init_loopback(0, 1)
     keep = []
     for s_ in range(4):
@@ -196,9 +192,8 @@ def test_sharded_step_from_host_slices():
     from hulk_amd import synth
     from hulk_amd._lib import HulkError
     from hulk_amd.distributed import num_steps, step_share
-    os.environ["HULK_BATCH"] = str(BATCH)
     total = 3 * BATCH * I + 2 * I + 500
-    sk = hulk_amd.GpuSketcher(K, W, S, interval=I)
+    sk = hulk_amd.GpuSketcher(K, W, S, interval=I, batch=BATCH)
     sk.comm_init_loopback(0, 1)
     for s_ in range(num_steps(total, BATCH, I, 1)):
         first, n, si = step_share(s_, BATCH, I, 0, 1, total)

@@ -3,9 +3,10 @@
 HOST transport): G ranks = G contexts on the one GPU, each driven by its own thread of this process, connected by an
 in-process exchange function (a barrier and shared arrays stand in for the network); the gathered sketch and the count-min
 counters must equal the CPU oracle's over the same global stream.  Random k, w, sketch size, interval, batch size T, world
-size (1..5: slot shards and ragged last steps of every shape), stream length (partial last interval), decay (concept drift
-takes the spectra exchange on every step), reads with N.  HULK_SHARD_FULL=1 in the environment forces the spectra exchange
-on every step of every case (the library reads it once per process).
+size (1..8: slot shards and ragged last steps of every shape, ranks without any interval), stream length (partial last
+interval), decay (concept drift takes the spectra exchange on every step), reads with N, the work lanes of the binning side
+(hulk_params.bin_pieces / bin_min_reads).  FUZZ_SHARD_FULL=1 (or the older HULK_SHARD_FULL=1) in the environment forces the
+spectra exchange on every step of every case (HULK_FLAG_SHARD_FULL on every context).
 usage: fuzz_shard.py [n_cases] [seed]     (run on the GPU box)"""
 import os
 import sys
@@ -17,12 +18,15 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch  # noqa: F401  (before libhulkhip, see hulk_amd/_lib.py)
 import hulk_amd
+from hulk_amd import _lib
 from hulk_amd.distributed import interval_slice, num_steps, slot_shard, step_share
 from oracle import pyorc
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
+FORCE_FULL = bool(os.environ.get("FUZZ_SHARD_FULL") or os.environ.get("HULK_SHARD_FULL"))
+MAX_WORLD = int(os.environ.get("FUZZ_MAX_WORLD", "8"))
 
 
 class Exchange:
@@ -61,7 +65,7 @@ for case in range(n_cases):
     k = int(rng.choice([11, 13, 15, 15, 17, 21]))
     w = int(rng.choice([4, 5, 9, 9, 12]))
     S = int(rng.choice([3, 8, 16, 50]))
-    world = int(rng.integers(1, 6))
+    world = int(rng.integers(1, MAX_WORLD + 1))
     T = int(rng.choice([1, 2, 4, 8, 16]))
     I = int(rng.choice([700, 1500, 3000]))
     L = int(rng.choice([60, 100, 150, 260])) if k + 16 * w > 270 else int(rng.choice([60, 100, 150]))
@@ -77,7 +81,7 @@ for case in range(n_cases):
     if mode == "sliced":
         total = n_int * I                                            # (whole intervals: every rank slices every interval)
     bases, offsets = reads(rng, total, L, alph)
-    os.environ["HULK_BATCH"] = str(T)
+    pieces, piece_min = int(rng.choice([1, 2, 3, 4, 8])), int(rng.choice([64, 500, 2000]))   # work lanes of the binning side
     ex = Exchange(world)
     out, errs = [None] * world, []
 
@@ -86,7 +90,8 @@ for case in range(n_cases):
             torch.cuda.set_device(0)
             sb, sc = slot_shard(S, rank, world)
             sk = hulk_amd.GpuSketcher(k, w, S, interval=(0 if mode == "sliced" else I), decay_ratio=decay, device=0,
-                                      slot_begin=sb, slot_count=sc)
+                                      slot_begin=sb, slot_count=sc, batch=T, bin_pieces=pieces, bin_min_reads=piece_min,
+                                      flags=_lib.HULK_FLAG_SHARD_FULL if FORCE_FULL else 0)
             sk.comm_init_host(rank, world, ex.make(rank))
             if mode != "sliced":
                 for s_ in range(num_steps(total, T, I, world)):

@@ -8,5 +8,5 @@ leg python tools/fuzz_parity.py 100000 $S
 FUZZ_BIG_K=1 leg python tools/fuzz_parity.py 100000 $((S + 1))
 FUZZ_WIDE_W=1 leg python tools/fuzz_parity.py 100000 $((S + 2))
 leg python tools/fuzz_shard.py 100000 $((S + 3))
-HULK_SHARD_FULL=1 leg python tools/fuzz_shard.py 100000 $((S + 4))
+FUZZ_SHARD_FULL=1 leg python tools/fuzz_shard.py 100000 $((S + 4))
 cat $O

@@ -7,13 +7,15 @@ ap.add_argument("--k", type=int, default=31); ap.add_argument("--w", type=int, d
 ap.add_argument("--S", type=int, default=1024); ap.add_argument("--decay", type=float, default=0.02)
 ap.add_argument("--reads", type=int, default=5_000_000); ap.add_argument("--interval", type=int, default=100_000)
 ap.add_argument("--batch", type=int, default=10); ap.add_argument("--len", type=int, default=150)
+ap.add_argument("--pieces", type=int, default=0, help="hulk_params.bin_pieces (0 = the library default)")
+ap.add_argument("--serial", action="store_true", help="HULK_FLAG_NO_OVERLAP: every kernel alone (profiling)")
 a = ap.parse_args()
-os.environ["HULK_BATCH"] = str(a.batch)
 import torch, hulk_amd
 from hulk_amd import synth
 t0 = time.time()
 sk = hulk_amd.GpuSketcher(a.k, a.w, a.S, interval=a.interval, decay_ratio=a.decay,
-                          stream=torch.cuda.current_stream().cuda_stream)
+                          stream=torch.cuda.current_stream().cuda_stream, batch=a.batch, bin_pieces=a.pieces,
+                          flags=16 if a.serial else 0)
 torch.cuda.synchronize(); t_create = time.time() - t0
 step = a.interval * a.batch
 bufs = []
