@@ -276,7 +276,7 @@ def main():
     ap.add_argument("--n-frac", type=float, default=0.0,
                     help="variant workload: this fraction of the reads gets one 'N' at a pseudo-random position (real Illumina "
                          "data has such reads; they leave the table-free fast path of the minimizer kernel).  Not the headline.")
-    ap.add_argument("--pieces", type=int, default=0, help="hulk_params.bin_pieces of the timed contexts (0 = the library's default)")
+    ap.add_argument("--lanes", type=int, default=0, help="hulk_params.work_lanes of the timed contexts (0 = the library's default, 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the value_cold pass (C2 exactly: 10 M reads, no warm-up)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the FASTQ file -> sketch figures (N = 1 only)")
@@ -420,8 +420,8 @@ def main():
     global_interval = INTERVAL * world if mode == "sliced-weak" else INTERVAL
     sb, sc = slot_shard(S, rank if not loop_world else 0, shard_world)
 
-    stream = torch.cuda.Stream(device=device)          # the work stream (the library flushes and exchanges on its own second one)
-    torch.cuda.set_stream(stream)
+    stream = torch.cuda.Stream(device=device)          # torch's stream: only the synthetic input is generated on it (and synchronised
+    torch.cuda.set_stream(stream)                      # before use); the contexts run on their own private streams
 
     def make_input(m, max_buf, n_total_steps=None):
         """this rank's share of every step under mode `m`, resident in HBM: (buffers, offsets, reads per spectrum, reads per
@@ -512,9 +512,8 @@ def main():
         sharded = comm and in_mode == "sharded"
         flags = (0 if prune else _lib.HULK_FLAG_NO_PRUNE) | (_lib.HULK_FLAG_NO_OVERLAP if serial else 0)
         def make():
-            return hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL if sharded else 0, decay_ratio=1.0, device=dev_index,
-                                        slot_begin=sb, slot_count=sc, stream=stream.cuda_stream, flags=flags, batch=BATCH,
-                                        bin_pieces=args.pieces)
+            return hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL if (sharded or not comm) else 0, decay_ratio=1.0, device=dev_index,
+                                        slot_begin=sb, slot_count=sc, flags=flags, batch=BATCH, work_lanes=args.lanes)
         sk = make()
         assert sk.batch_size == BATCH
         if comm:
@@ -526,9 +525,8 @@ def main():
                 sk.step_sharded(b.data_ptr(), offs.data_ptr(), n_step, READ_LEN, b.numel(), shard_world * BATCH)
             elif comm:
                 sk.step_sliced(b.data_ptr(), offs.data_ptr(), n_step, READ_LEN, b.numel(), per, BATCH)
-            else:
-                sk.bin_reads_device(b.data_ptr(), offs.data_ptr(), n_step, READ_LEN, b.numel(), reads_per_spectrum=per)
-                sk.flush_batch(BATCH)
+            else:                                  # one GPU: the product's entry point, the interval rule inside (16 flushes per call)
+                sk.add_reads_device(b.data_ptr(), offs.data_ptr(), n_step, READ_LEN, b.numel())
 
         for t in range(warmup):
             one_step(t)
@@ -588,8 +586,7 @@ def main():
         runs = []
         for _ in range(2):            # two complete cold runs, each on its own fresh context; the faster one is reported (both
             t0 = time.perf_counter()  # listed): the timed region is 7 ms, and one host hiccup on a shared box is 100x that
-            sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=dev_index, stream=stream.cuda_stream,
-                                      batch=BATCH, bin_pieces=args.pieces)
+            sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=dev_index, batch=BATCH, work_lanes=args.lanes)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for b, off, n in chunks:
@@ -608,7 +605,7 @@ def main():
     def run_c3():
         """BASELINE configs[2] ("C3") on an HBM-resident sample: k = 31, sketchSize = 1024, concept drift on (decay 0.02),
         interval 100k — 22.7 GB of fp64 CWS tables + 3.8 GB of K; one warm-up batch, then C3["reads"] reads through the
-        interval rule of hulk_add_reads_device, HIP events on the work stream; then the same again with every kernel alone
+        interval rule of hulk_add_reads_device, wall clock between two hulk_synchronize; then the same again with every kernel alone
         and k_minimizer_fast / k_cmsd_freq (the count-min replay with decay, countmin.go:141-147) bracketed."""
         k3, w3, S3, I3 = C3["k"], C3["w"], C3["S"], C3["interval"]
         stp = I3 * BATCH
@@ -620,8 +617,8 @@ def main():
                            "warm-up batch (BASELINE states 50 M: tests/test_gpu_fullsize.py::test_c3_full_size_50m_reads)"}
         for label, serial in (("overlapped", False), ("kernels_alone", True)):
             t0 = time.perf_counter()
-            sk = hulk_amd.GpuSketcher(k3, w3, S3, interval=I3, decay_ratio=C3["decay"], device=dev_index, stream=stream.cuda_stream,
-                                      batch=BATCH, bin_pieces=args.pieces, flags=_lib.HULK_FLAG_NO_OVERLAP if serial else 0)
+            sk = hulk_amd.GpuSketcher(k3, w3, S3, interval=I3, decay_ratio=C3["decay"], device=dev_index,
+                                      batch=BATCH, work_lanes=args.lanes, flags=_lib.HULK_FLAG_NO_OVERLAP if serial else 0)
             torch.cuda.synchronize()
             create_s = time.perf_counter() - t0
             b, o = bufs[0]
@@ -630,16 +627,14 @@ def main():
             if serial:
                 sk.set_profiling(2 | 4 | 16)
             state["kick"] = time.monotonic()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
+            t1 = time.perf_counter()
             done, i = 0, 1
             while done < C3["reads"]:
                 b, o = bufs[i % nbuf]
                 sk.add_reads_device(b.data_ptr(), o.data_ptr(), stp, READ_LEN, b.numel())
                 done += stp; i += 1
-            sk.synchronize()
-            e1.record(stream); torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1)
+            sk.synchronize()                       # (private streams: the context's own synchronisation point stops the clock)
+            ms = (time.perf_counter() - t1) * 1e3
             if serial:
                 pr = {kk: sk.get_profile(kk) for kk in ("k_minimizer_fast", "k_jump_bin", "k_jump_left", "k_cmsd_freq")}
                 res["kernels_alone"] = {"ms_per_batch": ms / (done / stp), "reads_per_s": done / ms * 1e3,
@@ -679,7 +674,7 @@ def main():
         t0 = time.perf_counter()
         def make():
             return hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=dev_index, slot_begin=sb,
-                                        slot_count=sc, stream=stream.cuda_stream, batch=BATCH, bin_pieces=args.pieces)
+                                        slot_count=sc, batch=BATCH, work_lanes=args.lanes)
         sk = connect(make(), make)
         torch.cuda.synchronize()
         dist.barrier()
@@ -763,7 +758,7 @@ def main():
                                + (f", VARIANT: {args.n_frac:g} of the reads carry one N" if args.n_frac > 0 else ""),
                    "reads_per_step": reads_per_step, "reads_per_rank_step": reads_per_rank_step,
                    "total_reads": total_reads, "intervals_per_step": BATCH, "global_interval": global_interval,
-                   "mode": mode, "bin_pieces": args.pieces or "library default (4)",
+                   "mode": mode, "work_lanes": args.lanes or 2,
                    "split": ("whole intervals per rank" if mode == "sharded" else "a slice of every interval per rank"),
                    "parallelism": f"read-shard x{world}, replicated count-min, slot-sharded CWS"},
         "scaling_note": ("per-rank work per step is fixed (16 whole intervals = 1.6 M reads), the global interval stays the "
@@ -775,8 +770,8 @@ def main():
         "roofline": None,          # (filled by the `kernels` leg)
         "sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest(),
         "n_minimizers_rank0": counters["n_minimizers"],
-        "timed_pass_note": "no HIP-event brackets in the timed steps; a batch is binned in pieces on two work streams and flushed "
-                           "on a third (the library's default); per-kernel durations: the `kernels` leg",
+        "timed_pass_note": "no HIP-event brackets in the timed steps; consecutive batches are binned on two alternating work streams "
+                           "and flushed on a third, all private to the context (the library's default); per-kernel durations: the `kernels` leg",
     })
     # SURVEY.md §8(d) prices the path at L + 4*S*k^4/I bytes per read (one K pass per interval): a MODEL of the
     # reference's data movement, not traffic this implementation generates (one K pass serves BATCH intervals and

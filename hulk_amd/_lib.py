@@ -42,8 +42,8 @@ class HulkParams(ctypes.Structure):
         ("num_bins", ctypes.c_int32), ("decay_ratio", ctypes.c_double),
         ("interval", ctypes.c_uint32), ("device", ctypes.c_int32),
         ("slot_begin", ctypes.c_uint32), ("slot_count", ctypes.c_uint32),
-        ("cws_source", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("batch", ctypes.c_uint32), ("bin_pieces", ctypes.c_uint32),
-        ("host_copy_threads", ctypes.c_uint32), ("bin_min_reads", ctypes.c_uint32),
+        ("cws_source", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("batch", ctypes.c_uint32), ("work_lanes", ctypes.c_uint32),
+        ("host_copy_threads", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
     ]
 
 

@@ -92,7 +92,8 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     if (p.flags & ~(HULK_FLAG_GAMMA_CPYTHON | HULK_FLAG_NO_PRUNE | HULK_FLAG_NO_SKIP | HULK_FLAG_SHARD_FULL | HULK_FLAG_NO_OVERLAP))
         return fail(nullptr, HULK_ERR_ARG, "unknown flags");
     if (p.batch > (uint32_t)SCAN_BATCH_MAX) return fail(nullptr, HULK_ERR_ARG, "batch must be 0 (default) or 1..16");
-    if (p.bin_pieces > (uint32_t)SCAN_BATCH_MAX) return fail(nullptr, HULK_ERR_ARG, "bin_pieces must be 0 (default) or 1..16");
+    if (p.work_lanes > 2) return fail(nullptr, HULK_ERR_ARG, "work_lanes must be 0 (default), 1 or 2");
+    if (p.reserved != 0) return fail(nullptr, HULK_ERR_ARG, "reserved must be 0");
     if (p.host_copy_threads > 32) return fail(nullptr, HULK_ERR_ARG, "host_copy_threads must be 0 (default) or 1..32");
     if (p.slot_count == 0) { p.slot_begin = 0; p.slot_count = p.sketch_size; }
     if ((uint64_t)p.slot_begin + p.slot_count > p.sketch_size) return fail(nullptr, HULK_ERR_ARG, "slot shard outside sketch");
@@ -129,9 +130,13 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
         return v;
     };
     c->T = knob("HULK_BATCH", p.batch, SCAN_BATCH_MAX, 1, SCAN_BATCH_MAX);
-    c->bin_pieces = knob("HULK_BIN_PIECES", p.bin_pieces, 4, 1, SCAN_BATCH_MAX);
+    // Two work lanes by default — unless count-min decay is on: the replay kernels of that flush hold a CU's whole LDS (112 KB
+    // of counters), a second binning lane keeps k_minimizer_fast workgroups (4 x 39.7 KB) resident on every CU twice as much
+    // of the time, and the flush, which the next batch on the same ring waits for, no longer finds CUs: C3-shaped
+    // 9.3e8 -> 3.0-5.2e8 reads/s with two lanes, C2 +2-4 % (profiles/r04_lanes.txt)
+    const bool decay_on = p.decay_ratio > 0.0 && p.decay_ratio < 1.0;
+    c->work_lanes = knob("HULK_WORK_LANES", p.work_lanes, decay_on ? 1 : 2, 1, 2);
     c->host_copy_threads = knob("HULK_HOST_COPY_THREADS", p.host_copy_threads, 4, 1, 32);
-    c->bin_min_reads = p.bin_min_reads ? p.bin_min_reads : 65536u;
     c->no_overlap = (p.flags & HULK_FLAG_NO_OVERLAP) != 0 || getenv("HULK_NO_OVERLAP") != nullptr;
     c->shard_full = (p.flags & HULK_FLAG_SHARD_FULL) != 0 || getenv("HULK_SHARD_FULL") != nullptr;
     c->ring_n = c->T + 1;
@@ -222,6 +227,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_scanmap); hipFree(c->d_slotmin); hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited); hipFree(c->d_kminslot);
     for (auto &hs : c->hstage) {
         if (hs.ev) hipEventDestroy(hs.ev);
+        if (hs.ev1) hipEventDestroy(hs.ev1);
         if (hs.h_bases) hipHostFree(hs.h_bases);
         if (hs.h_off) hipHostFree(hs.h_off);
         hipFree(hs.d_bases); hipFree(hs.d_off);
@@ -229,7 +235,6 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_min_slots);
     for (auto &ln : c->lane) {
         if (ln.stream) { hipStreamSynchronize(ln.stream); hipStreamDestroy(ln.stream); }
-        if (ln.ev_k1a) hipEventDestroy(ln.ev_k1a);
         hipFree(ln.d_slow_list); hipFree(ln.d_slow_count);
         hulk::MinimizerList &ml = ln.ml;
         hipFree(ml.x); hipFree(ml.slot); hipFree(ml.key); hipFree(ml.cnt); hipFree(ml.off); hipFree(ml.bsum); hipFree(ml.partial);
@@ -306,7 +311,7 @@ int hulk_bin_reads_device_at(hulk_ctx *c, const uint8_t *d_bases, const uint64_t
     const uint64_t skip = (uint64_t)first_spectrum * reads_per_spectrum;       // as if that many reads had been binned before
     for (uint64_t pos = 0; pos < n; pos += MAX_READS_PER_LAUNCH) {
         const uint64_t chunk = std::min<uint64_t>(MAX_READS_PER_LAUNCH, n - pos);
-        int rc = bin_reads(c, d_bases, d_offsets + pos, chunk, max_read_len, bases_bytes, reads_per_spectrum, skip + pos);
+        int rc = bin_reads(c, d_bases, d_offsets + pos, chunk, max_read_len, bases_bytes, reads_per_spectrum, skip + pos, true);
         if (rc != HULK_OK) return rc;
     }
     c->seq_count += n;
@@ -368,8 +373,7 @@ int hulk_add_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, u
         hulk_ctx::HostStage &hs = *hsp;
         const int rc = hulk_add_reads_device(c, hs.d_bases, hs.d_off, cn, (uint32_t)cmax, hs.cap_bases);
         if (rc != HULK_OK) return rc;
-        HIPCHK(c, hipEventRecord(hs.ev, c->stream));
-        hs.busy = true;
+        { const int rcb = stage_mark_busy(c, hs); if (rcb != HULK_OK) return rcb; }
         i0 = i1;
     }
     return HULK_OK;
@@ -377,10 +381,11 @@ int hulk_add_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, u
 
 int hulk_add_histogram(hulk_ctx *c, const uint32_t *bins) {
     if (!c || !bins) return fail(c, HULK_ERR_ARG, "NULL");
-    HIPCHK(c, hipMemcpyAsync(c->d_hist_tmp, bins, (size_t)c->B * 4, hipMemcpyHostToDevice, c->stream));
+    hipStream_t s = ring_stream(c);                              // (every write to a ring's spectra goes through its lane)
+    HIPCHK(c, hipMemcpyAsync(c->d_hist_tmp, bins, (size_t)c->B * 4, hipMemcpyHostToDevice, s));
     { int rcw = ring_ready_for_writes(c); if (rcw != HULK_OK) return rcw; }
-    HIPCHK(c, launch_add_hist(c->stream, ring_hist(c) + (size_t)c->ring_base * (size_t)c->B, c->d_hist_tmp, c->B));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, launch_add_hist(s, ring_hist(c) + (size_t)c->ring_base * (size_t)c->B, c->d_hist_tmp, c->B));
+    HIPCHK(c, hipStreamSynchronize(s));
     c->hist_hook_used = true;
     return HULK_OK;
 }

@@ -234,7 +234,7 @@ int hulk_step_sharded(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_off
     }
     if (c->shard_full) full = true;                                           // HULK_FLAG_SHARD_FULL: always the spectra exchange
     hipStream_t s = flush_stream_of(c);
-    HIPCHK(c, hipEventRecord(c->ev_binned, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_binned, ring_stream(c)));        // (the binning ran on the ring's work lane)
     if (!no_overlap_mode(c)) HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
     const int ring = c->cur_ring;
     uint32_t *hist = ring_hist(c);
@@ -312,8 +312,7 @@ int hulk_step_sharded_host(hulk_ctx *c, const uint8_t *bases, const uint64_t *of
     hulk_ctx::HostStage *hs = nullptr;
     { const int rcs = stage_host_reads(c, bases, offsets, 0, n, &hs); if (rcs != HULK_OK) return rcs; }
     const int rc = hulk_step_sharded(c, hs->d_bases, hs->d_off, n, (uint32_t)max_len, hs->cap_bases, step_intervals);
-    HIPCHK(c, hipEventRecord(hs->ev, c->stream));               // (the binning kernels are on the work stream)
-    hs->busy = true;
+    { const int rcb = stage_mark_busy(c, *hs); if (rcb != HULK_OK) return rcb; }      // (copies on the context's stream, kernels on a work lane)
     return rc;
 }
 

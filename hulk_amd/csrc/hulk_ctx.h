@@ -99,23 +99,23 @@ struct hulk_ctx {
     // and over PCIe runs while the kernels of chunk i do
     struct HostStage {
         uint8_t *h_bases = nullptr, *d_bases = nullptr; uint64_t *h_off = nullptr, *d_off = nullptr;
-        size_t cap_bases = 0, cap_off = 0; hipEvent_t ev = nullptr; bool busy = false;
+        size_t cap_bases = 0, cap_off = 0; hipEvent_t ev = nullptr, ev1 = nullptr; bool busy = false, busy1 = false;
     } hstage[2];
     int hstage_cur = 0;
-    // Work lanes of the short-read path (hulk_flush.hip, bin_reads): a batch is binned in pieces that alternate between the
-    // context's stream (lane 0) and a second work stream (lane 1, created with the first split batch); a lane owns the
-    // per-launch buffers of the short-read kernels: the minimizer list (grow-only) and the list of reads the fast kernel
-    // deferred (built by k_region_offsets)
+    // Work lanes (hulk_flush.hip, lane_stream): every launch that touches spectrum ring r runs on lane r's stream — lane 0 the
+    // context's stream, lane 1 a stream of its own, created with the first batch of ring 1 — so consecutive batches overlap.
+    // A lane owns the per-launch buffers of the short-read kernels: the minimizer list (grow-only) and the list of reads the
+    // fast kernel deferred (built by k_region_offsets)
     struct BinLane {
         hipStream_t stream = nullptr;                   // lane 1 only (lane 0 runs on the context's stream)
-        hipEvent_t ev_k1a = nullptr;                    // behind the lane's latest k_minimizer_fast
         hulk::MinimizerList ml{}; uint64_t ml_regions = 0;
         uint32_t *d_slow_list = nullptr, *d_slow_count = nullptr; uint64_t d_slow_cap = 0;
     } lane[2];
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;    // context stream -> lane 1 at the start of a split batch, and back
-    uint32_t bin_pieces = 1;                            // pieces a batch is binned in (hulk_params.bin_pieces)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;    // context stream -> lane 1 in front of a batch, and back (lanes_join)
+    hipStream_t last_bin_stream = nullptr;              // the stream the latest binning launches went to
+    bool copies_pending = false;                        // host -> device copies were queued on the context's stream since the last fork
+    uint32_t work_lanes = 2;                            // hulk_params.work_lanes
     uint32_t host_copy_threads = 4;                     // hulk_params.host_copy_threads
-    uint32_t bin_min_reads = 65536;                     // hulk_params.bin_min_reads
     bool no_overlap = false, shard_full = false;        // HULK_FLAG_NO_OVERLAP, HULK_FLAG_SHARD_FULL
     uint64_t *d_long_xs = nullptr, *d_long_table = nullptr; uint8_t *d_long_valid = nullptr;   // long-sequence scratch
     void *d_long_desc = nullptr; uint64_t long_desc_cap = 0;
@@ -159,7 +159,11 @@ hipEvent_t ring_write_event(hulk_ctx *c);
 int ring_ready_for_writes(hulk_ctx *c);
 int sync_all(hulk_ctx *c);
 int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
-              uint32_t max_len, uint64_t bases_bytes, uint64_t interval, uint64_t fill);
+              uint32_t max_len, uint64_t bases_bytes, uint64_t interval, uint64_t fill, bool join = false);
+hipStream_t lane_stream(hulk_ctx *c, int ring);
+hipStream_t ring_stream(hulk_ctx *c);
+int lanes_join(hulk_ctx *c);
+int stage_mark_busy(hulk_ctx *c, hulk_ctx::HostStage &hs);
 int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &fb);
 bool no_overlap_mode(const hulk_ctx *c);
 hipStream_t flush_stream_of(hulk_ctx *c);

@@ -10,6 +10,18 @@ namespace hulk {
 
 uint32_t *ring_hist(hulk_ctx *c) { return c->d_hist + (size_t)c->cur_ring * (size_t)c->ring_n * (size_t)c->B; }
 
+// The work lane of spectrum ring r.  With two lanes (hulk_params.work_lanes, the default) every launch that touches ring r —
+// binning, the deferred reads' generic kernel, the test hook — runs on lane r's stream, so consecutive batches, which
+// alternate between the rings, alternate between two streams and are NOT ordered against each other: batch n+1's
+// k_minimizer_fast (VALU + LDS, 4 waves per SIMD) runs beside batch n's k_jump_bin / k_jump_left / spectrum kernels (tails,
+// low occupancy) and the two fill each other's issue bubbles — what two independent contexts fed alternately measured as
+// +11 % (tools/two_ctx_overlap.py).  Lane 0 is the context's stream, lane 1 a stream of its own (same priority).
+hipStream_t lane_stream(hulk_ctx *c, int ring) {
+    return (ring == 1 && c->lane[1].stream) ? c->lane[1].stream : c->stream;
+}
+static int lane_of_ring(const hulk_ctx *c, int ring) { return (c->work_lanes > 1 && !c->no_overlap) ? ring : 0; }
+hipStream_t ring_stream(hulk_ctx *c) { return lane_stream(c, lane_of_ring(c, c->cur_ring)); }   // the lane of the current ring
+
 // the work stream may only write spectra of the current ring once the flush that last read them is done
 // a flush prepared on the current ring has to be queued before anything may wait for it (a partial interval keeps the
 // next batch in the same ring)
@@ -25,13 +37,14 @@ hipEvent_t ring_write_event(hulk_ctx *c) {
 }
 int ring_ready_for_writes(hulk_ctx *c) {
     { const int rc = ring_issue_own_flush(c); if (rc != HULK_OK) return rc; }
-    if (hipEvent_t e = ring_write_event(c)) HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
+    if (hipEvent_t e = ring_write_event(c)) HIPCHK(c, hipStreamWaitEvent(ring_stream(c), e, 0));
     return HULK_OK;
 }
 
 int sync_all(hulk_ctx *c) {
     { const int rc = issue_flush(c, nullptr); if (rc != HULK_OK) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->lane[1].stream) HIPCHK(c, hipStreamSynchronize(c->lane[1].stream));
     HIPCHK(c, hipStreamSynchronize(c->flush_stream));
     return HULK_OK;
 }
@@ -49,11 +62,11 @@ bool pick_config(uint32_t k, uint32_t max_len, MinimizerParams &P, int &threads)
 }
 
 // sequences with more than GENERIC_XCAP_MAX k-mer positions: grouped launches of the long-sequence kernels
-int bin_long_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, MinimizerParams P,
+int bin_long_reads(hulk_ctx *c, hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, MinimizerParams P,
                    uint32_t *hist) {
     std::vector<uint64_t> off(n + 1);
-    HIPCHK(c, hipMemcpyAsync(off.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(off.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
     // groups of long sequences, one launch set per group: bounded scratch (positions) and grid.y
     constexpr uint64_t GROUP_POS = 128ull << 20;        // positions per group (8 B + 1 B scratch, <= 16 B of table each)
     constexpr uint32_t GROUP_SEQS = 32768;
@@ -62,31 +75,31 @@ int bin_long_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offset
     auto launch_group = [&]() -> int {
         if (descs.empty()) return HULK_OK;
         if (pos_total > c->long_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipStreamSynchronize(s));
             hipFree(c->d_long_xs); hipFree(c->d_long_valid); c->d_long_xs = nullptr; c->d_long_valid = nullptr; c->long_cap = 0;
             HIPCHK(c, hipMalloc((void **)&c->d_long_xs, pos_total * 8));
             HIPCHK(c, hipMalloc((void **)&c->d_long_valid, pos_total));
             c->long_cap = pos_total;
         }
         if (tab_total > c->long_table_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipStreamSynchronize(s));
             hipFree(c->d_long_table); c->d_long_table = nullptr; c->long_table_cap = 0;
             HIPCHK(c, hipMalloc((void **)&c->d_long_table, tab_total * 8));
             c->long_table_cap = tab_total;
         }
         if (descs.size() > c->long_desc_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipStreamSynchronize(s));
             hipFree(c->d_long_desc); c->d_long_desc = nullptr; c->long_desc_cap = 0;
             HIPCHK(c, hipMalloc((void **)&c->d_long_desc, (descs.size() + 1024) * sizeof(hulk::LongSeqDesc)));
             c->long_desc_cap = descs.size() + 1024;
         }
         // pageable source: the copy is staged before the call returns, descs may be reused afterwards
         HIPCHK(c, hipMemcpyAsync(c->d_long_desc, descs.data(), descs.size() * sizeof(hulk::LongSeqDesc),
-                                 hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, launch_long_group(c->stream, d_bases, (const hulk::LongSeqDesc *)c->d_long_desc, (uint32_t)descs.size(),
+                                 hipMemcpyHostToDevice, s));
+        HIPCHK(c, launch_long_group(s, d_bases, (const hulk::LongSeqDesc *)c->d_long_desc, (uint32_t)descs.size(),
                                     max_npos, P, c->d_long_xs, c->d_long_valid, c->d_long_table, tab_total, hist,
                                     c->d_min_slots));
-        HIPCHK(c, hipStreamSynchronize(c->stream));      // descs.data() is pageable memory: keep it simple and ordered
+        HIPCHK(c, hipStreamSynchronize(s));      // descs.data() is pageable memory: keep it simple and ordered
         descs.clear(); pos_total = tab_total = max_npos = 0;
         return HULK_OK;
     };
@@ -161,16 +174,13 @@ static int lane_reserve(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, uint6
     return HULK_OK;
 }
 
-// One piece of a batch through the short-read kernels on stream s with lane ln's buffers: k_minimizer_fast -> region
-// scan -> k_jump_bin / k_jump_left -> spectrum kernels -> the generic kernel over the reads the fast one deferred.
-// after_k1a (may be null): recorded behind k_minimizer_fast;  before_k1a (may be null): waited for in front of it;
+// A launch chain of the short-read kernels on stream s with lane ln's buffers: k_minimizer_fast -> region scan ->
+// k_jump_bin / k_jump_left -> spectrum kernels -> the generic kernel over the reads the fast one deferred.
 // spectra_gate (may be null): the flush that last read this ring — only the histogram kernels wait for it (the minimizer
 // and jump-hash kernels do not touch the spectra)
-static int bin_fast_piece(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
-                          uint64_t n, uint32_t max_len, MinimizerParams P, uint32_t *hist, hipEvent_t before_k1a,
-                          hipEvent_t after_k1a, hipEvent_t spectra_gate) {
+static int bin_fast(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
+                    uint64_t n, uint32_t max_len, MinimizerParams P, uint32_t *hist, hipEvent_t spectra_gate) {
     { const int rc = lane_reserve(c, ln, s, n, P.pair != 0); if (rc != HULK_OK) return rc; }
-    if (before_k1a) HIPCHK(c, hipStreamWaitEvent(s, before_k1a, 0));
     ProfileRec pr{}; pr.which = 1;
     if ((c->profiling & 2)) {
         HIPCHK(c, hipEventCreateWithFlags(&pr.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pr.b, PROFILE_EVENT_FLAGS));
@@ -178,7 +188,6 @@ static int bin_fast_piece(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, con
     }
     HIPCHK(c, launch_minimizer_fast(s, d_bases, d_offsets, n, P, ln.ml, c->d_state, c->d_min_slots));
     if ((c->profiling & 2)) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
-    if (after_k1a) HIPCHK(c, hipEventRecord(after_k1a, s));
     ProfileRec pj{}; pj.which = 2;
     ProfileRec pl{}; pl.which = 3;
     if ((c->profiling & 4)) {
@@ -198,7 +207,7 @@ static int bin_fast_piece(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, con
     return HULK_OK;
 }
 
-// launch parameters of reads [first, ...) of a call that starts `fill` reads into spectrum ring_base
+// launch parameters of a call that starts `fill` reads into spectrum ring_base
 static MinimizerParams piece_params(const hulk_ctx *c, uint64_t bases_bytes, uint64_t interval, uint64_t fill, bool pair) {
     MinimizerParams P{};
     P.k = c->p.k; P.w = c->p.w; P.num_bins = c->B; P.bases_bytes = bases_bytes;
@@ -211,16 +220,44 @@ static MinimizerParams piece_params(const hulk_ctx *c, uint64_t bases_bytes, uin
     return P;
 }
 
-// Bins reads [0, n) of a call into the spectra of the current ring (read i -> spectrum (fill + i) / interval).
-// Short reads: the batch is cut at sketching-interval borders into `bin_pieces` pieces that alternate between two work
-// streams (lane 0 = the context's stream, lane 1 = a stream of its own), each with its own minimizer list; a piece's
-// k_minimizer_fast starts when the previous piece's has ended, so that from the second piece on a k_minimizer_fast
-// (VALU + LDS, 4 waves per SIMD) runs beside the k_jump_bin / spectrum kernels of the piece before it (VALU only) and the
-// two fill each other's issue bubbles.  Pieces touch disjoint spectra (their plain read-modify-writes cannot meet) and the
-// context's stream waits for lane 1 before the call returns: to the caller it is still one stream.
+// lane 1 comes into being with the first batch of ring 1
+static int lane_open(hulk_ctx *c, int li) {
+    if (li == 0 || c->lane[1].stream) return HULK_OK;
+    int prio = 0;
+    if (c->stream) (void)hipStreamGetPriority(c->stream, &prio);
+    HIPCHK(c, hipStreamCreateWithPriority(&c->lane[1].stream, hipStreamNonBlocking, prio));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    return HULK_OK;
+}
+// the context's stream has passed everything lane 1 was given so far
+int lanes_join(hulk_ctx *c) {
+    if (!c->lane[1].stream) return HULK_OK;
+    HIPCHK(c, hipEventRecord(c->ev_join, c->lane[1].stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return HULK_OK;
+}
+
+// Bins reads [0, n) of a call into the spectra of the current ring (read i -> spectrum (fill + i) / interval), on the
+// ring's work lane.  What the caller queued on the context's stream so far (its buffers, the host path's copies) is
+// passed to lane 1 through an event.  `join`: the context's stream waits for the lane before the call returns — always
+// when the context runs on a caller's stream (hulk_set_stream: to the caller it stays ONE stream, at the price of the
+// overlap between batches), and for the entry points whose results the caller reads on that stream (hulk_bin_reads_device).
 int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
-              uint32_t max_len, uint64_t bases_bytes, uint64_t interval, uint64_t fill) {
+              uint32_t max_len, uint64_t bases_bytes, uint64_t interval, uint64_t fill, bool join) {
     { int rcw = ring_issue_own_flush(c); if (rcw != HULK_OK) return rcw; }
+    const int li = lane_of_ring(c, c->cur_ring);
+    { const int rc = lane_open(c, li); if (rc != HULK_OK) return rc; }
+    hipStream_t s = li ? c->lane[1].stream : c->stream;
+    // what was queued on the context's stream for this batch — the caller's own work when the stream is the caller's, the
+    // host path's copies into the staging set (copies_pending) — has to be passed to lane 1.  Nothing else is: a fork in
+    // front of every batch would order lane 1 behind the batch lane 0 was just given, which is the overlap itself
+    if (li && (c->stream != c->own_stream || c->copies_pending)) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_fork, 0));
+        c->copies_pending = false;
+    }
+    c->last_bin_stream = s;
     uint32_t *hist = ring_hist(c);
     // the short-read kernel takes reads of <= 16*w k-mer positions and <= 256 bases; when the batch's
     // length bound already exceeds that, go straight to the generic kernel
@@ -230,58 +267,27 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
     const bool single_ok = max_len <= 256 && (uint64_t)max_len < (uint64_t)c->p.k + 16ull * c->p.w;
     const bool pair_ok = !single_ok && !getenv("HULK_NO_PAIR") && 16ull * c->p.w + c->p.k - 1 <= 256 && max_len <= 512 &&
                          (uint64_t)max_len < (uint64_t)c->p.k + 32ull * c->p.w - (c->p.w - 1);
-    const bool fast_ok = fast_base && (single_ok || pair_ok);
-    if (fast_ok) {
+    int rc = HULK_OK;
+    if (fast_base && (single_ok || pair_ok)) {
         // short-read kernel first; reads it cannot take (N bases, too long for 16 blocks of w
         // positions) are queued on the device and binned by the generic kernel right after
-        uint64_t cuts[SCAN_BATCH_MAX + 2]; uint32_t np = 0;
-        cuts[0] = 0;
-        uint32_t want = (no_overlap_mode(c) || !interval) ? 1u : c->bin_pieces;
-        if ((uint64_t)want * c->bin_min_reads > n) want = (uint32_t)(n / c->bin_min_reads);      // (0 or 1: one piece)
-        for (uint32_t p = 1; p < want; p++) {
-            // the interval border nearest to p / want of the reads
-            const uint64_t target = fill + n * p / want;
-            const uint64_t border = (target + interval / 2) / interval * interval;
-            if (border <= fill + cuts[np] || border >= fill + n) continue;
-            cuts[++np] = border - fill;
+        rc = bin_fast(c, c->lane[li], s, d_bases, d_offsets, n, max_len, piece_params(c, bases_bytes, interval, fill, pair_ok),
+                      hist, ring_write_event(c));
+    } else {
+        MinimizerParams P = piece_params(c, bases_bytes, interval, fill, false);
+        int threads = 256;
+        rc = issue_flush(c, nullptr);
+        if (rc == HULK_OK) {
+            if (hipEvent_t e = ring_write_event(c)) HIPCHK(c, hipStreamWaitEvent(s, e, 0));
+            const bool fits = pick_config(c->p.k, max_len, P, threads);
+            P.skip_long = fits ? 0u : 1u;
+            HIPCHK(c, launch_minimizer_bin(s, d_bases, d_offsets, n, P, threads, hist, c->d_state,
+                                           c->d_min_slots, nullptr, nullptr, 0));
+            if (!fits) rc = bin_long_reads(c, s, d_bases, d_offsets, n, P, hist);
         }
-        cuts[++np] = n;
-        hipEvent_t gate = ring_write_event(c);
-        if (np == 1)
-            return bin_fast_piece(c, c->lane[0], c->stream, d_bases, d_offsets, n, max_len,
-                                  piece_params(c, bases_bytes, interval, fill, pair_ok), hist, nullptr, nullptr, gate);
-        hulk_ctx::BinLane &l1 = c->lane[1];
-        if (!l1.stream) {
-            int prio = 0;
-            if (c->stream) (void)hipStreamGetPriority(c->stream, &prio);
-            HIPCHK(c, hipStreamCreateWithPriority(&l1.stream, hipStreamNonBlocking, prio));
-            for (int i = 0; i < 2; i++) HIPCHK(c, hipEventCreateWithFlags(&c->lane[i].ev_k1a, hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-        }
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));              // the caller's buffers, everything queued before
-        HIPCHK(c, hipStreamWaitEvent(l1.stream, c->ev_fork, 0));
-        for (uint32_t p = 0; p < np; p++) {
-            const int li = (int)(p & 1);
-            hipStream_t s = li ? l1.stream : c->stream;
-            const int rc = bin_fast_piece(c, c->lane[li], s, d_bases, d_offsets + cuts[p], cuts[p + 1] - cuts[p], max_len,
-                                          piece_params(c, bases_bytes, interval, fill + cuts[p], pair_ok), hist,
-                                          p ? c->lane[li ^ 1].ev_k1a : nullptr, c->lane[li].ev_k1a, gate);
-            if (rc != HULK_OK) return rc;
-        }
-        HIPCHK(c, hipEventRecord(c->ev_join, l1.stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        return HULK_OK;
     }
-    MinimizerParams P = piece_params(c, bases_bytes, interval, fill, false);
-    int threads = 256;
-    { const int rcf = issue_flush(c, nullptr); if (rcf != HULK_OK) return rcf; }
-    if (hipEvent_t e = ring_write_event(c)) HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
-    const bool fits = pick_config(c->p.k, max_len, P, threads);
-    P.skip_long = fits ? 0u : 1u;
-    HIPCHK(c, launch_minimizer_bin(c->stream, d_bases, d_offsets, n, P, threads, hist, c->d_state,
-                                   c->d_min_slots, nullptr, nullptr, 0));
-    if (!fits) return bin_long_reads(c, d_bases, d_offsets, n, P, hist);
+    if (rc != HULK_OK) return rc;
+    if (li && (join || c->stream != c->own_stream)) return lanes_join(c);
     return HULK_OK;
 }
 
@@ -364,7 +370,7 @@ int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream, bool use_de
     fb.ring_base = c->ring_base; fb.ring_n = c->ring_n; fb.count = count;
     fb.parity = (int)(c->flush_index & 1); fb.num_bins = c->B;
     // everything binned so far (or the caller's all-reduce on dep_stream) ends where this event is recorded
-    HIPCHK(c, hipEventRecord(c->ev_binned, use_dep ? dep_stream : c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_binned, use_dep ? dep_stream : ring_stream(c)));
     c->deferred.armed = true; c->deferred.fb = fb; c->deferred.ring = c->cur_ring;
     c->deferred.use_dep = use_dep; c->deferred.allreduce = allreduce;
     c->flush_index++;
@@ -397,7 +403,9 @@ int ctx_fail(hulk_ctx *c, int code, const char *full_message) {
 // a staging set that is free again (its last copies and kernels done) and holds nbytes of bases and cn reads
 int stage_ready(hulk_ctx *c, hulk_ctx::HostStage &hs, size_t nbytes, uint64_t cn) {
     if (!hs.ev) HIPCHK(c, hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
+    if (!hs.ev1) HIPCHK(c, hipEventCreateWithFlags(&hs.ev1, hipEventDisableTiming));
     if (hs.busy) { HIPCHK(c, hipEventSynchronize(hs.ev)); hs.busy = false; }     // its copies and kernels are done
+    if (hs.busy1) { HIPCHK(c, hipEventSynchronize(hs.ev1)); hs.busy1 = false; }  // ... on both work lanes
     if (nbytes + 32 > hs.cap_bases) {
         if (hs.h_bases) hipHostFree(hs.h_bases);
         hipFree(hs.d_bases); hs.h_bases = hs.d_bases = nullptr;
@@ -412,6 +420,14 @@ int stage_ready(hulk_ctx *c, hulk_ctx::HostStage &hs, size_t nbytes, uint64_t cn
         HIPCHK(c, hipHostMalloc((void **)&hs.h_off, hs.cap_off * 8, hipHostMallocDefault));
         HIPCHK(c, hipMalloc((void **)&hs.d_off, hs.cap_off * 8));
     }
+    return HULK_OK;
+}
+// the copies (context's stream) and the kernels (either work lane) that read the set have been queued: it is free again when
+// both streams have passed this point
+int stage_mark_busy(hulk_ctx *c, hulk_ctx::HostStage &hs) {
+    HIPCHK(c, hipEventRecord(hs.ev, c->stream));
+    hs.busy = true;
+    if (c->lane[1].stream) { HIPCHK(c, hipEventRecord(hs.ev1, c->lane[1].stream)); hs.busy1 = true; }
     return HULK_OK;
 }
 // reads [i0, i1) of the caller's host buffers -> the next of the two pinned + device staging sets: host copy (several
@@ -437,6 +453,7 @@ int stage_host_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets,
         for (uint64_t i = 0; i <= cn; i++) hs.h_off[i] = offsets[i0 + i] - lo;
         for (auto &x : th) x.join();
     }
+    c->copies_pending = true;
     HIPCHK(c, hipMemcpyAsync(hs.d_bases, hs.h_bases, nbytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(hs.d_off, hs.h_off, (cn + 1) * 8, hipMemcpyHostToDevice, c->stream));
     c->hstage_cur ^= 1;
@@ -463,12 +480,12 @@ int ctx_stage_acquire(hulk_ctx *c, size_t nbytes, uint64_t n, StageSet *out) {
     const int rc = stage_ready(c, hs, nbytes, n);
     if (rc != HULK_OK) return rc;
     out->h_bases = hs.h_bases; out->d_bases = hs.d_bases; out->h_off = hs.h_off; out->d_off = hs.d_off; out->cap_bases = hs.cap_bases;
+    c->copies_pending = true;                                   // (the caller queues its copies on ctx_stream())
     return HULK_OK;
 }
 int ctx_stage_release(hulk_ctx *c) {
     hulk_ctx::HostStage &hs = c->hstage[c->hstage_cur];
-    HIPCHK(c, hipEventRecord(hs.ev, c->stream));
-    hs.busy = true;
+    { const int rc = stage_mark_busy(c, hs); if (rc != HULK_OK) return rc; }
     c->hstage_cur ^= 1;
     return HULK_OK;
 }

@@ -232,15 +232,15 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
             atomicAdd(&hist[(size_t)qs[lane] * (size_t)P.num_bins + jump_hash(q[lane], P.num_bins)], 1u);
         nmin += qn;
     }
-    // same-address atomics serialise at ~12 ns each on this chip: every block owns one slot of
-    // min_slots[] instead (launches are stream-ordered, so a plain read-modify-write is safe)
+    // same-address atomics serialise at ~12 ns each on this chip: every block adds to its own slot of
+    // min_slots[] instead (an atomic all the same: launches of the two work lanes run side by side)
     __shared__ unsigned long long blk_nmin[4];
     if (lane == 0) blk_nmin[wid] = nmin;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long t = 0;
         for (int x = 0; x < nw; x++) t += blk_nmin[x];
-        if (t) min_slots[blockIdx.x] += t;
+        if (t) atomicAdd(&min_slots[blockIdx.x], t);
     }
     if (dbg && sink == 0xdeadbeefu) hist[0] = sink;     // keep ablated work alive
 }

@@ -45,17 +45,16 @@ class GpuSketcher:
 
     def __init__(self, k=21, w=9, sketch_size=50, interval=0, decay_ratio=1.0, num_bins=0,
                  device=0, slot_begin=0, slot_count=0, cws_source=_lib.HULK_CWS_GO_COMPAT,
-                 stream=None, flags=0, batch=0, bin_pieces=0, host_copy_threads=0, bin_min_reads=0):
-        """batch: sketching intervals per flush batch (0 = the library's default, 16); bin_pieces: pieces a batch is binned
-        in on alternating work streams (0 = default, 1 = one piece), none smaller than bin_min_reads; host_copy_threads: see
-        hulk_params (include/hulk_hip.h)."""
+                 stream=None, flags=0, batch=0, work_lanes=0, host_copy_threads=0):
+        """batch: sketching intervals per flush batch (0 = the library's default, 16); work_lanes: 2 (the default) = consecutive
+        batches are binned on two alternating work streams, 1 = one; host_copy_threads: see hulk_params (include/hulk_hip.h).
+        stream: run on the caller's hipStream_t — the context then joins its second lane into that stream after every call."""
         self._L = _lib.load()
         self._ctx = ctypes.c_void_p()
         p = HulkParams(k=k, w=w, sketch_size=sketch_size, num_bins=num_bins,
                        decay_ratio=decay_ratio, interval=interval, device=device,
                        slot_begin=slot_begin, slot_count=slot_count, cws_source=cws_source, flags=flags,
-                       batch=batch, bin_pieces=bin_pieces, host_copy_threads=host_copy_threads,
-                       bin_min_reads=bin_min_reads)
+                       batch=batch, work_lanes=work_lanes, host_copy_threads=host_copy_threads)
         rc = self._L.hulk_create(ctypes.byref(p), ctypes.byref(self._ctx))
         if rc != 0:
             self._ctx = None

@@ -52,7 +52,7 @@ extern "C" {
 /* 2: hulk_params.reserved[0] became `flags` (unknown bits are refused), hulk_set_profiling takes a mask, the multi-GPU
  * entry points (hulk_comm_*, hulk_step_*, hulk_gather_sketch).
  * 3: every knob a host may want per context is a field (as SketchCmd carries every flag as a field,
- *    src/pipeline/pipeline.go:14-30): hulk_params.batch / bin_pieces / host_copy_threads / bin_min_reads (were reserved[0..3], 0 = default),
+ *    src/pipeline/pipeline.go:14-30): hulk_params.batch / work_lanes / host_copy_threads (were reserved[0..2], 0 = default),
  *    HULK_FLAG_SHARD_FULL / HULK_FLAG_NO_OVERLAP, hulk_ingest_opts with hulk_parse_files_opts / hulk_sketch_files_opts.
  *    The HULK_* environment variables that remain are overrides for profiling scripts, read when a context is created.
  * Bindings compare it with the value they were written for. */
@@ -95,8 +95,8 @@ extern "C" {
 #define HULK_FLAG_NO_PRUNE 2u      /* CWS scan reads the whole table for every interval (no per-tile bound, no whole-batch bound) */
 #define HULK_FLAG_NO_SKIP 4u       /* keep the per-tile bound, drop the whole-batch bound */
 #define HULK_FLAG_SHARD_FULL 8u    /* hulk_step_sharded always exchanges the k-mer spectra (never the count-min increments) */
-#define HULK_FLAG_NO_OVERLAP 16u   /* one stream: flush kernels on the work stream, a batch binned in one piece (profiling:
-                                    * every kernel runs alone, so its own duration can be read) */
+#define HULK_FLAG_NO_OVERLAP 16u   /* one stream: flush kernels on the work stream, one work lane (profiling: every kernel
+                                    * runs alone, so its own duration can be read) */
 
 /* Largest k-mer spectrum this build bins: the binning kernels pack (spectrum slot << 20 | bin) into one dword
  * (k^4 = 923,521 < 2^20 at the reference's maximum k = 31; cmd/sketch.go:118). */
@@ -118,13 +118,15 @@ typedef struct hulk_params {
     uint32_t flags;        /* HULK_FLAG_* (0 = defaults) */
     uint32_t batch;        /* sketching intervals binned by one launch chain and flushed by ONE pass over the CWS table:
                             * 1..16, 0 = default (16).  Any value gives the same sketch (hulk_batch_size) */
-    uint32_t bin_pieces;   /* a batch of short reads is binned in this many pieces, cut at interval borders, alternating
-                            * between two work streams so that one piece's minimizer kernel runs beside the jump-hash kernel
-                            * of the piece before: 1..16, 0 = default (4), 1 = one piece on the context's stream */
+    uint32_t work_lanes;   /* 2: consecutive batches are binned on two alternating work streams, so that the minimizer kernel
+                            * of a batch runs beside the jump-hash / spectrum kernels of the batch before it; 1: one work
+                            * stream; 0 = default: 2, but 1 with count-min decay (0 < decay_ratio < 1), whose flush needs the
+                            * CUs a second lane would keep occupied.  A context on a caller's stream (hulk_set_stream) joins the second
+                            * lane into that stream at the end of every call — the caller still sees ONE stream — and so
+                            * gives up that overlap */
     uint32_t host_copy_threads; /* threads that copy a chunk of hulk_add_reads' host buffers into pinned staging: 1..32,
                             * 0 = default (4) */
-    uint32_t bin_min_reads; /* a batch is only cut into pieces of at least this many reads (a piece should fill the chip:
-                            * 256 CUs x 4 workgroups x 64 reads): 0 = default (65536); tests use small values */
+    uint32_t reserved;     /* must be 0 */
 } hulk_params;
 
 /* Version of this ABI (HULK_ABI_VERSION). */

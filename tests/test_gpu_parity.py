@@ -272,17 +272,20 @@ def test_interval_batches_ring_wraparound(batch):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("pieces,piece_min", [(2, 64), (3, 700), (4, 1), (16, 1), (8, 5000)])
-def test_batch_binned_in_pieces_on_two_work_streams(pieces, piece_min):
-    """A batch of short reads is cut at interval borders into hulk_params.bin_pieces pieces that alternate between the
-    context's stream and a second work stream, each with its own minimizer list (hulk_flush.hip, bin_reads).  Uneven host
-    calls (partial intervals pending across calls), reads with N (each lane's deferred-read list) and reads for the
-    generic kernel in between: spectrum, counters, count-min and sketch equal the oracle's, whatever the pieces."""
-    rng = np.random.default_rng(1000 + pieces)
+@pytest.mark.parametrize("lanes,batch,alph", [(2, 1, b"ACGT"), (2, 3, b"ACGTN"), (2, 8, b"ACGT"), (1, 3, b"ACGTN"), (2, 16, b"ACGTNacgt")])
+def test_batches_on_alternating_work_lanes(lanes, batch, alph):
+    """Consecutive batches are binned on two alternating work streams (one lane per spectrum ring, each with its own
+    minimizer list; hulk_flush.hip, lane_stream) and are not ordered against each other.  Uneven host calls (partial
+    intervals pending across calls keep a ring — and its lane — over several calls), reads with N (each lane's
+    deferred-read list), reads of 250-400 bases in between (two groups per read / the generic kernel on the ring's lane):
+    spectrum, counters, count-min and sketch equal the oracle's."""
+    rng = np.random.default_rng(1000 + 10 * lanes + batch)
     k, w, S, interval = 15, 9, 24, 500
-    seqs = random_reads(rng, 14_000, (40, 150), b"ACGTN" if pieces == 3 else b"ACGT")      # (min length w + k - 1 = 23)
+    seqs = random_reads(rng, 14_000, (40, 150), alph)      # (min length w + k - 1 = 23)
+    for i in range(5000, 5400):
+        seqs[i] = random_reads(rng, 1, 250 + (i % 3) * 75, alph)[0]
     o = pyorc.Sketcher(k, w, S, 0, 1.0, interval)
-    g = gpu().GpuSketcher(k, w, S, interval, batch=8 if pieces != 16 else 16, bin_pieces=pieces, bin_min_reads=piece_min)
+    g = gpu().GpuSketcher(k, w, S, interval, batch=batch, work_lanes=lanes)
     bases, offsets = pack_reads(seqs)
     o.add_reads(bases, offsets)
     cuts = [0, 3999, 4000, 9001, 9300, 14_000]

@@ -39,7 +39,7 @@ for case in range(n_cases):
     decay = float(rng.choice([1.0, 1.0, 1.0, 0.0, 0.02, 0.3, 0.97]))
     interval = int(rng.choice([0, 0, 1, 7, 50, 333]))
     batch = int(rng.choice([1, 2, 5, 8, 16]))
-    pieces, piece_min = int(rng.choice([1, 2, 3, 4, 16])), int(rng.choice([1, 16, 100]))     # work lanes of the short-read path
+    lanes = int(rng.choice([1, 2, 2]))                         # work lanes: batches on alternating streams
     alph = ALPH[int(rng.integers(0, len(ALPH)))]
     n = int(rng.integers(1, 1500))
     lo = w + k - 1
@@ -63,7 +63,7 @@ for case in range(n_cases):
         if rng.random() < 0.05:
             s[:] = s[0]
         seqs.append(bytes(s))
-    desc = f"case {case}: k={k} w={w} S={S} decay={decay} I={interval} batch={batch} pieces={pieces}/{piece_min} alph={alph!r} reads={len(seqs)} shape={shape}"
+    desc = f"case {case}: k={k} w={w} S={S} decay={decay} I={interval} batch={batch} lanes={lanes} alph={alph!r} reads={len(seqs)} shape={shape}"
     oerr = gerr = None
     if os.environ.get("FUZZ_DUMP") == str(case):           # write the case's reads (no GPU needed) and stop
         np.save(os.environ.get("FUZZ_DUMP_FILE", "fuzz_case.npy"), np.array(seqs, dtype=object), allow_pickle=True)
@@ -82,7 +82,7 @@ for case in range(n_cases):
         o.finish()
     except pyorc.OracleError as e:
         oerr = str(e)
-    g = hulk_amd.GpuSketcher(k, w, S, interval, decay, batch=batch, bin_pieces=pieces, bin_min_reads=piece_min)
+    g = hulk_amd.GpuSketcher(k, w, S, interval, decay, batch=batch, work_lanes=lanes)
     try:
         cuts = sorted(set([0, len(seqs)] + [int(x) for x in rng.integers(0, len(seqs) + 1, size=3)]))
         for x, y in zip(cuts[:-1], cuts[1:]):
@@ -115,7 +115,7 @@ for case in range(n_cases):
             for variant in ("same cuts", "one call", "NO_FAST"):
                 if variant == "NO_FAST":
                     os.environ["HULK_NO_FAST_K1"] = "1"
-                g2 = hulk_amd.GpuSketcher(k, w, S, interval, decay, batch=batch, bin_pieces=1 if variant == "one call" else pieces, bin_min_reads=piece_min)
+                g2 = hulk_amd.GpuSketcher(k, w, S, interval, decay, batch=batch, work_lanes=1 if variant == "one call" else lanes)
                 try:
                     cc = cuts if variant == "same cuts" else [0, len(seqs)]
                     for x, y in zip(cc[:-1], cc[1:]):

@@ -5,7 +5,7 @@ in-process exchange function (a barrier and shared arrays stand in for the netwo
 counters must equal the CPU oracle's over the same global stream.  Random k, w, sketch size, interval, batch size T, world
 size (1..8: slot shards and ragged last steps of every shape, ranks without any interval), stream length (partial last
 interval), decay (concept drift takes the spectra exchange on every step), reads with N, the work lanes of the binning side
-(hulk_params.bin_pieces / bin_min_reads).  FUZZ_SHARD_FULL=1 (or the older HULK_SHARD_FULL=1) in the environment forces the
+(hulk_params.work_lanes).  FUZZ_SHARD_FULL=1 (or the older HULK_SHARD_FULL=1) in the environment forces the
 spectra exchange on every step of every case (HULK_FLAG_SHARD_FULL on every context).
 usage: fuzz_shard.py [n_cases] [seed]     (run on the GPU box)"""
 import os
@@ -81,7 +81,7 @@ for case in range(n_cases):
     if mode == "sliced":
         total = n_int * I                                            # (whole intervals: every rank slices every interval)
     bases, offsets = reads(rng, total, L, alph)
-    pieces, piece_min = int(rng.choice([1, 2, 3, 4, 8])), int(rng.choice([64, 500, 2000]))   # work lanes of the binning side
+    lanes = int(rng.choice([1, 2, 2]))                                # work lanes of the binning side
     ex = Exchange(world)
     out, errs = [None] * world, []
 
@@ -90,7 +90,7 @@ for case in range(n_cases):
             torch.cuda.set_device(0)
             sb, sc = slot_shard(S, rank, world)
             sk = hulk_amd.GpuSketcher(k, w, S, interval=(0 if mode == "sliced" else I), decay_ratio=decay, device=0,
-                                      slot_begin=sb, slot_count=sc, batch=T, bin_pieces=pieces, bin_min_reads=piece_min,
+                                      slot_begin=sb, slot_count=sc, batch=T, work_lanes=lanes,
                                       flags=_lib.HULK_FLAG_SHARD_FULL if FORCE_FULL else 0)
             sk.comm_init_host(rank, world, ex.make(rank))
             if mode != "sliced":

@@ -7,14 +7,14 @@ ap.add_argument("--k", type=int, default=31); ap.add_argument("--w", type=int, d
 ap.add_argument("--S", type=int, default=1024); ap.add_argument("--decay", type=float, default=0.02)
 ap.add_argument("--reads", type=int, default=5_000_000); ap.add_argument("--interval", type=int, default=100_000)
 ap.add_argument("--batch", type=int, default=10); ap.add_argument("--len", type=int, default=150)
-ap.add_argument("--pieces", type=int, default=0, help="hulk_params.bin_pieces (0 = the library default)")
+ap.add_argument("--lanes", type=int, default=0, help="hulk_params.work_lanes (0 = the library default, 2)")
 ap.add_argument("--serial", action="store_true", help="HULK_FLAG_NO_OVERLAP: every kernel alone (profiling)")
 a = ap.parse_args()
 import torch, hulk_amd
 from hulk_amd import synth
 t0 = time.time()
 sk = hulk_amd.GpuSketcher(a.k, a.w, a.S, interval=a.interval, decay_ratio=a.decay,
-                          stream=torch.cuda.current_stream().cuda_stream, batch=a.batch, bin_pieces=a.pieces,
+                          batch=a.batch, work_lanes=a.lanes,
                           flags=16 if a.serial else 0)
 torch.cuda.synchronize(); t_create = time.time() - t0
 step = a.interval * a.batch
@@ -22,16 +22,15 @@ bufs = []
 for s in range(min(4, (a.reads + step - 1) // step)):
     b, o = synth.reads_torch(s * step, step, a.len); bufs.append((b, o))
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 done = 0; i = 0
 sk.add_reads_device(bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), step, a.len, bufs[0][0].numel()); done += step; i += 1   # warm
-torch.cuda.synchronize(); e0.record()
-t1 = time.time()
+sk.synchronize()                       # (the context runs on its private streams: its own synchronisation points bracket the clock)
+t1 = time.perf_counter()
 while done < a.reads:
     b, o = bufs[i % len(bufs)]
     sk.add_reads_device(b.data_ptr(), o.data_ptr(), step, a.len, b.numel()); done += step; i += 1
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1)
+sk.synchronize()
+ms = (time.perf_counter() - t1) * 1e3
 tiles = sk.scan_stats()
 sk.finish()
 mins, w = sk.sketch()

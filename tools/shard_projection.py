@@ -45,7 +45,7 @@ def run(world, steps, warmup=3, mode="sharded"):
     n_step = per * BATCH
     offsets = torch.arange(n_step + 1, dtype=torch.int64, device=dev) * READ_LEN
     sk = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL if mode == "sharded" else 0, decay_ratio=1.0, device=0,
-                              slot_begin=sb, slot_count=sc, stream=stream.cuda_stream, batch=BATCH)
+                              slot_begin=sb, slot_count=sc, batch=BATCH)
     sk.comm_init_loopback(0, world)
 
     def step(t):

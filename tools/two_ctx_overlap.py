@@ -16,7 +16,7 @@ for s_ in range(4):
 off = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
 torch.cuda.synchronize()
 def run(nctx, steps=24):
-    sks = [hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, batch=T, bin_pieces=int(os.environ.get('PIECES', '1'))) for _ in range(nctx)]
+    sks = [hulk_amd.GpuSketcher(K, W, S, interval=0, decay_ratio=1.0, batch=T, work_lanes=int(os.environ.get('LANES', '1'))) for _ in range(nctx)]
     def step(t):
         for sk in sks:
             b = bufs[t % 4]
