@@ -240,6 +240,7 @@ void hulk_destroy(hulk_ctx *c) {
         hipFree(ml.x); hipFree(ml.slot); hipFree(ml.key); hipFree(ml.cnt); hipFree(ml.off); hipFree(ml.bsum); hipFree(ml.partial);
         hipFree(ml.nib); hipFree(ml.nib_over); hipFree(ml.lo); hipFree(ml.lo_cnt); hipFree(ml.dmask); hipFree(ml.dsum);
     }
+    if (c->ev_stagger) hipEventDestroy(c->ev_stagger);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);

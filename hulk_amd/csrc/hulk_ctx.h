@@ -113,6 +113,7 @@ struct hulk_ctx {
     } lane[2];
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;    // context stream -> lane 1 in front of a batch, and back (lanes_join)
     hipStream_t last_bin_stream = nullptr;              // the stream the latest binning launches went to
+    int stagger = 1; hipEvent_t ev_stagger = nullptr;   // 1: the lanes are idle; 2: the first batch since recorded ev_stagger behind its k_minimizer_fast
     bool copies_pending = false;                        // host -> device copies were queued on the context's stream since the last fork
     uint32_t work_lanes = 2;                            // hulk_params.work_lanes
     uint32_t host_copy_threads = 4;                     // hulk_params.host_copy_threads

@@ -196,6 +196,13 @@ __global__ __launch_bounds__(256) void k_scan_test(const float *__restrict__ kmi
 }
 
 // workgroup of 16 waves = (quarter of a column word = 16 wave tiles, slot group); wave w takes wave tile 64 cw + 16 quarter + w
+// MERGE (no concept drift): AddElement's update is then a running minimum with strict <, so what a batch leaves in a
+// slot is the smallest A over ALL its (interval, bin) pairs, the earliest pair winning ties (histosketch.go:139-153) — the
+// per-interval minima are not needed.  The lanes keep ONE running minimum per row over the batch's intervals and the wave
+// reduces it once per tile instead of once per (tile, interval): the 19-instruction transposed reduction was 36 % of the
+// issue cycles of an interval's work on a tile (235 -> 151 cycles; profiles/r04_scan.txt).  k_cws_resolve<true> then
+// re-evaluates the candidate tiles for every interval of the batch and orders the exact values by (A, interval, bin).
+template <bool MERGE>
 __global__ __launch_bounds__(1024) void k_cws_scan(const float *__restrict__ k32,
                                                    const float *__restrict__ rcp32,
                                                    float *__restrict__ tilemin, int slots, int ntiles,
@@ -228,10 +235,20 @@ __global__ __launch_bounds__(1024) void k_cws_scan(const float *__restrict__ k32
                 kv[r] = (floatx4)(0.f);
         }
         floatx4 rc_next = *(const floatx4 *)(rcp32 + col);
+        float acc[SCAN_ROWS];
+#pragma unroll
+        for (int r = 0; r < SCAN_ROWS; r++) acc[r] = INFINITY;
         for (int t = 0; t < (int)fb.count; t++) {
             const floatx4 rc = rc_next;
             if (t + 1 < (int)fb.count) rc_next = *(const floatx4 *)(rcp32 + (size_t)(t + 1) * row_stride + col);
             if (!((gomask >> t) & 1u)) continue;
+            if (MERGE) {
+                // NaN (bin not in the stream) loses every v_min; the running minimum starts at +inf
+#pragma unroll
+                for (int r = 0; r < SCAN_ROWS; r++)
+                    acc[r] = fminf(fminf(fminf(fminf(kv[r].x * rc.x, kv[r].y * rc.y), kv[r].z * rc.z), kv[r].w * rc.w), acc[r]);
+                continue;
+            }
             float m[SCAN_ROWS];
             // v_mul_f32 x4 + v_min3_f32 x2 per row.  (v_pk_mul_f32 halves the multiplies but runs this loop 2x
             // SLOWER on MI355X — measured 304 vs 150 us — so the products stay scalar.)  NaN (bin not in the
@@ -245,6 +262,12 @@ __global__ __launch_bounds__(1024) void k_cws_scan(const float *__restrict__ k32
             if ((lane & 7) == 0)
                 tilemin[(((size_t)t * ngroups + grp) * wtiles + (size_t)wt) * SCAN_ROWS + (lane >> 3)] = mine;
         }
+        if (MERGE) {
+            static_assert(SCAN_ROWS == 8, "wave_min8_by_row reduces exactly 8 rows");
+            const float mine = wave_min8_by_row(acc);             // lane l: minimum of row l / 8 over the wave and the batch
+            if ((lane & 7) == 0)                                    // plane 0 of tilemin: [slot group][wave tile][row]
+                tilemin[((size_t)grp * wtiles + (size_t)wt) * SCAN_ROWS + (lane >> 3)] = mine;
+        }
     }
 }
 
@@ -256,6 +279,9 @@ __global__ __launch_bounds__(1024) void k_cws_scan(const float *__restrict__ k32
 // re-evaluated tile.
 // ------------------------------------------------------------------------------------------
 constexpr int WTILE = SCAN_TILE / 4;
+// MERGE (see k_cws_scan): one workgroup per slot; tilemin holds the batch's minima, the candidate tiles are re-evaluated
+// for every flushed interval of the batch and the exact values ordered by (A, interval, bin) — the stream order of ties.
+template <bool MERGE>
 __global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ rcb,
                                                      const double *__restrict__ f64,
                                                      const float *__restrict__ tilemin,
@@ -266,16 +292,17 @@ __global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ 
     float *tm = (float *)smem;                       // [wtiles]
     __shared__ float redf[4];
     __shared__ double redA[4];
-    __shared__ int32_t redB[4];
+    __shared__ long long redK[4];
     __shared__ int ncand;
     __shared__ int cand[64];
     if (st->skip_exact[fb.parity]) return;
-    const int slot = blockIdx.x, t = blockIdx.y;     // local slot, interval of the batch
+    const int slot = blockIdx.x, t = blockIdx.y;     // local slot, interval of the batch (MERGE: t = 0, the whole batch)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wtiles = ntiles * 4;
     const int32_t num_bins = fb.num_bins;
-    double bestA = INFINITY; int32_t bestB = 0x7fffffff;
-    if (flush_go(st, fb, t)) {                        // block-uniform
+    double bestA = INFINITY; int32_t bestB = 0x7fffffff; int bestT = 0x7fffffff;
+    const uint32_t gomask = MERGE ? batch_gomask(st, fb) : 0u;   // (whole waves: every thread of the block is active here)
+    if (MERGE ? gomask != 0u : flush_go(st, fb, t)) {  // block-uniform
         const double *row = rcb + (size_t)slot * (size_t)num_bins * 3;
         const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
         const float *tmin_t = tilemin + (((size_t)t * ngroups + slot / SCAN_ROWS) * wtiles) * SCAN_ROWS + (slot % SCAN_ROWS);
@@ -300,7 +327,27 @@ __global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ 
                 if (tm[x] <= thr) { const int at = atomicAdd(&ncand, 1); if (at < 64) cand[at] = x; else overflow = true; }
             __syncthreads();
             const int nc = ncand;                     // block-uniform
-            if (nc <= 64) {
+            if (MERGE) {
+                // every candidate tile (all tiles inside the band when there are more than 64), every flushed interval
+                for (int ci = 0; ci < (nc <= 64 ? nc : wtiles); ci++) {
+                    int x = ci;
+                    if (nc <= 64) x = cand[ci]; else if (!(tm[ci] <= thr)) continue;
+                    const int32_t bin = x * WTILE + tid;             // WTILE == blockDim.x
+                    if (bin >= num_bins) continue;
+                    const double r = row[(size_t)bin * 3 + 0];
+                    const double c = row[(size_t)bin * 3 + 1];
+                    const double b = row[(size_t)bin * 3 + 2];
+                    const double er = exp(r);
+                    for (int tt = 0; tt < (int)fb.count; tt++) {
+                        if (!((gomask >> tt) & 1u)) continue;
+                        const double f = f64[(size_t)tt * (size_t)num_bins + bin];
+                        if (f == 0.0) continue;
+                        const double Yka = exp(log(f) - b);
+                        const double A = c / (Yka * er);
+                        if (A < bestA || (A == bestA && (tt < bestT || (tt == bestT && bin < bestB)))) { bestA = A; bestB = bin; bestT = tt; }
+                    }
+                }
+            } else if (nc <= 64) {
                 for (int ci = 0; ci < nc; ci++) {
                     const int32_t bin = cand[ci] * WTILE + tid;      // WTILE == blockDim.x
                     if (bin < num_bins) {
@@ -334,16 +381,19 @@ __global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ 
                 }
             }
             (void)overflow;
+            // (interval, bin) as one key: the order of the stream
+            long long bestK = ((long long)bestT << 32) | (long long)(uint32_t)bestB;
             for (int off = 32; off; off >>= 1) {
                 const double oA = __shfl_xor(bestA, off);
-                const int32_t oB = __shfl_xor(bestB, off);
-                if (oA < bestA || (oA == bestA && oB < bestB)) { bestA = oA; bestB = oB; }
+                const long long oK = __shfl_xor(bestK, off);
+                if (oA < bestA || (oA == bestA && oK < bestK)) { bestA = oA; bestK = oK; }
             }
-            if (lane == 0) { redA[wid] = bestA; redB[wid] = bestB; }
+            if (lane == 0) { redA[wid] = bestA; redK[wid] = bestK; }
             __syncthreads();
 #pragma unroll
             for (int x = 0; x < 4; x++)
-                if (redA[x] < bestA || (redA[x] == bestA && redB[x] < bestB)) { bestA = redA[x]; bestB = redB[x]; }
+                if (redA[x] < bestA || (redA[x] == bestA && redK[x] < bestK)) { bestA = redA[x]; bestK = redK[x]; }
+            bestB = (int32_t)(uint32_t)bestK;
         }
     }
     if (tid == 0) { candA[(size_t)t * slots + slot] = bestA; candB[(size_t)t * slots + slot] = bestB; }
@@ -353,13 +403,13 @@ __global__ __launch_bounds__(256) void k_cws_resolve(const double *__restrict__ 
 // the smallest A of interval t replaces the slot iff it is strictly below the running weight.
 __global__ void k_cws_apply(const double *__restrict__ candA, const int32_t *__restrict__ candB,
                             unsigned long long *__restrict__ mins, double *__restrict__ weights,
-                            int slots, int slot_begin, const DevState *st, FlushBatch fb) {
+                            int slots, int slot_begin, const DevState *st, FlushBatch fb, int merged) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= slots || st->skip_exact[fb.parity]) return;
     const int gs = slot_begin + slot;
     double w = weights[gs]; unsigned long long m = mins[gs];
-    for (int t = 0; t < (int)fb.count; t++) {
-        if (!flush_go(st, fb, t)) continue;
+    for (int t = 0; t < (merged ? 1 : (int)fb.count); t++) {
+        if (!merged && !flush_go(st, fb, t)) continue;          // (merged: plane 0 is the batch's one candidate, or none)
         const double A = candA[(size_t)t * slots + slot];
         const int32_t b = candB[(size_t)t * slots + slot];
         if (b != 0x7fffffff && A < w) { w = A; m = (unsigned long long)b; }
@@ -749,10 +799,13 @@ __global__ void k_fill_f32(float *p, size_t n, float v) {
 }  // namespace
 
 // ---------------------------------------------------------------------------- host wrappers
+// A/B aid: HULK_SCAN_PER_INTERVAL=1 keeps the per-interval minima (and resolve) without concept drift too
+static bool scan_merge_off() { static const bool v = getenv("HULK_SCAN_PER_INTERVAL") != nullptr; return v; }
+
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
-                           unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap) {
+                           unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap, bool per_interval) {
     const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
     const int wtiles = ntiles * 4, wwords = (wtiles + 63) / 64;
     if (d_kmin32)
@@ -760,8 +813,12 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
     hipLaunchKernelGGL(k_scan_test, dim3((wwords + 3) / 4, groups), dim3(256), 0, s, d_kmin32, d_rext, d_weights, slot_begin,
                        slots, wtiles, wwords, drift_dw, st, fb, d_scanmap, d_visited);
     const int chunks = (wwords * 4 + 7) / 8;                     // units of 16 wave tiles, 8 (one per XCD) side by side
-    hipLaunchKernelGGL(k_cws_scan, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rcp32,
-                       d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
+    if (per_interval || scan_merge_off())                       // concept drift: the elements are taken in stream order
+        hipLaunchKernelGGL(k_cws_scan<false>, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rcp32,
+                           d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
+    else
+        hipLaunchKernelGGL(k_cws_scan<true>, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rcp32,
+                           d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
     return hipGetLastError();
 }
 
@@ -788,10 +845,15 @@ hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *
                               unsigned long long *d_mins, double *d_weights,
                               int slots, int slot_begin, int ntiles, const unsigned long long *d_scanmap, DevState *st,
                               const FlushBatch &fb) {
-    hipLaunchKernelGGL(k_cws_resolve, dim3(slots, fb.count), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
-                       d_rcb, d_f64, d_tilemin, d_candA, d_candB, slots, ntiles, d_scanmap, (ntiles * 4 + 63) / 64, st, fb);
+    const int merged = scan_merge_off() ? 0 : 1;                 // (this launcher is the no-drift path)
+    if (merged)
+        hipLaunchKernelGGL(k_cws_resolve<true>, dim3(slots, 1), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
+                           d_rcb, d_f64, d_tilemin, d_candA, d_candB, slots, ntiles, d_scanmap, (ntiles * 4 + 63) / 64, st, fb);
+    else
+        hipLaunchKernelGGL(k_cws_resolve<false>, dim3(slots, fb.count), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
+                           d_rcb, d_f64, d_tilemin, d_candA, d_candB, slots, ntiles, d_scanmap, (ntiles * 4 + 63) / 64, st, fb);
     hipLaunchKernelGGL(k_cws_apply, dim3((slots + 255) / 256), dim3(256), 0, s, d_candA, d_candB, d_mins,
-                       d_weights, slots, slot_begin, st, fb);
+                       d_weights, slots, slot_begin, st, fb, merged);
     return hipGetLastError();
 }
 

@@ -45,6 +45,7 @@ int sync_all(hulk_ctx *c) {
     { const int rc = issue_flush(c, nullptr); if (rc != HULK_OK) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->lane[1].stream) HIPCHK(c, hipStreamSynchronize(c->lane[1].stream));
+    c->stagger = 1;                                             // both lanes idle: see bin_fast
     HIPCHK(c, hipStreamSynchronize(c->flush_stream));
     return HULK_OK;
 }
@@ -181,6 +182,11 @@ static int lane_reserve(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, uint6
 static int bin_fast(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
                     uint64_t n, uint32_t max_len, MinimizerParams P, uint32_t *hist, hipEvent_t spectra_gate) {
     { const int rc = lane_reserve(c, ln, s, n, P.pair != 0); if (rc != HULK_OK) return rc; }
+    // Both lanes idle (the context was just synchronised): the two batches that come next would start their
+    // k_minimizer_fast together and run in lock step — same kernels side by side, nothing to fill — for several batches
+    // before they drift apart.  The second one therefore waits for the first one's k_minimizer_fast, which puts the lanes
+    // half a batch apart at once (k_minimizer_fast beside the other lane's k_jump_bin).
+    if (c->stagger == 2 && c->ev_stagger) { HIPCHK(c, hipStreamWaitEvent(s, c->ev_stagger, 0)); c->stagger = 0; }
     ProfileRec pr{}; pr.which = 1;
     if ((c->profiling & 2)) {
         HIPCHK(c, hipEventCreateWithFlags(&pr.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pr.b, PROFILE_EVENT_FLAGS));
@@ -188,6 +194,11 @@ static int bin_fast(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, const uin
     }
     HIPCHK(c, launch_minimizer_fast(s, d_bases, d_offsets, n, P, ln.ml, c->d_state, c->d_min_slots));
     if ((c->profiling & 2)) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
+    if (c->stagger == 1 && c->work_lanes > 1 && !c->no_overlap) {
+        if (!c->ev_stagger) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_stagger, s));
+        c->stagger = 2;
+    }
     ProfileRec pj{}; pj.which = 2;
     ProfileRec pl{}; pl.which = 3;
     if ((c->profiling & 4)) {
@@ -318,7 +329,8 @@ int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &
         }
         HIPCHK(c, launch_cws_scan(s, c->d_k32, c->d_rcp32, c->d_tilemin, (int)c->slots, c->ntiles,
                                   c->row_stride, c->d_state, fb, c->prune ? c->d_kmin32 : nullptr, c->d_rext,
-                                  c->d_weights, (int)c->slot_begin, c->d_visited, c->drift ? c->decay_weight : 0.0, c->d_scanmap));
+                                  c->d_weights, (int)c->slot_begin, c->d_visited, c->drift ? c->decay_weight : 0.0, c->d_scanmap,
+                                  c->drift /* per-interval minima: the drift resolve replays the stream in order */));
         c->scan_tiles_total += (uint64_t)((c->slots + SCAN_ROWS - 1) / SCAN_ROWS) * (uint64_t)c->ntiles * 4u;
         if ((c->profiling & 1)) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
         if (c->drift)

@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
                 const unsigned sh = (unsigned)(addr & 3) * 8;
                 const uint32_t lo = *(const uint32_t *)al;       // aligned dword holding base p
                 uint32_t hi = 0;
-                if (sh && al + 8 <= (uintptr_t)bases + P.bases_bytes) hi = *(const uint32_t *)(al + 4);
+                // (an ALIGNED dword with at least one byte inside the buffer lies in the buffer's last page: loading it whole is
+                //  safe, and a buffer need not end on a dword border — its last 1-3 bases are in such a dword)
+                if (sh && al + 4 < (uintptr_t)bases + P.bases_bytes) hi = *(const uint32_t *)(al + 4);
                 const uint32_t by = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
                 const int nv = left < 4 ? (int)left : 4;
                 unsigned pack = 0, npack = 0;
@@ -449,19 +451,19 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
         const uintptr_t lim = (uintptr_t)bases + P.bases_bytes;
         constexpr int NCH = PAIR ? 5 : 3;
         uint4 v[NCH]; bool whole[NCH];
-        const bool first_ok = raw_a0 + 16 <= lim;               // (false only for a buffer of < 16 bytes)
+        const bool first_ok = raw_a0 < lim;
 #pragma unroll
         for (int x = 0; x < NCH; x++) {
             const uintptr_t a = raw_a0 + 16u * (uint32_t)(lane + 64 * x);
-            whole[x] = a < raw_end + 16 && a + 16 <= lim;
+            whole[x] = a < raw_end + 16 && a < lim;       // (an aligned 16-byte chunk with a byte inside the buffer lies in its last page)
             v[x] = first_ok ? *(const uint4 *)(whole[x] ? a : raw_a0) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int x = 0; x < NCH; x++) {
             const uintptr_t a = raw_a0 + 16u * (uint32_t)(lane + 64 * x);
             if (whole[x]) *(uint4 *)(raw32 + 4 * (lane + 64 * x)) = v[x];
-            else if (a < raw_end + 16)                          // the buffer ends inside this chunk
-                for (int y = 0; y < 4; y++) raw32[4 * (lane + 64 * x) + y] = (a + 4 * y + 4 <= lim) ? *(const uint32_t *)(a + 4 * y) : 0u;
+            else if (a < raw_end + 16)                          // the chunk lies behind the buffer
+                for (int y = 0; y < 4; y++) raw32[4 * (lane + 64 * x) + y] = 0u;
         }
     }
     wave_sync();
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                     const uintptr_t al = addr & ~(uintptr_t)3, end = (uintptr_t)bases + P.bases_bytes;
                     sh = (unsigned)(addr & 3) * 8;
 #pragma unroll
-                    for (int x = 0; x < 5; x++) d[x] = (al + 4 * (x + 1) <= end) ? *(const uint32_t *)(al + 4 * x) : 0u;
+                    for (int x = 0; x < 5; x++) d[x] = (al + 4 * x < end) ? *(const uint32_t *)(al + 4 * x) : 0u;
                 }
                 // ASCII -> 2-bit, four bases per dword, no table: fold the case, code = (c >> 1 ^ c >> 2) & 3
                 // (A 0, C 1, G 2, T 3), and prove it by mapping the codes back to letters with one v_perm_b32:
