@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "hulk_batch_size", "hulk_bin_reads_device", "hulk_bin_reads_device_at", "hulk_histogram_device", "hulk_flush_batch", "hulk_flush_batch_after", "hulk_add_histogram", "hulk_flush",
     "hulk_finish", "hulk_get_sketch", "hulk_get_counters", "hulk_get_histogram", "hulk_get_cms",
     "hulk_get_cws_tables", "hulk_smash", "hulk_smash_ex", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
-    "hulk_parse_files", "hulk_sketch_files", "hulk_get_scan_stats", "hulk_synchronize",
+    "hulk_parse_files", "hulk_sketch_files", "hulk_parse_files_opts", "hulk_sketch_files_opts", "hulk_get_scan_stats", "hulk_synchronize",
     "hulk_comm_unique_id", "hulk_comm_init", "hulk_comm_init_host", "hulk_comm_init_loopback", "hulk_step_sharded", "hulk_step_sharded_host",
     "hulk_step_sliced", "hulk_gather_sketch", "hulk_get_comm_stats",
 )
@@ -50,6 +50,16 @@ class HulkParams(ctypes.Structure):
 class IngestStats(ctypes.Structure):
     _fields_ = [("n_seqs", ctypes.c_uint64), ("total_len", ctypes.c_uint64), ("n_lines", ctypes.c_uint64),
                 ("bytes_in", ctypes.c_uint64), ("seconds", ctypes.c_double)]
+
+
+HULK_INGEST_GZ_ONE_THREAD, HULK_INGEST_GZ_ZLIB, HULK_INGEST_TRACE = 1, 2, 4
+
+
+class IngestOpts(ctypes.Structure):
+    """hulk_ingest_opts (include/hulk_hip.h): the knobs of one run of the host ingest, 0 = default."""
+    _fields_ = [("parser_threads", ctypes.c_uint32), ("gz_threads", ctypes.c_uint32), ("file_readers", ctypes.c_uint32),
+                ("flags", ctypes.c_uint32), ("block_bytes", ctypes.c_uint64), ("gz_chunk_bytes", ctypes.c_uint64),
+                ("reserved", ctypes.c_uint64 * 2)]
 
 
 BATCH_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8),
@@ -199,6 +209,12 @@ def load():
     L.hulk_sketch_files.restype = ctypes.c_int
     L.hulk_sketch_files.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), u32, ctypes.c_int, u32,
                                     ctypes.POINTER(IngestStats)]
+    L.hulk_parse_files_opts.restype = ctypes.c_int
+    L.hulk_parse_files_opts.argtypes = [ctypes.POINTER(ctypes.c_char_p), u32, ctypes.c_int, ctypes.POINTER(IngestOpts), BATCH_FN, vp,
+                                        ctypes.POINTER(IngestStats), ctypes.c_char_p, u64]
+    L.hulk_sketch_files_opts.restype = ctypes.c_int
+    L.hulk_sketch_files_opts.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), u32, ctypes.c_int, ctypes.POINTER(IngestOpts),
+                                         ctypes.POINTER(IngestStats)]
     L.hulk_comm_unique_id.restype = ctypes.c_int; L.hulk_comm_unique_id.argtypes = [vp]
     L.hulk_comm_init.restype = ctypes.c_int; L.hulk_comm_init.argtypes = [vp, vp, u32, u32]
     L.hulk_comm_init_host.restype = ctypes.c_int; L.hulk_comm_init_host.argtypes = [vp, u32, u32, EXCHANGE_FN, vp]

@@ -44,16 +44,50 @@
 namespace {
 
 constexpr size_t MAX_TOKEN = 64 * 1024;      // bufio.MaxScanTokenSize
-// block size: 32 MB; HULK_INGEST_BLOCK (bytes, >= 128 KiB) shrinks it so that tests cross many block borders
-static size_t block_bytes() {
-    static const size_t v = [] {
-        const char *e = getenv("HULK_INGEST_BLOCK");
-        size_t b = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(32u << 20);
-        return b < 2 * MAX_TOKEN ? 2 * MAX_TOKEN : b;
-    }();
-    return v;
+// The knobs of ONE run (hulk_ingest_opts, include/hulk_hip.h): resolved once by run_ingest — defaults, then the caller's
+// fields, then the HULK_* environment variables as overrides for profiling scripts and tests — and handed down to the
+// readers; two runs side by side (two contexts of one host process) do not share them.
+struct IngestCfg {
+    size_t block = (size_t)(32u << 20);       // bytes per block of the line pump (>= 128 KiB)
+    unsigned parser_threads = 0;              // 0: one per hardware thread, at most 16 (more were measured slower)
+    unsigned gz_threads = 16;                 // members of a bgzip'd input / chunks of ONE gzip member inflated side by side
+    bool gz_par = true;                       // one ordinary gzip member on gz_threads threads (GzPar)
+    size_t gz_chunk = (size_t)(1u << 20);     // GzPar: compressed bytes per chunk (>= 8 KiB)
+    unsigned readers = 4;                     // pieces a block of a regular file is pread() in, side by side
+    bool zlib = false;                        // zlib's inflate instead of fast_inflate.h
+    bool trace = false;                       // per-phase seconds on stderr
+};
+static IngestCfg resolve_cfg(const hulk_ingest_opts *o, uint32_t threads) {
+    IngestCfg c;
+    c.parser_threads = threads;
+    if (o) {
+        if (o->parser_threads) c.parser_threads = o->parser_threads;
+        if (o->gz_threads) c.gz_threads = o->gz_threads;
+        if (o->block_bytes) c.block = (size_t)o->block_bytes;
+        if (o->gz_chunk_bytes) c.gz_chunk = (size_t)o->gz_chunk_bytes;
+        if (o->file_readers) c.readers = o->file_readers;
+        if (o->flags & HULK_INGEST_GZ_ONE_THREAD) c.gz_par = false;
+        if (o->flags & HULK_INGEST_GZ_ZLIB) c.zlib = true;
+        if (o->flags & HULK_INGEST_TRACE) c.trace = true;
+    } else {
+        const long hw = (long)std::thread::hardware_concurrency();
+        if (hw > 0 && (long)c.gz_threads > hw) c.gz_threads = (unsigned)hw;
+    }
+    if (const char *e = getenv("HULK_INGEST_BLOCK")) c.block = (size_t)strtoull(e, nullptr, 10);
+    if (const char *e = getenv("HULK_GZ_THREADS")) c.gz_threads = (unsigned)std::max(1L, strtol(e, nullptr, 10));
+    if (const char *e = getenv("HULK_GZ_PAR")) c.gz_par = !(e[0] == '0');
+    if (const char *e = getenv("HULK_GZ_PAR_CHUNK")) c.gz_chunk = (size_t)strtoull(e, nullptr, 10);
+    if (const char *e = getenv("HULK_INGEST_READERS")) c.readers = (unsigned)std::max(1L, strtol(e, nullptr, 10));
+    if (getenv("HULK_GZ_ZLIB")) c.zlib = true;
+    if (getenv("HULK_INGEST_TRACE")) c.trace = true;
+    if (c.block < 2 * MAX_TOKEN) c.block = 2 * MAX_TOKEN;
+    if (c.gz_threads < 1) c.gz_threads = 1;
+    if (c.gz_threads > 64) c.gz_threads = 64;
+    if (c.gz_chunk < (8u << 10)) c.gz_chunk = 8u << 10;
+    if (c.readers < 1) c.readers = 1;
+    if (c.readers > 16) c.readers = 16;
+    return c;
 }
-#define BLOCK_BYTES (block_bytes())
 constexpr size_t FASTA_BATCH_BYTES = 64u << 20;
 
 struct IngestError {
@@ -327,6 +361,7 @@ class Team {
         for (unsigned i; (i = next_.fetch_add(1, std::memory_order_relaxed)) < n;) f(i);
         std::unique_lock<std::mutex> g(m_);
         done_.wait(g, [this] { return pending_ == 0; });
+        if (failed_) { std::exception_ptr e = failed_; failed_ = nullptr; std::rethrow_exception(e); }
     }
 
  private:
@@ -339,7 +374,14 @@ class Team {
             seen = gen_;
             const std::function<void(unsigned)> *job = job_; const unsigned n = n_;
             g.unlock();
-            for (unsigned i; (i = next_.fetch_add(1, std::memory_order_relaxed)) < n;) (*job)(i);
+            try {
+                for (unsigned i; (i = next_.fetch_add(1, std::memory_order_relaxed)) < n;) (*job)(i);
+            } catch (...) {                                 // a worker has no caller to unwind to: run() rethrows it in the caller's thread
+                next_.store(n, std::memory_order_relaxed);
+                g.lock();
+                if (!failed_) failed_ = std::current_exception();
+                g.unlock();
+            }
             g.lock();
             if (--pending_ == 0) done_.notify_one();
         }
@@ -350,6 +392,7 @@ class Team {
     uint64_t gen_ = 0; bool stop_ = false;
     const std::function<void(unsigned)> *job_ = nullptr; unsigned n_ = 0, pending_ = 0;
     std::atomic<unsigned> next_{0};
+    std::exception_ptr failed_;
 };
 
 // One core copies ~8 GB/s out of a buffer another core wrote, less than several inflate threads deliver: large pieces are
@@ -376,16 +419,7 @@ static void copy_wide(uint8_t *dst, const uint8_t *src, size_t n) {
 // ------------------------------------------------------------------------------------------
 class GzBgzf : public GzStream {
  public:
-    static unsigned threads() {
-        static const unsigned v = [] {
-            const char *e = getenv("HULK_GZ_THREADS");
-            long r = e ? strtol(e, nullptr, 10) : 16;
-            const long hw = (long)std::thread::hardware_concurrency();
-            if (!e && hw > 0 && r > hw) r = hw;
-            return (unsigned)(r < 1 ? 1 : r > 64 ? 64 : r);
-        }();
-        return v;
-    }
+    unsigned threads() const { return cfg_.gz_threads; }
     // total size of the member whose header starts at p (n bytes available), 0 = not a BGZF member / header incomplete
     static size_t member_size(const uint8_t *p, size_t n, size_t *header_len) {
         if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || p[3] != 4) return 0;       // FEXTRA and nothing else
@@ -410,12 +444,12 @@ class GzBgzf : public GzStream {
         size_t hl;
         return m >= 18 && member_size(h, (size_t)m, &hl) != 0;
     }
-    explicit GzBgzf(int fd) : fd_(fd) { th_ = std::thread([this] { produce(); }); }
+    GzBgzf(int fd, const IngestCfg &cfg) : cfg_(cfg), fd_(fd) { th_ = std::thread([this] { produce(); }); }
     ~GzBgzf() override {
         { std::lock_guard<std::mutex> g(m_); stop_ = true; }
         cv_.notify_all();
         if (th_.joinable()) th_.join();
-        if (getenv("HULK_INGEST_TRACE"))
+        if (cfg_.trace)
             fprintf(stderr, "ingest trace: BGZF reader, %llu members inflated by %u threads%s\n", (unsigned long long)n_members_,
                     threads(), tail_ ? ", then handed over to the sequential reader" : "");
         if (tail_) tail_.reset();                                  // (owns and closes the descriptor from then on)
@@ -450,6 +484,7 @@ class GzBgzf : public GzStream {
     }
 
  private:
+    IngestCfg cfg_;                                          // this run's knobs (resolve_cfg)
     static constexpr size_t IN_BATCH = 8u << 20, MAX_ISIZE = 1u << 16;
     struct Member { size_t hdr_off, in_off, in_len, out_off; uint32_t crc, isize; };
     struct Batch {
@@ -577,30 +612,28 @@ class GzBgzf : public GzStream {
 // ------------------------------------------------------------------------------------------
 class GzPar : public GzStream {
  public:
-    static size_t chunk_bytes() {
-        static const size_t v = [] {
-            const char *e = getenv("HULK_GZ_PAR_CHUNK");
-            const size_t b = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(1u << 20);
-            return b < (8u << 10) ? (size_t)(8u << 10) : b;
-        }();
-        return v;
-    }
-    static bool wanted(int fd) {
-        static const bool on = [] { const char *e = getenv("HULK_GZ_PAR"); return !(e && e[0] == '0'); }();
+    size_t chunk_bytes() const { return cfg_.gz_chunk; }
+    // worth its threads and its scratch (2 T symbol buffers of ~21 chunk sizes each) from 4 chunks of compressed input on
+    static bool wanted(int fd, const IngestCfg &cfg) {
         struct stat sb;
-        return on && GzBgzf::threads() > 1 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= 4 * chunk_bytes();
+        return cfg.gz_par && cfg.gz_threads > 1 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= 4 * cfg.gz_chunk;
     }
-    explicit GzPar(int fd) : fd_(fd), t_start_(clock_s()) { th_ = std::thread([this] { produce(); t_done_ = clock_s() - t_start_; }); }
+    GzPar(int fd, const IngestCfg &cfg) : cfg_(cfg), fd_(fd), t_start_(clock_s()) {
+        // no more chunks per batch than the file has: a 5 MB file does not map the scratch of 16 decoders
+        struct stat sb;
+        if (fstat(fd, &sb) == 0) cfg_.gz_threads = (unsigned)std::max<size_t>(2, std::min<size_t>(cfg_.gz_threads, (size_t)sb.st_size / cfg_.gz_chunk));
+        th_ = std::thread([this] { produce(); t_done_ = clock_s() - t_start_; });
+    }
     static double clock_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     ~GzPar() override {
         { std::lock_guard<std::mutex> g(m_); stop_ = true; }
         cv_.notify_all();
         const double t_close = clock_s() - t_start_;
         if (th_.joinable()) th_.join();
-        if (getenv("HULK_INGEST_TRACE"))
+        if (cfg_.trace)
             fprintf(stderr, "ingest trace: parallel gzip reader timeline (s since it was opened): first batch out %.3f, last batch out %.3f, producer gone %.3f, "
                     "reader closed %.3f\n", t_first_, t_last_, t_done_, t_close);
-        if (getenv("HULK_INGEST_TRACE"))
+        if (cfg_.trace)
             fprintf(stderr, "ingest trace: parallel gzip reader, %llu batches, %llu chunks counted / %llu decoded, %llu bytes of text, %llu members ended here%s; producer s: "
                     "input %.3f, decode %.3f, windows %.3f, waiting for the batch in front to become bytes %.3f\n",
                     (unsigned long long)n_batches_, (unsigned long long)n_counted_, (unsigned long long)n_decoded_, (unsigned long long)n_bytes_,
@@ -635,6 +668,7 @@ class GzPar : public GzStream {
     }
 
  private:
+    IngestCfg cfg_;                                          // this run's knobs (resolve_cfg)
     static constexpr size_t W = hulk::inflate::SPEC_WINDOW;
     static constexpr int64_t PENDING = -1, NONE = -2;
     struct Batch {
@@ -679,7 +713,7 @@ class GzPar : public GzStream {
 
     void produce() {
         using namespace hulk::inflate;
-        const unsigned T = GzBgzf::threads();
+        const unsigned T = cfg_.gz_threads;
         const unsigned HW = std::max(1u, std::thread::hardware_concurrency());
         const size_t C = chunk_bytes(), EXTRA = std::max<size_t>(C, 1u << 20), IN_LEN = (size_t)T * C + EXTRA;
         // symbols per chunk: FASTQ deflates 3-5x; a block of zlib's is <= 32 Ki symbols of <= 258 bytes.  Where a chunk does not fit
@@ -776,7 +810,12 @@ class GzPar : public GzStream {
                 if (ok) {
                     b = get_free();
                     if (!b) return;
-                    if (b->out_cap < c.out_len) { b->out.reset(c.out_len + 64); b->out_cap = c.out_len; }
+                    try {
+                        if (b->out_cap < c.out_len) { b->out_cap = 0; b->out.reset(c.out_len + 64); b->out_cap = c.out_len; }
+                    } catch (const std::bad_alloc &) {
+                        b->out_len = 0; b->err = "gzip: out of memory for " + std::to_string(c.out_len) + " bytes of inflated text";
+                        publish(b); return;
+                    }
                     uint8_t *l = S.lut.data();
                     for (int i = 0; i < 256; i++) l[i] = (uint8_t)i;
                     memcpy(l + 256, win.data(), W);
@@ -884,9 +923,17 @@ class GzPar : public GzStream {
                 Batch *b = get_free();
                 if (!b) { gone = true; return; }
                 const size_t out_total = off[acc];
-                if (b->out_cap < out_total) { b->out.reset(out_total + out_total / 16 + 64); b->out_cap = out_total + out_total / 16; }
                 struct Piece { unsigned j; size_t at, len; uint32_t crc; };
                 std::vector<Piece> pieces;
+                // (this thread has no caller to unwind to: running out of memory here must end the run with a message, not the
+                //  process with std::terminate — ADVICE r3)
+                try {
+                    if (b->out_cap < out_total) { b->out_cap = 0; b->out.reset(out_total + out_total / 16 + 64); b->out_cap = out_total + out_total / 16; }
+                    pieces.reserve(acc * 8 + 64);
+                } catch (const std::bad_alloc &) {
+                    b->out_len = 0; b->err = "gzip: out of memory for " + std::to_string(out_total) + " bytes of inflated text";
+                    publish(b); gone = true; return;
+                }
                 const size_t target = std::max<size_t>(256u << 10, out_total / std::max(1u, std::min(HW, 4 * T)) + 1);
                 for (unsigned j = 0; j < acc; j++) {
                     const size_t len = S.ch[j].out_len, parts = std::max<size_t>(1, len / target), step = ((len + parts - 1) / parts + 63) & ~(size_t)63;
@@ -936,7 +983,7 @@ class GzPar : public GzStream {
 // ------------------------------------------------------------------------------------------
 class ByteSource {
  public:
-    ByteSource(const char *const *paths, uint32_t n) {
+    ByteSource(const char *const *paths, uint32_t n, const IngestCfg &cfg) : cfg_(cfg) {
         for (uint32_t i = 0; i < n; i++) paths_.push_back(paths[i] ? paths[i] : "");
         stdin_mode_ = paths_.empty();
     }
@@ -979,17 +1026,11 @@ class ByteSource {
     }
 
  private:
+    IngestCfg cfg_;                                          // this run's knobs (resolve_cfg)
     // A single read() out of the page cache is one core's memcpy (~10 GB/s), slower than the parser behind
     // it: large requests on a regular file are cut into pieces that are pread() side by side.
     static constexpr size_t PAR_READ_MIN = 8u << 20;
-    static unsigned readers() {
-        static const unsigned v = [] {
-            const char *e = getenv("HULK_INGEST_READERS");
-            long r = e ? strtol(e, nullptr, 10) : 4;
-            return (unsigned)(r < 1 ? 1 : r > 16 ? 16 : r);
-        }();
-        return v;
-    }
+    unsigned readers() const { return cfg_.readers; }
     static long pread_all(int fd, uint8_t *dst, size_t len, off_t at) {
         size_t got = 0;
         while (got < len) {
@@ -1037,10 +1078,10 @@ class ByteSource {
             const ssize_t m = ::pread(fd_, magic, 2, 0);
             if (m == 0) { close_current(); return err.set(HULK_ERR_IO, "EOF"); }                    // gzip.NewReader on an empty file
             if (m < 2 || magic[0] != 0x1f || magic[1] != 0x8b) { close_current(); return err.set(HULK_ERR_IO, "gzip: invalid header"); }
-            static const bool use_zlib = getenv("HULK_GZ_ZLIB") != nullptr;
+            const bool use_zlib = cfg_.zlib;
             if (!use_zlib) {
-                if (regular_ && GzBgzf::threads() > 1 && GzBgzf::looks_like(fd_)) gzf_.reset(new GzBgzf(fd_));
-                else if (regular_ && GzPar::wanted(fd_)) gzf_.reset(new GzPar(fd_));
+                if (regular_ && cfg_.gz_threads > 1 && GzBgzf::looks_like(fd_)) gzf_.reset(new GzBgzf(fd_, cfg_));
+                else if (regular_ && GzPar::wanted(fd_, cfg_)) gzf_.reset(new GzPar(fd_, cfg_));
                 else gzf_.reset(new GzFast(fd_));
                 return true;
             }
@@ -1079,7 +1120,7 @@ struct Block {
 
 class BlockReader {
  public:
-    BlockReader(const char *const *paths, uint32_t n) : src_(paths, n) { th_ = std::thread([this] { run(); }); }
+    BlockReader(const char *const *paths, uint32_t n, const IngestCfg &cfg) : block_(cfg.block), src_(paths, n, cfg) { th_ = std::thread([this] { run(); }); }
     ~BlockReader() {
         { std::lock_guard<std::mutex> g(m_); stop_ = true; }
         cv_.notify_all();
@@ -1109,14 +1150,14 @@ class BlockReader {
                 if (!pool_.empty()) { b = std::move(pool_.back()); pool_.pop_back(); }
             }
             if (!b) b.reset(new Block);
-            if (b->buf.size() < BLOCK_BYTES + MAX_TOKEN + 16) b->buf.resize(BLOCK_BYTES + MAX_TOKEN + 16);
+            if (b->buf.size() < block_ + MAX_TOKEN + 16) b->buf.resize(block_ + MAX_TOKEN + 16);
             size_t have = carry.size();
-            if (have > b->buf.size() - BLOCK_BYTES) b->buf.resize(have + BLOCK_BYTES + 16);
+            if (have > b->buf.size() - block_) b->buf.resize(have + block_ + 16);
             if (have) memcpy(b->buf.data(), carry.data(), have);
             carry.clear();
             IngestError e;
-            while (have < BLOCK_BYTES) {
-                const long n = src_.read(b->buf.data() + have, BLOCK_BYTES - have, e);
+            while (have < block_) {
+                const long n = src_.read(b->buf.data() + have, block_ - have, e);
                 if (n < 0) { finish(e); return; }
                 if (n == 0) { eof = true; break; }
                 have += (size_t)n; bytes_in_ += (uint64_t)n;
@@ -1145,6 +1186,7 @@ class BlockReader {
         { std::lock_guard<std::mutex> g(m_); err_ = e; done_ = true; }
         cv_.notify_all();
     }
+    const size_t block_;                                     // IngestCfg::block
     ByteSource src_;
     std::thread th_;
     std::mutex m_;
@@ -1207,15 +1249,13 @@ struct CallbackSink : Sink {
 // HULK_INGEST_TRACE=1: seconds the calling thread spent in each phase of a run, on stderr when the run ends (diagnosis)
 struct PhaseTrace {
     double wait_block = 0, parse = 0, stage_wait = 0, enqueue = 0, add_reads = 0;
-    static bool on() { static const bool v = getenv("HULK_INGEST_TRACE") != nullptr; return v; }
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 };
-static PhaseTrace g_trace;
 
 struct GpuSink : Sink {
     // the staging (two pinned + device sets) is the context's: nothing is allocated or freed per run after the first
-    hulk_ctx *ctx; hulk::StageSet st{}; uint64_t min_len;
-    explicit GpuSink(hulk_ctx *c) : ctx(c), min_len(hulk::ctx_min_read_len(c)) {}
+    hulk_ctx *ctx; hulk::StageSet st{}; uint64_t min_len; PhaseTrace &g_trace;      // (the run's own trace)
+    GpuSink(hulk_ctx *c, PhaseTrace &tr) : ctx(c), min_len(hulk::ctx_min_read_len(c)), g_trace(tr) {}
     bool prepare(uint64_t n, uint64_t nbytes, uint8_t **b, uint64_t **l, IngestError &err) override {
         const double tw0 = PhaseTrace::now();
         const int rc = hulk::ctx_stage_acquire(ctx, (size_t)nbytes, n, &st);
@@ -1443,15 +1483,17 @@ struct Parser {
     std::unique_ptr<Team> team_;
 };
 
-int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads, Sink &sink,
+int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, const IngestCfg &cfg, Sink &sink, PhaseTrace &g_trace,
                hulk_ingest_stats *stats, IngestError &err) {
     const auto t0 = std::chrono::steady_clock::now();
     if (n_paths && !paths) { err.set(HULK_ERR_ARG, "NULL path list"); return err.code; }
+    uint32_t threads = cfg.parser_threads;
+    // (0: one per hardware thread, at most 16 — 32 and 64 were measured slower on a 256-thread host; a caller's figure is taken as it is)
     if (threads == 0) { threads = std::thread::hardware_concurrency(); if (threads == 0) threads = 1; if (threads > 16) threads = 16; }
-    BlockReader reader(paths, n_paths);
+    if (threads > 256) threads = 256;
+    BlockReader reader(paths, n_paths, cfg);
     Parser ps(sink, threads, err);
     bool ok = true;
-    g_trace = PhaseTrace{};
     for (;;) {
         const double tb0 = PhaseTrace::now();
         std::unique_ptr<Block> b = reader.next(err);
@@ -1469,7 +1511,7 @@ int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, uint32_t t
         stats->bytes_in = reader.bytes_in();
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
-    if (PhaseTrace::on())
+    if (cfg.trace)
         fprintf(stderr, "ingest trace (calling thread, s): next block %.3f | parse + sink %.3f, of which: staging set (wait / first "
                         "allocation) %.3f, copies queued %.3f, hulk_add_reads_device %.3f\n", g_trace.wait_block, g_trace.parse,
                 g_trace.stage_wait, g_trace.enqueue, g_trace.add_reads);
@@ -1480,11 +1522,17 @@ int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, uint32_t t
 
 extern "C" {
 
-int hulk_parse_files(const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads, hulk_batch_fn fn,
-                     void *user, hulk_ingest_stats *stats, char *errbuf, uint64_t errbuf_len) {
+int hulk_parse_files_opts(const char *const *paths, uint32_t n_paths, int fasta, const hulk_ingest_opts *opts, hulk_batch_fn fn,
+                          void *user, hulk_ingest_stats *stats, char *errbuf, uint64_t errbuf_len) {
     IngestError err;
-    CallbackSink sink(fn, user);
-    const int rc = run_ingest(paths, n_paths, fasta, threads, sink, stats, err);
+    int rc;
+    if (opts && (opts->flags & ~(HULK_INGEST_GZ_ONE_THREAD | HULK_INGEST_GZ_ZLIB | HULK_INGEST_TRACE))) {
+        err.set(HULK_ERR_ARG, "hulk_ingest_opts: unknown flags"); rc = err.code;
+    } else {
+        CallbackSink sink(fn, user);
+        PhaseTrace trace;
+        rc = run_ingest(paths, n_paths, fasta, resolve_cfg(opts, 0), sink, trace, stats, err);
+    }
     if (errbuf && errbuf_len) {
         const std::string &m = rc == HULK_OK ? std::string() : err.msg;
         const size_t n = std::min<size_t>(m.size(), (size_t)errbuf_len - 1);
@@ -1493,17 +1541,34 @@ int hulk_parse_files(const char *const *paths, uint32_t n_paths, int fasta, uint
     return rc;
 }
 
-int hulk_sketch_files(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads,
-                      hulk_ingest_stats *stats) {
+int hulk_parse_files(const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads, hulk_batch_fn fn,
+                     void *user, hulk_ingest_stats *stats, char *errbuf, uint64_t errbuf_len) {
+    hulk_ingest_opts o; memset(&o, 0, sizeof o);
+    o.parser_threads = threads;
+    return hulk_parse_files_opts(paths, n_paths, fasta, threads ? &o : nullptr, fn, user, stats, errbuf, errbuf_len);
+}
+
+int hulk_sketch_files_opts(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, int fasta, const hulk_ingest_opts *opts,
+                           hulk_ingest_stats *stats) {
     if (!ctx) return HULK_ERR_ARG;
+    if (opts && (opts->flags & ~(HULK_INGEST_GZ_ONE_THREAD | HULK_INGEST_GZ_ZLIB | HULK_INGEST_TRACE)))
+        return hulk::ctx_fail(ctx, HULK_ERR_ARG, "hulk_ingest_opts: unknown flags");
     IngestError err;
     int rc;
     {
-        GpuSink sink(ctx);
-        rc = run_ingest(paths, n_paths, fasta, threads, sink, stats, err);
+        PhaseTrace trace;
+        GpuSink sink(ctx, trace);
+        rc = run_ingest(paths, n_paths, fasta, resolve_cfg(opts, 0), sink, trace, stats, err);
     }
     if (rc != HULK_OK) return hulk::ctx_fail(ctx, rc, err.msg.c_str());
     return HULK_OK;
+}
+
+int hulk_sketch_files(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads,
+                      hulk_ingest_stats *stats) {
+    hulk_ingest_opts o; memset(&o, 0, sizeof o);
+    o.parser_threads = threads;
+    return hulk_sketch_files_opts(ctx, paths, n_paths, fasta, threads ? &o : nullptr, stats);
 }
 
 }  // extern "C"

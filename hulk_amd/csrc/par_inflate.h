@@ -265,7 +265,7 @@ static inline void spec_run(SpecChunk &c, uint64_t start_bit, StopFn &&should_st
 
 // First bit in [from, to) that starts a plausible non-final dynamic block of text (see the head of this file); ~0 = none.
 static inline uint64_t find_block_start(const uint8_t *in, uint64_t in_bits, uint64_t from, uint64_t to) {
-    SpecTables *tb = new SpecTables;
+    SpecTables tbs, *tb = &tbs;                 // (on the stack: this runs on worker threads, where a failed `new` would end the process)
     uint64_t found = ~0ull;
     if (to > in_bits) to = in_bits;
     for (uint64_t p = from; p + 17 <= to; p++) {
@@ -277,7 +277,6 @@ static inline uint64_t find_block_start(const uint8_t *in, uint64_t in_bits, uin
         found = p;
         break;
     }
-    delete tb;
     return found;
 }
 

@@ -9,7 +9,12 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import BATCH_FN, HulkError, IngestStats
+from ._lib import BATCH_FN, HulkError, IngestOpts, IngestStats
+
+
+def make_opts(opts):
+    """dict of hulk_ingest_opts fields (parser_threads, gz_threads, file_readers, flags, block_bytes, gz_chunk_bytes) -> struct"""
+    return IngestOpts(**opts) if opts else None
 
 
 def _path_array(paths):
@@ -18,9 +23,10 @@ def _path_array(paths):
     return arr, len(enc)
 
 
-def parse_files(paths, fasta=False, threads=0, collect=True):
+def parse_files(paths, fasta=False, threads=0, collect=True, opts=None):
     """-> (bases uint8[], offsets uint64[n+1], stats dict).  paths == [] reads STDIN.
-    collect=False parses without handing the batches over (timing aid): empty arrays + stats."""
+    collect=False parses without handing the batches over (timing aid): empty arrays + stats.
+    opts: dict of hulk_ingest_opts fields for this run (hulk_parse_files_opts)."""
     L = _lib.load()
     arr, n = _path_array(paths)
     chunks, lens = [], []
@@ -35,7 +41,11 @@ def parse_files(paths, fasta=False, threads=0, collect=True):
     cb = BATCH_FN(on_batch) if collect else ctypes.cast(None, BATCH_FN)
     st = IngestStats()
     err = ctypes.create_string_buffer(1024)
-    rc = L.hulk_parse_files(arr, n, 1 if fasta else 0, threads, cb, None, ctypes.byref(st), err, 1024)
+    if opts:
+        o = make_opts(dict({"parser_threads": threads}, **opts))
+        rc = L.hulk_parse_files_opts(arr, n, 1 if fasta else 0, ctypes.byref(o), cb, None, ctypes.byref(st), err, 1024)
+    else:
+        rc = L.hulk_parse_files(arr, n, 1 if fasta else 0, threads, cb, None, ctypes.byref(st), err, 1024)
     if rc != 0:
         raise HulkError(rc, err.value.decode("latin-1") or L.hulk_strerror(rc).decode())
     bases = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8)

@@ -113,14 +113,19 @@ class GpuSketcher:
         self._chk(self._L.hulk_get_scan_stats(self._ctx, ctypes.byref(a), ctypes.byref(b)))
         return int(a.value), int(b.value)
 
-    def sketch_files(self, paths, fasta=False, threads=0):
+    def sketch_files(self, paths, fasta=False, threads=0, opts=None):
         """DataStreamer + FastqHandler + the AddSeq loop (pipeline/sketch.go:40-217) in native code:
-        parse the inputs ([] = STDIN, *.gz gunzipped) and add every read.  Returns the ingest stats."""
+        parse the inputs ([] = STDIN, *.gz gunzipped) and add every read.  Returns the ingest stats.
+        opts: dict of hulk_ingest_opts fields for this run."""
         import ctypes
         from ._lib import IngestStats
-        from .ingest import _path_array, stats_dict
+        from .ingest import _path_array, make_opts, stats_dict
         arr, n = _path_array(paths)
         st = IngestStats()
+        if opts:
+            o = make_opts(dict({"parser_threads": threads}, **opts))
+            self._chk(self._L.hulk_sketch_files_opts(self._ctx, arr, n, 1 if fasta else 0, ctypes.byref(o), ctypes.byref(st)))
+            return stats_dict(st)
         self._chk(self._L.hulk_sketch_files(self._ctx, arr, n, 1 if fasta else 0, threads, ctypes.byref(st)))
         return stats_dict(st)
 

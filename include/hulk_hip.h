@@ -176,10 +176,10 @@ int hulk_add_reads_device(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t 
  * reads by the reference's slot machine: FASTQ = l1..l3 take the next NON-EMPTY line, l4 takes the
  * next line whatever it is, the read is l2 and its l1 must start with '@' (checked when l4 arrives,
  * so a truncated last record is dropped silently); --fasta = lines of a '>' record concatenated,
- * parsing stops at the first empty line.  `threads` parser threads (0 = one per core, at most 16).
+ * parsing stops at the first empty line.  `threads` parser threads (0 = one per core, at most 16; see hulk_ingest_opts).
  * gzip input is inflated by the library itself, multistream as compress/gzip reads it: a regular one-member file of >= 4 MiB
- * by HULK_GZ_THREADS (default 16) threads at once (about 0.6 GB of scratch mappings while the file is open; HULK_GZ_PAR=0:
- * one thread), a bgzip'd file member by member on as many; bytes and messages are the same whichever reader runs. */
+ * by hulk_ingest_opts.gz_threads (default 16) threads at once (about 0.6 GB of scratch mappings while the file is open;
+ * HULK_INGEST_GZ_ONE_THREAD: one thread), a bgzip'd file member by member on as many; bytes and messages are the same whichever reader runs. */
 typedef struct hulk_ingest_stats {
     uint64_t n_seqs;      /* seqCount of SeqMinimizer.Run */
     uint64_t total_len;   /* lengthTotal */
@@ -192,11 +192,30 @@ typedef int (*hulk_batch_fn)(void *user, const uint8_t *bases, const uint64_t *o
 /* Parse only (no GPU, no context): every batch goes to `fn`.  Error text -> errbuf. */
 int hulk_parse_files(const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads,
                      hulk_batch_fn fn, void *user, hulk_ingest_stats *stats, char *errbuf, uint64_t errbuf_len);
+/* The knobs of a run of the host ingest, as fields (0 = the default everywhere).  hulk_parse_files / hulk_sketch_files take
+ * the defaults (and `threads` as parser_threads); the HULK_INGEST_* / HULK_GZ_* environment variables, where set, override
+ * either — they exist for profiling scripts and tests. */
+#define HULK_INGEST_GZ_ONE_THREAD 1u  /* every gzip input through the one-thread reader (no parallel member / BGZF readers) */
+#define HULK_INGEST_GZ_ZLIB 2u        /* zlib's inflate instead of the library's own decoder */
+#define HULK_INGEST_TRACE 4u          /* seconds per phase of the calling thread and of the gzip readers, on stderr */
+typedef struct hulk_ingest_opts {
+    uint32_t parser_threads;  /* 0 = one per hardware thread, at most 16 (the measured optimum); any other figure is taken as it is (<= 256) */
+    uint32_t gz_threads;      /* threads inflating the members of a bgzip'd input, or the chunks of ONE gzip member, side by side: 1..64, 0 = 16 */
+    uint32_t file_readers;    /* pieces a block of a regular file is read in, side by side: 1..16, 0 = 4 */
+    uint32_t flags;           /* HULK_INGEST_* */
+    uint64_t block_bytes;     /* bytes per block of the line pump: >= 128 KiB, 0 = 32 MiB */
+    uint64_t gz_chunk_bytes;  /* compressed bytes per chunk of the parallel one-member reader: >= 8 KiB, 0 = 1 MiB */
+    uint64_t reserved[2];     /* must be 0 */
+} hulk_ingest_opts;
+int hulk_parse_files_opts(const char *const *paths, uint32_t n_paths, int fasta, const hulk_ingest_opts *opts,
+                          hulk_batch_fn fn, void *user, hulk_ingest_stats *stats, char *errbuf, uint64_t errbuf_len);
 /* Parse and AddSeq every read (pinned double-buffered staging, copies and kernels asynchronous on
  * the context's stream while the next block is read and parsed).  The interval rule applies as in
  * hulk_add_reads; the caller still ends the run with hulk_finish (Flush + StopWork). */
 int hulk_sketch_files(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, int fasta, uint32_t threads,
                       hulk_ingest_stats *stats);
+int hulk_sketch_files_opts(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, int fasta, const hulk_ingest_opts *opts,
+                           hulk_ingest_stats *stats);
 
 /* Intervals are flushed in batches: up to hulk_batch_size() consecutive sketching intervals are
  * binned into separate k-mer spectra by one kernel launch and then pushed through count-min + CWS

@@ -482,3 +482,24 @@ def test_large_piece_copy_covers_its_last_bytes(tmp_path):
     p = str(tmp_path / "exact.fa.gz"); open(p, "wb").write(_bgzf(text, rng, level=1))
     assert os.path.getsize(p) < 8 << 20                                       # one batch of members, delivered by one read
     assert native([p], fasta=True) == [body]
+
+
+def test_knobs_are_fields_of_the_run_not_of_the_process(tmp_path):
+    """hulk_ingest_opts (ABI 3): block size, gzip threads / chunk, the one-thread and zlib readers are fields of ONE call —
+    several configurations in this one process, no environment variable, the reads of the restated line pump every time;
+    unknown flags are refused."""
+    from hulk_amd import _lib, ingest
+    rng = np.random.default_rng(404)
+    data = _random_fastq(rng, 9000, quirks=True)
+    plain = write(tmp_path, "k.fq", data)
+    gz = write(tmp_path, "k.fq.gz", data)                       # (write() compresses what ends in .gz)
+    want = restated([plain])
+    body = b"".join(want)
+    for path, opts in ((plain, {"block_bytes": 131072}), (plain, {"block_bytes": 131072, "file_readers": 1, "parser_threads": 3}),
+                       (gz, {"gz_threads": 3, "gz_chunk_bytes": 65536, "block_bytes": 262144}),
+                       (gz, {"flags": _lib.HULK_INGEST_GZ_ONE_THREAD}), (gz, {"flags": _lib.HULK_INGEST_GZ_ZLIB, "block_bytes": 131072}),
+                       (gz, {"parser_threads": 40})):
+        b, o, st = ingest.parse_files([path], opts=opts)
+        assert st["n_seqs"] == len(want) and b.tobytes() == body, opts
+    with pytest.raises(_lib.HulkError):
+        ingest.parse_files([plain], opts={"flags": 1 << 9})
