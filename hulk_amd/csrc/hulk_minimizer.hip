@@ -607,12 +607,15 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
         uint32_t validbits = 0;
         uint64_t X[WM];
 #pragma unroll
-        for (int t = 0; t < WM; t++) X[t] = XN;
-        if (mine) {
+        for (int t = 0; t < WM; t++) if (!WEQ || t >= w) X[t] = XN;   // (slots past the window size; none when w == WM)
+        {
             // Positions past the read's end are always the END of a lane's block and of the read: their values only
             // reach windows that are not reported (validbits gates every report), so they are computed like any
-            // other instead of being replaced by "no value" one by one.
-            validbits = (1u << (nposg - p0 < w ? nposg - p0 : w)) - 1u;
+            // other instead of being replaced by "no value" one by one.  The same holds for whole lanes: a lane without a
+            // position of its own (behind the read's end, or of a read that is deferred or in error) hashes whatever its
+            // staging dwords hold — values that only travel to lanes further behind, none of which reports — instead of
+            // being masked out and given nine "no value" registers first (9 v_mov_b64 + the exec juggling per iteration).
+            if (mine) validbits = (1u << (nposg - p0 < w ? nposg - p0 : w)) - 1u;
             const int32_t span0 = ap0 + k - 1 - w + 2;
             uint64_t f = 0, r = 0;
             uint32_t nb = 0, nn = 0;                            // next <=15 bases, 2 bits each; their code-4 flags (N variant)
@@ -821,35 +824,51 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
         // the wave's region of the minimizer list (consecutive ranks = consecutive addresses).
         uint32_t myslot[FAST_CAND / 16];
         uint32_t newmask = 0;
+        constexpr uint32_t TABM = (PAIR ? 2 * FAST_TAB : FAST_TAB) - 1;    // a pair owns two neighbouring tables
+        // Two candidates per lane and pass (c and c + 16): both values are read and both compare-and-swaps issued before
+        // either result is looked at — one LDS round trip per pair instead of two dependent ones, and half the ballots.
+        // (Same set semantics: the LDS executes a wave's atomics in program order, so of two equal values the second finds
+        // the first; a value that meets another in its slot probes on as before.)
 #pragma unroll
-        for (int rnd = 0; rnd < FAST_CAND / 16; rnd++) {
-            const uint32_t c = (uint32_t)gl + 16u * (uint32_t)rnd;
-            myslot[rnd] = 0;
-            if (!__any((int)(c < total))) break;
-            bool isnew = false; uint64_t x = 0;
-            if (c < total) {
-                x = cs[c];
-                if (KEY5) x = (x & ~31ull) << 3 | (x & 31ull);              // key -> X = hash << 8 | span
-                constexpr uint32_t TABM = (PAIR ? 2 * FAST_TAB : FAST_TAB) - 1;    // a pair owns two neighbouring tables
-                uint32_t sl = ((uint32_t)(x >> 8) ^ (uint32_t)(x >> 37)) & TABM;
-                unsigned long long o = (dbg & 4u) ? (unsigned long long)TAB_EMPTY
-                                                  : atomicCAS((unsigned long long *)&tab[sl], (unsigned long long)TAB_EMPTY, (unsigned long long)x);
-                while (o != TAB_EMPTY && o != x) {                 // occupied by another value: probe on
-                    sl = (sl + 1) & TABM;
-                    o = atomicCAS((unsigned long long *)&tab[sl], (unsigned long long)TAB_EMPTY, (unsigned long long)x);
+        for (int pr = 0; pr < FAST_CAND / 32; pr++) {
+            const uint32_t c0 = (uint32_t)gl + 32u * (uint32_t)pr, c1 = c0 + 16u;
+            myslot[2 * pr] = 0; myslot[2 * pr + 1] = 0;
+            if (!__any((int)(c0 < total))) break;
+            const bool a0 = c0 < total, a1 = c1 < total;
+            uint64_t x0 = 0, x1 = 0;
+            if (a0) x0 = cs[c0];
+            if (a1) x1 = cs[c1];
+            if (KEY5) { x0 = (x0 & ~31ull) << 3 | (x0 & 31ull); x1 = (x1 & ~31ull) << 3 | (x1 & 31ull); }   // key -> X = hash << 8 | span
+            uint32_t sl0 = ((uint32_t)(x0 >> 8) ^ (uint32_t)(x0 >> 37)) & TABM, sl1 = ((uint32_t)(x1 >> 8) ^ (uint32_t)(x1 >> 37)) & TABM;
+            unsigned long long o0 = (unsigned long long)TAB_EMPTY, o1 = (unsigned long long)TAB_EMPTY;
+            if (!(dbg & 4u)) {
+                if (a0) o0 = atomicCAS((unsigned long long *)&tab[sl0], (unsigned long long)TAB_EMPTY, (unsigned long long)x0);
+                if (a1) o1 = atomicCAS((unsigned long long *)&tab[sl1], (unsigned long long)TAB_EMPTY, (unsigned long long)x1);
+                while (a0 && o0 != TAB_EMPTY && o0 != x0) {        // occupied by another value: probe on
+                    sl0 = (sl0 + 1) & TABM;
+                    o0 = atomicCAS((unsigned long long *)&tab[sl0], (unsigned long long)TAB_EMPTY, (unsigned long long)x0);
                 }
-                isnew = (o == TAB_EMPTY);
-                myslot[rnd] = sl;
+                while (a1 && o1 != TAB_EMPTY && o1 != x1) {
+                    sl1 = (sl1 + 1) & TABM;
+                    o1 = atomicCAS((unsigned long long *)&tab[sl1], (unsigned long long)TAB_EMPTY, (unsigned long long)x1);
+                }
             }
-            const uint64_t nbal = __ballot(isnew);
-            if (nbal) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nbal >> 32),
-                                          __builtin_amdgcn_mbcnt_lo((uint32_t)nbal, 0u));
-                if (isnew) {
-                    newmask |= 1u << rnd;
-                    if (dbg & 1u) sink += (uint32_t)x; else { xl[wcount + rank] = x; sl8[wcount + rank] = (uint8_t)hslot; }
+            const bool new0 = a0 && o0 == TAB_EMPTY, new1 = a1 && o1 == TAB_EMPTY;
+            myslot[2 * pr] = sl0; myslot[2 * pr + 1] = sl1;
+            const uint64_t nb0 = __ballot(new0), nb1 = __ballot(new1);
+            if (nb0 | nb1) {
+                const uint32_t n0 = (uint32_t)__popcll(nb0);
+                if (new0) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nb0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nb0, 0u));
+                    newmask |= 1u << (2 * pr);
+                    if (dbg & 1u) sink += (uint32_t)x0; else { xl[wcount + rank] = x0; sl8[wcount + rank] = (uint8_t)hslot; }
                 }
-                wcount += (uint32_t)__popcll(nbal);
+                if (new1) {
+                    const uint32_t rank = n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(nb1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nb1, 0u));
+                    newmask |= 2u << (2 * pr);
+                    if (dbg & 1u) sink += (uint32_t)x1; else { xl[wcount + rank] = x1; sl8[wcount + rank] = (uint8_t)hslot; }
+                }
+                wcount += n0 + (uint32_t)__popcll(nb1);
             }
         }
         wave_sync();

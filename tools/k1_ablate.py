@@ -1,4 +1,6 @@
-"""Time k_minimizer_bin alone under ablation switches (HULK_K1_DEBUG)."""
+"""Time k_minimizer_fast alone under the ablation switches of its debug instantiation (HULK_K1_DEBUG bits: 1 no list
+stores, 4 no set (every candidate new), 8 phase A only, 16 no hash, 32 staging only, 64 bookkeeping only; 128 = none of them,
+the debug instantiation itself)."""
 import os, sys, subprocess, json
 if len(sys.argv) > 1:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +21,6 @@ if len(sys.argv) > 1:
     print(f"dbg={os.environ.get('HULK_K1_DEBUG','0'):>3}  whole K1 {e0.elapsed_time(e1)/20*1000/(n/100000):8.1f} us, "
           f"k_minimizer_fast alone {ms/max(nl,1)*1000/(n/100000):8.1f} us per 100k reads (n={n})")
 else:
-    for d in (0, 32, 64):
+    for d in (0, 128, 128 + 1, 128 + 4, 128 + 5, 128 + 8, 128 + 16, 128 + 32, 128 + 64):
         env = dict(os.environ, HULK_K1_DEBUG=str(d))
         subprocess.run([sys.executable, __file__, "child"], env=env)

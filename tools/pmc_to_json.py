@@ -25,7 +25,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
-out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r02_pmc.json")
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04_pmc.json")
 reads_per_launch = int(sys.argv[3]) if len(sys.argv) > 3 else 1_600_000
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()

@@ -9,13 +9,14 @@ ap.add_argument("--reads", type=int, default=5_000_000); ap.add_argument("--inte
 ap.add_argument("--batch", type=int, default=10); ap.add_argument("--len", type=int, default=150)
 ap.add_argument("--lanes", type=int, default=0, help="hulk_params.work_lanes (0 = the library default, 2)")
 ap.add_argument("--serial", action="store_true", help="HULK_FLAG_NO_OVERLAP: every kernel alone (profiling)")
+ap.add_argument("--no-prune", action="store_true", help="HULK_FLAG_NO_PRUNE: every interval against the whole CWS table")
 a = ap.parse_args()
 import torch, hulk_amd
 from hulk_amd import synth
 t0 = time.time()
 sk = hulk_amd.GpuSketcher(a.k, a.w, a.S, interval=a.interval, decay_ratio=a.decay,
                           batch=a.batch, work_lanes=a.lanes,
-                          flags=16 if a.serial else 0)
+                          flags=(16 if a.serial else 0) | (2 if a.no_prune else 0))
 torch.cuda.synchronize(); t_create = time.time() - t0
 step = a.interval * a.batch
 bufs = []
