@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_cmsd_base(const double *__restrict__ se
 // counter takes that lane's S from a register exchange without any look-up.  One round trip per chunk plus one per
 // level of same-counter chains inside it (was five); every CMSD_PERIOD elements the base moves on and the row's 2000
 // counters are rescaled by w^PERIOD (the period keeps w^-(j - base) far below the fp64 range for any decay < 1).
-// 517 -> 450 (staging) -> see DESIGN.md us per 16 spectra of 923,521 bins.
+// 517 -> 450 (staging) -> see docs/EXPERIMENTS.md: us per 16 spectra of 923,521 bins.
 constexpr int CMSD_FG = 8;            // chunks per barrier group of k_cmsd_freq
 __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
                                                    const uint8_t *__restrict__ meta8, const uint32_t *__restrict__ eidx,

@@ -1,5 +1,5 @@
 // hulk_minimizer.hip — reads -> distinct minimizers per read (reference: src/minimizer/minimizer.go:96-204).
-//   K1a k_minimizer_fast   short reads: a 16-lane group per read, minimizer list in HBM
+//   K1a k_minimizer_fast   short reads: a 16-lane group per read, minimizer list in HBM (docs/EXPERIMENTS.md)
 //       k_minimizer_bin    reads of up to 1024 k-mer positions, any bytes (fused jump hash + atomics)
 //       k_long_hash/k_long_emit   long reads and contigs, grouped launches
 // All kernels are wave64 code for CDNA4; none of them has a CPU or library fallback.
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     constexpr bool FMM = FM || KEY5;                               // 64-bit minima through v_min_f64
     constexpr uint64_t XN = FMM ? 0x7FF0000000000000ull : X_NONE;  // "no value": above every minimizer value / key
     // (wid is wave-uniform: keeping it in an SGPR also keeps it out of the register allocator's way — hipcc 7.2 lost the
-    // VGPR copy across the main loop in the <16, false, false, false, 0, true> instance)
+    // VGPR copy across the main loop in the <16, false, false, false, 0, true> instance, see docs/EXPERIMENTS.md)
     const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, gsh = lane & 48;
     // WEQ: the window size equals the block size WM (w = 9 is the reference's default): every `t < w` test and

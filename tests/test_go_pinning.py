@@ -1,6 +1,6 @@
 """Pins the oracle against REAL Go output when a maintainer has produced it with tools/go/ (see
 tools/go/README.md).  Without those files (this repository cannot build Go: no toolchain, no network)
-the tests skip and CWS parity with Go-produced sketches stays "unpinned" (DESIGN.md §5)."""
+the tests skip and CWS parity with Go-produced sketches stays "unpinned" (DESIGN.md §6)."""
 import glob
 import json
 import os

@@ -1,6 +1,6 @@
 // Micro-benchmark: issue cost of single gfx950 VALU instructions, one inline-asm instruction per kind, 8 independent
 // register chains per lane and 8 waves per SIMD (throughput, not latency).  Prints cycles per wave64 instruction per SIMD.
-// These are the figures behind the per-step budgets of k_jump_bin / k_minimizer_fast in DESIGN.md.
+// These are the figures behind the per-step budgets of k_jump_bin / k_minimizer_fast in docs/EXPERIMENTS.md.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
