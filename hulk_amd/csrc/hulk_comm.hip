@@ -129,11 +129,19 @@ int comm_leave(hulk_ctx *c, hipStream_t s) {
 }
 
 namespace {
+int comm_setup_alloc(hulk_ctx *c, int kind, uint32_t rank, uint32_t world);
+// (a failure half-way leaves nothing behind: the call can be repeated — ADVICE r3)
 int comm_setup(hulk_ctx *c, int kind, uint32_t rank, uint32_t world) {
     hulk_ctx::Comm &m = c->comm;
     if (m.kind != 0) return fail(c, HULK_ERR_STATE, "the context already has a communicator");
     if (world == 0 || rank >= world) return fail(c, HULK_ERR_ARG, "rank / world");
     if (c->seq_count || c->flush_index) return fail(c, HULK_ERR_STATE, "hulk_comm_init must precede the first read");
+    const int rc = comm_setup_alloc(c, kind, rank, world);
+    if (rc != HULK_OK) { const std::string keep = c->last_error; comm_teardown(c); c->last_error = keep; }
+    return rc;
+}
+int comm_setup_alloc(hulk_ctx *c, int kind, uint32_t rank, uint32_t world) {
+    hulk_ctx::Comm &m = c->comm;
     HIPCHK(c, hipSetDevice(c->p.device));
     const size_t NC = (size_t)c->cms_depth * c->cms_width;
     HIPCHK(c, dalloc(&m.d_hdr, (size_t)world * SHARD_HDR));
@@ -198,9 +206,20 @@ int hulk_comm_init_loopback(hulk_ctx *c, uint32_t rank, uint32_t world) {
     return comm_setup(c, 3, rank, world);
 }
 
+static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, uint32_t max_read_len,
+                             uint64_t bases_bytes, uint32_t step_intervals);
 int hulk_step_sharded(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, uint32_t max_read_len,
                       uint64_t bases_bytes, uint32_t step_intervals) {
     if (!c) return HULK_ERR_ARG;
+    const int rc = step_sharded_impl(c, d_bases, d_offsets, n, max_read_len, bases_bytes, step_intervals);
+    // a runtime or exchange failure may have left this rank outside a collective its peers are inside of: the communicator is
+    // not usable any more, and neither is the run — every later call reports the same status (argument errors, raised before
+    // anything is queued, leave the context as it was)
+    if (rc == HULK_ERR_COMM || rc == HULK_ERR_HIP) c->sticky = rc;
+    return rc;
+}
+static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, uint32_t max_read_len,
+                             uint64_t bases_bytes, uint32_t step_intervals) {
     hulk_ctx::Comm &m = c->comm;
     if (m.kind == 0) return fail(c, HULK_ERR_STATE, "hulk_step_sharded needs hulk_comm_init");
     if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");

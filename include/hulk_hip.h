@@ -267,7 +267,10 @@ int hulk_flush_batch_after(hulk_ctx *ctx, uint32_t n_spectra, void *dep_stream);
  * The last step of a stream may be ragged: `step_intervals` (the same value on every rank) is the number of intervals
  * of the global stream in this step, rank g holds min(T, max(0, step_intervals - g*T)) of them and the last one may
  * be partial (the reference's EOF flush, sketch.go:219-221).  hulk_finish afterwards only synchronises (and reports
- * "no sequences received", sketch.go:237-239, only if the GLOBAL stream was empty: a rank may hold none of a short stream). */
+ * "no sequences received", sketch.go:237-239, only if the GLOBAL stream was empty: a rank may hold none of a short stream).
+ * Failure: HULK_ERR_ARG / HULK_ERR_STATE are raised before anything is queued and leave the context as it was.  HULK_ERR_HIP /
+ * HULK_ERR_COMM from a step are FATAL for the communicator and the run — the peers may be inside a collective this rank has
+ * left — and every later call on the context returns the same status; the host ends all ranks. */
 #define HULK_UNIQUE_ID_BYTES 128
 /* ncclGetUniqueId: called by ONE rank; the host hands the 128 bytes to the other ranks over any channel it has. */
 int hulk_comm_unique_id(void *unique_id);
