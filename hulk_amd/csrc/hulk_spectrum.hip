@@ -294,10 +294,17 @@ __global__ __launch_bounds__(1024) void k_range_hist(MinimizerList ml, uint32_t 
 // grossly repetitive input (Poisson mean < 1 per bin); it cannot go unnoticed: every ds_add returns the previous word, a previous nibble
 // of 15 raises nib_over[t] and k_range_hist / k_merge_hist recount that spectrum exactly (they return at once
 // otherwise).  Layout of a part: words of 8 nibbles, bin b -> word b >> 3, nibble b & 7.
-constexpr int NIB_BINS = 262144;                       // bins per range (128 KB of LDS)
-constexpr int NIB_WORDS = NIB_BINS / 8;
+#ifndef HULK_NIB_RLOG_DEFAULT
+#define HULK_NIB_RLOG_DEFAULT 18
+#endif
+#ifndef HULK_NIB_BLOCK_DEFAULT
+#define HULK_NIB_BLOCK_DEFAULT 1024
+#endif
+constexpr int NIB_BINS_MAX = 262144;                   // largest range: 128 KB of LDS (the list's `nib` array is sized for it)
 __global__ __launch_bounds__(1024) void k_nibble_hist(MinimizerList ml, uint32_t n_regions, MinimizerParams P,
-                                                      uint32_t n_spectra, uint32_t n_parts, uint64_t n_reads, int nranges) {
+                                                      uint32_t n_spectra, uint32_t n_parts, uint64_t n_reads, int nranges, int rlog) {
+    const int32_t NIB_BINS = 1 << rlog, NIB_WORDS = NIB_BINS >> 3;       // bins per range / words of a range's part (launch parameter)
+    const uint32_t bs = blockDim.x;
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *lw = (uint32_t *)smem;
     // XCD-aware order as in k_range_hist: the ranges of one (spectrum, part) pair share an XCD's L2
@@ -342,14 +349,14 @@ __global__ __launch_bounds__(1024) void k_nibble_hist(MinimizerList ml, uint32_t
         const uint4 *k4 = (const uint4 *)(kl + i);
         const uint32_t n4 = hi > i ? (hi - i) / 4u : 0u;
         uint32_t j = (uint32_t)tid;
-        for (; j + 3u * 1024u < n4; j += 4u * 1024u) {
-            const uint4 q0 = k4[j], q1 = k4[j + 1024u], q2 = k4[j + 2048u], q3 = k4[j + 3072u];
+        for (; j + 3u * bs < n4; j += 4u * bs) {
+            const uint4 q0 = k4[j], q1 = k4[j + bs], q2 = k4[j + 2u * bs], q3 = k4[j + 3u * bs];
             HULK_NIB1(q0.x) HULK_NIB1(q0.y) HULK_NIB1(q0.z) HULK_NIB1(q0.w)
             HULK_NIB1(q1.x) HULK_NIB1(q1.y) HULK_NIB1(q1.z) HULK_NIB1(q1.w)
             HULK_NIB1(q2.x) HULK_NIB1(q2.y) HULK_NIB1(q2.z) HULK_NIB1(q2.w)
             HULK_NIB1(q3.x) HULK_NIB1(q3.y) HULK_NIB1(q3.z) HULK_NIB1(q3.w)
         }
-        for (; j < n4; j += 1024u) { const uint4 q0 = k4[j]; HULK_NIB1(q0.x) HULK_NIB1(q0.y) HULK_NIB1(q0.z) HULK_NIB1(q0.w) }
+        for (; j < n4; j += bs) { const uint4 q0 = k4[j]; HULK_NIB1(q0.x) HULK_NIB1(q0.y) HULK_NIB1(q0.z) HULK_NIB1(q0.w) }
         const uint32_t tail = i + n4 * 4u + (uint32_t)tid;
         if (tail < hi) { const uint32_t k = kl[tail]; HULK_NIB1(k) }
 #undef HULK_NIB1
@@ -363,7 +370,8 @@ __global__ __launch_bounds__(1024) void k_nibble_hist(MinimizerList ml, uint32_t
 // adds the parts of a spectrum (8 bins per thread and step) to the ring spectrum; a spectrum flagged in nib_over
 // is left to the exact recount
 __global__ __launch_bounds__(256) void k_nibble_merge(MinimizerList ml, uint32_t *__restrict__ hists, MinimizerParams P,
-                                                      uint32_t n_spectra, uint32_t n_parts, int nranges) {
+                                                      uint32_t n_spectra, uint32_t n_parts, int nranges, int rlog) {
+    const int32_t NIB_BINS = 1 << rlog, NIB_WORDS = NIB_BINS >> 3;
     const int t = blockIdx.y;
     if (ml.nib_over[t]) return;
     const uint32_t slot = P.interval ? (uint32_t)(((uint64_t)t + P.ring_base) % P.ring_n) : P.ring_base;
@@ -396,6 +404,36 @@ __global__ __launch_bounds__(256) void k_nibble_merge(MinimizerList ml, uint32_t
         } else {
 #pragma unroll
             for (int q = 0; q < 8; q++) if (c[q] && b0 + q < P.num_bins) hist[b0 + q] += c[q];
+        }
+    }
+}
+
+// exact recount of the spectra whose 4-bit counters overflowed (flagged in nib_over by k_nibble_hist): every key of such a
+// spectrum is added to it with a global atomic; without a flag (the normal case) every thread returns after one cached load
+__global__ __launch_bounds__(256) void k_recount_flagged(MinimizerList ml, uint32_t n_regions, MinimizerParams P, uint32_t n_spectra,
+                                                         uint64_t n_reads, uint32_t *__restrict__ hists) {
+    uint32_t flagged = 0;
+    for (uint32_t t = 0; t < n_spectra && t < 32u; t++) if (ml.nib_over[t]) flagged |= 1u << t;
+    if (!flagged) return;
+    const uint32_t *kl = ml.key;
+    while (flagged) {
+        const int t = __ffs((int)flagged) - 1;
+        flagged &= flagged - 1u;
+        uint64_t rd0 = 0, rd1 = n_reads;                              // reads of spectrum t, as in k_nibble_hist
+        if (P.interval) {
+            const uint64_t lo = (uint64_t)t * P.interval, hi = lo + P.interval;
+            rd0 = lo > P.fill ? lo - P.fill : 0;
+            rd1 = hi > P.fill ? hi - P.fill : 0;
+            if (rd1 > n_reads) rd1 = n_reads;
+        }
+        if (rd0 >= rd1) continue;
+        const uint32_t slot = P.interval ? (uint32_t)(((uint64_t)t + P.ring_base) % P.ring_n) : P.ring_base;
+        const uint32_t g0 = (uint32_t)(rd0 / FAST_READS_PER_WAVE), g1 = (uint32_t)((rd1 - 1) / FAST_READS_PER_WAVE);
+        const uint32_t a = ml.off[g0], b = ml.off[(g1 + 1 < n_regions ? g1 + 1 : n_regions)];
+        uint32_t *h = hists + (size_t)slot * (size_t)P.num_bins;
+        for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
+            const uint32_t k = kl[i];
+            if ((k >> 20) == slot) atomicAdd(&h[k & 0xFFFFFu], 1u);
         }
     }
 }
@@ -466,17 +504,25 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     }
     static int use_nib = -1;
     if (use_nib < 0) use_nib = getenv("HULK_NO_NIBBLE") ? 0 : 1;
-    const uint32_t *only_if = nullptr;
     if (use_nib && ml.nib && ml.nib_over) {
         // ~131 k keys per part (16 parts per 100k-read interval, swept 49k..197k): a 4-bit counter then overflows only on
         // grossly repetitive input, which the exact kernels below pick up
+        // Range size and workgroup shape: a workgroup of 1024 threads that holds 2^18 four-bit counters (up to 128 KB of LDS)
+        // reads every key once, but it only fits a CU that is free of k_minimizer_fast workgroups (4 x 39.7 KB) — and with two
+        // work lanes the OTHER lane's are always there: rocprofv3 showed this kernel at 216 us per launch beside them against
+        // 41 us alone, waiting for CUs (profiles/r04_kernel_stats.md).  Ranges of 2^16 bins (32 KB) in workgroups of 256 threads
+        // slip in beside three of those; the keys are then read once per range (through the XCD's L2, see the kernel).
+        static const int rlog = [] { const char *e = getenv("HULK_NIB_RLOG"); const int v = e ? atoi(e) : HULK_NIB_RLOG_DEFAULT; return v < 13 ? 13 : v > 18 ? 18 : v; }();
+        static const int nib_block = [] { const char *e = getenv("HULK_NIB_BLOCK"); const int v = e ? atoi(e) : HULK_NIB_BLOCK_DEFAULT; return v == 256 || v == 512 ? v : 1024; }();
+        const int32_t NIB_BINS = 1 << rlog, NIB_WORDS = NIB_BINS >> 3;
         const int nr = (P.num_bins + NIB_BINS - 1) / NIB_BINS;
+        const int nr18 = (P.num_bins + NIB_BINS_MAX - 1) / NIB_BINS_MAX;
         const uint64_t rps = P.interval ? std::min<uint64_t>(P.interval, n_reads) : n_reads;
         // (per bin RANGE: with nr ranges a part's keys spread over nr workgroups, so a part is nr times as long — the mean
         //  count per 4-bit counter stays ~0.5, and k = 31 (4 ranges) builds 256 parts per batch instead of 1024: +3 %)
         static int keys_env = -1;
         if (keys_env < 0) { const char *ek = getenv("HULK_NIB_KEYS"); keys_env = ek ? atoi(ek) : 0; }
-        const uint64_t keys_per_part = keys_env > 0 ? (uint64_t)keys_env : 131072ull * (uint64_t)nr;
+        const uint64_t keys_per_part = keys_env > 0 ? (uint64_t)keys_env : 131072ull * (uint64_t)nr18;   // (mean count per counter ~0.6 whatever the range size)
         uint32_t np = (uint32_t)((rps * 20 + keys_per_part - 1) / keys_per_part);
         if (np < 1) np = 1;
         // short intervals (a rank's slice of a strong-scaling run): still ~128 workgroups, one per CU would leave half the chip idle
@@ -484,29 +530,32 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
         if (min_blocks < 0) { const char *em = getenv("HULK_NIB_MIN_BLOCKS"); min_blocks = em ? atoi(em) : 128; }
         if (rps >= 4096 && (uint64_t)np * n_spectra * nr < (uint64_t)min_blocks) np = (uint32_t)(((uint64_t)min_blocks + (uint64_t)n_spectra * nr - 1) / ((uint64_t)n_spectra * nr));
         if (np > ml.nib_parts) np = ml.nib_parts;
-        while (np > 1 && (uint64_t)np * n_spectra * nr > 2048) np--;
+        while (np > 1 && (uint64_t)np * n_spectra * nr > 8192) np--;
         const int words = ((std::min<int32_t>(P.num_bins, NIB_BINS) + 7) >> 3);
         static bool nib_attr = false;
         if (!nib_attr) {
-            e = hipFuncSetAttribute((const void *)k_nibble_hist, hipFuncAttributeMaxDynamicSharedMemorySize, NIB_WORDS * 4);
+            e = hipFuncSetAttribute((const void *)k_nibble_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (NIB_BINS_MAX / 8) * 4);
             if (e != hipSuccess) return e;
             nib_attr = true;
         }
         const unsigned pg = (n_spectra * np + 7) / 8;
-        hipLaunchKernelGGL(k_nibble_hist, dim3(8u * (unsigned)nr * pg), dim3(1024), (size_t)words * 4, s, ml, n_regions, P,
-                           n_spectra, np, n_reads, nr);
+        hipLaunchKernelGGL(k_nibble_hist, dim3(8u * (unsigned)nr * pg), dim3(nib_block), (size_t)words * 4, s, ml, n_regions, P,
+                           n_spectra, np, n_reads, nr, rlog);
         int nb = (nr * NIB_WORDS + 255) / 256; if (nb > 512) nb = 512;      // one word (8 bins) per thread up to 131072 words
-        hipLaunchKernelGGL(k_nibble_merge, dim3(nb, n_spectra), dim3(256), 0, s, ml, d_hists, P, n_spectra, np, nr);
-        only_if = ml.nib_over;                              // the exact kernels only recount flagged spectra
+        hipLaunchKernelGGL(k_nibble_merge, dim3(nb, n_spectra), dim3(256), 0, s, ml, d_hists, P, n_spectra, np, nr, rlog);
+        // A spectrum in which a 4-bit counter overflowed (grossly repetitive input) is recounted exactly: k_nibble_merge left
+        // it alone, k_recount_flagged adds its keys with global atomics.  Rare, so its shape is chosen for the common case,
+        // in which it finds no flag: 256 light workgroups without LDS.  (Until round 4 the exact range histogram ran here with
+        // an "only if flagged" test: 96 workgroups of 128 KB of LDS that return at once — but first have to be PLACED, and
+        // beside the other lane's kernels that took 138 us of this lane's stream per batch.)
+        hipLaunchKernelGGL(k_recount_flagged, dim3(256), dim3(256), 0, s, ml, n_regions, P, n_spectra, n_reads, d_hists);
+        return hipGetLastError();
     }
-    if (only_if) n_parts = 1;                                  // recount mode: rare, a small grid is enough
     const unsigned pair_groups = (n_spectra * n_parts + 7) / 8;
     hipLaunchKernelGGL(k_range_hist, dim3(8u * (unsigned)nranges * pair_groups), dim3(1024), HIST_RANGE * 4, s, ml, n_regions,
-                       ml.partial, P, n_spectra, n_parts, n_reads, nranges, only_if, only_if ? d_hists : nullptr);
-    if (!only_if) {
-        int mb = (P.num_bins + 255) / 256; if (mb > 512) mb = 512;
-        hipLaunchKernelGGL(k_merge_hist, dim3(mb, n_spectra), dim3(256), 0, s, ml.partial, d_hists, P, n_spectra, n_parts, only_if);
-    }
+                       ml.partial, P, n_spectra, n_parts, n_reads, nranges, nullptr, nullptr);
+    int mb = (P.num_bins + 255) / 256; if (mb > 512) mb = 512;
+    hipLaunchKernelGGL(k_merge_hist, dim3(mb, n_spectra), dim3(256), 0, s, ml.partial, d_hists, P, n_spectra, n_parts, nullptr);
     return hipGetLastError();
 }
 
