@@ -402,7 +402,8 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     // its last, in r the pair of base p gets |= N(p-1) for every base of the k-mer, bit 2k of r is set when the k-mer's last
     // base is an N, and f == r has to be tested for odd k too.  An iteration of the wave takes this variant of phase A only
     // when one of its 4 reads has an N (wave-uniform branch): +13 instructions per k-mer position there, nothing elsewhere.
-    // Any other byte outside ACGTacgt still defers the read to k_minimizer_bin and its full seq_nt4_table.  (PAIR: the second
+    // So do reads with any other code-4 byte (IUPAC letters, anything seq_nt4_table maps to 4); U / u is T; only the raw bytes
+    // 0..3 (which the table maps to themselves) defer the read to k_minimizer_bin.  (PAIR: the second
     // group's first k-mer needs N(posoff - 1), a base only its partner staged: read from the partner's flag dwords.)
     constexpr bool NV = (DX && HP && 2 * (KC + WM) <= 64) || (!DX && WM <= 9);   // one-window form, or the rolling form (the
                                                                                    // 16-position instances are at 128 VGPRs already)
@@ -571,19 +572,23 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
                         const uint32_t m = nb >= 4 ? ~0u : nb <= 0 ? 0u : (1u << (8 * nb)) - 1u;
                         const uint32_t mm = (__builtin_amdgcn_perm(0u, 0x54474341u, c) ^ up) & m;      // bytes that did not come back
                         if (NV) {
-                            // 0x80 per byte: it is an N / n (which the code formula maps to 0, the code stored for a code-4
-                            // base) — or it is something else this kernel does not take
-                            const uint32_t tN = up ^ 0x4E4E4E4Eu;
-                            const uint32_t isN = ~(((tN & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | tN | 0x7F7F7F7Fu) & m;
+                            // 0x80 per byte that did not come back.  seq_nt4_table (minimizer.go:23-40) gives U / u the code of
+                            // T — which the formula already produced — the raw bytes 0..3 their own value (not taken here: the
+                            // read is deferred), and EVERY other byte code 4: N, the IUPAC letters, anything else.  Those get a
+                            // flag, and code 0 is what is stored for them (the formula gives 0 for N / n only: cleared below).
                             const uint32_t nz = (((mm & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | mm) & 0x80808080u;
-                            hard |= nz & ~isN;
-                            const uint32_t b4 = isN >> 7;                                  // bits 0, 8, 16, 24
+                            const uint32_t tU = up ^ 0x55555555u, t3 = by & 0xFCFCFCFCu;
+                            const uint32_t isU = ~(((tU & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | tU | 0x7F7F7F7Fu);
+                            const uint32_t is03 = ~(((t3 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t3 | 0x7F7F7F7Fu);
+                            hard |= nz & is03;
+                            const uint32_t b4 = (nz & ~isU & ~is03) >> 7;                  // bits 0, 8, 16, 24
                             const uint32_t fl = (b4 & 1u) | ((b4 >> 6) & 4u) | ((b4 >> 12) & 16u) | ((b4 >> 18) & 64u);   // -> bits 0, 2, 4, 6
                             npack |= fl << (8 * x);
                         } else hard |= mm;
                     }
                     sawN = hard != 0;
                     softN = NV && npack != 0;
+                    if (NV) pack &= ~(npack * 3u);
                 }
             }
             pk32[gl] = pack;

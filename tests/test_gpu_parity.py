@@ -112,6 +112,42 @@ def test_n_lowercase_and_min_length():
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("k,w,L", [(21, 9, 150), (21, 9, 280), (31, 9, 150), (17, 5, 100), (12, 3, 60), (21, 12, 150)])
+def test_every_byte_of_the_nt4_table(k, w, L):
+    """seq_nt4_table (minimizer.go:23-40) has four kinds of bytes: ACGT in both cases, U / u (the code of T), the raw bytes
+    0..3 (their own value) and everything else — N, the IUPAC letters, punctuation, bytes above 127 — code 4, which the
+    recurrence does not special-case (minimizer.go:118-122).  The short-read kernel takes all of them but the raw 0..3 (those
+    reads go to the generic kernel); (21, 12): an instance without the code-4 variant, where such reads are deferred as before.
+    One foreign byte at every position of a read, every byte value once, several per read, next to an N, at both ends, in
+    the first bases of the NEXT read: spectrum, minimizer count and sketch against the oracle."""
+    rng = np.random.default_rng(77 + k + 100 * w + L)
+    iupac = b"RYKMSWBDHVXrykmswbdhvx.-*Uu"
+    seqs = []
+    for p in range(L):                                   # one foreign byte at every position
+        b = bytearray(random_reads(rng, 1, L)[0]); b[p] = iupac[p % len(iupac)]; seqs.append(bytes(b))
+    for v in range(256):                                 # every byte value once, somewhere
+        b = bytearray(random_reads(rng, 1, L)[0]); b[int(rng.integers(0, L))] = v; seqs.append(bytes(b))
+    allb = bytes(range(256))
+    for _ in range(300):                                 # several per read, any byte, N among them
+        b = bytearray(random_reads(rng, 1, L)[0])
+        for q in rng.integers(0, L, size=int(rng.integers(1, 7))):
+            b[q] = allb[int(rng.integers(4, 256))] if rng.random() < 0.8 else ord("N")
+        seqs.append(bytes(b))
+    base = random_reads(rng, 1, L)[0]
+    seqs += [b"R" + base[1:], base[:-1] + b"Y", b"U" + base[1:-1] + b"u", b"R" * L, b"U" * L, b"RN" + base[2:], b"\x03" + base[1:],
+             base[:-1] + b"\x00", b"\x80" * L, base]
+    seqs += random_reads(rng, 300, (w + k - 1, L), b"ACGTUuRYn")       # ragged
+    seqs += random_reads(rng, 400, L)                    # clean reads in between: waves with and without a flag
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    o, g = run_both(seqs, k, w, 8, batches=3)
+    assert np.array_equal(g.histogram(), o.histogram().astype(np.uint32))
+    assert o.counters()["n_minimizers"] == g.counters()["n_minimizers"]
+    o.finish(); g.finish()
+    assert_same_sketch(o, g)
+    g.close(); o.close()
+
+
 @pytest.mark.parametrize("k,w,long_reads", [(21, 9, False), (21, 4, False), (21, 9, True), (21, 4, True),
                                             (31, 9, False), (31, 9, True), (17, 5, False), (24, 9, False), (12, 3, True)])
 def test_fast_kernel_instance_with_n_bases(k, w, long_reads):
