@@ -23,7 +23,7 @@ def _run(extra, env_extra=None, timeout=900):
         extra = [x for x in extra if x != "--c3"]
     else:
         extra = extra + ["--no-c3", "--no-c5"]
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"] + extra,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2"] + extra,   # (2: both work lanes have run once before the clock starts)
                        capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -48,7 +48,7 @@ def test_bench_json_contract_and_collective_path():
     for metric in ("weightedjaccard", "jaccard"):
         assert c5[metric]["ms_kernel"] < c5[metric]["ms_end_to_end"] and 0.0 < c5[metric]["lds_pipe_frac"] < 1.0
     assert c5["pairs"] == 1024 * 1024
-    assert a["n_gpus"] == 1 and a["steps"] == 3 and a["warmup"] == 1 and a["vs_baseline"] is None
+    assert a["n_gpus"] == 1 and a["steps"] == 3 and a["warmup"] == 2 and a["vs_baseline"] is None
     assert a["unit"] == "reads/s" and a["higher_is_better"] is True and a["scaling"] == "weak"
     assert "workload" in a["config"] and "model" not in a["config"]
     r = a["roofline"]
