@@ -59,7 +59,7 @@ sys.path.insert(0, ROOT)
 K, W, S, READ_LEN, INTERVAL = 21, 9, 512, 150, 100_000
 NUM_BINS = K ** 4        # cmd/sketch.go:118
 STEPTIMES = int(os.environ.get("HULK_BENCH_STEPTIMES", "0"))     # diagnosis: per-step wall times of every pass on stderr
-RAMP_STEPS = int(os.environ.get("HULK_BENCH_RAMP_STEPS", "40"))   # discarded steps on a throw-away context right before every pass's warm-up
+RAMP_MS = float(os.environ.get("HULK_BENCH_RAMP_MS", "40"))   # ms of elementwise kernels on a scratch tensor right before every pass's warm-up
 PREWARM_S = float(os.environ.get("HULK_BENCH_PREWARM_S", "2"))   # seconds of discarded passes before the timed ones
 BATCH = int(os.environ.get("HULK_BENCH_BATCH", "16"))   # sketching intervals per step (one pass over the CWS table)
 C2_READS = 10_000_000        # BASELINE configs[1]
@@ -456,6 +456,7 @@ def main():
 
     main_input = make_input(mode, 24)
     torch.cuda.synchronize()
+    ramp_buf = torch.zeros(1 << 26, dtype=torch.float32, device=device)      # 256 MB of scratch for the clock ramp (run_pass)
 
     rccl_error = [None]            # set on every rank when RCCL could not be bound / initialised on ANY rank (reported in the line)
     host_group = [None]
@@ -532,17 +533,17 @@ def main():
 
         # Creating a context leaves the GPU idle for 10-90 ms (allocations, the CWS tables from their cache) and its clocks
         # drop: the W warm-up steps that follow (5 ms at the driver's W = 5) are over before they are back, and the first ~15
-        # timed steps run 2-15 % slow (profiles/r03_firstpass_steps.txt; 0.44-1.5 ms of a 20-step pass, by the box).  RAMP_STEPS
-        # discarded steps on a throw-away context put the chip back under load first; the W warm-up steps and the K timed
-        # steps of THIS context follow without a gap.  (Nothing is taken out of the timed region: `ms_per_step_long` is the
-        # same measurement over 200 steps.)
-        ramp_ctx = None
-        if RAMP_STEPS > 0 and not serial:
-            ramp_ctx = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL, decay_ratio=1.0, device=dev_index, batch=BATCH, work_lanes=args.lanes)
-            for t in range(RAMP_STEPS):           # (plain single-context steps over this rank's share: no collective)
-                rb = bufs[t % len(bufs)]
-                ramp_ctx.add_reads_device(rb.data_ptr(), offs.data_ptr(), n_step, READ_LEN, rb.numel())
-            ramp_ctx.synchronize()
+        # timed steps run 2-15 % slow (profiles/r03_firstpass_steps.txt; 0.44-1.5 ms of a 20-step pass, by the box).  RAMP_MS
+        # of plain elementwise kernels on a scratch tensor put the chip back under load first; the W warm-up steps and the K
+        # timed steps follow without a gap.  (Nothing is taken out of the timed region: `ms_per_step_long` is the same
+        # measurement over 200 steps.  A second hulk context as the load was tried first: its allocations and frees made
+        # later contexts of the process 20 % slower — profiles/r04_bench_ramp.txt.)
+        if RAMP_MS > 0 and not serial:
+            t_end = time.perf_counter() + RAMP_MS * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(8):
+                    ramp_buf.sin_()
+                torch.cuda.synchronize()
         for t in range(warmup):
             one_step(t)
         sk.synchronize()
@@ -583,8 +584,6 @@ def main():
         mins, weights = sk.gather_sketch() if (comm and not loop_world) else sk.sketch()
         cstats = sk.comm_stats() if comm else None
         sk.close()
-        if ramp_ctx is not None:
-            ramp_ctx.close()
         return dict(elapsed=elapsed, steps=k_steps, prof=prof, counters=counters, mins=mins, weights=weights, tiles0=tiles0,
                     tiles1=tiles1, comm=cstats)
 
@@ -783,7 +782,7 @@ def main():
                          "reference's 100k reads: the sketch is the single-GPU sketch of the same (N times longer) stream"
                          if mode == "sharded" else "total work per step fixed" if mode == "sliced-strong" else
                          "per-rank work fixed, global interval N x 100k: another sketch than C2's"),
-        "rccl_ranks": rccl_ranks, "prewarm_seconds": PREWARM_S, "ramp_steps": RAMP_STEPS,
+        "rccl_ranks": rccl_ranks, "prewarm_seconds": PREWARM_S, "ramp_ms": RAMP_MS,
         "collective": comm_desc,
         "roofline": None,          # (filled by the `kernels` leg)
         "sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest(),

@@ -204,6 +204,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
 #undef CHK_CREATE
     int rc = build_chains(c);
     if (rc == HULK_OK && p.cws_source == HULK_CWS_GO_COMPAT) rc = generate_tables(c);
+    if (rc == HULK_OK) rc = lanes_prereserve(c);
     if (rc == HULK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = HULK_ERR_HIP;
     if (rc != HULK_OK) { g_create_error = c->last_error.empty() ? err_text(rc) : c->last_error; hulk_destroy(c); return rc; }
     *out = c;

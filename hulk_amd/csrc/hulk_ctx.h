@@ -164,6 +164,7 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
 hipStream_t lane_stream(hulk_ctx *c, int ring);
 hipStream_t ring_stream(hulk_ctx *c);
 int lanes_join(hulk_ctx *c);
+int lanes_prereserve(hulk_ctx *c);
 int stage_mark_busy(hulk_ctx *c, hulk_ctx::HostStage &hs);
 int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &fb);
 bool no_overlap_mode(const hulk_ctx *c);

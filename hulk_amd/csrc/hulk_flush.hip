@@ -241,6 +241,23 @@ static int lane_open(hulk_ctx *c, int li) {
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     return HULK_OK;
 }
+// hulk_create: the work lanes' buffers (minimizer list, hand-over areas, 4-bit histogram parts: ~3 GB per lane at the
+// defaults) sized for the largest batch the interval rule hands to bin_reads, so that no call of the stream allocates.
+// (hipMalloc in the middle of a stream was measured at anything between 0.1 ms and 1.8 SECONDS, depending on what the
+// process freed before: profiles/r04_bench_ramp.txt.)  Without an interval a call may be of any size: the first one sizes
+// the lists, as any later call that needs more does.
+int lanes_prereserve(hulk_ctx *c) {
+    const uint64_t I = c->p.interval;
+    if (!I || getenv("HULK_NO_PRERESERVE")) return HULK_OK;
+    const uint64_t n = std::min<uint64_t>((uint64_t)c->T * I, MAX_READS_PER_LAUNCH);
+    const int nl = (c->work_lanes > 1 && !c->no_overlap) ? 2 : 1;
+    for (int li = 0; li < nl; li++) {
+        { const int rc = lane_open(c, li); if (rc != HULK_OK) return rc; }
+        const int rc = lane_reserve(c, c->lane[li], li ? c->lane[1].stream : c->stream, n, false);
+        if (rc != HULK_OK) return rc;
+    }
+    return HULK_OK;
+}
 // the context's stream has passed everything lane 1 was given so far
 int lanes_join(hulk_ctx *c) {
     if (!c->lane[1].stream) return HULK_OK;

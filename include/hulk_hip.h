@@ -131,7 +131,7 @@ typedef struct hulk_params {
 
 /* Version of this ABI (HULK_ABI_VERSION). */
 int hulk_abi_version(void);
-/* "abi=2 arch=gfx950 sources=<first 16 hex digits of the SHA-256 over hulk_amd/csrc's sources and headers, in the Makefile's
+/* "abi=3 arch=gfx950 sources=<first 16 hex digits of the SHA-256 over hulk_amd/csrc's sources and headers, in the Makefile's
  * order> hipcc=<version>": which tree and compiler this .so was built from (a binding or a test can refuse a stale one). */
 const char *hulk_build_info(void);
 /* Reference error text for a status code. */
@@ -139,7 +139,9 @@ const char *hulk_strerror(int status);
 /* Message of the last failure on this context ("" if none). NULL ctx => last hulk_create failure. */
 const char *hulk_last_error(const hulk_ctx *ctx);
 
-/* findMinimizers + NewHistoSketch.  Allocates device state, generates/uploads the CWS tables. */
+/* findMinimizers + NewHistoSketch.  Allocates device state, generates/uploads the CWS tables.  With an interval, the work
+ * lanes' buffers are sized here for the largest batch the interval rule forms (batch x interval reads, ~3 GB per lane at
+ * the defaults): no call of the stream allocates device memory.  (interval = 0: the first call sizes them.) */
 int hulk_create(const hulk_params *params, hulk_ctx **out);
 void hulk_destroy(hulk_ctx *ctx);
 
