@@ -1102,8 +1102,16 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
     return hipGetLastError();
 }
 
-// a region holds at most one value per k-mer position of the wave's 16 reads
-uint32_t minimizer_list_rcap(uint32_t w, bool pair) { return FAST_READS_PER_WAVE * (pair ? 2u * 16u * w - (w - 1u) : 16u * w); }
+// a region holds at most one value per k-mer position of the wave's 16 reads — and at most FAST_CAND per 16-lane group (a
+// read with more run starts is deferred to the generic kernel and contributes none).  The second bound is the smaller one
+// from w = 5 up (1024 + pad instead of 2304 entries at w = 9): the lists of a batch shrink from 3.4 to 1.6 GB per lane, of
+// which the reads of C2 fill 40 % instead of 19 %.  The pad keeps the region stride off a power of two.
+uint32_t minimizer_list_rcap(uint32_t w, bool pair) {
+    static const uint32_t pad = [] { const char *e = getenv("HULK_RCAP_PAD"); return e ? (uint32_t)atol(e) : 64u; }();
+    const uint32_t by_pos = FAST_READS_PER_WAVE * (pair ? 2u * 16u * w - (w - 1u) : 16u * w);
+    const uint32_t by_cand = FAST_READS_PER_WAVE * (uint32_t)FAST_CAND * (pair ? 2u : 1u);
+    return by_pos < by_cand + pad ? by_pos : by_cand + pad;
+}
 
 hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSeqDesc *d_desc, uint32_t n_seqs,
                              uint64_t max_npos, MinimizerParams P, uint64_t *d_xs, uint8_t *d_valid, uint64_t *d_table,
