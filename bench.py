@@ -51,7 +51,6 @@ import sys
 import threading
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before torch initialises HIP (hulk_amd/_lib.py: a context's streams must not share a queue)
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -104,10 +104,6 @@ def _needed(path, prefix):
     return None
 
 
-# libhulkhip.so raises HIP's default of 4 hardware queues per process when it is loaded (hulk_api.hip: a context's four streams
-# must not share a queue); set here as well, because torch may initialise HIP before the library is loaded
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 HIP_RUNTIME_BOUND = None        # which HIP runtime load() mapped first: "torch:<path>", "system" or "already loaded (torch)"
 
 

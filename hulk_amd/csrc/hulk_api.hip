@@ -11,15 +11,6 @@ using namespace hulk;
 namespace {
 thread_local std::string g_create_error;
 
-// A context issues work on four streams of its own (two work lanes, the flush, the estimates) and expects them to run side
-// by side.  HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default: with a second context in
-// the process (or a host with streams of its own) two streams of one context can share a queue and run in order — measured
-// as 1.21 instead of 0.95 ms per batch for the context that drew the short straw, gone with 8 or 16 queues
-// (profiles/r04_hw_queues.txt).  The HIP runtime reads the variable when it initialises, i.e. at the first HIP call of the
-// process: the library raises the default when it is loaded (an existing setting is left alone; a process that initialised
-// HIP earlier keeps what it had — set the variable in its environment).
-__attribute__((constructor)) void hulk_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
-
 // helpers.Pow (src/helpers/helpers.go:18-28)
 uint64_t ipow(uint64_t a, uint64_t b) {
     uint64_t p = 1;

@@ -208,6 +208,15 @@ int hulk_comm_init_loopback(hulk_ctx *c, uint32_t rank, uint32_t world) {
 
 static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, uint32_t max_read_len,
                              uint64_t bases_bytes, uint32_t step_intervals);
+// host transport: the gathered header of the step lies in the host staging right behind this rank's own block — the next
+// step's choice of exchange is taken from there, without another trip through the device
+static void hdr_from_host_stage(hulk_ctx *c) {
+    hulk_ctx::Comm &m = c->comm;
+    if (m.kind != 2) return;
+    const int cur = (int)(m.step & 1);
+    memcpy(m.h_hdr[cur], m.h_stage + SHARD_HDR * 4, (size_t)m.world * SHARD_HDR * 4);
+    m.hdr_pending[cur] = false;
+}
 int hulk_step_sharded(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, uint32_t max_read_len,
                       uint64_t bases_bytes, uint32_t step_intervals) {
     if (!c) return HULK_ERR_ARG;
@@ -249,9 +258,37 @@ static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t
     if (!full) {
         const int prev = (int)((m.step - 1) & 1);
         if (m.hdr_pending[prev]) { HIPCHK(c, hipEventSynchronize(m.ev_hdr[prev])); m.hdr_pending[prev] = false; }
+        // every block of the gathered header carries the number of the step it was written in (word 0): what is read here
+        // must be the previous step's, from every rank — a rank that read an older copy of the buffer would pick another
+        // exchange than its peers, which no collective survives.  (One run in ~20 of the suite's 4-rank fuzz slice failed
+        // that way once the process had 16 hardware queues; the copy below is then waited for on the stream itself.)
+        const volatile uint32_t *hh = m.h_hdr[prev];
+        auto stale = [&] { for (uint32_t r = 0; r < m.world; r++) if (hh[(size_t)r * SHARD_HDR] != (uint32_t)m.step) return true; return false; };
+        if (stale()) {
+            // Seen on ROCm 7.2 once the process had 16 hardware queues (one run in ~20 of the suite's 4-rank fuzz slice): the
+            // asynchronous device-to-host copy of the header at the end of a step delivered what the buffer held BEFORE that
+            // step's exchange — it had run ahead of its stream — and its event was complete.  The device buffer still holds
+            // the previous step's gathered header (this step's writes are not queued yet): wait for the stream, fetch it again.
+            hipStream_t fs = flush_stream_of(c);
+            HIPCHK(c, hipStreamSynchronize(fs));
+            HIPCHK(c, hipMemcpyAsync(m.h_hdr[prev], m.d_hdr, (size_t)m.world * SHARD_HDR * 4, hipMemcpyDeviceToHost, fs));
+            HIPCHK(c, hipStreamSynchronize(fs));
+            m.hdr_resyncs++;
+            if (getenv("HULK_SHARD_DEBUG"))
+                fprintf(stderr, "hulk shard: rank %u step %llu: stale header copy, fetched again (%s)\n", m.rank, (unsigned long long)m.step,
+                        stale() ? "still stale" : "ok");
+            if (stale()) return fail(c, HULK_ERR_COMM, "the exchange header of the previous step did not arrive from every rank");
+        }
         for (uint32_t r = 0; r < m.world; r++) if (m.h_hdr[prev][(size_t)r * SHARD_HDR + 1]) full = true;
     }
     if (c->shard_full) full = true;                                           // HULK_FLAG_SHARD_FULL: always the spectra exchange
+    static const bool shard_debug = getenv("HULK_SHARD_DEBUG") != nullptr;     // diagnosis: every rank's view of the verdicts
+    if (shard_debug) {
+        std::string v;
+        if (m.step) for (uint32_t r = 0; r < m.world; r++) v += std::to_string(m.h_hdr[(m.step - 1) & 1][(size_t)r * SHARD_HDR + 1]) + " ";
+        fprintf(stderr, "hulk shard: ctx %p rank %u step %llu intervals %u own %u full %d verdicts [ %s]\n", (void *)c, m.rank,
+                (unsigned long long)m.step, step_intervals, own, (int)full, v.c_str());
+    }
     hipStream_t s = flush_stream_of(c);
     HIPCHK(c, hipEventRecord(c->ev_binned, ring_stream(c)));        // (the binning ran on the ring's work lane)
     if (!no_overlap_mode(c)) HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
@@ -262,6 +299,7 @@ static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t
     FlushBatch fb{};
     fb.ring_base = 0; fb.ring_n = c->ring_n; fb.count = own; fb.parity = 0; fb.num_bins = c->B;
     HIPCHK(c, hipMemsetAsync(own_hdr, 0, SHARD_HDR * 4, s));
+    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)own_hdr, (int)(uint32_t)(m.step + 1), 1, s));   // word 0: the step this block belongs to
     // this rank's verdict for the NEXT step: the whole-batch bound on the counters and weights as they stand now
     // (a rank without slots has nothing to protect: its verdict stays 0)
     if (c->slots)
@@ -277,6 +315,7 @@ static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t
         if (rc != HULK_OK) return rc;
         if (m.kind == 1) NCCLCHK(c, rccl()->GroupStart());
         rc = comm_allgather(c, m.stream, own_hdr, m.d_hdr, SHARD_HDR * 4);
+        if (rc == HULK_OK) hdr_from_host_stage(c);
         const int rc2 = rc == HULK_OK ? comm_allgather(c, m.stream, own_delta, m.d_delta, (size_t)c->T * NC * 4) : rc;
         if (m.kind == 1) NCCLCHK(c, rccl()->GroupEnd());                 // (closed whatever the calls inside it returned)
         if (rc2 != HULK_OK) return rc2;
@@ -295,6 +334,7 @@ static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t
         }
         rc = comm_enter(c, s);
         if (rc == HULK_OK) rc = comm_allgather(c, m.stream, own_hdr, m.d_hdr, SHARD_HDR * 4);
+        if (rc == HULK_OK) hdr_from_host_stage(c);
         if (rc == HULK_OK) rc = comm_allgather(c, m.stream, hist, m.d_gather, (size_t)c->T * B * 4);
         if (rc == HULK_OK) rc = comm_leave(c, s);
         if (rc != HULK_OK) return rc;
@@ -313,9 +353,11 @@ static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t
         m.steps_full++;
     }
     const int cur = (int)(m.step & 1);
-    HIPCHK(c, hipMemcpyAsync(m.h_hdr[cur], m.d_hdr, (size_t)m.world * SHARD_HDR * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipEventRecord(m.ev_hdr[cur], s));
-    m.hdr_pending[cur] = true;
+    if (m.kind != 2) {                                              // (host transport: hdr_from_host_stage has it already)
+        HIPCHK(c, hipMemcpyAsync(m.h_hdr[cur], m.d_hdr, (size_t)m.world * SHARD_HDR * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(m.ev_hdr[cur], s));
+        m.hdr_pending[cur] = true;
+    }
     m.step++;
     m.global_intervals += step_intervals;
     c->cur_ring ^= 1;

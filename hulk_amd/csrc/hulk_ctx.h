@@ -71,10 +71,11 @@ struct hulk_ctx {
         // the collectives run on a stream of their own at the HIGHEST priority: a few workgroups that must not queue behind the
         // thousands of pending minimizer workgroups of the next step (the flush stream around them has the lowest)
         hipStream_t stream = nullptr; hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-        uint32_t *d_hdr = nullptr;                      // [world][SHARD_HDR]: {-, need_full, used bins per interval ...}
+        uint32_t *d_hdr = nullptr;                      // [world][SHARD_HDR]: {step + 1, need_full, used bins per interval ...}
         uint32_t *d_delta = nullptr;                    // [world][T][depth * width] count-min increments per interval
         uint32_t *d_gather = nullptr; size_t gather_words = 0;   // [world][T][num_bins] spectra of a full exchange
         uint32_t *h_hdr[2] = {nullptr, nullptr}; hipEvent_t ev_hdr[2] = {nullptr, nullptr}; bool hdr_pending[2] = {false, false};
+        uint64_t hdr_resyncs = 0;                       // times the header copy was not there after its event (see step_sharded_impl)
         uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;      // host transport: pinned staging
         unsigned long long *d_sk = nullptr;             // hulk_gather_sketch: [world][2 + 2 S]
         uint64_t step = 0, steps_delta = 0, steps_full = 0, bytes_rx = 0;

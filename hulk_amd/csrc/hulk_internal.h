@@ -121,7 +121,7 @@ hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, i
                                const double *d_weights, int slots, int slot_begin, DevState *st, const FlushBatch &fb,
                                int enable, uint32_t *d_need_full = nullptr);
 // hulk_step_sharded's delta exchange (hulk_countmin.hip): a rank's exchange block is SHARD_HDR header words
-// {-, need_full, used bins per interval ...} and [T][depth * width] count-min increments
+// {step + 1, need_full, used bins per interval ...} and [T][depth * width] count-min increments
 constexpr int SHARD_HDR = 32;
 hipError_t launch_shard_local(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, uint32_t *d_hdr, uint32_t *d_delta,
                               int depth, int width, const FlushBatch &fb);

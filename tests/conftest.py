@@ -11,8 +11,6 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before anything initialises HIP (hulk_amd/_lib.py)
-
 # torch ships its own HIP runtime: it has to be loaded before libhulkhip.so pulls in /opt/rocm's, or
 # torch.cuda finds no device later in the same process (some GPU tests use torch for device buffers)
 try:
