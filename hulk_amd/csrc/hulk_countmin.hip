@@ -708,7 +708,8 @@ __global__ __launch_bounds__(512) void k_shard_local(uint32_t *__restrict__ hist
 
 __global__ __launch_bounds__(256) void k_shard_apply(const uint32_t *__restrict__ hdr_all, const uint32_t *__restrict__ delta_all,
                                                      unsigned long long *__restrict__ ctr, int ncounters, uint32_t world,
-                                                     uint32_t T, uint32_t step_intervals, int32_t num_bins, DevState *st) {
+                                                     uint32_t T, uint32_t step_intervals, int32_t num_bins, DevState *st,
+                                                     uint32_t step_tag) {
     // grid = (counters / 256, ranks): a workgroup adds ONE rank's intervals to its 256 counters (integer sums: the order of
     // the ranks' atomic adds does not matter); the rank's header words come in with one load per lane
     __shared__ uint32_t h[SHARD_HDR];
@@ -728,6 +729,7 @@ __global__ __launch_bounds__(256) void k_shard_apply(const uint32_t *__restrict_
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
+        if (h[0] != step_tag) set_error(st, -37);                              // HULK_ERR_COMM: a block that is not of this step (word 0: hulk_comm.hip)
         if (few) set_error(st, -5);
         if (elems) atomicAdd(&st->n_elements, elems);
     }
@@ -755,11 +757,11 @@ hipError_t launch_shard_local(hipStream_t s, uint32_t *d_hists, const uint16_t *
 
 hipError_t launch_shard_apply(hipStream_t s, const uint32_t *d_hdr_all, const uint32_t *d_delta_all, unsigned long long *d_ctr,
                               int depth, int width, uint32_t world, uint32_t T, uint32_t step_intervals, int32_t num_bins,
-                              DevState *st) {
+                              DevState *st, uint32_t step_tag) {
     const int nc = depth * width;
     const uint32_t ranks = std::min<uint32_t>(world, (step_intervals + T - 1) / T);      // ranks that hold intervals of this step
     hipLaunchKernelGGL(k_shard_apply, dim3((nc + 255) / 256, ranks ? ranks : 1), dim3(256), 0, s, d_hdr_all, d_delta_all, d_ctr, nc,
-                       world, T, step_intervals, num_bins, st);
+                       world, T, step_intervals, num_bins, st, step_tag);
     return hipGetLastError();
 }
 

@@ -127,7 +127,7 @@ hipError_t launch_shard_local(hipStream_t s, uint32_t *d_hists, const uint16_t *
                               int depth, int width, const FlushBatch &fb);
 hipError_t launch_shard_apply(hipStream_t s, const uint32_t *d_hdr_all, const uint32_t *d_delta_all, unsigned long long *d_ctr,
                               int depth, int width, uint32_t world, uint32_t T, uint32_t step_intervals, int32_t num_bins,
-                              DevState *st);
+                              DevState *st, uint32_t step_tag);
 hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *d_f64,
                               const float *d_tilemin, double *d_candA, int32_t *d_candB,
                               unsigned long long *d_mins, double *d_weights,
