@@ -788,7 +788,9 @@ def main():
         "sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest(),
         "n_minimizers_rank0": counters["n_minimizers"],
         "timed_pass_note": "no HIP-event brackets in the timed steps; consecutive batches are binned on two alternating work streams "
-                           "and flushed on a third, all private to the context (the library's default); per-kernel durations: the `kernels` leg",
+                           "and flushed on a third, all private to the context (the library's default); per-kernel durations: the `kernels` leg; "
+                           f"{RAMP_MS:g} ms of elementwise torch kernels run right before the W warm-up steps (creating the timed context leaves "
+                           "the GPU idle and its clocks drop), outside the timed region",
     })
     # SURVEY.md §8(d) prices the path at L + 4*S*k^4/I bytes per read (one K pass per interval): a MODEL of the
     # reference's data movement, not traffic this implementation generates (one K pass serves BATCH intervals and
