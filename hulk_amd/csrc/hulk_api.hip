@@ -162,6 +162,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_cbase, T * cms_binorder_entries(c->cms_depth, c->cms_width)));
     CHK_CREATE(dalloc(&c->d_f64, T * B));
     CHK_CREATE(dalloc(&c->d_rcp32, T * c->row_stride));
+    CHK_CREATE(dalloc(&c->d_rmm, 2 * c->row_stride));
     CHK_CREATE(dalloc(&c->d_mins, S));
     CHK_CREATE(dalloc(&c->d_weights, S));
     CHK_CREATE(dalloc(&c->d_rcb, SL * B * 3));
@@ -224,7 +225,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_segadd); hipFree(c->d_segfac); hipFree(c->d_cstart); hipFree(c->d_sege0);
     hipFree(c->d_ctr); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
     hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd);
-    hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_k32); hipFree(c->d_tilemin);
+    hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_rmm); hipFree(c->d_k32); hipFree(c->d_tilemin);
     hipFree(c->d_scanmap); hipFree(c->d_slotmin); hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited); hipFree(c->d_kminslot);
     for (auto &hs : c->hstage) {
         if (hs.ev) hipEventDestroy(hs.ev);
@@ -304,6 +305,7 @@ int hulk_add_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d
 int hulk_bin_reads_device_at(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
                              uint32_t max_read_len, uint64_t bases_bytes, uint64_t reads_per_spectrum, uint32_t first_spectrum) {
     if (!c) return HULK_ERR_ARG;
+    { const int rcf = fatal_status(c); if (rcf != HULK_OK) return rcf; }
     if (c->finished) return fail(c, HULK_ERR_STATE, "context already finished");
     if (n && (!d_bases || !d_offsets)) return fail(c, HULK_ERR_ARG, "NULL buffer");
     if (c->ring_base != 0) return fail(c, HULK_ERR_STATE, "a partial interval is pending");
@@ -405,6 +407,7 @@ int hulk_flush(hulk_ctx *c) {
 
 int hulk_finish(hulk_ctx *c) {
     if (!c) return HULK_ERR_ARG;
+    { const int rcf = fatal_status(c); if (rcf != HULK_OK) return rcf; }
     if (!c->finished) {
         // pipeline/sketch.go:219-221; a tail batch of hulk_bin_reads_device may span several spectra (ragged last
         // batch of a multi-GPU run): all of them are flushed, in order

@@ -105,31 +105,78 @@ int comm_allreduce_u32(hulk_ctx *c, hipStream_t s, uint32_t *d_buf, size_t words
 // frees everything hulk_comm_init* set up (also after a failed ncclCommInitRank, so that the call can be repeated)
 void comm_teardown(hulk_ctx *c) {
     hulk_ctx::Comm &m = c->comm;
-    if (m.stream) hipStreamSynchronize(m.stream);                 // no collective in flight when the communicator goes
+    if (c->flush_stream) hipStreamSynchronize(c->flush_stream);   // no collective in flight when the communicator goes
+    if (c->stream) hipStreamSynchronize(c->stream);
     if (m.nccl && rccl()->CommDestroy) rccl()->CommDestroy(m.nccl);
     hipFree(m.d_hdr); hipFree(m.d_delta); hipFree(m.d_gather); hipFree(m.d_sk);
     for (int i = 0; i < 2; i++) { if (m.h_hdr[i]) hipHostFree(m.h_hdr[i]); if (m.ev_hdr[i]) hipEventDestroy(m.ev_hdr[i]); }
     if (m.h_stage) hipHostFree(m.h_stage);
-    if (m.ev_ready) hipEventDestroy(m.ev_ready);
-    if (m.ev_done) hipEventDestroy(m.ev_done);
-    if (m.stream) hipStreamDestroy(m.stream);
     m = hulk_ctx::Comm{};
 }
 
-// what stream s has queued so far -> the collectives' stream, and back
-int comm_enter(hulk_ctx *c, hipStream_t s) {
-    // host transport: the buffers leave through the host anyway — wait for the producing stream HERE instead of handing the
-    // dependency to the copy that follows on the exchange stream (with GPU_MAX_HW_QUEUES=16 such a copy was seen to read its
-    // source before the kernels it waited for through an event had written it; docs/EXPERIMENTS.md)
-    if (c->comm.kind == 2) HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipEventRecord(c->comm.ev_ready, s));
-    HIPCHK(c, hipStreamWaitEvent(c->comm.stream, c->comm.ev_ready, 0));
-    return HULK_OK;
-}
-int comm_leave(hulk_ctx *c, hipStream_t s) {
-    HIPCHK(c, hipEventRecord(c->comm.ev_done, c->comm.stream));
-    HIPCHK(c, hipStreamWaitEvent(s, c->comm.ev_done, 0));
-    return HULK_OK;
+// The exchange of a sharded step on stream s: every rank's payload (count-min increments or spectra; may be empty) and,
+// BEHIND it, its sealed header block.  The collectives run on the flush stream itself, in line with the kernels that wrote
+// the buffers and the kernels that read them: the dependency is the stream's order and nothing else.  (Round 4 ran them on
+// a highest-priority stream of their own behind an event, and met a void header block once per ~20 runs of the in-process
+// fuzz under GPU_MAX_HW_QUEUES=16.  The bare pattern — fills + kernel -> event -> copy on another stream — does not
+// misorder on this runtime: 3.9e6 iterations of tools/ubench/hdr_race.hip, profiles/r05_hdr_race.txt.  One stream fewer
+// per rank, no cross-stream edge to get wrong, and a header that proves its own integrity: see the seal.)
+int comm_exchange(hulk_ctx *c, hipStream_t s, uint32_t *own_hdr, const void *own_payload, void *d_payload_all, size_t pbytes,
+                  uint32_t step_tag) {
+    hulk_ctx::Comm &m = c->comm;
+    const size_t hbytes = SHARD_HDR * 4;
+    m.bytes_rx += (uint64_t)(pbytes + hbytes) * (m.world - 1);
+    switch (m.kind) {
+        case 1: {
+            NCCLCHK(c, rccl()->GroupStart());
+            ncclResult_t r1 = ncclSuccess, r2 = ncclSuccess;
+            if (pbytes) r1 = rccl()->AllGather(own_payload, d_payload_all, pbytes, ncclUint8, m.nccl, s);
+            r2 = rccl()->AllGather(own_hdr, m.d_hdr, hbytes, ncclUint8, m.nccl, s);
+            const ncclResult_t r3 = rccl()->GroupEnd();              // (closed whatever the calls inside it returned)
+            if (r1 != ncclSuccess) return fail_nccl(c, r1, "ncclAllGather (payload)");
+            if (r2 != ncclSuccess) return fail_nccl(c, r2, "ncclAllGather (header)");
+            if (r3 != ncclSuccess) return fail_nccl(c, r3, "ncclGroupEnd");
+            return HULK_OK;
+        }
+        case 2: {
+            // staging: [own payload][own header][gathered payloads][gathered headers].  The header is copied out BEHIND the
+            // payload on the same stream and checked on the host before anything is sent: this rank knows the seal its block
+            // must carry.  A copy that is not there after the stream's synchronisation (seen once per ~20 runs of the 4..8-rank
+            // in-process fuzz with 16 hardware queues) is waited for and taken again.
+            { const int rc = comm_host_stage(c, (pbytes + hbytes) * (m.world + 1)); if (rc != HULK_OK) return rc; }
+            uint8_t *h_pay = m.h_stage, *h_hdr = m.h_stage + pbytes, *h_pay_all = h_hdr + hbytes, *h_hdr_all = h_pay_all + pbytes * m.world;
+            const volatile uint32_t *hv = (const volatile uint32_t *)h_hdr;
+            for (int attempt = 0;; attempt++) {
+                ((volatile uint32_t *)h_hdr)[SHARD_TAG] = 0;
+                const bool skip = m.inject == HULK_INJECT_STALE_STAGE && m.inject_step == m.step && attempt == 0;   // test hook
+                if (pbytes) HIPCHK(c, hipMemcpyAsync(h_pay, own_payload, pbytes, hipMemcpyDeviceToHost, s));
+                if (!skip) HIPCHK(c, hipMemcpyAsync(h_hdr, own_hdr, hbytes, hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipStreamSynchronize(s));
+                if (hv[SHARD_TAG] == step_tag || m.inject == HULK_INJECT_STALE_SEAL) break;
+                m.hdr_resyncs++;
+                if (attempt == 3) return fail(c, HULK_ERR_COMM, "this rank's exchange header did not reach its host staging (4 attempts)");
+                HIPCHK(c, hipDeviceSynchronize());
+            }
+            if (pbytes && m.fn(m.user, HULK_XCHG_ALLGATHER, h_pay, h_pay_all, pbytes) != 0)
+                return fail(c, HULK_ERR_COMM, "the host's exchange function failed (all-gather)");
+            if (m.fn(m.user, HULK_XCHG_ALLGATHER, h_hdr, h_hdr_all, hbytes) != 0)
+                return fail(c, HULK_ERR_COMM, "the host's exchange function failed (all-gather)");
+            if (pbytes) HIPCHK(c, hipMemcpyAsync(d_payload_all, h_pay_all, pbytes * m.world, hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipMemcpyAsync(m.d_hdr, h_hdr_all, hbytes * m.world, hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            return HULK_OK;
+        }
+        case 3:
+            for (uint32_t r = 0; r < m.world; r++) {
+                uint8_t *dp = (uint8_t *)d_payload_all + (size_t)r * pbytes;
+                uint32_t *dh = m.d_hdr + (size_t)r * SHARD_HDR;
+                if (pbytes && dp != (const uint8_t *)own_payload) HIPCHK(c, hipMemcpyAsync(dp, own_payload, pbytes, hipMemcpyDeviceToDevice, s));
+                if (dh != own_hdr) HIPCHK(c, hipMemcpyAsync(dh, own_hdr, hbytes, hipMemcpyDeviceToDevice, s));
+            }
+            return HULK_OK;
+        default: break;
+    }
+    return fail(c, HULK_ERR_STATE, "no communicator");
 }
 
 namespace {
@@ -152,16 +199,13 @@ int comm_setup_alloc(hulk_ctx *c, int kind, uint32_t rank, uint32_t world) {
     HIPCHK(c, dalloc(&m.d_delta, (size_t)world * c->T * NC));
     HIPCHK(c, dalloc(&m.d_sk, (size_t)world * (2 + 2 * (size_t)c->S)));
     HIPCHK(c, hipMemset(m.d_hdr, 0, (size_t)world * SHARD_HDR * 4));
-    {
-        int lo = 0, hi = 0;
-        HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(c, hipStreamCreateWithPriority(&m.stream, hipStreamNonBlocking, hi));   // `hi` = greatest priority
-        HIPCHK(c, hipEventCreateWithFlags(&m.ev_ready, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&m.ev_done, hipEventDisableTiming));
-    }
+    HIPCHK(c, hipDeviceSynchronize());
     for (int i = 0; i < 2; i++) {
-        HIPCHK(c, hipHostMalloc((void **)&m.h_hdr[i], (size_t)world * SHARD_HDR * 4, hipHostMallocDefault));
-        HIPCHK(c, hipEventCreateWithFlags(&m.ev_hdr[i], hipEventDisableTiming));
+        // the host's view of a step's gathered header: mapped pinned memory, stored to by k_shard_check; its event is a
+        // default one (system-scope release when it completes)
+        HIPCHK(c, hipHostMalloc((void **)&m.h_hdr[i], (size_t)world * SHARD_HDR * 4, hipHostMallocMapped));
+        memset(m.h_hdr[i], 0, (size_t)world * SHARD_HDR * 4);
+        HIPCHK(c, hipEventCreate(&m.ev_hdr[i]));
     }
     m.rank = rank; m.world = world; m.kind = kind;
     return HULK_OK;
@@ -212,15 +256,6 @@ int hulk_comm_init_loopback(hulk_ctx *c, uint32_t rank, uint32_t world) {
 
 static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, uint32_t max_read_len,
                              uint64_t bases_bytes, uint32_t step_intervals);
-// host transport: the gathered header of the step lies in the host staging right behind this rank's own block — the next
-// step's choice of exchange is taken from there, without another trip through the device
-static void hdr_from_host_stage(hulk_ctx *c) {
-    hulk_ctx::Comm &m = c->comm;
-    if (m.kind != 2) return;
-    const int cur = (int)(m.step & 1);
-    memcpy(m.h_hdr[cur], m.h_stage + SHARD_HDR * 4, (size_t)m.world * SHARD_HDR * 4);
-    m.hdr_pending[cur] = false;
-}
 int hulk_step_sharded(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, uint32_t max_read_len,
                       uint64_t bases_bytes, uint32_t step_intervals) {
     if (!c) return HULK_ERR_ARG;
@@ -256,49 +291,34 @@ static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t
     c->seq_count += n;
     rc = issue_flush(c);
     if (rc != HULK_OK) return rc;
+    hipStream_t s = flush_stream_of(c);
+    const uint32_t tag = (uint32_t)(m.step + 1);                    // the seal of this step's header blocks
     // 2. which exchange: the verdicts of the step before (they travelled with its exchange) — any rank's need_full keeps
     //    the spectra exchange.  The wait ends when the previous step's exchange has run: this step's binning is queued.
     bool full = c->drift || c->scaling || !c->prune || c->no_skip || m.step == 0;
     if (!full) {
         const int prev = (int)((m.step - 1) & 1);
         if (m.hdr_pending[prev]) { HIPCHK(c, hipEventSynchronize(m.ev_hdr[prev])); m.hdr_pending[prev] = false; }
-        // every block of the gathered header carries the number of the step it was written in (word 0): what is read here
+        // every block of the gathered header is sealed with the number of the step it was written in: what is read here
         // must be the previous step's, from every rank — a rank that read an older copy of the buffer would pick another
-        // exchange than its peers, which no collective survives.  (One run in ~20 of the suite's 4-rank fuzz slice failed
-        // that way once the process had 16 hardware queues; the copy below is then waited for on the stream itself.)
+        // exchange than its peers, which no collective survives
         const volatile uint32_t *hh = m.h_hdr[prev];
-        auto stale = [&] { for (uint32_t r = 0; r < m.world; r++) if (hh[(size_t)r * SHARD_HDR] != (uint32_t)m.step) return true; return false; };
+        auto stale = [&] { for (uint32_t r = 0; r < m.world; r++) if (hh[(size_t)r * SHARD_HDR + SHARD_TAG] != (uint32_t)m.step) return true; return false; };
         if (stale()) {
-            // Seen on ROCm 7.2 once the process had 16 hardware queues (one run in ~20 of the suite's 4-rank fuzz slice): the
-            // asynchronous device-to-host copy of the header at the end of a step delivered what the buffer held BEFORE that
-            // step's exchange — it had run ahead of its stream — and its event was complete.  The device buffer still holds
-            // the previous step's gathered header (this step's writes are not queued yet): wait for the stream, fetch it again.
-            hipStream_t fs = flush_stream_of(c);
-            HIPCHK(c, hipStreamSynchronize(fs));
-            HIPCHK(c, hipMemcpyAsync(m.h_hdr[prev], m.d_hdr, (size_t)m.world * SHARD_HDR * 4, hipMemcpyDeviceToHost, fs));
-            HIPCHK(c, hipStreamSynchronize(fs));
+            // the device buffer still holds the previous step's gathered header (this step's writes are not queued yet):
+            // wait for the stream and fetch it with a copy
+            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, hipMemcpyAsync(m.h_hdr[prev], m.d_hdr, (size_t)m.world * SHARD_HDR * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
             m.hdr_resyncs++;
-            if (getenv("HULK_SHARD_DEBUG")) {
-                std::string tg;
-                for (uint32_t r = 0; r < m.world; r++) tg += std::to_string(hh[(size_t)r * SHARD_HDR]) + " ";
-                fprintf(stderr, "hulk shard: rank %u step %llu: stale header copy, fetched again (%s; step tags [ %s])\n", m.rank,
-                        (unsigned long long)m.step, stale() ? "still stale" : "ok", tg.c_str());
-            }
-            // still not the previous step's: a block was stale when its rank SENT it — every rank holds the same gathered
-            // bytes and comes to the same conclusion: the verdicts are unknown, and the spectra exchange is always right
-            if (stale()) full = true;
+            // still not the previous step's: a block was void when its rank SENT it — every rank holds the same gathered
+            // bytes and comes to the same conclusion: the verdicts are unknown, and the spectra exchange is always right.
+            // (If the previous step took the delta exchange, k_shard_check has raised HULK_ERR_COMM on every rank as well.)
+            if (stale()) { full = true; m.hdr_void++; }
         }
-        for (uint32_t r = 0; r < m.world; r++) if (m.h_hdr[prev][(size_t)r * SHARD_HDR + 1]) full = true;
+        for (uint32_t r = 0; r < m.world; r++) if (m.h_hdr[prev][(size_t)r * SHARD_HDR + SHARD_VERDICT]) full = true;
     }
     if (c->shard_full) full = true;                                           // HULK_FLAG_SHARD_FULL: always the spectra exchange
-    static const bool shard_debug = getenv("HULK_SHARD_DEBUG") != nullptr;     // diagnosis: every rank's view of the verdicts
-    if (shard_debug) {
-        std::string v;
-        if (m.step) for (uint32_t r = 0; r < m.world; r++) v += std::to_string(m.h_hdr[(m.step - 1) & 1][(size_t)r * SHARD_HDR + 1]) + " ";
-        fprintf(stderr, "hulk shard: ctx %p rank %u step %llu intervals %u own %u full %d verdicts [ %s]\n", (void *)c, m.rank,
-                (unsigned long long)m.step, step_intervals, own, (int)full, v.c_str());
-    }
-    hipStream_t s = flush_stream_of(c);
     HIPCHK(c, hipEventRecord(c->ev_binned, ring_stream(c)));        // (the binning ran on the ring's work lane)
     if (!no_overlap_mode(c)) HIPCHK(c, hipStreamWaitEvent(s, c->ev_binned, 0));
     const int ring = c->cur_ring;
@@ -308,30 +328,27 @@ static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t
     FlushBatch fb{};
     fb.ring_base = 0; fb.ring_n = c->ring_n; fb.count = own; fb.parity = 0; fb.num_bins = c->B;
     HIPCHK(c, hipMemsetAsync(own_hdr, 0, SHARD_HDR * 4, s));
-    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)own_hdr, (int)(uint32_t)(m.step + 1), 1, s));   // word 0: the step this block belongs to
-    // this rank's verdict for the NEXT step: the whole-batch bound on the counters and weights as they stand now
-    // (a rank without slots has nothing to protect: its verdict stays 0)
-    if (c->slots)
-        HIPCHK(c, launch_flush_decide(s, c->d_ctr, (int)NC, c->d_kminslot, c->d_weights, (int)c->slots, (int)c->slot_begin,
-                                      c->d_state, fb, 1, own_hdr + 1));
+    uint32_t *own_delta = m.d_delta + (size_t)m.rank * c->T * NC;
     if (!full) {
-        uint32_t *own_delta = m.d_delta + (size_t)m.rank * c->T * NC;
         HIPCHK(c, hipMemsetAsync(own_delta, 0, (size_t)c->T * NC * 4, s));
         HIPCHK(c, launch_shard_local(s, hist, c->d_pos16, own_hdr, own_delta, c->cms_depth, c->cms_width, fb));
         HIPCHK(c, hipEventRecord(c->ev_flushed[ring], s));          // the ring is wiped: the work stream may fill it again
         c->pending_flush[ring] = true;
-        rc = comm_enter(c, s);
+    }
+    // this rank's verdict for the NEXT step — the whole-batch bound on the counters and weights as they stand now (a rank
+    // without slots has nothing to protect: verdict 0) — sealed into the block with the step's tag by the LAST store into it
+    const bool void_seal = m.inject == HULK_INJECT_STALE_SEAL && m.inject_step == m.step;    // test hook: a block of another step
+    HIPCHK(c, launch_flush_decide(s, c->d_ctr, (int)NC, c->d_kminslot, c->d_weights, (int)c->slots, (int)c->slot_begin,
+                                  c->d_state, fb, c->slots ? 1 : 2, (unsigned long long *)own_hdr, void_seal ? tag - 1 : tag));
+    const int cur = (int)(m.step & 1);
+    if (!full) {
+        rc = comm_exchange(c, s, own_hdr, own_delta, m.d_delta, (size_t)c->T * NC * 4, tag);
         if (rc != HULK_OK) return rc;
-        if (m.kind == 1) NCCLCHK(c, rccl()->GroupStart());
-        rc = comm_allgather(c, m.stream, own_hdr, m.d_hdr, SHARD_HDR * 4);
-        if (rc == HULK_OK) hdr_from_host_stage(c);
-        const int rc2 = rc == HULK_OK ? comm_allgather(c, m.stream, own_delta, m.d_delta, (size_t)c->T * NC * 4) : rc;
-        if (m.kind == 1) NCCLCHK(c, rccl()->GroupEnd());                 // (closed whatever the calls inside it returned)
-        if (rc2 != HULK_OK) return rc2;
-        rc = comm_leave(c, s);
-        if (rc != HULK_OK) return rc;
+        // a void block in a delta step cannot be repaired (the spectra are wiped): HULK_ERR_COMM on every rank
+        HIPCHK(c, launch_shard_check(s, m.d_hdr, m.world, tag, c->d_state, m.h_hdr[cur], 1));
+        HIPCHK(c, hipEventRecord(m.ev_hdr[cur], s));
         HIPCHK(c, launch_shard_apply(s, m.d_hdr, m.d_delta, c->d_ctr, c->cms_depth, c->cms_width, m.world, c->T,
-                                     step_intervals, c->B, c->d_state, (uint32_t)(m.step + 1)));
+                                     step_intervals, c->B, c->d_state, tag));
         m.steps_delta++;
     } else {
         const size_t need = (size_t)m.world * c->T * B;
@@ -341,12 +358,11 @@ static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t
             HIPCHK(c, hipMalloc((void **)&m.d_gather, need * 4));
             m.gather_words = need;
         }
-        rc = comm_enter(c, s);
-        if (rc == HULK_OK) rc = comm_allgather(c, m.stream, own_hdr, m.d_hdr, SHARD_HDR * 4);
-        if (rc == HULK_OK) hdr_from_host_stage(c);
-        if (rc == HULK_OK) rc = comm_allgather(c, m.stream, hist, m.d_gather, (size_t)c->T * B * 4);
-        if (rc == HULK_OK) rc = comm_leave(c, s);
+        rc = comm_exchange(c, s, own_hdr, hist, m.d_gather, (size_t)c->T * B * 4, tag);
         if (rc != HULK_OK) return rc;
+        // (the header of a spectra exchange carries only the verdicts: a void block makes the next step a spectra exchange)
+        HIPCHK(c, launch_shard_check(s, m.d_hdr, m.world, tag, c->d_state, m.h_hdr[cur], 0));
+        HIPCHK(c, hipEventRecord(m.ev_hdr[cur], s));
         if (own) HIPCHK(c, hipMemsetAsync(hist, 0, (size_t)own * B * 4, s));    // Wipe of the rank's own copy
         HIPCHK(c, hipEventRecord(c->ev_flushed[ring], s));
         c->pending_flush[ring] = true;
@@ -361,12 +377,9 @@ static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t
         }
         m.steps_full++;
     }
-    const int cur = (int)(m.step & 1);
-    if (m.kind != 2) {                                              // (host transport: hdr_from_host_stage has it already)
-        HIPCHK(c, hipMemcpyAsync(m.h_hdr[cur], m.d_hdr, (size_t)m.world * SHARD_HDR * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipEventRecord(m.ev_hdr[cur], s));
-        m.hdr_pending[cur] = true;
-    }
+    // (the host's view of the gathered header was stored by k_shard_check and its event recorded right behind that kernel:
+    // the flush kernels queued after it do not delay the next step's choice)
+    m.hdr_pending[cur] = true;
     m.step++;
     m.global_intervals += step_intervals;
     c->cur_ring ^= 1;
@@ -392,10 +405,10 @@ int hulk_step_sliced(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offs
     if (c->comm.kind == 0) return fail(c, HULK_ERR_STATE, "hulk_step_sliced needs hulk_comm_init");
     if (n_spectra == 0 || n_spectra > c->T) return fail(c, HULK_ERR_ARG, "n_spectra");
     int rc = hulk_bin_reads_device_at(c, d_bases, d_offsets, n, max_read_len, bases_bytes, reads_per_spectrum, 0);
-    if (rc != HULK_OK) return rc;
-    if (c->bin_spectra > n_spectra) return fail(c, HULK_ERR_ARG, "more spectra binned than n_spectra");
-    rc = flush_batch(c, n_spectra, nullptr, false, true);
+    if (rc == HULK_OK && c->bin_spectra > n_spectra) return fail(c, HULK_ERR_ARG, "more spectra binned than n_spectra");
+    if (rc == HULK_OK) rc = flush_batch(c, n_spectra, nullptr, false, true);
     if (rc == HULK_OK) { c->cur_ring ^= 1; c->bin_spectra = 0; }
+    if (rc == HULK_ERR_COMM || rc == HULK_ERR_HIP) c->sticky = rc;      // as hulk_step_sharded: the peers may be inside the all-reduce
     return rc;
 }
 
@@ -422,6 +435,20 @@ int hulk_gather_sketch(hulk_ctx *c, uint64_t *mins, double *weights) {
         if (sb + sc > S) return fail(c, HULK_ERR_COMM, "a rank reported a slot shard outside the sketch");
         for (uint64_t i = sb; i < sb + sc; i++) { mins[i] = b[2 + i]; memcpy(&weights[i], &b[2 + S + i], 8); }
     }
+    return HULK_OK;
+}
+
+int hulk_get_comm_health(hulk_ctx *c, uint64_t *refetched, uint64_t *void_blocks) {
+    if (!c) return HULK_ERR_ARG;
+    if (refetched) *refetched = c->comm.hdr_resyncs;
+    if (void_blocks) *void_blocks = c->comm.hdr_void;
+    return HULK_OK;
+}
+
+int hulk_debug_inject(hulk_ctx *c, uint32_t what, uint64_t step) {
+    if (!c) return HULK_ERR_ARG;
+    if (what > HULK_INJECT_STALE_STAGE) return fail(c, HULK_ERR_ARG, "hulk_debug_inject: what");
+    c->comm.inject = what; c->comm.inject_step = step;
     return HULK_OK;
 }
 

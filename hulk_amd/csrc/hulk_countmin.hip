@@ -697,7 +697,7 @@ __global__ __launch_bounds__(512) void k_shard_local(uint32_t *__restrict__ hist
             if (b < (int64_t)B) cnt += hist[b] != 0;
         }
         for (int off = 32; off; off >>= 1) cnt += __shfl_xor(cnt, off);
-        if (lane == 0 && cnt) atomicAdd(&hdr[2 + t], cnt);
+        if (lane == 0 && cnt) atomicAdd(&hdr[SHARD_USED + t], cnt);
     }
     __syncthreads();
     uint32_t *out = delta + (size_t)t * depth * width;
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void k_shard_apply(const uint32_t *__restrict_
     // flush_go()'s rule per interval
     uint32_t gomask = 0; unsigned long long elems = 0; bool few = false;
     for (uint32_t t = 0; t < cnt; t++) {
-        const uint32_t used = h[2 + t];
+        const uint32_t used = h[SHARD_USED + t];
         if (used == 0) continue;                                               // boss.go:118: nothing to flush
         if ((double)used / (double)num_bins < 0.01) { few = true; continue; }  // kmerspectrum.go:88-96 ("not used yet")
         gomask |= 1u << t;
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256) void k_shard_apply(const uint32_t *__restrict_
     }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
-        if (h[0] != step_tag) set_error(st, -37);                              // HULK_ERR_COMM: a block that is not of this step (word 0: hulk_comm.hip)
+        if (h[SHARD_TAG] != step_tag) set_error(st, -37);                      // HULK_ERR_COMM: a block that is not of this step (the seal: hulk_comm.hip)
         if (few) set_error(st, -5);
         if (elems) atomicAdd(&st->n_elements, elems);
     }
@@ -743,7 +743,30 @@ __global__ __launch_bounds__(256) void k_shard_apply(const uint32_t *__restrict_
     for (uint32_t t = 0; t < (uint32_t)SCAN_BATCH_MAX; t++) sum += v[t];
     if (sum) atomicAdd(&ctr[i], sum);
 }
+// The gathered header of a step, on every rank: each block must be sealed with this step's tag.  `fatal` (delta exchange:
+// the used-bin counts of a void block cannot be trusted and the spectra behind them are wiped) raises HULK_ERR_COMM; after
+// a spectra exchange the header only carries the verdicts for the next step, which a void block turns into "full" on every
+// rank (hulk_comm.hip).  The kernel itself stores the header to the host's mapped copy: no copy engine between the
+// exchange and the host's view of it.
+__global__ __launch_bounds__(256) void k_shard_check(const uint32_t *__restrict__ hdr_all, uint32_t world, uint32_t step_tag,
+                                                     DevState *st, uint32_t *__restrict__ h_out, int fatal) {
+    const uint32_t n = world * SHARD_HDR;
+    bool bad = false;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t v = hdr_all[i];
+        if ((i % SHARD_HDR) == SHARD_TAG && v != step_tag) bad = true;
+        if (h_out) __builtin_nontemporal_store(v, &h_out[i]);
+    }
+    if (bad && fatal) set_error(st, -37);                                      // HULK_ERR_COMM
+    __threadfence_system();
+}
 }  // namespace
+
+hipError_t launch_shard_check(hipStream_t s, const uint32_t *d_hdr_all, uint32_t world, uint32_t step_tag, DevState *st,
+                              uint32_t *h_out, int fatal) {
+    hipLaunchKernelGGL(k_shard_check, dim3(1), dim3(256), 0, s, d_hdr_all, world, step_tag, st, h_out, fatal);
+    return hipGetLastError();
+}
 
 hipError_t launch_shard_local(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, uint32_t *d_hdr, uint32_t *d_delta,
                               int depth, int width, const FlushBatch &fb) {

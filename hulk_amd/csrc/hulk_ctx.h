@@ -68,14 +68,14 @@ struct hulk_ctx {
         uint32_t rank = 0, world = 1;
         ncclComm_t nccl = nullptr;
         hulk_exchange_fn fn = nullptr; void *user = nullptr;
-        // the collectives run on a stream of their own at the HIGHEST priority: a few workgroups that must not queue behind the
-        // thousands of pending minimizer workgroups of the next step (the flush stream around them has the lowest)
-        hipStream_t stream = nullptr; hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-        uint32_t *d_hdr = nullptr;                      // [world][SHARD_HDR]: {step + 1, need_full, used bins per interval ...}
+        // (the collectives run on the flush stream, in line with the kernels around them: hulk_comm.hip, comm_exchange)
+        uint32_t *d_hdr = nullptr;                      // [world][SHARD_HDR]: {need_full, step + 1 (the seal), used bins per interval ...}
         uint32_t *d_delta = nullptr;                    // [world][T][depth * width] count-min increments per interval
         uint32_t *d_gather = nullptr; size_t gather_words = 0;   // [world][T][num_bins] spectra of a full exchange
         uint32_t *h_hdr[2] = {nullptr, nullptr}; hipEvent_t ev_hdr[2] = {nullptr, nullptr}; bool hdr_pending[2] = {false, false};
-        uint64_t hdr_resyncs = 0;                       // times the header copy was not there after its event (see step_sharded_impl)
+        uint64_t hdr_resyncs = 0;                       // times a header was not where its copy / event said it was, and was fetched again
+        uint64_t hdr_void = 0;                          // times a rank's block of the previous step carried another step's seal
+        uint32_t inject = 0; uint64_t inject_step = 0;  // hulk_debug_inject (test hook)
         uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;      // host transport: pinned staging
         unsigned long long *d_sk = nullptr;             // hulk_gather_sketch: [world][2 + 2 S]
         uint64_t step = 0, steps_delta = 0, steps_full = 0, bytes_rx = 0;
@@ -90,6 +90,7 @@ struct hulk_ctx {
     double *d_segadd = nullptr, *d_segfac = nullptr, *d_cstart = nullptr; uint32_t *d_sege0 = nullptr; // ... with decay
     double *d_f64 = nullptr, *d_weights = nullptr, *d_rcb = nullptr;
     float *d_rcp32 = nullptr, *d_k32 = nullptr, *d_tilemin = nullptr;
+    float *d_rmm = nullptr;                                                        // [2][row_stride]: k_rcp_minmax (per-bin max / min of the batch's reciprocal vectors)
     unsigned long long *d_scanmap = nullptr;                                       // [slot groups][wave tiles / 64]: k_scan_test's verdicts
     float *d_slotmin = nullptr;                                                    // [T][slot groups][8]: k_slot_tmin (concept drift only)
     float *d_kmin32 = nullptr, *d_rext = nullptr, *d_kminslot = nullptr;          // bound test of k_cws_scan (no concept drift only)
@@ -160,6 +161,7 @@ int ring_issue_own_flush(hulk_ctx *c);
 hipEvent_t ring_write_event(hulk_ctx *c);
 int ring_ready_for_writes(hulk_ctx *c);
 int sync_all(hulk_ctx *c);
+int fatal_status(hulk_ctx *c);
 int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n,
               uint32_t max_len, uint64_t bases_bytes, uint64_t interval, uint64_t fill, bool join = false);
 hipStream_t lane_stream(hulk_ctx *c, int ring);
@@ -178,8 +180,6 @@ int check_host_reads(hulk_ctx *c, const uint64_t *offsets, uint64_t n, uint64_t 
 
 // ---- hulk_comm.hip
 void comm_teardown(hulk_ctx *c);
-int comm_enter(hulk_ctx *c, hipStream_t s);
-int comm_leave(hulk_ctx *c, hipStream_t s);
 int comm_allreduce_u32(hulk_ctx *c, hipStream_t s, uint32_t *d_buf, size_t words);
 
 }  // namespace hulk

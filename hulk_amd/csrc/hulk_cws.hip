@@ -64,7 +64,7 @@ __global__ __launch_bounds__(1024) void k_flush_decide(const unsigned long long 
                                                        const float *__restrict__ kminslot,
                                                        const double *__restrict__ weights, int slots, int slot_begin,
                                                        DevState *st, FlushBatch fb, int enable,
-                                                       uint32_t *need_full) {
+                                                       unsigned long long *seal, uint32_t seal_tag) {
     __shared__ unsigned long long red[16];
     __shared__ int anypass;
     const int tid = threadIdx.x;
@@ -77,7 +77,8 @@ __global__ __launch_bounds__(1024) void k_flush_decide(const unsigned long long 
     m = red[0];
     for (int i = 1; i < 16; i++) m = red[i] < m ? red[i] : m;
     bool pass = false;
-    if (!enable || m == 0) pass = true;                          // an untouched counter: estimates can be as small as 1
+    if (enable == 2) pass = false;                               // seal only (a rank without slots has nothing to protect)
+    else if (!enable || m == 0) pass = true;                     // an untouched counter: estimates can be as small as 1
     else {
         const double rmax = 1.0 / (double)m;
         for (int s = tid; s < slots; s += blockDim.x) {
@@ -90,8 +91,13 @@ __global__ __launch_bounds__(1024) void k_flush_decide(const unsigned long long 
     }
     if (pass) atomicOr(&anypass, 1);
     __syncthreads();
-    // need_full: the verdict goes to a rank's exchange header instead (hulk_step_sharded: it governs the NEXT step)
-    if (tid == 0) { if (need_full) *need_full = anypass ? 1u : 0u; else st->skip_exact[fb.parity] = anypass ? 0u : 1u; }
+    // seal: the verdict goes to a rank's exchange header instead (hulk_step_sharded: it governs the NEXT step) — as ONE
+    // 64-bit word {step tag : verdict}, the LAST store into the block (everything else of the block was written by kernels
+    // in front of this one on the stream): a block with the step's tag has all of its content, a block without is void
+    if (tid == 0) {
+        if (seal) *seal = ((unsigned long long)seal_tag << 32) | (anypass ? 1ull : 0ull);
+        else st->skip_exact[fb.parity] = anypass ? 0u : 1u;
+    }
 }
 __global__ __launch_bounds__(256) void k_slot_kmin(const float *__restrict__ kmin32, float *__restrict__ kminslot, int wtiles) {
     __shared__ float red[4];
@@ -127,6 +133,30 @@ __global__ __launch_bounds__(256) void k_rcp_extrema(const float *__restrict__ r
         float *o = rext + ((size_t)t * (size_t)(ntiles * 4) + (size_t)(tile * 4 + wid)) * 2;
         o[0] = hi; o[1] = lo;
     }
+}
+
+// Without concept drift only min_t K * rcp_t[bin] over the batch's flushed intervals is wanted (k_cws_scan<MERGE>), and a
+// rounded fp32 product is monotone in either factor: for K < 0 the minimum is K * max_t rcp_t, for K >= 0 it is
+// K * min_t rcp_t — so min(K * rmax, K * rmin) with two per-bin vectors equals the minimum over the T products bit for bit
+// (NaN = bin not in an interval's stream is passed over by v_max / v_min; a bin in no interval stays NaN and loses).
+// rmm[0][bin] = max_t, rmm[1][bin] = min_t.  Reads T x 0.8 MB (k = 21), writes 1.6 MB: ~5 us, and the scan behind it does
+// 12 VALU per row of a tile instead of 8 per row AND interval (128 at T = 16) against 64 KB less L2 traffic per tile.
+__global__ __launch_bounds__(256) void k_rcp_minmax(const float *__restrict__ rcp32, float *__restrict__ rmm, size_t row_stride,
+                                                    const DevState *st, FlushBatch fb) {
+    if (st->skip_exact[fb.parity]) return;
+    const size_t col = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (col >= row_stride) return;
+    const uint32_t gomask = batch_gomask(st, fb);
+    const float qnan = __builtin_nanf("");
+    floatx4 hi = (floatx4)(qnan), lo = (floatx4)(qnan);
+    for (int t = 0; t < (int)fb.count; t++) {
+        if (!((gomask >> t) & 1u)) continue;
+        const floatx4 v = *(const floatx4 *)(rcp32 + (size_t)t * row_stride + col);
+        hi.x = fmaxf(hi.x, v.x); hi.y = fmaxf(hi.y, v.y); hi.z = fmaxf(hi.z, v.z); hi.w = fmaxf(hi.w, v.w);
+        lo.x = fminf(lo.x, v.x); lo.y = fminf(lo.y, v.y); lo.z = fminf(lo.z, v.z); lo.w = fminf(lo.w, v.w);
+    }
+    *(floatx4 *)(rmm + col) = hi;
+    *(floatx4 *)(rmm + row_stride + col) = lo;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -202,12 +232,15 @@ __global__ __launch_bounds__(256) void k_scan_test(const float *__restrict__ kmi
 // reduces it once per tile instead of once per (tile, interval): the 19-instruction transposed reduction was 36 % of the
 // issue cycles of an interval's work on a tile (235 -> 151 cycles; profiles/r04_scan.txt).  k_cws_resolve<true> then
 // re-evaluates the candidate tiles for every interval of the batch and orders the exact values by (A, interval, bin).
-template <bool MERGE>
+// MODE 0: per-interval minima (concept drift); 1: MERGE over the T reciprocal vectors (kept as the comparator of MODE 2:
+// hulk_debug_switches SCAN_MERGE_LOOP); 2: MERGE over the two vectors of k_rcp_minmax (`rcp32` = rmm) — the product path.
+template <int MODE>
 __global__ __launch_bounds__(1024) void k_cws_scan(const float *__restrict__ k32,
                                                    const float *__restrict__ rcp32,
                                                    float *__restrict__ tilemin, int slots, int ntiles,
                                                    size_t row_stride, const DevState *st, FlushBatch fb,
                                                    const unsigned long long *__restrict__ scanmap, int wwords) {
+    constexpr bool MERGE = MODE != 0;
     // XCD-aware order (workgroup b lands on XCD b % 8): XCD x works through column unit 8*chunk + x (16 wave tiles) for
     // ALL slot groups before moving on, so a column's reciprocal vectors (T x 16 KB) are fetched into
     // that XCD's L2 once and re-used by the other groups; the 8 XCDs stream 8 adjacent 16 KB pieces of
@@ -233,6 +266,22 @@ __global__ __launch_bounds__(1024) void k_cws_scan(const float *__restrict__ k32
                 kv[r] = __builtin_nontemporal_load((const floatx4 *)(k32 + (size_t)slot * row_stride + col));
             else
                 kv[r] = (floatx4)(0.f);
+        }
+        if (MODE == 2) {
+            // min_t K * rcp_t = min(K * max_t rcp_t, K * min_t rcp_t): 8 v_mul + 4 v_min3 per row, whatever the batch size
+            const floatx4 hi = *(const floatx4 *)(rcp32 + col), lo = *(const floatx4 *)(rcp32 + row_stride + col);
+            float m[SCAN_ROWS];
+#pragma unroll
+            for (int r = 0; r < SCAN_ROWS; r++) {
+                const float a = fminf(fminf(kv[r].x * hi.x, kv[r].x * lo.x), kv[r].y * hi.y);
+                const float b = fminf(fminf(kv[r].y * lo.y, kv[r].z * hi.z), kv[r].z * lo.z);
+                m[r] = fminf(fminf(fminf(a, b), fminf(kv[r].w * hi.w, kv[r].w * lo.w)), INFINITY);
+            }
+            static_assert(SCAN_ROWS == 8, "wave_min8_by_row reduces exactly 8 rows");
+            const float mine = wave_min8_by_row(m);
+            if ((lane & 7) == 0)                                    // plane 0 of tilemin: [slot group][wave tile][row]
+                tilemin[((size_t)grp * wtiles + (size_t)wt) * SCAN_ROWS + (lane >> 3)] = mine;
+            return;
         }
         floatx4 rc_next = *(const floatx4 *)(rcp32 + col);
         float acc[SCAN_ROWS];
@@ -801,11 +850,13 @@ __global__ void k_fill_f32(float *p, size_t n, float v) {
 // ---------------------------------------------------------------------------- host wrappers
 // A/B aid: HULK_SCAN_PER_INTERVAL=1 keeps the per-interval minima (and resolve) without concept drift too
 static bool scan_merge_off() { static const bool v = getenv("HULK_SCAN_PER_INTERVAL") != nullptr; return v; }
+static bool scan_merge_loop() { static const bool v = getenv("HULK_SCAN_MERGE_LOOP") != nullptr; return v; }
 
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
-                           unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap, bool per_interval) {
+                           unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap, bool per_interval,
+                           float *d_rmm) {
     const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
     const int wtiles = ntiles * 4, wwords = (wtiles + 63) / 64;
     if (d_kmin32)
@@ -814,11 +865,16 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
                        slots, wtiles, wwords, drift_dw, st, fb, d_scanmap, d_visited);
     const int chunks = (wwords * 4 + 7) / 8;                     // units of 16 wave tiles, 8 (one per XCD) side by side
     if (per_interval || scan_merge_off())                       // concept drift: the elements are taken in stream order
-        hipLaunchKernelGGL(k_cws_scan<false>, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rcp32,
+        hipLaunchKernelGGL(k_cws_scan<0>, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rcp32,
                            d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
-    else
-        hipLaunchKernelGGL(k_cws_scan<true>, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rcp32,
+    else if (scan_merge_loop())
+        hipLaunchKernelGGL(k_cws_scan<1>, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rcp32,
                            d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
+    else {
+        hipLaunchKernelGGL(k_rcp_minmax, dim3((unsigned)((row_stride / 4 + 255) / 256)), dim3(256), 0, s, d_rcp32, d_rmm, row_stride, st, fb);
+        hipLaunchKernelGGL(k_cws_scan<2>, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rmm,
+                           d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
+    }
     return hipGetLastError();
 }
 
@@ -829,9 +885,9 @@ hipError_t launch_slot_kmin(hipStream_t s, const float *d_kmin32, float *d_kmins
 
 hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, int ncounters, const float *d_kminslot,
                                const double *d_weights, int slots, int slot_begin, DevState *st, const FlushBatch &fb,
-                               int enable, uint32_t *d_need_full) {
+                               int enable, unsigned long long *d_seal, uint32_t seal_tag) {
     hipLaunchKernelGGL(k_flush_decide, dim3(1), dim3(1024), 0, s, d_ctr, ncounters, d_kminslot, d_weights, slots,
-                       slot_begin, st, fb, enable, d_need_full);
+                       slot_begin, st, fb, enable, d_seal, seal_tag);
     return hipGetLastError();
 }
 

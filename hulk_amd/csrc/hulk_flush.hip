@@ -41,7 +41,15 @@ int ring_ready_for_writes(hulk_ctx *c) {
     return HULK_OK;
 }
 
+// HULK_ERR_HIP / HULK_ERR_COMM from a step are fatal (hulk_hip.h): a stream of this context may be waiting for a collective
+// the peers have left, so nothing is queued or waited for any more — every entry point returns the status
+int fatal_status(hulk_ctx *c) {
+    if (c->sticky == HULK_ERR_HIP || c->sticky == HULK_ERR_COMM) return fail(c, c->sticky);
+    return HULK_OK;
+}
+
 int sync_all(hulk_ctx *c) {
+    { const int rc = fatal_status(c); if (rc != HULK_OK) return rc; }
     { const int rc = issue_flush(c, nullptr); if (rc != HULK_OK) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->lane[1].stream) HIPCHK(c, hipStreamSynchronize(c->lane[1].stream));
@@ -347,7 +355,7 @@ int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &
         HIPCHK(c, launch_cws_scan(s, c->d_k32, c->d_rcp32, c->d_tilemin, (int)c->slots, c->ntiles,
                                   c->row_stride, c->d_state, fb, c->prune ? c->d_kmin32 : nullptr, c->d_rext,
                                   c->d_weights, (int)c->slot_begin, c->d_visited, c->drift ? c->decay_weight : 0.0, c->d_scanmap,
-                                  c->drift /* per-interval minima: the drift resolve replays the stream in order */));
+                                  c->drift /* per-interval minima: the drift resolve replays the stream in order */, c->d_rmm));
         c->scan_tiles_total += (uint64_t)((c->slots + SCAN_ROWS - 1) / SCAN_ROWS) * (uint64_t)c->ntiles * 4u;
         if ((c->profiling & 1)) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
         if (c->drift)
@@ -377,9 +385,7 @@ int issue_flush(hulk_ctx *c, hipEvent_t gate) {
     if (!no_overlap_mode(c) && gate) HIPCHK(c, hipStreamWaitEvent(s, gate, 0));
     uint32_t *hist = c->d_hist + (size_t)ring * (size_t)c->ring_n * (size_t)c->B;
     if (c->deferred.allreduce) {                                 // hulk_step_sliced: sum the ranks' spectra first
-        int rc = comm_enter(c, s);
-        if (rc == HULK_OK) rc = comm_allreduce_u32(c, c->comm.stream, hist + (size_t)fb.ring_base * (size_t)c->B, (size_t)fb.count * (size_t)c->B);
-        if (rc == HULK_OK) rc = comm_leave(c, s);
+        const int rc = comm_allreduce_u32(c, s, hist + (size_t)fb.ring_base * (size_t)c->B, (size_t)fb.count * (size_t)c->B);
         if (rc != HULK_OK) return rc;
     }
     { const int rc = flush_kernels(c, s, hist, fb); if (rc != HULK_OK) return rc; }
@@ -390,6 +396,7 @@ int issue_flush(hulk_ctx *c, hipEvent_t gate) {
 
 // Flush `count` consecutive spectra of the ring (starting at ring_base) through count-min + CWS.
 int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream, bool use_dep, bool allreduce) {
+    { const int rcf = fatal_status(c); if (rcf != HULK_OK) return rcf; }
     if (count == 0) return HULK_OK;
     int rc = ensure_tables(c);
     if (rc != HULK_OK) return rc;

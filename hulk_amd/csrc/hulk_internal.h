@@ -114,15 +114,22 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
-                           unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap, bool per_interval);
+                           unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap, bool per_interval,
+                           float *d_rmm);
 hipError_t launch_tile_kmin(hipStream_t s, const float *d_k32, float *d_kmin32, int slots, int ntiles, size_t row_stride);
 hipError_t launch_slot_kmin(hipStream_t s, const float *d_kmin32, float *d_kminslot, int slots, int ntiles);
 hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, int ncounters, const float *d_kminslot,
                                const double *d_weights, int slots, int slot_begin, DevState *st, const FlushBatch &fb,
-                               int enable, uint32_t *d_need_full = nullptr);
-// hulk_step_sharded's delta exchange (hulk_countmin.hip): a rank's exchange block is SHARD_HDR header words
-// {step + 1, need_full, used bins per interval ...} and [T][depth * width] count-min increments
+                               int enable, unsigned long long *d_seal = nullptr, uint32_t seal_tag = 0);
+// hulk_step_sharded's exchange (hulk_countmin.hip): a rank's block is SHARD_HDR header words — the 64-bit SEAL
+// {word 0: need_full verdict for the next step, word 1: step + 1}, written last and with one store by k_flush_decide, then the
+// used bins per interval — and, for the delta exchange, [T][depth * width] count-min increments
 constexpr int SHARD_HDR = 32;
+constexpr int SHARD_VERDICT = 0, SHARD_TAG = 1, SHARD_USED = 2;
+// every rank's block of the gathered header must carry this step's tag (else DevState.err = HULK_ERR_COMM); the gathered
+// header is stored to `h_out` (mapped pinned host memory) by the kernel itself, for the host's choice of the next exchange
+hipError_t launch_shard_check(hipStream_t s, const uint32_t *d_hdr_all, uint32_t world, uint32_t step_tag, DevState *st,
+                              uint32_t *h_out, int fatal);
 hipError_t launch_shard_local(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, uint32_t *d_hdr, uint32_t *d_delta,
                               int depth, int width, const FlushBatch &fb);
 hipError_t launch_shard_apply(hipStream_t s, const uint32_t *d_hdr_all, const uint32_t *d_delta_all, unsigned long long *d_ctr,

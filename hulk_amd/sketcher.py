@@ -218,7 +218,14 @@ class GpuSketcher:
     def comm_stats(self):
         a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
         self._chk(self._L.hulk_get_comm_stats(self._ctx, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
-        return {"steps_delta": a.value, "steps_full": b.value, "bytes_received": c.value}
+        h, v = ctypes.c_uint64(), ctypes.c_uint64()
+        self._chk(self._L.hulk_get_comm_health(self._ctx, ctypes.byref(h), ctypes.byref(v)))
+        return {"steps_delta": a.value, "steps_full": b.value, "bytes_received": c.value,
+                "headers_refetched": h.value, "void_blocks": v.value}
+
+    def debug_inject(self, what: int, step: int):
+        """Test hook (hulk_debug_inject): make this rank's header block of `step` void / its host staging late."""
+        self._chk(self._L.hulk_debug_inject(self._ctx, what, step))
 
     @property
     def batch_size(self):

@@ -306,6 +306,18 @@ int hulk_step_sliced(hulk_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_of
 int hulk_gather_sketch(hulk_ctx *ctx, uint64_t *mins, double *weights);
 /* Steps taken by each exchange and the bytes this rank received through the transport (cumulative). */
 int hulk_get_comm_stats(hulk_ctx *ctx, uint64_t *steps_delta, uint64_t *steps_full, uint64_t *bytes_received);
+/* Health of the exchange headers (cumulative): `refetched` = times this rank's view of a header (its own block in the host
+ * transport's staging, or the gathered header of the previous step) was not there when its copy / event said so and was
+ * taken again after a synchronisation; `void_blocks` = times a rank's block of the previous step carried another step's seal
+ * (every rank then takes the spectra exchange; after a delta step the run ends with HULK_ERR_COMM).  Both are 0 in a healthy run. */
+int hulk_get_comm_health(hulk_ctx *ctx, uint64_t *refetched, uint64_t *void_blocks);
+/* Test hook (tests/test_gpu_two_rank.py): at step `step` of hulk_step_sharded this rank
+ *   HULK_INJECT_STALE_SEAL   seals its header block with the PREVIOUS step's tag (a block that is not of this step);
+ *   HULK_INJECT_STALE_STAGE  (host transport) finds its own block missing from the host staging on the first attempt. */
+#define HULK_INJECT_NONE 0u
+#define HULK_INJECT_STALE_SEAL 1u
+#define HULK_INJECT_STALE_STAGE 2u
+int hulk_debug_inject(hulk_ctx *ctx, uint32_t what, uint64_t step);
 
 /* Test hook: add counts to the current k-mer spectrum directly (host uint32[num_bins]). */
 int hulk_add_histogram(hulk_ctx *ctx, const uint32_t *bins);

@@ -215,3 +215,119 @@ def test_sharded_step_from_host_slices():
     with pytest.raises(HulkError, match="sequence length must be >= w \\+ k - 1"):
         bad.step_sharded_host(np.frombuffer(b"ACGTACGTAC", dtype=np.uint8), np.array([0, 10], dtype=np.uint64), 1)
     bad.close()
+
+
+# ---- a void / late exchange header (hulk_debug_inject): no silent wrong sketch, no rank out of step -------------------------
+class _ThreadExchange:
+    """all-gather / uint32 sum among the threads of this process (the in-process transport of tools/fuzz_shard.py)"""
+    def __init__(self, world):
+        import threading
+        self.world, self.bar, self.slots = world, threading.Barrier(world), [None] * world
+
+    def make(self, rank):
+        def exchange(op, send, recv):
+            self.slots[rank] = send.copy()
+            self.bar.wait(timeout=120)
+            if op == 0:
+                recv[:] = np.concatenate(self.slots)
+            else:
+                acc = np.zeros(len(send) // 4, dtype=np.uint32)
+                for s_ in self.slots:
+                    acc += s_.view(np.uint32)
+                recv[:] = acc.view(np.uint8)
+            self.bar.wait(timeout=120)
+        return exchange
+
+
+def _run_threads(world, total, inject=None):
+    """`world` ranks of hulk_step_sharded_host as threads on the one GPU; inject = (rank, what, step).
+    -> per rank (mins, weights, cms, error text or None, comm stats)"""
+    import threading
+    import torch
+    import hulk_amd
+    from hulk_amd import synth
+    from hulk_amd.distributed import num_steps, slot_shard, step_share
+    bases, offsets = synth.reads_numpy(0, total, L)
+    ex = _ThreadExchange(world)
+    out, errs = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            sb, sc = slot_shard(S, rank, world)
+            sk = hulk_amd.GpuSketcher(K, W, S, interval=I, device=0, slot_begin=sb, slot_count=sc, batch=BATCH)
+            sk.comm_init_host(rank, world, ex.make(rank))
+            if inject and inject[0] == rank:
+                sk.debug_inject(inject[1], inject[2])
+            for s_ in range(num_steps(total, BATCH, I, world)):
+                first, n, si = step_share(s_, BATCH, I, rank, world, total)
+                lo, hi = (int(offsets[first]), int(offsets[first + n])) if n else (0, 0)
+                sk.step_sharded_host(bases[lo:hi], offsets[first:first + n + 1] - offsets[first] if n else np.zeros(1, np.uint64), si)
+            err = None
+            try:
+                sk.finish()
+                m, wt = sk.gather_sketch()
+                cms = sk.cms()
+            except hulk_amd.HulkError as e:
+                err, m, wt, cms = str(e), None, None, None
+            out[rank] = (m, wt, cms, err, sk.comm_stats())
+            sk.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+            ex.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=300)
+    assert not errs, errs
+    assert all(o is not None for o in out)
+    return out
+
+
+def test_void_or_late_header_block_is_never_a_silent_wrong_sketch():
+    """The choice delta / full of step s+1 rides on step s's gathered header.  Every block is sealed with its step's tag by
+    ONE 64-bit store, the last into the block (k_flush_decide).  A block of another step (hulk_debug_inject):
+      * in a spectra-exchange step: every rank sees the same void block, takes the spectra exchange once more, and the
+        sketch is the single-rank sketch;
+      * in a delta step (its used-bin counts decide which increments apply, and the spectra are wiped): HULK_ERR_COMM on
+        every rank — loud, and no rank is left inside a collective;
+      * a header that is late in the host transport's staging is waited for and taken again: sketch unchanged."""
+    import torch
+    import hulk_amd
+    from hulk_amd import _lib, synth
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world = 3
+    total = 7 * world * BATCH * I + 2 * I + 17
+    base = _run_threads(world, total)
+    nf, nd = base[0][4]["steps_full"], base[0][4]["steps_delta"]
+    assert nf >= 1 and nd >= 2, base[0][4]
+    assert all(o[3] is None and o[4]["void_blocks"] == 0 for o in base)
+    bases, offsets = synth.reads_numpy(0, total, L)
+    g = hulk_amd.GpuSketcher(K, W, S, interval=I)
+    g.add_reads(bases, offsets)
+    g.finish()
+    m1, w1 = g.sketch()
+    c1 = g.cms()
+    g.close()
+    for o in base:
+        assert np.array_equal(o[0], m1) and np.array_equal(o[1], w1) and np.array_equal(o[2], c1)
+    # (1) void block in the last spectra-exchange step: one more spectra exchange, same sketch
+    r1 = _run_threads(world, total, inject=(1, _lib.HULK_INJECT_STALE_SEAL, nf - 1))
+    for o in r1:
+        assert o[3] is None, o[3]
+        assert o[4]["steps_full"] == nf + 1 and o[4]["void_blocks"] == 1, o[4]
+        assert np.array_equal(o[0], m1) and np.array_equal(o[1], w1) and np.array_equal(o[2], c1)
+    # (2) void block in a delta step: HULK_ERR_COMM everywhere
+    r2 = _run_threads(world, total, inject=(2, _lib.HULK_INJECT_STALE_SEAL, nf + 1))
+    for o in r2:
+        assert o[3] is not None and ("exchange" in o[3].lower() or "rccl" in o[3].lower() or "comm" in o[3].lower()), o[3]
+    # (3) own block late in the host staging: fetched again, nothing else changes
+    r3 = _run_threads(world, total, inject=(0, _lib.HULK_INJECT_STALE_STAGE, nf))
+    for rank, o in enumerate(r3):
+        assert o[3] is None, o[3]
+        assert o[4]["steps_full"] == nf and o[4]["void_blocks"] == 0, o[4]
+        assert (o[4]["headers_refetched"] >= 1) == (rank == 0), o[4]
+        assert np.array_equal(o[0], m1) and np.array_equal(o[1], w1) and np.array_equal(o[2], c1)

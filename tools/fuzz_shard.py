@@ -56,6 +56,7 @@ def reads(rng_, n, L, alph):
 
 
 bad = 0
+health = {"headers_refetched": 0, "void_blocks": 0}                  # hulk_get_comm_health over every rank of every case
 t_start = time.time()
 budget = float(os.environ.get("FUZZ_SECONDS", 0))                    # stop after this many seconds (the summary counts the cases done)
 for case in range(n_cases):
@@ -133,6 +134,10 @@ for case in range(n_cases):
         x.start()
     for x in th:
         x.join()
+    for x in out:
+        if x is not None:
+            for key in health:
+                health[key] += x[4].get(key, 0)
     o = pyorc.Sketcher(k, w, S, 0, decay, I)
     oerr = None
     try:
@@ -159,5 +164,6 @@ for case in range(n_cases):
                 print("MISMATCH", desc, "rank", r_, st, int((m != om).sum()), "mins differ")
                 break
     o.close()
-print(f"{n_cases} cases, {bad} mismatches, {time.time() - t_start:.1f} s (seed {seed})")
+print(f"{n_cases} cases, {bad} mismatches, {time.time() - t_start:.1f} s (seed {seed}); exchange headers fetched again: "
+      f"{health['headers_refetched']}, void blocks: {health['void_blocks']}")
 sys.exit(1 if bad else 0)
