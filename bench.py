@@ -229,6 +229,29 @@ def e2e_file_rates(n_reads=2_000_000):
                           "parse_only_reads_per_s": pst["n_seqs"] / pst["seconds"] if pst["seconds"] > 0 else None,
                           "sketch_md5": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()}
         assert out["plain"]["sketch_md5"] == out["gz"]["sketch_md5"] == out["bgzf"]["sketch_md5"]
+        # The plain file four times over (8 M reads, 2.5 GB of text): the line machine on the device (the default: the host
+        # only read()s blocks into pinned memory and copies them over PCIe) beside the host's parser threads, same sketch.
+        big = os.path.join(d, "reads_x4.fq")
+        with open(big, "wb") as fo:
+            for _ in range(4):
+                with open(plain, "rb") as fi:
+                    shutil.copyfileobj(fi, fo, 1 << 24)
+        from hulk_amd import _lib as _l
+        for label, flags in (("plain_8m", 0), ("plain_8m_host_parser", _l.HULK_INGEST_HOST_PARSER)):
+            runs, md5 = [], None
+            for _ in range(3):
+                g = hulk_amd.GpuSketcher(K, W, S, interval=INTERVAL)
+                t0 = time.perf_counter()
+                st = g.sketch_files([big], opts={"flags": flags})
+                g.finish()
+                dt = time.perf_counter() - t0
+                mins, _ = g.sketch()
+                g.close()
+                assert st["n_seqs"] == 4 * n_reads
+                runs.append(dt); md5 = hashlib.md5(mins.astype("<u8").tobytes()).hexdigest()
+            out[label] = {"value": 4 * n_reads / min(runs), "unit": "reads/s", "reads": 4 * n_reads, "seconds": min(runs), "seconds_all_runs": runs,
+                          "file_bytes": os.path.getsize(big), "file_GB_per_s": os.path.getsize(big) / min(runs) / 1e9, "sketch_md5": md5}
+        assert out["plain_8m"]["sketch_md5"] == out["plain_8m_host_parser"]["sketch_md5"]
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return out
@@ -237,8 +260,12 @@ def e2e_file_rates(n_reads=2_000_000):
 def c5_leg():
     """BASELINE configs[4] ("C5"): `hulk smash` over 1024 sketches of sketchSize 2048 (cmd/smash.go:183-226), both metrics:
     end to end through hulk_smash (host arrays in, PCIe both ways) and the distance kernel alone (hulk_smash_ex, HIP events).
-    LDS-pipe fraction of k_smash: every (pair, slot) step is three ds_read_b64 wave-instructions per wave (2 LDS cycles each,
-    MI355X_MICROARCH.md "LDS") -> N^2 * S * 3 / 64 wave-instructions * 2 cycles / 256 CUs / 2.4 GHz over the kernel time."""
+    k_smash is VALU-bound: per slot a thread does 72 VALU instructions for its 4 x 4 pairs (16 v_cmp_eq_f64, 32 v_cndmask,
+    20 v_add_f64; 48 for the plain Jaccard count) = 4.5 per (pair, slot) against 0.375 ds_read_b128 —
+    valu_frac = N^2 * S * 4.5 / 64 wave-instructions * 4.4 cycles (profiles/r03_op_cost.txt) / 1024 SIMDs over the kernel time.
+    `directory`: the reference's whole command (cmd/smash.go:160-226, sketchio.go:100-195): 1024 sketch JSON files are
+    written to a scratch directory first (untimed), then hulk_amd.smash.smash() loads and MD5-verifies them, orders them,
+    computes the matrix on the GPU and writes the CSV — timed as a whole and per stage."""
     from hulk_amd.smash import distance_matrix
     rng = np.random.default_rng(5)
     N, S_ = C5["n"], C5["S"]
@@ -248,9 +275,10 @@ def c5_leg():
     distance_matrix(mins[:8], w[:8], "weightedjaccard")           # module load
     out = {"workload": f"C5: pairwise matrix over {N} synthetic sketches, sketchSize {S_} (hulk smash, cmd/smash.go:183-226)",
            "pairs": N * N}
-    lds_cycles = N * N * S_ * 3 / 64.0 * 2 / 256.0
     for metric in ("weightedjaccard", "jaccard"):
         best = None
+        per_pair_slot = 4.5 if metric == "weightedjaccard" else 3.0
+        valu_cycles = N * N * S_ * per_pair_slot / 64.0 * 4.4 / 1024.0
         for _ in range(3):
             tm = {}
             t0 = time.perf_counter()
@@ -259,8 +287,33 @@ def c5_leg():
             if best is None or dt < best[0]:
                 best = (dt, tm["kernel_ms"], hashlib.md5(np.ascontiguousarray(d).tobytes()).hexdigest())
         out[metric] = {"ms_end_to_end": best[0] * 1e3, "ms_kernel": best[1], "pairs_per_s": N * N / best[0],
-                       "lds_pipe_frac": (lds_cycles / (CLOCK_GHZ * 1e9)) / (best[1] * 1e-3) if best[1] > 0 else None,
+                       "valu_frac": (valu_cycles / (CLOCK_GHZ * 1e9)) / (best[1] * 1e-3) if best[1] > 0 else None,
                        "matrix_md5": best[2]}
+    # the command as the reference runs it: a directory of sketch files in, a CSV out
+    import shutil
+    import tempfile
+    from hulk_amd import sketchio
+    from hulk_amd import smash as smash_mod
+    d_ = tempfile.mkdtemp(prefix="hulk_c5_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        for i in range(N):
+            hd = sketchio.HULKdata()
+            hd.filename = f"sample_{i:04d}.fq"
+            hd.add(sketchio.HistoSketch(21, mins[i], w[i], 194481, False))
+            hd.write_json(os.path.join(d_, f"sample_{i:04d}.json"))
+        file_bytes = sum(os.path.getsize(os.path.join(d_, f)) for f in os.listdir(d_))
+        stages = {}
+        t0 = time.perf_counter()
+        order, dist = smash_mod.smash(d_, os.path.join(d_, "out"), ksize=21, algo="histosketch", metric="weightedjaccard", stages=stages)
+        total = time.perf_counter() - t0
+        assert len(order) == N
+        out["directory"] = {"files": N, "file_bytes": file_bytes, "seconds_total": total,
+                            "seconds_load_and_md5": stages.get("load"), "seconds_matrix": stages.get("matrix"),
+                            "seconds_csv": stages.get("csv"),
+                            "matrix_md5": hashlib.md5(np.ascontiguousarray(dist).tobytes()).hexdigest(),
+                            "same_matrix_as_arrays": hashlib.md5(np.ascontiguousarray(dist).tobytes()).hexdigest() == out["weightedjaccard"]["matrix_md5"]}
+    finally:
+        shutil.rmtree(d_, ignore_errors=True)
     return out
 
 

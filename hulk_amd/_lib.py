@@ -13,6 +13,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhulkhip.so")
+# the profiling build (make -C hulk_amd/csrc EXPERIMENTS=1: the experiment switches of docs/EXPERIMENTS.md compiled in);
+# tools/ select it with HULK_LIB=exp, or HULK_LIB=<path> for any other build of the library
+EXP_LIB_PATH = os.path.join(_HERE, "csrc", "libhulkhip_exp.so")
+if os.environ.get("HULK_LIB"):
+    LIB_PATH = EXP_LIB_PATH if os.environ["HULK_LIB"] == "exp" else os.environ["HULK_LIB"]
 
 HULK_OK = 0
 HULK_ABI_VERSION = 3            # include/hulk_hip.h; load() refuses a libhulkhip.so built from another version of the header
@@ -53,7 +58,7 @@ class IngestStats(ctypes.Structure):
                 ("bytes_in", ctypes.c_uint64), ("seconds", ctypes.c_double)]
 
 
-HULK_INGEST_GZ_ONE_THREAD, HULK_INGEST_GZ_ZLIB, HULK_INGEST_TRACE = 1, 2, 4
+HULK_INGEST_GZ_ONE_THREAD, HULK_INGEST_GZ_ZLIB, HULK_INGEST_TRACE, HULK_INGEST_HOST_PARSER = 1, 2, 4, 8
 
 
 class IngestOpts(ctypes.Structure):

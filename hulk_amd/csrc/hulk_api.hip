@@ -3,6 +3,8 @@
 // hulk_flush.hip, the tables hulk_tables.hip, the multi-GPU entry points hulk_comm.hip (hulk_ctx.h maps the pieces).
 #include "hulk_ctx.h"
 
+#include <mutex>
+
 #include <algorithm>
 #include <cmath>
 
@@ -126,7 +128,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     // (the HULK_* variables read here are overrides for profiling scripts; a host sets the fields)
     auto knob = [](const char *name, uint32_t field, uint32_t dflt, uint32_t lo, uint32_t hi) {
         uint32_t v = field ? field : dflt;
-        if (const char *e = getenv(name)) { const long x = atol(e); if (x >= (long)lo && x <= (long)hi) v = (uint32_t)x; }
+        if (const char *e = HULK_EXP_ENV(name)) { const long x = atol(e); if (x >= (long)lo && x <= (long)hi) v = (uint32_t)x; }
         return v;
     };
     c->T = knob("HULK_BATCH", p.batch, SCAN_BATCH_MAX, 1, SCAN_BATCH_MAX);
@@ -137,8 +139,8 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     const bool decay_on = p.decay_ratio > 0.0 && p.decay_ratio < 1.0;
     c->work_lanes = knob("HULK_WORK_LANES", p.work_lanes, decay_on ? 1 : 2, 1, 2);
     c->host_copy_threads = knob("HULK_HOST_COPY_THREADS", p.host_copy_threads, 4, 1, 32);
-    c->no_overlap = (p.flags & HULK_FLAG_NO_OVERLAP) != 0 || getenv("HULK_NO_OVERLAP") != nullptr;
-    c->shard_full = (p.flags & HULK_FLAG_SHARD_FULL) != 0 || getenv("HULK_SHARD_FULL") != nullptr;
+    c->no_overlap = (p.flags & HULK_FLAG_NO_OVERLAP) != 0 || HULK_EXP_ENV("HULK_NO_OVERLAP") != nullptr;
+    c->shard_full = (p.flags & HULK_FLAG_SHARD_FULL) != 0 || HULK_EXP_ENV("HULK_SHARD_FULL") != nullptr;
     c->ring_n = c->T + 1;
     const size_t T = c->T, RN = c->ring_n;
     CHK_CREATE(dalloc(&c->d_hist, 2 * RN * B));
@@ -147,7 +149,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
         // critical path
         int lo = 0, hi = 0;
         CHK_CREATE(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const char *pe = getenv("HULK_FLUSH_PRIORITY");
+        const char *pe = HULK_EXP_ENV("HULK_FLUSH_PRIORITY");
         const int prio = pe ? atoi(pe) : lo;   // `lo` = least priority (numerically greatest)
         CHK_CREATE(hipStreamCreateWithPriority(&c->flush_stream, hipStreamNonBlocking, prio));
     }
@@ -177,8 +179,8 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(hipMemsetAsync(c->d_visited, 0, (size_t)MIN_SLOTS * 8, c->stream));
     // exact pruning of the K scan: without drift weights only fall; with drift (curMin = w / decayWeight) that still
     // holds for negative weights, which is what k_cws_scan tests then; decayRatio == 0 (decayWeight 0) is left alone
-    c->prune = !(c->drift && c->decay_weight <= 0.0) && !getenv("HULK_NO_PRUNE") && !(p.flags & HULK_FLAG_NO_PRUNE);
-    c->no_skip = getenv("HULK_NO_SKIP") != nullptr || (p.flags & HULK_FLAG_NO_SKIP) != 0;
+    c->prune = !(c->drift && c->decay_weight <= 0.0) && !HULK_EXP_ENV("HULK_NO_PRUNE") && !(p.flags & HULK_FLAG_NO_PRUNE);
+    c->no_skip = HULK_EXP_ENV("HULK_NO_SKIP") != nullptr || (p.flags & HULK_FLAG_NO_SKIP) != 0;
     if (c->scaling) {
         const size_t NC = (size_t)c->cms_depth * c->cms_width;
         CHK_CREATE(dalloc(&c->d_blkcnt, T * (size_t)elem_index_blocks(c->B)));
@@ -501,6 +503,24 @@ int hulk_selftest_reciprocal(hulk_ctx *c, uint64_t *mismatches) {
     return HULK_OK;
 }
 
+// Device buffers of hulk_smash, kept between calls (grow-only, one set per process and device: three hipMallocs and
+// hipFrees were 0.7 of the 2.4 ms a C5 call took end to end).  hulk_smash has no context to hang them on: a mutex
+// serialises the calls that share them.
+namespace {
+struct SmashBuffers {
+    std::mutex mu;
+    int device = -1;
+    unsigned long long *d_m = nullptr; double *d_w = nullptr, *d_o = nullptr;
+    size_t cap_ns = 0, cap_nn = 0;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    void drop() {
+        hipFree(d_m); hipFree(d_w); hipFree(d_o); d_m = nullptr; d_w = d_o = nullptr; cap_ns = cap_nn = 0;
+        if (ea) hipEventDestroy(ea); if (eb) hipEventDestroy(eb); ea = eb = nullptr; device = -1;
+    }
+};
+SmashBuffers g_smash;
+}  // namespace
+
 int hulk_smash_ex(int device, const uint64_t *mins, const double *weights, uint32_t n_sketches, uint32_t sketch_size,
                   int metric, double *distances, double *kernel_ms) {
     if (!mins || !weights || !distances) return fail(nullptr, HULK_ERR_ARG, "NULL");
@@ -508,23 +528,32 @@ int hulk_smash_ex(int device, const uint64_t *mins, const double *weights, uint3
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, HULK_ERR_NO_DEVICE);
     if (device < 0 || device >= ndev) return fail(nullptr, HULK_ERR_ARG, "device ordinal");
-#define SM_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { hipFree(d_m); hipFree(d_w); hipFree(d_o); if (ea) hipEventDestroy(ea); if (eb) hipEventDestroy(eb); return fail_hip(nullptr, e_, #call); } } while (0)
-    unsigned long long *d_m = nullptr; double *d_w = nullptr, *d_o = nullptr;
-    hipEvent_t ea = nullptr, eb = nullptr;
+    std::lock_guard<std::mutex> lock(g_smash.mu);
+    SmashBuffers &B = g_smash;
+#define SM_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { B.drop(); return fail_hip(nullptr, e_, #call); } } while (0)
     const size_t NS = (size_t)n_sketches * sketch_size, NN = (size_t)n_sketches * n_sketches;
     SM_CHK(hipSetDevice(device));
-    SM_CHK(hipMalloc((void **)&d_m, (NS ? NS : 1) * 8));
-    SM_CHK(hipMalloc((void **)&d_w, (NS ? NS : 1) * 8));
-    SM_CHK(hipMalloc((void **)&d_o, (NN ? NN : 1) * 8));
-    SM_CHK(hipMemcpy(d_m, mins, NS * 8, hipMemcpyHostToDevice));
-    SM_CHK(hipMemcpy(d_w, weights, NS * 8, hipMemcpyHostToDevice));
-    if (kernel_ms) { SM_CHK(hipEventCreate(&ea)); SM_CHK(hipEventCreate(&eb)); SM_CHK(hipEventRecord(ea, nullptr)); }
-    SM_CHK(launch_smash(nullptr, d_m, d_w, n_sketches, sketch_size, metric, d_o));
-    if (kernel_ms) { SM_CHK(hipEventRecord(eb, nullptr)); }
-    SM_CHK(hipMemcpy(distances, d_o, NN * 8, hipMemcpyDeviceToHost));
-    if (kernel_ms) { float ms = 0; SM_CHK(hipEventElapsedTime(&ms, ea, eb)); *kernel_ms = ms; hipEventDestroy(ea); hipEventDestroy(eb); }
+    if (B.device != device) { B.drop(); B.device = device; }
+    if (NS > B.cap_ns || !B.d_m) {
+        hipFree(B.d_m); hipFree(B.d_w); B.d_m = nullptr; B.d_w = nullptr; B.cap_ns = 0;
+        SM_CHK(hipMalloc((void **)&B.d_m, (NS ? NS : 1) * 8));
+        SM_CHK(hipMalloc((void **)&B.d_w, (NS ? NS : 1) * 8));
+        B.cap_ns = NS;
+    }
+    if (NN > B.cap_nn || !B.d_o) {
+        hipFree(B.d_o); B.d_o = nullptr; B.cap_nn = 0;
+        SM_CHK(hipMalloc((void **)&B.d_o, (NN ? NN : 1) * 8));
+        B.cap_nn = NN;
+    }
+    if (!B.ea) { SM_CHK(hipEventCreate(&B.ea)); SM_CHK(hipEventCreate(&B.eb)); }
+    SM_CHK(hipMemcpy(B.d_m, mins, NS * 8, hipMemcpyHostToDevice));
+    SM_CHK(hipMemcpy(B.d_w, weights, NS * 8, hipMemcpyHostToDevice));
+    if (kernel_ms) SM_CHK(hipEventRecord(B.ea, nullptr));
+    SM_CHK(launch_smash(nullptr, B.d_m, B.d_w, n_sketches, sketch_size, metric, B.d_o));
+    if (kernel_ms) SM_CHK(hipEventRecord(B.eb, nullptr));
+    SM_CHK(hipMemcpy(distances, B.d_o, NN * 8, hipMemcpyDeviceToHost));
+    if (kernel_ms) { float ms = 0; SM_CHK(hipEventElapsedTime(&ms, B.ea, B.eb)); *kernel_ms = ms; }
 #undef SM_CHK
-    hipFree(d_m); hipFree(d_w); hipFree(d_o);
     return HULK_OK;
 }
 

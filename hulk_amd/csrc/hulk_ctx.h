@@ -21,7 +21,7 @@
 // memory nothing has written shows up the same way in every process (tools/fuzz_parity.py found one such read by its
 // dependence on what earlier contexts had left behind).
 static inline int poison_byte() {
-    static const int v = [] { const char *e = getenv("HULK_POISON"); return e ? (int)(strtol(e, nullptr, 0) & 0xff) : -1; }();
+    static const int v = [] { const char *e = HULK_EXP_ENV("HULK_POISON"); return e ? (int)(strtol(e, nullptr, 0) & 0xff) : -1; }();
     return v;
 }
 static inline hipError_t poison_malloc(void **p, size_t n) {

@@ -770,44 +770,81 @@ __global__ __launch_bounds__(256) void k_cws_beta(const uint64_t *__restrict__ u
 // hulk smash: pairwise distance matrix over N sketches of S slots.
 // distances.GetDistance "jaccard" (distances.go:19-26) and GetWJD (distances.go:44-72) with the
 // reference's quirk that BOTH weight vectors come from the subject sketch (sketchio.go:293-301).
-// Thread (s, q) accumulates over the slots IN ORDER, so the fp64 sums are bit-identical to the Go
-// loops; a 16x16 tile of pairs shares the slot chunks of its 16 subjects / 16 queries through LDS.
+// Every pair (s, q) accumulates over the slots IN ORDER, so the fp64 sums are bit-identical to the Go loops.
+// Register tile: a thread owns 4 subjects x 4 queries, a workgroup of 128 threads a tile of 32 subjects x 64 queries;
+// the slot chunks are staged TRANSPOSED ([slot][row], rows padded to a 16-byte multiple off the bank period), so per slot a
+// thread reads its 4 subject mins, 4 subject weights and 4 query mins with six ds_read_b128 — 0.375 LDS reads per
+// (pair, slot) instead of 3 — and runs 16 independent accumulators.  `+= equal ? |w| : 0.0` is the reference's
+// conditional add bit for bit (the sums are non-negative: x + 0.0 == x); the union of the weighted metric is the sum of
+// the subject's |w| whatever the query (both branches of distances.go:58-68 add max(wA, wB) = |w| when hsB = subject).
 // ==========================================================================================
-constexpr int SMASH_T = 16, SMASH_CH = 64;
-__global__ __launch_bounds__(256) void k_smash(const unsigned long long *__restrict__ mins,
+constexpr int SMASH_TS = 32, SMASH_TQ = 64, SMASH_CH = 32, SMASH_PAD = 2;
+template <int METRIC>
+__global__ __launch_bounds__(128) void k_smash(const unsigned long long *__restrict__ mins,
                                                const double *__restrict__ weights, uint32_t N, uint32_t S,
-                                               int metric, double *__restrict__ out) {
+                                               double *__restrict__ out) {
     // the reference compares the `mins` as float64 (sketchio.go:271-277): converted once, when a chunk is staged
-    __shared__ double ma[SMASH_T][SMASH_CH + 1], mb[SMASH_T][SMASH_CH + 1];
-    __shared__ double wa[SMASH_T][SMASH_CH + 1];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;        // query, subject inside the tile
-    const uint32_t s = blockIdx.y * SMASH_T + ty, q = blockIdx.x * SMASH_T + tx;
-    double intersect = 0.0, uni = 0.0;
+    __shared__ __align__(16) double ma[SMASH_CH][SMASH_TS + SMASH_PAD], wa[SMASH_CH][SMASH_TS + SMASH_PAD];
+    __shared__ __align__(16) double mb[SMASH_CH][SMASH_TQ + SMASH_PAD];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;     // query quad, subject quad inside the tile
+    const uint32_t s0 = blockIdx.y * SMASH_TS, q0 = blockIdx.x * SMASH_TQ;
+    double acc[4][4], uni[4];
+    uint32_t cnt[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uni[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { acc[i][j] = 0.0; cnt[i][j] = 0; }
+    }
     for (uint32_t c0 = 0; c0 < S; c0 += SMASH_CH) {
-        for (int i = threadIdx.x; i < SMASH_T * SMASH_CH; i += 256) {
+        // global reads run along the slots (coalesced), LDS writes go down a column
+        for (int i = tid; i < SMASH_TS * SMASH_CH; i += 128) {
             const int r = i / SMASH_CH, c = i % SMASH_CH;
-            const uint32_t sa = blockIdx.y * SMASH_T + r, qb = blockIdx.x * SMASH_T + r, col = c0 + c;
-            const bool okc = col < S;
-            ma[r][c] = (okc && sa < N) ? (double)mins[(size_t)sa * S + col] : 0.0;
-            wa[r][c] = (okc && sa < N) ? weights[(size_t)sa * S + col] : 0.0;
-            mb[r][c] = (okc && qb < N) ? (double)mins[(size_t)qb * S + col] : 0.0;
+            const uint32_t row = s0 + r, col = c0 + c;
+            const bool ok = col < S && row < N;
+            ma[c][r] = ok ? (double)mins[(size_t)row * S + col] : 0.0;
+            if (METRIC == 1) wa[c][r] = ok ? fabs(weights[(size_t)row * S + col]) : 0.0;   // max(max(w,0), max(-w,0)) == |w| (NaN stays NaN)
+        }
+        for (int i = tid; i < SMASH_TQ * SMASH_CH; i += 128) {
+            const int r = i / SMASH_CH, c = i % SMASH_CH;
+            const uint32_t row = q0 + r, col = c0 + c;
+            mb[c][r] = (col < S && row < N) ? (double)mins[(size_t)row * S + col] : 0.0;
         }
         __syncthreads();
         const uint32_t lim = S - c0 < (uint32_t)SMASH_CH ? S - c0 : (uint32_t)SMASH_CH;
-        if (metric == 1) {
-            for (uint32_t c = 0; c < lim; c++) {
-                // math.Max(math.Max(w,0), math.Max(-w,0)) == |w| (NaN stays NaN); weightB == weightA
-                const double wgt = fabs(wa[ty][c]);
-                if (ma[ty][c] == mb[tx][c]) { intersect += wgt; uni += wgt; }
-                else uni += wgt;
+#pragma unroll 2
+        for (uint32_t c = 0; c < lim; c++) {                       // (unrolled by two: the next slot's six LDS reads are in flight under this one's 72 VALU)
+            const double2 a01 = *(const double2 *)&ma[c][4 * ty], a23 = *(const double2 *)&ma[c][4 * ty + 2];
+            const double2 b01 = *(const double2 *)&mb[c][4 * tx], b23 = *(const double2 *)&mb[c][4 * tx + 2];
+            const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
+            if (METRIC == 1) {
+                const double2 w01 = *(const double2 *)&wa[c][4 * ty], w23 = *(const double2 *)&wa[c][4 * ty + 2];
+                const double w[4] = {w01.x, w01.y, w23.x, w23.y};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    uni[i] += w[i];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j] += (a[i] == b[j]) ? w[i] : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) cnt[i][j] += (a[i] == b[j]) ? 1u : 0u;      // a count of 1.0s is exact in fp64
             }
-        } else {
-            for (uint32_t c = 0; c < lim; c++) if (ma[ty][c] == mb[tx][c]) intersect += 1.0;
         }
         __syncthreads();
     }
-    if (s < N && q < N)
-        out[(size_t)s * N + q] = metric == 1 ? 1 - (intersect / uni) : 1.0 - (intersect / (double)S);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t s = s0 + 4 * ty + i;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t q = q0 + 4 * tx + j;
+            if (s < N && q < N)
+                out[(size_t)s * N + q] = METRIC == 1 ? 1 - (acc[i][j] / uni[i]) : 1.0 - ((double)cnt[i][j] / (double)S);
+        }
+    }
 }
 
 // K = c * exp(b - r) in fp64, rounded once to fp32 (pad columns stay 0: 0 * NaN = NaN, ignored)
@@ -849,8 +886,8 @@ __global__ void k_fill_f32(float *p, size_t n, float v) {
 
 // ---------------------------------------------------------------------------- host wrappers
 // A/B aid: HULK_SCAN_PER_INTERVAL=1 keeps the per-interval minima (and resolve) without concept drift too
-static bool scan_merge_off() { static const bool v = getenv("HULK_SCAN_PER_INTERVAL") != nullptr; return v; }
-static bool scan_merge_loop() { static const bool v = getenv("HULK_SCAN_MERGE_LOOP") != nullptr; return v; }
+static bool scan_merge_off() { static const bool v = HULK_EXP_ENV("HULK_SCAN_PER_INTERVAL") != nullptr; return v; }
+static bool scan_merge_loop() { static const bool v = HULK_EXP_ENV("HULK_SCAN_MERGE_LOOP") != nullptr; return v; }
 
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
@@ -970,8 +1007,9 @@ hipError_t launch_cws_beta(hipStream_t s, const uint64_t *d_uraw, uint64_t first
 hipError_t launch_smash(hipStream_t s, const unsigned long long *d_mins, const double *d_weights, uint32_t N, uint32_t S,
                         int metric, double *d_out) {
     if (N == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_smash, dim3((N + SMASH_T - 1) / SMASH_T, (N + SMASH_T - 1) / SMASH_T), dim3(256), 0, s, d_mins,
-                       d_weights, N, S, metric, d_out);
+    const dim3 g((N + SMASH_TQ - 1) / SMASH_TQ, (N + SMASH_TS - 1) / SMASH_TS);
+    if (metric == 1) hipLaunchKernelGGL(k_smash<1>, g, dim3(128), 0, s, d_mins, d_weights, N, S, d_out);
+    else hipLaunchKernelGGL(k_smash<0>, g, dim3(128), 0, s, d_mins, d_weights, N, S, d_out);
     return hipGetLastError();
 }
 

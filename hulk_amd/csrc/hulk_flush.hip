@@ -219,7 +219,7 @@ static int bin_fast(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, const uin
     pick_config(c->p.k, max_len, P, threads);      // (the fast path implies max_len <= 512: always fits)
     // the list is normally empty or short; its length is only known on the device, so the grid is fixed: enough
     // workgroups that 1 % of deferred reads (reads with N) do not queue behind 512 waves (blocks past the list exit at once)
-    static const uint32_t slow_blocks = [] { const char *e = getenv("HULK_SLOW_BLOCKS"); const long v = e ? atol(e) : 2048; return (uint32_t)(v < 1 ? 1 : v > 8192 ? 8192 : v); }();
+    static const uint32_t slow_blocks = [] { const char *e = HULK_EXP_ENV("HULK_SLOW_BLOCKS"); const long v = e ? atol(e) : 2048; return (uint32_t)(v < 1 ? 1 : v > 8192 ? 8192 : v); }();
     const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(slow_blocks, (n + 3) / 4);
     HIPCHK(c, launch_minimizer_bin(s, d_bases, d_offsets, n, P, threads, hist, c->d_state, c->d_min_slots, ln.d_slow_list,
                                    ln.d_slow_count, list_blocks));
@@ -234,7 +234,7 @@ static MinimizerParams piece_params(const hulk_ctx *c, uint64_t bases_bytes, uin
     // whole intervals in front of this launch move the first spectrum, not the fill: the kernels then see a launch that
     // starts inside spectrum ring_base (hist_slot() is unchanged by this) and build no empty spectra in front of it
     if (P.interval && P.fill >= P.interval) { P.ring_base = (uint32_t)((P.ring_base + P.fill / P.interval) % P.ring_n); P.fill %= P.interval; }
-    if (const char *e = getenv("HULK_K1_DEBUG")) P.debug = (uint32_t)atoi(e);
+    if (const char *e = HULK_EXP_ENV("HULK_K1_DEBUG")) P.debug = (uint32_t)atoi(e);
     P.pair = pair ? 1u : 0u;
     return P;
 }
@@ -256,7 +256,7 @@ static int lane_open(hulk_ctx *c, int li) {
 // the lists, as any later call that needs more does.
 int lanes_prereserve(hulk_ctx *c) {
     const uint64_t I = c->p.interval;
-    if (!I || getenv("HULK_NO_PRERESERVE")) return HULK_OK;
+    if (!I || HULK_EXP_ENV("HULK_NO_PRERESERVE")) return HULK_OK;
     const uint64_t n = std::min<uint64_t>((uint64_t)c->T * I, MAX_READS_PER_LAUNCH);
     const int nl = (c->work_lanes > 1 && !c->no_overlap) ? 2 : 1;
     for (int li = 0; li < nl; li++) {
@@ -299,9 +299,9 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
     // length bound already exceeds that, go straight to the generic kernel
     // ... or, two groups per read, <= 2*16w - (w-1) positions (300 bases at k = 21, w = 9) while a group's own
     // 16w + k - 1 bases fit its 256-base staging
-    const bool fast_base = c->p.w >= 1 && c->p.w <= 16 && !getenv("HULK_NO_FAST_K1") && n < 0xffffffffull;
+    const bool fast_base = c->p.w >= 1 && c->p.w <= 16 && !HULK_EXP_ENV("HULK_NO_FAST_K1") && n < 0xffffffffull;
     const bool single_ok = max_len <= 256 && (uint64_t)max_len < (uint64_t)c->p.k + 16ull * c->p.w;
-    const bool pair_ok = !single_ok && !getenv("HULK_NO_PAIR") && 16ull * c->p.w + c->p.k - 1 <= 256 && max_len <= 512 &&
+    const bool pair_ok = !single_ok && !HULK_EXP_ENV("HULK_NO_PAIR") && 16ull * c->p.w + c->p.k - 1 <= 256 && max_len <= 512 &&
                          (uint64_t)max_len < (uint64_t)c->p.k + 32ull * c->p.w - (c->p.w - 1);
     int rc = HULK_OK;
     if (fast_base && (single_ok || pair_ok)) {
@@ -517,6 +517,18 @@ int ctx_stage_acquire(hulk_ctx *c, size_t nbytes, uint64_t n, StageSet *out) {
     if (rc != HULK_OK) return rc;
     out->h_bases = hs.h_bases; out->d_bases = hs.d_bases; out->h_off = hs.h_off; out->d_off = hs.d_off; out->cap_bases = hs.cap_bases;
     c->copies_pending = true;                                   // (the caller queues its copies on ctx_stream())
+    return HULK_OK;
+}
+int ctx_device(const hulk_ctx *c) { return c->p.device; }
+int ctx_wait_event(hulk_ctx *c, hipEvent_t e) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
+    c->copies_pending = true;                                   // (lane 1 is told through the fork in front of its next batch)
+    return HULK_OK;
+}
+int ctx_record_busy(hulk_ctx *c, hipEvent_t e0, hipEvent_t e1, bool *has1) {
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    *has1 = false;
+    if (c->lane[1].stream) { HIPCHK(c, hipEventRecord(e1, c->lane[1].stream)); *has1 = true; }
     return HULK_OK;
 }
 int ctx_stage_release(hulk_ctx *c) {

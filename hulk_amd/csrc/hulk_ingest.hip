@@ -40,6 +40,7 @@
 #include "fast_inflate.h"
 #include "par_inflate.h"
 #include "crc32_clmul.h"
+#include "hulk_fastq.h"
 
 namespace {
 
@@ -56,6 +57,7 @@ struct IngestCfg {
     unsigned readers = 4;                     // pieces a block of a regular file is pread() in, side by side
     bool zlib = false;                        // zlib's inflate instead of fast_inflate.h
     bool trace = false;                       // per-phase seconds on stderr
+    bool host_parser = false;                 // FASTQ lines -> reads on the host's parser threads instead of the device
 };
 static IngestCfg resolve_cfg(const hulk_ingest_opts *o, uint32_t threads) {
     IngestCfg c;
@@ -69,7 +71,9 @@ static IngestCfg resolve_cfg(const hulk_ingest_opts *o, uint32_t threads) {
         if (o->flags & HULK_INGEST_GZ_ONE_THREAD) c.gz_par = false;
         if (o->flags & HULK_INGEST_GZ_ZLIB) c.zlib = true;
         if (o->flags & HULK_INGEST_TRACE) c.trace = true;
-    } else {
+        if (o->flags & HULK_INGEST_HOST_PARSER) c.host_parser = true;
+    }
+    if (!o || !o->gz_threads) {                   // the default of 16 inflate threads is for hosts that have them
         const long hw = (long)std::thread::hardware_concurrency();
         if (hw > 0 && (long)c.gz_threads > hw) c.gz_threads = (unsigned)hw;
     }
@@ -87,6 +91,20 @@ static IngestCfg resolve_cfg(const hulk_ingest_opts *o, uint32_t threads) {
     if (c.readers < 1) c.readers = 1;
     if (c.readers > 16) c.readers = 16;
     return c;
+}
+// hulk_ingest_opts as hulk_create checks hulk_params: unknown flags, non-zero reserved fields and values outside the ranges
+// the header states are refused, not clamped (an empty string: the options are fine)
+static std::string check_opts(const hulk_ingest_opts *o) {
+    if (!o) return std::string();
+    if (o->flags & ~(HULK_INGEST_GZ_ONE_THREAD | HULK_INGEST_GZ_ZLIB | HULK_INGEST_TRACE | HULK_INGEST_HOST_PARSER)) return "hulk_ingest_opts: unknown flags";
+    if (o->reserved[0] || o->reserved[1]) return "hulk_ingest_opts: reserved must be 0";
+    if (o->parser_threads > 256) return "hulk_ingest_opts: parser_threads must be 0 (default) or 1..256";
+    if (o->gz_threads > 64) return "hulk_ingest_opts: gz_threads must be 0 (default) or 1..64";
+    if (o->file_readers > 16) return "hulk_ingest_opts: file_readers must be 0 (default) or 1..16";
+    if (o->block_bytes && o->block_bytes < 2 * MAX_TOKEN) return "hulk_ingest_opts: block_bytes must be 0 (default) or >= 128 KiB";
+    if (o->block_bytes > (1ull << 31)) return "hulk_ingest_opts: block_bytes must be <= 2 GiB";
+    if (o->gz_chunk_bytes && o->gz_chunk_bytes < (8u << 10)) return "hulk_ingest_opts: gz_chunk_bytes must be 0 (default) or >= 8 KiB";
+    return std::string();
 }
 constexpr size_t FASTA_BATCH_BYTES = 64u << 20;
 
@@ -318,7 +336,7 @@ struct BigBuf {
         void *m = ::mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m == MAP_FAILED) { p = nullptr; n = 0; throw std::bad_alloc(); }
         p = m;
-        static const bool thp = getenv("HULK_GZ_NO_THP") == nullptr;
+        static const bool thp = HULK_EXP_ENV("HULK_GZ_NO_THP") == nullptr;
         if (thp) ::madvise(p, n, MADV_HUGEPAGE);
     }
     template <class T> T *as() const { return (T *)p; }
@@ -358,9 +376,16 @@ class Team {
             job_ = &job; n_ = n; next_.store(0, std::memory_order_relaxed); pending_ = (unsigned)th_.size(); gen_++;
         }
         cv_.notify_all();
-        for (unsigned i; (i = next_.fetch_add(1, std::memory_order_relaxed)) < n;) f(i);
+        std::exception_ptr mine;                         // the caller's own share may throw too: the workers still hold `job`
+        try {
+            for (unsigned i; (i = next_.fetch_add(1, std::memory_order_relaxed)) < n;) f(i);
+        } catch (...) {
+            mine = std::current_exception();
+            next_.store(n, std::memory_order_relaxed);   // nothing more is handed out
+        }
         std::unique_lock<std::mutex> g(m_);
-        done_.wait(g, [this] { return pending_ == 0; });
+        done_.wait(g, [this] { return pending_ == 0; });   // ... and nobody touches `job` or the caller's buffers after this
+        if (mine) { failed_ = nullptr; std::rethrow_exception(mine); }
         if (failed_) { std::exception_ptr e = failed_; failed_ = nullptr; std::rethrow_exception(e); }
     }
 
@@ -1370,13 +1395,15 @@ struct Parser {
     bool have_pending = false;
     bool carry_bad = false; std::string carry_hdr;
 
-    bool fastq_block(const Block &blk) {
-        const uint8_t *base = blk.buf.data(), *end = base + blk.len;
-        uint32_t P = (uint32_t)std::min<size_t>(threads, std::max<size_t>(1, blk.len / 16384));
+    bool fastq_block(const Block &blk) { return fastq_bytes(blk.buf.data(), blk.len, blk.tail_too_long); }
+    // `len` bytes that end in '\n'; tail_too_long: the unterminated line behind them already has MAX_TOKEN bytes
+    bool fastq_bytes(const uint8_t *base, size_t blen, bool tail_too_long) {
+        const uint8_t *end = base + blen;
+        uint32_t P = (uint32_t)std::min<size_t>(threads, std::max<size_t>(1, blen / 16384));
         std::vector<const uint8_t *> cutp(P + 1);
         cutp[0] = base; cutp[P] = end;
         for (uint32_t i = 1; i < P; i++) {
-            const uint8_t *q = base + blk.len * i / P;
+            const uint8_t *q = base + blen * i / P;
             if (q < cutp[i - 1]) q = cutp[i - 1];
             const uint8_t *nl = q < end ? (const uint8_t *)memchr(q, '\n', (size_t)(end - q)) : nullptr;
             cutp[i] = nl ? nl + 1 : end;
@@ -1405,7 +1432,7 @@ struct Parser {
             if (s2[i].started || s2[i].completed) { carry_bad = s2[i].bad_pending; carry_hdr = s2[i].bad_pending_hdr; }
             if (s1[i].too_long) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
         }
-        if (blk.tail_too_long) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
+        if (tail_too_long) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
         fq_state = st[P];
         // a record whose sequence line has been seen but not its 4th line is not a read yet
         uint64_t n = seq0[P];
@@ -1518,6 +1545,319 @@ int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, const Inge
     return ok ? HULK_OK : err.code;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// FASTQ -> reads on the DEVICE (hulk_fastq.hip).  The host's part of a run shrinks to moving bytes: a reader thread fills
+// pinned buffers with raw file bytes (ByteSource: files, gzip, STDIN — fixed-size blocks, cut anywhere), the calling thread
+// queues one host-to-device copy and one chain of parse kernels per block and hands the parsed reads of the block before to
+// hulk_add_reads_device.  Streams: copies on `cs`, parse kernels on `ps`, binning on the context's lanes;
+//   copy(b) -> parse(b) [after parse(b-1): the tail; after the binning of block b-2 has read the output set] -> the block's
+//   scalars reach the host -> hulk_add_reads_device(b) while copy(b+1) / parse(b+1) are already under way.
+// Buffers: 4 pinned blocks, 3 raw device blocks (porch + block), 2 output sets (bases + offsets), one set of line-index arrays
+// — about 130 MB pinned and 250 MB of HBM at the default block size.  They belong to the PROCESS, not to a context: a run
+// borrows an idle set for its device and block size and hands it back (a `hulk sketch` per file on fresh contexts would
+// otherwise pin and unpin 128 MB per file: tens of milliseconds each).
+// ------------------------------------------------------------------------------------------
+struct FqDev {
+    static constexpr int NRAW = 3, NOUT = 2, NHOST = 4, NST = 4;
+    int device = 0; size_t block = 0; uint32_t porch = 0;
+    hipStream_t cs = nullptr, ps = nullptr;
+    uint8_t *d_raw[NRAW] = {}, *h_buf[NHOST] = {}, *d_bases[NOUT] = {};
+    uint64_t *d_off[NOUT] = {};
+    hulk::FqState *d_state = nullptr, *h_state = nullptr;          // [NST]
+    hipEvent_t ev_copied[NHOST] = {}, ev_parsed[NST] = {}, ev_busy[NOUT][2] = {};
+    bool busy0[NOUT] = {}, busy1[NOUT] = {};
+    hulk::FqBuffers B;
+    size_t raw_bytes() const { return (size_t)porch + block + 64; }
+    void release() {
+        if (cs) hipStreamSynchronize(cs);
+        if (ps) hipStreamSynchronize(ps);
+        for (auto &p : d_raw) { hipFree(p); p = nullptr; }
+        for (auto &p : d_bases) { hipFree(p); p = nullptr; }
+        for (auto &p : d_off) { hipFree(p); p = nullptr; }
+        for (auto &p : h_buf) { if (p) hipHostFree(p); p = nullptr; }
+        hipFree(d_state); d_state = nullptr;
+        if (h_state) hipHostFree(h_state); h_state = nullptr;
+        hipFree(B.wgcnt); hipFree(B.line_end); hipFree(B.linfo); hipFree(B.wgmap); hipFree(B.wgseq); hipFree(B.src_out);
+        hipFree(B.lmap); hipFree(B.wgstate); hipFree(B.wgbytes);
+        B = hulk::FqBuffers{};
+        for (auto &e : ev_copied) { if (e) hipEventDestroy(e); e = nullptr; }
+        for (auto &e : ev_parsed) { if (e) hipEventDestroy(e); e = nullptr; }
+        for (auto &pr : ev_busy) for (auto &e : pr) { if (e) hipEventDestroy(e); e = nullptr; }
+        if (cs) hipStreamDestroy(cs); if (ps) hipStreamDestroy(ps);
+        cs = ps = nullptr;
+    }
+    static void destroy(void *p) { FqDev *d = (FqDev *)p; d->release(); delete d; }
+};
+
+// idle buffer sets of the process (at most FQ_POOL_MAX are kept; the others are freed when their run ends)
+static std::mutex g_fq_mu;
+static std::vector<FqDev *> g_fq_idle;
+constexpr size_t FQ_POOL_MAX = 2;
+static void fq_dev_release(FqDev *d) {
+    if (!d) return;
+    {
+        std::lock_guard<std::mutex> g(g_fq_mu);
+        if (g_fq_idle.size() < FQ_POOL_MAX) { g_fq_idle.push_back(d); return; }
+    }
+    FqDev::destroy(d);
+}
+// a parser for blocks of `block` bytes on the context's device: an idle set of the process, or a new one
+static FqDev *fq_dev_for(hulk_ctx *ctx, size_t block, IngestError &err) {
+    const int device = hulk::ctx_device(ctx);
+    {
+        std::lock_guard<std::mutex> g(g_fq_mu);
+        for (size_t i = 0; i < g_fq_idle.size(); i++)
+            if (g_fq_idle[i]->device == device && g_fq_idle[i]->block == block) {
+                FqDev *d = g_fq_idle[i]; g_fq_idle.erase(g_fq_idle.begin() + i); return d;
+            }
+        // (a set of another shape makes room)
+        if (g_fq_idle.size() >= FQ_POOL_MAX) { FqDev::destroy(g_fq_idle.front()); g_fq_idle.erase(g_fq_idle.begin()); }
+    }
+    FqDev *d = new FqDev();
+    d->device = device; d->block = block; d->porch = 1u << 20;
+#define FQ_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err.set(HULK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); FqDev::destroy(d); return nullptr; } } while (0)
+    FQ_HIP(hipSetDevice(d->device));
+    FQ_HIP(hipStreamCreateWithFlags(&d->cs, hipStreamNonBlocking));
+    FQ_HIP(hipStreamCreateWithFlags(&d->ps, hipStreamNonBlocking));
+    hulk::FqBuffers &B = d->B;
+    B.porch = d->porch;
+    B.line_cap = (uint32_t)((d->porch + block) / 8 + 1024);
+    B.read_cap = B.line_cap / 2;
+    B.bytes_cap = d->porch + block;
+    for (auto &p : d->d_raw) { FQ_HIP(hipMalloc((void **)&p, d->raw_bytes())); FQ_HIP(hipMemset(p, '\n', d->raw_bytes())); }
+    for (auto &p : d->h_buf) FQ_HIP(hipHostMalloc((void **)&p, block, hipHostMallocDefault));
+    for (auto &p : d->d_bases) FQ_HIP(hipMalloc((void **)&p, B.bytes_cap + 64));
+    for (auto &p : d->d_off) FQ_HIP(hipMalloc((void **)&p, ((size_t)B.read_cap + 2) * 8));
+    FQ_HIP(hipMalloc((void **)&d->d_state, FqDev::NST * sizeof(hulk::FqState)));
+    FQ_HIP(hipHostMalloc((void **)&d->h_state, FqDev::NST * sizeof(hulk::FqState), hipHostMallocDefault));
+    const size_t nchunk = (d->raw_bytes() + 16383) / 16384 + 8, nlwg = ((size_t)B.line_cap + 1023) / 1024 + 8;
+    FQ_HIP(hipMalloc((void **)&B.wgcnt, nchunk * 4));
+    FQ_HIP(hipMalloc((void **)&B.line_end, (size_t)B.line_cap * 4));
+    FQ_HIP(hipMalloc((void **)&B.linfo, (size_t)B.line_cap * 4));
+    FQ_HIP(hipMalloc((void **)&B.lmap, (size_t)B.line_cap));
+    FQ_HIP(hipMalloc((void **)&B.wgmap, nlwg * 4));
+    FQ_HIP(hipMalloc((void **)&B.wgstate, nlwg));
+    FQ_HIP(hipMalloc((void **)&B.wgseq, nlwg * 4));
+    FQ_HIP(hipMalloc((void **)&B.wgbytes, nlwg * 8));
+    FQ_HIP(hipMalloc((void **)&B.src_out, ((size_t)B.read_cap + 2) * 4));
+    for (auto &e : d->ev_copied) FQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : d->ev_parsed) FQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &pr : d->ev_busy) for (auto &e : pr) FQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    FQ_HIP(hipDeviceSynchronize());
+#undef FQ_HIP
+    return d;
+}
+
+// reader thread of the device path: raw blocks of exactly `block` bytes (the last one shorter) into the pinned buffers
+class RawReader {
+ public:
+    struct Item { int idx = -1; size_t len = 0; bool eof = false; };
+    RawReader(const char *const *paths, uint32_t n, const IngestCfg &cfg, FqDev *dev) : dev_(dev), src_(paths, n, cfg) {
+        for (int i = 0; i < FqDev::NHOST; i++) free_.push_back(i);
+        th_ = std::thread([this] { run(); });
+    }
+    ~RawReader() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    bool next(Item &it, IngestError &err) {                  // false: the stream has ended (or failed: err)
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return !q_.empty() || done_; });
+        if (!q_.empty()) { it = q_.front(); q_.pop_front(); return true; }
+        if (err_.code != HULK_OK) err = err_;
+        return false;
+    }
+    void recycle(int idx) { { std::lock_guard<std::mutex> g(m_); free_.push_back(idx); } cv_.notify_all(); }
+    uint64_t bytes_in() const { return bytes_in_; }
+
+ private:
+    void run() {
+        for (;;) {
+            int idx;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return !free_.empty() || stop_; });
+                if (stop_) break;
+                idx = free_.front(); free_.pop_front();
+            }
+            size_t have = 0; bool eof = false; IngestError e;
+            while (have < dev_->block) {
+                const long n = src_.read(dev_->h_buf[idx] + have, dev_->block - have, e);
+                if (n < 0) { std::lock_guard<std::mutex> g(m_); err_ = e; done_ = true; cv_.notify_all(); return; }
+                if (n == 0) { eof = true; break; }
+                have += (size_t)n; bytes_in_ += (uint64_t)n;
+            }
+            { std::lock_guard<std::mutex> g(m_); Item it; it.idx = idx; it.len = have; it.eof = eof; q_.push_back(it); }
+            cv_.notify_all();
+            if (eof) break;
+        }
+        { std::lock_guard<std::mutex> g(m_); done_ = true; }
+        cv_.notify_all();
+    }
+    FqDev *dev_;
+    ByteSource src_;
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Item> q_;
+    std::deque<int> free_;
+    bool done_ = false, stop_ = false;
+    IngestError err_;
+    std::atomic<uint64_t> bytes_in_{0};
+};
+
+// hulk_sketch_files over the device parser.  `host_took_over` tells the statistics that the host parser finished the stream.
+int run_ingest_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, const IngestCfg &cfg, PhaseTrace &g_trace,
+                      hulk_ingest_stats *stats, IngestError &err) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n_paths && !paths) { err.set(HULK_ERR_ARG, "NULL path list"); return err.code; }
+    // (the line index holds (porch + block) / 8 lines in 8 K workgroups of 1 K: blocks of up to 32 MiB)
+    const size_t block = std::min<size_t>(cfg.block, (size_t)32u << 20);
+    FqDev *D = fq_dev_for(ctx, block, err);
+    if (!D) return err.code;
+    struct Lease { FqDev *d; ~Lease() { hipStreamSynchronize(d->cs); hipStreamSynchronize(d->ps); fq_dev_release(d); } } lease{D};
+    (void)lease;                                                 // (declared before the reader: released after its thread has ended)
+#define DEV_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err.set(HULK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); return err.code; } } while (0)
+    DEV_HIP(hipSetDevice(D->device));
+    // (busy0 / busy1 of the output sets survive between runs: the binning kernels of the run before — this context's or
+    //  another's — may still be reading a set when this run's first parse is queued; its events say when they are done)
+    GpuSink sink(ctx, g_trace);                                  // the host parser's way into the context, should it take over
+    uint32_t threads = cfg.parser_threads;
+    if (threads == 0) { threads = std::thread::hardware_concurrency(); if (threads == 0) threads = 1; if (threads > 16) threads = 16; }
+    Parser hp(sink, threads, err);
+    const uint64_t min_len = hulk::ctx_min_read_len(ctx);
+    uint64_t n_lines = 0, dev_seqs = 0, dev_len = 0;
+    bool on_host = false, ok = true;
+    std::vector<uint8_t> carry;                                  // host take-over: bytes behind the last '\n' handed to the parser
+    std::deque<RawReader::Item> held;                            // blocks whose reads have not been handed over yet (oldest first)
+    uint64_t first_held = 0;                                     // number of the block held.front()
+    uint32_t last_tail_lines = 0;
+    {
+        RawReader reader(paths, n_paths, cfg, D);
+        // the host parser over one raw block (cut anywhere): everything up to the last '\n', the rest is carried
+        auto host_feed = [&](const uint8_t *p, size_t len, bool eof) -> bool {
+            carry.insert(carry.end(), p, p + len);
+            size_t cut = carry.size();
+            while (cut > 0 && carry[cut - 1] != '\n') cut--;
+            const bool too_long = !eof && carry.size() - cut >= MAX_TOKEN;
+            bool r = true;
+            if (cut || too_long) r = hp.fastq_bytes(carry.data(), cut, too_long);
+            carry.erase(carry.begin(), carry.begin() + cut);
+            return r;
+        };
+        // the reads of block x (parsed on the device) -> the context; false: failure (err) — or the host takes over (on_host)
+        auto consume = [&](uint64_t x) -> bool {
+            const int st = (int)(x % FqDev::NST), o = (int)(x % FqDev::NOUT);
+            const double tw0 = PhaseTrace::now();
+            if (hipEventSynchronize(D->ev_parsed[st]) != hipSuccess) return err.set(HULK_ERR_HIP, "hipEventSynchronize (device FASTQ parser)");
+            g_trace.stage_wait += PhaseTrace::now() - tw0;
+            const hulk::FqState S = D->h_state[st];
+            if (S.need_host) {
+                // the stream goes to the host parser from the last record boundary: the previous block's tail (still in its raw
+                // buffer on the device), then this block's bytes and everything behind it, out of the pinned buffers
+                on_host = true;
+                if (hipStreamSynchronize(D->ps) != hipSuccess) return err.set(HULK_ERR_HIP, "hipStreamSynchronize (device FASTQ parser)");
+                carry.clear();
+                if (x > 0) {
+                    const hulk::FqState Pv = D->h_state[(x - 1) % FqDev::NST];
+                    carry.resize(Pv.tail_len);
+                    if (Pv.tail_len && hipMemcpy(carry.data(), D->d_raw[(x - 1) % FqDev::NRAW] + Pv.tail_start, Pv.tail_len, hipMemcpyDeviceToHost) != hipSuccess)
+                        return err.set(HULK_ERR_HIP, "hipMemcpy (tail of the device FASTQ parser)");
+                }
+                return true;
+            }
+            const uint64_t n = S.n_seq - S.pending;
+            n_lines += S.n_lines - S.tail_lines; last_tail_lines = S.tail_lines;
+            if (n == 0) return true;
+            // NewMinimizerSketch's checks (minimizer.go:70-76), as hulk_add_reads makes them
+            if (S.min_len < 1) return err.set(HULK_ERR_EMPTY_SEQ, hulk_strerror(HULK_ERR_EMPTY_SEQ));
+            if (S.min_len < min_len) return err.set(HULK_ERR_SHORT_SEQ, hulk_strerror(HULK_ERR_SHORT_SEQ));
+            const double tc1 = PhaseTrace::now();
+            int rc = hulk::ctx_wait_event(ctx, D->ev_parsed[st]);
+            if (rc == HULK_OK) rc = hulk_add_reads_device(ctx, D->d_bases[o], D->d_off[o], n, S.max_len, D->B.bytes_cap + 64);
+            if (rc == HULK_OK) rc = hulk::ctx_record_busy(ctx, D->ev_busy[o][0], D->ev_busy[o][1], &D->busy1[o]);
+            g_trace.add_reads += PhaseTrace::now() - tc1;
+            if (rc != HULK_OK) return err.set(rc, hulk_last_error(ctx));
+            D->busy0[o] = true;
+            dev_seqs += n; dev_len += S.seq_bytes - S.pending_len;
+            return true;
+        };
+        uint64_t b = 0;
+        for (;;) {
+            RawReader::Item it;
+            const double tb0 = PhaseTrace::now();
+            const bool got = reader.next(it, err);
+            const double tb1 = PhaseTrace::now(); g_trace.wait_block += tb1 - tb0;
+            if (!got) { ok = err.code == HULK_OK; break; }
+            if (on_host) {
+                ok = host_feed(D->h_buf[it.idx], it.len, it.eof);
+                g_trace.parse += PhaseTrace::now() - tb1;
+                reader.recycle(it.idx);
+                if (!ok || it.eof) break;
+                continue;
+            }
+            if (it.len == 0) { reader.recycle(it.idx); break; }     // (end of the stream right on a block border)
+            const int r = (int)(b % FqDev::NRAW), o = (int)(b % FqDev::NOUT), st = (int)(b % FqDev::NST);
+            // raw slot r held block b-3 and served block b-2 as the source of its tail
+            if (b >= 3) DEV_HIP(hipStreamWaitEvent(D->cs, D->ev_parsed[(b - 2) % FqDev::NST], 0));
+            DEV_HIP(hipMemcpyAsync(D->d_raw[r] + D->porch, D->h_buf[it.idx], it.len, hipMemcpyHostToDevice, D->cs));
+            DEV_HIP(hipEventRecord(D->ev_copied[it.idx], D->cs));
+            DEV_HIP(hipStreamWaitEvent(D->ps, D->ev_copied[it.idx], 0));
+            if (D->busy0[o]) { DEV_HIP(hipStreamWaitEvent(D->ps, D->ev_busy[o][0], 0)); D->busy0[o] = false; }
+            if (D->busy1[o]) { DEV_HIP(hipStreamWaitEvent(D->ps, D->ev_busy[o][1], 0)); D->busy1[o] = false; }
+            DEV_HIP(hulk::launch_fq_parse(D->ps, D->B, b ? D->d_raw[(b - 1) % FqDev::NRAW] : nullptr, b ? D->d_state + (b - 1) % FqDev::NST : nullptr,
+                                          D->d_raw[r], D->d_state + st, (uint32_t)it.len, D->d_off[o], D->d_bases[o]));
+            DEV_HIP(hipMemcpyAsync(D->h_state + st, D->d_state + st, sizeof(hulk::FqState), hipMemcpyDeviceToHost, D->ps));
+            DEV_HIP(hipEventRecord(D->ev_parsed[st], D->ps));
+            g_trace.enqueue += PhaseTrace::now() - tb1;
+            held.push_back(it);
+            if (held.size() > 1) {                                  // block b-1, while block b is copied and parsed
+                if (!consume(first_held)) { ok = false; break; }
+                if (on_host) break;
+                reader.recycle(held.front().idx); held.pop_front(); first_held++;
+            }
+            b++;
+            if (it.eof) break;
+        }
+        if (ok && !on_host && !held.empty()) {
+            if (!consume(first_held)) ok = false;
+            else if (!on_host) { reader.recycle(held.front().idx); held.pop_front(); first_held++; }
+        }
+        if (ok && on_host) {
+            // the blocks the device had been given but whose reads were not handed over, in order, then the rest of the stream
+            bool eof = false;
+            while (ok && !held.empty()) {
+                const RawReader::Item it = held.front(); held.pop_front();
+                ok = host_feed(D->h_buf[it.idx], it.len, it.eof); eof = it.eof;
+                reader.recycle(it.idx);
+            }
+            while (ok && !eof) {
+                RawReader::Item it;
+                if (!reader.next(it, err)) { ok = err.code == HULK_OK; break; }
+                ok = host_feed(D->h_buf[it.idx], it.len, it.eof); eof = it.eof;
+                reader.recycle(it.idx);
+            }
+        }
+        if (ok && !on_host) n_lines += last_tail_lines;           // a record in progress at the end of the stream is dropped, its lines were read
+        if (ok) ok = sink.finish(err);
+        // nothing of this run may still read the pinned blocks or write the output sets when the next run starts
+        hipStreamSynchronize(D->cs); hipStreamSynchronize(D->ps);
+        if (stats) {
+            stats->n_seqs = sink.n_seqs + dev_seqs; stats->total_len = sink.total_len + dev_len; stats->n_lines = n_lines + hp.n_lines;
+            stats->bytes_in = reader.bytes_in();
+            stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+    }
+#undef DEV_HIP
+    if (cfg.trace)
+        fprintf(stderr, "ingest trace (device FASTQ parser%s; calling thread, s): next block %.3f | copies + parse kernels queued %.3f, "
+                        "waiting for a block's scalars %.3f, hulk_add_reads_device %.3f, host parser %.3f\n", on_host ? ", host parser took over" : "",
+                g_trace.wait_block, g_trace.enqueue, g_trace.stage_wait, g_trace.add_reads, g_trace.parse);
+    return ok ? HULK_OK : err.code;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1526,8 +1866,8 @@ int hulk_parse_files_opts(const char *const *paths, uint32_t n_paths, int fasta,
                           void *user, hulk_ingest_stats *stats, char *errbuf, uint64_t errbuf_len) {
     IngestError err;
     int rc;
-    if (opts && (opts->flags & ~(HULK_INGEST_GZ_ONE_THREAD | HULK_INGEST_GZ_ZLIB | HULK_INGEST_TRACE))) {
-        err.set(HULK_ERR_ARG, "hulk_ingest_opts: unknown flags"); rc = err.code;
+    if (const std::string bad = check_opts(opts); !bad.empty()) {
+        err.set(HULK_ERR_ARG, bad); rc = err.code;
     } else {
         CallbackSink sink(fn, user);
         PhaseTrace trace;
@@ -1551,14 +1891,17 @@ int hulk_parse_files(const char *const *paths, uint32_t n_paths, int fasta, uint
 int hulk_sketch_files_opts(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, int fasta, const hulk_ingest_opts *opts,
                            hulk_ingest_stats *stats) {
     if (!ctx) return HULK_ERR_ARG;
-    if (opts && (opts->flags & ~(HULK_INGEST_GZ_ONE_THREAD | HULK_INGEST_GZ_ZLIB | HULK_INGEST_TRACE)))
-        return hulk::ctx_fail(ctx, HULK_ERR_ARG, "hulk_ingest_opts: unknown flags");
+    if (const std::string bad = check_opts(opts); !bad.empty()) return hulk::ctx_fail(ctx, HULK_ERR_ARG, bad.c_str());
     IngestError err;
     int rc;
     {
         PhaseTrace trace;
-        GpuSink sink(ctx, trace);
-        rc = run_ingest(paths, n_paths, fasta, resolve_cfg(opts, 0), sink, trace, stats, err);
+        const IngestCfg cfg = resolve_cfg(opts, 0);
+        if (!fasta && !cfg.host_parser) rc = run_ingest_device(ctx, paths, n_paths, cfg, trace, stats, err);
+        else {
+            GpuSink sink(ctx, trace);
+            rc = run_ingest(paths, n_paths, fasta, cfg, sink, trace, stats, err);
+        }
     }
     if (rc != HULK_OK) return hulk::ctx_fail(ctx, rc, err.msg.c_str());
     return HULK_OK;

@@ -2,6 +2,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+// Experiment switches (HULK_JUMP_*, HULK_NIB_*, HULK_NO_FMIN, HULK_K1_DEBUG, HULK_POISON, the HULK_NO_* / HULK_BATCH overrides
+// of hulk_params fields ... docs/EXPERIMENTS.md) exist only in the profiling build, `make EXPERIMENTS=1` ->
+// libhulkhip_exp.so (tools/ select it with HULK_LIB).  The shipping library reads the environment in two places only:
+// HULK_RCCL_LIB (which RCCL to bind) and the ingest overrides of hulk_ingest_opts (hulk_ingest.hip, once per run).
+#ifdef HULK_EXPERIMENTS
+#define HULK_EXP_ENV(name) getenv(name)
+#else
+#define HULK_EXP_ENV(name) ((const char *)nullptr)
+#endif
 
 namespace hulk {
 
@@ -181,5 +192,12 @@ int ctx_fail(hulk_ctx *c, int code, const char *full_message);
 struct StageSet { uint8_t *h_bases, *d_bases; uint64_t *h_off, *d_off; size_t cap_bases; };
 int ctx_stage_acquire(hulk_ctx *c, size_t nbytes, uint64_t n, StageSet *out);
 int ctx_stage_release(hulk_ctx *c);
+// for the device FASTQ parser of hulk_sketch_files (hulk_ingest.hip / hulk_fastq.hip)
+int ctx_device(const hulk_ctx *c);
+// the context's stream waits for `e` (a parse that filled device buffers the next hulk_add_reads_device reads)
+int ctx_wait_event(hulk_ctx *c, hipEvent_t e);
+// record e0 on the context's stream and, if there is a second work lane, e1 on it: both passed = the kernels queued so far
+// have read their inputs.  *has1 says whether e1 was recorded.
+int ctx_record_busy(hulk_ctx *c, hipEvent_t e0, hipEvent_t e1, bool *has1);
 
 }  // namespace hulk

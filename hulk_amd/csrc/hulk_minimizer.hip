@@ -1075,7 +1075,7 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
     const uint64_t blocks = (n_reads + 4 * FAST_READS_PER_WAVE - 1) / (4 * FAST_READS_PER_WAVE);
     const dim3 g((unsigned)blocks), b(256);
     // k <= 27: 64-bit minima through v_min_f64 (see umin64); HULK_NO_FMIN keeps the integer compares (A/B aid)
-    static const bool no_fmin = getenv("HULK_NO_FMIN") != nullptr;
+    static const bool no_fmin = HULK_EXP_ENV("HULK_NO_FMIN") != nullptr;
     const bool fm = P.k <= 27 && !no_fmin;
 #define HULK_LAUNCH_FAST3(WM, FMv, DBGv, WEQv, KCv, PAIRv)                                                           \
     hipLaunchKernelGGL((k_minimizer_fast<WM, FMv, DBGv, WEQv, KCv, PAIRv>), g, b, lds, s, d_bases, d_offsets, n_reads, \
@@ -1107,7 +1107,7 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
 // from w = 5 up (1024 + pad instead of 2304 entries at w = 9): the lists of a batch shrink from 3.4 to 1.6 GB per lane, of
 // which the reads of C2 fill 40 % instead of 19 %.  The pad keeps the region stride off a power of two.
 uint32_t minimizer_list_rcap(uint32_t w, bool pair) {
-    static const uint32_t pad = [] { const char *e = getenv("HULK_RCAP_PAD"); return e ? (uint32_t)atol(e) : 64u; }();
+    static const uint32_t pad = [] { const char *e = HULK_EXP_ENV("HULK_RCAP_PAD"); return e ? (uint32_t)atol(e) : 64u; }();
     const uint32_t by_pos = FAST_READS_PER_WAVE * (pair ? 2u * 16u * w - (w - 1u) : 16u * w);
     const uint32_t by_cand = FAST_READS_PER_WAVE * (uint32_t)FAST_CAND * (pair ? 2u : 1u);
     return by_pos < by_cand + pad ? by_pos : by_cand + pad;

@@ -473,11 +473,11 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     // k_jump_bin needs no LDS; a dummy allocation caps its occupancy so that the flush kernels of the
     // previous batch (other stream) find free wave slots next to it
     static int jump_lds = -1;
-    if (jump_lds < 0) { const char *e = getenv("HULK_JUMP_LDS"); jump_lds = e ? atoi(e) : 0; }
+    if (jump_lds < 0) { const char *e = HULK_EXP_ENV("HULK_JUMP_LDS"); jump_lds = e ? atoi(e) : 0; }
     static int jump_c = -1;
-    if (jump_c < 0) { const char *ec = getenv("HULK_JUMP_C"); jump_c = ec ? atoi(ec) : 0; }
+    if (jump_c < 0) { const char *ec = HULK_EXP_ENV("HULK_JUMP_C"); jump_c = ec ? atoi(ec) : 0; }
     static int jump_cut = -1;
-    if (jump_cut < 0) { const char *ec = getenv("HULK_JUMP_CUT"); jump_cut = ec ? atoi(ec) : 10; }
+    if (jump_cut < 0) { const char *ec = HULK_EXP_ENV("HULK_JUMP_CUT"); jump_cut = ec ? atoi(ec) : 10; }
     const uint32_t cut = (jump_c || !ml.lo) ? 0u : (uint32_t)jump_cut;
     if (jump_begin) { e = hipEventRecord(jump_begin, s); if (e != hipSuccess) return e; }      // bench.py: k_jump_bin alone ...
     hipLaunchKernelGGL(k_jump_bin, dim3((n_regions + 3) / 4), dim3(256), (size_t)jump_lds, s, ml, n_regions, P.num_bins, jump_c, cut);
@@ -491,7 +491,7 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     const int nranges = (P.num_bins + HIST_RANGE - 1) / HIST_RANGE;
     static int parts_target = -1;
     // workgroups per launch (swept 256..768: 110-123 us for histogram + merge, flat)
-    if (parts_target < 0) { const char *ep = getenv("HULK_HIST_BLOCKS"); parts_target = ep ? atoi(ep) : 512; }
+    if (parts_target < 0) { const char *ep = HULK_EXP_ENV("HULK_HIST_BLOCKS"); parts_target = ep ? atoi(ep) : 512; }
     uint32_t n_parts = (uint32_t)parts_target / (uint32_t)(nranges * n_spectra);
     if (n_parts < 1) n_parts = 1;
     if (n_parts > ml.max_parts) n_parts = ml.max_parts;
@@ -503,7 +503,7 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
         attr_set = true;
     }
     static int use_nib = -1;
-    if (use_nib < 0) use_nib = getenv("HULK_NO_NIBBLE") ? 0 : 1;
+    if (use_nib < 0) use_nib = HULK_EXP_ENV("HULK_NO_NIBBLE") ? 0 : 1;
     if (use_nib && ml.nib && ml.nib_over) {
         // ~131 k keys per part (16 parts per 100k-read interval, swept 49k..197k): a 4-bit counter then overflows only on
         // grossly repetitive input, which the exact kernels below pick up
@@ -512,8 +512,8 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
         // work lanes the OTHER lane's are always there: rocprofv3 showed this kernel at 216 us per launch beside them against
         // 41 us alone, waiting for CUs (profiles/r04_kernel_stats.md).  Ranges of 2^16 bins (32 KB) in workgroups of 256 threads
         // slip in beside three of those; the keys are then read once per range (through the XCD's L2, see the kernel).
-        static const int rlog = [] { const char *e = getenv("HULK_NIB_RLOG"); const int v = e ? atoi(e) : HULK_NIB_RLOG_DEFAULT; return v < 13 ? 13 : v > 18 ? 18 : v; }();
-        static const int nib_block = [] { const char *e = getenv("HULK_NIB_BLOCK"); const int v = e ? atoi(e) : HULK_NIB_BLOCK_DEFAULT; return v == 256 || v == 512 ? v : 1024; }();
+        static const int rlog = [] { const char *e = HULK_EXP_ENV("HULK_NIB_RLOG"); const int v = e ? atoi(e) : HULK_NIB_RLOG_DEFAULT; return v < 13 ? 13 : v > 18 ? 18 : v; }();
+        static const int nib_block = [] { const char *e = HULK_EXP_ENV("HULK_NIB_BLOCK"); const int v = e ? atoi(e) : HULK_NIB_BLOCK_DEFAULT; return v == 256 || v == 512 ? v : 1024; }();
         const int32_t NIB_BINS = 1 << rlog, NIB_WORDS = NIB_BINS >> 3;
         const int nr = (P.num_bins + NIB_BINS - 1) / NIB_BINS;
         const int nr18 = (P.num_bins + NIB_BINS_MAX - 1) / NIB_BINS_MAX;
@@ -521,13 +521,13 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
         // (per bin RANGE: with nr ranges a part's keys spread over nr workgroups, so a part is nr times as long — the mean
         //  count per 4-bit counter stays ~0.5, and k = 31 (4 ranges) builds 256 parts per batch instead of 1024: +3 %)
         static int keys_env = -1;
-        if (keys_env < 0) { const char *ek = getenv("HULK_NIB_KEYS"); keys_env = ek ? atoi(ek) : 0; }
+        if (keys_env < 0) { const char *ek = HULK_EXP_ENV("HULK_NIB_KEYS"); keys_env = ek ? atoi(ek) : 0; }
         const uint64_t keys_per_part = keys_env > 0 ? (uint64_t)keys_env : 131072ull * (uint64_t)nr18;   // (mean count per counter ~0.6 whatever the range size)
         uint32_t np = (uint32_t)((rps * 20 + keys_per_part - 1) / keys_per_part);
         if (np < 1) np = 1;
         // short intervals (a rank's slice of a strong-scaling run): still ~128 workgroups, one per CU would leave half the chip idle
         static int min_blocks = -1;
-        if (min_blocks < 0) { const char *em = getenv("HULK_NIB_MIN_BLOCKS"); min_blocks = em ? atoi(em) : 128; }
+        if (min_blocks < 0) { const char *em = HULK_EXP_ENV("HULK_NIB_MIN_BLOCKS"); min_blocks = em ? atoi(em) : 128; }
         if (rps >= 4096 && (uint64_t)np * n_spectra * nr < (uint64_t)min_blocks) np = (uint32_t)(((uint64_t)min_blocks + (uint64_t)n_spectra * nr - 1) / ((uint64_t)n_spectra * nr));
         if (np > ml.nib_parts) np = ml.nib_parts;
         while (np > 1 && (uint64_t)np * n_spectra * nr > 8192) np--;

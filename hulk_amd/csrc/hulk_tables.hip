@@ -28,7 +28,7 @@ int32_t jump_host(uint64_t key, int64_t n) {
 // position g = jump(bin*(d+1), width) (countmin.go:122-125), ascending bin inside a group.
 int build_chains(hulk_ctx *c) {
     const int D = c->cms_depth, W = c->cms_width; const int32_t B = c->B;
-    if (!getenv("HULK_CHAINS_HOST")) {          // (the host loop below is kept as the A/B check of k_build_chains)
+    if (!HULK_EXP_ENV("HULK_CHAINS_HOST")) {          // (the host loop below is kept as the A/B check of k_build_chains)
         HIPCHK(c, dalloc(&c->d_meta8, (size_t)D * B));
         HIPCHK(c, dalloc(&c->d_pos16, (size_t)D * B));
         HIPCHK(c, launch_build_chains(c->stream, c->d_pos16, c->d_meta8, B, D, W));
@@ -202,7 +202,7 @@ int generate_tables_device(hulk_ctx *c) {
         GEN_CHK(hipMemsetAsync(d_tot, 0, 16, c->stream));
         GEN_CHK(hipStreamSynchronize(c->stream));                              // w0 is a stack buffer
     }
-    static const bool one_level = getenv("HULK_ALFG_ONE_LEVEL") != nullptr;      // A/B aid: the single walk over all chunks
+    static const bool one_level = HULK_EXP_ENV("HULK_ALFG_ONE_LEVEL") != nullptr;      // A/B aid: the single walk over all chunks
     GEN_CHK(launch_alfg(c->stream, d_coef, one_level ? nullptr : d_coef + 607, 1u << (GO_RNG_JUMP_FAR_LOG2 - GO_RNG_JUMP_LOG2),
                         d_win, d_raw, 0, (uint32_t)n_chunks, C));
     GEN_CHK(launch_rng_candidates(c->stream, d_raw, total_raw, d_list, LIST_CAP, d_cnt));
@@ -260,7 +260,7 @@ int generate_tables_device(hulk_ctx *c) {
 }
 
 int generate_tables(hulk_ctx *c) {
-    static const bool host_only = getenv("HULK_CWS_HOST") != nullptr;
+    static const bool host_only = HULK_EXP_ENV("HULK_CWS_HOST") != nullptr;
     if (!host_only) {
         const int rc = generate_tables_device(c);
         if (rc <= 0) return rc;                                                // done, or a real error

@@ -86,11 +86,13 @@ def find_sketch(data, ksize, algo, path):
 
 
 def smash(sketch_dir, out_file, ksize=21, algo="histosketch", metric="jaccard", recursive=False, device=0,
-          banner_matrix=False):
+          banner_matrix=False, stages=None):
     """runSmash + makeMatrix: writes <out_file>.hulk-matrix.csv and returns (ordering, distances).
     banner_matrix: also <out_file>.banner-matrix.csv (makeBannerMatrix, cmd/smash.go:229-261): one line
     per sketch = its mins + the banner label; the reference iterates a Go map (random order), here the
-    sorted file order is used."""
+    sorted file order is used.  stages: a dict that receives the seconds of "load" (JSON + MD5 check), "matrix", "csv"."""
+    import time
+    t_start = time.perf_counter()
     if metric not in AVAIL_METRICS:
         raise HulkError(-30, f"supplied distance metric is not available: {metric}\nplease select one of the following: {AVAIL_METRICS}")
     if algo not in AVAIL_ALGORITHMS:
@@ -117,7 +119,9 @@ def smash(sketch_dir, out_file, ksize=21, algo="histosketch", metric="jaccard", 
         raise HulkError(-30, "weighted jaccard is only supported for histosketches")
     else:
         weights = np.zeros(mins.shape)                          # MinHash signatures carry no weights (khf.go:12-16)
+    t_loaded = time.perf_counter()
     dist = distance_matrix(mins, weights, metric, device)
+    t_matrix = time.perf_counter()
     od = os.path.dirname(out_file)
     if od and od != "." and not os.path.exists(od):
         os.makedirs(od, mode=0o700)
@@ -129,4 +133,6 @@ def smash(sketch_dir, out_file, ksize=21, algo="histosketch", metric="jaccard", 
         with open(out_file + ".banner-matrix.csv", "w", encoding="utf-8", newline="") as fh:
             for f, a in zip(ordering, sk):
                 fh.write(",".join([str(int(v)) for v in a.mins] + [go_csv_field(loaded[f].banner_label)]) + "\n")
+    if stages is not None:
+        stages.update(load=t_loaded - t_start, matrix=t_matrix - t_loaded, csv=time.perf_counter() - t_matrix)
     return ordering, dist

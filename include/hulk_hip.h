@@ -200,6 +200,10 @@ int hulk_parse_files(const char *const *paths, uint32_t n_paths, int fasta, uint
 #define HULK_INGEST_GZ_ONE_THREAD 1u  /* every gzip input through the one-thread reader (no parallel member / BGZF readers) */
 #define HULK_INGEST_GZ_ZLIB 2u        /* zlib's inflate instead of the library's own decoder */
 #define HULK_INGEST_TRACE 4u          /* seconds per phase of the calling thread and of the gzip readers, on stderr */
+#define HULK_INGEST_HOST_PARSER 8u    /* hulk_sketch_files*: FASTQ lines -> reads on the host's parser threads.  Default: the raw file
+                                       * bytes go to the GPU as they are read and the line machine runs there (hulk_fastq.hip); a block
+                                       * the device will not decide — a header without '@', a line of 64 KiB, an over-long run of empty
+                                       * lines — hands the stream to the host parser, whose reads and messages are the same */
 typedef struct hulk_ingest_opts {
     uint32_t parser_threads;  /* 0 = one per hardware thread, at most 16 (the measured optimum); any other figure is taken as it is (<= 256) */
     uint32_t gz_threads;      /* threads inflating the members of a bgzip'd input, or the chunks of ONE gzip member, side by side: 1..64, 0 = 16 */

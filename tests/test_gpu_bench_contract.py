@@ -46,8 +46,10 @@ def test_bench_json_contract_and_collective_path():
     assert c3["negative_weights"] == 1024 and c3["kernels_alone"]["k_cmsd_freq_us"] > 0 and c3["kernels_alone"]["k_minimizer_fast_us"] > 0
     c5 = a["c5"]
     for metric in ("weightedjaccard", "jaccard"):
-        assert c5[metric]["ms_kernel"] < c5[metric]["ms_end_to_end"] and 0.0 < c5[metric]["lds_pipe_frac"] < 1.0
+        assert c5[metric]["ms_kernel"] < c5[metric]["ms_end_to_end"] and 0.0 < c5[metric]["valu_frac"] < 1.0
     assert c5["pairs"] == 1024 * 1024
+    # ... and the command as the reference runs it: 1024 sketch files in, MD5-verified, the same matrix out
+    assert c5["directory"]["files"] == 1024 and c5["directory"]["same_matrix_as_arrays"] and c5["directory"]["seconds_load_and_md5"] > 0
     assert a["n_gpus"] == 1 and a["steps"] == 3 and a["warmup"] == 2 and a["vs_baseline"] is None
     assert a["unit"] == "reads/s" and a["higher_is_better"] is True and a["scaling"] == "weak"
     assert "workload" in a["config"] and "model" not in a["config"]
@@ -73,6 +75,9 @@ def test_bench_json_contract_and_collective_path():
         assert len(e2e[c]["seconds_all_runs"]) == 4 and min(e2e[c]["seconds_all_runs"]) == e2e[c]["seconds"]
         assert e2e[c]["parse_only_reads_per_s"] > 1e5
     assert e2e["gz"]["value"] < 1.5 * e2e["plain"]["value"] and e2e["bgzf"]["value"] < 1.5 * e2e["plain"]["value"]
+    # 8 M reads with the line machine on the device and on the host's parser threads: same sketch
+    assert e2e["plain_8m"]["reads"] == 8_000_000 and e2e["plain_8m"]["sketch_md5"] == e2e["plain_8m_host_parser"]["sketch_md5"]
+    assert e2e["plain_8m"]["value"] > 1e6 and e2e["plain_8m_host_parser"]["value"] > 1e6
     # the sharded step at world size 1: RCCL communicator, exchange inside the library, same sketch
     b = _run(["--no-cpu-baseline", "--no-cold", "--force-collective"], {"HULK_BENCH_C4_READS_PER_RANK": "5000000"})
     assert b["sketch_md5"] == a["sketch_md5"]

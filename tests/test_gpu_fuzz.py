@@ -31,3 +31,14 @@ def test_fuzz_slice_of_the_multi_rank_protocol(full):
                        capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "0 mismatches" in p.stdout
+
+
+def test_fuzz_slice_of_the_device_fastq_parser():
+    """tools/fuzz_devparse.py: hulk_sketch_files with the line machine on the GPU (hulk_fastq.hip) and, beside it, on the host
+    (HULK_INGEST_HOST_PARSER), against oracle/linepump.py: line soups with empty lines, CR/LF, stray headers, 64 KiB lines,
+    several inputs, gzip, blocks of 128 KiB..1 MiB so that records straddle the borders — reads, total length, line count and
+    the k-mer spectrum of everything binned, or the reference's error text."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_devparse.py"), "60", "3"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "0 mismatches" in p.stdout

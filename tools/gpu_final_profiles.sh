@@ -1,4 +1,5 @@
 # Evidence for profiles/ of the current state (round label R, default r04): kernel stats (two streams; every kernel
+export HULK_LIB=${HULK_LIB:-exp}    # the profiling build: HULK_NO_OVERLAP and the other experiment switches exist only there (make EXPERIMENTS=1)
 # alone; every kernel alone with the CWS bounds really off), PMC json, bench line.   gpurun -- 'bash tools/gpu_final_profiles.sh'
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 R=${R:-r04}

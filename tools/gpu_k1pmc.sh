@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+export HULK_LIB=${HULK_LIB:-exp}    # the profiling build: HULK_NO_OVERLAP and the other experiment switches exist only there (make EXPERIMENTS=1)
 for d in 64 32 24 8 0; do
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"; do
 OUT=/tmp/k1p; rm -rf $OUT

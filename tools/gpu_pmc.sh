@@ -1,4 +1,5 @@
 # PMC passes for the bench (separate runs, --kernel-trace only — never combined with other trace domains):
+export HULK_LIB=${HULK_LIB:-exp}    # the profiling build: HULK_NO_OVERLAP and the other experiment switches exist only there (make EXPERIMENTS=1)
 # HBM traffic, VALU activity, LDS activity / bank conflicts, L2 hits.  Results -> gpurun_out/pmc/<pass>/
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc; rm -rf $OUT; mkdir -p $OUT

@@ -1,4 +1,5 @@
 # C3-shaped configuration (k=31, sketchSize=1024, decay 0.02): rate with the two streams, then rocprofv3 kernel stats with every kernel alone
+export HULK_LIB=${HULK_LIB:-exp}    # the profiling build: HULK_NO_OVERLAP and the other experiment switches exist only there (make EXPERIMENTS=1)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/c3; mkdir -p $O
 python tools/run_config.py --k 31 --S 1024 --decay 0.02 --reads 16000000 --interval 100000 --batch 16 > $O/rate.json 2> $O/rate.err; cat $O/rate.json

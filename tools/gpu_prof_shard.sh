@@ -1,4 +1,5 @@
 # one rank's share of an 8-rank strong-scaling step (tools/shard_projection.py), each kernel alone: rocprofv3 kernel stats
+export HULK_LIB=${HULK_LIB:-exp}    # the profiling build: HULK_NO_OVERLAP and the other experiment switches exist only there (make EXPERIMENTS=1)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/shard; mkdir -p $O
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_shard; rm -rf $OUT; mkdir -p $OUT

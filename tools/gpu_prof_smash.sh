@@ -1,4 +1,5 @@
 # BASELINE C5 (hulk smash: 1024 sketches x sketchSize 2048): rocprofv3 kernel stats of tools/smash_c5.py -> gpurun_out/smash/
+export HULK_LIB=${HULK_LIB:-exp}    # the profiling build: HULK_NO_OVERLAP and the other experiment switches exist only there (make EXPERIMENTS=1)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/smash; rm -rf $O; mkdir -p $O
 cd /tmp && rocprofv3 --kernel-trace --stats -d $O/prof -o b -- python $GRAFT_REPO_ROOT/tools/smash_c5.py > $O/out.txt 2> $O/err.txt

@@ -22,5 +22,5 @@ if len(sys.argv) > 1:
           f"k_minimizer_fast alone {ms/max(nl,1)*1000/(n/100000):8.1f} us per 100k reads (n={n})")
 else:
     for d in (0, 128, 128 + 1, 128 + 4, 128 + 5, 128 + 8, 128 + 16, 128 + 32, 128 + 64):
-        env = dict(os.environ, HULK_K1_DEBUG=str(d))
+        env = dict(os.environ, HULK_K1_DEBUG=str(d), HULK_LIB="exp")   # (the switch exists in the profiling build only)
         subprocess.run([sys.executable, __file__, "child"], env=env)
