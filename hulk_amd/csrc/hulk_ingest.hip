@@ -58,6 +58,7 @@ struct IngestCfg {
     bool zlib = false;                        // zlib's inflate instead of fast_inflate.h
     bool trace = false;                       // per-phase seconds on stderr
     bool host_parser = false;                 // FASTQ lines -> reads on the host's parser threads instead of the device
+    bool block_set = false, readers_set = false;   // the caller (or the environment) chose; else the device path takes its own defaults
 };
 static IngestCfg resolve_cfg(const hulk_ingest_opts *o, uint32_t threads) {
     IngestCfg c;
@@ -65,9 +66,9 @@ static IngestCfg resolve_cfg(const hulk_ingest_opts *o, uint32_t threads) {
     if (o) {
         if (o->parser_threads) c.parser_threads = o->parser_threads;
         if (o->gz_threads) c.gz_threads = o->gz_threads;
-        if (o->block_bytes) c.block = (size_t)o->block_bytes;
+        if (o->block_bytes) { c.block = (size_t)o->block_bytes; c.block_set = true; }
         if (o->gz_chunk_bytes) c.gz_chunk = (size_t)o->gz_chunk_bytes;
-        if (o->file_readers) c.readers = o->file_readers;
+        if (o->file_readers) { c.readers = o->file_readers; c.readers_set = true; }
         if (o->flags & HULK_INGEST_GZ_ONE_THREAD) c.gz_par = false;
         if (o->flags & HULK_INGEST_GZ_ZLIB) c.zlib = true;
         if (o->flags & HULK_INGEST_TRACE) c.trace = true;
@@ -77,11 +78,11 @@ static IngestCfg resolve_cfg(const hulk_ingest_opts *o, uint32_t threads) {
         const long hw = (long)std::thread::hardware_concurrency();
         if (hw > 0 && (long)c.gz_threads > hw) c.gz_threads = (unsigned)hw;
     }
-    if (const char *e = getenv("HULK_INGEST_BLOCK")) c.block = (size_t)strtoull(e, nullptr, 10);
+    if (const char *e = getenv("HULK_INGEST_BLOCK")) { c.block = (size_t)strtoull(e, nullptr, 10); c.block_set = true; }
     if (const char *e = getenv("HULK_GZ_THREADS")) c.gz_threads = (unsigned)std::max(1L, strtol(e, nullptr, 10));
     if (const char *e = getenv("HULK_GZ_PAR")) c.gz_par = !(e[0] == '0');
     if (const char *e = getenv("HULK_GZ_PAR_CHUNK")) c.gz_chunk = (size_t)strtoull(e, nullptr, 10);
-    if (const char *e = getenv("HULK_INGEST_READERS")) c.readers = (unsigned)std::max(1L, strtol(e, nullptr, 10));
+    if (const char *e = getenv("HULK_INGEST_READERS")) { c.readers = (unsigned)std::max(1L, strtol(e, nullptr, 10)); c.readers_set = true; }
     if (getenv("HULK_GZ_ZLIB")) c.zlib = true;
     if (getenv("HULK_INGEST_TRACE")) c.trace = true;
     if (c.block < 2 * MAX_TOKEN) c.block = 2 * MAX_TOKEN;
@@ -1709,11 +1710,17 @@ class RawReader {
 };
 
 // hulk_sketch_files over the device parser.  `host_took_over` tells the statistics that the host parser finished the stream.
-int run_ingest_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, const IngestCfg &cfg, PhaseTrace &g_trace,
+int run_ingest_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, const IngestCfg &cfg_in, PhaseTrace &g_trace,
                       hulk_ingest_stats *stats, IngestError &err) {
     const auto t0 = std::chrono::steady_clock::now();
     if (n_paths && !paths) { err.set(HULK_ERR_ARG, "NULL path list"); return err.code; }
-    // (the line index holds (porch + block) / 8 lines in 8 K workgroups of 1 K: blocks of up to 32 MiB)
+    // The host's whole job is read() into pinned memory and one PCIe copy per block, so its best settings are not the
+    // parser's: 16 MiB blocks read in 16 pieces side by side moved 46 GB/s of a page-cached file (1.5e8 reads/s of 150 bp
+    // FASTQ: the PCIe link), 4 pieces 33; 8 MiB blocks 28 (profiles/r05_devparse.txt).  A caller's figures are taken as they are
+    // (the line index holds (porch + block) / 8 lines in 8 K workgroups of 1 K: blocks of up to 32 MiB).
+    IngestCfg cfg = cfg_in;
+    if (!cfg.block_set) cfg.block = (size_t)16u << 20;
+    if (!cfg.readers_set) { const unsigned hw = std::thread::hardware_concurrency(); cfg.readers = hw ? std::min(16u, hw) : 4u; }
     const size_t block = std::min<size_t>(cfg.block, (size_t)32u << 20);
     FqDev *D = fq_dev_for(ctx, block, err);
     if (!D) return err.code;
