@@ -174,6 +174,8 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     CHK_CREATE(dalloc(&c->d_rext, T * (size_t)c->ntiles * 4 * 2));
     CHK_CREATE(dalloc(&c->d_kminslot, (SL ? SL : 1)));
     CHK_CREATE(dalloc(&c->d_scanmap, ((SL + SCAN_ROWS - 1) / SCAN_ROWS + 1) * (((size_t)c->ntiles * 4 + 63) / 64)));
+    CHK_CREATE(dalloc(&c->d_scanlist, ((SL + SCAN_ROWS - 1) / SCAN_ROWS + 1) * ((size_t)c->ntiles * 4 + 64)));
+    CHK_CREATE(dalloc(&c->d_scanlist_n, 4));
     CHK_CREATE(dalloc(&c->d_slotmin, T * ((SL + SCAN_ROWS - 1) / SCAN_ROWS) * SCAN_ROWS));
     CHK_CREATE(dalloc(&c->d_visited, (size_t)MIN_SLOTS));
     CHK_CREATE(hipMemsetAsync(c->d_visited, 0, (size_t)MIN_SLOTS * 8, c->stream));
@@ -228,7 +230,7 @@ void hulk_destroy(hulk_ctx *c) {
     hipFree(c->d_ctr); hipFree(c->d_pos16); hipFree(c->d_mins); hipFree(c->d_f64); hipFree(c->d_weights);
     hipFree(c->d_blkcnt); hipFree(c->d_eidx); hipFree(c->d_etot); hipFree(c->d_ctrd);
     hipFree(c->d_candA); hipFree(c->d_candB); hipFree(c->d_rcb); hipFree(c->d_rcp32); hipFree(c->d_rmm); hipFree(c->d_k32); hipFree(c->d_tilemin);
-    hipFree(c->d_scanmap); hipFree(c->d_slotmin); hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited); hipFree(c->d_kminslot);
+    hipFree(c->d_scanmap); hipFree(c->d_scanlist); hipFree(c->d_scanlist_n); hipFree(c->d_slotmin); hipFree(c->d_kmin32); hipFree(c->d_rext); hipFree(c->d_visited); hipFree(c->d_kminslot);
     for (auto &hs : c->hstage) {
         if (hs.ev) hipEventDestroy(hs.ev);
         if (hs.ev1) hipEventDestroy(hs.ev1);
@@ -510,11 +512,11 @@ namespace {
 struct SmashBuffers {
     std::mutex mu;
     int device = -1;
-    unsigned long long *d_m = nullptr; double *d_w = nullptr, *d_o = nullptr;
-    size_t cap_ns = 0, cap_nn = 0;
+    unsigned long long *d_m = nullptr; double *d_w = nullptr, *d_o = nullptr, *d_mT = nullptr, *d_wT = nullptr;
+    size_t cap_ns = 0, cap_nn = 0, cap_t = 0;
     hipEvent_t ea = nullptr, eb = nullptr;
     void drop() {
-        hipFree(d_m); hipFree(d_w); hipFree(d_o); d_m = nullptr; d_w = d_o = nullptr; cap_ns = cap_nn = 0;
+        hipFree(d_m); hipFree(d_w); hipFree(d_o); hipFree(d_mT); hipFree(d_wT); d_m = nullptr; d_w = d_o = d_mT = d_wT = nullptr; cap_ns = cap_nn = cap_t = 0;
         if (ea) hipEventDestroy(ea); if (eb) hipEventDestroy(eb); ea = eb = nullptr; device = -1;
     }
 };
@@ -540,6 +542,13 @@ int hulk_smash_ex(int device, const uint64_t *mins, const double *weights, uint3
         SM_CHK(hipMalloc((void **)&B.d_w, (NS ? NS : 1) * 8));
         B.cap_ns = NS;
     }
+    const size_t NT = (size_t)smash_padded_n(n_sketches) * sketch_size;
+    if (NT > B.cap_t || !B.d_mT) {
+        hipFree(B.d_mT); hipFree(B.d_wT); B.d_mT = nullptr; B.d_wT = nullptr; B.cap_t = 0;
+        SM_CHK(hipMalloc((void **)&B.d_mT, (NT ? NT : 1) * 8));
+        SM_CHK(hipMalloc((void **)&B.d_wT, (NT ? NT : 1) * 8));
+        B.cap_t = NT;
+    }
     if (NN > B.cap_nn || !B.d_o) {
         hipFree(B.d_o); B.d_o = nullptr; B.cap_nn = 0;
         SM_CHK(hipMalloc((void **)&B.d_o, (NN ? NN : 1) * 8));
@@ -549,7 +558,7 @@ int hulk_smash_ex(int device, const uint64_t *mins, const double *weights, uint3
     SM_CHK(hipMemcpy(B.d_m, mins, NS * 8, hipMemcpyHostToDevice));
     SM_CHK(hipMemcpy(B.d_w, weights, NS * 8, hipMemcpyHostToDevice));
     if (kernel_ms) SM_CHK(hipEventRecord(B.ea, nullptr));
-    SM_CHK(launch_smash(nullptr, B.d_m, B.d_w, n_sketches, sketch_size, metric, B.d_o));
+    SM_CHK(launch_smash(nullptr, B.d_m, B.d_w, n_sketches, sketch_size, metric, B.d_o, B.d_mT, B.d_wT));
     if (kernel_ms) SM_CHK(hipEventRecord(B.eb, nullptr));
     SM_CHK(hipMemcpy(distances, B.d_o, NN * 8, hipMemcpyDeviceToHost));
     if (kernel_ms) { float ms = 0; SM_CHK(hipEventElapsedTime(&ms, B.ea, B.eb)); *kernel_ms = ms; }

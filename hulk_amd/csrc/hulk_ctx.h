@@ -92,6 +92,7 @@ struct hulk_ctx {
     float *d_rcp32 = nullptr, *d_k32 = nullptr, *d_tilemin = nullptr;
     float *d_rmm = nullptr;                                                        // [2][row_stride]: k_rcp_minmax (per-bin max / min of the batch's reciprocal vectors)
     unsigned long long *d_scanmap = nullptr;                                       // [slot groups][wave tiles / 64]: k_scan_test's verdicts
+    uint32_t *d_scanlist = nullptr, *d_scanlist_n = nullptr;                       // ... and as a list (slot group << 12 | wave tile) + its length
     float *d_slotmin = nullptr;                                                    // [T][slot groups][8]: k_slot_tmin (concept drift only)
     float *d_kmin32 = nullptr, *d_rext = nullptr, *d_kminslot = nullptr;          // bound test of k_cws_scan (no concept drift only)
     unsigned long long *d_visited = nullptr; uint64_t scan_tiles_total = 0; bool prune = false, no_skip = false;

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void k_scan_test(const float *__restrict__ kmi
                                                    const double *__restrict__ weights, int slot_begin, int slots,
                                                    int wtiles, int wwords, double drift_dw, const DevState *st,
                                                    FlushBatch fb, unsigned long long *__restrict__ scanmap,
-                                                   unsigned long long *__restrict__ visited) {
+                                                   unsigned long long *__restrict__ visited, uint32_t *__restrict__ scanlist,
+                                                   uint32_t *__restrict__ scanlist_n) {
     if (st->skip_exact[fb.parity]) return;                       // k_flush_decide: nothing in this batch can matter
     const int grp = blockIdx.y, lane = threadIdx.x & 63;
     const int word = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -223,6 +224,15 @@ __global__ __launch_bounds__(256) void k_scan_test(const float *__restrict__ kmi
         scanmap[(size_t)grp * wwords + word] = mask;
         if (mask) atomicAdd(&visited[(blockIdx.x + blockIdx.y * gridDim.x) & (MIN_SLOTS - 1)], (unsigned long long)__popcll(mask));
     }
+    // ... and the tiles to read as a LIST (slot group << 12 | wave tile; wave tiles < 4096 for every num_bins <= 2^20): the scan
+    // runs over it with a fixed grid.  (One workgroup of 16 waves per 16 tiles of the whole table, most of them returning at
+    // once, was 235 us per flush at k = 31, sketchSize 1024 for the 3 % of the tiles the bounds let through: 30 k workgroups.)
+    if (mask && scanlist) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(scanlist_n, (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, 0);
+        if (pass) scanlist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = ((uint32_t)grp << 12) | (uint32_t)wt;
+    }
 }
 
 // workgroup of 16 waves = (quarter of a column word = 16 wave tiles, slot group); wave w takes wave tile 64 cw + 16 quarter + w
@@ -233,30 +243,13 @@ __global__ __launch_bounds__(256) void k_scan_test(const float *__restrict__ kmi
 // issue cycles of an interval's work on a tile (235 -> 151 cycles; profiles/r04_scan.txt).  k_cws_resolve<true> then
 // re-evaluates the candidate tiles for every interval of the batch and orders the exact values by (A, interval, bin).
 // MODE 0: per-interval minima (concept drift); 1: MERGE over the T reciprocal vectors (kept as the comparator of MODE 2:
-// hulk_debug_switches SCAN_MERGE_LOOP); 2: MERGE over the two vectors of k_rcp_minmax (`rcp32` = rmm) — the product path.
+// HULK_SCAN_MERGE_LOOP in the profiling build); 2: MERGE over the two vectors of k_rcp_minmax (`rcp32` = rmm) — the product path.
+// One wave tile (8 rows x 256 bins of K) by one wave:
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_cws_scan(const float *__restrict__ k32,
-                                                   const float *__restrict__ rcp32,
-                                                   float *__restrict__ tilemin, int slots, int ntiles,
-                                                   size_t row_stride, const DevState *st, FlushBatch fb,
-                                                   const unsigned long long *__restrict__ scanmap, int wwords) {
+__device__ __forceinline__ void scan_wave_tile(const float *__restrict__ k32, const float *__restrict__ rcp32, float *__restrict__ tilemin,
+                                               int slots, int ngroups, int wtiles, size_t row_stride, const FlushBatch &fb, uint32_t gomask,
+                                               int grp, int wt, int lane) {
     constexpr bool MERGE = MODE != 0;
-    // XCD-aware order (workgroup b lands on XCD b % 8): XCD x works through column unit 8*chunk + x (16 wave tiles) for
-    // ALL slot groups before moving on, so a column's reciprocal vectors (T x 16 KB) are fetched into
-    // that XCD's L2 once and re-used by the other groups; the 8 XCDs stream 8 adjacent 16 KB pieces of
-    // the same K rows at the same time.
-    if (st->skip_exact[fb.parity]) return;
-    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
-    const int r = (int)(blockIdx.x >> 3), grp = r % ngroups, unit = (r / ngroups) * 8 + (int)(blockIdx.x & 7);
-    const int cw = unit >> 2, quarter = unit & 3;                // unit = 16 wave tiles: fine enough to balance the 8 XCDs
-    if (cw >= wwords) return;
-    const unsigned long long mask = scanmap[(size_t)grp * wwords + cw];
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    if (!((mask >> (16 * quarter + wid)) & 1ull)) return;        // wave-uniform: this tile cannot change the sketch
-    const int wtiles = ntiles * 4;                               // 256-bin wave tiles per row
-    const uint32_t gomask = batch_gomask(st, fb);
-    {
-        const int wt = cw * 64 + quarter * 16 + wid;
         const size_t col = (size_t)wt * 256 + (size_t)lane * 4;
         floatx4 kv[SCAN_ROWS];
 #pragma unroll
@@ -317,7 +310,46 @@ __global__ __launch_bounds__(1024) void k_cws_scan(const float *__restrict__ k32
             if ((lane & 7) == 0)                                    // plane 0 of tilemin: [slot group][wave tile][row]
                 tilemin[((size_t)grp * wtiles + (size_t)wt) * SCAN_ROWS + (lane >> 3)] = mine;
         }
+}
+
+// the scan over the list of k_scan_test: a fixed grid of 4-wave workgroups, wave w takes items w, w + waves, ...
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cws_scan_list(const float *__restrict__ k32, const float *__restrict__ rcp32,
+                                                       float *__restrict__ tilemin, int slots, int ntiles, size_t row_stride,
+                                                       const DevState *st, FlushBatch fb, const uint32_t *__restrict__ scanlist,
+                                                       const uint32_t *__restrict__ scanlist_n) {
+    if (st->skip_exact[fb.parity]) return;
+    const uint32_t n = *scanlist_n;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), waves = gridDim.x * 4;
+    if (wave >= n) return;
+    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS, wtiles = ntiles * 4;
+    const uint32_t gomask = batch_gomask(st, fb);
+    for (uint32_t i = wave; i < n; i += waves) {
+        const uint32_t item = scanlist[i];
+        scan_wave_tile<MODE>(k32, rcp32, tilemin, slots, ngroups, wtiles, row_stride, fb, gomask, (int)(item >> 12), (int)(item & 4095u), lane);
     }
+}
+
+// (the grid form: one workgroup of 16 waves per 16 wave tiles of the whole table — HULK_SCAN_GRID in the profiling build)
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_cws_scan(const float *__restrict__ k32,
+                                                   const float *__restrict__ rcp32,
+                                                   float *__restrict__ tilemin, int slots, int ntiles,
+                                                   size_t row_stride, const DevState *st, FlushBatch fb,
+                                                   const unsigned long long *__restrict__ scanmap, int wwords) {
+    // XCD-aware order (workgroup b lands on XCD b % 8): XCD x works through column unit 8*chunk + x (16 wave tiles) for
+    // ALL slot groups before moving on; the 8 XCDs stream 8 adjacent 16 KB pieces of the same K rows at the same time.
+    if (st->skip_exact[fb.parity]) return;
+    const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
+    const int r = (int)(blockIdx.x >> 3), grp = r % ngroups, unit = (r / ngroups) * 8 + (int)(blockIdx.x & 7);
+    const int cw = unit >> 2, quarter = unit & 3;                // unit = 16 wave tiles: fine enough to balance the 8 XCDs
+    if (cw >= wwords) return;
+    const unsigned long long mask = scanmap[(size_t)grp * wwords + cw];
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    if (!((mask >> (16 * quarter + wid)) & 1ull)) return;        // wave-uniform: this tile cannot change the sketch
+    scan_wave_tile<MODE>(k32, rcp32, tilemin, slots, ngroups, ntiles * 4, row_stride, fb, batch_gomask(st, fb), grp,
+                         cw * 64 + quarter * 16 + wid, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -771,23 +803,46 @@ __global__ __launch_bounds__(256) void k_cws_beta(const uint64_t *__restrict__ u
 // distances.GetDistance "jaccard" (distances.go:19-26) and GetWJD (distances.go:44-72) with the
 // reference's quirk that BOTH weight vectors come from the subject sketch (sketchio.go:293-301).
 // Every pair (s, q) accumulates over the slots IN ORDER, so the fp64 sums are bit-identical to the Go loops.
-// Register tile: a thread owns 4 subjects x 4 queries, a workgroup of 128 threads a tile of 32 subjects x 64 queries;
-// the slot chunks are staged TRANSPOSED ([slot][row], rows padded to a 16-byte multiple off the bank period), so per slot a
-// thread reads its 4 subject mins, 4 subject weights and 4 query mins with six ds_read_b128 — 0.375 LDS reads per
-// (pair, slot) instead of 3 — and runs 16 independent accumulators.  `+= equal ? |w| : 0.0` is the reference's
-// conditional add bit for bit (the sums are non-negative: x + 0.0 == x); the union of the weighted metric is the sum of
-// the subject's |w| whatever the query (both branches of distances.go:58-68 add max(wA, wB) = |w| when hsB = subject).
+//   k_smash_prep  once per call: mins -> float64 (the reference compares them as float64, sketchio.go:271-277), weights ->
+//                 |w| (max(max(w,0), max(-w,0)), NaN stays NaN), both stored SLOT-major ([slot][sketch]) so that a tile's rows
+//                 are contiguous
+//   k_smash       register tile: a thread owns 4 subjects x 4 queries, a workgroup of 128 threads a tile of 32 subjects x 64
+//                 queries; chunks of 32 slots go through LDS as [slot][row] (the prep's layout: 16-byte loads in, 16-byte LDS
+//                 stores, no transposition) in two buffers — chunk n+1 is loaded into registers before chunk n is computed
+//                 and stored behind it, one barrier per chunk.  Per slot a thread reads its 4 subject mins, 4 subject
+//                 weights and 4 query mins with six ds_read_b128 (0.375 LDS reads per (pair, slot), was 3) and runs 16
+//                 independent accumulators; `+= equal ? |w| : 0.0` is the reference's conditional add bit for bit (the sums
+//                 are non-negative: x + 0.0 == x); the union of the weighted metric is the sum of the subject's |w| whatever
+//                 the query (both branches of distances.go:58-68 add max(wA, wB) = |w| when hsB = subject).
 // ==========================================================================================
 constexpr int SMASH_TS = 32, SMASH_TQ = 64, SMASH_CH = 32, SMASH_PAD = 2;
+__global__ __launch_bounds__(256) void k_smash_prep(const unsigned long long *__restrict__ mins, const double *__restrict__ weights,
+                                                    uint32_t N, uint32_t S, uint32_t NP, double *__restrict__ mT, double *__restrict__ wT) {
+    // 32 x 32 tiles through LDS: reads run along the slots of a sketch, writes along the sketches of a slot
+    __shared__ double tm[32][33], tw[32][33];
+    const uint32_t n0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (uint32_t r = ty; r < 32; r += 8) {
+        const uint32_t n = n0 + r, c = c0 + tx;
+        const bool ok = n < N && c < S;
+        tm[r][tx] = ok ? (double)mins[(size_t)n * S + c] : 0.0;
+        tw[r][tx] = ok ? fabs(weights[(size_t)n * S + c]) : 0.0;
+    }
+    __syncthreads();
+    for (uint32_t r = ty; r < 32; r += 8) {
+        const uint32_t c = c0 + r, n = n0 + tx;
+        if (c < S && n < NP) { mT[(size_t)c * NP + n] = tm[tx][r]; wT[(size_t)c * NP + n] = tw[tx][r]; }
+    }
+}
+
 template <int METRIC>
-__global__ __launch_bounds__(128) void k_smash(const unsigned long long *__restrict__ mins,
-                                               const double *__restrict__ weights, uint32_t N, uint32_t S,
-                                               double *__restrict__ out) {
-    // the reference compares the `mins` as float64 (sketchio.go:271-277): converted once, when a chunk is staged
-    __shared__ __align__(16) double ma[SMASH_CH][SMASH_TS + SMASH_PAD], wa[SMASH_CH][SMASH_TS + SMASH_PAD];
-    __shared__ __align__(16) double mb[SMASH_CH][SMASH_TQ + SMASH_PAD];
+__global__ __launch_bounds__(128) void k_smash(const double *__restrict__ mT, const double *__restrict__ wT, uint32_t N, uint32_t NP,
+                                               uint32_t S, double *__restrict__ out) {
+    __shared__ __align__(16) double ma[2][SMASH_CH][SMASH_TS + SMASH_PAD], wa[2][SMASH_CH][SMASH_TS + SMASH_PAD];
+    __shared__ __align__(16) double mb[2][SMASH_CH][SMASH_TQ + SMASH_PAD];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;     // query quad, subject quad inside the tile
     const uint32_t s0 = blockIdx.y * SMASH_TS, q0 = blockIdx.x * SMASH_TQ;
+    // staging: thread t moves slot (t / 4) of the chunk: 8 subject rows (mins, weights) and 16 query rows from (t % 4) on
+    const int lc = tid >> 2, lr = tid & 3;
     double acc[4][4], uni[4];
     uint32_t cnt[4][4];
 #pragma unroll
@@ -796,29 +851,39 @@ __global__ __launch_bounds__(128) void k_smash(const unsigned long long *__restr
 #pragma unroll
         for (int j = 0; j < 4; j++) { acc[i][j] = 0.0; cnt[i][j] = 0; }
     }
-    for (uint32_t c0 = 0; c0 < S; c0 += SMASH_CH) {
-        // global reads run along the slots (coalesced), LDS writes go down a column
-        for (int i = tid; i < SMASH_TS * SMASH_CH; i += 128) {
-            const int r = i / SMASH_CH, c = i % SMASH_CH;
-            const uint32_t row = s0 + r, col = c0 + c;
-            const bool ok = col < S && row < N;
-            ma[c][r] = ok ? (double)mins[(size_t)row * S + col] : 0.0;
-            if (METRIC == 1) wa[c][r] = ok ? fabs(weights[(size_t)row * S + col]) : 0.0;   // max(max(w,0), max(-w,0)) == |w| (NaN stays NaN)
-        }
-        for (int i = tid; i < SMASH_TQ * SMASH_CH; i += 128) {
-            const int r = i / SMASH_CH, c = i % SMASH_CH;
-            const uint32_t row = q0 + r, col = c0 + c;
-            mb[c][r] = (col < S && row < N) ? (double)mins[(size_t)row * S + col] : 0.0;
-        }
-        __syncthreads();
+    double2 ra[4], rw[4], rb[8];
+    auto fetch = [&](uint32_t c0) {
+        const uint32_t col = c0 + (uint32_t)lc;
+        const bool ok = col < S;                                    // (rows past N hold zeros: NP is N rounded up to the tile)
+        const double2 *pa = (const double2 *)(mT + (size_t)col * NP + s0 + 8 * lr);
+        const double2 *pw = (const double2 *)(wT + (size_t)col * NP + s0 + 8 * lr);
+        const double2 *pb = (const double2 *)(mT + (size_t)col * NP + q0 + 16 * lr);
+#pragma unroll
+        for (int x = 0; x < 4; x++) { ra[x] = ok ? pa[x] : make_double2(0.0, 0.0); if (METRIC == 1) rw[x] = ok ? pw[x] : make_double2(0.0, 0.0); }
+#pragma unroll
+        for (int x = 0; x < 8; x++) rb[x] = ok ? pb[x] : make_double2(0.0, 0.0);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int x = 0; x < 4; x++) { *(double2 *)&ma[buf][lc][8 * lr + 2 * x] = ra[x]; if (METRIC == 1) *(double2 *)&wa[buf][lc][8 * lr + 2 * x] = rw[x]; }
+#pragma unroll
+        for (int x = 0; x < 8; x++) *(double2 *)&mb[buf][lc][16 * lr + 2 * x] = rb[x];
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t c0 = 0; c0 < S; c0 += SMASH_CH, buf ^= 1) {
+        const bool more = c0 + SMASH_CH < S;
+        if (more) fetch(c0 + SMASH_CH);                             // in flight under this chunk's arithmetic
         const uint32_t lim = S - c0 < (uint32_t)SMASH_CH ? S - c0 : (uint32_t)SMASH_CH;
 #pragma unroll 2
         for (uint32_t c = 0; c < lim; c++) {                       // (unrolled by two: the next slot's six LDS reads are in flight under this one's 72 VALU)
-            const double2 a01 = *(const double2 *)&ma[c][4 * ty], a23 = *(const double2 *)&ma[c][4 * ty + 2];
-            const double2 b01 = *(const double2 *)&mb[c][4 * tx], b23 = *(const double2 *)&mb[c][4 * tx + 2];
+            const double2 a01 = *(const double2 *)&ma[buf][c][4 * ty], a23 = *(const double2 *)&ma[buf][c][4 * ty + 2];
+            const double2 b01 = *(const double2 *)&mb[buf][c][4 * tx], b23 = *(const double2 *)&mb[buf][c][4 * tx + 2];
             const double a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
             if (METRIC == 1) {
-                const double2 w01 = *(const double2 *)&wa[c][4 * ty], w23 = *(const double2 *)&wa[c][4 * ty + 2];
+                const double2 w01 = *(const double2 *)&wa[buf][c][4 * ty], w23 = *(const double2 *)&wa[buf][c][4 * ty + 2];
                 const double w[4] = {w01.x, w01.y, w23.x, w23.y};
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -833,6 +898,7 @@ __global__ __launch_bounds__(128) void k_smash(const unsigned long long *__restr
                     for (int j = 0; j < 4; j++) cnt[i][j] += (a[i] == b[j]) ? 1u : 0u;      // a count of 1.0s is exact in fp64
             }
         }
+        if (more) stash(buf ^ 1);                                   // (the other buffer: nobody reads it during this chunk)
         __syncthreads();
     }
 #pragma unroll
@@ -889,28 +955,36 @@ __global__ void k_fill_f32(float *p, size_t n, float v) {
 static bool scan_merge_off() { static const bool v = HULK_EXP_ENV("HULK_SCAN_PER_INTERVAL") != nullptr; return v; }
 static bool scan_merge_loop() { static const bool v = HULK_EXP_ENV("HULK_SCAN_MERGE_LOOP") != nullptr; return v; }
 
+static bool scan_grid_form() { static const bool v = HULK_EXP_ENV("HULK_SCAN_GRID") != nullptr; return v; }
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
                            unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap, bool per_interval,
-                           float *d_rmm) {
+                           float *d_rmm, uint32_t *d_scanlist, uint32_t *d_scanlist_n) {
     const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
     const int wtiles = ntiles * 4, wwords = (wtiles + 63) / 64;
+    const bool grid_form = scan_grid_form();
     if (d_kmin32)
         hipLaunchKernelGGL(k_rcp_extrema, dim3(ntiles, fb.count), dim3(256), 0, s, d_rcp32, d_rext, ntiles, row_stride, st, fb);
+    if (!grid_form) { const hipError_t e = hipMemsetAsync(d_scanlist_n, 0, 4, s); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(k_scan_test, dim3((wwords + 3) / 4, groups), dim3(256), 0, s, d_kmin32, d_rext, d_weights, slot_begin,
-                       slots, wtiles, wwords, drift_dw, st, fb, d_scanmap, d_visited);
-    const int chunks = (wwords * 4 + 7) / 8;                     // units of 16 wave tiles, 8 (one per XCD) side by side
-    if (per_interval || scan_merge_off())                       // concept drift: the elements are taken in stream order
-        hipLaunchKernelGGL(k_cws_scan<0>, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rcp32,
-                           d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
-    else if (scan_merge_loop())
-        hipLaunchKernelGGL(k_cws_scan<1>, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rcp32,
-                           d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
-    else {
+                       slots, wtiles, wwords, drift_dw, st, fb, d_scanmap, d_visited, grid_form ? nullptr : d_scanlist, d_scanlist_n);
+    const int mode = (per_interval || scan_merge_off()) ? 0 : scan_merge_loop() ? 1 : 2;   // 0: concept drift, the elements are taken in stream order
+    if (mode == 2)
         hipLaunchKernelGGL(k_rcp_minmax, dim3((unsigned)((row_stride / 4 + 255) / 256)), dim3(256), 0, s, d_rcp32, d_rmm, row_stride, st, fb);
-        hipLaunchKernelGGL(k_cws_scan<2>, dim3((unsigned)(chunks * 8 * groups)), dim3(1024), 0, s, d_k32, d_rmm,
-                           d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
+    const float *rv = mode == 2 ? d_rmm : d_rcp32;
+    if (grid_form) {
+        const dim3 g((unsigned)(((wwords * 4 + 7) / 8) * 8 * groups));            // units of 16 wave tiles, 8 (one per XCD) side by side
+        if (mode == 0) hipLaunchKernelGGL(k_cws_scan<0>, g, dim3(1024), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
+        else if (mode == 1) hipLaunchKernelGGL(k_cws_scan<1>, g, dim3(1024), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
+        else hipLaunchKernelGGL(k_cws_scan<2>, g, dim3(1024), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
+    } else {
+        // enough waves for the whole table to be in flight at 8 KB per wave; a short list leaves most of them nothing to do
+        const size_t items = (size_t)groups * wtiles;
+        const dim3 g((unsigned)std::min<size_t>(2048, (items + 3) / 4));
+        if (mode == 0) hipLaunchKernelGGL(k_cws_scan_list<0>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n);
+        else if (mode == 1) hipLaunchKernelGGL(k_cws_scan_list<1>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n);
+        else hipLaunchKernelGGL(k_cws_scan_list<2>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n);
     }
     return hipGetLastError();
 }
@@ -1004,12 +1078,16 @@ hipError_t launch_cws_beta(hipStream_t s, const uint64_t *d_uraw, uint64_t first
     return hipGetLastError();
 }
 
+// sketches rounded up to the query tile: the slot-major arrays are [S][smash_padded_n(N)], zero rows behind N
+uint32_t smash_padded_n(uint32_t N) { return (N + SMASH_TQ - 1) / SMASH_TQ * SMASH_TQ; }
 hipError_t launch_smash(hipStream_t s, const unsigned long long *d_mins, const double *d_weights, uint32_t N, uint32_t S,
-                        int metric, double *d_out) {
+                        int metric, double *d_out, double *d_mT, double *d_wT) {
     if (N == 0) return hipSuccess;
-    const dim3 g((N + SMASH_TQ - 1) / SMASH_TQ, (N + SMASH_TS - 1) / SMASH_TS);
-    if (metric == 1) hipLaunchKernelGGL(k_smash<1>, g, dim3(128), 0, s, d_mins, d_weights, N, S, d_out);
-    else hipLaunchKernelGGL(k_smash<0>, g, dim3(128), 0, s, d_mins, d_weights, N, S, d_out);
+    const uint32_t NP = smash_padded_n(N);
+    hipLaunchKernelGGL(k_smash_prep, dim3((S + 31) / 32, NP / 32), dim3(256), 0, s, d_mins, d_weights, N, S, NP, d_mT, d_wT);
+    const dim3 g(NP / SMASH_TQ, (N + SMASH_TS - 1) / SMASH_TS);
+    if (metric == 1) hipLaunchKernelGGL(k_smash<1>, g, dim3(128), 0, s, d_mT, d_wT, N, NP, S, d_out);
+    else hipLaunchKernelGGL(k_smash<0>, g, dim3(128), 0, s, d_mT, d_wT, N, NP, S, d_out);
     return hipGetLastError();
 }
 

@@ -355,7 +355,8 @@ int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &
         HIPCHK(c, launch_cws_scan(s, c->d_k32, c->d_rcp32, c->d_tilemin, (int)c->slots, c->ntiles,
                                   c->row_stride, c->d_state, fb, c->prune ? c->d_kmin32 : nullptr, c->d_rext,
                                   c->d_weights, (int)c->slot_begin, c->d_visited, c->drift ? c->decay_weight : 0.0, c->d_scanmap,
-                                  c->drift /* per-interval minima: the drift resolve replays the stream in order */, c->d_rmm));
+                                  c->drift /* per-interval minima: the drift resolve replays the stream in order */, c->d_rmm,
+                                  c->d_scanlist, c->d_scanlist_n));
         c->scan_tiles_total += (uint64_t)((c->slots + SCAN_ROWS - 1) / SCAN_ROWS) * (uint64_t)c->ntiles * 4u;
         if ((c->profiling & 1)) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
         if (c->drift)

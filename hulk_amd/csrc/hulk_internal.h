@@ -126,7 +126,7 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
                            unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap, bool per_interval,
-                           float *d_rmm);
+                           float *d_rmm, uint32_t *d_scanlist, uint32_t *d_scanlist_n);
 hipError_t launch_tile_kmin(hipStream_t s, const float *d_k32, float *d_kmin32, int slots, int ntiles, size_t row_stride);
 hipError_t launch_slot_kmin(hipStream_t s, const float *d_kmin32, float *d_kminslot, int slots, int ntiles);
 hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, int ncounters, const float *d_kminslot,
@@ -170,7 +170,8 @@ hipError_t launch_rng_candidates(hipStream_t s, const uint64_t *d_raw, uint64_t 
 hipError_t launch_cws_beta(hipStream_t s, const uint64_t *d_uraw, uint64_t first_entry, uint64_t n, double *d_rcb,
                            uint64_t num_bins, uint64_t slot_begin, uint64_t slots);
 hipError_t launch_smash(hipStream_t s, const unsigned long long *d_mins, const double *d_weights, uint32_t N, uint32_t S,
-                        int metric, double *d_out);
+                        int metric, double *d_out, double *d_mT, double *d_wT);     // d_mT, d_wT: scratch [S][smash_padded_n(N)]
+uint32_t smash_padded_n(uint32_t N);
 hipError_t launch_build_k32(hipStream_t s, const double *d_rcb, float *d_k32, int slots,
                             int32_t num_bins, size_t row_stride);
 hipError_t launch_selftest_rcp(hipStream_t s, unsigned long long *d_mismatches);
