@@ -25,7 +25,7 @@ HULK_UNIQUE_ID_BYTES = 128
 HULK_XCHG_ALLGATHER, HULK_XCHG_ALLREDUCE_U32 = 0, 1
 HULK_CWS_GO_COMPAT = 0
 HULK_CWS_EXTERNAL = 1
-HULK_FLAG_GAMMA_CPYTHON, HULK_FLAG_NO_PRUNE, HULK_FLAG_NO_SKIP, HULK_FLAG_SHARD_FULL, HULK_FLAG_NO_OVERLAP = 1, 2, 4, 8, 16
+HULK_FLAG_GAMMA_CPYTHON, HULK_FLAG_NO_PRUNE, HULK_FLAG_NO_SKIP, HULK_FLAG_SHARD_FULL, HULK_FLAG_NO_OVERLAP, HULK_FLAG_NO_PRERESERVE = 1, 2, 4, 8, 16, 32
 HULK_MAX_BINS = 1 << 20
 HULK_INJECT_NONE, HULK_INJECT_STALE_SEAL, HULK_INJECT_STALE_STAGE = 0, 1, 2
 

@@ -91,7 +91,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     // the binning kernels pack (spectrum slot << 20 | bin) into a dword (hulk_spectrum.hip); k^4 <= 31^4 < 2^20
     if (bins > (int64_t)HULK_MAX_BINS)
         return fail(nullptr, HULK_ERR_ARG, "num_bins " + std::to_string(bins) + " exceeds HULK_MAX_BINS (2^20; k^4 at k = 31 is 923521)");
-    if (p.flags & ~(HULK_FLAG_GAMMA_CPYTHON | HULK_FLAG_NO_PRUNE | HULK_FLAG_NO_SKIP | HULK_FLAG_SHARD_FULL | HULK_FLAG_NO_OVERLAP))
+    if (p.flags & ~(HULK_FLAG_GAMMA_CPYTHON | HULK_FLAG_NO_PRUNE | HULK_FLAG_NO_SKIP | HULK_FLAG_SHARD_FULL | HULK_FLAG_NO_OVERLAP | HULK_FLAG_NO_PRERESERVE))
         return fail(nullptr, HULK_ERR_ARG, "unknown flags");
     if (p.batch > (uint32_t)SCAN_BATCH_MAX) return fail(nullptr, HULK_ERR_ARG, "batch must be 0 (default) or 1..16");
     if (p.work_lanes > 2) return fail(nullptr, HULK_ERR_ARG, "work_lanes must be 0 (default), 1 or 2");

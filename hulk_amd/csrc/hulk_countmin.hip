@@ -178,18 +178,12 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
             for (int c = 0; c < CMS_GROUP; c++) {
                 const int ch = g * CMS_GROUP + c;
                 if (ch >= seg_chunks) break;
-                const int64_t b = b0 + (int64_t)ch * 64 + lane;
-                const uint32_t h = hh[c], p = pp[c], m = mm[c];
-                // own count + the counts of the earlier lanes of this chunk that share the counter
-                uint32_t acc = h, cur = m & 0x7fu;
-                while (__any((int)(cur < 64u))) {
-                    const uint32_t oh = (uint32_t)__shfl((int)h, (int)(cur & 63u));
-                    const uint32_t oc = (uint32_t)__shfl((int)m, (int)(cur & 63u)) & 0x7fu;
-                    if (cur < 64u) { acc += oh; cur = oc; }
-                }
-                const unsigned long long est = rc[p] + acc;          // every lane reads before any lane writes
-                my[c * 64 + lane] = est;
-                if ((m & 0x80u) && b < (int64_t)B) rc[p] = est;      // last lane of the chunk for this counter
+                const uint32_t h = hh[c], p = pp[c];
+                // The LDS keeps the bin order by itself: ds_add_rtn_u64 returns the counter as it stood before this lane's add,
+                // same-address lanes of one instruction are applied in ascending lane order, a wave's instructions in program
+                // order (tools/ubench/lds_atomic_order.hip).  (Until round 5 the lanes followed a static "previous lane on the
+                // same counter" table with register exchanges, then read and wrote the counter: 117 us per 16 spectra at k = 21.)
+                if (h) my[c * 64 + lane] = atomicAdd(&rc[p], (unsigned long long)h) + h;
             }
         }
         if (d == depth && g > 0) {
@@ -335,7 +329,7 @@ __global__ __launch_bounds__(256) void k_cmsd_base(const double *__restrict__ se
 // counters are rescaled by w^PERIOD (the period keeps w^-(j - base) far below the fp64 range for any decay < 1).
 // 517 -> 450 (staging) -> see docs/EXPERIMENTS.md: us per 16 spectra of 923,521 bins.
 constexpr int CMSD_FG = 8;            // chunks per barrier group of k_cmsd_freq
-__global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
+__global__ __launch_bounds__(512) void k_cmsd_freq_chain(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
                                                    const uint8_t *__restrict__ meta8, const uint32_t *__restrict__ eidx,
                                                    const uint32_t *__restrict__ sege0, const double *__restrict__ cstart,
                                                    double *__restrict__ f64, float *__restrict__ rcp32, int depth,
@@ -480,6 +474,133 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
     }
 }
 
+
+// The same replay with the counter kept ADDITIVELY normalised, S = sum over its elements i of v_i * w^-(i - base), so that its
+// value right after element j is S * w^(j - base): an element then only ADDS g = v * w^-(j - base) to its counter, and the
+// LDS does the bin-order bookkeeping by itself — ds_add_rtn_f64 returns the counter as it stood before this lane's add,
+// same-address lanes of one instruction are applied in ascending lane order and the instructions of a wave in program order
+// (tools/ubench/lds_atomic_order.hip checks both on the chip).  No "previous lane on the same counter" table, no ballots,
+// no register exchanges, no read-then-write hazard between consecutive chunks: the eight atomics of a group are in flight
+// together.  ~15 VALU + 6 LDS instructions per (row, chunk) where the chain form has ~90 VALU: 450 -> see
+// profiles/r05_c3_kernel_stats_serial.md.  (Rounding: C = (S + v*wi) * wf against the chain form's S*wf + v — both are
+// re-associations of the reference's step-by-step scaling, ~1e-13 relative; bit-reproducible from run to run.)
+__global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
+                                                   const uint32_t *__restrict__ eidx, const uint32_t *__restrict__ sege0,
+                                                   const double *__restrict__ cstart, double *__restrict__ f64,
+                                                   float *__restrict__ rcp32, int depth, int width, int seg_chunks,
+                                                   size_t row_stride, double omega, DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int GB = CMSD_FG * 64;
+    constexpr unsigned long long INF_BITS = 0x7FF0000000000000ull;
+    double *lval = (double *)smem;                                               // [depth][width] normalised counters
+    unsigned long long *smin = (unsigned long long *)(lval + (size_t)depth * width);   // [2][GB] min over the rows, as bits
+    __shared__ double tabf_lo[64], tabf_hi[66], tabi_lo[64], tabi_hi[66];          // w^x and w^-x for x = lo + 64 hi
+    const int seg = blockIdx.x, t = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;
+    const uint32_t gomask = batch_gomask(st, fb);
+    const bool go = (gomask >> t) & 1u;
+    const uint32_t slot = ring_slot(fb, t);
+    if (seg == 0 && tid == 0) {
+        const unsigned used = st->used[fb.parity][slot];
+        if (used != 0 && !go) set_error(st, -5);
+        if (go) atomicAdd(&st->n_elements, (unsigned long long)used);
+    }
+    if (!go) return;
+    const size_t B = (size_t)fb.num_bins;
+    const double lnw = log(omega);                               // < 0
+    // elements per base: |ln w| * (period + 64) <= 600  =>  w^-(j - base) <= e^600 (counters stay below ~1e270)
+    int period = 4032;
+    if (-lnw * (double)(period + 64) > 600.0) period = (int)(600.0 / -lnw) - 64;
+    period &= ~63;
+    if (period < 64) period = 64;
+    {
+        const double *bt = cstart + (((size_t)t * depth) * CMS_SEGS) * width;
+        for (int i = tid; i < depth * width; i += blockDim.x) {
+            const int dd = i / width, p = i - dd * width;
+            lval[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];       // value as of element e0 - 1: see `base` below
+        }
+        for (int i = tid; i < 2 * GB; i += blockDim.x) smin[i] = INF_BITS;
+        if (tid < 64) { tabf_lo[tid] = exp((double)tid * lnw); tabi_lo[tid] = exp(-(double)tid * lnw); }
+        if (tid >= 64 && tid < 64 + 66) { const int x = tid - 64; tabf_hi[x] = exp((double)(64 * x) * lnw); tabi_hi[x] = exp(-(double)(64 * x) * lnw); }
+    }
+    __syncthreads();
+    uint32_t *hist = hists + (size_t)slot * B;
+    const uint32_t *ei = eidx + (size_t)t * B;
+    double *ft = f64 + (size_t)t * B;
+    float *rt = rcp32 + (size_t)t * row_stride;
+    const int64_t b0 = (int64_t)seg * seg_chunks * 64;
+    // a counter holding S stands for the value S * w^(j - base) right after element j has been added (cstart = the value right
+    // after element e0 - 1: S = cstart at base = e0 - 1)
+    long long base = (long long)sege0[(size_t)t * CMS_SEGS + seg] - 1;
+    const double wperiod = exp((double)period * lnw);
+    const int ngroups = (seg_chunks + CMSD_FG - 1) / CMSD_FG;
+    const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
+    double *rv = lval + (size_t)(d < depth ? d : 0) * width;
+    // row waves: the three per-bin inputs of the WHOLE next group (8 chunks = 24 loads per lane) are requested before the
+    // current group is computed: with one workgroup per CU nothing else hides their latency
+    uint32_t nh[CMSD_FG], np_[CMSD_FG], nj[CMSD_FG];
+    auto fetch = [&](int g) {
+#pragma unroll
+        for (int c = 0; c < CMSD_FG; c++) {
+            const int ch = g * CMSD_FG + c;
+            const int64_t b = b0 + (int64_t)ch * 64 + lane;
+            nh[c] = 0; np_[c] = 0; nj[c] = 0;
+            if (d < depth && ch < seg_chunks && b < (int64_t)B) { nh[c] = hist[b]; np_[c] = pd[b]; nj[c] = ei[b]; }
+        }
+    };
+    fetch(0);
+    uint32_t chh[CMSD_FG], cp[CMSD_FG], cj[CMSD_FG];
+    for (int g = 0; g <= ngroups; g++) {
+#pragma unroll
+        for (int c = 0; c < CMSD_FG; c++) { chh[c] = nh[c]; cp[c] = np_[c]; cj[c] = nj[c]; }
+        if (g + 1 < ngroups) fetch(g + 1);
+        if (d < depth && g < ngroups) {
+            unsigned long long *my = smin + (size_t)(g & 1) * GB;
+#pragma unroll
+            for (int c = 0; c < CMSD_FG; c++) {
+                const int ch = g * CMSD_FG + c;
+                if (ch >= seg_chunks) break;
+                const uint32_t h = chh[c], p = cp[c]; const long long j = (long long)cj[c];
+                // move the base on when the chunk's elements would leave the tables (wave-uniform: element indices
+                // ascend with the lane; lane 0 holds the chunk's first)
+                {
+                    const long long jfirst = (long long)__builtin_amdgcn_readfirstlane((int)cj[c]);
+                    while (jfirst - base > (long long)period) {
+                        for (int i = lane; i < width; i += 64) rv[i] *= wperiod;
+                        base += period;
+                    }
+                }
+                if (h) {
+                    const uint32_t x = (uint32_t)(j - base);                     // 1 .. period + 64
+                    const double wi = tabi_lo[x & 63u] * tabi_hi[x >> 6], wf = tabf_lo[x & 63u] * tabf_hi[x >> 6];
+                    const double gv = (double)h * wi;
+                    const double before = atomicAdd(&rv[p], gv);                 // ds_add_rtn_f64: the counter in bin order
+                    const double C = (before + gv) * wf;
+                    atomicMin(&my[c * 64 + lane], (unsigned long long)__double_as_longlong(C));
+                }
+            }
+        }
+        if (d == depth && g > 0) {
+            unsigned long long *src = smin + (size_t)((g - 1) & 1) * GB;
+#pragma unroll
+            for (int c = 0; c < CMSD_FG; c++) {
+                const int ch = (g - 1) * CMSD_FG + c;
+                const int64_t b = b0 + (int64_t)ch * 64 + lane;
+                if (ch < seg_chunks && b < (int64_t)B) {
+                    const unsigned long long bits = src[c * 64 + lane];
+                    src[c * 64 + lane] = INF_BITS;
+                    if (bits != INF_BITS) {
+                        const double mn = __longlong_as_double((long long)bits);
+                        ft[b] = mn; rt[b] = (float)(1.0 / mn);
+                    } else { ft[b] = 0.0; rt[b] = __builtin_nanf(""); }
+                    hist[b] = 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ==========================================================================================
 // Concept drift (decay_ratio != 1): reference src/countmin/countmin.go:49-56,103-110,141-147 and
 // src/histosketch/histosketch.go:79-81,139-153.
@@ -595,6 +716,7 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_cmsd_segsum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cmsd_freq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cmsd_freq_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -603,8 +725,13 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
     hipLaunchKernelGGL(k_cmsd_base, dim3((depth * width + 255) / 256), dim3(256), 0, s, d_segadd, d_segfac, d_ctrd, d_cstart,
                        depth, width, st, fb);
     if (freq_begin) { const hipError_t e = hipEventRecord(freq_begin, s); if (e != hipSuccess) return e; }   // bench.py: k_cmsd_freq alone
-    hipLaunchKernelGGL(k_cmsd_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_meta8, d_eidx, d_sege0,
-                       d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
+    static const bool chain = HULK_EXP_ENV("HULK_CMSD_CHAIN") != nullptr;      // the round-3 form, kept as the A/B comparator
+    if (chain)
+        hipLaunchKernelGGL(k_cmsd_freq_chain, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_meta8, d_eidx, d_sege0,
+                           d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
+    else
+        hipLaunchKernelGGL(k_cmsd_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_eidx, d_sege0,
+                           d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
     if (freq_end) { const hipError_t e = hipEventRecord(freq_end, s); if (e != hipSuccess) return e; }
     return hipGetLastError();
 }

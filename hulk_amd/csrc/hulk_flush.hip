@@ -256,7 +256,7 @@ static int lane_open(hulk_ctx *c, int li) {
 // the lists, as any later call that needs more does.
 int lanes_prereserve(hulk_ctx *c) {
     const uint64_t I = c->p.interval;
-    if (!I || HULK_EXP_ENV("HULK_NO_PRERESERVE")) return HULK_OK;
+    if (!I || (c->p.flags & HULK_FLAG_NO_PRERESERVE) || HULK_EXP_ENV("HULK_NO_PRERESERVE")) return HULK_OK;
     const uint64_t n = std::min<uint64_t>((uint64_t)c->T * I, MAX_READS_PER_LAUNCH);
     const int nl = (c->work_lanes > 1 && !c->no_overlap) ? 2 : 1;
     for (int li = 0; li < nl; li++) {

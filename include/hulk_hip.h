@@ -97,6 +97,10 @@ extern "C" {
 #define HULK_FLAG_SHARD_FULL 8u    /* hulk_step_sharded always exchanges the k-mer spectra (never the count-min increments) */
 #define HULK_FLAG_NO_OVERLAP 16u   /* one stream: flush kernels on the work stream, one work lane (profiling: every kernel
                                     * runs alone, so its own duration can be read) */
+#define HULK_FLAG_NO_PRERESERVE 32u /* hulk_create does not size the work lanes' minimizer lists for batch x interval reads (about
+                                     * 3 GB per lane at the defaults): they grow with the first batches instead, at the price of an
+                                     * allocation in the middle of the stream.  For contexts that see few or long reads, or many
+                                     * contexts (ranks) on one GPU. */
 
 /* Largest k-mer spectrum this build bins: the binning kernels pack (spectrum slot << 20 | bin) into one dword
  * (k^4 = 923,521 < 2^20 at the reference's maximum k = 31; cmd/sketch.go:118). */
