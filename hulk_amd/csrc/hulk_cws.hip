@@ -182,9 +182,11 @@ __global__ __launch_bounds__(256) void k_scan_test(const float *__restrict__ kmi
                                                    unsigned long long *__restrict__ visited, uint32_t *__restrict__ scanlist,
                                                    uint32_t *__restrict__ scanlist_n) {
     if (st->skip_exact[fb.parity]) return;                       // k_flush_decide: nothing in this batch can matter
-    const int grp = blockIdx.y, lane = threadIdx.x & 63;
-    const int word = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (word >= wwords) return;
+    // workgroup = one column word (64 wave tiles) x four slot groups, the groups running fastest over the grid: the list below
+    // comes out column by column, so the waves that scan neighbouring items share a column's reciprocal vectors
+    const int grp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int word = blockIdx.y;
+    if (grp >= (slots + SCAN_ROWS - 1) / SCAN_ROWS) return;
     const int wt = word * 64 + lane;
     const uint32_t gomask = batch_gomask(st, fb);
     bool pass = false;
@@ -321,11 +323,14 @@ __global__ __launch_bounds__(256) void k_cws_scan_list(const float *__restrict__
     if (st->skip_exact[fb.parity]) return;
     const uint32_t n = *scanlist_n;
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), waves = gridDim.x * 4;
-    if (wave >= n) return;
+    // XCD-aware (workgroup b runs on XCD b % 8; the grid is a multiple of 8): every XCD takes one contiguous eighth of the
+    // list — the list is column-major, so the slot groups that read the same column's reciprocal vectors meet in one L2
+    const uint32_t xcd = blockIdx.x & 7u, per = (n + 7u) / 8u, first = xcd * per, last = first + per < n ? first + per : n;
+    const uint32_t wave = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), waves = (gridDim.x >> 3) * 4;
+    if (first + wave >= last) return;
     const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS, wtiles = ntiles * 4;
     const uint32_t gomask = batch_gomask(st, fb);
-    for (uint32_t i = wave; i < n; i += waves) {
+    for (uint32_t i = first + wave; i < last; i += waves) {
         const uint32_t item = scanlist[i];
         scan_wave_tile<MODE>(k32, rcp32, tilemin, slots, ngroups, wtiles, row_stride, fb, gomask, (int)(item >> 12), (int)(item & 4095u), lane);
     }
@@ -967,7 +972,7 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
     if (d_kmin32)
         hipLaunchKernelGGL(k_rcp_extrema, dim3(ntiles, fb.count), dim3(256), 0, s, d_rcp32, d_rext, ntiles, row_stride, st, fb);
     if (!grid_form) { const hipError_t e = hipMemsetAsync(d_scanlist_n, 0, 4, s); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(k_scan_test, dim3((wwords + 3) / 4, groups), dim3(256), 0, s, d_kmin32, d_rext, d_weights, slot_begin,
+    hipLaunchKernelGGL(k_scan_test, dim3((groups + 3) / 4, wwords), dim3(256), 0, s, d_kmin32, d_rext, d_weights, slot_begin,
                        slots, wtiles, wwords, drift_dw, st, fb, d_scanmap, d_visited, grid_form ? nullptr : d_scanlist, d_scanlist_n);
     const int mode = (per_interval || scan_merge_off()) ? 0 : scan_merge_loop() ? 1 : 2;   // 0: concept drift, the elements are taken in stream order
     if (mode == 2)
@@ -981,7 +986,7 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
     } else {
         // enough waves for the whole table to be in flight at 8 KB per wave; a short list leaves most of them nothing to do
         const size_t items = (size_t)groups * wtiles;
-        const dim3 g((unsigned)std::min<size_t>(2048, (items + 3) / 4));
+        const dim3 g((unsigned)((std::min<size_t>(2048, (items + 3) / 4) + 7) / 8 * 8));
         if (mode == 0) hipLaunchKernelGGL(k_cws_scan_list<0>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n);
         else if (mode == 1) hipLaunchKernelGGL(k_cws_scan_list<1>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n);
         else hipLaunchKernelGGL(k_cws_scan_list<2>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n);
