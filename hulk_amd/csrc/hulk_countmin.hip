@@ -484,13 +484,14 @@ __global__ __launch_bounds__(512) void k_cmsd_freq_chain(uint32_t *__restrict__ 
 // together.  ~15 VALU + 6 LDS instructions per (row, chunk) where the chain form has ~90 VALU: 450 -> see
 // profiles/r05_c3_kernel_stats_serial.md.  (Rounding: C = (S + v*wi) * wf against the chain form's S*wf + v — both are
 // re-associations of the reference's step-by-step scaling, ~1e-13 relative; bit-reproducible from run to run.)
+template <int FG>
 __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
                                                    const uint32_t *__restrict__ eidx, const uint32_t *__restrict__ sege0,
                                                    const double *__restrict__ cstart, double *__restrict__ f64,
                                                    float *__restrict__ rcp32, int depth, int width, int seg_chunks,
                                                    size_t row_stride, double omega, DevState *st, FlushBatch fb) {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int GB = CMSD_FG * 64;
+    constexpr int GB = FG * 64;
     constexpr unsigned long long INF_BITS = 0x7FF0000000000000ull;
     double *lval = (double *)smem;                                               // [depth][width] normalised counters
     unsigned long long *smin = (unsigned long long *)(lval + (size_t)depth * width);   // [2][GB] min over the rows, as bits
@@ -533,33 +534,33 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
     // after element e0 - 1: S = cstart at base = e0 - 1)
     long long base = (long long)sege0[(size_t)t * CMS_SEGS + seg] - 1;
     const double wperiod = exp((double)period * lnw);
-    const int ngroups = (seg_chunks + CMSD_FG - 1) / CMSD_FG;
+    const int ngroups = (seg_chunks + FG - 1) / FG;
     const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
     double *rv = lval + (size_t)(d < depth ? d : 0) * width;
     // row waves: the three per-bin inputs of the WHOLE next group (8 chunks = 24 loads per lane) are requested before the
     // current group is computed: with one workgroup per CU nothing else hides their latency
-    uint32_t nh[CMSD_FG], np_[CMSD_FG], nj[CMSD_FG];
+    uint32_t nh[FG], np_[FG], nj[FG];
     auto fetch = [&](int g) {
 #pragma unroll
-        for (int c = 0; c < CMSD_FG; c++) {
-            const int ch = g * CMSD_FG + c;
+        for (int c = 0; c < FG; c++) {
+            const int ch = g * FG + c;
             const int64_t b = b0 + (int64_t)ch * 64 + lane;
             nh[c] = 0; np_[c] = 0; nj[c] = 0;
             if (d < depth && ch < seg_chunks && b < (int64_t)B) { nh[c] = hist[b]; np_[c] = pd[b]; nj[c] = ei[b]; }
         }
     };
     fetch(0);
-    uint32_t chh[CMSD_FG], cp[CMSD_FG], cj[CMSD_FG];
+    uint32_t chh[FG], cp[FG], cj[FG];
     for (int g = 0; g <= ngroups; g++) {
 #pragma unroll
-        for (int c = 0; c < CMSD_FG; c++) { chh[c] = nh[c]; cp[c] = np_[c]; cj[c] = nj[c]; }
+        for (int c = 0; c < FG; c++) { chh[c] = nh[c]; cp[c] = np_[c]; cj[c] = nj[c]; }
         if (g + 1 < ngroups) fetch(g + 1);
         if (d < depth && g < ngroups) {
             unsigned long long *my = smin + (size_t)(g & 1) * GB;
 #pragma unroll
-            for (int c = 0; c < CMSD_FG; c++) {
-                const int ch = g * CMSD_FG + c;
-                if (ch >= seg_chunks) break;
+            for (int c = 0; c < FG; c++) {
+                const int ch = g * FG + c;
+                if (ch >= seg_chunks) continue;
                 const uint32_t h = chh[c], p = cp[c]; const long long j = (long long)cj[c];
                 // move the base on when the chunk's elements would leave the tables (wave-uniform: element indices
                 // ascend with the lane; lane 0 holds the chunk's first)
@@ -583,8 +584,8 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
         if (d == depth && g > 0) {
             unsigned long long *src = smin + (size_t)((g - 1) & 1) * GB;
 #pragma unroll
-            for (int c = 0; c < CMSD_FG; c++) {
-                const int ch = (g - 1) * CMSD_FG + c;
+            for (int c = 0; c < FG; c++) {
+                const int ch = (g - 1) * FG + c;
                 const int64_t b = b0 + (int64_t)ch * 64 + lane;
                 if (ch < seg_chunks && b < (int64_t)B) {
                     const unsigned long long bits = src[c * 64 + lane];
@@ -715,7 +716,8 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_cmsd_segsum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cmsd_freq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cmsd_freq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cmsd_freq<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds3 + (size_t)2 * 8 * 64 * 8));
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cmsd_freq_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -726,11 +728,15 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
                        depth, width, st, fb);
     if (freq_begin) { const hipError_t e = hipEventRecord(freq_begin, s); if (e != hipSuccess) return e; }   // bench.py: k_cmsd_freq alone
     static const bool chain = HULK_EXP_ENV("HULK_CMSD_CHAIN") != nullptr;      // the round-3 form, kept as the A/B comparator
+    static const bool fg16 = HULK_EXP_ENV("HULK_CMSD_FG16") != nullptr;        // 16 chunks per barrier group (A/B)
     if (chain)
         hipLaunchKernelGGL(k_cmsd_freq_chain, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_meta8, d_eidx, d_sege0,
                            d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
+    else if (fg16)
+        hipLaunchKernelGGL(k_cmsd_freq<16>, dim3(CMS_SEGS, fb.count), dim3(512), lds3 + (size_t)2 * 8 * 64 * 8, s, d_hists, d_pos16, d_eidx, d_sege0,
+                           d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
     else
-        hipLaunchKernelGGL(k_cmsd_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_eidx, d_sege0,
+        hipLaunchKernelGGL(k_cmsd_freq<8>, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_eidx, d_sege0,
                            d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
     if (freq_end) { const hipError_t e = hipEventRecord(freq_end, s); if (e != hipSuccess) return e; }
     return hipGetLastError();
