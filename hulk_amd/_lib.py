@@ -28,6 +28,7 @@ HULK_CWS_EXTERNAL = 1
 HULK_FLAG_GAMMA_CPYTHON, HULK_FLAG_NO_PRUNE, HULK_FLAG_NO_SKIP, HULK_FLAG_SHARD_FULL, HULK_FLAG_NO_OVERLAP, HULK_FLAG_NO_PRERESERVE = 1, 2, 4, 8, 16, 32
 HULK_MAX_BINS = 1 << 20
 HULK_INJECT_NONE, HULK_INJECT_STALE_SEAL, HULK_INJECT_STALE_STAGE = 0, 1, 2
+HULK_DEBUG_TILEMIN, HULK_DEBUG_SCANMAP = 1, 2
 
 # every symbol include/hulk_hip.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = (
@@ -38,7 +39,7 @@ ABI_SYMBOLS = (
     "hulk_get_cws_tables", "hulk_smash", "hulk_smash_ex", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
     "hulk_parse_files", "hulk_sketch_files", "hulk_parse_files_opts", "hulk_sketch_files_opts", "hulk_get_scan_stats", "hulk_synchronize",
     "hulk_comm_unique_id", "hulk_comm_init", "hulk_comm_init_host", "hulk_comm_init_loopback", "hulk_step_sharded", "hulk_step_sharded_host",
-    "hulk_step_sliced", "hulk_gather_sketch", "hulk_get_comm_stats", "hulk_get_comm_health", "hulk_debug_inject",
+    "hulk_step_sliced", "hulk_gather_sketch", "hulk_get_comm_stats", "hulk_get_comm_health", "hulk_debug_inject", "hulk_debug_read",
 )
 
 
@@ -232,5 +233,6 @@ def load():
     L.hulk_get_comm_stats.restype = ctypes.c_int; L.hulk_get_comm_stats.argtypes = [vp, vp, vp, vp]
     L.hulk_get_comm_health.restype = ctypes.c_int; L.hulk_get_comm_health.argtypes = [vp, vp, vp]
     L.hulk_debug_inject.restype = ctypes.c_int; L.hulk_debug_inject.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64]
+    L.hulk_debug_read.restype = ctypes.c_int; L.hulk_debug_read.argtypes = [vp, ctypes.c_uint32, vp, vp]
     _lib = L
     return L

@@ -584,6 +584,22 @@ int hulk_get_scan_stats(hulk_ctx *c, uint64_t *tiles_visited, uint64_t *tiles_to
     return HULK_OK;
 }
 
+int hulk_debug_read(hulk_ctx *c, uint32_t what, void *out, uint64_t *bytes_io) {
+    if (!c || !out || !bytes_io) return fail(c, HULK_ERR_ARG, "NULL");
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
+    const size_t groups = (c->slots + SCAN_ROWS - 1) / SCAN_ROWS, wtiles = (size_t)c->ntiles * 4;
+    const void *src = nullptr; size_t need = 0;
+    if (what == HULK_DEBUG_TILEMIN) { src = c->d_tilemin; need = groups * wtiles * SCAN_ROWS * sizeof(float); }
+    else if (what == HULK_DEBUG_SCANMAP) { src = c->d_scanmap; need = groups * ((wtiles + 63) / 64) * 8; }
+    else return fail(c, HULK_ERR_ARG, "hulk_debug_read: what");
+    const uint64_t cap = *bytes_io;
+    *bytes_io = need;
+    if (cap < need) return fail(c, HULK_ERR_ARG, "hulk_debug_read: buffer too small");
+    HIPCHK(c, hipMemcpyAsync(out, src, need, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HULK_OK;
+}
+
 int hulk_synchronize(hulk_ctx *c) {
     if (!c) return HULK_ERR_ARG;
     return sync_all(c);

@@ -223,6 +223,15 @@ class GpuSketcher:
         return {"steps_delta": a.value, "steps_full": b.value, "bytes_received": c.value,
                 "headers_refetched": h.value, "void_blocks": v.value}
 
+    def debug_read(self, what: int):
+        """Test hook (hulk_debug_read): HULK_DEBUG_TILEMIN -> float32 array, HULK_DEBUG_SCANMAP -> uint64 array."""
+        n = ctypes.c_uint64(0)
+        buf = np.zeros(1, dtype=np.uint8)
+        self._L.hulk_debug_read(self._ctx, what, buf.ctypes.data, ctypes.byref(n))       # (too small: reports the size)
+        buf = np.zeros(n.value, dtype=np.uint8)
+        self._chk(self._L.hulk_debug_read(self._ctx, what, buf.ctypes.data, ctypes.byref(n)))
+        return buf.view(np.float32 if what == _lib.HULK_DEBUG_TILEMIN else np.uint64)
+
     def debug_inject(self, what: int, step: int):
         """Test hook (hulk_debug_inject): make this rank's header block of `step` void / its host staging late."""
         self._chk(self._L.hulk_debug_inject(self._ctx, what, step))

@@ -326,6 +326,13 @@ int hulk_get_comm_health(hulk_ctx *ctx, uint64_t *refetched, uint64_t *void_bloc
 #define HULK_INJECT_STALE_SEAL 1u
 #define HULK_INJECT_STALE_STAGE 2u
 int hulk_debug_inject(hulk_ctx *ctx, uint32_t what, uint64_t step);
+/* Test hook: internal buffers of the CWS scan as the latest flush left them (after a synchronisation).
+ *   HULK_DEBUG_TILEMIN  float[slot groups][wave tiles][8]: the fp32 tile minima of the batch (no concept drift: plane 0)
+ *   HULK_DEBUG_SCANMAP  uint64[slot groups][(wave tiles + 63) / 64]: which tiles the scan read
+ * *bytes_io: capacity of `out` in, bytes written out (HULK_ERR_ARG if too small; the size needed is returned in it). */
+#define HULK_DEBUG_TILEMIN 1u
+#define HULK_DEBUG_SCANMAP 2u
+int hulk_debug_read(hulk_ctx *ctx, uint32_t what, void *out, uint64_t *bytes_io);
 
 /* Test hook: add counts to the current k-mer spectrum directly (host uint32[num_bins]). */
 int hulk_add_histogram(hulk_ctx *ctx, const uint32_t *bins);

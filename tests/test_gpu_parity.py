@@ -2,6 +2,7 @@
 Bar: histogram / counters / count-min counters / `mins` bit-exact; `weights` within 1e-9
 relative (north-star tolerance is 1e-5; fp64 literal re-evaluation does far better)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ from oracle import pyorc
 pytestmark = pytest.mark.gpu
 
 WEIGHT_RTOL = 1e-9
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def gpu():
@@ -884,3 +886,42 @@ def test_bin_reads_at_first_spectrum_any_order():
     assert np.array_equal(g.cms(), o.cms())
     assert_same_sketch(o, g)
     g.close(); o.close()
+
+
+def test_two_vector_scan_gives_the_tile_minima_of_the_per_interval_products():
+    """k_cws_scan<2> forms min_t K * rcp_t as min(K * max_t rcp_t, K * min_t rcp_t) (a rounded fp32 product is monotone in either
+    factor): its tile minima must equal, bit for bit, those of the loop over the batch's T reciprocal vectors (k_cws_scan<1>,
+    HULK_SCAN_MERGE_LOOP in the profiling build) — and the sketch that of the per-interval path (HULK_SCAN_PER_INTERVAL).
+    The switches are read once per process: one child process per variant, every tile read (HULK_FLAG_NO_PRUNE)."""
+    import subprocess
+    import sys
+    import tempfile
+    exp = os.path.join(ROOT, "hulk_amd", "csrc", "libhulkhip_exp.so")
+    if not os.path.exists(exp):
+        pytest.skip("profiling build (make -C hulk_amd/csrc EXPERIMENTS=1) not present")
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, hulk_amd\n"
+        "from hulk_amd import _lib, synth\n"
+        "bases, offsets = synth.reads_numpy(3, 26000, 150)\n"
+        "g = hulk_amd.GpuSketcher(17, 9, 40, interval=2000, batch=8, flags=_lib.HULK_FLAG_NO_PRUNE)\n"
+        "g.add_reads(bases, offsets); g.finish()\n"
+        "m, w = g.sketch()\n"
+        "np.savez(sys.argv[1], mins=m, weights=w, tilemin=g.debug_read(_lib.HULK_DEBUG_TILEMIN), scanmap=g.debug_read(_lib.HULK_DEBUG_SCANMAP))\n"
+        "g.close()\n")
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for label, extra in (("two_vector", {}), ("loop", {"HULK_SCAN_MERGE_LOOP": "1"}), ("per_interval", {"HULK_SCAN_PER_INTERVAL": "1"}),
+                             ("grid", {"HULK_SCAN_GRID": "1"})):
+            p = os.path.join(td, label + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, p], env=dict(os.environ, HULK_LIB="exp", **extra), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            out[label] = dict(np.load(p))
+    a, b = out["two_vector"], out["loop"]
+    assert np.array_equal(a["scanmap"], b["scanmap"]) and a["scanmap"].any()
+    assert a["tilemin"].view(np.uint32).tolist() == b["tilemin"].view(np.uint32).tolist() or np.array_equal(a["tilemin"], b["tilemin"], equal_nan=True)
+    assert np.isfinite(a["tilemin"]).any()
+    assert np.array_equal(out["grid"]["tilemin"], a["tilemin"], equal_nan=True)       # list form == grid form
+    for label in ("loop", "per_interval", "grid"):
+        assert np.array_equal(out[label]["mins"], a["mins"]) and np.array_equal(out[label]["weights"], a["weights"]), label

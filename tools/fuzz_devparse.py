@@ -56,8 +56,12 @@ def soup(n_lines, kind):
 
 
 t_start = time.time()
+budget = float(os.environ.get("FUZZ_SECONDS", 0))                    # stop after this many seconds (the summary counts the cases done)
 with tempfile.TemporaryDirectory() as td:
     for case in range(n_cases):
+        if budget and time.time() - t_start > budget:
+            n_cases = case
+            break
         kind = int(rng.choice([0, 0, 1, 1, 2]))
         paths = []
         for f in range(int(rng.integers(1, 4))):

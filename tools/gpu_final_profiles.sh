@@ -2,7 +2,7 @@
 export HULK_LIB=${HULK_LIB:-exp}    # the profiling build: HULK_NO_OVERLAP and the other experiment switches exist only there (make EXPERIMENTS=1)
 # alone; every kernel alone with the CWS bounds really off), PMC json, bench line.   gpurun -- 'bash tools/gpu_final_profiles.sh'
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-R=${R:-r04}
+R=${R:-r05}
 O=$GRAFT_REPO_ROOT/gpurun_out/final_$R; rm -rf $O; mkdir -p $O
 run() { # name, bench args, env...
   name=$1; args=$2; shift; shift
