@@ -995,6 +995,21 @@ def main():
         run_leg("unpruned", unpruned, collective=True)
     elif args.no_prune:
         out["value_unpruned"] = value
+    # ---- leg `scan_unpruned`: the one HBM-bound kernel of the path priced on a FULL pass: HULK_FLAG_NO_PRUNE + NO_OVERLAP
+    # (k_cws_scan alone, bracketed by HIP events on its stream): 4 * slots * k^4 bytes of K32 + the two reciprocal vectors
+    # per launch over its average duration (profiles/r05_kernel_stats_serial_noprune.md holds the same figure from rocprofv3)
+    if not single and plain_single and rank == 0:
+        def scan_unpruned():
+            p = run_pass(False, brackets=1, serial=True, n_steps=min(steps, 10))
+            n_l, ms_ = p["prof"]["k_cws_scan"]
+            bytes_ = 4.0 * sc * (((K ** 4 + 1023) // 1024) * 1024) + 2 * 4.0 * (K ** 4)
+            avg = (ms_ / 1e3) / max(n_l, 1)
+            assert np.array_equal(p["mins"], mins) and np.array_equal(p["weights"], weights)
+            out["roofline_cws_scan_unpruned"] = {"bound": "hbm", "kernel": "k_cws_scan_list<2> (every tile of K32 read: HULK_FLAG_NO_PRUNE)",
+                                                 "achieved": bytes_ / avg / 1e9 if avg > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": (bytes_ / avg / 1e9 / HBM_PEAK_GBS) if avg > 0 else 0.0, "traffic": None,
+                                                 "launches": int(n_l), "avg_launch_us": avg * 1e6, "alg_bytes_per_launch": bytes_}
+        run_leg("scan_unpruned", scan_unpruned)
     # ---- leg `long`: the timed pass again with >= 200 steps (the 20 steps of the headline still carry the tail of the clock
     # ramp of their own pass: --steps 20 / 100 / 400 gave 0.9946 / 0.9863 / 0.9842 ms per step in round 3)
     if not single and not args.no_long and LONG_STEPS > steps:

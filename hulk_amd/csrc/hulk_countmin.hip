@@ -39,13 +39,11 @@ __global__ __launch_bounds__(256) void k_count_used(const uint32_t *__restrict__
 // Here every array is read in BIN order (coalesced) and the 7 x 2000 running counters live in LDS:
 //   k_cms_segsum : per (spectrum, row, bin segment) sums per counter            (LDS atomics)
 //   k_cms_base   : counter value in front of every (spectrum, segment)          (tiny prefix kernel)
-//   k_cms_freq   : one workgroup per (segment, spectrum): waves 0..6 replay their row in bin order —
-//                  est = ctr[pos] + (own + earlier same-counter bins of the 64-bin chunk, followed
-//                  through a static "previous lane with the same counter" table) — wave 7 takes the
-//                  minimum over the rows, writes f / 1/f and wipes the spectrum.  No est arrays at all.
+//   k_cms_freq   : one workgroup per (segment, spectrum): waves 0..6 replay their row in bin order — one returning LDS
+//                  atomic add per (row, bin): the LDS itself applies same-counter lanes in bin order — and meet in an LDS
+//                  minimum per bin; wave 7 writes f / 1/f and wipes the spectrum.  No est arrays at all.
 // ------------------------------------------------------------------------------------------
 constexpr int CMS_SEGS = 16;          // bin segments per spectrum
-constexpr int CMS_GROUP = 4;          // 64-bin chunks staged per barrier
 
 __global__ __launch_bounds__(512) void k_cms_segsum(const uint32_t *__restrict__ hists,
                                                     const uint16_t *__restrict__ pos16,
@@ -107,14 +105,14 @@ __global__ __launch_bounds__(256) void k_cms_base(const uint32_t *__restrict__ s
 }
 
 __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
-                                                  const uint8_t *__restrict__ meta8,
                                                   const unsigned long long *__restrict__ base,
                                                   double *__restrict__ f64, float *__restrict__ rcp32,
                                                   int depth, int width, int seg_chunks, size_t row_stride,
                                                   DevState *st, FlushBatch fb) {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int FG = 8, GB = FG * 64;                                          // chunks of 64 bins per barrier
     unsigned long long *lctr = (unsigned long long *)smem;                       // [depth][width]
-    unsigned long long *stage = lctr + (size_t)depth * width;                    // [2][depth][CMS_GROUP*64]
+    unsigned long long *smin = lctr + (size_t)depth * width;                     // [2][GB] minimum over the rows
     const int seg = blockIdx.x, t = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;                  // waves 0..depth-1: rows; wave depth: combiner
     const uint32_t gomask = batch_gomask(st, fb);
@@ -139,64 +137,58 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
             const int dd = i / width, p = i - dd * width;
             lctr[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];
         }
+        for (int i = tid; i < 2 * GB; i += blockDim.x) smin[i] = ~0ull;
     }
     __syncthreads();
     uint32_t *hist = hists + (size_t)slot * B;
     double *ft = f64 + (size_t)t * B;
     float *rt = rcp32 + (size_t)t * row_stride;
     const int64_t b0 = (int64_t)seg * seg_chunks * 64;
-    const int ngroups = (seg_chunks + CMS_GROUP - 1) / CMS_GROUP;
-    constexpr int GB = CMS_GROUP * 64;
-    // software pipeline: the loads of group g+1 are issued before group g is processed
+    const int ngroups = (seg_chunks + FG - 1) / FG;
     const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
-    const uint8_t *md = meta8 + (size_t)(d < depth ? d : 0) * B;
-    uint32_t nh[CMS_GROUP], np_[CMS_GROUP], nm[CMS_GROUP];
-    auto load_group = [&](int g) {
+    unsigned long long *rc = lctr + (size_t)(d < depth ? d : 0) * width;
+    // The LDS keeps the bin order by itself: ds_add_rtn_u64 returns the counter as it stood before this lane's add, same-
+    // address lanes of one instruction are applied in ascending lane order, a wave's instructions in program order
+    // (tools/ubench/lds_atomic_order.hip) — est = old + own count is the reference's counter after Add (countmin.go:122-127).
+    // The rows meet in one LDS minimum per bin; the combiner wave is one group behind.  (Until round 5: a static "previous
+    // lane on the same counter" table followed with register exchanges, per-row staging, 4 chunks per barrier: 117 us.)
+    uint32_t nh[FG], np_[FG];
+    auto fetch = [&](int g) {
 #pragma unroll
-        for (int c = 0; c < CMS_GROUP; c++) {
-            const int ch = g * CMS_GROUP + c;
+        for (int c = 0; c < FG; c++) {
+            const int ch = g * FG + c;
             const int64_t b = b0 + (int64_t)ch * 64 + lane;
-            const bool ok = g < ngroups && ch < seg_chunks && b < (int64_t)B;
-            nh[c] = ok ? hist[b] : 0u;
-            if (d < depth) { np_[c] = ok ? pd[b] : 0u; nm[c] = ok ? md[b] : (64u | 0x80u); }
+            nh[c] = 0; np_[c] = 0;
+            if (ch < seg_chunks && b < (int64_t)B) { nh[c] = hist[b]; if (d < depth) np_[c] = pd[b]; }
         }
     };
-    load_group(0);
-    uint32_t ph[CMS_GROUP];                                      // combiner: spectrum values of the group it finishes next
+    fetch(0);
+    uint32_t ph[FG];                                            // combiner: spectrum values of the group it finishes next
 #pragma unroll
-    for (int c = 0; c < CMS_GROUP; c++) ph[c] = 0;
+    for (int c = 0; c < FG; c++) ph[c] = 0;
     for (int g = 0; g <= ngroups; g++) {
-        // rows: stage group g        combiner: finish group g-1
-        uint32_t hh[CMS_GROUP], pp[CMS_GROUP], mm[CMS_GROUP];
+        uint32_t hh[FG], pp[FG];
 #pragma unroll
-        for (int c = 0; c < CMS_GROUP; c++) { hh[c] = nh[c]; pp[c] = np_[c]; mm[c] = nm[c]; }
-        load_group(g + 1);
+        for (int c = 0; c < FG; c++) { hh[c] = nh[c]; pp[c] = np_[c]; }
+        if (g + 1 < ngroups) fetch(g + 1);
         if (d < depth && g < ngroups) {
-            unsigned long long *my = stage + ((size_t)(g & 1) * depth + d) * GB;
-            unsigned long long *rc = lctr + (size_t)d * width;
+            unsigned long long *my = smin + (size_t)(g & 1) * GB;
 #pragma unroll
-            for (int c = 0; c < CMS_GROUP; c++) {
-                const int ch = g * CMS_GROUP + c;
-                if (ch >= seg_chunks) break;
-                const uint32_t h = hh[c], p = pp[c];
-                // The LDS keeps the bin order by itself: ds_add_rtn_u64 returns the counter as it stood before this lane's add,
-                // same-address lanes of one instruction are applied in ascending lane order, a wave's instructions in program
-                // order (tools/ubench/lds_atomic_order.hip).  (Until round 5 the lanes followed a static "previous lane on the
-                // same counter" table with register exchanges, then read and wrote the counter: 117 us per 16 spectra at k = 21.)
-                if (h) my[c * 64 + lane] = atomicAdd(&rc[p], (unsigned long long)h) + h;
+            for (int c = 0; c < FG; c++) {
+                const uint32_t h = hh[c];
+                if (h) atomicMin(&my[c * 64 + lane], atomicAdd(&rc[pp[c]], (unsigned long long)h) + h);
             }
         }
         if (d == depth && g > 0) {
-            const unsigned long long *src = stage + ((size_t)((g - 1) & 1) * depth) * GB;
+            unsigned long long *src = smin + (size_t)((g - 1) & 1) * GB;
 #pragma unroll
-            for (int c = 0; c < CMS_GROUP; c++) {
-                const int ch = (g - 1) * CMS_GROUP + c;
-                if (ch >= seg_chunks) break;
+            for (int c = 0; c < FG; c++) {
+                const int ch = (g - 1) * FG + c;
                 const int64_t b = b0 + (int64_t)ch * 64 + lane;
-                if (b < (int64_t)B) {
+                if (ch < seg_chunks && b < (int64_t)B) {
                     if (ph[c]) {
-                        unsigned long long mn = ~0ull;
-                        for (int dd = 0; dd < depth; dd++) { const unsigned long long e = src[(size_t)dd * GB + c * 64 + lane]; mn = e < mn ? e : mn; }
+                        const unsigned long long mn = src[c * 64 + lane];
+                        src[c * 64 + lane] = ~0ull;
                         const double f = (double)mn;
                         ft[b] = f; rt[b] = (float)(1.0 / f);
                         hist[b] = 0;                                 // Wipe (kmerspectrum.go:58-64)
@@ -205,7 +197,7 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
             }
         }
 #pragma unroll
-        for (int c = 0; c < CMS_GROUP; c++) ph[c] = hh[c];          // group g is finished by the combiner at g+1
+        for (int c = 0; c < FG; c++) ph[c] = hh[c];             // group g is finished by the combiner at g+1
         __syncthreads();
     }
 }
@@ -686,7 +678,7 @@ hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t 
     const int chunks = (fb.num_bins + 63) / 64;
     const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
     const size_t lds1 = (size_t)depth * width * 4;
-    const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * depth * CMS_GROUP * 64 * 8;
+    const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * 8 * 64 * 8;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_cms_freq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
@@ -696,8 +688,9 @@ hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t 
     hipLaunchKernelGGL(k_cms_segsum, dim3(CMS_SEGS, fb.count), dim3(512), lds1, s, d_hists, d_pos16, d_segsum, depth, width,
                        seg_chunks, st, fb);
     hipLaunchKernelGGL(k_cms_base, dim3((depth * width + 255) / 256), dim3(256), 0, s, d_segsum, d_ctr, d_base, depth, width, st, fb);
-    hipLaunchKernelGGL(k_cms_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_meta8, d_base, d_f64,
+    hipLaunchKernelGGL(k_cms_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_base, d_f64,
                        d_rcp32, depth, width, seg_chunks, row_stride, st, fb);
+    (void)d_meta8;
     return hipGetLastError();
 }
 

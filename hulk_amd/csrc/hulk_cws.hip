@@ -965,7 +965,7 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
                            unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap, bool per_interval,
-                           float *d_rmm, uint32_t *d_scanlist, uint32_t *d_scanlist_n) {
+                           float *d_rmm, uint32_t *d_scanlist, uint32_t *d_scanlist_n, hipEvent_t scan_begin, hipEvent_t scan_end) {
     const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
     const int wtiles = ntiles * 4, wwords = (wtiles + 63) / 64;
     const bool grid_form = scan_grid_form();
@@ -978,6 +978,7 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
     if (mode == 2)
         hipLaunchKernelGGL(k_rcp_minmax, dim3((unsigned)((row_stride / 4 + 255) / 256)), dim3(256), 0, s, d_rcp32, d_rmm, row_stride, st, fb);
     const float *rv = mode == 2 ? d_rmm : d_rcp32;
+    if (scan_begin) { const hipError_t e = hipEventRecord(scan_begin, s); if (e != hipSuccess) return e; }   // bench.py: the scan kernel alone
     if (grid_form) {
         const dim3 g((unsigned)(((wwords * 4 + 7) / 8) * 8 * groups));            // units of 16 wave tiles, 8 (one per XCD) side by side
         if (mode == 0) hipLaunchKernelGGL(k_cws_scan<0>, g, dim3(1024), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
@@ -991,6 +992,7 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
         else if (mode == 1) hipLaunchKernelGGL(k_cws_scan_list<1>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n);
         else hipLaunchKernelGGL(k_cws_scan_list<2>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n);
     }
+    if (scan_end) { const hipError_t e = hipEventRecord(scan_end, s); if (e != hipSuccess) return e; }
     return hipGetLastError();
 }
 

@@ -126,7 +126,8 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
                            unsigned long long *d_visited, double drift_dw, unsigned long long *d_scanmap, bool per_interval,
-                           float *d_rmm, uint32_t *d_scanlist, uint32_t *d_scanlist_n);
+                           float *d_rmm, uint32_t *d_scanlist, uint32_t *d_scanlist_n, hipEvent_t scan_begin = nullptr,
+                           hipEvent_t scan_end = nullptr);
 hipError_t launch_tile_kmin(hipStream_t s, const float *d_k32, float *d_kmin32, int slots, int ntiles, size_t row_stride);
 hipError_t launch_slot_kmin(hipStream_t s, const float *d_kmin32, float *d_kminslot, int slots, int ntiles);
 hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, int ncounters, const float *d_kminslot,

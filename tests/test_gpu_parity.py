@@ -904,11 +904,14 @@ def test_two_vector_scan_gives_the_tile_minima_of_the_per_interval_products():
         f"sys.path.insert(0, {ROOT!r})\n"
         "import torch, hulk_amd\n"
         "from hulk_amd import _lib, synth\n"
-        "bases, offsets = synth.reads_numpy(3, 26000, 150)\n"
+        "bases, offsets = synth.reads_numpy(3, 27500, 150)\n"
         "g = hulk_amd.GpuSketcher(17, 9, 40, interval=2000, batch=8, flags=_lib.HULK_FLAG_NO_PRUNE)\n"
-        "g.add_reads(bases, offsets); g.finish()\n"
+        "cut = 16000                                  # exactly one batch of 8 intervals: flushed by this call\n"
+        "g.add_reads(bases[:cut * 150], offsets[:cut + 1])\n"
+        "tm, sm = g.debug_read(_lib.HULK_DEBUG_TILEMIN), g.debug_read(_lib.HULK_DEBUG_SCANMAP)\n"
+        "g.add_reads(bases[cut * 150:], offsets[cut:] - offsets[cut]); g.finish()\n"
         "m, w = g.sketch()\n"
-        "np.savez(sys.argv[1], mins=m, weights=w, tilemin=g.debug_read(_lib.HULK_DEBUG_TILEMIN), scanmap=g.debug_read(_lib.HULK_DEBUG_SCANMAP))\n"
+        "np.savez(sys.argv[1], mins=m, weights=w, tilemin=tm, scanmap=sm)\n"
         "g.close()\n")
     out = {}
     with tempfile.TemporaryDirectory() as td:
