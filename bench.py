@@ -73,7 +73,7 @@ def _newest(*names):
     return os.path.join("profiles", names[-1])
 
 
-PMC_PROFILE = _newest("r04_pmc.json", "r03_pmc.json")
+PMC_PROFILE = _newest("r05_pmc.json", "r04_pmc.json", "r03_pmc.json")
 ISA_MIX = _newest("r04_isa_mix.json", "r03_isa_mix.json")   # tools/isa_mix.py over the production kernels, priced by profiles/r03_op_cost.txt
 LEG_TIMEOUT_S = float(os.environ.get("HULK_BENCH_LEG_TIMEOUT_S", "300"))
 FAIL_LEGS = set(x for x in os.environ.get("HULK_BENCH_FAIL", "").split(",") if x)
@@ -938,7 +938,8 @@ def main():
         out.update({
             "roofline": {"bound": "hbm", "kernel": "k_minimizer_fast", "achieved": k1_ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_ach / HBM_PEAK_GBS,
-                         "traffic": None, "traffic_from_profile": from_profile("k_minimizer_fast", "hbm_bytes_per_launch"),
+                         "traffic": from_profile("k_minimizer_fast", "hbm_bytes_per_launch"),       # PMC passes of the same command, committed (traffic_profile)
+                         "traffic_from_profile": from_profile("k_minimizer_fast", "hbm_bytes_per_launch"),
                          "traffic_profile": PMC_PROFILE if pmc else None,
                          "launches": int(n_k1), "avg_launch_us": k1_avg_s * 1e6,
                          "alg_bytes_per_launch": k1_bytes, "alg_bytes_per_read": READ_LEN + 8,
@@ -949,7 +950,7 @@ def main():
                                            "alone) and every instrumented kernel bracketed by HIP events on the stream it is "
                                            "launched on — the headline pass itself carries no brackets and overlaps its kernels, "
                                            "which stretches each kernel's own duration; rocprofv3 of HULK_NO_OVERLAP=1 bench.py "
-                                           "(profiles/r04_kernel_stats_serial.md) shows the same per-launch figures",
+                                           "(profiles/r05_kernel_stats_serial.md) shows the same per-launch figures",
                          "note": f"single kernels by measured time: k_minimizer_fast {k1_avg_s * 1e6:.1f} us, k_jump_bin "
                                  f"{kj_avg_s * 1e6:.1f} us, k_jump_left {kl_avg_s * 1e6:.1f} us per launch of {reads_per_rank_step} reads "
                                  "(stage K1b = the last two; it has no SURVEY 8(d) bytes — the minimizer list is an artefact of "
@@ -964,7 +965,7 @@ def main():
             "ms_per_step_kernels_alone": instr_pass["elapsed"] / instr_pass["steps"] * 1e3,
             "roofline_cws_scan": {"bound": "hbm", "kernel": "k_cws_scan", "achieved": achieved,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                  "traffic": None, "traffic_from_profile": from_profile("k_cws_scan", "hbm_bytes_per_launch"),
+                                  "traffic": None, "traffic_from_profile": from_profile("k_cws_scan_list", "hbm_bytes_per_launch") or from_profile("k_cws_scan", "hbm_bytes_per_launch"),
                                   "launches": int(n_launch),
                                   "avg_launch_us": avg_s * 1e6, "alg_bytes_per_launch": alg_bytes,
                                   "intervals_per_launch": BATCH, "tiles_read_per_launch": visited,

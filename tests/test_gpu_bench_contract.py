@@ -56,7 +56,7 @@ def test_bench_json_contract_and_collective_path():
     r = a["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # algorithmic bytes = SURVEY.md §8(d)'s per-read figure (L + 8) x the reads of one launch; nothing else priced in
-    assert r["alg_bytes_per_launch"] == a["config"]["reads_per_rank_step"] * (150 + 8) and r["traffic"] is None
+    assert r["alg_bytes_per_launch"] == a["config"]["reads_per_rank_step"] * (150 + 8) and r["traffic"] == r["traffic_from_profile"]     # (PMC passes of the same command: profiles/r05_pmc.json)
     assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
     # the line names the longest single kernel from the durations it measured itself
     assert r["longest_kernel"] == ("k_minimizer_fast" if r["avg_launch_us"] >= a["k_jump_bin"]["avg_launch_us"] else "k_jump_bin")
