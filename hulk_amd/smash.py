@@ -128,7 +128,11 @@ def smash(sketch_dir, out_file, ksize=21, algo="histosketch", metric="jaccard", 
     with open(out_file + ".hulk-matrix.csv", "w", encoding="utf-8", newline="") as fh:
         fh.write(",".join(go_csv_field(f) for f in ordering) + "\n")
         for row in dist:
-            fh.write(",".join(go_format_f2(100 - (d * 100)) for d in row) + "\n")
+            v = 100 - (row * 100)                                  # (elementwise IEEE double arithmetic: the Go expression)
+            if np.isfinite(v).all():                               # FormatFloat(v, 'f', 2, 64) == "%.2f" for finite values
+                fh.write(",".join(["%.2f" % x for x in v.tolist()]) + "\n")
+            else:
+                fh.write(",".join(go_format_f2(x) for x in v.tolist()) + "\n")
     if banner_matrix:
         with open(out_file + ".banner-matrix.csv", "w", encoding="utf-8", newline="") as fh:
             for f, a in zip(ordering, sk):
