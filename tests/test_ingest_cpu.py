@@ -503,3 +503,26 @@ def test_knobs_are_fields_of_the_run_not_of_the_process(tmp_path):
         assert st["n_seqs"] == len(want) and b.tobytes() == body, opts
     with pytest.raises(_lib.HulkError):
         ingest.parse_files([plain], opts={"flags": 1 << 9})
+
+
+def test_ingest_opts_are_validated_like_hulk_params(tmp_path):
+    """Out-of-range fields, unknown flags and non-zero reserved words of hulk_ingest_opts are refused (HULK_ERR_ARG, with the
+    field's name), not clamped — as hulk_create treats hulk_params."""
+    import ctypes
+    from hulk_amd import _lib, ingest
+    plain = write(tmp_path, "v.fq", b"@r\nACGT\n+\nIIII\n")
+    for opts, word in (({"gz_threads": 65}, "gz_threads"), ({"file_readers": 17}, "file_readers"), ({"parser_threads": 257}, "parser_threads"),
+                       ({"block_bytes": 4096}, "block_bytes"), ({"gz_chunk_bytes": 100}, "gz_chunk_bytes"), ({"flags": 1 << 12}, "flags")):
+        with pytest.raises(_lib.HulkError) as e:
+            ingest.parse_files([plain], opts=opts)
+        assert e.value.code == -30 and word in str(e.value), (opts, str(e.value))
+    o = _lib.IngestOpts()
+    o.reserved[1] = 7
+    L = _lib.load()
+    err = ctypes.create_string_buffer(256)
+    arr, n = ingest._path_array([plain])
+    rc = L.hulk_parse_files_opts(arr, n, 0, ctypes.byref(o), ctypes.cast(None, _lib.BATCH_FN), None, None, err, 256)
+    assert rc == -30 and b"reserved" in err.value
+    # the host-parser flag is a known flag (it only matters to hulk_sketch_files)
+    b, off, st = ingest.parse_files([plain], opts={"flags": _lib.HULK_INGEST_HOST_PARSER})
+    assert st["n_seqs"] == 1 and b.tobytes() == b"ACGT"
