@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     "hulk_get_cws_tables", "hulk_smash", "hulk_smash_ex", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
     "hulk_parse_files", "hulk_sketch_files", "hulk_parse_files_opts", "hulk_sketch_files_opts", "hulk_get_scan_stats", "hulk_synchronize",
     "hulk_comm_unique_id", "hulk_comm_init", "hulk_comm_init_host", "hulk_comm_init_loopback", "hulk_step_sharded", "hulk_step_sharded_host",
-    "hulk_step_sliced", "hulk_gather_sketch", "hulk_get_comm_stats", "hulk_get_comm_health", "hulk_debug_inject", "hulk_debug_read",
+    "hulk_step_sliced", "hulk_gather_sketch", "hulk_get_comm_stats", "hulk_get_comm_health", "hulk_debug_inject", "hulk_debug_read", "hulk_release_caches",
 )
 
 
@@ -234,5 +234,6 @@ def load():
     L.hulk_get_comm_health.restype = ctypes.c_int; L.hulk_get_comm_health.argtypes = [vp, vp, vp]
     L.hulk_debug_inject.restype = ctypes.c_int; L.hulk_debug_inject.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64]
     L.hulk_debug_read.restype = ctypes.c_int; L.hulk_debug_read.argtypes = [vp, ctypes.c_uint32, vp, vp]
+    L.hulk_release_caches.restype = ctypes.c_int; L.hulk_release_caches.argtypes = []
     _lib = L
     return L

@@ -566,6 +566,12 @@ int hulk_smash_ex(int device, const uint64_t *mins, const double *weights, uint3
     return HULK_OK;
 }
 
+int hulk_release_caches(void) {
+    { std::lock_guard<std::mutex> lock(g_smash.mu); g_smash.drop(); }
+    hulk::fq_release_idle();
+    return HULK_OK;
+}
+
 int hulk_smash(int device, const uint64_t *mins, const double *weights, uint32_t n_sketches, uint32_t sketch_size,
                int metric, double *distances) {
     return hulk_smash_ex(device, mins, weights, n_sketches, sketch_size, metric, distances, nullptr);

@@ -1603,6 +1603,15 @@ static void fq_dev_release(FqDev *d) {
     }
     FqDev::destroy(d);
 }
+}  // namespace
+namespace hulk {
+void fq_release_idle() {
+    std::vector<FqDev *> drop;
+    { std::lock_guard<std::mutex> g(g_fq_mu); drop.swap(g_fq_idle); }
+    for (FqDev *d : drop) FqDev::destroy(d);
+}
+}  // namespace hulk
+namespace {
 // a parser for blocks of `block` bytes on the context's device: an idle set of the process, or a new one
 static FqDev *fq_dev_for(hulk_ctx *ctx, size_t block, IngestError &err) {
     const int device = hulk::ctx_device(ctx);

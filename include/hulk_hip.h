@@ -334,6 +334,11 @@ int hulk_debug_inject(hulk_ctx *ctx, uint32_t what, uint64_t step);
 #define HULK_DEBUG_SCANMAP 2u
 int hulk_debug_read(hulk_ctx *ctx, uint32_t what, void *out, uint64_t *bytes_io);
 
+/* Process-level buffers the library keeps between calls — the device FASTQ parser's pinned and device blocks (hulk_sketch_files:
+ * about 130 MB pinned, 250 MB of HBM per set, at most two sets) and hulk_smash's device arrays — are freed; the next call that
+ * needs them allocates again.  Call it with no hulk_sketch_files / hulk_smash in flight on another thread. */
+int hulk_release_caches(void);
+
 /* Test hook: add counts to the current k-mer spectrum directly (host uint32[num_bins]). */
 int hulk_add_histogram(hulk_ctx *ctx, const uint32_t *bins);
 

@@ -101,3 +101,39 @@ def test_fasta_and_errors(tmp_path):
         d.sketch_files([bad])
     assert e.value.message == "read ID in fastq file does not begin with @: r1"
     d.close()
+
+
+def test_device_parser_host_parser_and_released_caches_agree(tmp_path):
+    """hulk_sketch_files with the FASTQ line machine on the device (the default), on the host's parser threads
+    (HULK_INGEST_HOST_PARSER) and again on the device after hulk_release_caches() dropped the process's buffers: the same
+    reads, lines and sketch.  Records straddle 128 KiB blocks; CR/LF line ends, empty lines between records, an unterminated last
+    line; a second input continues the slot machine of the first."""
+    from hulk_amd import _lib, synth
+    rng = np.random.default_rng(12)
+    bases, _ = synth.reads_numpy(5, 30000, 150)
+    raw = bases[:30000 * 150].tobytes()
+    recs = []
+    for i in range(30000):
+        eol = b"\r\n" if i % 7 == 0 else b"\n"
+        recs.append(b"@read%d some text" % i + eol + raw[i * 150:(i + 1) * 150] + eol + b"+" + eol + b"I" * 150 + eol)
+        if i % 1000 == 3:
+            recs.append(eol * int(rng.integers(1, 4)))                     # empty lines are skipped in front of a header
+    half = len(recs) // 2
+    p1, p2 = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")
+    open(p1, "wb").write(b"".join(recs[:half]).rstrip(b"\r\n"))          # the first input's last line is not terminated
+    open(p2, "wb").write(b"".join(recs[half:]))
+    from oracle import linepump
+    want = linepump.sequences([p1, p2])
+    res = []
+    for flags, release in ((0, False), (_lib.HULK_INGEST_HOST_PARSER, False), (0, True)):
+        if release:
+            assert _lib.load().hulk_release_caches() == 0
+        g = gpu().GpuSketcher(21, 9, 64, interval=4000)
+        st = g.sketch_files([p1, p2], opts={"flags": flags, "block_bytes": 131072})
+        g.finish()
+        res.append((st["n_seqs"], st["total_len"], st["n_lines"], g.sketch(), g.counters()))
+        g.close()
+    assert res[0][0] == len(want) and res[0][1] == sum(len(s) for s in want)
+    for r in res[1:]:
+        assert r[:3] == res[0][:3] and r[4] == res[0][4]
+        assert np.array_equal(r[3][0], res[0][3][0]) and np.array_equal(r[3][1], res[0][3][1])
