@@ -33,6 +33,17 @@ def test_fuzz_slice_of_the_multi_rank_protocol(full):
     assert "0 mismatches" in p.stdout
 
 
+def test_fuzz_slice_of_the_multi_rank_protocol_with_sixteen_hardware_queues():
+    """The same slice with GPU_MAX_HW_QUEUES=16 — the setting under which round 4 met a void exchange header once per ~20
+    runs.  The exchange now runs on the flush stream with sealed, self-checking headers: the sketches must match and the
+    summary line must carry the header-health counters (hulk_get_comm_health over every rank of every case)."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_shard.py"), "30", "16"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "0 mismatches" in p.stdout and "void blocks: 0" in p.stdout
+
+
 def test_fuzz_slice_of_the_device_fastq_parser():
     """tools/fuzz_devparse.py: hulk_sketch_files with the line machine on the GPU (hulk_fastq.hip) and, beside it, on the host
     (HULK_INGEST_HOST_PARSER), against oracle/linepump.py: line soups with empty lines, CR/LF, stray headers, 64 KiB lines,
