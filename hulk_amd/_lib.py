@@ -20,12 +20,12 @@ if os.environ.get("HULK_LIB"):
     LIB_PATH = EXP_LIB_PATH if os.environ["HULK_LIB"] == "exp" else os.environ["HULK_LIB"]
 
 HULK_OK = 0
-HULK_ABI_VERSION = 3            # include/hulk_hip.h; load() refuses a libhulkhip.so built from another version of the header
+HULK_ABI_VERSION = 4            # include/hulk_hip.h; load() refuses a libhulkhip.so built from another version of the header
 HULK_UNIQUE_ID_BYTES = 128
 HULK_XCHG_ALLGATHER, HULK_XCHG_ALLREDUCE_U32 = 0, 1
 HULK_CWS_GO_COMPAT = 0
 HULK_CWS_EXTERNAL = 1
-HULK_FLAG_GAMMA_CPYTHON, HULK_FLAG_NO_PRUNE, HULK_FLAG_NO_SKIP, HULK_FLAG_SHARD_FULL, HULK_FLAG_NO_OVERLAP, HULK_FLAG_NO_PRERESERVE = 1, 2, 4, 8, 16, 32
+HULK_FLAG_GAMMA_CPYTHON, HULK_FLAG_NO_PRUNE, HULK_FLAG_NO_SKIP, HULK_FLAG_SHARD_FULL, HULK_FLAG_NO_OVERLAP, HULK_FLAG_NO_PRERESERVE, HULK_FLAG_CMS_CHAIN = 1, 2, 4, 8, 16, 32, 64
 HULK_MAX_BINS = 1 << 20
 HULK_INJECT_NONE, HULK_INJECT_STALE_SEAL, HULK_INJECT_STALE_STAGE = 0, 1, 2
 HULK_DEBUG_TILEMIN, HULK_DEBUG_SCANMAP = 1, 2
@@ -39,8 +39,12 @@ ABI_SYMBOLS = (
     "hulk_get_cws_tables", "hulk_smash", "hulk_smash_ex", "hulk_selftest_reciprocal", "hulk_set_profiling", "hulk_get_profile",
     "hulk_parse_files", "hulk_sketch_files", "hulk_parse_files_opts", "hulk_sketch_files_opts", "hulk_get_scan_stats", "hulk_synchronize",
     "hulk_comm_unique_id", "hulk_comm_init", "hulk_comm_init_host", "hulk_comm_init_loopback", "hulk_step_sharded", "hulk_step_sharded_host",
-    "hulk_step_sliced", "hulk_gather_sketch", "hulk_get_comm_stats", "hulk_get_comm_health", "hulk_debug_inject", "hulk_debug_read", "hulk_release_caches",
+    "hulk_step_sliced", "hulk_gather_sketch", "hulk_get_comm_stats", "hulk_get_comm_health", "hulk_release_caches", "hulk_get_device_checks", "hulk_get_profile_table",
+    "hulk_load_sketches", "hulk_sketch_set_free", "hulk_sketch_set_info", "hulk_sketch_set_mins", "hulk_sketch_set_weights", "hulk_sketch_set_path",
+    "hulk_sketch_set_banner", "hulk_smash_files",
 )
+# test hooks: exported by the profiling build only (make -C hulk_amd/csrc EXPERIMENTS=1; HULK_LIB=exp)
+EXPERIMENT_SYMBOLS = ("hulk_debug_inject", "hulk_debug_read")
 
 
 class HulkParams(ctypes.Structure):
@@ -73,6 +77,11 @@ BATCH_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes
                             ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint64)
 # hulk_exchange_fn: (user, op, send, recv, bytes) -> 0 on success
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
+
+
+class SmashStats(ctypes.Structure):
+    _fields_ = [("seconds_load", ctypes.c_double), ("seconds_matrix", ctypes.c_double), ("seconds_csv", ctypes.c_double),
+                ("kernel_ms", ctypes.c_double), ("n_sketches", ctypes.c_uint32), ("sketch_size", ctypes.c_uint32)]
 
 
 class HulkError(RuntimeError):
@@ -232,8 +241,28 @@ def load():
     L.hulk_gather_sketch.restype = ctypes.c_int; L.hulk_gather_sketch.argtypes = [vp, vp, vp]
     L.hulk_get_comm_stats.restype = ctypes.c_int; L.hulk_get_comm_stats.argtypes = [vp, vp, vp, vp]
     L.hulk_get_comm_health.restype = ctypes.c_int; L.hulk_get_comm_health.argtypes = [vp, vp, vp]
-    L.hulk_debug_inject.restype = ctypes.c_int; L.hulk_debug_inject.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64]
-    L.hulk_debug_read.restype = ctypes.c_int; L.hulk_debug_read.argtypes = [vp, ctypes.c_uint32, vp, vp]
+    if hasattr(L, "hulk_debug_inject"):                 # the profiling build (hulk_build_info ends in " experiments=1")
+        L.hulk_debug_inject.restype = ctypes.c_int; L.hulk_debug_inject.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint64]
+        L.hulk_debug_read.restype = ctypes.c_int; L.hulk_debug_read.argtypes = [vp, ctypes.c_uint32, vp, vp]
+    cpp = ctypes.POINTER(ctypes.c_char_p)
+    L.hulk_load_sketches.restype = ctypes.c_int
+    L.hulk_load_sketches.argtypes = [cpp, u32, u32, ctypes.c_char_p, u32, ctypes.POINTER(vp), ctypes.c_char_p, u64]
+    L.hulk_sketch_set_free.restype = None; L.hulk_sketch_set_free.argtypes = [vp]
+    L.hulk_sketch_set_info.restype = ctypes.c_int; L.hulk_sketch_set_info.argtypes = [vp, vp, vp]
+    L.hulk_sketch_set_mins.restype = vp; L.hulk_sketch_set_mins.argtypes = [vp]
+    L.hulk_sketch_set_weights.restype = vp; L.hulk_sketch_set_weights.argtypes = [vp]
+    L.hulk_sketch_set_path.restype = ctypes.c_char_p; L.hulk_sketch_set_path.argtypes = [vp, u32]
+    L.hulk_sketch_set_banner.restype = ctypes.c_char_p; L.hulk_sketch_set_banner.argtypes = [vp, u32]
+    L.hulk_smash_files.restype = ctypes.c_int
+    L.hulk_smash_files.argtypes = [ctypes.c_int, cpp, u32, u32, ctypes.c_char_p, ctypes.c_char_p, u32, ctypes.c_char_p, ctypes.c_char_p, vp,
+                                   ctypes.POINTER(SmashStats), ctypes.c_char_p, u64]
+    L.hulk_get_device_checks.restype = ctypes.c_int; L.hulk_get_device_checks.argtypes = [vp, vp, vp]
+    L.hulk_get_profile_table.restype = ctypes.c_int; L.hulk_get_profile_table.argtypes = [vp, ctypes.c_char_p, u64]
     L.hulk_release_caches.restype = ctypes.c_int; L.hulk_release_caches.argtypes = []
     _lib = L
     return L
+
+
+def is_experiments_build() -> bool:
+    """True when the loaded library is the profiling build (libhulkhip_exp.so: experiment switches and test hooks compiled in)."""
+    return b"experiments=1" in load().hulk_build_info()

@@ -70,7 +70,12 @@ int hulk_abi_version(void) { return HULK_ABI_VERSION; }
 #ifndef HULK_HIPCC_VERSION
 #define HULK_HIPCC_VERSION "unknown"
 #endif
-const char *hulk_build_info(void) { return "abi=3 arch=gfx950 sources=" HULK_SOURCE_HASH " hipcc=" HULK_HIPCC_VERSION; }
+#ifdef HULK_EXPERIMENTS
+#define HULK_BUILD_KIND " experiments=1"
+#else
+#define HULK_BUILD_KIND ""
+#endif
+const char *hulk_build_info(void) { return "abi=4 arch=gfx950 sources=" HULK_SOURCE_HASH " hipcc=" HULK_HIPCC_VERSION HULK_BUILD_KIND; }
 const char *hulk_strerror(int status) { return err_text(status); }
 const char *hulk_last_error(const hulk_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
 
@@ -91,7 +96,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     // the binning kernels pack (spectrum slot << 20 | bin) into a dword (hulk_spectrum.hip); k^4 <= 31^4 < 2^20
     if (bins > (int64_t)HULK_MAX_BINS)
         return fail(nullptr, HULK_ERR_ARG, "num_bins " + std::to_string(bins) + " exceeds HULK_MAX_BINS (2^20; k^4 at k = 31 is 923521)");
-    if (p.flags & ~(HULK_FLAG_GAMMA_CPYTHON | HULK_FLAG_NO_PRUNE | HULK_FLAG_NO_SKIP | HULK_FLAG_SHARD_FULL | HULK_FLAG_NO_OVERLAP | HULK_FLAG_NO_PRERESERVE))
+    if (p.flags & ~(HULK_FLAG_GAMMA_CPYTHON | HULK_FLAG_NO_PRUNE | HULK_FLAG_NO_SKIP | HULK_FLAG_SHARD_FULL | HULK_FLAG_NO_OVERLAP | HULK_FLAG_NO_PRERESERVE | HULK_FLAG_CMS_CHAIN))
         return fail(nullptr, HULK_ERR_ARG, "unknown flags");
     if (p.batch > (uint32_t)SCAN_BATCH_MAX) return fail(nullptr, HULK_ERR_ARG, "batch must be 0 (default) or 1..16");
     if (p.work_lanes > 2) return fail(nullptr, HULK_ERR_ARG, "work_lanes must be 0 (default), 1 or 2");
@@ -121,6 +126,13 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
 
 #define CHK_CREATE(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int rc_ = fail_hip(nullptr, e_, #call); hulk_destroy(c); return rc_; } } while (0)
     CHK_CREATE(hipSetDevice(p.device));
+    {   // the count-min replay takes the value a returning LDS atomic hands back as "the counter before this bin": checked on
+        // the device, once per process and device; where it does not hold (or on request) the chain-form kernels run
+        const int ord = lds_order_verified(p.device);
+        if (ord < 0) { const int rc_ = fail_hip(nullptr, (hipError_t)(-ord), "LDS atomic-order self-test"); hulk_destroy(c); return rc_; }
+        c->lds_order_ok = ord == 1;
+        c->cms_chain = !c->lds_order_ok || (p.flags & HULK_FLAG_CMS_CHAIN) != 0;
+    }
     CHK_CREATE(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     const size_t B = (size_t)c->B, S = c->S, SL = c->slots;
@@ -224,6 +236,7 @@ void hulk_destroy(hulk_ctx *c) {
     if (c->ev_binned) hipEventDestroy(c->ev_binned);
     for (int i = 0; i < 2; i++) if (c->ev_flushed[i]) hipEventDestroy(c->ev_flushed[i]);
     for (auto &pr : c->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
+    for (auto &m : c->marks) hipEventDestroy(m.e);
     hipFree(c->d_state); hipFree(c->d_hist); hipFree(c->d_hist_tmp);
     hipFree(c->d_meta8); hipFree(c->d_segsum); hipFree(c->d_cbase);
     hipFree(c->d_segadd); hipFree(c->d_segfac); hipFree(c->d_cstart); hipFree(c->d_sege0);
@@ -590,6 +603,7 @@ int hulk_get_scan_stats(hulk_ctx *c, uint64_t *tiles_visited, uint64_t *tiles_to
     return HULK_OK;
 }
 
+#ifdef HULK_EXPERIMENTS
 int hulk_debug_read(hulk_ctx *c, uint32_t what, void *out, uint64_t *bytes_io) {
     if (!c || !out || !bytes_io) return fail(c, HULK_ERR_ARG, "NULL");
     { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
@@ -605,6 +619,14 @@ int hulk_debug_read(hulk_ctx *c, uint32_t what, void *out, uint64_t *bytes_io) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HULK_OK;
 }
+#endif
+
+int hulk_get_device_checks(hulk_ctx *c, uint32_t *lds_order_ok, uint32_t *cms_chain_form) {
+    if (!c) return HULK_ERR_ARG;
+    if (lds_order_ok) *lds_order_ok = c->lds_order_ok ? 1u : 0u;
+    if (cms_chain_form) *cms_chain_form = c->cms_chain ? 1u : 0u;
+    return HULK_OK;
+}
 
 int hulk_synchronize(hulk_ctx *c) {
     if (!c) return HULK_ERR_ARG;
@@ -614,7 +636,35 @@ int hulk_synchronize(hulk_ctx *c) {
 int hulk_set_profiling(hulk_ctx *c, int enabled) {
     if (!c) return HULK_ERR_ARG;
     // 1 (the on/off switch) = every instrumented kernel; otherwise a mask: 2 k_minimizer_fast, 4 k_jump_bin, 8 k_cws_scan, 16 k_cmsd_freq
-    c->profiling = enabled == 1 ? 15 : ((enabled & 6) | ((enabled & 8) ? 1 : 0) | ((enabled & 16) ? 8 : 0));
+    c->profiling = enabled == 1 ? 15 : ((enabled & 6) | ((enabled & 8) ? 1 : 0) | ((enabled & 16) ? 8 : 0) | ((enabled & 32) ? 16 : 0));
+    return HULK_OK;
+}
+
+int hulk_get_profile_table(hulk_ctx *c, char *out, uint64_t cap) {
+    if (!c || !out || cap == 0) return fail(c, HULK_ERR_ARG, "NULL");
+    { int rcs = sync_all(c); if (rcs != HULK_OK) return rcs; }
+    struct Row { const char *k; uint64_t n; double ms; };
+    std::vector<Row> rows;
+    const size_t M = c->marks.size();
+    for (size_t i = 0; i < M; i++) {
+        const ProfMark &a = c->marks[i];
+        if (a.kernel[0] == '-') continue;
+        size_t j = i + 1;
+        while (j < M && c->marks[j].s != a.s) j++;                 // the next mark on the same stream ends this kernel
+        if (j == M) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, a.e, c->marks[j].e) != hipSuccess) continue;
+        size_t r = 0;
+        while (r < rows.size() && strcmp(rows[r].k, a.kernel) != 0) r++;
+        if (r == rows.size()) rows.push_back(Row{a.kernel, 0, 0.0});
+        rows[r].n++; rows[r].ms += ms;
+    }
+    for (auto &m : c->marks) hipEventDestroy(m.e);
+    c->marks.clear();
+    std::string txt;
+    for (const Row &r : rows) { char line[160]; snprintf(line, sizeof line, "%s\t%llu\t%.6f\n", r.k, (unsigned long long)r.n, r.ms); txt += line; }
+    if (txt.size() + 1 > cap) return fail(c, HULK_ERR_ARG, "hulk_get_profile_table: buffer too small");
+    memcpy(out, txt.c_str(), txt.size() + 1);
     return HULK_OK;
 }
 

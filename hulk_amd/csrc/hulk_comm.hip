@@ -39,6 +39,13 @@ Rccl *rccl() {
     }();
     return &R;
 }
+// hulk_debug_inject (test hook of the profiling build; the shipping library has neither the entry point nor the branches)
+#ifdef HULK_EXPERIMENTS
+inline bool injected(const hulk_ctx::Comm &m, uint32_t what) { return m.inject == what && m.inject_step == m.step; }
+#else
+inline bool injected(const hulk_ctx::Comm &, uint32_t) { return false; }
+constexpr uint32_t HULK_INJECT_STALE_SEAL = 1u, HULK_INJECT_STALE_STAGE = 2u;
+#endif
 int fail_nccl(hulk_ctx *c, ncclResult_t r, const char *what) {
     return fail(c, HULK_ERR_COMM, std::string(what) + ": " + (rccl()->GetErrorString ? rccl()->GetErrorString(r) : "RCCL error"));
 }
@@ -148,11 +155,11 @@ int comm_exchange(hulk_ctx *c, hipStream_t s, uint32_t *own_hdr, const void *own
             const volatile uint32_t *hv = (const volatile uint32_t *)h_hdr;
             for (int attempt = 0;; attempt++) {
                 ((volatile uint32_t *)h_hdr)[SHARD_TAG] = 0;
-                const bool skip = m.inject == HULK_INJECT_STALE_STAGE && m.inject_step == m.step && attempt == 0;   // test hook
+                const bool skip = injected(m, HULK_INJECT_STALE_STAGE) && attempt == 0;   // test hook
                 if (pbytes) HIPCHK(c, hipMemcpyAsync(h_pay, own_payload, pbytes, hipMemcpyDeviceToHost, s));
                 if (!skip) HIPCHK(c, hipMemcpyAsync(h_hdr, own_hdr, hbytes, hipMemcpyDeviceToHost, s));
                 HIPCHK(c, hipStreamSynchronize(s));
-                if (hv[SHARD_TAG] == step_tag || m.inject == HULK_INJECT_STALE_SEAL) break;
+                if (hv[SHARD_TAG] == step_tag || injected(m, HULK_INJECT_STALE_SEAL)) break;      // (the hook's void seal is this step's only)
                 m.hdr_resyncs++;
                 if (attempt == 3) return fail(c, HULK_ERR_COMM, "this rank's exchange header did not reach its host staging (4 attempts)");
                 HIPCHK(c, hipDeviceSynchronize());
@@ -337,7 +344,7 @@ static int step_sharded_impl(hulk_ctx *c, const uint8_t *d_bases, const uint64_t
     }
     // this rank's verdict for the NEXT step — the whole-batch bound on the counters and weights as they stand now (a rank
     // without slots has nothing to protect: verdict 0) — sealed into the block with the step's tag by the LAST store into it
-    const bool void_seal = m.inject == HULK_INJECT_STALE_SEAL && m.inject_step == m.step;    // test hook: a block of another step
+    const bool void_seal = injected(m, HULK_INJECT_STALE_SEAL);    // test hook: a block of another step
     HIPCHK(c, launch_flush_decide(s, c->d_ctr, (int)NC, c->d_kminslot, c->d_weights, (int)c->slots, (int)c->slot_begin,
                                   c->d_state, fb, c->slots ? 1 : 2, (unsigned long long *)own_hdr, void_seal ? tag - 1 : tag));
     const int cur = (int)(m.step & 1);
@@ -445,12 +452,14 @@ int hulk_get_comm_health(hulk_ctx *c, uint64_t *refetched, uint64_t *void_blocks
     return HULK_OK;
 }
 
+#ifdef HULK_EXPERIMENTS
 int hulk_debug_inject(hulk_ctx *c, uint32_t what, uint64_t step) {
     if (!c) return HULK_ERR_ARG;
     if (what > HULK_INJECT_STALE_STAGE) return fail(c, HULK_ERR_ARG, "hulk_debug_inject: what");
     c->comm.inject = what; c->comm.inject_step = step;
     return HULK_OK;
 }
+#endif
 
 int hulk_get_comm_stats(hulk_ctx *c, uint64_t *steps_delta, uint64_t *steps_full, uint64_t *bytes_received) {
     if (!c) return HULK_ERR_ARG;

@@ -6,7 +6,9 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <algorithm>
+#include <mutex>
 
 namespace hulk {
 namespace {
@@ -202,6 +204,114 @@ __global__ __launch_bounds__(512) void k_cms_freq(uint32_t *__restrict__ hists, 
     }
 }
 
+// The fallback of k_cms_freq for a device whose LDS does NOT apply the same-address lanes of a returning atomic in ascending
+// lane order (lds_order_verified below; HULK_FLAG_CMS_CHAIN forces it): the bin order inside a 64-bin chunk comes from the static
+// table k_build_chains wrote — meta8 = {the nearest LOWER lane of the chunk on the same counter (64: none), bit 7: the last lane
+// on its counter} — followed with ballots and register exchanges; the LDS is only read by the first lane of a counter's run
+// and written by its last.  Same integers, same order of additions: bit-identical to k_cms_freq (tested), about twice its time.
+__global__ __launch_bounds__(512) void k_cms_freq_chain(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
+                                                        const uint8_t *__restrict__ meta8,
+                                                        const unsigned long long *__restrict__ base,
+                                                        double *__restrict__ f64, float *__restrict__ rcp32,
+                                                        int depth, int width, int seg_chunks, size_t row_stride,
+                                                        DevState *st, FlushBatch fb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int FG = 8, GB = FG * 64;
+    unsigned long long *lctr = (unsigned long long *)smem;                       // [depth][width]
+    unsigned long long *smin = lctr + (size_t)depth * width;                     // [2][GB] minimum over the rows
+    const int seg = blockIdx.x, t = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;
+    const uint32_t gomask = batch_gomask(st, fb);
+    const bool go = (gomask >> t) & 1u;
+    const uint32_t slot = ring_slot(fb, t);
+    if (seg == 0 && tid == 0) {
+        const unsigned used = st->used[fb.parity][slot];
+        if (used != 0 && !go) set_error(st, -5);                                 // "not used yet" (kmerspectrum.go:94-96)
+        if (go) atomicAdd(&st->n_elements, (unsigned long long)used);
+    }
+    if (!go) return;
+    const size_t B = (size_t)fb.num_bins;
+    if (st->skip_exact[fb.parity]) {
+        uint32_t *hw = hists + (size_t)slot * B;
+        const int64_t w0 = (int64_t)seg * seg_chunks * 64, w1 = w0 + (int64_t)seg_chunks * 64;
+        for (int64_t b = w0 + tid; b < w1 && b < (int64_t)B; b += blockDim.x) hw[b] = 0;
+        return;
+    }
+    {
+        const unsigned long long *bt = base + (((size_t)t * depth) * CMS_SEGS) * width;
+        for (int i = tid; i < depth * width; i += blockDim.x) {
+            const int dd = i / width, p = i - dd * width;
+            lctr[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];
+        }
+        for (int i = tid; i < 2 * GB; i += blockDim.x) smin[i] = ~0ull;
+    }
+    __syncthreads();
+    uint32_t *hist = hists + (size_t)slot * B;
+    double *ft = f64 + (size_t)t * B;
+    float *rt = rcp32 + (size_t)t * row_stride;
+    const int64_t b0 = (int64_t)seg * seg_chunks * 64;
+    const int ngroups = (seg_chunks + FG - 1) / FG;
+    const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
+    const uint8_t *md = meta8 + (size_t)(d < depth ? d : 0) * B;
+    unsigned long long *rc = lctr + (size_t)(d < depth ? d : 0) * width;
+    uint32_t ph[FG];
+#pragma unroll
+    for (int c = 0; c < FG; c++) ph[c] = 0;
+    for (int g = 0; g <= ngroups; g++) {
+        uint32_t hh[FG];
+#pragma unroll
+        for (int c = 0; c < FG; c++) {
+            const int ch = g * FG + c;
+            const int64_t b = b0 + (int64_t)ch * 64 + lane;
+            const bool valid = g < ngroups && ch < seg_chunks && b < (int64_t)B;
+            hh[c] = valid ? hist[b] : 0u;
+            if (d < depth && g < ngroups && ch < seg_chunks) {                   // (wave-uniform)
+                const uint32_t h = hh[c], p = valid ? pd[b] : 0u, m = valid ? md[b] : (64u | 0x80u);
+                const uint32_t prev = m & 0x7fu;
+                unsigned long long *my = smin + (size_t)(g & 1) * GB;
+                bool ready = false; unsigned long long Sn = 0;
+                if (prev >= 64u) {                                               // first lane of the chunk on this counter
+                    Sn = rc[p] + h;
+                    if (h) atomicMin(&my[c * 64 + lane], Sn);
+                    ready = true;
+                }
+                unsigned long long done = __ballot(ready);
+                while (done != ~0ull) {
+                    const unsigned long long ps = __shfl(Sn, (int)(prev & 63u));
+                    const bool pr = (done >> (prev & 63u)) & 1ull;
+                    if (!ready && pr) {
+                        Sn = ps + h;
+                        if (h) atomicMin(&my[c * 64 + lane], Sn);
+                        ready = true;
+                    }
+                    done = __ballot(ready);
+                }
+                if ((m & 0x80u) && valid) rc[p] = Sn;
+            }
+        }
+        if (d == depth && g > 0) {
+            unsigned long long *src = smin + (size_t)((g - 1) & 1) * GB;
+#pragma unroll
+            for (int c = 0; c < FG; c++) {
+                const int ch = (g - 1) * FG + c;
+                const int64_t b = b0 + (int64_t)ch * 64 + lane;
+                if (ch < seg_chunks && b < (int64_t)B) {
+                    if (ph[c]) {
+                        const unsigned long long mn = src[c * 64 + lane];
+                        src[c * 64 + lane] = ~0ull;
+                        const double f = (double)mn;
+                        ft[b] = f; rt[b] = (float)(1.0 / f);
+                        hist[b] = 0;                                 // Wipe (kmerspectrum.go:58-64)
+                    } else { ft[b] = 0.0; rt[b] = __builtin_nanf(""); }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < FG; c++) ph[c] = hh[c];
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K3 with uniform scaling (0 < decay < 1), bin-order form.  Counter (d,p) right after stream element j
 // is C(j) = w*C(j-1) + (v_j if element j hits it).  Over a bin segment holding elements [e0,e1):
@@ -312,14 +422,17 @@ __global__ __launch_bounds__(256) void k_cmsd_base(const double *__restrict__ se
 // staging slot while the row waves are one group ahead.
 //
 // The row waves are a chain of dependent LDS round trips, one workgroup per CU (112 KB of counters), so the number of
-// round trips per chunk IS the kernel's time.  Counters are therefore kept NORMALISED to a base element index:
-// S = C * w^-(t - base) for a counter last touched at element t, so that its value at element j is S * w^(j - base) —
-// a factor that depends on j alone (two small tables, requested together with the counter itself) instead of on the
-// counter's own time (a second, dependent look-up), and a lane that follows another lane of its chunk on the same
-// counter takes that lane's S from a register exchange without any look-up.  One round trip per chunk plus one per
-// level of same-counter chains inside it (was five); every CMSD_PERIOD elements the base moves on and the row's 2000
+// round trips per chunk IS the kernel's time.  A counter is kept ADDITIVELY normalised to a base element index,
+// S = sum over its elements i of v_i * w^-(i - base), so that its value right after element j is S * w^(j - base): an element
+// only ADDS g = v * w^-(j - base) to its counter.  Every CMSD_PERIOD elements the base moves on and the row's 2000
 // counters are rescaled by w^PERIOD (the period keeps w^-(j - base) far below the fp64 range for any decay < 1).
-// 517 -> 450 (staging) -> see docs/EXPERIMENTS.md: us per 16 spectra of 923,521 bins.
+//
+// k_cmsd_freq (below) lets the LDS keep the bin order: ds_add_rtn_f64 returns the counter as it stood before this lane's add.
+// k_cmsd_freq_chain (here) is its FALLBACK for a device whose LDS does not apply same-address lanes of one instruction in
+// ascending lane order (lds_order_verified; HULK_FLAG_CMS_CHAIN forces it): the order inside a 64-bin chunk comes from
+// k_build_chains' static table (meta8: nearest lower lane on the same counter, last-lane flag), followed with ballots and
+// register exchanges; the same additions in the same order — bit-identical to k_cmsd_freq where the LDS does keep the order
+// (tested) — at ~1.8x its time (517 -> 450 us was this form's round-3/4 history, docs/EXPERIMENTS.md).
 constexpr int CMSD_FG = 8;            // chunks per barrier group of k_cmsd_freq
 __global__ __launch_bounds__(512) void k_cmsd_freq_chain(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
                                                    const uint8_t *__restrict__ meta8, const uint32_t *__restrict__ eidx,
@@ -332,7 +445,7 @@ __global__ __launch_bounds__(512) void k_cmsd_freq_chain(uint32_t *__restrict__ 
     constexpr unsigned long long INF_BITS = 0x7FF0000000000000ull;
     double *lval = (double *)smem;                                               // [depth][width] normalised counters
     unsigned long long *smin = (unsigned long long *)(lval + (size_t)depth * width);   // [2][GB] min over the rows, as bits
-    __shared__ double tabf_lo[64], tabf_hi[66];                                   // w^x for x = lo + 64 hi
+    __shared__ double tabf_lo[64], tabf_hi[66], tabi_lo[64], tabi_hi[66];          // w^x and w^-x for x = lo + 64 hi
     const int seg = blockIdx.x, t = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;
     const uint32_t gomask = batch_gomask(st, fb);
@@ -346,7 +459,6 @@ __global__ __launch_bounds__(512) void k_cmsd_freq_chain(uint32_t *__restrict__ 
     if (!go) return;
     const size_t B = (size_t)fb.num_bins;
     const double lnw = log(omega);                               // < 0
-    // elements per base: |ln w| * (period + 64) <= 600  =>  w^-(j - base) <= e^600 (counters stay below ~1e270)
     int period = 4032;
     if (-lnw * (double)(period + 64) > 600.0) period = (int)(600.0 / -lnw) - 64;
     period &= ~63;
@@ -355,11 +467,11 @@ __global__ __launch_bounds__(512) void k_cmsd_freq_chain(uint32_t *__restrict__ 
         const double *bt = cstart + (((size_t)t * depth) * CMS_SEGS) * width;
         for (int i = tid; i < depth * width; i += blockDim.x) {
             const int dd = i / width, p = i - dd * width;
-            lval[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];       // value as of element e0 - 1: see `base` below
+            lval[i] = bt[((size_t)dd * CMS_SEGS + seg) * width + p];
         }
         for (int i = tid; i < 2 * GB; i += blockDim.x) smin[i] = INF_BITS;
-        if (tid < 64) tabf_lo[tid] = exp((double)tid * lnw);
-        if (tid >= 64 && tid < 64 + 66) { const int x = tid - 64; tabf_hi[x] = exp((double)(64 * x) * lnw); }
+        if (tid < 64) { tabf_lo[tid] = exp((double)tid * lnw); tabi_lo[tid] = exp(-(double)tid * lnw); }
+        if (tid >= 64 && tid < 64 + 66) { const int x = tid - 64; tabf_hi[x] = exp((double)(64 * x) * lnw); tabi_hi[x] = exp(-(double)(64 * x) * lnw); }
     }
     __syncthreads();
     uint32_t *hist = hists + (size_t)slot * B;
@@ -367,16 +479,12 @@ __global__ __launch_bounds__(512) void k_cmsd_freq_chain(uint32_t *__restrict__ 
     double *ft = f64 + (size_t)t * B;
     float *rt = rcp32 + (size_t)t * row_stride;
     const int64_t b0 = (int64_t)seg * seg_chunks * 64;
-    // counters are as of element `base`: a counter holding S stands for the value S * w^(j - base) just before element j
-    // adds to it (cstart = value right after element e0 - 1, i.e. at j = e0 it has been scaled once: j - base = 1)
     long long base = (long long)sege0[(size_t)t * CMS_SEGS + seg] - 1;
     const double wperiod = exp((double)period * lnw);
     const int ngroups = (seg_chunks + CMSD_FG - 1) / CMSD_FG;
     const uint16_t *pd = pos16 + (size_t)(d < depth ? d : 0) * B;
     const uint8_t *md = meta8 + (size_t)(d < depth ? d : 0) * B;
     double *rv = lval + (size_t)(d < depth ? d : 0) * width;
-    // row waves: the four per-bin inputs of the WHOLE next group (8 chunks = 32 loads per lane) are requested before the
-    // current group is computed: with one workgroup per CU nothing else hides their latency
     uint32_t nh[CMSD_FG], np_[CMSD_FG], nm[CMSD_FG], nj[CMSD_FG];
     auto fetch = [&](int g) {
 #pragma unroll
@@ -401,8 +509,6 @@ __global__ __launch_bounds__(512) void k_cmsd_freq_chain(uint32_t *__restrict__ 
                 if (ch >= seg_chunks) break;
                 const int64_t b = b0 + (int64_t)ch * 64 + lane;
                 const uint32_t h = chh[c], p = cp[c], m = cm[c]; const long long j = (long long)cj[c];
-                // move the base on when the chunk's elements would leave the tables (wave-uniform: element indices
-                // ascend with the lane; lane 0 holds the chunk's first)
                 {
                     const long long jfirst = (long long)__builtin_amdgcn_readfirstlane((int)cj[c]);
                     while (jfirst - base > (long long)period) {
@@ -411,33 +517,25 @@ __global__ __launch_bounds__(512) void k_cmsd_freq_chain(uint32_t *__restrict__ 
                     }
                 }
                 const uint32_t x = h ? (uint32_t)(j - base) : 0u;                // 1 .. period + 64 (unused for bins not in the stream)
-                // w^x from the two tables; w^-x as its reciprocal on the VALU (the kernel is bound by the LDS pipe: the two
-                // table reads this replaces were 2 of its ~11 LDS instructions per row and chunk — any pair with wf * wi = 1
-                // to rounding serves, the counter is only ever kept as S = C * wi and used as S * wf')
-                const double wf = tabf_lo[x & 63u] * tabf_hi[x >> 6];
-                double wi;
-                {
-                    double y = __builtin_amdgcn_rcp(wf), e = __builtin_fma(-wf, y, 1.0);
-                    y = __builtin_fma(y, e, y); e = __builtin_fma(-wf, y, 1.0);
-                    wi = __builtin_fma(y, e, y);
-                }
+                const double wi = tabi_lo[x & 63u] * tabi_hi[x >> 6], wf = tabf_lo[x & 63u] * tabf_hi[x >> 6];
+                const double gv = (double)h * wi;
                 // resolve the lanes in same-counter order: a lane is computed once its predecessor is (whether it is comes
-                // from the wave's ballot of finished lanes, not from a second register exchange)
+                // from the wave's ballot of finished lanes).  `before` is what ds_add_rtn_f64 returns in k_cmsd_freq.
                 const uint32_t prev = m & 0x7fu;
                 bool ready = false; double Sn = 0.0;
                 if (prev >= 64u) {                                  // first lane of the chunk on this counter: LDS state
-                    const double S0 = rv[p];
-                    if (h) { const double C = S0 * wf + (double)h; Sn = C * wi; atomicMin(&my[c * 64 + lane], (unsigned long long)__double_as_longlong(C)); }
-                    else Sn = S0;
+                    const double before = rv[p];
+                    if (h) { Sn = before + gv; atomicMin(&my[c * 64 + lane], (unsigned long long)__double_as_longlong(Sn * wf)); }
+                    else Sn = before;
                     ready = true;
                 }
                 unsigned long long done = __ballot(ready);
                 while (done != ~0ull) {
-                    const double ps = __shfl(Sn, (int)(prev & 63u));
+                    const double before = __shfl(Sn, (int)(prev & 63u));
                     const bool pr = (done >> (prev & 63u)) & 1ull;
                     if (!ready && pr) {
-                        if (h) { const double C = ps * wf + (double)h; Sn = C * wi; atomicMin(&my[c * 64 + lane], (unsigned long long)__double_as_longlong(C)); }
-                        else Sn = ps;
+                        if (h) { Sn = before + gv; atomicMin(&my[c * 64 + lane], (unsigned long long)__double_as_longlong(Sn * wf)); }
+                        else Sn = before;
                         ready = true;
                     }
                     done = __ballot(ready);
@@ -667,6 +765,7 @@ __global__ __launch_bounds__(256) void k_elem_index(const uint32_t *__restrict__
 // ---------------------------------------------------------------------------- host wrappers
 hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *st, const FlushBatch &fb) {
     int blocks = (fb.num_bins + 2047) / 2048; if (blocks > 128) blocks = 128;
+    prof_mark(s, "k_count_used");
     hipLaunchKernelGGL(k_count_used, dim3(blocks, fb.count), dim3(256), 0, s, d_hists, st, fb);
     return hipGetLastError();
 }
@@ -674,7 +773,7 @@ hipError_t launch_count_used(hipStream_t s, const uint32_t *d_hists, DevState *s
 hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
                                unsigned long long *d_ctr, uint32_t *d_segsum, unsigned long long *d_base,
                                double *d_f64, float *d_rcp32, int depth, int width, size_t row_stride,
-                               DevState *st, const FlushBatch &fb) {
+                               DevState *st, const FlushBatch &fb, bool chain) {
     const int chunks = (fb.num_bins + 63) / 64;
     const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
     const size_t lds1 = (size_t)depth * width * 4;
@@ -682,15 +781,25 @@ hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t 
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_cms_freq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_cms_freq_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    prof_mark(s, "k_cms_segsum");
     hipLaunchKernelGGL(k_cms_segsum, dim3(CMS_SEGS, fb.count), dim3(512), lds1, s, d_hists, d_pos16, d_segsum, depth, width,
                        seg_chunks, st, fb);
+    prof_mark(s, "k_cms_base");
     hipLaunchKernelGGL(k_cms_base, dim3((depth * width + 255) / 256), dim3(256), 0, s, d_segsum, d_ctr, d_base, depth, width, st, fb);
-    hipLaunchKernelGGL(k_cms_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_base, d_f64,
-                       d_rcp32, depth, width, seg_chunks, row_stride, st, fb);
-    (void)d_meta8;
+    if (chain) {
+        prof_mark(s, "k_cms_freq_chain");
+        hipLaunchKernelGGL(k_cms_freq_chain, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_meta8, d_base, d_f64,
+                           d_rcp32, depth, width, seg_chunks, row_stride, st, fb);
+    }
+    else {
+        prof_mark(s, "k_cms_freq");
+        hipLaunchKernelGGL(k_cms_freq, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_base, d_f64,
+                           d_rcp32, depth, width, seg_chunks, row_stride, st, fb);
+    }
     return hipGetLastError();
 }
 
@@ -700,7 +809,7 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
                                 const uint32_t *d_eidx, const uint32_t *d_etot, double *d_ctrd, double *d_segadd,
                                 double *d_segfac, uint32_t *d_sege0, double *d_cstart, double *d_f64, float *d_rcp32,
                                 int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb,
-                                hipEvent_t freq_begin, hipEvent_t freq_end) {
+                                hipEvent_t freq_begin, hipEvent_t freq_end, bool chain_form) {
     const int chunks = (fb.num_bins + 63) / 64;
     const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
     if (depth > 8) return hipErrorInvalidValue;                     // k_cmsd_segsum: one wave per row, 8 waves
@@ -715,22 +824,30 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    prof_mark(s, "k_cmsd_segsum");
     hipLaunchKernelGGL(k_cmsd_segsum, dim3(CMS_SEGS, fb.count), dim3(512), lds1, s, d_hists, d_pos16, d_eidx, d_etot, d_segadd,
                        d_segfac, d_sege0, depth, width, seg_chunks, omega, st, fb);
+    prof_mark(s, "k_cmsd_base");
     hipLaunchKernelGGL(k_cmsd_base, dim3((depth * width + 255) / 256), dim3(256), 0, s, d_segadd, d_segfac, d_ctrd, d_cstart,
                        depth, width, st, fb);
     if (freq_begin) { const hipError_t e = hipEventRecord(freq_begin, s); if (e != hipSuccess) return e; }   // bench.py: k_cmsd_freq alone
-    static const bool chain = HULK_EXP_ENV("HULK_CMSD_CHAIN") != nullptr;      // the round-3 form, kept as the A/B comparator
+    const bool chain = chain_form || HULK_EXP_ENV("HULK_CMSD_CHAIN") != nullptr;   // the fallback (lds_order_verified / HULK_FLAG_CMS_CHAIN)
     static const bool fg16 = HULK_EXP_ENV("HULK_CMSD_FG16") != nullptr;        // 16 chunks per barrier group (A/B)
-    if (chain)
+    if (chain) {
+        prof_mark(s, "k_cmsd_freq_chain");
         hipLaunchKernelGGL(k_cmsd_freq_chain, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_meta8, d_eidx, d_sege0,
                            d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
-    else if (fg16)
+    }
+    else if (fg16) {
+        prof_mark(s, "k_cmsd_freq");
         hipLaunchKernelGGL(k_cmsd_freq<16>, dim3(CMS_SEGS, fb.count), dim3(512), lds3 + (size_t)2 * 8 * 64 * 8, s, d_hists, d_pos16, d_eidx, d_sege0,
                            d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
-    else
+    }
+    else {
+        prof_mark(s, "k_cmsd_freq");
         hipLaunchKernelGGL(k_cmsd_freq<8>, dim3(CMS_SEGS, fb.count), dim3(512), lds3, s, d_hists, d_pos16, d_eidx, d_sege0,
                            d_cstart, d_f64, d_rcp32, depth, width, seg_chunks, row_stride, omega, st, fb);
+    }
     if (freq_end) { const hipError_t e = hipEventRecord(freq_end, s); if (e != hipSuccess) return e; }
     return hipGetLastError();
 }
@@ -738,12 +855,87 @@ hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t
 hipError_t launch_elem_index(hipStream_t s, const uint32_t *d_hists, uint32_t *d_blkcnt, uint32_t *d_eidx,
                              uint32_t *d_etot, const FlushBatch &fb, DevState *st) {
     const int nblk = (fb.num_bins + EIDX_BLOCK - 1) / EIDX_BLOCK;
+    prof_mark(s, "k_elem_count");
     hipLaunchKernelGGL(k_elem_count, dim3(nblk, fb.count), dim3(256), 0, s, d_hists, d_blkcnt, nblk, fb);
+    prof_mark(s, "k_elem_index");
     hipLaunchKernelGGL(k_elem_index, dim3(nblk, fb.count), dim3(256), 0, s, d_hists, d_blkcnt, d_eidx, d_etot, nblk, fb, st);
     return hipGetLastError();
 }
 
 int elem_index_blocks(int32_t num_bins) { return (num_bins + EIDX_BLOCK - 1) / EIDX_BLOCK; }
+
+// ------------------------------------------------------------------------------------------
+// The hardware property k_cms_freq / k_cmsd_freq / k_cmsd_segsum rest on, checked on the device itself once per process and
+// device (hulk_create): for ONE returning LDS atomic add (ds_add_rtn_u64 / ds_add_rtn_f64) whose lanes hit the same address, the
+// value a lane gets back is the value before the instruction plus the operands of the LOWER lanes on that address (ascending
+// lane order), and the instructions of a wave are applied in program order.  Patterns: all 64 lanes on one address, pairs,
+// pseudo-random partitions into 1..61 groups; two instructions back to back on different partitions.  Every lane checks its own
+// returned value against the sum it can form from the wave's operands (readlane).  out[0] / out[1]: lanes out of order for
+// u64 / f64.  (tools/ubench/lds_atomic_order.hip is the stand-alone form of the same test.)
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void k_lds_order_probe(unsigned int *out, int rounds, unsigned int sabotage) {
+    __shared__ unsigned long long su[64];
+    __shared__ double sd[64];
+    const int l = threadIdx.x;
+    unsigned bad_u = 0, bad_d = 0;
+    uint32_t rng = 0x9E3779B9u * (uint32_t)(l + 1);
+    for (int r = 0; r < rounds; r++) {
+        const int mode = r & 3;
+        rng = rng * 1664525u + 1013904223u; const uint32_t ra = rng >> 8;
+        rng = rng * 1664525u + 1013904223u; const uint32_t rb = rng >> 8;
+        const int p0 = mode == 0 ? 0 : mode == 1 ? l / 2 : (int)(ra % (uint32_t)(1 + r % 61));
+        const int p1 = mode == 0 ? 0 : mode == 1 ? (63 - l) / 2 : (int)(rb % (uint32_t)(1 + r % 59));
+        const unsigned long long v0 = 1ull + (unsigned)l, v1 = 1000ull + (unsigned)l;
+        su[l] = 7ull * (unsigned)l; sd[l] = (double)(7 * l);
+        __syncthreads();
+        const unsigned long long a_u = atomicAdd(&su[p0], v0);
+        const unsigned long long b_u = atomicAdd(&su[p1], v1);
+        const double a_d = atomicAdd(&sd[p0], (double)v0);
+        const double b_d = atomicAdd(&sd[p1], (double)v1);
+        // expectation: start value + lower lanes of the same instruction (+ every lane of the earlier instruction) on that address
+        unsigned long long ea = 7ull * (unsigned)p0, eb = 7ull * (unsigned)p1;
+        for (int j = 0; j < 64; j++) {
+            const int q0 = __builtin_amdgcn_readlane(p0, j), q1 = __builtin_amdgcn_readlane(p1, j);
+            if (q0 == p0 && j < l) ea += 1ull + (unsigned)j;
+            if (q0 == p1) eb += 1ull + (unsigned)j;
+            if (q1 == p1 && j < l) eb += 1000ull + (unsigned)j;
+        }
+        if (sabotage) ea += (unsigned)(l == 5);                   // (self-test of the checker: HULK_LDS_PROBE_SABOTAGE, profiling build)
+        bad_u += (a_u != ea) + (b_u != eb);
+        bad_d += (a_d != (double)ea) + (b_d != (double)eb);       // (sums of small integers: exact in fp64)
+        __syncthreads();
+    }
+    for (int off = 32; off; off >>= 1) { bad_u += __shfl_xor(bad_u, off); bad_d += __shfl_xor(bad_d, off); }
+    if (l == 0) { out[0] = bad_u; out[1] = bad_d; }
+}
+}  // namespace
+
+// 1: the LDS applies same-address lanes in ascending lane order (what every gfx950 measured so far does), 0: it does not — the
+// count-min replay then runs k_cms_freq_chain / k_cmsd_freq_chain —, < 0: the probe could not run (hipError_t negated).
+int lds_order_verified(int device) {
+    static std::mutex mu;
+    static int cache[64];
+    static bool init = false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!init) { for (int &x : cache) x = -1000000; init = true; }
+    if (device >= 0 && device < 64 && cache[device] != -1000000) return cache[device];
+    unsigned int *d_out = nullptr, h[2] = {1, 1};
+    hipError_t e = hipMalloc((void **)&d_out, 8);
+    if (e == hipSuccess) {
+        const unsigned sabotage = HULK_EXP_ENV("HULK_LDS_PROBE_SABOTAGE") != nullptr;
+        hipLaunchKernelGGL(k_lds_order_probe, dim3(1), dim3(64), 0, 0, d_out, 488, sabotage);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(h, d_out, 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_out);
+    }
+    const int res = e != hipSuccess ? -(int)e : (h[0] == 0 && h[1] == 0) ? 1 : 0;
+    if (res == 0)
+        fprintf(stderr, "libhulkhip: device %d: the LDS does not apply same-address lanes of a returning atomic in ascending lane order "
+                        "(%u u64, %u f64 lanes out of order): the count-min replay uses the chain-form kernels\n", device, h[0], h[1]);
+    if (device >= 0 && device < 64 && res >= 0) cache[device] = res;
+    return res;
+}
 
 // Static chain tables of the bin-order count-min kernels (built once per context): for row d the counter position
 // g = jump(bin + d*bin, width) of every bin (countmin.go:122-125), and per 64-bin chunk which earlier lane of the chunk
@@ -890,6 +1082,7 @@ __global__ __launch_bounds__(256) void k_shard_check(const uint32_t *__restrict_
 
 hipError_t launch_shard_check(hipStream_t s, const uint32_t *d_hdr_all, uint32_t world, uint32_t step_tag, DevState *st,
                               uint32_t *h_out, int fatal) {
+    prof_mark(s, "k_shard_check");
     hipLaunchKernelGGL(k_shard_check, dim3(1), dim3(256), 0, s, d_hdr_all, world, step_tag, st, h_out, fatal);
     return hipGetLastError();
 }
@@ -899,6 +1092,7 @@ hipError_t launch_shard_local(hipStream_t s, uint32_t *d_hists, const uint16_t *
     if (fb.count == 0) return hipSuccess;
     const int chunks = (fb.num_bins + 63) / 64;
     const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
+    prof_mark(s, "k_shard_local");
     hipLaunchKernelGGL(k_shard_local, dim3(CMS_SEGS, fb.count), dim3(512), (size_t)depth * width * 4, s, d_hists, d_pos16, d_hdr,
                        d_delta, depth, width, seg_chunks, fb);
     return hipGetLastError();
@@ -909,6 +1103,7 @@ hipError_t launch_shard_apply(hipStream_t s, const uint32_t *d_hdr_all, const ui
                               DevState *st, uint32_t step_tag) {
     const int nc = depth * width;
     const uint32_t ranks = std::min<uint32_t>(world, (step_intervals + T - 1) / T);      // ranks that hold intervals of this step
+    prof_mark(s, "k_shard_apply");
     hipLaunchKernelGGL(k_shard_apply, dim3((nc + 255) / 256, ranks ? ranks : 1), dim3(256), 0, s, d_hdr_all, d_delta_all, d_ctr, nc,
                        world, T, step_intervals, num_bins, st, step_tag);
     return hipGetLastError();

@@ -39,6 +39,7 @@ static inline hipError_t poison_host_malloc(void **p, size_t n, unsigned flags) 
 
 namespace hulk {
 constexpr uint64_t MAX_READS_PER_LAUNCH = 4u << 20;   // 4 Mi reads -> <= ~7 GB of minimizer list at w = 9
+struct ProfMark { hipEvent_t e; const char *kernel; hipStream_t s; };   // hulk_set_profiling bit 32 (prof_mark)
 struct ProfileRec { hipEvent_t a, b; int which; };   // which: 0 = k_cws_scan, 1 = k_minimizer_fast, 2 = k_jump_bin, 3 = k_jump_left, 4 = k_cmsd_freq
 }  // namespace hulk
 
@@ -121,6 +122,7 @@ struct hulk_ctx {
     uint32_t work_lanes = 2;                            // hulk_params.work_lanes
     uint32_t host_copy_threads = 4;                     // hulk_params.host_copy_threads
     bool no_overlap = false, shard_full = false;        // HULK_FLAG_NO_OVERLAP, HULK_FLAG_SHARD_FULL
+    bool lds_order_ok = true, cms_chain = false;        // lds_order_verified(device); the count-min replay runs the chain-form kernels (HULK_FLAG_CMS_CHAIN or !lds_order_ok)
     uint64_t *d_long_xs = nullptr, *d_long_table = nullptr; uint8_t *d_long_valid = nullptr;   // long-sequence scratch
     void *d_long_desc = nullptr; uint64_t long_desc_cap = 0;
     uint64_t long_cap = 0, long_table_cap = 0;   // minimizer list of the short-read kernel (grow-only)
@@ -133,6 +135,7 @@ struct hulk_ctx {
     std::string last_error;
     int profiling = 0;   /* bit 0 k_cws_scan, bit 1 k_minimizer_fast, bit 2 k_jump_bin + k_jump_left, bit 3 k_cmsd_freq (hulk_set_profiling) */
     std::vector<hulk::ProfileRec> prof;
+    std::vector<hulk::ProfMark> marks;
 };
 
 namespace hulk {
@@ -178,6 +181,13 @@ int check_device_error(hulk_ctx *c);
 int stage_host_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, uint64_t i0, uint64_t i1,
                      hulk_ctx::HostStage **out);
 int check_host_reads(hulk_ctx *c, const uint64_t *offsets, uint64_t n, uint64_t *max_len_out);
+
+// arms prof_mark() for the launches this thread issues on behalf of `c` (a context is single-caller)
+struct ProfScope {
+    hulk_ctx *prev;
+    explicit ProfScope(hulk_ctx *c);
+    ~ProfScope();
+};
 
 // ---- hulk_comm.hip
 void comm_teardown(hulk_ctx *c);

@@ -969,28 +969,33 @@ hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp
     const int groups = (slots + SCAN_ROWS - 1) / SCAN_ROWS;
     const int wtiles = ntiles * 4, wwords = (wtiles + 63) / 64;
     const bool grid_form = scan_grid_form();
-    if (d_kmin32)
+    if (d_kmin32) {
+        prof_mark(s, "k_rcp_extrema");
         hipLaunchKernelGGL(k_rcp_extrema, dim3(ntiles, fb.count), dim3(256), 0, s, d_rcp32, d_rext, ntiles, row_stride, st, fb);
+    }
     if (!grid_form) { const hipError_t e = hipMemsetAsync(d_scanlist_n, 0, 4, s); if (e != hipSuccess) return e; }
+    prof_mark(s, "k_scan_test");
     hipLaunchKernelGGL(k_scan_test, dim3((groups + 3) / 4, wwords), dim3(256), 0, s, d_kmin32, d_rext, d_weights, slot_begin,
                        slots, wtiles, wwords, drift_dw, st, fb, d_scanmap, d_visited, grid_form ? nullptr : d_scanlist, d_scanlist_n);
     const int mode = (per_interval || scan_merge_off()) ? 0 : scan_merge_loop() ? 1 : 2;   // 0: concept drift, the elements are taken in stream order
-    if (mode == 2)
+    if (mode == 2) {
+        prof_mark(s, "k_rcp_minmax");
         hipLaunchKernelGGL(k_rcp_minmax, dim3((unsigned)((row_stride / 4 + 255) / 256)), dim3(256), 0, s, d_rcp32, d_rmm, row_stride, st, fb);
+    }
     const float *rv = mode == 2 ? d_rmm : d_rcp32;
     if (scan_begin) { const hipError_t e = hipEventRecord(scan_begin, s); if (e != hipSuccess) return e; }   // bench.py: the scan kernel alone
     if (grid_form) {
         const dim3 g((unsigned)(((wwords * 4 + 7) / 8) * 8 * groups));            // units of 16 wave tiles, 8 (one per XCD) side by side
-        if (mode == 0) hipLaunchKernelGGL(k_cws_scan<0>, g, dim3(1024), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
-        else if (mode == 1) hipLaunchKernelGGL(k_cws_scan<1>, g, dim3(1024), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
-        else hipLaunchKernelGGL(k_cws_scan<2>, g, dim3(1024), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords);
+        if (mode == 0) { prof_mark(s, "k_cws_scan"); hipLaunchKernelGGL(k_cws_scan<0>, g, dim3(1024), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords); }
+        else if (mode == 1) { prof_mark(s, "k_cws_scan"); hipLaunchKernelGGL(k_cws_scan<1>, g, dim3(1024), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords); }
+        else { prof_mark(s, "k_cws_scan"); hipLaunchKernelGGL(k_cws_scan<2>, g, dim3(1024), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanmap, wwords); }
     } else {
         // enough waves for the whole table to be in flight at 8 KB per wave; a short list leaves most of them nothing to do
         const size_t items = (size_t)groups * wtiles;
         const dim3 g((unsigned)((std::min<size_t>(2048, (items + 3) / 4) + 7) / 8 * 8));
-        if (mode == 0) hipLaunchKernelGGL(k_cws_scan_list<0>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n);
-        else if (mode == 1) hipLaunchKernelGGL(k_cws_scan_list<1>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n);
-        else hipLaunchKernelGGL(k_cws_scan_list<2>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n);
+        if (mode == 0) { prof_mark(s, "k_cws_scan_list"); hipLaunchKernelGGL(k_cws_scan_list<0>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n); }
+        else if (mode == 1) { prof_mark(s, "k_cws_scan_list"); hipLaunchKernelGGL(k_cws_scan_list<1>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n); }
+        else { prof_mark(s, "k_cws_scan_list"); hipLaunchKernelGGL(k_cws_scan_list<2>, g, dim3(256), 0, s, d_k32, rv, d_tilemin, slots, ntiles, row_stride, st, fb, d_scanlist, d_scanlist_n); }
     }
     if (scan_end) { const hipError_t e = hipEventRecord(scan_end, s); if (e != hipSuccess) return e; }
     return hipGetLastError();
@@ -1004,6 +1009,7 @@ hipError_t launch_slot_kmin(hipStream_t s, const float *d_kmin32, float *d_kmins
 hipError_t launch_flush_decide(hipStream_t s, const unsigned long long *d_ctr, int ncounters, const float *d_kminslot,
                                const double *d_weights, int slots, int slot_begin, DevState *st, const FlushBatch &fb,
                                int enable, unsigned long long *d_seal, uint32_t seal_tag) {
+    prof_mark(s, "k_flush_decide");
     hipLaunchKernelGGL(k_flush_decide, dim3(1), dim3(1024), 0, s, d_ctr, ncounters, d_kminslot, d_weights, slots,
                        slot_begin, st, fb, enable, d_seal, seal_tag);
     return hipGetLastError();
@@ -1020,12 +1026,17 @@ hipError_t launch_cws_resolve(hipStream_t s, const double *d_rcb, const double *
                               int slots, int slot_begin, int ntiles, const unsigned long long *d_scanmap, DevState *st,
                               const FlushBatch &fb) {
     const int merged = scan_merge_off() ? 0 : 1;                 // (this launcher is the no-drift path)
-    if (merged)
+    if (merged) {
+        prof_mark(s, "k_cws_resolve");
         hipLaunchKernelGGL(k_cws_resolve<true>, dim3(slots, 1), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
                            d_rcb, d_f64, d_tilemin, d_candA, d_candB, slots, ntiles, d_scanmap, (ntiles * 4 + 63) / 64, st, fb);
-    else
+    }
+    else {
+        prof_mark(s, "k_cws_resolve");
         hipLaunchKernelGGL(k_cws_resolve<false>, dim3(slots, fb.count), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
                            d_rcb, d_f64, d_tilemin, d_candA, d_candB, slots, ntiles, d_scanmap, (ntiles * 4 + 63) / 64, st, fb);
+    }
+    prof_mark(s, "k_cws_apply");
     hipLaunchKernelGGL(k_cws_apply, dim3((slots + 255) / 256), dim3(256), 0, s, d_candA, d_candB, d_mins,
                        d_weights, slots, slot_begin, st, fb, merged);
     return hipGetLastError();
@@ -1036,8 +1047,10 @@ hipError_t launch_cws_resolve_drift(hipStream_t s, const double *d_rcb, const do
                                     int slots, int slot_begin, int ntiles, double decay_weight, float *d_slotmin,
                                     const unsigned long long *d_scanmap, DevState *st, const FlushBatch &fb) {
     const int ngroups = (slots + SCAN_ROWS - 1) / SCAN_ROWS, wwords = (ntiles * 4 + 63) / 64;
+    prof_mark(s, "k_slot_tmin");
     hipLaunchKernelGGL(k_slot_tmin, dim3(ngroups, fb.count), dim3(256), 0, s, d_tilemin, d_slotmin, ntiles * 4, ngroups,
                        d_scanmap, wwords, st, fb);
+    prof_mark(s, "k_cws_resolve_drift");
     hipLaunchKernelGGL(k_cws_resolve_drift, dim3(slots), dim3(256), (size_t)ntiles * 4 * sizeof(float), s,
                        d_rcb, d_f64, d_tilemin, d_mins, d_weights, slots, slot_begin, ntiles, decay_weight, d_slotmin,
                        d_scanmap, wwords, st, fb);

@@ -8,6 +8,18 @@
 
 namespace hulk {
 
+namespace { thread_local hulk_ctx *g_prof_ctx = nullptr; }
+ProfScope::ProfScope(hulk_ctx *c) : prev(g_prof_ctx) { g_prof_ctx = (c && (c->profiling & 16)) ? c : nullptr; }
+ProfScope::~ProfScope() { g_prof_ctx = prev; }
+void prof_mark(hipStream_t s, const char *kernel) {
+    hulk_ctx *c = g_prof_ctx;
+    if (!c) return;
+    ProfMark m{nullptr, kernel, s};
+    if (hipEventCreateWithFlags(&m.e, PROFILE_EVENT_FLAGS) != hipSuccess) return;
+    if (hipEventRecord(m.e, s) != hipSuccess) { (void)hipEventDestroy(m.e); return; }
+    c->marks.push_back(m);
+}
+
 uint32_t *ring_hist(hulk_ctx *c) { return c->d_hist + (size_t)c->cur_ring * (size_t)c->ring_n * (size_t)c->B; }
 
 // The work lane of spectrum ring r.  With two lanes (hulk_params.work_lanes, the default) every launch that touches ring r —
@@ -190,6 +202,7 @@ static int lane_reserve(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, uint6
 static int bin_fast(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets,
                     uint64_t n, uint32_t max_len, MinimizerParams P, uint32_t *hist, hipEvent_t spectra_gate) {
     { const int rc = lane_reserve(c, ln, s, n, P.pair != 0); if (rc != HULK_OK) return rc; }
+    ProfScope prof_scope(c);
     // Both lanes idle (the context was just synchronised): the two batches that come next would start their
     // k_minimizer_fast together and run in lock step — same kernels side by side, nothing to fill — for several batches
     // before they drift apart.  The second one therefore waits for the first one's k_minimizer_fast, which puts the lanes
@@ -223,6 +236,7 @@ static int bin_fast(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, const uin
     const uint32_t list_blocks = (uint32_t)std::min<uint64_t>(slow_blocks, (n + 3) / 4);
     HIPCHK(c, launch_minimizer_bin(s, d_bases, d_offsets, n, P, threads, hist, c->d_state, c->d_min_slots, ln.d_slow_list,
                                    ln.d_slow_count, list_blocks));
+    prof_mark(s, "-");
     return HULK_OK;
 }
 
@@ -329,6 +343,8 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
 
 // The kernels of one flush: `fb.count` consecutive spectra of `hist` (starting at fb.ring_base) through count-min + CWS, on stream s.
 int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &fb) {
+    ProfScope prof_scope(c);
+    struct Close { hipStream_t s; ~Close() { prof_mark(s, "-"); } } prof_close{s};
     if (!c->scaling) HIPCHK(c, launch_count_used(s, hist, c->d_state, fb));    // (with decay k_elem_index delivers the count)
     {   // whole-batch bound on the counters as they stand BEFORE this batch is added (see k_flush_decide)
         HIPCHK(c, launch_flush_decide(s, c->d_ctr, c->cms_depth * c->cms_width, c->d_kminslot, c->d_weights, (int)c->slots,
@@ -340,11 +356,11 @@ int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &
         if ((c->profiling & 8)) { HIPCHK(c, hipEventCreateWithFlags(&pf.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pf.b, PROFILE_EVENT_FLAGS)); }
         HIPCHK(c, launch_cmsd_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_eidx, c->d_etot, c->d_ctrd, c->d_segadd,
                                        c->d_segfac, c->d_sege0, c->d_cstart, c->d_f64, c->d_rcp32, c->cms_depth,
-                                       c->cms_width, c->row_stride, c->decay_weight, c->d_state, fb, pf.a, pf.b));
+                                       c->cms_width, c->row_stride, c->decay_weight, c->d_state, fb, pf.a, pf.b, c->cms_chain));
         if ((c->profiling & 8)) c->prof.push_back(pf);
     } else {
         HIPCHK(c, launch_cms_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_ctr, c->d_segsum, c->d_cbase, c->d_f64,
-                                      c->d_rcp32, c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb));
+                                      c->d_rcp32, c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb, c->cms_chain));
     }
     if (c->slots) {
         ProfileRec pr{};

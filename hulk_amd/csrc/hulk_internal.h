@@ -115,13 +115,14 @@ hipError_t launch_build_chains(hipStream_t s, uint16_t *d_pos16, uint8_t *d_meta
 hipError_t launch_cms_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
                                unsigned long long *d_ctr, uint32_t *d_segsum, unsigned long long *d_base,
                                double *d_f64, float *d_rcp32, int depth, int width, size_t row_stride,
-                               DevState *st, const FlushBatch &fb);
+                               DevState *st, const FlushBatch &fb, bool chain = false);
+int lds_order_verified(int device);   // 1 / 0 / -(hipError_t): see hulk_countmin.hip
 size_t cms_binorder_entries(int depth, int width);   // entries of segsum / base per spectrum
 hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
                                 const uint32_t *d_eidx, const uint32_t *d_etot, double *d_ctrd, double *d_segadd,
                                 double *d_segfac, uint32_t *d_sege0, double *d_cstart, double *d_f64, float *d_rcp32,
                                 int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb,
-                                hipEvent_t freq_begin = nullptr, hipEvent_t freq_end = nullptr);
+                                hipEvent_t freq_begin = nullptr, hipEvent_t freq_end = nullptr, bool chain_form = false);
 hipError_t launch_cws_scan(hipStream_t s, const float *d_k32, const float *d_rcp32, float *d_tilemin,
                            int slots, int ntiles, size_t row_stride, DevState *st, const FlushBatch &fb,
                            const float *d_kmin32, float *d_rext, const double *d_weights, int slot_begin,
@@ -178,6 +179,12 @@ hipError_t launch_build_k32(hipStream_t s, const double *d_rcb, float *d_k32, in
 hipError_t launch_selftest_rcp(hipStream_t s, unsigned long long *d_mismatches);
 hipError_t launch_fill_f32(hipStream_t s, float *p, size_t n, float v);
 hipError_t launch_add_hist(hipStream_t s, uint32_t *d_hist, const uint32_t *d_add, int32_t num_bins);
+
+// Per-kernel timing of WHOLE launch chains (hulk_set_profiling bit 32 -> hulk_get_profile_table): every launch site of the step
+// path names the kernel it is about to launch; while a context with that bit set is driving the launches on this thread
+// (ProfScope, hulk_flush.hip) an event is recorded on the stream in front of it, and a kernel's duration is the time to the
+// next mark on the same stream ("-" closes a chain).  Meant for the one-stream mode (HULK_FLAG_NO_OVERLAP): every kernel alone.
+void prof_mark(hipStream_t s, const char *kernel);
 
 // context accessors for hulk_ingest.hip (defined in hulk_flush.hip; not part of the ABI)
 }  // namespace hulk

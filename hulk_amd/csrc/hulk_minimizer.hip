@@ -1057,6 +1057,7 @@ hipError_t launch_minimizer_bin(hipStream_t s, const uint8_t *d_bases, const uin
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    prof_mark(s, "k_minimizer_bin");
     hipLaunchKernelGGL(k_minimizer_bin, dim3((unsigned)blocks), dim3(block_threads), lds, s, d_bases,
                        d_offsets, n_reads, P, d_hist, d_state, d_min_slots, d_read_list, d_read_list_count);
     return hipGetLastError();
@@ -1077,6 +1078,7 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
     // k <= 27: 64-bit minima through v_min_f64 (see umin64); HULK_NO_FMIN keeps the integer compares (A/B aid)
     static const bool no_fmin = HULK_EXP_ENV("HULK_NO_FMIN") != nullptr;
     const bool fm = P.k <= 27 && !no_fmin;
+    prof_mark(s, "k_minimizer_fast");
 #define HULK_LAUNCH_FAST3(WM, FMv, DBGv, WEQv, KCv, PAIRv)                                                           \
     hipLaunchKernelGGL((k_minimizer_fast<WM, FMv, DBGv, WEQv, KCv, PAIRv>), g, b, lds, s, d_bases, d_offsets, n_reads, \
                        P, ml, d_state, d_min_slots)
@@ -1121,8 +1123,11 @@ hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSe
     const uint64_t cap = std::max<uint64_t>(1, 131072 / n_seqs);
     if (bx > cap) bx = cap;
     if (bx > 8192) bx = 8192;
+    prof_mark(s, "k_fill_u64");
     hipLaunchKernelGGL(k_fill_u64, dim3(4096), dim3(256), 0, s, d_table, table_total, TAB_EMPTY);
+    prof_mark(s, "k_long_hash");
     hipLaunchKernelGGL(k_long_hash, dim3((unsigned)bx, n_seqs), dim3(256), 0, s, d_bases, d_desc, P, d_xs, d_valid);
+    prof_mark(s, "k_long_emit");
     hipLaunchKernelGGL(k_long_emit, dim3((unsigned)bx, n_seqs), dim3(256), 0, s, d_desc, d_xs, d_valid, P, d_table,
                        d_hists, d_min_slots);
     return hipGetLastError();

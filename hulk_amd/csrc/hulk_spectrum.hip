@@ -467,7 +467,9 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     hipError_t e = hipSuccess;
     const uint32_t n_regions = (uint32_t)((n_reads + FAST_READS_PER_WAVE - 1) / FAST_READS_PER_WAVE);
     const uint32_t nblk = (n_regions + 1023) / 1024;
+    prof_mark(s, "k_region_bsum");
     hipLaunchKernelGGL(k_region_bsum, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.dmask, ml.dsum, n_regions);
+    prof_mark(s, "k_region_offsets");
     hipLaunchKernelGGL(k_region_offsets, dim3(nblk), dim3(1024), 0, s, ml.cnt, ml.bsum, ml.off, n_regions, ml.nib_over, ml.dmask,
                        ml.dsum, d_slow_list, d_slow_count);
     // k_jump_bin needs no LDS; a dummy allocation caps its occupancy so that the flush kernels of the
@@ -480,10 +482,11 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
     if (jump_cut < 0) { const char *ec = HULK_EXP_ENV("HULK_JUMP_CUT"); jump_cut = ec ? atoi(ec) : 10; }
     const uint32_t cut = (jump_c || !ml.lo) ? 0u : (uint32_t)jump_cut;
     if (jump_begin) { e = hipEventRecord(jump_begin, s); if (e != hipSuccess) return e; }      // bench.py: k_jump_bin alone ...
+    prof_mark(s, "k_jump_bin");
     hipLaunchKernelGGL(k_jump_bin, dim3((n_regions + 3) / 4), dim3(256), (size_t)jump_lds, s, ml, n_regions, P.num_bins, jump_c, cut);
     if (jump_end) { e = hipEventRecord(jump_end, s); if (e != hipSuccess) return e; }
     if (left_begin) { e = hipEventRecord(left_begin, s); if (e != hipSuccess) return e; }      // ... and k_jump_left alone
-    if (cut) hipLaunchKernelGGL(k_jump_left, dim3((n_regions + 3) / 4), dim3(256), 0, s, ml, n_regions, P.num_bins);
+    if (cut) { prof_mark(s, "k_jump_left"); hipLaunchKernelGGL(k_jump_left, dim3((n_regions + 3) / 4), dim3(256), 0, s, ml, n_regions, P.num_bins); }
     if (left_end) { e = hipEventRecord(left_end, s); if (e != hipSuccess) return e; }
     // the kernels below write the spectra of the ring: the flush that last read them has to be done
     if (wait_before_spectra) { e = hipStreamWaitEvent(s, wait_before_spectra, 0); if (e != hipSuccess) return e; }
@@ -539,22 +542,27 @@ hipError_t launch_minimizer_post(hipStream_t s, uint64_t n_reads, MinimizerParam
             nib_attr = true;
         }
         const unsigned pg = (n_spectra * np + 7) / 8;
+        prof_mark(s, "k_nibble_hist");
         hipLaunchKernelGGL(k_nibble_hist, dim3(8u * (unsigned)nr * pg), dim3(nib_block), (size_t)words * 4, s, ml, n_regions, P,
                            n_spectra, np, n_reads, nr, rlog);
         int nb = (nr * NIB_WORDS + 255) / 256; if (nb > 512) nb = 512;      // one word (8 bins) per thread up to 131072 words
+        prof_mark(s, "k_nibble_merge");
         hipLaunchKernelGGL(k_nibble_merge, dim3(nb, n_spectra), dim3(256), 0, s, ml, d_hists, P, n_spectra, np, nr, rlog);
         // A spectrum in which a 4-bit counter overflowed (grossly repetitive input) is recounted exactly: k_nibble_merge left
         // it alone, k_recount_flagged adds its keys with global atomics.  Rare, so its shape is chosen for the common case,
         // in which it finds no flag: 256 light workgroups without LDS.  (Until round 4 the exact range histogram ran here with
         // an "only if flagged" test: 96 workgroups of 128 KB of LDS that return at once — but first have to be PLACED, and
         // beside the other lane's kernels that took 138 us of this lane's stream per batch.)
+        prof_mark(s, "k_recount_flagged");
         hipLaunchKernelGGL(k_recount_flagged, dim3(256), dim3(256), 0, s, ml, n_regions, P, n_spectra, n_reads, d_hists);
         return hipGetLastError();
     }
     const unsigned pair_groups = (n_spectra * n_parts + 7) / 8;
+    prof_mark(s, "k_range_hist");
     hipLaunchKernelGGL(k_range_hist, dim3(8u * (unsigned)nranges * pair_groups), dim3(1024), HIST_RANGE * 4, s, ml, n_regions,
                        ml.partial, P, n_spectra, n_parts, n_reads, nranges, nullptr, nullptr);
     int mb = (P.num_bins + 255) / 256; if (mb > 512) mb = 512;
+    prof_mark(s, "k_merge_hist");
     hipLaunchKernelGGL(k_merge_hist, dim3(mb, n_spectra), dim3(256), 0, s, ml.partial, d_hists, P, n_spectra, n_parts, nullptr);
     return hipGetLastError();
 }

@@ -223,8 +223,13 @@ class GpuSketcher:
         return {"steps_delta": a.value, "steps_full": b.value, "bytes_received": c.value,
                 "headers_refetched": h.value, "void_blocks": v.value}
 
+    def _need_experiments(self):
+        if not _lib.is_experiments_build():
+            raise RuntimeError("test hook of the profiling build: run with HULK_LIB=exp (make -C hulk_amd/csrc EXPERIMENTS=1)")
+
     def debug_read(self, what: int):
         """Test hook (hulk_debug_read): HULK_DEBUG_TILEMIN -> float32 array, HULK_DEBUG_SCANMAP -> uint64 array."""
+        self._need_experiments()
         n = ctypes.c_uint64(0)
         buf = np.zeros(1, dtype=np.uint8)
         self._L.hulk_debug_read(self._ctx, what, buf.ctypes.data, ctypes.byref(n))       # (too small: reports the size)
@@ -234,6 +239,7 @@ class GpuSketcher:
 
     def debug_inject(self, what: int, step: int):
         """Test hook (hulk_debug_inject): make this rank's header block of `step` void / its host staging late."""
+        self._need_experiments()
         self._chk(self._L.hulk_debug_inject(self._ctx, what, step))
 
     @property
@@ -307,6 +313,22 @@ class GpuSketcher:
         n = ctypes.c_uint64()
         self._chk(self._L.hulk_selftest_reciprocal(self._ctx, ctypes.byref(n)))
         return n.value
+
+    def device_checks(self):
+        """What hulk_create verified on the device: {"lds_order_ok": ..., "cms_chain_form": ...} (hulk_get_device_checks)."""
+        a, b = ctypes.c_uint32(), ctypes.c_uint32()
+        self._chk(self._L.hulk_get_device_checks(self._ctx, ctypes.byref(a), ctypes.byref(b)))
+        return {"lds_order_ok": bool(a.value), "cms_chain_form": bool(b.value)}
+
+    def profile_table(self):
+        """{kernel: (launches, total_ms)} of every launch since hulk_set_profiling(32) (hulk_get_profile_table; clears the log)."""
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._chk(self._L.hulk_get_profile_table(self._ctx, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            k, n, ms = line.split("\t")
+            out[k] = (int(n), float(ms))
+        return out
 
     def set_profiling(self, on=True):
         self._chk(self._L.hulk_set_profiling(self._ctx, int(on)))

@@ -85,9 +85,72 @@ def find_sketch(data, ksize, algo, path):
     return hit[0]
 
 
+def _paths(files):
+    import ctypes
+    enc = [os.fsencode(f) for f in files]
+    return (ctypes.c_char_p * max(len(enc), 1))(*enc), len(enc)
+
+
+def load_sketches(files, ksize=21, algo="histosketch", threads=0):
+    """LoadHULKdata + FindSketch for every file, in native code on `threads` host threads (hulk_load_sketches; no GPU needed):
+    -> (ordering, mins[n][S], weights[n][S], banner labels), ordering = the sorted paths.  Raises HulkError with the reference's text."""
+    import ctypes
+    L = _lib.load()
+    arr, n = _paths(files)
+    h = ctypes.c_void_p()
+    err = ctypes.create_string_buffer(4096)
+    rc = L.hulk_load_sketches(arr, n, ksize, algo.encode(), threads, ctypes.byref(h), err, len(err))
+    if rc != 0:
+        raise HulkError(rc, err.value.decode("utf-8", "replace"))
+    try:
+        cn, cs = ctypes.c_uint32(), ctypes.c_uint32()
+        L.hulk_sketch_set_info(h, ctypes.byref(cn), ctypes.byref(cs))
+        n, S = cn.value, cs.value
+        mins = np.ctypeslib.as_array(ctypes.cast(L.hulk_sketch_set_mins(h), ctypes.POINTER(ctypes.c_uint64)), shape=(n * max(S, 1),))[:n * S].reshape(n, S).copy()
+        weights = np.ctypeslib.as_array(ctypes.cast(L.hulk_sketch_set_weights(h), ctypes.POINTER(ctypes.c_double)), shape=(n * max(S, 1),))[:n * S].reshape(n, S).copy()
+        ordering = [os.fsdecode(L.hulk_sketch_set_path(h, i)) for i in range(n)]
+        banners = [L.hulk_sketch_set_banner(h, i).decode("utf-8", "replace") for i in range(n)]
+    finally:
+        L.hulk_sketch_set_free(h)
+    return ordering, mins, weights, banners
+
+
 def smash(sketch_dir, out_file, ksize=21, algo="histosketch", metric="jaccard", recursive=False, device=0,
+          banner_matrix=False, stages=None, threads=0):
+    """runSmash + makeMatrix (cmd/smash.go:60-226), native from the file names on (hulk_smash_files): the JSON files are parsed
+    and MD5-verified on `threads` host threads, the N x N x S comparison runs on the GPU, the CSV is written by the library.
+    Writes <out_file>.hulk-matrix.csv (and, banner_matrix, <out_file>.banner-matrix.csv: makeBannerMatrix, cmd/smash.go:229-261 —
+    the reference iterates a Go map, here the sorted file order is used) and returns (ordering, distances).
+    stages: a dict that receives the seconds of "load" (JSON + MD5 check), "matrix", "csv" and "kernel_ms"."""
+    import ctypes
+    if metric not in AVAIL_METRICS:
+        raise HulkError(-30, f"supplied distance metric is not available: {metric}\nplease select one of the following: {AVAIL_METRICS}")
+    if algo not in AVAIL_ALGORITHMS:
+        raise HulkError(-30, f"supplied algorithm not available: {algo}\nplease select one of the following: {AVAIL_ALGORITHMS}")
+    files = collect_jsons(sketch_dir, recursive)
+    od = os.path.dirname(out_file)
+    if od and od != "." and not os.path.exists(od):
+        os.makedirs(od, mode=0o700)
+    L = _lib.load()
+    arr, n = _paths(files)
+    n_unique = len(set(files))
+    dist = np.zeros((n_unique, n_unique), dtype=np.float64)
+    st = _lib.SmashStats()
+    err = ctypes.create_string_buffer(4096)
+    rc = L.hulk_smash_files(device, arr, n, ksize, algo.encode(), metric.encode(), threads, os.fsencode(out_file + ".hulk-matrix.csv"),
+                            os.fsencode(out_file + ".banner-matrix.csv") if banner_matrix else None, dist.ctypes.data,
+                            ctypes.byref(st), err, len(err))
+    if rc != 0:
+        raise HulkError(rc, err.value.decode("utf-8", "replace"))
+    if stages is not None:
+        stages.update(load=st.seconds_load, matrix=st.seconds_matrix, csv=st.seconds_csv, kernel_ms=st.kernel_ms)
+    return sorted(set(files)), dist
+
+
+def smash_python(sketch_dir, out_file, ksize=21, algo="histosketch", metric="jaccard", recursive=False, device=0,
           banner_matrix=False, stages=None):
-    """runSmash + makeMatrix: writes <out_file>.hulk-matrix.csv and returns (ordering, distances).
+    """The same run with the load, the ordering and the CSV in Python (json + hashlib; the form `smash` had until round 6, kept as
+    the comparator of the native one in tests/).  runSmash + makeMatrix: writes <out_file>.hulk-matrix.csv and returns (ordering, distances).
     banner_matrix: also <out_file>.banner-matrix.csv (makeBannerMatrix, cmd/smash.go:229-261): one line
     per sketch = its mins + the banner label; the reference iterates a Go map (random order), here the
     sorted file order is used.  stages: a dict that receives the seconds of "load" (JSON + MD5 check), "matrix", "csv"."""

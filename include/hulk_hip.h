@@ -55,8 +55,11 @@ extern "C" {
  *    src/pipeline/pipeline.go:14-30): hulk_params.batch / work_lanes / host_copy_threads (were reserved[0..2], 0 = default),
  *    HULK_FLAG_SHARD_FULL / HULK_FLAG_NO_OVERLAP, hulk_ingest_opts with hulk_parse_files_opts / hulk_sketch_files_opts.
  *    The HULK_* environment variables that remain are overrides for profiling scripts, read when a context is created.
+ * 4: HULK_FLAG_CMS_CHAIN + hulk_get_device_checks (the count-min replay's hardware assumption is verified on the device by
+ *    hulk_create), hulk_get_profile_table (hulk_set_profiling bit 32), hulk_load_sketches / hulk_smash_files (the directory form
+ *    of `hulk smash`); the test hooks hulk_debug_inject / hulk_debug_read left the shipping library (profiling build only).
  * Bindings compare it with the value they were written for. */
-#define HULK_ABI_VERSION 3
+#define HULK_ABI_VERSION 4
 
 #define HULK_OK 0
 #define HULK_ERR_W (-1)          /* "w must be: 0 < w < 257"                  minimizer.go:63 */
@@ -97,6 +100,11 @@ extern "C" {
 #define HULK_FLAG_SHARD_FULL 8u    /* hulk_step_sharded always exchanges the k-mer spectra (never the count-min increments) */
 #define HULK_FLAG_NO_OVERLAP 16u   /* one stream: flush kernels on the work stream, one work lane (profiling: every kernel
                                     * runs alone, so its own duration can be read) */
+#define HULK_FLAG_CMS_CHAIN 64u    /* the count-min replay (countmin.go:103-147 in bin order) runs its chain-form kernels: the order of
+                                    * the bins inside a 64-bin chunk comes from a static table and register exchanges instead of from
+                                    * the order in which the LDS applies the lanes of one returning atomic add.  hulk_create selects
+                                    * them by itself on a device whose LDS does not keep that order (hulk_get_device_checks); same
+                                    * additions in the same order: bit-identical counters, estimates and sketch (tested) */
 #define HULK_FLAG_NO_PRERESERVE 32u /* hulk_create does not size the work lanes' minimizer lists for batch x interval reads (about
                                      * 3 GB per lane at the defaults): they grow with the first batches instead, at the price of an
                                      * allocation in the middle of the stream.  For contexts that see few or long reads, or many
@@ -135,8 +143,9 @@ typedef struct hulk_params {
 
 /* Version of this ABI (HULK_ABI_VERSION). */
 int hulk_abi_version(void);
-/* "abi=3 arch=gfx950 sources=<first 16 hex digits of the SHA-256 over hulk_amd/csrc's sources and headers, in the Makefile's
- * order> hipcc=<version>": which tree and compiler this .so was built from (a binding or a test can refuse a stale one). */
+/* "abi=4 arch=gfx950 sources=<first 16 hex digits of the SHA-256 over hulk_amd/csrc's sources and headers, in the Makefile's
+ * order> hipcc=<version>[ experiments=1]": which tree and compiler this .so was built from (a binding or a test can refuse a
+ * stale one); " experiments=1" marks the profiling build (make EXPERIMENTS=1: experiment switches and test hooks compiled in). */
 const char *hulk_build_info(void);
 /* Reference error text for a status code. */
 const char *hulk_strerror(int status);
@@ -319,6 +328,9 @@ int hulk_get_comm_stats(hulk_ctx *ctx, uint64_t *steps_delta, uint64_t *steps_fu
  * taken again after a synchronisation; `void_blocks` = times a rank's block of the previous step carried another step's seal
  * (every rank then takes the spectra exchange; after a delta step the run ends with HULK_ERR_COMM).  Both are 0 in a healthy run. */
 int hulk_get_comm_health(hulk_ctx *ctx, uint64_t *refetched, uint64_t *void_blocks);
+/* ---- test hooks: compiled into the PROFILING build only (make -C hulk_amd/csrc EXPERIMENTS=1 -> libhulkhip_exp.so, which
+ * defines HULK_EXPERIMENTS; hulk_build_info() then ends in " experiments=1").  The shipping libhulkhip.so does not export them. */
+#ifdef HULK_EXPERIMENTS
 /* Test hook (tests/test_gpu_two_rank.py): at step `step` of hulk_step_sharded this rank
  *   HULK_INJECT_STALE_SEAL   seals its header block with the PREVIOUS step's tag (a block that is not of this step);
  *   HULK_INJECT_STALE_STAGE  (host transport) finds its own block missing from the host staging on the first attempt. */
@@ -333,6 +345,7 @@ int hulk_debug_inject(hulk_ctx *ctx, uint32_t what, uint64_t step);
 #define HULK_DEBUG_TILEMIN 1u
 #define HULK_DEBUG_SCANMAP 2u
 int hulk_debug_read(hulk_ctx *ctx, uint32_t what, void *out, uint64_t *bytes_io);
+#endif /* HULK_EXPERIMENTS */
 
 /* Process-level buffers the library keeps between calls — the device FASTQ parser's pinned and device blocks (hulk_sketch_files:
  * about 130 MB pinned, 250 MB of HBM per set, at most two sets) and hulk_smash's device arrays — are freed; the next call that
@@ -372,6 +385,45 @@ int hulk_smash(int device, const uint64_t *mins, const double *weights, uint32_t
 int hulk_smash_ex(int device, const uint64_t *mins, const double *weights, uint32_t n_sketches,
                   uint32_t sketch_size, int metric, double *distances, double *kernel_ms);
 
+/* What hulk_create verified on this context's device.  *lds_order_ok: 1 if one returning LDS atomic add (ds_add_rtn_u64 /
+ * ds_add_rtn_f64) applies the lanes that hit one address in ascending lane order and a wave's instructions in program order —
+ * the property the count-min replay kernels take the reference's bin order from (countmin.go:103-138); checked once per
+ * process and device with all-equal, paired and pseudo-random address patterns.  *cms_chain_form: 1 if this context runs the
+ * chain-form replay kernels (the property does not hold, or HULK_FLAG_CMS_CHAIN). */
+int hulk_get_device_checks(hulk_ctx *ctx, uint32_t *lds_order_ok, uint32_t *cms_chain_form);
+
+/* ---- `hulk smash`, the directory form (cmd/smash.go:160-226), native: LoadHULKdata for every file (sketchio.go:100-195: JSON,
+ * class / version, the MD5 of the little-endian mins against the stored md5sum, helpers.go:156-166) on `threads` host threads
+ * (0 = one per hardware thread, at most 32), FindSketch(ksize, algo) per file (sketchio.go:198-257), the equal-length check of
+ * GetDistance (sketchio.go:274-277).  Paths are taken in sort.Strings order (a path given twice counts once: the reference keeps
+ * them in a map).  Failures: HULK_ERR_ARG with the reference's text in `errbuf` (and hulk_last_error(NULL)) — of the first file
+ * in sorted order that fails to load; then "<n> sketches found ... needs at least 2"; then of the first file whose FindSketch
+ * fails; then the length mismatch.  hulk_load_sketches needs no GPU. */
+typedef struct hulk_sketch_set hulk_sketch_set;
+int hulk_load_sketches(const char *const *paths, uint32_t n_paths, uint32_t ksize, const char *algo, uint32_t threads,
+                       hulk_sketch_set **out, char *errbuf, uint64_t errbuf_len);
+void hulk_sketch_set_free(hulk_sketch_set *set);
+int hulk_sketch_set_info(const hulk_sketch_set *set, uint32_t *n_sketches, uint32_t *sketch_size);
+const uint64_t *hulk_sketch_set_mins(const hulk_sketch_set *set);      /* [n_sketches][sketch_size], sorted-path order */
+const double *hulk_sketch_set_weights(const hulk_sketch_set *set);     /* the same shape (zeros for kmv / khf: they carry no weights) */
+const char *hulk_sketch_set_path(const hulk_sketch_set *set, uint32_t i);
+const char *hulk_sketch_set_banner(const hulk_sketch_set *set, uint32_t i);   /* banner_label of file i */
+typedef struct hulk_smash_stats {
+    double seconds_load;     /* reading, parsing and verifying the files */
+    double seconds_matrix;   /* hulk_smash (copies + kernels) */
+    double seconds_csv;      /* formatting and writing the CSV file(s) */
+    double kernel_ms;        /* the distance kernel alone */
+    uint32_t n_sketches, sketch_size;
+} hulk_smash_stats;
+/* runSmash + makeMatrix: load, smash on `device`, and — matrix_csv_path != NULL — write the file encoding/csv would: the sorted
+ * paths as header, then one row per subject of strconv.FormatFloat(100 - 100 * distance, 'f', 2, 64) (cmd/smash.go:183-226);
+ * banner_csv_path != NULL: makeBannerMatrix's file (cmd/smash.go:229-261: a sketch's mins + its banner label per line, in
+ * sorted file order).  metric: "jaccard" | "weightedjaccard"; algo: "histosketch" | "kmv" | "khf".  `distances` (may be NULL)
+ * receives [n][n] in sorted-path order; `stats` may be NULL. */
+int hulk_smash_files(int device, const char *const *paths, uint32_t n_paths, uint32_t ksize, const char *algo, const char *metric,
+                     uint32_t threads, const char *matrix_csv_path, const char *banner_csv_path, double *distances,
+                     hulk_smash_stats *stats, char *errbuf, uint64_t errbuf_len);
+
 /* Device self-test: the jump hash replaces the fp64 division 2^31/r by a Newton reciprocal; this
  * checks RN(1/r) against IEEE division for EVERY r in [1, 2^31] and returns the mismatch count. */
 int hulk_selftest_reciprocal(hulk_ctx *ctx, uint64_t *mismatches);
@@ -384,12 +436,18 @@ int hulk_get_scan_stats(hulk_ctx *ctx, uint64_t *tiles_visited, uint64_t *tiles_
 
 /* Per-kernel timing for bench.py: when enabled, hipEvents bracket every launch of the heavy kernels
  * ("k_minimizer_fast", "k_jump_bin", "k_jump_left", "k_cws_scan", "k_cmsd_freq"; each alone) on the stream they are launched on.
- * enabled: 0 off, 1 all of them, otherwise a mask (2 k_minimizer_fast, 4 k_jump_bin and k_jump_left, 8 k_cws_scan, 16 k_cmsd_freq)
+ * enabled: 0 off, 1 all of them, otherwise a mask (2 k_minimizer_fast, 4 k_jump_bin and k_jump_left, 8 k_cws_scan, 16 k_cmsd_freq,
+ * 32 every launch: hulk_get_profile_table)
  * — every bracketed launch costs the stream two event records (~3 % of a C2 step for all of them), so the timed pass of
  * bench.py brackets nothing and the durations come from a separate pass. */
 int hulk_set_profiling(hulk_ctx *ctx, int enabled);
 /* Number of timed launches of `kernel` and their summed duration (synchronises; clears that log). */
 int hulk_get_profile(hulk_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);
+/* hulk_set_profiling bit 32: EVERY kernel launch of the step path (binning chain and flush) is timed — an event in front of each
+ * launch, a kernel's duration = the time to the next event on its stream — meant for HULK_FLAG_NO_OVERLAP contexts, where every
+ * kernel runs alone.  Writes "kernel<TAB>launches<TAB>total_ms<LF>" lines (NUL-terminated) into `out` (HULK_ERR_ARG if `cap`
+ * is too small), synchronises, clears the log. */
+int hulk_get_profile_table(hulk_ctx *ctx, char *out, uint64_t cap);
 
 #ifdef __cplusplus
 }

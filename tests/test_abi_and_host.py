@@ -12,9 +12,16 @@ import pytest
 from conftest import ROOT
 
 
-def header_symbols():
+def header_symbols(experiments=False):
+    """entry points include/hulk_hip.h declares: for the shipping library, or (experiments=True) the test hooks it declares
+    under #ifdef HULK_EXPERIMENTS — exported by the profiling build only"""
     txt = open(os.path.join(ROOT, "include", "hulk_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    blocks = re.findall(r"#ifdef HULK_EXPERIMENTS\n(.*?)#endif", txt, flags=re.S)
+    if experiments:
+        txt = "\n".join(blocks)
+    else:
+        txt = re.sub(r"#ifdef HULK_EXPERIMENTS\n.*?#endif", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(hulk_[a-z0-9_]+)\s*\(", txt)))
 
 
@@ -28,7 +35,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"{s} declared in include/hulk_hip.h but not exported"
     assert sorted(_lib.ABI_SYMBOLS) == syms, "hulk_amd/_lib.py binding list out of sync with the header"
     L.hulk_abi_version.restype = ctypes.c_int
-    assert L.hulk_abi_version() == _lib.HULK_ABI_VERSION == 3
+    assert L.hulk_abi_version() == _lib.HULK_ABI_VERSION == 4
+    # the test hooks are not in the shipping library; the profiling build has them and says what it is
+    hooks = header_symbols(experiments=True)
+    assert hooks == sorted(_lib.EXPERIMENT_SYMBOLS) == ["hulk_debug_inject", "hulk_debug_read"]
+    assert not any(hasattr(L, h) for h in hooks)
+    L.hulk_build_info.restype = ctypes.c_char_p
+    assert b"experiments" not in L.hulk_build_info()
+    if os.path.exists(_lib.EXP_LIB_PATH):
+        X = ctypes.CDLL(_lib.EXP_LIB_PATH)
+        X.hulk_build_info.restype = ctypes.c_char_p
+        assert all(hasattr(X, h) for h in hooks + syms) and X.hulk_build_info().endswith(b" experiments=1")
     L.hulk_strerror.restype = ctypes.c_char_p
     assert L.hulk_strerror(-4) == b"sequence length must be >= w + k - 1"
     assert L.hulk_strerror(-5) == b"not used yet"
@@ -41,7 +58,8 @@ def test_params_struct_layout_matches_header():
     assert HulkParams.cws_source.offset == 40 and HulkParams.flags.offset == 44
     hdr = open(os.path.join(ROOT, "include", "hulk_hip.h")).read()
     from hulk_amd import _lib
-    for name in ("HULK_FLAG_GAMMA_CPYTHON", "HULK_FLAG_NO_PRUNE", "HULK_FLAG_NO_SKIP"):
+    for name in ("HULK_FLAG_GAMMA_CPYTHON", "HULK_FLAG_NO_PRUNE", "HULK_FLAG_NO_SKIP", "HULK_FLAG_SHARD_FULL", "HULK_FLAG_NO_OVERLAP",
+                 "HULK_FLAG_NO_PRERESERVE", "HULK_FLAG_CMS_CHAIN"):
         assert int(re.search(rf"#define {name} (\d+)u", hdr).group(1)) == getattr(_lib, name)
     assert "#define HULK_MAX_BINS (1 << 20)" in hdr and _lib.HULK_MAX_BINS == 1 << 20
 

@@ -19,7 +19,7 @@ import (
 )
 
 // abiVersion is the HULK_ABI_VERSION this file was written against; New refuses another library.
-const abiVersion = 3
+const abiVersion = 4
 
 // Sketcher plays the role of theBoss + the Sketcher's HistoSketch for one run.
 type Sketcher struct {
