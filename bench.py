@@ -29,6 +29,9 @@ rule, pipeline/sketch.go:211-215), so every mode but `sliced-weak` computes the 
   after the EOF gather of the sketch.
 HULK_BENCH_TRANSPORT=gloo (test aid): the ranks share GPU 0 and the library's HOST transport carries the exchange over gloo
 (RCCL refuses two ranks on one device) — same protocol, same kernels; tests/test_gpu_bench_contract.py runs world 2 this way.
+HULK_BENCH_TRANSPORT=fakerccl (test aid): the ranks share GPU 0 and go through the library's RCCL branch (hulk_comm_init:
+ncclCommInitRank, grouped ncclAllGather / ncclAllReduce on the flush stream) with the nccl* symbols bound to the test double
+tests/cpp/libfakerccl.so (HULK_RCCL_LIB); torch.distributed (control plane: barriers, the unique id) runs over gloo.
 
 Passes, in order: discarded ones (the first pass of a process measures low, and a GPU fresh from idle for seconds: one
 pass + HULK_BENCH_PREWARM_S = 2 s of them), then the HEADLINE (W warm-up + K timed steps between barriers, no event
@@ -160,7 +163,7 @@ def self_spawn(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) and relay their JSON line."""
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus and os.environ.get("HULK_BENCH_TRANSPORT") != "gloo":      # (gloo: test aid, the ranks share GPU 0)
+    if have < args.gpus and os.environ.get("HULK_BENCH_TRANSPORT") not in ("gloo", "fakerccl"):      # (test aids: the ranks share GPU 0)
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -307,7 +310,12 @@ def c5_leg():
         order, dist = smash_mod.smash(d_, os.path.join(d_, "out"), ksize=21, algo="histosketch", metric="weightedjaccard", stages=stages)
         total = time.perf_counter() - t0
         assert len(order) == N
-        out["directory"] = {"files": N, "file_bytes": file_bytes, "seconds_total": total,
+        t0 = time.perf_counter()                               # the same command with the loader and the CSV in Python (the round-5 form)
+        smash_mod.smash_python(d_, os.path.join(d_, "out_py"), ksize=21, algo="histosketch", metric="weightedjaccard")
+        total_py = time.perf_counter() - t0
+        same_csv = open(os.path.join(d_, "out.hulk-matrix.csv"), "rb").read() == open(os.path.join(d_, "out_py.hulk-matrix.csv"), "rb").read()
+        out["directory"] = {"files": N, "file_bytes": file_bytes, "seconds_total": total, "seconds_total_python_loader": total_py,
+                            "csv_same_as_python_form": same_csv, "loader": "native (hulk_smash_files: JSON + MD5 on host threads, CSV by the library)",
                             "seconds_load_and_md5": stages.get("load"), "seconds_matrix": stages.get("matrix"),
                             "seconds_csv": stages.get("csv"),
                             "matrix_md5": hashlib.md5(np.ascontiguousarray(dist).tobytes()).hexdigest(),
@@ -372,9 +380,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     transport = os.environ.get("HULK_BENCH_TRANSPORT", "rccl")         # "gloo": test aid, all ranks on GPU 0 (module docstring)
-    if transport not in ("rccl", "gloo"):
-        raise SystemExit("HULK_BENCH_TRANSPORT must be rccl or gloo")
-    dev_index = 0 if transport == "gloo" else local_rank
+    if transport not in ("rccl", "gloo", "fakerccl"):
+        raise SystemExit("HULK_BENCH_TRANSPORT must be rccl, gloo or fakerccl")
+    shared_gpu = transport in ("gloo", "fakerccl")                     # test aids: every rank on GPU 0, torch.distributed over gloo
+    if transport == "fakerccl":
+        os.environ.setdefault("HULK_RCCL_LIB", os.path.join(ROOT, "tests", "cpp", "libfakerccl.so"))
+        if not os.path.exists(os.environ["HULK_RCCL_LIB"]):
+            raise SystemExit(f"HULK_BENCH_TRANSPORT=fakerccl: {os.environ['HULK_RCCL_LIB']} is missing (python -c 'import __graft_entry__ as g; g.build()')")
+    dev_index = 0 if shared_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = f"cuda:{dev_index}"
     use_dist = world > 1 or args.force_collective
@@ -383,7 +396,7 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if transport == "gloo":
+        if shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
@@ -392,7 +405,7 @@ def main():
         assert dist.get_world_size() == world
 
     def host_tensor(vals, dtype):
-        return torch.tensor(vals, dtype=dtype, device="cpu" if transport == "gloo" else device)
+        return torch.tensor(vals, dtype=dtype, device="cpu" if shared_gpu else device)
 
     # ---- the line so far, and the watchdog that prints it if a leg never returns -------------------------------------
     out = {}                       # rank 0: the JSON line; filled as the legs complete
@@ -694,7 +707,7 @@ def main():
             sk.add_reads_device(b.data_ptr(), o.data_ptr(), stp, READ_LEN, b.numel())
             sk.synchronize(); torch.cuda.synchronize()
             if serial:
-                sk.set_profiling(2 | 4 | 16)
+                sk.set_profiling(32)                       # every launch of the chain timed (hulk_get_profile_table): steady state, the warm-up batch is out
             state["kick"] = time.monotonic()
             t1 = time.perf_counter()
             done, i = 0, 1
@@ -706,10 +719,16 @@ def main():
             sk.synchronize()                       # (private streams: the context's own synchronisation point stops the clock)
             ms = (time.perf_counter() - t1) * 1e3
             if serial:
-                pr = {kk: sk.get_profile(kk) for kk in ("k_minimizer_fast", "k_jump_bin", "k_jump_left", "k_cmsd_freq")}
-                res["kernels_alone"] = {"ms_per_batch": ms / (done / stp), "reads_per_s": done / ms * 1e3, "reads": done,
-                                        **{kk + "_us": (v[1] / max(v[0], 1)) * 1e3 for kk, v in pr.items()},
-                                        "note": "HULK_FLAG_NO_OVERLAP: one stream, one piece per batch, per launch of a 16-interval batch"}
+                tbl = sk.profile_table()
+                nb = done / stp
+                res["kernels_alone"] = {"ms_per_batch": ms / nb, "reads_per_s": done / ms * 1e3, "reads": done, "batches": nb,
+                                        **{kk + "_us": (tbl[kk][1] / max(tbl[kk][0], 1)) * 1e3 for kk in ("k_minimizer_fast", "k_jump_bin", "k_jump_left", "k_cmsd_freq") if kk in tbl},
+                                        # every kernel of the binning chain and of the decay flush: microseconds per batch (all its launches), steady state
+                                        "us_per_batch": {kk: round(v[1] / nb * 1e3, 2) for kk, v in sorted(tbl.items(), key=lambda kv: -kv[1][1])},
+                                        "launches_per_batch": {kk: round(v[0] / nb, 2) for kk, v in tbl.items()},
+                                        "us_per_batch_sum": round(sum(v[1] for v in tbl.values()) / nb * 1e3, 1),
+                                        "note": "HULK_FLAG_NO_OVERLAP: one stream, one piece per batch; hulk_set_profiling(32): an event in front of every launch, "
+                                                "a kernel = the time to the next event (includes ~2-4 us of event handling per launch); the first (cold) batch excluded"}
                 sk.set_profiling(0)
             else:
                 res.update({"value": done / ms * 1e3, "unit": "reads/s", "reads": done, "ms_per_batch": ms / (done / stp),
@@ -809,6 +828,7 @@ def main():
         how = ("loopback stand-in (no peers)" if loop_world else
                f"host transport over gloo (RCCL unavailable: {rccl_error[0]})" if rccl_error[0] else
                "RCCL (ncclAllGather / ncclAllReduce, bound by hulk_comm_init)" if transport == "rccl" else
+               "the library's RCCL branch over the test double tests/cpp/libfakerccl.so (test aid: all ranks on GPU 0)" if transport == "fakerccl" else
                "host transport over gloo (test aid: all ranks on GPU 0)")
         what = ("one all-gather per step: k-mer spectra while an element can still lower a weight, count-min increments after"
                 if mode == "sharded" else "one all-reduce (uint32 sum) of the step's spectra")

@@ -884,8 +884,12 @@ __global__ __launch_bounds__(64) void k_lds_order_probe(unsigned int *out, int r
         const int mode = r & 3;
         rng = rng * 1664525u + 1013904223u; const uint32_t ra = rng >> 8;
         rng = rng * 1664525u + 1013904223u; const uint32_t rb = rng >> 8;
-        const int p0 = mode == 0 ? 0 : mode == 1 ? l / 2 : (int)(ra % (uint32_t)(1 + r % 61));
-        const int p1 = mode == 0 ? 0 : mode == 1 ? (63 - l) / 2 : (int)(rb % (uint32_t)(1 + r % 59));
+        // (range reduction by multiply-shift, not `ra % m`: for operands it can prove to be below 2^24 hipcc 7.2 expands the
+        // remainder through v_rcp_iflag_f32 and never corrects an OVER-estimated quotient — x = q * m - 1 near 2^24 comes back as
+        // 0xFFFFFF; the first version of this probe indexed the LDS with that and "found" 32 lanes out of order.
+        // tools/ubench/urem24_check.hip, profiles/r06_urem24.txt.  No kernel of the library has such an operand pair.)
+        const int p0 = mode == 0 ? 0 : mode == 1 ? l / 2 : (int)((ra * (uint32_t)(1 + r % 61)) >> 24);
+        const int p1 = mode == 0 ? 0 : mode == 1 ? (63 - l) / 2 : (int)((rb * (uint32_t)(1 + r % 59)) >> 24);
         const unsigned long long v0 = 1ull + (unsigned)l, v1 = 1000ull + (unsigned)l;
         su[l] = 7ull * (unsigned)l; sd[l] = (double)(7 * l);
         __syncthreads();

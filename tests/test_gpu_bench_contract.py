@@ -156,15 +156,28 @@ def test_bench_says_so_when_rccl_cannot_be_bound():
     assert a["sketch_md5"] == b["sketch_md5"]
 
 
-def test_bench_world_two_end_to_end_on_one_gpu():
-    """`python bench.py --gpus 2` the way the driver invokes it (no launcher), both ranks on GPU 0 over the host transport:
-    everything bench.py does at N > 1 runs — self_spawn, the pre-warm agreement, all three modes, value_c4 with its ragged
-    last step, the JSON relay — and the sharded sketch is the single-GPU sketch of the same 2 x longer stream."""
+_one_rank = {}
+
+
+def _one_rank_run(key, extra):
+    """single-rank comparison runs, shared between the transports of the world-two test"""
+    if key not in _one_rank:
+        _one_rank[key] = _run(extra)
+    return _one_rank[key]
+
+
+@pytest.mark.parametrize("transport", ["gloo", "fakerccl"])
+def test_bench_world_two_end_to_end_on_one_gpu(transport):
+    """`python bench.py --gpus 2` the way the driver invokes it (no launcher), both ranks on GPU 0 — over the library's host
+    transport (gloo) and over its RCCL branch (fakerccl: hulk_comm_init / ncclAllGather / ncclAllReduce bound to the test double
+    tests/cpp/libfakerccl.so, the code path real RCCL ranks take): everything bench.py does at N > 1 runs — self_spawn, the
+    pre-warm agreement, all three modes, value_c4 with its ragged last step, the JSON relay — and the sharded sketch is the
+    single-GPU sketch of the same 2 x longer stream."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env.update(HULK_BENCH_TRANSPORT="gloo", HULK_BENCH_PREWARM_S="0.3", HULK_BENCH_C4_READS_PER_RANK="4100000")
+    env.update(HULK_BENCH_TRANSPORT=transport, HULK_BENCH_PREWARM_S="0.3", HULK_BENCH_C4_READS_PER_RANK="4100000")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
-    _keep("world_two", p)                                     # (what the two ranks printed: gpurun_out/contract_world_two.txt)
+    _keep("world_two_" + transport, p)                        # (what the two ranks printed: gpurun_out/contract_world_two_<transport>.txt)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
@@ -176,15 +189,18 @@ def test_bench_world_two_end_to_end_on_one_gpu():
     assert abs(out["ms_per_step"] * out["value"] / 1e3 - out["config"]["reads_per_step"]) < 1.0
     cs = out["collective"]["timed_pass"]
     assert cs["steps_full"] >= 1 and cs["steps_delta"] >= 1 and cs["bytes_received"] > 0
+    assert cs["headers_refetched"] == 0 and cs["void_blocks"] == 0, cs
+    assert ("test double" in out["collective"]["transport"]) == (transport == "fakerccl"), out["collective"]["transport"]
+    assert not [k for k in out if k.endswith("_error")], {k: out[k] for k in out if k.endswith("_error")}
     assert [o["mode"] for o in out["other_scaling"]] == ["sliced-strong", "sliced-weak"]
     # value_c4: 2 x 4.1 M reads = 82 intervals = 2 whole steps of 32 + a ragged one of 18 (rank 0: 16, rank 1: 2)
-    assert out["c4_reads"] == 8_200_000 and out["c4_steps"] == 3 and out["value_c4"] > 1e6      # (a rate over gloo on one GPU: only that it ran)
+    assert out["c4_reads"] == 8_200_000 and out["c4_steps"] == 3 and out["value_c4"] > 1e6      # (a rate over a host path on one GPU: only that it ran)
     # the same global stream on ONE rank (4 steps of 32 intervals = 8 plain steps of 16): the same sketch
-    one = _run(["--no-cpu-baseline", "--no-cold", "--no-e2e", "--single-pass", "--steps", "6", "--warmup", "2"])
+    one = _one_rank_run("six", ["--no-cpu-baseline", "--no-cold", "--no-e2e", "--single-pass", "--steps", "6", "--warmup", "2"])
     assert one["config"]["total_reads"] == 6 * 1_600_000
     assert out["sketch_md5"] == one["sketch_md5"]
     strong = [o for o in out["other_scaling"] if o["mode"] == "sliced-strong"][0]
-    half = _run(["--no-cpu-baseline", "--no-cold", "--no-e2e", "--single-pass", "--steps", "3", "--warmup", "1"])
+    half = _one_rank_run("three", ["--no-cpu-baseline", "--no-cold", "--no-e2e", "--single-pass", "--steps", "3", "--warmup", "1"])
     assert strong["sketch_md5"] == half["sketch_md5"]
 
 

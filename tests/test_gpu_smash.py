@@ -83,6 +83,31 @@ def test_smash_cli_end_to_end(tmp_path):
         assert line == ",".join(str(int(v)) for v in mins[names.index(f)]) + ",blank"
     assert main(["smash", "-d", str(d), "-m", "euclidean", "-o", out]) == 1     # not in availMetrics
     assert main(["smash", "-d", str(d), "-k", "21", "-o", out]) == 1            # no sketch with that k
+    # the native form (hulk_smash_files: loader, ordering and CSV in the library) writes the bytes the Python form wrote until
+    # round 6 (json + hashlib + "%.2f"), matrix and banner file alike, and a file name that encoding/csv must quote
+    from hulk_amd import smash as smash_mod
+    odd = d / 'a,"b".json'
+    odd.write_text((d / "s0.json").read_text())
+    for metric in ("jaccard", "weightedjaccard"):
+        o1, m1 = smash_mod.smash(str(d), out + ".native", 15, "histosketch", metric, banner_matrix=True)
+        o2, m2 = smash_mod.smash_python(str(d), out + ".python", 15, "histosketch", metric, banner_matrix=True)
+        assert o1 == o2 and len(o1) == 4 and np.array_equal(m1, m2, equal_nan=True)
+        for suffix in (".hulk-matrix.csv", ".banner-matrix.csv"):
+            assert open(out + ".native" + suffix, "rb").read() == open(out + ".python" + suffix, "rb").read()
+    assert open(out + ".native.hulk-matrix.csv").readline().startswith('"' + str(d) + '/a,""b"".json",')
+    # LoadHULKdata's checks at the command's level (sketchio.go:171-193, 243-254): corrupted MD5, another version, duplicate k
+    import json
+    from hulk_amd._lib import HulkError
+    raw = json.loads((d / "s0.json").read_text())
+    for name, edit, text in (("zz_md5.json", lambda x: x["signatures"][0]["Sketch"]["mins"].__setitem__(0, x["signatures"][0]["Sketch"]["mins"][0] ^ 1), "md5sum mismatch: "),
+                             ("zz_ver.json", lambda x: x.__setitem__("version", "0.0.1"), "the loaded sketch was created with a different version of HULK: 0.0.1"),
+                             ("zz_dup.json", lambda x: x["signatures"].append(x["signatures"][0]), "found 2 possible duplicate sketches in the supplied sketch file: ")):
+        x = json.loads(json.dumps(raw)); edit(x)
+        (d / name).write_text(json.dumps(x, indent=4))
+        with pytest.raises(HulkError, match=text):
+            smash_mod.smash(str(d), out + ".bad", 15)
+        assert main(["smash", "-d", str(d), "-k", "15", "-o", out + ".bad"]) == 1
+        (d / name).unlink()
 
 
 def test_c5_full_size_sampled_against_oracle():

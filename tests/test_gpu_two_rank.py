@@ -299,6 +299,19 @@ def test_void_or_late_header_block_is_never_a_silent_wrong_sketch():
     from hulk_amd import _lib, synth
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    if not _lib.is_experiments_build():
+        # hulk_debug_inject is a hook of the PROFILING build (the shipping library does not export it): this test body runs in
+        # a child pytest that loads libhulkhip_exp.so
+        import subprocess
+        import sys
+        if not os.path.exists(_lib.EXP_LIB_PATH):
+            pytest.skip("profiling build (make -C hulk_amd/csrc EXPERIMENTS=1) not present")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                            __file__ + "::test_void_or_late_header_block_is_never_a_silent_wrong_sketch"],
+                           env=dict(os.environ, HULK_LIB="exp"), capture_output=True, text=True, timeout=1500,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+        return
     world = 3
     total = 7 * world * BATCH * I + 2 * I + 1100      # (a ragged last step; enough reads in the partial interval for the 1 % rule)
     base = _run_threads(world, total)
