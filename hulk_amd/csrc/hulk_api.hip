@@ -133,7 +133,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
         c->lds_order_ok = ord == 1;
         c->cms_chain = !c->lds_order_ok || (p.flags & HULK_FLAG_CMS_CHAIN) != 0;
     }
-    CHK_CREATE(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    CHK_CREATE(create_lane_stream(&c->own_stream, 0));             // (non-blocking, default priority)
     c->stream = c->own_stream;
     const size_t B = (size_t)c->B, S = c->S, SL = c->slots;
     CHK_CREATE(dalloc(&c->d_state, 1));
@@ -259,6 +259,7 @@ void hulk_destroy(hulk_ctx *c) {
         hipFree(ml.x); hipFree(ml.slot); hipFree(ml.key); hipFree(ml.cnt); hipFree(ml.off); hipFree(ml.bsum); hipFree(ml.partial);
         hipFree(ml.nib); hipFree(ml.nib_over); hipFree(ml.lo); hipFree(ml.lo_cnt); hipFree(ml.dmask); hipFree(ml.dsum);
     }
+    for (int i = 0; i < 2; i++) if (c->ev_heavy[i]) hipEventDestroy(c->ev_heavy[i]);
     if (c->ev_stagger) hipEventDestroy(c->ev_stagger);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);

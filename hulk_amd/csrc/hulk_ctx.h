@@ -117,6 +117,7 @@ struct hulk_ctx {
     } lane[2];
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;    // context stream -> lane 1 in front of a batch, and back (lanes_join)
     hipStream_t last_bin_stream = nullptr;              // the stream the latest binning launches went to
+    hipEvent_t ev_heavy[2] = {nullptr, nullptr}; int heavy_idx = 0; bool heavy_set[2] = {false, false};   // experiment HULK_C3_GATE (profiling build)
     int stagger = 1; hipEvent_t ev_stagger = nullptr;   // 1: the lanes are idle; 2: the first batch since recorded ev_stagger behind its k_minimizer_fast
     bool copies_pending = false;                        // host -> device copies were queued on the context's stream since the last fork
     uint32_t work_lanes = 2;                            // hulk_params.work_lanes
@@ -182,6 +183,8 @@ int stage_host_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets,
                      hulk_ctx::HostStage **out);
 int check_host_reads(hulk_ctx *c, const uint64_t *offsets, uint64_t n, uint64_t *max_len_out);
 
+// work-lane stream; in the profiling build HULK_K1_CU_FREE=N leaves N of the 256 CUs (every 256/N-th) to the other streams
+hipError_t create_lane_stream(hipStream_t *s, int priority);
 // arms prof_mark() for the launches this thread issues on behalf of `c` (a context is single-caller)
 struct ProfScope {
     hulk_ctx *prev;

@@ -20,6 +20,20 @@ void prof_mark(hipStream_t s, const char *kernel) {
     c->marks.push_back(m);
 }
 
+hipError_t create_lane_stream(hipStream_t *s, int priority) {
+    if (const char *e = HULK_EXP_ENV("HULK_K1_CU_FREE")) {       // experiment: the binning kernels may not use N of the CUs
+        const int nfree = atoi(e);
+        if (nfree > 0 && nfree < 256) {
+            uint32_t mask[8];
+            for (int i = 0; i < 8; i++) mask[i] = 0xffffffffu;
+            const int every = 256 / nfree;
+            for (int i = 0, n = 0; i < 256 && n < nfree; i += every, n++) mask[i >> 5] &= ~(1u << (i & 31));
+            return hipExtStreamCreateWithCUMask(s, 8, mask);      // (default priority)
+        }
+    }
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority);
+}
+
 uint32_t *ring_hist(hulk_ctx *c) { return c->d_hist + (size_t)c->cur_ring * (size_t)c->ring_n * (size_t)c->B; }
 
 // The work lane of spectrum ring r.  With two lanes (hulk_params.work_lanes, the default) every launch that touches ring r —
@@ -213,6 +227,12 @@ static int bin_fast(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, const uin
         HIPCHK(c, hipEventCreateWithFlags(&pr.a, PROFILE_EVENT_FLAGS)); HIPCHK(c, hipEventCreateWithFlags(&pr.b, PROFILE_EVENT_FLAGS));
         HIPCHK(c, hipEventRecord(pr.a, s));
     }
+    if (c->scaling && HULK_EXP_ENV("HULK_C3_GATE")) {
+        // experiment: k_minimizer_fast does not start while the 112 KB-LDS kernels of the flush queued TWO batches ago (the one that
+        // ran beside the previous batch's jump-hash kernels) still hold the CUs' LDS — it would run at a quarter of its occupancy
+        const int older = c->heavy_idx ^ 1;
+        if (c->heavy_set[older]) HIPCHK(c, hipStreamWaitEvent(s, c->ev_heavy[older], 0));
+    }
     HIPCHK(c, launch_minimizer_fast(s, d_bases, d_offsets, n, P, ln.ml, c->d_state, c->d_min_slots));
     if ((c->profiling & 2)) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
     if (c->stagger == 1 && c->work_lanes > 1 && !c->no_overlap) {
@@ -258,7 +278,7 @@ static int lane_open(hulk_ctx *c, int li) {
     if (li == 0 || c->lane[1].stream) return HULK_OK;
     int prio = 0;
     if (c->stream) (void)hipStreamGetPriority(c->stream, &prio);
-    HIPCHK(c, hipStreamCreateWithPriority(&c->lane[1].stream, hipStreamNonBlocking, prio));
+    HIPCHK(c, create_lane_stream(&c->lane[1].stream, prio));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     return HULK_OK;
@@ -326,6 +346,8 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
     } else {
         MinimizerParams P = piece_params(c, bases_bytes, interval, fill, false);
         int threads = 256;
+        ProfScope prof_scope(c);
+        struct Close { hipStream_t s; ~Close() { prof_mark(s, "-"); } } prof_close{s};
         rc = issue_flush(c, nullptr);
         if (rc == HULK_OK) {
             if (hipEvent_t e = ring_write_event(c)) HIPCHK(c, hipStreamWaitEvent(s, e, 0));
@@ -358,6 +380,12 @@ int flush_kernels(hulk_ctx *c, hipStream_t s, uint32_t *hist, const FlushBatch &
                                        c->d_segfac, c->d_sege0, c->d_cstart, c->d_f64, c->d_rcp32, c->cms_depth,
                                        c->cms_width, c->row_stride, c->decay_weight, c->d_state, fb, pf.a, pf.b, c->cms_chain));
         if ((c->profiling & 8)) c->prof.push_back(pf);
+        if (HULK_EXP_ENV("HULK_C3_GATE")) {
+            c->heavy_idx ^= 1;
+            if (!c->ev_heavy[c->heavy_idx]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_heavy[c->heavy_idx], hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(c->ev_heavy[c->heavy_idx], s));
+            c->heavy_set[c->heavy_idx] = true;
+        }
     } else {
         HIPCHK(c, launch_cms_binorder(s, hist, c->d_pos16, c->d_meta8, c->d_ctr, c->d_segsum, c->d_cbase, c->d_f64,
                                       c->d_rcp32, c->cms_depth, c->cms_width, c->row_stride, c->d_state, fb, c->cms_chain));

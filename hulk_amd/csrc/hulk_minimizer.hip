@@ -405,7 +405,11 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     // So do reads with any other code-4 byte (IUPAC letters, anything seq_nt4_table maps to 4); U / u is T; only the raw bytes
     // 0..3 (which the table maps to themselves) defer the read to k_minimizer_bin.  (PAIR: the second
     // group's first k-mer needs N(posoff - 1), a base only its partner staged: read from the partner's flag dwords.)
+#ifdef HULK_ANALYSIS_NO_NV      // tools/valu_by_line.py: the static count of the main loop without the N variant = what a read without N executes
+    constexpr bool NV = false;
+#else
     constexpr bool NV = (DX && HP && 2 * (KC + WM) <= 64) || (!DX && WM <= 9);   // one-window form, or the rolling form (the
+#endif
                                                                                    // 16-position instances are at 128 VGPRs already)
     const int half = PAIR ? (grp & 1) : 0;                         // which half of the read this group takes
     const int sub = PAIR ? ((grp & 3) >> 1) : (grp & 3);           // read of the iteration

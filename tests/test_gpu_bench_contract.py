@@ -34,7 +34,7 @@ def _run(extra, env_extra=None, timeout=900):
     if "--c3" in extra:                                      # (the C3 / C5 legs only where a test looks at them)
         extra = [x for x in extra if x != "--c3"]
     else:
-        extra = extra + ["--no-c3", "--no-c5"]
+        extra = extra + ["--no-c3", "--no-c5", "--no-long-reads"]
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2"] + extra,   # (2: both work lanes have run once before the clock starts)
                        capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -77,6 +77,17 @@ def test_bench_json_contract_and_collective_path():
     assert a["rccl_ranks"] == 0 and a["collective"] is None
     # C2 exactly as BASELINE states it: 10 M reads on a fresh context; below the steady-state rate, above 1e8
     assert a["cold_reads"] == 10_000_000 and 1e8 < a["value_cold"] < 1.2 * a["value"]
+    # ... and the same run with the GPU's clocks ramped between hulk_create and the first read: idle clocks separated from code
+    assert 1e8 < a["value_cold_ramped"] < 1.2 * a["value"] and len(a["cold_ramped_seconds_all_runs"]) == 2
+    # sequences beyond the short-read kernels: 5 kb reads and 500 kb contigs (sketch.go:102-135), a rate, a kernel table, a roofline
+    lr = a["long_reads"]
+    for shape, n, L in (("reads_5kb", 200_000, 5_000), ("contigs_500kb", 2_000, 500_000)):
+        x = lr[shape]
+        assert x["sequences"] == n and x["length"] == L and x["bases_per_s"] > 1e9 and x["reads_per_s"] * L == pytest.approx(x["bases_per_s"])
+        assert x["kernels_alone"]["us"]["k_long_hash"] > 0 and x["kernels_alone"]["us"]["k_long_emit"] > 0
+        r_ = x["roofline_k_long_hash"]
+        assert r_["bound"] == "hbm" and 0 < r_["frac"] < 1 and abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-12
+        assert 150 < x["minimizers_per_kb"] < 250                # ~2 / (w + 1) distinct minimizers per position of a random sequence
     assert a["value_unpruned"] is not None and a["value_unpruned"] <= 1.2 * a["value"]
     # end to end from a FASTQ file, plain and .gz: host-bound, far below the kernel-path rate, same sketch both ways
     e2e = a["e2e"]
@@ -126,12 +137,12 @@ def test_bench_line_survives_any_secondary_leg():
     """Fault isolation: every secondary leg may raise (HULK_BENCH_FAIL names the legs that do) and the ONE line still comes
     out with the headline in it, `<leg>_error` for each of them, and exit status 0."""
     ok = _run(["--no-cpu-baseline", "--single-pass", "--no-cold", "--no-e2e"])
-    legs = "kernels,unpruned,long,cold,c3,c5,e2e,cpu_baseline"
+    legs = "kernels,unpruned,long,cold,c3,long_reads,c5,e2e,cpu_baseline"
     a = _run(["--c3"], {"HULK_BENCH_FAIL": legs})
     for leg in legs.split(","):
         assert "HULK_BENCH_FAIL" in a[leg + "_error"], leg
     assert a["value"] > 1e7 and a["sketch_md5"] == ok["sketch_md5"] and a["roofline"] is None
-    for gone in ("value_unpruned", "ms_per_step_long", "value_cold", "c3", "c5", "e2e", "cpu_baseline"):
+    for gone in ("value_unpruned", "ms_per_step_long", "value_cold", "c3", "long_reads", "c5", "e2e", "cpu_baseline"):
         assert gone not in a, gone
     # at N > 1 (here: world 1 through the collective path) the modes and C4 each on their own; a failed collective leg
     # makes the ranks skip the collective legs behind it (they may no longer be in step), never the line

@@ -196,3 +196,48 @@ def test_host_buffers_in_chunks_equal_device_path():
     assert g.counters() == c
     assert np.array_equal(m, m2) and np.array_equal(w, w2)
     g.close()
+
+
+def test_long_sequences_against_oracle_and_split_invariance():
+    """bench.py's `long_reads` shapes (5 kb reads, 500 kb FASTA contigs: src/pipeline/sketch.go:102-135 hands the whole record to
+    AddSeq) run k_minimizer_bin's deferral + k_long_hash / k_long_emit.  A prefix against the oracle — spectrum, minimizer count,
+    sketch — and, at the leg's full size, properties that do not need it: the k-mer spectrum is a sum over sequences (two halves
+    binned separately add up to the whole), every sequence is counted once, the result does not depend on how calls cut the stream."""
+    import torch
+    from hulk_amd import synth
+    from oracle import pyorc
+    # (1) prefix vs the oracle: 300 reads of 5 kb, one contig of 500 kb (interval 0: one spectrum, one flush)
+    for n, Lx in ((300, 5_000), (1, 500_000)):
+        bases, offsets = synth.reads_numpy(0, n, Lx)
+        g = gpu().GpuSketcher(21, 9, 64)
+        g.add_reads(bases, offsets)
+        gh = g.histogram()
+        g.finish()
+        o = pyorc.Sketcher(21, 9, 64, 0, 1.0, 0)
+        o.add_reads(bases, offsets)
+        oh = o.histogram().astype(np.uint32)
+        o.finish()
+        assert np.array_equal(gh, oh), f"spectra differ in {(gh != oh).sum()} bins"
+        assert g.counters()["n_minimizers"] == o.counters()["n_minimizers"]
+        gm, gw = g.sketch(); om, ow = o.sketch()
+        assert np.array_equal(gm, om) and np.allclose(gw, ow, rtol=1e-9, atol=0)
+        g.close(); o.close()
+    # (2) the leg's sizes: linearity of the spectrum and call-boundary invariance
+    for n, Lx in ((200_000, 5_000), (2_000, 500_000)):
+        b, off = synth.reads_torch(0, n, Lx)
+        torch.cuda.synchronize()
+        hists, cnts = [], []
+        for cuts in ((0, n), (0, n // 2, n), (0, n // 3 + 1, n)):
+            g = gpu().GpuSketcher(21, 9, 8)
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                sub_off = (off[lo:hi + 1] - off[lo]).contiguous()
+                sub = b[int(off[lo]):]
+                torch.cuda.synchronize()
+                g.add_reads_device(sub.data_ptr(), sub_off.data_ptr(), hi - lo, Lx, sub.numel())
+                g.synchronize()
+            hists.append(g.histogram()); cnts.append(g.counters())
+            g.close()
+        assert np.array_equal(hists[0], hists[1]) and np.array_equal(hists[0], hists[2])
+        assert cnts[0] == cnts[1] == cnts[2] and cnts[0]["n_reads"] == n and cnts[0]["total_len"] == n * Lx
+        assert int(hists[0].sum()) == cnts[0]["n_minimizers"]                    # every distinct minimizer of a sequence is one increment
+        assert 0.15 * n * Lx < cnts[0]["n_minimizers"] < 0.25 * n * Lx           # ~2 / (w + 1) per position
