@@ -76,7 +76,7 @@ def _newest(*names):
     return os.path.join("profiles", names[-1])
 
 
-PMC_PROFILE = _newest("r05_pmc.json", "r04_pmc.json", "r03_pmc.json")
+PMC_PROFILE = _newest("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json")
 ISA_MIX = _newest("r04_isa_mix.json", "r03_isa_mix.json")   # tools/isa_mix.py over the production kernels, priced by profiles/r03_op_cost.txt
 LEG_TIMEOUT_S = float(os.environ.get("HULK_BENCH_LEG_TIMEOUT_S", "300"))
 FAIL_LEGS = set(x for x in os.environ.get("HULK_BENCH_FAIL", "").split(",") if x)
@@ -1027,6 +1027,8 @@ def main():
                          "traffic": from_profile("k_minimizer_fast", "hbm_bytes_per_launch"),       # PMC passes of the same command, committed (traffic_profile)
                          "traffic_from_profile": from_profile("k_minimizer_fast", "hbm_bytes_per_launch"),
                          "traffic_profile": PMC_PROFILE if pmc else None,
+                         "traffic_note": "HBM bytes per launch from the rocprofv3 PMC passes of this same command, committed as traffic_profile (collected "
+                                         "separately per MI355X_MICROARCH.md: a --pmc run cannot be combined with the timed one); not a measurement of THIS run",
                          "launches": int(n_k1), "avg_launch_us": k1_avg_s * 1e6,
                          "alg_bytes_per_launch": k1_bytes, "alg_bytes_per_read": READ_LEN + 8,
                          "intermediate_bytes": float(reads_per_rank_step) * 9.0 * per_read_min,
@@ -1036,7 +1038,7 @@ def main():
                                            "alone) and every instrumented kernel bracketed by HIP events on the stream it is "
                                            "launched on — the headline pass itself carries no brackets and overlaps its kernels, "
                                            "which stretches each kernel's own duration; rocprofv3 of HULK_NO_OVERLAP=1 bench.py "
-                                           "(profiles/r05_kernel_stats_serial.md) shows the same per-launch figures",
+                                           "(profiles/r06_kernel_stats_serial.md) shows the same per-launch figures",
                          "note": f"single kernels by measured time: k_minimizer_fast {k1_avg_s * 1e6:.1f} us, k_jump_bin "
                                  f"{kj_avg_s * 1e6:.1f} us, k_jump_left {kl_avg_s * 1e6:.1f} us per launch of {reads_per_rank_step} reads "
                                  "(stage K1b = the last two; it has no SURVEY 8(d) bytes — the minimizer list is an artefact of "
@@ -1084,7 +1086,7 @@ def main():
         out["value_unpruned"] = value
     # ---- leg `scan_unpruned`: the one HBM-bound kernel of the path priced on a FULL pass: HULK_FLAG_NO_PRUNE + NO_OVERLAP
     # (k_cws_scan alone, bracketed by HIP events on its stream): 4 * slots * k^4 bytes of K32 + the two reciprocal vectors
-    # per launch over its average duration (profiles/r05_kernel_stats_serial_noprune.md holds the same figure from rocprofv3)
+    # per launch over its average duration (profiles/r06_kernel_stats_serial_noprune.md holds the same figure from rocprofv3)
     if not single and plain_single and rank == 0:
         def scan_unpruned():
             p = run_pass(False, brackets=1, serial=True, n_steps=min(steps, 10))

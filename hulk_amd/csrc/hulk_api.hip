@@ -114,6 +114,7 @@ int hulk_create(const hulk_params *params, hulk_ctx **out) {
     if (!strstr(prop.gcnArchName, "gfx950"))
         return fail(nullptr, HULK_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName);
 
+    fq_sweep_idle();                                             // (the device FASTQ parser's pooled buffers: hulk_ingest.hip)
     hulk_ctx *c = new hulk_ctx();
     c->p = p; c->B = (int32_t)bins; c->S = p.sketch_size; c->slot_begin = p.slot_begin; c->slots = p.slot_count;
     c->drift = p.decay_ratio != 1.0;
@@ -267,6 +268,7 @@ void hulk_destroy(hulk_ctx *c) {
     comm_teardown(c);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
+    fq_sweep_idle();
 }
 
 int hulk_set_stream(hulk_ctx *c, void *hip_stream) {

@@ -41,7 +41,7 @@ uint32_t *ring_hist(hulk_ctx *c) { return c->d_hist + (size_t)c->cur_ring * (siz
 // alternate between the rings, alternate between two streams and are NOT ordered against each other: batch n+1's
 // k_minimizer_fast (VALU + LDS, 4 waves per SIMD) runs beside batch n's k_jump_bin / k_jump_left / spectrum kernels (tails,
 // low occupancy) and the two fill each other's issue bubbles — what two independent contexts fed alternately measured as
-// +11 % (tools/two_ctx_overlap.py).  Lane 0 is the context's stream, lane 1 a stream of its own (same priority).
+// +11 % (tools/archive/two_ctx_overlap.py).  Lane 0 is the context's stream, lane 1 a stream of its own (same priority).
 hipStream_t lane_stream(hulk_ctx *c, int ring) {
     return (ring == 1 && c->lane[1].stream) ? c->lane[1].stream : c->stream;
 }

@@ -1555,13 +1555,17 @@ int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, const Inge
 //   copy(b) -> parse(b) [after parse(b-1): the tail; after the binning of block b-2 has read the output set] -> the block's
 //   scalars reach the host -> hulk_add_reads_device(b) while copy(b+1) / parse(b+1) are already under way.
 // Buffers: 4 pinned blocks, 3 raw device blocks (porch + block), 2 output sets (bases + offsets), one set of line-index arrays
-// — about 130 MB pinned and 250 MB of HBM at the default block size.  They belong to the PROCESS, not to a context: a run
-// borrows an idle set for its device and block size and hands it back (a `hulk sketch` per file on fresh contexts would
-// otherwise pin and unpin 128 MB per file: tens of milliseconds each).
+// — 4 x 16 MiB = 64 MB pinned and about 250 MB of HBM at the default block size.  They belong to the PROCESS, not to a context: a
+// run borrows an idle set for its device and block size and hands it back (a `hulk sketch` per file on fresh contexts would
+// otherwise pin and unpin 64 MB per file: tens of milliseconds each).  The pool is bounded in size (FQ_POOL_MAX sets) and in AGE:
+// a set nobody borrowed for FQ_IDLE_SECONDS is freed by the next hulk_create / hulk_destroy / hulk_sketch_files of the process
+// (fq_sweep_idle), so a host that sketched one file does not hold the buffers for as long as it keeps using the library;
+// hulk_release_caches() frees them at once.
 // ------------------------------------------------------------------------------------------
 struct FqDev {
     static constexpr int NRAW = 3, NOUT = 2, NHOST = 4, NST = 4;
     int device = 0; size_t block = 0; uint32_t porch = 0;
+    double idle_since = 0.0;                                       // when the set went back to the pool (steady clock, seconds)
     hipStream_t cs = nullptr, ps = nullptr;
     uint8_t *d_raw[NRAW] = {}, *h_buf[NHOST] = {}, *d_bases[NOUT] = {};
     uint64_t *d_off[NOUT] = {};
@@ -1595,11 +1599,13 @@ struct FqDev {
 static std::mutex g_fq_mu;
 static std::vector<FqDev *> g_fq_idle;
 constexpr size_t FQ_POOL_MAX = 2;
+constexpr double FQ_IDLE_SECONDS = 10.0;
+static double fq_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static void fq_dev_release(FqDev *d) {
     if (!d) return;
     {
         std::lock_guard<std::mutex> g(g_fq_mu);
-        if (g_fq_idle.size() < FQ_POOL_MAX) { g_fq_idle.push_back(d); return; }
+        if (g_fq_idle.size() < FQ_POOL_MAX) { d->idle_since = fq_now(); g_fq_idle.push_back(d); return; }
     }
     FqDev::destroy(d);
 }
@@ -1608,6 +1614,18 @@ namespace hulk {
 void fq_release_idle() {
     std::vector<FqDev *> drop;
     { std::lock_guard<std::mutex> g(g_fq_mu); drop.swap(g_fq_idle); }
+    for (FqDev *d : drop) FqDev::destroy(d);
+}
+// frees the idle sets nobody has borrowed for FQ_IDLE_SECONDS (called from hulk_create / hulk_destroy / hulk_sketch_files)
+void fq_sweep_idle() {
+    std::vector<FqDev *> drop;
+    {
+        std::lock_guard<std::mutex> g(g_fq_mu);
+        const double t = fq_now();
+        for (size_t i = 0; i < g_fq_idle.size();)
+            if (t - g_fq_idle[i]->idle_since > FQ_IDLE_SECONDS) { drop.push_back(g_fq_idle[i]); g_fq_idle.erase(g_fq_idle.begin() + i); }
+            else i++;
+    }
     for (FqDev *d : drop) FqDev::destroy(d);
 }
 }  // namespace hulk

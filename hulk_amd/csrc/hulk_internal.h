@@ -204,6 +204,7 @@ int ctx_stage_release(hulk_ctx *c);
 // for the device FASTQ parser of hulk_sketch_files (hulk_ingest.hip / hulk_fastq.hip)
 int ctx_device(const hulk_ctx *c);
 void fq_release_idle();      // hulk_release_caches: the idle buffer sets of the process (hulk_ingest.hip)
+void fq_sweep_idle();        // ... those idle for more than 10 s only (hulk_create / hulk_destroy / hulk_sketch_files)
 // the context's stream waits for `e` (a parse that filled device buffers the next hulk_add_reads_device reads)
 int ctx_wait_event(hulk_ctx *c, hipEvent_t e);
 // record e0 on the context's stream and, if there is a second work lane, e1 on it: both passed = the kernels queued so far

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_minimizer_bin(const uint8_t *__restrict
 
     uint32_t qn = 0;                 // wave-uniform
     unsigned long long nmin = 0;     // wave-uniform
-    const uint32_t dbg = P.debug;    // ablation switches for tools/k1_ablate.py (0 in production)
+    const uint32_t dbg = P.debug;    // ablation switches for tools/archive/k1_ablate.py (0 in production)
     uint32_t sink = 0;
 
     if (!read_list && blockIdx.x == 0 && threadIdx.x == 0 && n_reads)
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
     uint8_t *sl8 = ml.slot + region * ml.rcap;
     uint32_t wcount = 0;              // wave-uniform: values written to the region so far
     uint32_t dmask = 0;               // wave-uniform: reads of the region handed to the generic kernel
-    // ablation switches (tools/k1_ablate.py) exist only in the DBG instantiation: in the production kernel they
+    // ablation switches (tools/archive/k1_ablate.py) exist only in the DBG instantiation: in the production kernel they
     // cost a branch per k-mer position and SGPRs the compiler then spills to VGPR lanes
     const uint32_t dbg = DBG ? P.debug : 0u;
     uint32_t sink = 0;

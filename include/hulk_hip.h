@@ -348,8 +348,9 @@ int hulk_debug_read(hulk_ctx *ctx, uint32_t what, void *out, uint64_t *bytes_io)
 #endif /* HULK_EXPERIMENTS */
 
 /* Process-level buffers the library keeps between calls — the device FASTQ parser's pinned and device blocks (hulk_sketch_files:
- * about 130 MB pinned, 250 MB of HBM per set, at most two sets) and hulk_smash's device arrays — are freed; the next call that
- * needs them allocates again.  Call it with no hulk_sketch_files / hulk_smash in flight on another thread. */
+ * 64 MB pinned and about 250 MB of HBM per set at the default block size; at most two sets, and a set nobody borrowed for 10 s is
+ * freed by the process's next hulk_create / hulk_destroy / hulk_sketch_files) and hulk_smash's device arrays — are freed at once;
+ * the next call that needs them allocates again.  Call it with no hulk_sketch_files / hulk_smash in flight on another thread. */
 int hulk_release_caches(void);
 
 /* Test hook: add counts to the current k-mer spectrum directly (host uint32[num_bins]). */

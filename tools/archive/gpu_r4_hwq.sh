@@ -3,7 +3,7 @@
 # (2 work lanes + flush + estimates)?  The contract test first (fresh box), then A/B.
 O=gpurun_out; mkdir -p $O; : > $O/hwq_ab.txt
 timeout 1500 python -m pytest tests/test_gpu_bench_contract.py -x -q -m gpu > $O/hwq_contract.txt 2>&1; echo "contract rc=$?" >> $O/hwq_contract.txt; tail -3 $O/hwq_contract.txt
-one() { python bench.py "$@" --no-cold --no-e2e --no-c3 --no-c5 --no-cpu-baseline 2>> $O/hwq.err | python -c "
+one() { python bench.py "$@" --no-cold --no-e2e --no-c3 --no-c5 --no-long-reads --no-cpu-baseline 2>> $O/hwq.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 print('$LABEL: %.4f ms/step  unpruned %s  long %s  md5 %s %s' % (d['ms_per_step'], d.get('ms_per_step_unpruned'), d.get('ms_per_step_long'), d['sketch_md5'][:8], [k for k in d if k.endswith('_error')]))" | tee -a $O/hwq_ab.txt; }

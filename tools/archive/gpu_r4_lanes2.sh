@@ -8,7 +8,7 @@ from hulk_amd import _lib
 for prio in default -1 0 1; do
   if [ $prio = default ]; then unset HULK_FLUSH_PRIORITY; else export HULK_FLUSH_PRIORITY=$prio; fi
   for p in 2; do
-    timeout 300 python bench.py --lanes $p --single-pass --no-cold --no-e2e --no-c3 --no-c5 --no-cpu-baseline --steps ${STEPS:-60} --warmup 4 2> $O/lanes_$p.err | python -c "
+    timeout 300 python bench.py --lanes $p --single-pass --no-cold --no-e2e --no-c3 --no-c5 --no-long-reads --no-cpu-baseline --steps ${STEPS:-60} --warmup 4 2> $O/lanes_$p.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d.get('roofline') or {}
 print('flush prio $prio lanes $p: %.4f ms/step  %.4g reads/s  md5 %s' % (d['ms_per_step'], d['value'], d['sketch_md5'][:8]))" | tee -a $O/lanes_sweep2.txt

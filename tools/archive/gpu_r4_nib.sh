@@ -4,7 +4,7 @@ O=gpurun_out; mkdir -p $O; rm -f $O/nib_sweep.txt
 for cfg in "18 1024" "16 256"; do set -- $cfg
 HULK_NIB_RLOG=$1 HULK_NIB_BLOCK=$2 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "nibble or random_reads or fixture or lanes or k31 or ring_wraparound or repetitive or every_short" > $O/nib_parity.txt 2>&1; echo "parity rlog=$1 block=$2 rc=$? $(tail -1 $O/nib_parity.txt)" | tee -a $O/nib_sweep.txt
 done
-one() { python bench.py "$@" --single-pass --no-cold --no-e2e --no-c3 --no-c5 --no-cpu-baseline --steps 60 --warmup 4 2>> $O/nib.err | python -c "
+one() { python bench.py "$@" --single-pass --no-cold --no-e2e --no-c3 --no-c5 --no-long-reads --no-cpu-baseline --steps 60 --warmup 4 2>> $O/nib.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 print('$LABEL: %.4f ms/step  kernels alone %.4f  md5 %s %s' % (d['ms_per_step'], d.get('ms_per_step_kernels_alone',0), d['sketch_md5'][:8], [k for k in d if k.endswith('_error')]))" | tee -a $O/nib_sweep.txt; }

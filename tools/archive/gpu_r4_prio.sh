@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4: priority of the flush stream when the flush is NOT skipped (bounds off; C3 with decay): lowest (default) / same as the lanes / highest
 O=gpurun_out; mkdir -p $O; : > $O/prio_ab.txt
-one() { python bench.py "$@" --no-cold --no-e2e --no-c3 --no-c5 --no-cpu-baseline --no-long 2>> $O/prio.err | python -c "
+one() { python bench.py "$@" --no-cold --no-e2e --no-c3 --no-c5 --no-long-reads --no-cpu-baseline --no-long 2>> $O/prio.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 print('$LABEL: %.4f ms/step  md5 %s %s' % (d['ms_per_step'], d['sketch_md5'][:8], [k for k in d if k.endswith('_error')]))" | tee -a $O/prio_ab.txt; }

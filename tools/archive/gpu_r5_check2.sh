@@ -19,7 +19,7 @@ print('e2e', {k:round(v.get('value')/1e6,1) for k,v in e.items() if isinstance(v
 print('cpu', d.get('cpu_baseline'))
 PY
 export HULK_LIB=exp R=r05
-TITLE="Round 5: each kernel alone (HULK_NO_OVERLAP=1), CWS-scan bounds OFF (bench.py --no-prune = HULK_FLAG_NO_PRUNE on the timed context)" CMD="HULK_LIB=exp HULK_NO_OVERLAP=1 python bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --no-prune"
+TITLE="Round 5: each kernel alone (HULK_NO_OVERLAP=1), CWS-scan bounds OFF (bench.py --no-prune = HULK_FLAG_NO_PRUNE on the timed context)" CMD="HULK_LIB=exp HULK_NO_OVERLAP=1 python bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --no-long-reads --no-prune"
 HULK_NO_OVERLAP=1 BENCH_ARGS="--no-prune" bash tools/gpu_prof_bench.sh > $O/np.txt 2>&1
 python tools/rocprof_summary.py gpurun_out/prof_bench/b_results.db $O/r05_kernel_stats_serial_noprune.md "$TITLE" "$CMD" > /dev/null
 grep -E "^\| k_(cms|cws_scan|count|flush|rcp)" $O/r05_kernel_stats_serial_noprune.md | head

@@ -8,7 +8,7 @@ for lanes in 1 2; do
 done
 HULK_LIB=exp HULK_CMSD_CHAIN=1 python tools/run_config.py --k 31 --S 1024 --decay 0.02 --reads 32000000 --interval 100000 --batch 16 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c3 chain-form k_cmsd_freq (profiling build): %.3e reads/s' % d['reads_per_s'])"
 R=r05 bash tools/gpu_prof_c3.sh 2>&1 | grep -E "^\| k_(cmsd|cms_|cws_scan|minimizer_fast|jump|nibble|elem|slot|scan|rcp)" | head -24
-timeout 600 python bench.py --no-cpu-baseline --no-c5 --no-e2e > $O/bench_cmsd.json 2> $O/bench_cmsd.err; echo "bench rc=$?"
+timeout 600 python bench.py --no-cpu-baseline --no-c5 --no-long-reads --no-e2e > $O/bench_cmsd.json 2> $O/bench_cmsd.err; echo "bench rc=$?"
 python - <<'PY'
 import json
 d=json.load(open('gpurun_out/bench_cmsd.json'))

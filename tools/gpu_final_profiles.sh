@@ -2,7 +2,7 @@
 export HULK_LIB=${HULK_LIB:-exp}    # the profiling build: HULK_NO_OVERLAP and the other experiment switches exist only there (make EXPERIMENTS=1)
 # alone; every kernel alone with the CWS bounds really off), PMC json, bench line.   gpurun -- 'bash tools/gpu_final_profiles.sh'
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-R=${R:-r05}
+R=${R:-r06}
 O=$GRAFT_REPO_ROOT/gpurun_out/final_$R; rm -rf $O; mkdir -p $O
 run() { # name, bench args, env...
   name=$1; args=$2; shift; shift
@@ -11,9 +11,9 @@ run() { # name, bench args, env...
   cp gpurun_out/prof_bench/bench.json $O/$name.bench.json
   rm -rf gpurun_out/prof_bench
 }
-TITLE="Round ${R#r0}: default configuration (two streams, CWS-scan bounds on)" CMD="python bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --single-pass" run ${R}_kernel_stats "" A=1
-TITLE="Round ${R#r0}: each kernel alone (HULK_NO_OVERLAP=1), CWS-scan bounds on" CMD="HULK_NO_OVERLAP=1 python bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --single-pass" run ${R}_kernel_stats_serial "" HULK_NO_OVERLAP=1
-TITLE="Round ${R#r0}: each kernel alone (HULK_NO_OVERLAP=1), CWS-scan bounds OFF (bench.py --no-prune = HULK_FLAG_NO_PRUNE on the timed context)" CMD="HULK_NO_OVERLAP=1 python bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --no-prune" run ${R}_kernel_stats_serial_noprune "--no-prune" HULK_NO_OVERLAP=1
+TITLE="Round ${R#r0}: default configuration (two streams, CWS-scan bounds on)" CMD="python bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --no-long-reads --single-pass" run ${R}_kernel_stats "" A=1
+TITLE="Round ${R#r0}: each kernel alone (HULK_NO_OVERLAP=1), CWS-scan bounds on" CMD="HULK_NO_OVERLAP=1 python bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --no-long-reads --single-pass" run ${R}_kernel_stats_serial "" HULK_NO_OVERLAP=1
+TITLE="Round ${R#r0}: each kernel alone (HULK_NO_OVERLAP=1), CWS-scan bounds OFF (bench.py --no-prune = HULK_FLAG_NO_PRUNE on the timed context)" CMD="HULK_NO_OVERLAP=1 python bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --no-long-reads --no-prune" run ${R}_kernel_stats_serial_noprune "--no-prune" HULK_NO_OVERLAP=1
 HULK_NO_OVERLAP=1 bash tools/gpu_pmc.sh > $O/pmc_print.txt 2>&1
 python tools/pmc_to_json.py gpurun_out/pmc $O/${R}_pmc.json
 rm -rf gpurun_out/pmc

@@ -3,7 +3,7 @@ export HULK_LIB=${HULK_LIB:-exp}    # the profiling build: HULK_NO_OVERLAP and t
 # HBM traffic, VALU activity, LDS activity / bank conflicts, L2 hits.  Results -> gpurun_out/pmc/<pass>/
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc; rm -rf $OUT; mkdir -p $OUT
-BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --single-pass --steps 5 --warmup 1 $BENCH_ARGS"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --no-long-reads --single-pass --steps 5 --warmup 1 $BENCH_ARGS"
 cd /tmp
 pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o p --output-format csv -- $BENCH > /dev/null 2> $OUT/$name.err; }
 pass fetch FETCH_SIZE

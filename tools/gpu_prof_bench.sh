@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 export HULK_LIB=${HULK_LIB:-exp}    # the profiling build: HULK_NO_OVERLAP and the other experiment switches exist only there (make EXPERIMENTS=1)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_bench; rm -rf $OUT; mkdir -p $OUT
-cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT -o b -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --single-pass $BENCH_ARGS > $OUT/bench.json 2> $OUT/err.txt
+cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT -o b -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-cold --no-e2e --no-c3 --no-c5 --no-long-reads --single-pass $BENCH_ARGS > $OUT/bench.json 2> $OUT/err.txt
 tail -1 $OUT/bench.json | cut -c1-400
 python - <<'PY'
 import sqlite3,glob,os

@@ -16,5 +16,5 @@ echo "two lanes + gate:                                     $(HULK_C3_GATE=1 c3 
 cat $O/r6d_c3_sched.txt
 unset HULK_LIB
 timeout 900 python -m pytest tests/test_gpu_fullsize.py::test_long_sequences_against_oracle_and_split_invariance -x -q -m gpu > $O/r6d_longtest.txt 2>&1; echo "long test rc=$?"; tail -3 $O/r6d_longtest.txt
-timeout 900 python bench.py --no-c3 --no-c5 --no-e2e --no-cpu-baseline > $O/r6d_bench.json 2> $O/r6d_bench.err; echo "bench rc=$?"; tail -c 300 $O/r6d_bench.err
+timeout 900 python bench.py --no-c3 --no-c5 --no-long-reads --no-e2e --no-cpu-baseline > $O/r6d_bench.json 2> $O/r6d_bench.err; echo "bench rc=$?"; tail -c 300 $O/r6d_bench.err
 timeout 1200 python tools/gpu_flake_hunt2.py 90 --world 2 --transport gloo --jobs 3 --seconds 480 > $O/r6d_flake_gloo.txt 2>&1; echo "flake gloo rc=$?"; tail -3 $O/r6d_flake_gloo.txt
