@@ -16,6 +16,7 @@
 #ifndef HULK_HPP
 #define HULK_HPP
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <stdexcept>
@@ -198,6 +199,29 @@ inline std::vector<double> Smash(const std::vector<HistoSketch> &sketches, const
     else throw Error(HULK_ERR_ARG, "supplied distance metric is not available: " + metric);
     const int rc = hulk_smash(device, mins.data(), weights.data(), N, S, m, out.data());
     if (rc != HULK_OK) throw Error(rc, hulk_strerror(rc));
+    return out;
+}
+
+// `hulk smash` as the reference runs it (cmd/smash.go:160-226): the sketch files of a directory in, <outFile>.hulk-matrix.csv out —
+// LoadHULKdata (JSON, class / version, MD5) for every file, FindSketch(kSize, algo), the matrix on the GPU, the CSV — all inside the
+// library (hulk_smash_files).  Returns the distances in sorted-path order, [s * N + q]; throws hulk::Error with the reference's message.
+struct SmashStats { double SecondsLoad = 0, SecondsMatrix = 0, SecondsCSV = 0, KernelMs = 0; uint32_t Sketches = 0, SketchSize = 0; };
+inline std::vector<double> SmashFiles(const std::vector<std::string> &jsonFiles, uint32_t kSize, const std::string &algo,
+                                      const std::string &metric, const std::string &matrixCSV, const std::string &bannerCSV = std::string(),
+                                      SmashStats *stats = nullptr, int device = 0, uint32_t threads = 0) {
+    std::vector<const char *> ptr;
+    for (const auto &f : jsonFiles) ptr.push_back(f.c_str());
+    std::vector<std::string> uniq(jsonFiles);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    std::vector<double> out(uniq.size() * uniq.size());
+    hulk_smash_stats st;
+    char err[4096] = {0};
+    const int rc = hulk_smash_files(device, ptr.data(), (uint32_t)ptr.size(), kSize, algo.c_str(), metric.c_str(), threads,
+                                    matrixCSV.empty() ? nullptr : matrixCSV.c_str(), bannerCSV.empty() ? nullptr : bannerCSV.c_str(),
+                                    out.data(), &st, err, sizeof err);
+    if (rc != HULK_OK) throw Error(rc, err);
+    if (stats) *stats = SmashStats{st.seconds_load, st.seconds_matrix, st.seconds_csv, st.kernel_ms, st.n_sketches, st.sketch_size};
     return out;
 }
 

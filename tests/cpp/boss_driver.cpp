@@ -41,6 +41,15 @@ int main(int argc, char **argv) {
             catch (const hulk::Error &e) { std::printf("%d|%s\n", e.code(), e.what()); }
             return 0;
         }
+        if (mode == "smashfiles") {
+            // boss_driver smashfiles <out.csv> <metric> <k> <file.json>...: `hulk smash` through hulk::SmashFiles
+            if (argc < 7) { std::fprintf(stderr, "usage: boss_driver smashfiles <out.csv> <metric> <k> <a.json> <b.json> ...\n"); return 2; }
+            std::vector<std::string> files(argv + 5, argv + argc);
+            hulk::SmashStats st;
+            const std::vector<double> d = hulk::SmashFiles(files, (uint32_t)std::atoi(argv[4]), "histosketch", argv[3], argv[2], std::string(), &st);
+            std::printf("{\"n\": %u, \"size\": %u, \"d01\": %.17g}\n", st.Sketches, st.SketchSize, d.size() > 1 ? d[1] : -1.0);
+            return 0;
+        }
         if (argc < 8) { std::fprintf(stderr, "usage: boss_driver addseq|files|sharded <path> k w S interval decay\n"); return 2; }
         hulk::SketchInfo info;
         info.KmerSize = (unsigned)std::atoi(argv[3]); info.WindowSize = (unsigned)std::atoi(argv[4]);

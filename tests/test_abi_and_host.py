@@ -219,3 +219,18 @@ def test_header_is_c99_and_a_c_host_links(tmp_path):
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, (p.returncode, p.stderr)
     assert "abi=" in p.stdout and "arch=gfx950" in p.stdout
+
+
+def test_rccl_test_double_exports_what_the_library_binds():
+    """tests/cpp/libfakerccl.so (built by __graft_entry__.build(); the stand-in for librccl.so.1 of tests/test_gpu_fake_rccl.py)
+    exports every nccl* symbol hulk_comm.hip resolves with dlsym — read from the source, so a new binding cannot be forgotten."""
+    lib = os.path.join(ROOT, "tests", "cpp", "libfakerccl.so")
+    if not os.path.exists(lib):
+        pytest.skip("libfakerccl.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    src = open(os.path.join(ROOT, "hulk_amd", "csrc", "hulk_comm.hip")).read()
+    bound = set(re.findall(r"RCCL_SYM\((\w+)\)", src)) - {"f"}
+    assert len(bound) == 8, bound
+    F = ctypes.CDLL(lib)
+    for name in bound:
+        assert hasattr(F, "nccl" + name), name
+    assert hasattr(F, "fakeRcclStats")

@@ -68,3 +68,36 @@ def test_cpp_errors_carry_the_reference_text(tmp_path):
     lines = p.stdout.strip().splitlines()
     assert lines == ["-1|w must be: 0 < w < 257", "-6|histosketching only supports k <= 31",
                      "-7|decay ratio must be between 0.0 and 1.0", "-4|sequence length must be >= w + k - 1"]
+
+
+@pytest.mark.gpu
+def test_cpp_smash_files_writes_the_python_forms_csv(tmp_path):
+    """hulk::SmashFiles (include/hulk.hpp over hulk_smash_files): the directory form of `hulk smash` from a C++ host — the CSV is
+    byte for byte the one the Python form writes, a corrupted file raises hulk::Error with the reference's text."""
+    import hulk_amd
+    from hulk_amd import smash as smash_mod, synth
+    from hulk_amd.sketchio import HULKdata
+    exe = build(tmp_path)
+    d = tmp_path / "sk"
+    d.mkdir()
+    files = []
+    for i, first in enumerate((0, 2000, 70000)):
+        g = hulk_amd.GpuSketcher(15, 9, 48, interval=1000)
+        g.add_reads(*synth.reads_numpy(first, 3000, 120))
+        g.finish()
+        doc = HULKdata(); doc.add(g.histosketch()); doc.filename = f"r{i}.fq,"; doc.banner_label = "blank"
+        p = d / f"s{i}.json"
+        doc.write_json(p)
+        files.append(str(p))
+        g.close()
+    out_cpp, out_py = str(tmp_path / "cpp.csv"), str(tmp_path / "py")
+    r = subprocess.run([exe, "smashfiles", out_cpp, "weightedjaccard", "15"] + files[::-1], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    order, dist = smash_mod.smash_python(str(d), out_py, 15, "histosketch", "weightedjaccard")
+    assert info["n"] == 3 and info["size"] == 48 and info["d01"] == dist[0, 1]
+    assert open(out_cpp, "rb").read() == open(out_py + ".hulk-matrix.csv", "rb").read()
+    bad = d / "t_bad.json"
+    bad.write_text((d / "s0.json").read_text().replace('"version": "1.0.0"', '"version": "2.0.0"'))
+    r = subprocess.run([exe, "smashfiles", out_cpp, "jaccard", "15"] + files + [str(bad)], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "the loaded sketch was created with a different version of HULK: 2.0.0" in (r.stdout + r.stderr)
