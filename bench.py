@@ -810,6 +810,46 @@ def main():
             res[label] = shape
             del b, off
             torch.cuda.empty_cache()
+        # ... and the reference's --fasta mode end to end (sketch.go:102-135: the lines of a '>' record concatenated, parsing stops at the
+        # first empty line): a file of 200 contigs x 500 kb in 60-column lines on /dev/shm -> hulk_sketch_files(fasta) -> hulk_finish; the
+        # fastest of three runs, each on a fresh context.  Host-bound (the FASTA line pump runs on the host's parser threads).
+        import shutil
+        import tempfile
+        d_ = tempfile.mkdtemp(prefix="hulk_fa_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            nfa, Lfa = 200, 500_000
+            path = os.path.join(d_, "contigs.fa")
+            with open(path, "wb") as fh:
+                for i in range(nfa):
+                    seq = synth.reads_numpy(i, 1, Lfa)[0].tobytes()
+                    fh.write(b">contig_%d\n" % i + b"\n".join(seq[j:j + 60] for j in range(0, Lfa, 60)) + b"\n")
+            runs, md5s = [], set()
+            for _ in range(3):
+                sk = hulk_amd.GpuSketcher(K, W, S, interval=0, device=dev_index)
+                state["kick"] = time.monotonic()
+                t0 = time.perf_counter()
+                st = sk.sketch_files([path], fasta=True)
+                sk.finish()
+                runs.append(time.perf_counter() - t0)
+                assert st["n_seqs"] == nfa and st["total_len"] == nfa * Lfa, st
+                mins, _ = sk.sketch()
+                md5s.add(hashlib.md5(mins.astype("<u8").tobytes()).hexdigest())
+                sk.close()
+            assert len(md5s) == 1
+            # the same contigs through the device-pointer call: the file path changes nothing but where the bytes come from
+            b, off = synth.reads_torch(0, nfa, Lfa, device=device)
+            torch.cuda.synchronize()
+            sk = hulk_amd.GpuSketcher(K, W, S, interval=0, device=dev_index)
+            sk.add_reads_device(b.data_ptr(), off.data_ptr(), nfa, Lfa, b.numel())
+            sk.finish()
+            mins, _ = sk.sketch()
+            sk.close()
+            md5_file = md5s.pop()
+            res["fasta_file"] = {"contigs": nfa, "length": Lfa, "file_bytes": os.path.getsize(path), "seconds": min(runs), "seconds_all_runs": runs,
+                                 "bases_per_s": nfa * Lfa / min(runs), "file_GB_per_s": os.path.getsize(path) / min(runs) / 1e9, "sketch_md5": md5_file,
+                                 "same_sketch_as_device_buffers": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest() == md5_file}
+        finally:
+            shutil.rmtree(d_, ignore_errors=True)
         return res
 
     def run_c4():

@@ -88,6 +88,8 @@ def test_bench_json_contract_and_collective_path():
         r_ = x["roofline_k_long_hash"]
         assert r_["bound"] == "hbm" and 0 < r_["frac"] < 1 and abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-12
         assert 150 < x["minimizers_per_kb"] < 250                # ~2 / (w + 1) distinct minimizers per position of a random sequence
+    fa = lr["fasta_file"]                                          # the reference's --fasta mode from a file: same sketch as the same contigs in HBM
+    assert fa["contigs"] == 200 and fa["bases_per_s"] > 1e8 and fa["same_sketch_as_device_buffers"] is True
     assert a["value_unpruned"] is not None and a["value_unpruned"] <= 1.2 * a["value"]
     # end to end from a FASTQ file, plain and .gz: host-bound, far below the kernel-path rate, same sketch both ways
     e2e = a["e2e"]

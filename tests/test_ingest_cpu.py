@@ -526,3 +526,49 @@ def test_ingest_opts_are_validated_like_hulk_params(tmp_path):
     # the host-parser flag is a known flag (it only matters to hulk_sketch_files)
     b, off, st = ingest.parse_files([plain], opts={"flags": _lib.HULK_INGEST_HOST_PARSER})
     assert st["n_seqs"] == 1 and b.tobytes() == b"ACGT"
+
+
+@pytest.mark.parametrize("threads,block", [(1, 0), (2, 131072), (5, 131072), (16, 262144), (16, 0)])
+def test_fasta_parallel_pieces_equal_the_restatement(tmp_path, threads, block):
+    """--fasta (sketch.go:102-135) with a block cut into pieces parsed side by side (round 6): records that span pieces and blocks,
+    sequence lines in front of the first header (dropped), CR/LF, headers back to back (an empty record), a header as the last
+    line, and an EMPTY line that ends the parsing — in the first piece, in a later one, right behind a header — against the
+    literal restatement, for several thread counts and block sizes (128 KiB blocks: a 700 kb record spans six of them)."""
+    rng = np.random.default_rng(threads * 1000 + block // 1024)
+    acgt = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
+
+    def record(name, L, width, eol=b"\n"):
+        seq = bytes(acgt[rng.integers(0, len(acgt), size=L)])
+        return b">" + name + eol + b"".join(seq[i:i + width] + eol for i in range(0, L, width))
+
+    body = (b"ACGTACGT\nTTTT\n" +                                  # no record owns these
+            record(b"c1 first", 700_000, 60) + record(b"c2", 1, 60) + b">empty_record\n" + b">c3\n" + record(b"c4 crlf", 250_000, 70, b"\r\n") +
+            record(b"c5", 333_333, 61) + b">last_header_without_sequence\n")
+    opts = {"block_bytes": block} if block else None
+
+    def nat(path):
+        b, o, st = ingest.parse_files([path], fasta=True, threads=threads, opts=opts)
+        return [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(len(o) - 1)], st
+
+    p = write(tmp_path, "full.fa", body)
+    got, st = nat(p)
+    want = restated([p], fasta=True)
+    assert got == want and len(got) == 7 and [len(x) for x in got] == [700_000, 1, 0, 0, 250_000, 333_333, 0]
+    assert st["n_lines"] == body.count(b"\n")
+    # an empty line ends the parsing wherever it stands; nothing behind it counts (not even a line of 64 KiB)
+    for cut in (5, 12_345, 400_000, 711_700, len(body) // 2, len(body) - 40):
+        at = body.index(b"\n", cut) + 1
+        q = write(tmp_path, f"stop_{cut}.fa", body[:at] + b"\n" + b"A" * 70_000 + b"\n" + body[at:])
+        try:
+            want = restated([q], fasta=True)
+        except linepump.PumpError:                                  # the empty line stands in front of the first header: the reference dies on l1[0] = 64
+            with pytest.raises(HulkError, match="no header"):
+                nat(q)
+            continue
+        got, st = nat(q)
+        assert got == want, cut
+        assert st["n_lines"] == body[:at].count(b"\n") + 1
+    # a line of >= 64 KiB in front of any empty line is the scanner's error (sketch.go:53: bufio.Scanner: token too long)
+    q = write(tmp_path, "long.fa", body[:300_000] + b"C" * 65_536 + b"\n" + body[300_000:])
+    with pytest.raises(HulkError, match="token too long"):
+        nat(q)

@@ -3,7 +3,13 @@
 #include <hip/hip_runtime.h>
 #include "include/hulk_hip.h"
 #include "hulk_amd/csrc/hulk_internal.h"
+#include "hulk_amd/csrc/hulk_fastq.h"
 namespace hulk {
+// (the device FASTQ path of hulk_sketch_files is not run here — hulk_parse_files is host only — but it has to link)
+int ctx_device(const hulk_ctx *) { return 0; }
+int ctx_wait_event(hulk_ctx *, hipEvent_t) { return -1; }
+int ctx_record_busy(hulk_ctx *, hipEvent_t, hipEvent_t, bool *) { return -1; }
+hipError_t launch_fq_parse(hipStream_t, const FqBuffers &, const uint8_t *, const FqState *, uint8_t *, FqState *, uint32_t, uint64_t *, uint8_t *) { return hipErrorUnknown; }
 hipStream_t ctx_stream(hulk_ctx *) { return nullptr; }
 uint64_t ctx_min_read_len(const hulk_ctx *) { return 0; }
 int ctx_fail(hulk_ctx *, int code, const char *) { return code; }
@@ -13,6 +19,22 @@ int ctx_stage_release(hulk_ctx *) { return 0; }
 extern "C" {
 const char *hipGetErrorString(hipError_t) { return "stub"; }
 hipError_t hipMemcpyAsync(void *, const void *, size_t, hipMemcpyKind, hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t *, unsigned) { return hipErrorUnknown; }
+hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipFree(void *) { return hipSuccess; }
+hipError_t hipHostFree(void *) { return hipSuccess; }
+hipError_t hipHostMalloc(void **, size_t, unsigned) { return hipErrorUnknown; }
+hipError_t hipMalloc(void **, size_t) { return hipErrorUnknown; }
+hipError_t hipMemcpy(void *, const void *, size_t, hipMemcpyKind) { return hipErrorUnknown; }
+hipError_t hipMemset(void *, int, size_t) { return hipErrorUnknown; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t *, unsigned) { return hipErrorUnknown; }
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 int hulk_add_reads_device(hulk_ctx *, const uint8_t *, const uint64_t *, uint64_t, uint32_t, uint64_t) { return 0; }
 const char *hulk_last_error(const hulk_ctx *) { return ""; }
 const char *hulk_strerror(int) { return "error"; }

@@ -24,3 +24,10 @@ PY
   set -- $OUT/t.fq $OUT/t.fq.gz $OUT/t2.fq.gz $OUT/tcut.fq.gz
 fi
 for f in "$@"; do echo "== $f"; HULK_GZ_PAR_CHUNK=${HULK_GZ_PAR_CHUNK:-262144} $OUT/parse_tsan "$f" 1 2>&1 | tail -12 | cut -c1-240 || true; done
+# the FASTA mode: the block cut into pieces parsed side by side (parse_rate's third argument: 1 = --fasta)
+python3 - <<PY
+import random
+random.seed(2)
+open("$OUT/t.fa", "wb").write(b"".join(b">c%d\n" % i + b"".join(bytes(random.choices(b"ACGT", k=60)) + b"\n" for _ in range(3000)) for i in range(40)))
+PY
+echo "== $OUT/t.fa (fasta)"; HULK_INGEST_BLOCK=262144 $OUT/parse_tsan $OUT/t.fa 1 1 2>&1 | tail -12 | cut -c1-240 || true
