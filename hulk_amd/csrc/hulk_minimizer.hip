@@ -907,7 +907,10 @@ __global__ __launch_bounds__(256, 4) void k_minimizer_fast(const uint8_t *__rest
 // table in HBM (64-bit compare-and-swap), tried only where the window minimum differs from the one the
 // previous position emitted (same set, ~5x fewer atomics); new values are jump-hashed and counted.
 // ------------------------------------------------------------------------------------------
-constexpr int LONG_PPT = 8;        // consecutive positions per thread in the long-sequence kernels
+#ifndef HULK_LONG_PPT
+#define HULK_LONG_PPT 8
+#endif
+constexpr int LONG_PPT = HULK_LONG_PPT;        // consecutive positions per thread in the long-sequence kernels
 __global__ __launch_bounds__(256) void k_long_hash(const uint8_t *__restrict__ bases, const LongSeqDesc *__restrict__ desc,
                                                    MinimizerParams P, uint64_t *__restrict__ Xs_all,
                                                    uint8_t *__restrict__ valid_all) {
