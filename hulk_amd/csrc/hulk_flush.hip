@@ -109,7 +109,8 @@ int bin_long_reads(hulk_ctx *c, hipStream_t s, const uint8_t *d_bases, const uin
     uint64_t pos_total = 0, tab_total = 0, max_npos = 0;
     auto launch_group = [&]() -> int {
         if (descs.empty()) return HULK_OK;
-        if (pos_total > c->long_cap) {
+        static const bool two_pass = HULK_EXP_ENV("HULK_LONG_TWO_PASS") != nullptr;      // the round-1..5 form as comparator (9 B of scratch per position)
+        if (two_pass && pos_total > c->long_cap) {
             HIPCHK(c, hipStreamSynchronize(s));
             hipFree(c->d_long_xs); hipFree(c->d_long_valid); c->d_long_xs = nullptr; c->d_long_valid = nullptr; c->long_cap = 0;
             HIPCHK(c, hipMalloc((void **)&c->d_long_xs, pos_total * 8));

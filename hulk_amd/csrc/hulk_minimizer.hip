@@ -996,12 +996,14 @@ __global__ __launch_bounds__(256) void k_long_emit(const LongSeqDesc *__restrict
             // the reference inserts the window minimum into the read's set at every emitting position; the
             // previous position already inserted the same value if it emitted with the same minimum
             if (emit && !(prev_emit && mprev == m)) {
+                if (P.debug & 2u) { fresh++; continue; }            // (ablation, profiling build: no set, no jump hash, no spectrum)
                 // per-read set: only the thread whose compare-and-swap claims the slot counts the value
                 uint64_t slot = (m ^ (m >> 29)) * 0x9E3779B97F4A7C15ull >> 20 & table_mask;
                 for (;;) {
                     const unsigned long long old = atomicCAS((unsigned long long *)&table[slot], (unsigned long long)TAB_EMPTY,
                                                              (unsigned long long)m);
                     if (old == TAB_EMPTY) {
+                        if (P.debug & 1u) { fresh++; break; }     // (ablation: the set only)
                         const unsigned at = atomicAdd(&qn, 1u);
                         if (at < QCAP) q[at] = m; else atomicAdd(&hist[jump_hash(m, P.num_bins)], 1u);   // (queue full: in place)
                         fresh++;
@@ -1017,12 +1019,132 @@ __global__ __launch_bounds__(256) void k_long_emit(const LongSeqDesc *__restrict
     __syncthreads();
     {
         const unsigned nq = qn < QCAP ? qn : QCAP;
+        if (P.debug & 4u) { unsigned acc = 0; for (unsigned i = threadIdx.x; i < nq; i += blockDim.x) acc += (unsigned)jump_hash(q[i], P.num_bins); if (acc == 0xdeadbeefu) hist[0] = acc; }   // (ablation: jump hash without the spectrum's atomics)
+        else
         for (unsigned i = threadIdx.x; i < nq; i += blockDim.x) atomicAdd(&hist[jump_hash(q[i], P.num_bins)], 1u);
     }
     for (int off = 32; off; off >>= 1) fresh += __shfl_xor(fresh, off);
     if (lane_id() == 0) red[threadIdx.x >> 6] = fresh;
     __syncthreads();
     if (threadIdx.x == 0) {
+        const unsigned t = red[0] + red[1] + red[2] + red[3];
+        if (t) atomicAdd(&min_slots[(blockIdx.x + 131u * blockIdx.y) & (MIN_SLOTS - 1)], (unsigned long long)t);
+    }
+}
+
+// The two passes above as ONE tile kernel (round 6).  k_long_hash / k_long_emit hand 9 bytes per position through HBM and both touch
+// them a thread at a time — 8 consecutive u64 per lane, 64 B between neighbouring lanes: every load instruction of a wave hit 64
+// different lines; the window minimum alone (no set, no jump hash) took 11 of k_long_emit's 25 ms per Gbase, k_long_hash 6 more.
+// Here a workgroup owns a TILE of a sequence: LONG_TILE = 2048 consecutive k-mer positions, of which the first H = w rounded up to
+// 8 are context the tile in front of it reports (their hashes are recomputed: 0.8 % at w = 9).  The tile's bases are staged once, as
+// seq_nt4_table codes (coalesced), every thread rolls the literal recurrence (N-safe, as k_long_hash) over its 8 positions into LDS,
+// and the window minima, run starts, the per-sequence set (HBM, 64-bit CAS: unchanged) and the queue of new values follow from
+// LDS.  Same values, same set, same counts as the two-pass form (HULK_LONG_TWO_PASS in the profiling build keeps it as comparator).
+constexpr int LONG_TILE = 2048;                 // tile indices per workgroup = 256 threads x 8 positions
+__global__ __launch_bounds__(256) void k_long_tile(const uint8_t *__restrict__ bases, const LongSeqDesc *__restrict__ desc,
+                                                   MinimizerParams P, uint64_t *__restrict__ table_all,
+                                                   uint32_t *__restrict__ hists, unsigned long long *__restrict__ min_slots) {
+    constexpr unsigned QCAP = 2048;
+    __shared__ uint8_t lut[256];
+    __shared__ uint8_t code[LONG_TILE + 64];     // code[b] = nt4 of base (o - 1 + b)
+    __shared__ uint64_t Xs[LONG_TILE];
+    __shared__ uint8_t valid[LONG_TILE];
+    __shared__ uint64_t q[QCAP];
+    __shared__ unsigned qn, red[4];
+    const int tid = threadIdx.x;
+    lut[tid] = nt4_of((unsigned)tid);
+    const LongSeqDesc d = desc[blockIdx.y];
+    const uint8_t *seq = bases + d.seq_off;
+    uint64_t *table = table_all + d.tab_off;
+    const uint64_t table_mask = d.tab_mask;
+    uint32_t *hist = hists + (size_t)d.hslot * (size_t)P.num_bins;
+    const int64_t k = (int64_t)P.k, w = (int64_t)P.w, L = (int64_t)d.L;
+    const int64_t wwin = w > 0 ? w : 1;
+    const int64_t npos = L - k + 1;
+    const int64_t H = (wwin + 7) & ~(int64_t)7;                  // context positions in front of a tile (>= w, a multiple of 8)
+    const int64_t TP = LONG_TILE - H;                            // positions a tile reports
+    const int64_t ntiles = (npos + TP - 1) / TP;
+    const uint64_t mask = (1ull << (2 * k)) - 1, shift = (uint64_t)(2 * (k - 1));
+    unsigned fresh = 0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t o = tile * TP - H;                         // sequence position of tile index 0 (negative in the first tile)
+        if (tid == 0) qn = 0;
+        __syncthreads();                                         // (also: the previous tile's readers of code / Xs / q are done, lut is built)
+        for (int b = tid; b < LONG_TILE + (int)k; b += 256) {
+            const int64_t pos = o - 1 + b;
+            code[b] = (pos >= 0 && pos < L) ? lut[seq[pos]] : (uint8_t)0;
+        }
+        __syncthreads();
+        {   // hashed canonical k-mers of the thread's 8 positions (the literal recurrence: minimizer.go:114-160)
+            const int i0 = tid * 8;
+            uint64_t f = 0, r = 0;
+            // base (first position) - 1 still reaches r's lowest pair when it is code 4: k_long_hash starts there too
+            for (int b = i0; b < i0 + 8 + (int)k; b++) {
+                const uint64_t c = code[b];
+                f = (f << 2 | c) & mask;
+                r = (r >> 2) | ((3ull ^ c) << shift);
+                const int i = b - (int)k;                        // tile index of the k-mer that ends with this base
+                if (i < i0) continue;
+                const int64_t j = o + i, p = j + k - 1;
+                uint64_t X = X_NONE; uint8_t ok = 0;
+                if (j >= 0 && j < npos && f != r) {
+                    const uint64_t canon = f > r ? r : f;
+                    int64_t span = p - w + 2;
+                    if (span >= k) span = k;
+                    X = hash64(canon, mask) << 8 | (uint64_t)(int64_t)(int32_t)span;
+                    ok = 1;
+                }
+                Xs[i] = X; valid[i] = ok;
+            }
+        }
+        __syncthreads();
+        if (tid * 8 >= (int)H) {
+            const int i0 = tid * 8;
+            // sliding window minimum m(i) = min Xs[i-w+1 .. i] (positions in front of the sequence hold "no value"); a full rescan
+            // only when the value that leaves the window is the current minimum
+            uint64_t m = X_NONE;
+            for (int p = i0 - (int)wwin; p <= i0 - 1; p++) { const uint64_t x = Xs[p]; m = x < m ? x : m; }
+            uint64_t mprev = m;
+            bool prev_emit = valid[i0 - 1] && (o + i0 - 1) + k - 1 >= w - 1;
+            for (int i = i0; i < i0 + 8; i++) {
+                const int64_t j = o + i;
+                if (j >= npos) break;
+                const uint64_t x = Xs[i];
+                if (Xs[i - (int)wwin] == m) {
+                    m = x;
+                    for (int p = i - (int)wwin + 1; p < i; p++) { const uint64_t y = Xs[p]; m = y < m ? y : m; }
+                } else {
+                    m = x < m ? x : m;
+                }
+                const bool emit = valid[i] && j + k - 1 >= w - 1;
+                if (emit && !(prev_emit && mprev == m)) {
+                    uint64_t slot = (m ^ (m >> 29)) * 0x9E3779B97F4A7C15ull >> 20 & table_mask;
+                    for (;;) {
+                        const unsigned long long old = atomicCAS((unsigned long long *)&table[slot], (unsigned long long)TAB_EMPTY,
+                                                                 (unsigned long long)m);
+                        if (old == TAB_EMPTY) {
+                            const unsigned at = atomicAdd(&qn, 1u);
+                            if (at < QCAP) q[at] = m; else atomicAdd(&hist[jump_hash(m, P.num_bins)], 1u);   // (queue full: in place)
+                            fresh++;
+                            break;
+                        }
+                        if (old == m) break;
+                        slot = (slot + 1) & table_mask;
+                    }
+                }
+                prev_emit = emit; mprev = m;
+            }
+        }
+        __syncthreads();
+        {
+            const unsigned nq = qn < QCAP ? qn : QCAP;
+            for (unsigned i = tid; i < nq; i += 256) atomicAdd(&hist[jump_hash(q[i], P.num_bins)], 1u);
+        }
+    }
+    for (int off = 32; off; off >>= 1) fresh += __shfl_xor(fresh, off);
+    if (lane_id() == 0) red[tid >> 6] = fresh;
+    __syncthreads();
+    if (tid == 0) {
         const unsigned t = red[0] + red[1] + red[2] + red[3];
         if (t) atomicAdd(&min_slots[(blockIdx.x + 131u * blockIdx.y) & (MIN_SLOTS - 1)], (unsigned long long)t);
     }
@@ -1125,18 +1247,30 @@ uint32_t minimizer_list_rcap(uint32_t w, bool pair) {
 hipError_t launch_long_group(hipStream_t s, const uint8_t *d_bases, const LongSeqDesc *d_desc, uint32_t n_seqs,
                              uint64_t max_npos, MinimizerParams P, uint64_t *d_xs, uint8_t *d_valid, uint64_t *d_table,
                              uint64_t table_total, uint32_t *d_hists, unsigned long long *d_min_slots) {
-    // blocks per sequence: enough for the longest of the group, bounded so that the grid stays ~2^17 blocks
-    uint64_t bx = (max_npos + 256 * LONG_PPT - 1) / (256 * LONG_PPT);
-    const uint64_t cap = std::max<uint64_t>(1, 131072 / n_seqs);
-    if (bx > cap) bx = cap;
-    if (bx > 8192) bx = 8192;
     prof_mark(s, "k_fill_u64");
     hipLaunchKernelGGL(k_fill_u64, dim3(4096), dim3(256), 0, s, d_table, table_total, TAB_EMPTY);
-    prof_mark(s, "k_long_hash");
-    hipLaunchKernelGGL(k_long_hash, dim3((unsigned)bx, n_seqs), dim3(256), 0, s, d_bases, d_desc, P, d_xs, d_valid);
-    prof_mark(s, "k_long_emit");
-    hipLaunchKernelGGL(k_long_emit, dim3((unsigned)bx, n_seqs), dim3(256), 0, s, d_desc, d_xs, d_valid, P, d_table,
-                       d_hists, d_min_slots);
+    if (d_xs && d_valid) {                                        // the two-pass form (profiling build, HULK_LONG_TWO_PASS: the comparator)
+        // blocks per sequence: enough for the longest of the group, bounded so that the grid stays ~2^17 blocks
+        uint64_t bx = (max_npos + 256 * LONG_PPT - 1) / (256 * LONG_PPT);
+        const uint64_t cap = std::max<uint64_t>(1, 131072 / n_seqs);
+        if (bx > cap) bx = cap;
+        if (bx > 8192) bx = 8192;
+        prof_mark(s, "k_long_hash");
+        hipLaunchKernelGGL(k_long_hash, dim3((unsigned)bx, n_seqs), dim3(256), 0, s, d_bases, d_desc, P, d_xs, d_valid);
+        prof_mark(s, "k_long_emit");
+        hipLaunchKernelGGL(k_long_emit, dim3((unsigned)bx, n_seqs), dim3(256), 0, s, d_desc, d_xs, d_valid, P, d_table,
+                           d_hists, d_min_slots);
+        return hipGetLastError();
+    }
+    // tiles per sequence: enough for the longest of the group (shorter ones leave their surplus workgroups at once), bounded so that
+    // the grid stays ~2^18 workgroups: a workgroup then strides over its sequence's tiles
+    const uint64_t H = (((uint64_t)(P.w ? P.w : 1) + 7) & ~7ull), TP = (uint64_t)LONG_TILE - H;
+    uint64_t bx = (max_npos + TP - 1) / TP;
+    const uint64_t cap = std::max<uint64_t>(1, 262144 / n_seqs);
+    if (bx > cap) bx = cap;
+    if (bx > 65535) bx = 65535;
+    prof_mark(s, "k_long_tile");
+    hipLaunchKernelGGL(k_long_tile, dim3((unsigned)bx, n_seqs), dim3(256), 0, s, d_bases, d_desc, P, d_table, d_hists, d_min_slots);
     return hipGetLastError();
 }
 

@@ -84,8 +84,8 @@ def test_bench_json_contract_and_collective_path():
     for shape, n, L in (("reads_5kb", 200_000, 5_000), ("contigs_500kb", 2_000, 500_000)):
         x = lr[shape]
         assert x["sequences"] == n and x["length"] == L and x["bases_per_s"] > 1e9 and x["reads_per_s"] * L == pytest.approx(x["bases_per_s"])
-        assert x["kernels_alone"]["us"]["k_long_hash"] > 0 and x["kernels_alone"]["us"]["k_long_emit"] > 0
-        r_ = x["roofline_k_long_hash"]
+        assert x["kernels_alone"]["us"]["k_long_tile"] > 0
+        r_ = x["roofline_k_long_tile"]
         assert r_["bound"] == "hbm" and 0 < r_["frac"] < 1 and abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-12
         assert 150 < x["minimizers_per_kb"] < 250                # ~2 / (w + 1) distinct minimizers per position of a random sequence
     fa = lr["fasta_file"]                                          # the reference's --fasta mode from a file: same sketch as the same contigs in HBM

@@ -200,7 +200,7 @@ def test_host_buffers_in_chunks_equal_device_path():
 
 def test_long_sequences_against_oracle_and_split_invariance():
     """bench.py's `long_reads` shapes (5 kb reads, 500 kb FASTA contigs: src/pipeline/sketch.go:102-135 hands the whole record to
-    AddSeq) run k_minimizer_bin's deferral + k_long_hash / k_long_emit.  A prefix against the oracle — spectrum, minimizer count,
+    AddSeq) run k_minimizer_bin's deferral + k_long_tile.  A prefix against the oracle — spectrum, minimizer count,
     sketch — and, at the leg's full size, properties that do not need it: the k-mer spectrum is a sum over sequences (two halves
     binned separately add up to the whole), every sequence is counted once, the result does not depend on how calls cut the stream."""
     import torch
