@@ -447,6 +447,64 @@ def test_long_sequences_fasta_style():
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("k,w", [(21, 9), (5, 1), (31, 16), (15, 40), (11, 255), (21, 256), (8, 8)])
+def test_long_tile_kernel_at_its_tile_borders(k, w):
+    """k_long_tile (round 6): a workgroup owns 2048 consecutive k-mer positions of a sequence, the first w rounded up to 8 of them
+    context.  Sequences whose number of positions sits on and around multiples of the tile's reporting span, for every shape of w
+    (1: every position reports; 8: w itself a multiple of 8; 255 / 256: the largest windows, 256 context positions), code-4 bytes
+    right at the tile borders (the N of base p reaches the k-mers of p - 1 and p + 1: minimizer.go:118-122), a sequence made of one
+    repeated unit (the per-sequence set sees every value again in every tile), lower case — spectrum and minimizer count against the
+    oracle; and the profiling build's two-pass kernels (HULK_LONG_TWO_PASS) give the same."""
+    rng = np.random.default_rng(100 * k + w)
+    H = (max(w, 1) + 7) // 8 * 8
+    TP = 2048 - H
+    seqs = []
+    for npos in (1025, TP - 1, TP, TP + 1, 2 * TP, 2 * TP + 1, 3 * TP - 1, 3 * TP + H):
+        L = npos + k - 1
+        if L < w + k - 1:
+            continue
+        s = bytearray(random_reads(rng, 1, L, b"ACGTacgt")[0])
+        for border in (TP, 2 * TP):                                # code-4 bytes where one tile ends and the next begins
+            for at in (border - 1, border, border + k - 1, border + k):
+                if 0 <= at < L and rng.random() < 0.5:
+                    s[at] = ord("N")
+        seqs.append(bytes(s))
+    unit = random_reads(rng, 1, 700)[0]
+    seqs.append(unit * 9)                                          # 6300 bases: the same ~140 minimizers in every tile
+    seqs += random_reads(rng, 40, (w + k - 1, 400))                # short reads beside them (other kernels, same spectrum)
+    B = min(k ** 4, 300007) if k ** 4 > 2 else 16
+    o, g = run_both(seqs, k, w, 4, num_bins=B if k < 9 else 0, batches=2)
+    gh = g.histogram()
+    assert np.array_equal(gh, o.histogram().astype(np.uint32)), f"{int((gh != o.histogram()).sum())} bins differ"
+    n_min = o.counters()["n_minimizers"]
+    assert n_min == g.counters()["n_minimizers"]
+    g.close(); o.close()
+    # the two-pass comparator (profiling build)
+    import subprocess
+    import sys
+    import tempfile
+    if not os.path.exists(os.path.join(ROOT, "hulk_amd", "csrc", "libhulkhip_exp.so")):
+        return
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "seqs.npy"), np.array(seqs, dtype=object), allow_pickle=True)
+        code = (
+            "import sys, hashlib, numpy as np\n"
+            f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+            "import torch, hulk_amd\n"
+            "from conftest import pack_reads\n"
+            "seqs = list(np.load(sys.argv[1], allow_pickle=True))\n"
+            f"g = hulk_amd.GpuSketcher({k}, {w}, 4, num_bins={B if k < 9 else 0})\n"
+            "g.add_reads(*pack_reads(seqs))\n"
+            "print(hashlib.md5(g.histogram().tobytes()).hexdigest(), g.counters()['n_minimizers'])\n"
+            "g.close()\n")
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(td, "seqs.npy")], env=dict(os.environ, HULK_LIB="exp", HULK_LONG_TWO_PASS="1"),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        md5, nmin = r.stdout.split()[-2:]
+        import hashlib
+        assert md5 == hashlib.md5(gh.tobytes()).hexdigest() and int(nmin) == n_min
+
+
 def test_repetitive_reads_fall_back_to_generic_kernel():
     """> 64 run starts in one read (low-complexity / tandem repeats) leave the fast path."""
     rng = np.random.default_rng(4)
