@@ -89,6 +89,7 @@ struct Doc {
 struct Reader {
     const char *p, *end;
     std::string err;
+    int depth = 0;                                                // nesting of skipped values (encoding/json gives up at 10000 too)
     bool fail(const char *what) { if (err.empty()) err = what; return false; }
     void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
     bool lit(const char *s) { const size_t n = strlen(s); if ((size_t)(end - p) >= n && memcmp(p, s, n) == 0) { p += n; return true; } return false; }
@@ -168,23 +169,25 @@ struct Reader {
         if (p >= end) return fail("unexpected end of JSON input");
         const char c = *p;
         if (c == '"') return str(nullptr);
-        if (c == '{') {
-            p++; ws();
-            if (p < end && *p == '}') { p++; return true; }
-            for (;;) {
-                ws();
-                if (!str(nullptr)) return false;
-                ws();
-                if (p >= end || *p != ':') return fail("expected ':'");
-                p++;
-                if (!skip()) return false;
-                ws();
-                if (p < end && *p == ',') { p++; continue; }
+        if (c == '{' || c == '[') {
+            if (++depth > 10000) return fail("exceeded max depth");
+            struct Leave { int &d; ~Leave() { d--; } } leave{depth};
+            if (c == '{') {
+                p++; ws();
                 if (p < end && *p == '}') { p++; return true; }
-                return fail("expected ',' or '}'");
+                for (;;) {
+                    ws();
+                    if (!str(nullptr)) return false;
+                    ws();
+                    if (p >= end || *p != ':') return fail("expected ':'");
+                    p++;
+                    if (!skip()) return false;
+                    ws();
+                    if (p < end && *p == ',') { p++; continue; }
+                    if (p < end && *p == '}') { p++; return true; }
+                    return fail("expected ',' or '}'");
+                }
             }
-        }
-        if (c == '[') {
             p++; ws();
             if (p < end && *p == ']') { p++; return true; }
             for (;;) {

@@ -132,6 +132,9 @@ def test_error_texts_and_their_order(tmp_path):
     open(trunc, "w").write(open(good[0]).read()[:-40])
     _expect(good + [trunc], "malformed sketch file")
     _expect(good + [str(tmp_path / "missing.json")], "No such file")
+    deep = str(tmp_path / "a_deep.json")                          # nesting deeper than encoding/json follows: an error, not a stack overflow
+    open(deep, "w").write('{"x": ' + "[" * 200_000 + "]" * 200_000 + ', ' + open(good[0]).read().lstrip()[1:])
+    _expect(good + [deep], "exceeded max depth")
     # FindSketch (sketchio.go:198-257): raised after every file has loaded, for the first file in sorted order that has one
     _expect(good, "specified k-mer size (31) not found in the supplied sketch file: g0.fq,\n", ksize=31)
     dup = variant("a_dup.json", lambda d: d["signatures"].append(d["signatures"][0]))
