@@ -48,7 +48,7 @@ def _worker(rank, world, uid_q, out_q, mode, inject):
         for _ in range(world - 1):
             uid_q.put(uid)
     else:
-        uid = uid_q.get(timeout=120)
+        uid = uid_q.get(timeout=900)      # (the first `import torch` of a fresh box takes minutes: rank 0 may be late)
     sb, sc = slot_shard(S, rank, world)
     sharded = mode.startswith("sharded")
     flags = _lib.HULK_FLAG_SHARD_FULL if mode == "sharded-full" else 0
@@ -102,7 +102,7 @@ def _run_ranks(world, mode, inject=None, exp=False, sync=False):
         pytest.skip("needs a GPU")
     saved = {k: os.environ.get(k) for k in ("HULK_RCCL_LIB", "HULK_LIB", "FAKE_RCCL_SYNC", "FAKE_RCCL_TIMEOUT_S")}
     os.environ["HULK_RCCL_LIB"] = _fake_lib()
-    os.environ["FAKE_RCCL_TIMEOUT_S"] = "90"
+    os.environ["FAKE_RCCL_TIMEOUT_S"] = "600"              # (a peer that is still importing torch on a cold box is not a hang)
     if exp:
         os.environ["HULK_LIB"] = "exp"
     if sync:
@@ -116,7 +116,7 @@ def _run_ranks(world, mode, inject=None, exp=False, sync=False):
         res = {}
         try:
             for _ in range(world):
-                r = out_q.get(timeout=420)
+                r = out_q.get(timeout=1500)
                 res[r[0]] = r
         finally:
             for p in procs:
