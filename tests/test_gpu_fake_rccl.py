@@ -115,9 +115,16 @@ def _run_ranks(world, mode, inject=None, exp=False, sync=False):
             p.start()
         res = {}
         try:
-            for _ in range(world):
-                r = out_q.get(timeout=1500)
-                res[r[0]] = r
+            import queue
+            import time
+            t_end = time.time() + 1500
+            while len(res) < world and time.time() < t_end:
+                try:
+                    r = out_q.get(timeout=5)
+                    res[r[0]] = r
+                except queue.Empty:
+                    if any(p.exitcode not in (None, 0) for p in procs):      # a rank died (the double aborts on a protocol error): no point in waiting
+                        break
         finally:
             for p in procs:
                 p.join(timeout=60)
