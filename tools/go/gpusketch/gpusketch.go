@@ -184,3 +184,29 @@ func (g *Sketcher) err(rc C.int) error {
 	}
 	return errors.New(C.GoString(C.hulk_last_error(g.ctx)))
 }
+
+// SmashFiles = runSmash + makeMatrix (cmd/smash.go:160-226) in one call: LoadHULKdata for every file (JSON, class / version, the MD5 of
+// the little-endian mins), FindSketch(kSize, algo), the pairwise matrix on the GPU and <outFile>.hulk-matrix.csv as encoding/csv
+// writes it, all inside libhulkhip.  The error text is the one the reference would have logged.
+func SmashFiles(jsonFiles []string, kSize uint, algo, metric, matrixCSV string, device int) error {
+	cPaths := make([]*C.char, len(jsonFiles))
+	for i, f := range jsonFiles {
+		cPaths[i] = C.CString(f)
+		defer C.free(unsafe.Pointer(cPaths[i]))
+	}
+	cAlgo, cMetric, cOut := C.CString(algo), C.CString(metric), C.CString(matrixCSV)
+	defer C.free(unsafe.Pointer(cAlgo))
+	defer C.free(unsafe.Pointer(cMetric))
+	defer C.free(unsafe.Pointer(cOut))
+	errbuf := make([]byte, 4096)
+	var first **C.char
+	if len(cPaths) > 0 {
+		first = &cPaths[0]
+	}
+	rc := C.hulk_smash_files(C.int(device), first, C.uint32_t(len(cPaths)), C.uint32_t(kSize), cAlgo, cMetric, 0, cOut, nil, nil, nil,
+		(*C.char)(unsafe.Pointer(&errbuf[0])), C.uint64_t(len(errbuf)))
+	if rc != C.HULK_OK {
+		return errors.New(C.GoString((*C.char)(unsafe.Pointer(&errbuf[0]))))
+	}
+	return nil
+}
