@@ -207,11 +207,24 @@ def test_header_is_c99_and_a_c_host_links(tmp_path):
     libdir = os.path.join(root, "hulk_amd", "csrc")
     src = tmp_path / "host.c"
     src.write_text('#include <stdio.h>\n#include <string.h>\n#include "hulk_hip.h"\n'
-                   "int main(void) {\n"
+                   "int main(int argc, char **argv) {\n"
                    "    hulk_params p; memset(&p, 0, sizeof p);\n"
                    "    if (hulk_abi_version() != HULK_ABI_VERSION) return 2;\n"
                    "    if (!strstr(hulk_strerror(HULK_ERR_SHORT_SEQ), \"w + k - 1\")) return 3;\n"
                    '    printf("%s\\n", hulk_build_info());\n'
+                   "    /* the sketch-file loader of `hulk smash` needs no GPU: a C host can call it (argv: two sketch files) */\n"
+                   "    if (argc == 3) {\n"
+                   "        const char *paths[2]; hulk_sketch_set *set = NULL; char err[512]; uint32_t n = 0, size = 0;\n"
+                   "        paths[0] = argv[1]; paths[1] = argv[2];\n"
+                   "        if (hulk_load_sketches(paths, 2, 21, \"histosketch\", 2, &set, err, sizeof err) != HULK_OK) { printf(\"load: %s\\n\", err); return 4; }\n"
+                   "        if (hulk_sketch_set_info(set, &n, &size) != HULK_OK || n != 2 || size != 3) return 5;\n"
+                   "        if (hulk_sketch_set_mins(set)[4] != 12u || hulk_sketch_set_weights(set)[5] != -0.5) return 6;\n"
+                   "        if (!strstr(hulk_sketch_set_path(set, 1), \"b.json\") || strcmp(hulk_sketch_set_banner(set, 0), \"blank\")) return 7;\n"
+                   "        hulk_sketch_set_free(set);\n"
+                   "        paths[1] = \"/nonexistent.json\";\n"
+                   "        if (hulk_load_sketches(paths, 2, 21, \"histosketch\", 0, &set, err, sizeof err) != HULK_ERR_ARG || set != NULL) return 8;\n"
+                   '        printf("loader ok\\n");\n'
+                   "    }\n"
                    "    return 0;\n}\n")
     exe = tmp_path / "host"
     subprocess.run(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
@@ -219,6 +232,15 @@ def test_header_is_c99_and_a_c_host_links(tmp_path):
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, (p.returncode, p.stderr)
     assert "abi=" in p.stdout and "arch=gfx950" in p.stdout
+    from hulk_amd.sketchio import HULKdata, HistoSketch
+    files = []
+    for name, mins, wts in (("a.json", [3, 7, 11], [1.5, -2.0, 1e-9]), ("b.json", [5, 12, 0], [0.25, 4.0, -0.5])):
+        d = HULKdata(); d.filename = name; d.banner_label = "blank"
+        d.add(HistoSketch(21, np.array(mins, dtype=np.uint64), np.array(wts), 21 ** 4, False))
+        d.write_json(tmp_path / name)
+        files.append(str(tmp_path / name))
+    p = subprocess.run([str(exe)] + files, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "loader ok" in p.stdout, (p.returncode, p.stdout, p.stderr)
 
 
 def test_rccl_test_double_exports_what_the_library_binds():

@@ -986,3 +986,32 @@ def test_two_vector_scan_gives_the_tile_minima_of_the_per_interval_products():
     assert np.array_equal(out["grid"]["tilemin"], a["tilemin"], equal_nan=True)       # list form == grid form
     for label in ("loop", "per_interval", "grid"):
         assert np.array_equal(out[label]["mins"], a["mins"]) and np.array_equal(out[label]["weights"], a["weights"]), label
+
+
+def test_profile_table_times_every_launch_of_a_one_stream_context():
+    """hulk_set_profiling bit 32 + hulk_get_profile_table (ABI 4): on a HULK_FLAG_NO_OVERLAP context every launch of the binning chain
+    and of the flush is timed once per batch, the durations are positive and add up to less than the wall clock, and the switch changes
+    no result."""
+    import time
+    from hulk_amd import _lib, synth
+    bases, offsets = synth.reads_numpy(0, 24_000, 150)
+    out = {}
+    for prof in (0, 32):
+        g = gpu().GpuSketcher(15, 9, 16, interval=2000, batch=4, flags=_lib.HULK_FLAG_NO_OVERLAP)
+        g.set_profiling(prof)
+        t0 = time.perf_counter()
+        g.add_reads(bases, offsets)                              # 12 intervals = 3 batches of 4
+        g.synchronize()
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        tbl = g.profile_table() if prof else {}
+        g.finish()
+        out[prof] = (g.sketch(), g.cms(), tbl, wall_ms)
+        g.close()
+    assert np.array_equal(out[0][0][0], out[32][0][0]) and np.array_equal(out[0][0][1], out[32][0][1]) and np.array_equal(out[0][1], out[32][1])
+    tbl, wall_ms = out[32][2], out[32][3]
+    for kname in ("k_minimizer_fast", "k_region_offsets", "k_jump_bin", "k_nibble_hist", "k_nibble_merge", "k_count_used", "k_flush_decide",
+                  "k_cms_segsum", "k_cms_base", "k_cms_freq", "k_scan_test", "k_cws_apply"):
+        assert kname in tbl and tbl[kname][0] >= 3 and tbl[kname][1] > 0, (kname, tbl.get(kname))
+    assert tbl["k_cms_freq"][0] == tbl["k_flush_decide"][0] == 3                      # one flush per batch of 4 intervals
+    assert "-" not in tbl and 0 < sum(v[1] for v in tbl.values()) < wall_ms
+    assert out[0][2] == {}
