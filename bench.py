@@ -643,6 +643,7 @@ def main():
         elapsed = time.perf_counter() - t0
         tiles1 = sk.scan_stats()
         prof = {k: sk.get_profile(k) for k in ("k_cws_scan", "k_minimizer_fast", "k_jump_bin", "k_jump_left")} if brackets else {}
+        table = sk.profile_table() if (brackets and brackets != 1 and (brackets & 32)) else None     # every launch of the chain (hulk_get_profile_table)
         sk.set_profiling(False)
         if use_dist:
             tt = host_tensor([elapsed], torch.float64)
@@ -655,7 +656,7 @@ def main():
         cstats = sk.comm_stats() if comm else None
         sk.close()
         return dict(elapsed=elapsed, steps=k_steps, prof=prof, counters=counters, mins=mins, weights=weights, tiles0=tiles0,
-                    tiles1=tiles1, comm=cstats)
+                    tiles1=tiles1, comm=cstats, table=table)
 
     def run_cold():
         """C2 exactly as BASELINE.json states it: 10 M reads, interval 100k, through the interval rule of
@@ -1133,7 +1134,7 @@ def main():
     # per launch over its average duration (profiles/r06_kernel_stats_serial_noprune.md holds the same figure from rocprofv3)
     if not single and plain_single and rank == 0:
         def scan_unpruned():
-            p = run_pass(False, brackets=1, serial=True, n_steps=min(steps, 10))
+            p = run_pass(False, brackets=8 | 32, serial=True, n_steps=min(steps, 10))
             n_l, ms_ = p["prof"]["k_cws_scan"]
             bytes_ = 4.0 * sc * (((K ** 4 + 1023) // 1024) * 1024) + 2 * 4.0 * (K ** 4)
             avg = (ms_ / 1e3) / max(n_l, 1)
@@ -1142,6 +1143,16 @@ def main():
                                                  "achieved": bytes_ / avg / 1e9 if avg > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                  "frac": (bytes_ / avg / 1e9 / HBM_PEAK_GBS) if avg > 0 else 0.0, "traffic": None,
                                                  "launches": int(n_l), "avg_launch_us": avg * 1e6, "alg_bytes_per_launch": bytes_}
+            # the whole scan STAGE of a flush — the three small kernels in front of the scan (per-tile extrema of the reciprocals, the bound
+            # test that builds the tile list, the per-bin max / min vectors) and the scan itself — from the every-launch table of the same pass
+            tb = p.get("table") or {}
+            stage = [kk for kk in ("k_rcp_extrema", "k_scan_test", "k_rcp_minmax", "k_cws_scan_list", "k_cws_scan") if kk in tb]
+            if stage and n_l:
+                st_us = sum(tb[kk][1] for kk in stage) * 1e3 / n_l
+                out["roofline_cws_scan_unpruned"].update({"stage_kernels": stage, "stage_us_per_flush": st_us,
+                                                          "frac_whole_stage": bytes_ / (st_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                          "stage_note": "avg_launch_us / frac: the scan kernel alone (HIP events around it); stage_us_per_flush / frac_whole_stage: "
+                                                                        "with the three kernels that prepare it (hulk_set_profiling(32): time to the next launch's event)"})
         run_leg("scan_unpruned", scan_unpruned)
     # ---- leg `long`: the timed pass again with >= 200 steps (the 20 steps of the headline still carry the tail of the clock
     # ramp of their own pass: --steps 20 / 100 / 400 gave 0.9946 / 0.9863 / 0.9842 ms per step in round 3)
