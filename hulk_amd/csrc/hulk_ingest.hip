@@ -1456,15 +1456,16 @@ struct Parser {
     // piece compacts its sequence lines into a buffer of its own and notes where header lines fell — and copied side by side to
     // the end of `fa_bases`; what is left to do in stream order is a walk over the (few) headers.  (Until round 6: one thread,
     // one std::vector::insert per 60-byte line — 1.6 GB/s of file, 20x below what the long-sequence kernels take.)
-    struct RawBuf {                                                     // bytes without a constructor: a vector's resize zero-fills
-        uint8_t *p = nullptr; size_t n = 0, cap = 0;
-        ~RawBuf() { free(p); }
+    struct RawBuf {                                                     // bytes without a constructor (a vector's resize zero-fills), on huge pages:
+        uint8_t *p = nullptr; size_t n = 0, cap = 0;                    // 100 MB of 4 KB pages are 25 k page faults to fill and as many to unmap
+        ~RawBuf() { if (p) ::munmap(p, cap); }
         uint8_t *grow(size_t add) {
             if (n + add > cap) {
-                const size_t nc = std::max(cap * 2, n + add + 4096);
-                uint8_t *q = (uint8_t *)realloc(p, nc);
-                if (!q) throw std::bad_alloc();
-                p = q; cap = nc;
+                const size_t nc = (std::max(cap * 2, n + add + 4096) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+                void *q = p ? ::mremap(p, cap, nc, MREMAP_MAYMOVE) : ::mmap(nullptr, nc, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+                if (q == MAP_FAILED) throw std::bad_alloc();
+                ::madvise(q, nc, MADV_HUGEPAGE);
+                p = (uint8_t *)q; cap = nc;
             }
             uint8_t *r = p + n; n += add; return r;
         }
@@ -1472,7 +1473,7 @@ struct Parser {
         size_t size() const { return n; }
     };
     struct FaPiece {
-        std::unique_ptr<uint8_t[]> buf; size_t cap = 0, nbytes = 0;     // the piece's sequence bytes (the buffer lives as long as the parser: no page faults per block)
+        std::unique_ptr<BigBuf> buf; size_t cap = 0, nbytes = 0;        // the piece's sequence bytes (huge pages; the buffer lives as long as the parser: no page faults per block)
         std::vector<uint64_t> hdr_at;                                   // offsets into buf at which a header line stood
         uint64_t n_lines = 0; bool stopped = false, too_long = false;   // lines seen up to the event; an empty line / a line of >= 64 KiB ends the piece
     };
@@ -1498,9 +1499,9 @@ struct Parser {
         return true;
     }
     static void fasta_piece(const uint8_t *p, const uint8_t *end, FaPiece &r) {
-        if ((size_t)(end - p) + 1 > r.cap) { r.cap = (size_t)(end - p) + 1 + ((size_t)(end - p) >> 3); r.buf.reset(new uint8_t[r.cap]); }
+        if ((size_t)(end - p) + 1 > r.cap) { r.cap = (size_t)(end - p) + 1 + ((size_t)(end - p) >> 3); r.buf.reset(new BigBuf(r.cap)); }
         r.hdr_at.clear(); r.n_lines = 0; r.stopped = r.too_long = false;
-        uint8_t *out = r.buf.get();
+        uint8_t *out = r.buf->as<uint8_t>();
         while (p < end) {
             const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
             if (!nl) nl = end;
@@ -1508,11 +1509,11 @@ struct Parser {
             const size_t L = line_len(p, nl);
             r.n_lines++;
             if (L == 0) { r.stopped = true; break; }                    // sketch.go:103-105: break
-            if (p[0] == '>') r.hdr_at.push_back((uint64_t)(out - r.buf.get()));
+            if (p[0] == '>') r.hdr_at.push_back((uint64_t)(out - r.buf->as<uint8_t>()));
             else { memcpy(out, p, L); out += L; }
             p = nl + 1;
         }
-        r.nbytes = (size_t)(out - r.buf.get());
+        r.nbytes = (size_t)(out - r.buf->as<uint8_t>());
     }
     bool fasta_block(const Block &blk) {
         if (fa_stopped) return true;
@@ -1539,7 +1540,7 @@ struct Parser {
         }
         const size_t old = fa_bases.size(), add = at[used];
         uint8_t *dst = fa_bases.grow(add);
-        run_parallel(used, [&](uint32_t i) { if (pc[i].nbytes) memcpy(dst + at[i], pc[i].buf.get(), pc[i].nbytes); });
+        run_parallel(used, [&](uint32_t i) { if (pc[i].nbytes) memcpy(dst + at[i], pc[i].buf->as<uint8_t>(), pc[i].nbytes); });
         // the headers, in stream order: a header closes the record in progress (or, the first one, drops what stood in front of it)
         size_t rec_start = old - fa_cur;                                // where the record in progress begins
         for (uint32_t i = 0; i < used; i++)
