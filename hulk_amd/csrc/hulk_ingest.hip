@@ -1589,30 +1589,34 @@ int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, const Inge
     // (0: one per hardware thread, at most 16 — 32 and 64 were measured slower on a 256-thread host; a caller's figure is taken as it is)
     if (threads == 0) { threads = std::thread::hardware_concurrency(); if (threads == 0) threads = 1; if (threads > 16) threads = 16; }
     if (threads > 256) threads = 256;
-    BlockReader reader(paths, n_paths, cfg);
-    Parser ps(sink, threads, err);
     bool ok = true;
-    for (;;) {
-        const double tb0 = PhaseTrace::now();
-        std::unique_ptr<Block> b = reader.next(err);
-        const double tb1 = PhaseTrace::now(); g_trace.wait_block += tb1 - tb0;
-        if (!b) { ok = err.code == HULK_OK; break; }
-        ok = fasta ? ps.fasta_block(*b) : ps.fastq_block(*b);
-        g_trace.parse += PhaseTrace::now() - tb1;
-        reader.recycle(std::move(b));
-        if (!ok || (fasta && ps.fa_stopped)) break;
-    }
-    if (ok && fasta) ok = ps.fasta_end();
-    if (ok) ok = sink.finish(err);
-    if (stats) {
-        stats->n_seqs = sink.n_seqs; stats->total_len = sink.total_len; stats->n_lines = ps.n_lines;
-        stats->bytes_in = reader.bytes_in();
-        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    }
+    double t_body_end = 0.0;
+    {
+        BlockReader reader(paths, n_paths, cfg);
+        Parser ps(sink, threads, err);
+        for (;;) {
+            const double tb0 = PhaseTrace::now();
+            std::unique_ptr<Block> b = reader.next(err);
+            const double tb1 = PhaseTrace::now(); g_trace.wait_block += tb1 - tb0;
+            if (!b) { ok = err.code == HULK_OK; break; }
+            ok = fasta ? ps.fasta_block(*b) : ps.fastq_block(*b);
+            g_trace.parse += PhaseTrace::now() - tb1;
+            reader.recycle(std::move(b));
+            if (!ok || (fasta && ps.fa_stopped)) break;
+        }
+        if (ok && fasta) ok = ps.fasta_end();
+        if (ok) ok = sink.finish(err);
+        if (stats) {
+            stats->n_seqs = sink.n_seqs; stats->total_len = sink.total_len; stats->n_lines = ps.n_lines;
+            stats->bytes_in = reader.bytes_in();
+            stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        t_body_end = PhaseTrace::now();
+    }                                                             // (the reader's thread and blocks, the parser's team and buffers go here)
     if (cfg.trace)
         fprintf(stderr, "ingest trace (calling thread, s): next block %.3f | parse + sink %.3f, of which: staging set (wait / first "
-                        "allocation) %.3f, copies queued %.3f, hulk_add_reads_device %.3f\n", g_trace.wait_block, g_trace.parse,
-                g_trace.stage_wait, g_trace.enqueue, g_trace.add_reads);
+                        "allocation) %.3f, copies queued %.3f, hulk_add_reads_device %.3f | releasing the reader and the parser %.3f\n", g_trace.wait_block, g_trace.parse,
+                g_trace.stage_wait, g_trace.enqueue, g_trace.add_reads, PhaseTrace::now() - t_body_end);
     return ok ? HULK_OK : err.code;
 }
 
