@@ -323,6 +323,42 @@ class GzFast : public GzStream {
 
 // Large scratch buffers of the gzip readers: anonymous mappings that ask for transparent huge pages (a first touch by 16+
 // threads at once is otherwise 4 KiB page faults queueing on the process's mapping lock).  HULK_GZ_NO_THP=1: plain pages.
+// Regions handed back are kept by the PROCESS for a while (RegionPool): the kernel zeroes pages when they are mapped and, on the
+// GPU box, takes as long again to take them back — a run over one 100 MB FASTA file spent 10 ms faulting ~330 MB of block,
+// piece and batch buffers in and 16 ms unmapping them, next to 10 ms of parsing (HULK_INGEST_TRACE).  A second file of the
+// process finds the regions mapped and touched.  Bounded in size (POOL_BYTES) and in age (FQ_IDLE_SECONDS, swept with the device
+// parser's sets: fq_sweep_idle; hulk_release_caches() unmaps at once).  Contents are NOT zeroed on reuse (no user relies on it).
+struct RegionPool {
+    struct Ent { void *p; size_t n; double t; };
+    static constexpr size_t POOL_BYTES = (size_t)1 << 30, ONE_MAX = (size_t)256 << 20;
+    std::mutex mu; std::vector<Ent> v; size_t bytes = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    static RegionPool &get() { static RegionPool *g = new RegionPool(); return *g; }      // (never destroyed: buffers of static objects may come back late)
+    void *take(size_t n) {                                  // a region of exactly n bytes (sizes are few: block, piece and batch buffers)
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = v.size(); i-- > 0;)
+            if (v[i].n == n) { void *p = v[i].p; bytes -= n; v.erase(v.begin() + i); return p; }
+        return nullptr;
+    }
+    bool give(void *p, size_t n) {
+        static const bool off = HULK_EXP_ENV("HULK_NO_REGION_POOL") != nullptr;
+        if (off || n > ONE_MAX) return false;
+        std::lock_guard<std::mutex> g(mu);
+        if (bytes + n > POOL_BYTES) return false;
+        v.push_back({p, n, now()}); bytes += n;
+        return true;
+    }
+    void sweep(double older_than) {
+        std::vector<Ent> drop;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            const double t = now();
+            for (size_t i = 0; i < v.size();)
+                if (t - v[i].t >= older_than) { drop.push_back(v[i]); bytes -= v[i].n; v.erase(v.begin() + i); } else i++;
+        }
+        for (auto &e : drop) ::munmap(e.p, e.n);
+    }
+};
 struct BigBuf {
     void *p = nullptr; size_t n = 0;
     BigBuf() {}
@@ -330,10 +366,11 @@ struct BigBuf {
     BigBuf(const BigBuf &) = delete;
     BigBuf &operator=(const BigBuf &) = delete;
     ~BigBuf() { release(); }
-    void release() { if (p) ::munmap(p, n); p = nullptr; n = 0; }
+    void release() { if (p && !RegionPool::get().give(p, n)) ::munmap(p, n); p = nullptr; n = 0; }
     void reset(size_t bytes) {
         release();
         n = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        if ((p = RegionPool::get().take(n))) return;
         void *m = ::mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m == MAP_FAILED) { p = nullptr; n = 0; throw std::bad_alloc(); }
         p = m;
@@ -1458,13 +1495,17 @@ struct Parser {
     // one std::vector::insert per 60-byte line — 1.6 GB/s of file, 20x below what the long-sequence kernels take.)
     struct RawBuf {                                                     // bytes without a constructor (a vector's resize zero-fills), on huge pages:
         uint8_t *p = nullptr; size_t n = 0, cap = 0;                    // 100 MB of 4 KB pages are 25 k page faults to fill and as many to unmap
-        ~RawBuf() { if (p) ::munmap(p, cap); }
+        static constexpr size_t FIRST = (size_t)128 << 20;              // a batch (64 MB) + a block + a record's tail fit: growing is the exception,
+        ~RawBuf() { if (p && !(cap == FIRST && RegionPool::get().give(p, cap))) ::munmap(p, cap); }   // and the region goes back to the process's pool
         uint8_t *grow(size_t add) {
             if (n + add > cap) {
-                const size_t nc = (std::max(cap * 2, n + add + 4096) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
-                void *q = p ? ::mremap(p, cap, nc, MREMAP_MAYMOVE) : ::mmap(nullptr, nc, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+                const size_t nc = (std::max(std::max(cap * 2, FIRST), n + add + 4096) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+                void *q = p ? ::mremap(p, cap, nc, MREMAP_MAYMOVE) : (nc == FIRST ? RegionPool::get().take(nc) : nullptr);
+                if (!q) {
+                    q = ::mmap(nullptr, nc, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+                    if (q != MAP_FAILED) ::madvise(q, nc, MADV_HUGEPAGE);
+                } else if (p && q != MAP_FAILED) ::madvise(q, nc, MADV_HUGEPAGE);
                 if (q == MAP_FAILED) throw std::bad_alloc();
-                ::madvise(q, nc, MADV_HUGEPAGE);
                 p = (uint8_t *)q; cap = nc;
             }
             uint8_t *r = p + n; n += add; return r;
@@ -1689,6 +1730,7 @@ void fq_release_idle() {
     std::vector<FqDev *> drop;
     { std::lock_guard<std::mutex> g(g_fq_mu); drop.swap(g_fq_idle); }
     for (FqDev *d : drop) FqDev::destroy(d);
+    RegionPool::get().sweep(0.0);
 }
 // frees the idle sets nobody has borrowed for FQ_IDLE_SECONDS (called from hulk_create / hulk_destroy / hulk_sketch_files)
 void fq_sweep_idle() {
@@ -1701,6 +1743,7 @@ void fq_sweep_idle() {
             else i++;
     }
     for (FqDev *d : drop) FqDev::destroy(d);
+    RegionPool::get().sweep(FQ_IDLE_SECONDS);
 }
 }  // namespace hulk
 namespace {

@@ -572,3 +572,31 @@ def test_fasta_parallel_pieces_equal_the_restatement(tmp_path, threads, block):
     q = write(tmp_path, "long.fa", body[:300_000] + b"C" * 65_536 + b"\n" + body[300_000:])
     with pytest.raises(HulkError, match="token too long"):
         nat(q)
+
+
+def test_recycled_buffers_carry_nothing_over(tmp_path):
+    """The ingest path's large buffers (block, piece and batch regions) go back to a pool of the PROCESS and are handed out again
+    with their old contents (hulk_ingest.hip RegionPool).  A long FASTA file, then a shorter one with other bases, then FASTQ,
+    with and without hulk_release_caches() in between: every parse equals the restatement."""
+    from hulk_amd import _lib
+    rng = np.random.default_rng(77)
+
+    def fa(n_rec, L, alphabet):
+        a = np.frombuffer(alphabet, dtype=np.uint8)
+        out = []
+        for i in range(n_rec):
+            seq = bytes(a[rng.integers(0, len(a), size=L)])
+            out.append(b">r%d\n" % i + b"".join(seq[j:j + 60] + b"\n" for j in range(0, L, 60)))
+        return b"".join(out)
+
+    long_ = write(tmp_path, "long.fa", fa(3, 500_000, b"ACGT"))
+    short = write(tmp_path, "short.fa", fa(5, 150_001, b"TG"))
+    fq = write(tmp_path, "r.fq", b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"ACGTTGCA" * 20, b"I" * 160) for i in range(5000)))
+    want = {p_: restated([p_], fasta=f_) for p_, f_ in ((long_, True), (short, True), (fq, False))}
+    for release in (False, True, False):
+        for path, fasta in ((long_, True), (short, True), (fq, False), (short, True), (long_, True)):
+            b, o, st = ingest.parse_files([path], fasta=fasta, threads=8)
+            got = [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(len(o) - 1)]
+            assert got == want[path], (path, release)
+            if release:
+                assert _lib.load().hulk_release_caches() == 0
