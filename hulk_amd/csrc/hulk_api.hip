@@ -261,6 +261,7 @@ void hulk_destroy(hulk_ctx *c) {
         hipFree(ml.nib); hipFree(ml.nib_over); hipFree(ml.lo); hipFree(ml.lo_cnt); hipFree(ml.dmask); hipFree(ml.dsum);
     }
     for (int i = 0; i < 2; i++) if (c->ev_heavy[i]) hipEventDestroy(c->ev_heavy[i]);
+    if (c->ev_hold) hipEventDestroy(c->ev_hold);
     if (c->ev_stagger) hipEventDestroy(c->ev_stagger);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);

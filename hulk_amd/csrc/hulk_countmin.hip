@@ -312,6 +312,14 @@ __global__ __launch_bounds__(512) void k_cms_freq_chain(uint32_t *__restrict__ h
     }
 }
 
+// Wave priority of the issue arbiter (0..3).  The count-min replay kernels with decay are chains of dependent LDS round trips, one
+// workgroup per CU; beside them run kernels that fill the SIMDs' issue slots (k_minimizer_fast, k_jump_bin).  A replay wave that is
+// ready should not queue behind eight of theirs.
+__device__ __forceinline__ void set_wave_prio(int p) {
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p >= 3) __builtin_amdgcn_s_setprio(3);
+}
 // ------------------------------------------------------------------------------------------
 // K3 with uniform scaling (0 < decay < 1), bin-order form.  Counter (d,p) right after stream element j
 // is C(j) = w*C(j-1) + (v_j if element j hits it).  Over a bin segment holding elements [e0,e1):
@@ -329,6 +337,7 @@ __global__ __launch_bounds__(512) void k_cmsd_segsum(const uint32_t *__restrict_
                                                      double omega, const DevState *st, FlushBatch fb) {
     extern __shared__ __align__(16) unsigned char smem[];
     double *ladd = (double *)smem;                                // [depth][width]
+    set_wave_prio(fb.prio);
     const int seg = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     const uint32_t gomask = batch_gomask(st, fb);
     if (!((gomask >> t) & 1u)) return;
@@ -434,6 +443,7 @@ __global__ __launch_bounds__(256) void k_cmsd_base(const double *__restrict__ se
 // register exchanges; the same additions in the same order — bit-identical to k_cmsd_freq where the LDS does keep the order
 // (tested) — at ~1.8x its time (517 -> 450 us was this form's round-3/4 history, docs/EXPERIMENTS.md).
 constexpr int CMSD_FG = 8;            // chunks per barrier group of k_cmsd_freq
+constexpr int CMSD_WAVE_PRIO = 0;     // s_setprio of the replay kernels (set_wave_prio)
 __global__ __launch_bounds__(512) void k_cmsd_freq_chain(uint32_t *__restrict__ hists, const uint16_t *__restrict__ pos16,
                                                    const uint8_t *__restrict__ meta8, const uint32_t *__restrict__ eidx,
                                                    const uint32_t *__restrict__ sege0, const double *__restrict__ cstart,
@@ -586,6 +596,7 @@ __global__ __launch_bounds__(512) void k_cmsd_freq(uint32_t *__restrict__ hists,
     double *lval = (double *)smem;                                               // [depth][width] normalised counters
     unsigned long long *smin = (unsigned long long *)(lval + (size_t)depth * width);   // [2][GB] min over the rows, as bits
     __shared__ double tabf_lo[64], tabf_hi[66], tabi_lo[64], tabi_hi[66];          // w^x and w^-x for x = lo + 64 hi
+    set_wave_prio(fb.prio);
     const int seg = blockIdx.x, t = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, d = tid >> 6;
     const uint32_t gomask = batch_gomask(st, fb);
@@ -808,11 +819,13 @@ size_t cms_binorder_entries(int depth, int width) { return (size_t)depth * CMS_S
 hipError_t launch_cmsd_binorder(hipStream_t s, uint32_t *d_hists, const uint16_t *d_pos16, const uint8_t *d_meta8,
                                 const uint32_t *d_eidx, const uint32_t *d_etot, double *d_ctrd, double *d_segadd,
                                 double *d_segfac, uint32_t *d_sege0, double *d_cstart, double *d_f64, float *d_rcp32,
-                                int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb,
+                                int depth, int width, size_t row_stride, double omega, DevState *st, const FlushBatch &fb_in,
                                 hipEvent_t freq_begin, hipEvent_t freq_end, bool chain_form) {
+    FlushBatch fb = fb_in;
     const int chunks = (fb.num_bins + 63) / 64;
     const int seg_chunks = (chunks + CMS_SEGS - 1) / CMS_SEGS;
     if (depth > 8) return hipErrorInvalidValue;                     // k_cmsd_segsum: one wave per row, 8 waves
+    { static const char *e = HULK_EXP_ENV("HULK_CMSD_PRIO"); fb.prio = e ? atoi(e) : CMSD_WAVE_PRIO; }
     const size_t lds1 = (size_t)depth * width * 8 + (size_t)2 * 512 * 8;
     const size_t lds3 = (size_t)depth * width * 8 + (size_t)2 * CMSD_FG * 64 * 8;
     static bool attr_set = false;

@@ -118,6 +118,7 @@ struct hulk_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;    // context stream -> lane 1 in front of a batch, and back (lanes_join)
     hipStream_t last_bin_stream = nullptr;              // the stream the latest binning launches went to
     hipEvent_t ev_heavy[2] = {nullptr, nullptr}; int heavy_idx = 0; bool heavy_set[2] = {false, false};   // experiment HULK_C3_GATE (profiling build)
+    hipEvent_t ev_hold = nullptr;                                                                         // experiment HULK_C3_HOLD (profiling build)
     int stagger = 1; hipEvent_t ev_stagger = nullptr;   // 1: the lanes are idle; 2: the first batch since recorded ev_stagger behind its k_minimizer_fast
     bool copies_pending = false;                        // host -> device copies were queued on the context's stream since the last fork
     uint32_t work_lanes = 2;                            // hulk_params.work_lanes

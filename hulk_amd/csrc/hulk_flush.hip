@@ -236,6 +236,14 @@ static int bin_fast(hulk_ctx *c, hulk_ctx::BinLane &ln, hipStream_t s, const uin
     }
     HIPCHK(c, launch_minimizer_fast(s, d_bases, d_offsets, n, P, ln.ml, c->d_state, c->d_min_slots));
     if ((c->profiling & 2)) { HIPCHK(c, hipEventRecord(pr.b, s)); c->prof.push_back(pr); }
+    if (c->deferred.armed && c->scaling && HULK_EXP_ENV("HULK_C3_HOLD")) {
+        // experiment: the flush of the batch before was held back (flush_batch) and is queued now, behind THIS batch's k_minimizer_fast:
+        // its 112 KB-LDS replay kernels then run beside k_jump_bin, which needs no LDS, and k_minimizer_fast keeps its occupancy
+        if (!c->ev_hold) HIPCHK(c, hipEventCreateWithFlags(&c->ev_hold, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_hold, s));
+        const int rch = issue_flush(c, c->ev_hold);
+        if (rch != HULK_OK) return rch;
+    }
     if (c->stagger == 1 && c->work_lanes > 1 && !c->no_overlap) {
         if (!c->ev_stagger) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming));
         HIPCHK(c, hipEventRecord(c->ev_stagger, s));
@@ -457,6 +465,7 @@ int flush_batch(hulk_ctx *c, uint32_t count, hipStream_t dep_stream, bool use_de
     // count-min kernels would meet k_jump_bin, which needs no LDS, instead of k_minimizer_fast — was measured: C3-shaped
     // 8.9e8 vs 9.8e8 reads/s without the delay.  What does pay is that the next batch's minimizer and jump-hash kernels
     // no longer wait for this flush: only the histogram kernels behind them do, see bin_reads.)
+    if (c->scaling && !c->no_overlap && HULK_EXP_ENV("HULK_C3_HOLD")) return HULK_OK;       // (experiment: see bin_fast)
     return issue_flush(c);
 }
 

@@ -39,6 +39,7 @@ struct FlushBatch {
     uint32_t ring_base, ring_n, count;
     int parity;
     int32_t num_bins;
+    int prio = 0;       // wave priority (s_setprio) the latency-bound count-min replay kernels raise themselves to
 };
 
 // Minimizer list written by k_minimizer_fast: one region of `rcap` entries per wave (16 reads).

@@ -1201,7 +1201,16 @@ hipError_t launch_minimizer_fast(hipStream_t s, const uint8_t *d_bases, const ui
                                  DevState *d_state, unsigned long long *d_min_slots) {
     if (n_reads == 0) return hipSuccess;
     const bool pair = P.pair != 0;
-    const size_t lds = minimizer_fast_lds(P.w, pair);
+    size_t lds = minimizer_fast_lds(P.w, pair);
+    {   // (profiling build) HULK_K1_LDS_TOTAL=bytes: the kernel's LDS request padded up to it — how it runs at 3 / 2 / 1 workgroups per CU
+        static const char *e = HULK_EXP_ENV("HULK_K1_LDS_TOTAL");
+        static const size_t want = e ? (size_t)atol(e) : 0;
+        if (want > lds) {
+            static bool once = false;
+            if (!once && want > 65536) { once = true; (void)hipFuncSetAttribute((const void *)k_minimizer_fast<9, false, false, true, 31, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want); }
+            lds = want;
+        }
+    }
     const uint64_t blocks = (n_reads + 4 * FAST_READS_PER_WAVE - 1) / (4 * FAST_READS_PER_WAVE);
     const dim3 g((unsigned)blocks), b(256);
     // k <= 27: 64-bit minima through v_min_f64 (see umin64); HULK_NO_FMIN keeps the integer compares (A/B aid)
