@@ -45,4 +45,36 @@ struct FqBuffers {
 hipError_t launch_fq_parse(hipStream_t s, const FqBuffers &B, const uint8_t *prev_raw, const FqState *prev_state, uint8_t *raw,
                            FqState *state, uint32_t len, uint64_t *off_out, uint8_t *bases_out);
 
+// ---- FASTA (sketch.go:102-135) on the device --------------------------------------------------------------------------
+// A '>' line closes the record in progress and opens the next; every other line is sequence, appended; the first EMPTY line
+// ends the parsing.  Sequences are unbounded (a chromosome spans hundreds of blocks), lines are not: a block's sequence
+// lines are compacted to the end of an accumulation buffer that outlives the block, header lines leave the position they
+// stood at (the record offsets).  Nothing here needs the host parser: an empty line, a line of 64 KiB or more and the
+// unterminated tail are reported in the block's scalars and the host acts on them in stream order.
+constexpr uint32_t FA_NONE = 0xffffffffu;
+struct FaState {
+    uint32_t start, end;
+    uint32_t n_lines;        // '\n' terminated lines in [start, end), at most the index's capacity (see FaBuffers::line_cap)
+    uint32_t need_host;      // (FQ_NEED_LINES when the count was clamped: then first_empty is set, and nothing behind it counts)
+    uint32_t first_empty;    // index of the first empty line (FA_NONE: none) — sketch.go:103-105: break
+    uint32_t long_line;      // index of the first line of FQ_MAX_TOKEN bytes or more (FA_NONE: none)
+    uint32_t n_hdr;          // '>' lines in front of the first of those two
+    uint32_t tail_start, tail_len;   // the unterminated line at the block's end: the next block parses it again
+    uint32_t min_len, max_len;       // over the records that begin AND end at a header of this block (n_hdr - 1 of them)
+    unsigned long long seq_bytes;    // sequence bytes appended by this block
+    unsigned long long first_hdr, last_hdr;   // positions in the accumulation buffer the block's first / last header stood at
+};
+struct FaBuffers {
+    uint32_t porch = 0;
+    // Lines the index holds: (64 KiB + block) / 2 + 2.  A non-empty line takes two bytes at least, so a block with more lines
+    // than that has an empty one among the first line_cap — where the parsing ends anyway: clamping the index loses nothing.
+    uint32_t line_cap = 0;
+    uint32_t *wgcnt = nullptr, *line_end = nullptr, *linfo = nullptr, *ldst = nullptr, *wghdr = nullptr;
+    unsigned long long *wgbytes = nullptr;
+};
+// Parse raw[porch - tail .. porch + len) on stream s.  Sequence bytes go to acc + out_base .., the positions of header lines
+// to rec_off[0 .. n_hdr) (the caller guarantees room for line_cap entries); scalars to *state.
+hipError_t launch_fa_parse(hipStream_t s, const FaBuffers &B, const uint8_t *prev_raw, const FaState *prev_state, uint8_t *raw,
+                           FaState *state, uint32_t len, uint8_t *acc, uint64_t out_base, uint64_t *rec_off);
+
 }  // namespace hulk

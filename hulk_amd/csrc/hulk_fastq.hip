@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void k_fq_tail_in(const uint8_t *__restrict__ 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tl; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-__global__ __launch_bounds__(FQ_T) void k_fq_count(const uint8_t *__restrict__ raw, const FqState *__restrict__ st,
+template <class ST>
+__global__ __launch_bounds__(FQ_T) void k_fq_count(const uint8_t *__restrict__ raw, const ST *__restrict__ st,
                                                    uint32_t *__restrict__ wgcnt) {
     __shared__ uint32_t red[FQ_T / 64];
     const uint32_t lo = st->start, hi = st->end, a0 = lo & ~15u;
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(FQ_T) void k_fq_count(const uint8_t *__restrict__ r
 }
 
 // exclusive scan of n <= 8 * FQ_T workgroup counts in place; the total goes to *total_out (clamped to cap -> need_host)
-__global__ __launch_bounds__(FQ_T) void k_fq_scan_u32(uint32_t *__restrict__ v, uint32_t n, FqState *st, uint32_t cap) {
+template <class ST>
+__global__ __launch_bounds__(FQ_T) void k_fq_scan_u32(uint32_t *__restrict__ v, uint32_t n, ST *st, uint32_t cap) {
     __shared__ uint32_t lds[FQ_T / 64 + 1];
     uint32_t mine[8], sum = 0;
 #pragma unroll
@@ -150,7 +152,8 @@ __global__ __launch_bounds__(FQ_T) void k_fq_scan_u32(uint32_t *__restrict__ v, 
     }
 }
 
-__global__ __launch_bounds__(FQ_T) void k_fq_lines(const uint8_t *__restrict__ raw, const FqState *__restrict__ st,
+template <class ST>
+__global__ __launch_bounds__(FQ_T) void k_fq_lines(const uint8_t *__restrict__ raw, const ST *__restrict__ st,
                                                    const uint32_t *__restrict__ wgbase, uint32_t *__restrict__ line_end, uint32_t cap) {
     __shared__ uint32_t lds[FQ_T / 64 + 1];
     const uint32_t lo = st->start, hi = st->end, a0 = lo & ~15u;
@@ -300,6 +303,156 @@ __global__ __launch_bounds__(256) void k_fq_copy(const uint8_t *__restrict__ raw
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// FASTA (hulk_fastq.h).  The newline index is the FASTQ parser's (k_fq_count / k_fq_scan_u32 / k_fq_lines); then
+//   k_fa_class   per line: length (CR dropped), first byte; the first empty line and the first line of 64 KiB or more (atomicMin)
+//   k_fa_flags / k_fa_scan    header lines and sequence bytes in front of the first of those, per workgroup -> prefix sums
+//   k_fa_emit    a sequence line's destination (bytes from the block's first sequence byte), a header's position -> rec_off
+//   k_fa_copy    the sequence lines to the end of the accumulation buffer, a wave per line
+//   k_fa_lens    shortest / longest record between two headers of the block, the block's first / last header position
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fa_begin(const uint8_t *__restrict__ prev_raw, const FaState *__restrict__ prev,
+                                                  uint8_t *__restrict__ raw, FaState *st, uint32_t porch, uint32_t len) {
+    const uint32_t tl = prev ? prev->tail_len : 0u;
+    const bool fits = tl <= porch;               // (the host ends the run at a tail of FQ_MAX_TOKEN bytes: it always fits)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        FaState s{};
+        s.start = fits ? porch - tl : porch;
+        s.end = porch + len;
+        s.need_host = fits ? 0u : FQ_NEED_TAIL;
+        s.first_empty = FA_NONE; s.long_line = FA_NONE;
+        s.min_len = FA_NONE; s.max_len = 0;
+        *st = s;
+    }
+    if (!fits || !tl) return;
+    const uint8_t *src = prev_raw + prev->tail_start;
+    uint8_t *dst = raw + porch - tl;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tl; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(FQ_T) void k_fa_class(const uint8_t *__restrict__ raw, FaState *st, const uint32_t *__restrict__ line_end,
+                                                   uint32_t *__restrict__ linfo) {
+    const uint32_t NL = st->n_lines;
+    const uint32_t i = blockIdx.x * FQ_T + threadIdx.x;
+    if (i >= NL) return;
+    const uint32_t b = i ? line_end[i - 1] + 1u : st->start, e = line_end[i];
+    const uint32_t rawlen = e - b;
+    uint32_t L = rawlen;
+    if (L && raw[e - 1] == '\r') L--;                               // ScanLines' dropCR
+    const uint32_t first = L ? raw[b] : 0u;
+    if (rawlen >= FQ_MAX_TOKEN) atomicMin(&st->long_line, i);
+    if (L == 0) atomicMin(&st->first_empty, i);
+    linfo[i] = (L < 0xffffffu ? L : 0xffffffu) | first << 24;
+}
+
+// lines in front of the first event (empty line / line too long) count
+__device__ __forceinline__ uint32_t fa_live_lines(const FaState *st) {
+    uint32_t ev = st->n_lines;
+    if (st->first_empty < ev) ev = st->first_empty;
+    if (st->long_line < ev) ev = st->long_line;
+    return ev;
+}
+
+__global__ __launch_bounds__(FQ_T) void k_fa_flags(const FaState *st, const uint32_t *__restrict__ linfo, uint32_t *__restrict__ wghdr,
+                                                   unsigned long long *__restrict__ wgbytes) {
+    __shared__ uint32_t rc[FQ_T / 64]; __shared__ unsigned long long rb[FQ_T / 64];
+    const uint32_t ev = fa_live_lines(st);
+    if (blockIdx.x * FQ_T >= ev) { if (threadIdx.x == 0) { wghdr[blockIdx.x] = 0; wgbytes[blockIdx.x] = 0; } return; }
+    const uint32_t i = blockIdx.x * FQ_T + threadIdx.x;
+    uint32_t c = 0; unsigned long long by = 0;
+    if (i < ev) {
+        const uint32_t info = linfo[i];
+        if ((info >> 24) == '>') c = 1; else by = info & 0xffffffu;
+    }
+    for (int off = 32; off; off >>= 1) { c += __shfl_xor(c, off); by += __shfl_xor(by, off); }
+    if ((threadIdx.x & 63) == 0) { rc[threadIdx.x >> 6] = c; rb[threadIdx.x >> 6] = by; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tc = 0; unsigned long long tb = 0;
+        for (int x = 0; x < FQ_T / 64; x++) { tc += rc[x]; tb += rb[x]; }
+        wghdr[blockIdx.x] = tc; wgbytes[blockIdx.x] = tb;
+    }
+}
+
+// exclusive scans of up to 16 * FQ_T workgroup sums; the block's scalars
+__global__ __launch_bounds__(FQ_T) void k_fa_scan(uint32_t *__restrict__ wghdr, unsigned long long *__restrict__ wgbytes, uint32_t n,
+                                                  FaState *st, const uint32_t *__restrict__ line_end) {
+    __shared__ uint32_t lds[FQ_T / 64 + 1]; __shared__ unsigned long long ldb[FQ_T / 64 + 1];
+    uint32_t mc[16], sc = 0; unsigned long long mb[16], sb = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t at = threadIdx.x * 16 + i;
+        mc[i] = at < n ? wghdr[at] : 0u; mb[i] = at < n ? wgbytes[at] : 0ull; sc += mc[i]; sb += mb[i];
+    }
+    uint32_t tc; unsigned long long tb;
+    uint32_t rcn = wg_excl_u32(sc, lds, tc);
+    unsigned long long rbn = wg_excl_u64(sb, ldb, tb);
+#pragma unroll
+    for (int i = 0; i < 16; i++) { const uint32_t at = threadIdx.x * 16 + i; if (at < n) { wghdr[at] = rcn; wgbytes[at] = rbn; } rcn += mc[i]; rbn += mb[i]; }
+    if (threadIdx.x == 0) {
+        st->n_hdr = tc;
+        st->seq_bytes = tb;
+        const uint32_t NL = st->n_lines;
+        st->tail_start = NL ? line_end[NL - 1] + 1u : st->start;
+        st->tail_len = st->end - st->tail_start;
+    }
+}
+
+__global__ __launch_bounds__(FQ_T) void k_fa_emit(const FaState *st, const uint32_t *__restrict__ linfo, const uint32_t *__restrict__ wghdr,
+                                                  const unsigned long long *__restrict__ wgbytes, uint32_t *__restrict__ ldst,
+                                                  uint64_t *__restrict__ rec_off, uint64_t out_base) {
+    __shared__ uint32_t lds[FQ_T / 64 + 1]; __shared__ unsigned long long ldb[FQ_T / 64 + 1];
+    const uint32_t ev = fa_live_lines(st);
+    if (blockIdx.x * FQ_T >= ev) return;
+    const uint32_t i = blockIdx.x * FQ_T + threadIdx.x;
+    uint32_t c = 0, L = 0;
+    if (i < ev) {
+        const uint32_t info = linfo[i];
+        if ((info >> 24) == '>') c = 1; else L = info & 0xffffffu;
+    }
+    uint32_t tc; unsigned long long tb;
+    const uint32_t hidx = wghdr[blockIdx.x] + wg_excl_u32(c, lds, tc);
+    const unsigned long long at = wgbytes[blockIdx.x] + wg_excl_u64((unsigned long long)L, ldb, tb);
+    if (i < ev) {
+        if (c) { rec_off[hidx] = out_base + at; ldst[i] = FA_NONE; }
+        else ldst[i] = (uint32_t)at;                                // (a block's sequence bytes are fewer than its raw bytes: 32 bits)
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fa_copy(const uint8_t *__restrict__ raw, const FaState *__restrict__ st,
+                                                 const uint32_t *__restrict__ line_end, const uint32_t *__restrict__ linfo,
+                                                 const uint32_t *__restrict__ ldst, uint8_t *__restrict__ out) {
+    const uint32_t ev = fa_live_lines(st);
+    const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    // 64 consecutive lines per wave and round: every lane fetches one line's (source, destination, length), the wave copies them in turn
+    for (uint32_t r0 = wave * 64u; r0 < ev; r0 += nw * 64u) {
+        const uint32_t r = r0 + lane;
+        uint32_t src = 0, dst = FA_NONE, L = 0;
+        if (r < ev) { dst = ldst[r]; L = linfo[r] & 0xffffffu; src = r ? line_end[r - 1] + 1u : st->start; }
+        const uint32_t cnt = ev - r0 < 64u ? ev - r0 : 64u;
+        for (uint32_t x = 0; x < cnt; x++) {
+            const uint32_t d = (uint32_t)__shfl((int)dst, (int)x);
+            if (d == FA_NONE) continue;
+            const uint32_t s_ = (uint32_t)__shfl((int)src, (int)x), n = (uint32_t)__shfl((int)L, (int)x);
+            for (uint32_t y = lane; y < n; y += 64u) out[(size_t)d + y] = raw[s_ + y];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fa_lens(FaState *st, const uint64_t *__restrict__ rec_off) {
+    const uint32_t n = st->n_hdr;
+    uint32_t mn = FA_NONE, mx = 0;
+    for (uint32_t h = 1u + blockIdx.x * blockDim.x + threadIdx.x; h < n; h += gridDim.x * blockDim.x) {
+        const uint64_t d = rec_off[h] - rec_off[h - 1];
+        const uint32_t d32 = d < 0xfffffffeull ? (uint32_t)d : 0xfffffffeu;
+        mn = d32 < mn ? d32 : mn; mx = d32 > mx ? d32 : mx;
+    }
+    for (int off = 32; off; off >>= 1) { const uint32_t a = __shfl_xor(mn, off), b = __shfl_xor(mx, off); mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
+    if ((threadIdx.x & 63) == 0) { if (mn != FA_NONE) atomicMin(&st->min_len, mn); if (mx) atomicMax(&st->max_len, mx); }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) { st->first_hdr = rec_off[0]; st->last_hdr = rec_off[n - 1]; }
+}
+
 }  // namespace
 
 hipError_t launch_fq_parse(hipStream_t s, const FqBuffers &B, const uint8_t *prev_raw, const FqState *prev_state, uint8_t *raw,
@@ -309,9 +462,9 @@ hipError_t launch_fq_parse(hipStream_t s, const FqBuffers &B, const uint8_t *pre
     const uint32_t nlwg = (B.line_cap + FQ_T - 1) / FQ_T;
     if (nchunks > 8 * FQ_T || nlwg > 8 * FQ_T) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_fq_tail_in, dim3(64), dim3(256), 0, s, prev_raw, prev_state, raw, state, B.porch, len);
-    hipLaunchKernelGGL(k_fq_count, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt);
-    hipLaunchKernelGGL(k_fq_scan_u32, dim3(1), dim3(FQ_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
-    hipLaunchKernelGGL(k_fq_lines, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
+    hipLaunchKernelGGL(k_fq_count<FqState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt);
+    hipLaunchKernelGGL(k_fq_scan_u32<FqState>, dim3(1), dim3(FQ_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
+    hipLaunchKernelGGL(k_fq_lines<FqState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
     hipLaunchKernelGGL(k_fq_class, dim3(nlwg), dim3(FQ_T), 0, s, raw, state, B.line_end, B.linfo, B.lmap, B.wgmap);
     hipLaunchKernelGGL(k_fq_scan_maps, dim3(1), dim3(FQ_T), 0, s, B.wgmap, nlwg, B.wgstate, state);
     hipLaunchKernelGGL(k_fq_flags, dim3(nlwg), dim3(FQ_T), 0, s, state, B.linfo, B.lmap, B.wgstate, B.wgseq, B.wgbytes);
@@ -319,6 +472,26 @@ hipError_t launch_fq_parse(hipStream_t s, const FqBuffers &B, const uint8_t *pre
     hipLaunchKernelGGL(k_fq_emit, dim3(nlwg), dim3(FQ_T), 0, s, state, B.line_end, B.linfo, B.lmap, B.wgstate, B.wgseq, B.wgbytes, off_out,
                        B.src_out, B.read_cap);
     hipLaunchKernelGGL(k_fq_copy, dim3(2048), dim3(256), 0, s, raw, state, off_out, B.src_out, bases_out, B.read_cap, B.bytes_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_fa_parse(hipStream_t s, const FaBuffers &B, const uint8_t *prev_raw, const FaState *prev_state, uint8_t *raw,
+                           FaState *state, uint32_t len, uint8_t *acc, uint64_t out_base, uint64_t *rec_off) {
+    const uint32_t span = B.porch + len + 16u;
+    const uint32_t nchunks = (span + FQ_CHUNK - 1) / FQ_CHUNK;
+    const uint32_t nlwg = (B.line_cap + FQ_T - 1) / FQ_T;
+    if (nchunks > 8 * FQ_T || nlwg > 16 * FQ_T) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_fa_begin, dim3(64), dim3(256), 0, s, prev_raw, prev_state, raw, state, B.porch, len);
+    hipLaunchKernelGGL(k_fq_count<FaState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt);
+    hipLaunchKernelGGL(k_fq_scan_u32<FaState>, dim3(1), dim3(FQ_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
+    hipLaunchKernelGGL(k_fq_lines<FaState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
+    // (a block of 60-byte lines has 1/30 of line_cap: the workgroups behind the last line leave at once)
+    hipLaunchKernelGGL(k_fa_class, dim3(nlwg), dim3(FQ_T), 0, s, raw, state, B.line_end, B.linfo);
+    hipLaunchKernelGGL(k_fa_flags, dim3(nlwg), dim3(FQ_T), 0, s, state, B.linfo, B.wghdr, B.wgbytes);
+    hipLaunchKernelGGL(k_fa_scan, dim3(1), dim3(FQ_T), 0, s, B.wghdr, B.wgbytes, nlwg, state, B.line_end);
+    hipLaunchKernelGGL(k_fa_emit, dim3(nlwg), dim3(FQ_T), 0, s, state, B.linfo, B.wghdr, B.wgbytes, B.ldst, rec_off, out_base);
+    hipLaunchKernelGGL(k_fa_copy, dim3(2048), dim3(256), 0, s, raw, state, B.line_end, B.linfo, B.ldst, acc + out_base);
+    hipLaunchKernelGGL(k_fa_lens, dim3(64), dim3(256), 0, s, state, rec_off);
     return hipGetLastError();
 }
 

@@ -1688,10 +1688,26 @@ struct FqDev {
     hipEvent_t ev_copied[NHOST] = {}, ev_parsed[NST] = {}, ev_busy[NOUT][2] = {};
     bool busy0[NOUT] = {}, busy1[NOUT] = {};
     hulk::FqBuffers B;
+    // --fasta (run_ingest_fasta_device), allocated by the first such run of the set: a line index with room for (64 KiB + block) / 2
+    // lines, two accumulation buffers (sequence bytes of complete records + the record in progress; they grow with the longest
+    // record) and their record offsets — about 110 MB + 2 x (192 MB + 70 MB) of HBM at the default block size
+    struct Fasta {
+        bool ready = false;
+        hulk::FaBuffers B;
+        hulk::FaState *d_state = nullptr, *h_state = nullptr;      // [NST]
+        uint8_t *acc[2] = {}; size_t acc_cap[2] = {};
+        uint64_t *rec_off[2] = {}; size_t rec_cap = 0;
+        hipEvent_t ev_busy[2][2] = {};
+        bool busy0[2] = {}, busy1[2] = {};
+    } fa;
     size_t raw_bytes() const { return (size_t)porch + block + 64; }
     void release() {
         if (cs) hipStreamSynchronize(cs);
         if (ps) hipStreamSynchronize(ps);
+        hipFree(fa.B.wgcnt); hipFree(fa.B.line_end); hipFree(fa.B.linfo); hipFree(fa.B.ldst); hipFree(fa.B.wghdr); hipFree(fa.B.wgbytes);
+        hipFree(fa.d_state); if (fa.h_state) hipHostFree(fa.h_state);
+        for (int i = 0; i < 2; i++) { hipFree(fa.acc[i]); hipFree(fa.rec_off[i]); for (auto &e : fa.ev_busy[i]) if (e) hipEventDestroy(e); }
+        fa = Fasta{};
         for (auto &p : d_raw) { hipFree(p); p = nullptr; }
         for (auto &p : d_bases) { hipFree(p); p = nullptr; }
         for (auto &p : d_off) { hipFree(p); p = nullptr; }
@@ -2009,6 +2025,224 @@ int run_ingest_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths,
     return ok ? HULK_OK : err.code;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// --fasta -> sequences ON THE DEVICE (hulk_fastq.hip, k_fa_*): sketch.go:102-135 with the host reduced to read() into pinned
+// memory, one PCIe copy per block and the bookkeeping of records in stream order.  Unlike FASTQ a block's result depends on
+// where the previous block left the accumulation buffer, and the host learns that from the previous block's scalars: the parse
+// kernels of block b are queued when block b-1's scalars have arrived (its copy was queued before: the link stays busy, and
+// the parse of a block is shorter than its copy).
+//   acc[cur]     : [records handed over][complete records][record in progress]; rec_off[cur][r] = where record r begins
+//   a batch      : the complete records, handed to hulk_add_reads_device when they hold FASTA_BATCH_BYTES (the host parser's
+//                  rule) or the offsets run short; the record in progress then moves to the front of the other buffer
+//   events       : an empty line ends the stream (sketch.go:103-105), a line of 64 KiB or more is bufio.Scanner's error — the
+//                  first of the two in stream order counts, as in Parser::fasta_block
+// ------------------------------------------------------------------------------------------
+static bool fa_ensure(FqDev *D, IngestError &err) {
+    FqDev::Fasta &F = D->fa;
+    if (F.ready) return true;
+#define FA_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return err.set(HULK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+    F.B.porch = D->porch;
+    F.B.line_cap = (uint32_t)((MAX_TOKEN + D->block) / 2 + 2);
+    const size_t nchunk = (D->raw_bytes() + 16383) / 16384 + 8, nlwg = ((size_t)F.B.line_cap + 1023) / 1024 + 8;
+    FA_HIP(hipMalloc((void **)&F.B.wgcnt, nchunk * 4));
+    FA_HIP(hipMalloc((void **)&F.B.line_end, (size_t)F.B.line_cap * 4));
+    FA_HIP(hipMalloc((void **)&F.B.linfo, (size_t)F.B.line_cap * 4));
+    FA_HIP(hipMalloc((void **)&F.B.ldst, (size_t)F.B.line_cap * 4));
+    FA_HIP(hipMalloc((void **)&F.B.wghdr, nlwg * 4));
+    FA_HIP(hipMalloc((void **)&F.B.wgbytes, nlwg * 8));
+    FA_HIP(hipMalloc((void **)&F.d_state, FqDev::NST * sizeof(hulk::FaState)));
+    FA_HIP(hipHostMalloc((void **)&F.h_state, FqDev::NST * sizeof(hulk::FaState), hipHostMallocDefault));
+    F.rec_cap = (size_t)F.B.line_cap + ((size_t)1 << 19);
+    for (int i = 0; i < 2; i++) {
+        F.acc_cap[i] = (size_t)192 << 20;
+        FA_HIP(hipMalloc((void **)&F.acc[i], F.acc_cap[i] + 64));
+        FA_HIP(hipMalloc((void **)&F.rec_off[i], (F.rec_cap + 2) * 8));
+        for (auto &e : F.ev_busy[i]) FA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    FA_HIP(hipDeviceSynchronize());
+#undef FA_HIP
+    F.ready = true;
+    return true;
+}
+
+int run_ingest_fasta_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths, const IngestCfg &cfg_in, PhaseTrace &g_trace,
+                            hulk_ingest_stats *stats, IngestError &err) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n_paths && !paths) { err.set(HULK_ERR_ARG, "NULL path list"); return err.code; }
+    IngestCfg cfg = cfg_in;
+    if (!cfg.block_set) cfg.block = (size_t)16u << 20;              // (as the FASTQ path: the host's job is read() and one copy per block)
+    if (!cfg.readers_set) { const unsigned hw = std::thread::hardware_concurrency(); cfg.readers = hw ? std::min(16u, hw) : 4u; }
+    const size_t block = std::min<size_t>(cfg.block, (size_t)32u << 20);
+    FqDev *D = fq_dev_for(ctx, block, err);
+    if (!D) return err.code;
+    struct Lease { FqDev *d; ~Lease() { hipStreamSynchronize(d->cs); hipStreamSynchronize(d->ps); fq_dev_release(d); } } lease{D};
+    (void)lease;
+#define DEV_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err.set(HULK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); return err.code; } } while (0)
+    DEV_HIP(hipSetDevice(D->device));
+    if (!fa_ensure(D, err)) return err.code;
+    FqDev::Fasta &F = D->fa;
+    const uint64_t min_len = hulk::ctx_min_read_len(ctx);
+    int cur = 0;
+    uint64_t acc_len = 0, open_start = 0;        // bytes in acc[cur]; where the record in progress begins
+    uint64_t rec_count = 0, batch_start = 0;     // headers recorded in rec_off[cur] (the last one opened the record in progress); rec_off[cur][0]
+    bool have_hdr = false, stopped = false, ok = true;
+    uint64_t bmin = ~0ull, bmax = 0;             // over the complete records not handed over yet
+    uint64_t n_lines = 0, dev_seqs = 0, bytes_done = 0;
+    hipEvent_t last_parsed = nullptr;
+    // a buffer is written from acc_len on; what the context still reads of it (records handed over by the run before) lies below —
+    // except in a buffer taken over EMPTY: wait for its readers first
+    auto wait_readers = [&](int b) -> bool {
+        if (F.busy0[b]) { if (hipStreamWaitEvent(D->ps, F.ev_busy[b][0], 0) != hipSuccess) return err.set(HULK_ERR_HIP, "hipStreamWaitEvent (FASTA buffers)"); F.busy0[b] = false; }
+        if (F.busy1[b]) { if (hipStreamWaitEvent(D->ps, F.ev_busy[b][1], 0) != hipSuccess) return err.set(HULK_ERR_HIP, "hipStreamWaitEvent (FASTA buffers)"); F.busy1[b] = false; }
+        return true;
+    };
+    // room for `need` bytes in acc[b] (contents up to `keep` survive)
+    auto ensure_acc = [&](int b, uint64_t need, uint64_t keep) -> bool {
+        if (need <= F.acc_cap[b]) return true;
+        size_t nc = F.acc_cap[b];
+        while (nc < need) nc *= 2;
+        uint8_t *q = nullptr;
+        if (hipStreamSynchronize(D->ps) != hipSuccess || hipMalloc((void **)&q, nc + 64) != hipSuccess)
+            return err.set(HULK_ERR_HIP, "hipMalloc (FASTA accumulation buffer)");
+        if (keep && hipMemcpy(q, F.acc[b], keep, hipMemcpyDeviceToDevice) != hipSuccess) { hipFree(q); return err.set(HULK_ERR_HIP, "hipMemcpy (FASTA accumulation buffer)"); }
+        // (what the context queued on the old buffer has to be through before it goes: hipFree waits for the device)
+        hipFree(F.acc[b]);
+        F.acc[b] = q; F.acc_cap[b] = nc; F.busy0[b] = F.busy1[b] = false;
+        return true;
+    };
+    // hand the complete records of acc[cur] to the context; final: the record in progress is complete too (end of the stream)
+    auto hand_over = [&](bool final) -> bool {
+        uint64_t n = rec_count ? rec_count - 1 : 0;
+        if (final && have_hdr) {
+            const uint64_t L = acc_len - open_start;
+            bmin = std::min(bmin, L); bmax = std::max(bmax, L);
+            if (hipMemcpyAsync(F.rec_off[cur] + rec_count, &acc_len, 8, hipMemcpyHostToDevice, D->ps) != hipSuccess || hipStreamSynchronize(D->ps) != hipSuccess)
+                return err.set(HULK_ERR_HIP, "hipMemcpyAsync (last FASTA record)");
+            n++;
+        }
+        if (n) {
+            // NewMinimizerSketch's checks (minimizer.go:70-76), as hulk_add_reads makes them
+            if (bmin < 1) return err.set(HULK_ERR_EMPTY_SEQ, hulk_strerror(HULK_ERR_EMPTY_SEQ));
+            if (bmin < min_len) return err.set(HULK_ERR_SHORT_SEQ, hulk_strerror(HULK_ERR_SHORT_SEQ));
+            if (bmax > 0xffffffffull) return err.set(HULK_ERR_READ_TOO_LONG, hulk_strerror(HULK_ERR_READ_TOO_LONG));
+            const double tc1 = PhaseTrace::now();
+            int rc = last_parsed ? hulk::ctx_wait_event(ctx, last_parsed) : HULK_OK;
+            if (rc == HULK_OK) rc = hulk_add_reads_device(ctx, F.acc[cur], F.rec_off[cur], n, (uint32_t)bmax, F.acc_cap[cur] + 64);
+            if (rc == HULK_OK) rc = hulk::ctx_record_busy(ctx, F.ev_busy[cur][0], F.ev_busy[cur][1], &F.busy1[cur]);
+            g_trace.add_reads += PhaseTrace::now() - tc1;
+            if (rc != HULK_OK) return err.set(rc, hulk_last_error(ctx));
+            F.busy0[cur] = true;
+            dev_seqs += n; bytes_done += (final ? acc_len : open_start) - batch_start;
+        }
+        bmin = ~0ull; bmax = 0;
+        return true;
+    };
+    // the record in progress moves to the front of the other buffer; the next blocks append there
+    auto switch_buffers = [&]() -> bool {
+        const int nb = cur ^ 1;
+        const uint64_t part = have_hdr ? acc_len - open_start : 0;
+        // (the context may still read records of `nb` handed over two batches ago: it is written from byte 0 now)
+        if (F.busy0[nb] || F.busy1[nb]) {
+            if (!wait_readers(nb)) return false;
+        }
+        if (!ensure_acc(nb, part + MAX_TOKEN + block + 64, 0)) return false;
+        if (part && hipMemcpyAsync(F.acc[nb], F.acc[cur] + open_start, part, hipMemcpyDeviceToDevice, D->ps) != hipSuccess)
+            return err.set(HULK_ERR_HIP, "hipMemcpyAsync (FASTA record in progress)");
+        if (hipMemsetAsync(F.rec_off[nb], 0, 8, D->ps) != hipSuccess) return err.set(HULK_ERR_HIP, "hipMemsetAsync (FASTA record offsets)");
+        cur = nb; acc_len = part; open_start = 0; batch_start = 0; rec_count = have_hdr ? 1 : 0;
+        return true;
+    };
+    {
+        RawReader reader(paths, n_paths, cfg, D);
+        if (!wait_readers(0) || !wait_readers(1)) return err.code;
+        std::deque<RawReader::Item> held;
+        uint64_t b = 0;
+        bool eof = false;
+        // block x's scalars -> the stream's bookkeeping; false: the run fails (err)
+        auto consume = [&](uint64_t x) -> bool {
+            const int st = (int)(x % FqDev::NST);
+            const double tw0 = PhaseTrace::now();
+            if (hipEventSynchronize(D->ev_parsed[st]) != hipSuccess) return err.set(HULK_ERR_HIP, "hipEventSynchronize (device FASTA parser)");
+            g_trace.stage_wait += PhaseTrace::now() - tw0;
+            const hulk::FaState S = F.h_state[st];
+            const bool stop = S.first_empty != hulk::FA_NONE && S.first_empty < S.long_line;
+            const bool too_long = S.long_line != hulk::FA_NONE && !stop;
+            n_lines += stop ? (uint64_t)S.first_empty + 1 : too_long ? (uint64_t)S.long_line : (uint64_t)S.n_lines;
+            if (S.n_hdr) {
+                if (have_hdr) { const uint64_t L = S.first_hdr - open_start; bmin = std::min(bmin, L); bmax = std::max(bmax, L); }
+                else batch_start = S.first_hdr;                         // (sequence lines in front of the stream's first header: no record owns them)
+                if (S.n_hdr > 1) { bmin = std::min<uint64_t>(bmin, S.min_len); bmax = std::max<uint64_t>(bmax, S.max_len); }
+                rec_count += S.n_hdr; open_start = S.last_hdr; have_hdr = true;
+            }
+            acc_len += S.seq_bytes;
+            if (!have_hdr) acc_len = 0;                                 // (l2 = nil: sequence lines before any header are dropped)
+            if (too_long) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
+            if (stop) { stopped = true; return true; }
+            if (S.tail_len >= MAX_TOKEN) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
+            return true;
+        };
+        for (;;) {
+            RawReader::Item it;
+            const double tb0 = PhaseTrace::now();
+            const bool got = reader.next(it, err);
+            const double tb1 = PhaseTrace::now(); g_trace.wait_block += tb1 - tb0;
+            if (!got) { ok = err.code == HULK_OK; break; }
+            const int r = (int)(b % FqDev::NRAW), st = (int)(b % FqDev::NST);
+            if (it.len) {
+                DEV_HIP(hipMemcpyAsync(D->d_raw[r] + D->porch, D->h_buf[it.idx], it.len, hipMemcpyHostToDevice, D->cs));
+                DEV_HIP(hipEventRecord(D->ev_copied[it.idx], D->cs));
+            }
+            g_trace.enqueue += PhaseTrace::now() - tb1;
+            if (!held.empty()) {                                        // block b-1: its scalars, while block b crosses the link
+                if (!consume(b - 1)) { ok = false; break; }
+                reader.recycle(held.front().idx); held.pop_front();
+                if (stopped) { reader.recycle(it.idx); break; }
+                // a batch is due (the host parser's rule), or the offsets / the buffer could not take another block
+                const bool full = rec_count > 1 && open_start - batch_start >= FASTA_BATCH_BYTES;
+                if (full || rec_count + F.B.line_cap + 2 > F.rec_cap) {
+                    if (!hand_over(false) || !switch_buffers()) { ok = false; break; }
+                }
+            }
+            if (it.len == 0) { reader.recycle(it.idx); eof = true; break; }   // (end of the stream right on a block border)
+            if (!ensure_acc(cur, acc_len + MAX_TOKEN + it.len + 64, acc_len)) { ok = false; break; }
+            const double tq0 = PhaseTrace::now();
+            DEV_HIP(hipStreamWaitEvent(D->ps, D->ev_copied[it.idx], 0));
+            DEV_HIP(hulk::launch_fa_parse(D->ps, F.B, b ? D->d_raw[(b - 1) % FqDev::NRAW] : nullptr, b ? F.d_state + (b - 1) % FqDev::NST : nullptr,
+                                          D->d_raw[r], F.d_state + st, (uint32_t)it.len, F.acc[cur], acc_len, F.rec_off[cur] + rec_count));
+            DEV_HIP(hipMemcpyAsync(F.h_state + st, F.d_state + st, sizeof(hulk::FaState), hipMemcpyDeviceToHost, D->ps));
+            DEV_HIP(hipEventRecord(D->ev_parsed[st], D->ps));
+            last_parsed = D->ev_parsed[st];
+            g_trace.enqueue += PhaseTrace::now() - tq0;
+            held.push_back(it);
+            b++;
+            if (it.eof) { eof = true; break; }
+        }
+        if (ok && !stopped && !held.empty()) {
+            if (!consume(b - 1)) ok = false;
+            reader.recycle(held.front().idx); held.pop_front();
+        }
+        (void)eof;
+        if (ok) {
+            // sketch.go:126-135 flushes the final entry unconditionally; with no header line at all the reference dies on l1[0] = 64
+            if (!have_hdr) ok = err.set(HULK_ERR_FASTA_HEADER, hulk_strerror(HULK_ERR_FASTA_HEADER));
+            else ok = hand_over(true);
+        }
+        hipStreamSynchronize(D->cs); hipStreamSynchronize(D->ps);
+        if (stats) {
+            stats->n_seqs = dev_seqs; stats->total_len = bytes_done; stats->n_lines = n_lines;
+            stats->bytes_in = reader.bytes_in();
+            stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+    }
+#undef DEV_HIP
+    if (cfg.trace)
+        fprintf(stderr, "ingest trace (device FASTA parser; calling thread, s): next block %.3f | copies + parse kernels queued %.3f, "
+                        "waiting for a block's scalars %.3f, hulk_add_reads_device %.3f\n",
+                g_trace.wait_block, g_trace.enqueue, g_trace.stage_wait, g_trace.add_reads);
+    return ok ? HULK_OK : err.code;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2049,6 +2283,7 @@ int hulk_sketch_files_opts(hulk_ctx *ctx, const char *const *paths, uint32_t n_p
         PhaseTrace trace;
         const IngestCfg cfg = resolve_cfg(opts, 0);
         if (!fasta && !cfg.host_parser) rc = run_ingest_device(ctx, paths, n_paths, cfg, trace, stats, err);
+        else if (fasta && !cfg.host_parser) rc = run_ingest_fasta_device(ctx, paths, n_paths, cfg, trace, stats, err);
         else {
             GpuSink sink(ctx, trace);
             rc = run_ingest(paths, n_paths, fasta, cfg, sink, trace, stats, err);

@@ -137,3 +137,111 @@ def test_device_parser_host_parser_and_released_caches_agree(tmp_path):
     for r in res[1:]:
         assert r[:3] == res[0][:3] and r[4] == res[0][4]
         assert np.array_equal(r[3][0], res[0][3][0]) and np.array_equal(r[3][1], res[0][3][1])
+
+
+def _fa_run(paths, flags, k=11, w=5, S=32, interval=0, block=131072):
+    """(stats triple, sketch, counters) of one hulk_sketch_files(--fasta) run, or the error's (code, message)"""
+    from hulk_amd._lib import HulkError
+    g = gpu().GpuSketcher(k, w, S, interval=interval)
+    try:
+        st = g.sketch_files(paths, fasta=True, opts={"flags": flags, "block_bytes": block})
+        g.finish()
+        return (st["n_seqs"], st["total_len"], st["n_lines"]), g.sketch(), g.counters()
+    except HulkError as e:
+        return ("error", e.code, e.message)
+    finally:
+        g.close()
+
+
+def _same(a, b):
+    if a[0] == "error" or b[0] == "error":
+        return a == b
+    return a[0] == b[0] and a[2] == b[2] and np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
+
+
+def test_device_fasta_parser_equals_the_host_parser(tmp_path):
+    """--fasta with the line pump on the device (hulk_fastq.hip k_fa_*, the default) against the host's parser threads
+    (HULK_INGEST_HOST_PARSER) and the literal restatement of sketch.go:102-135: records that span many 128 KiB blocks, sequence
+    lines in front of the first header (dropped), CR/LF, headers back to back (an empty record: the reference's error), a header as
+    the last line, an unterminated last line, a second input that continues the first one's record, an EMPTY line that ends the
+    parsing in the first block, a later one and right behind a header, a line of 64 KiB (bufio.Scanner's error) in front of and
+    behind an empty line, and no header at all."""
+    from hulk_amd import _lib
+    from oracle import linepump
+    rng = np.random.default_rng(2024)
+    acgt = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
+
+    def record(name, L, width, eol=b"\n"):
+        seq = bytes(acgt[rng.integers(0, len(acgt), size=L)])
+        return b">" + name + eol + b"".join(seq[i:i + width] + eol for i in range(0, L, width))
+
+    def write(name, data):
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        return p
+
+    HOST = _lib.HULK_INGEST_HOST_PARSER
+    good = (b"ACGTACGT\nTTTT\n" + record(b"c1 first", 700_000, 60) + record(b"c2", 40, 60) + record(b"c4 crlf", 250_000, 70, b"\r\n") +
+            record(b"c5", 333_333, 61) + record(b"c6", 15, 80))
+    cases = {"good": [write("good.fa", good)],
+             "unterminated": [write("unterminated.fa", good.rstrip(b"\n"))],
+             "two inputs": [write("a.fa", good[:900_001]), write("b.fa", good[900_001:])],
+             "empty record": [write("empty_record.fa", good + b">e1\n>e2\n" + record(b"c7", 100, 60))],
+             "last header": [write("last_header.fa", good + b">last_header_without_sequence\n")],
+             "no header": [write("no_header.fa", b"ACGT\n" * 1000)],
+             "nothing": [write("nothing.fa", b"")],
+             "long line": [write("long.fa", good[:300_000] + b"C" * 65_536 + b"\n" + good[300_000:])],
+             "long tail": [write("long_tail.fa", good[:300_000] + b"C" * 200_000)]}
+    for cut in (5, 12_345, 400_000, 711_700, len(good) // 2, len(good) - 40):
+        at = good.index(b"\n", cut) + 1
+        cases[f"stop {cut}"] = [write(f"stop_{cut}.fa", good[:at] + b"\n" + b"A" * 70_000 + b"\n" + good[at:])]
+        cases[f"stop crlf {cut}"] = [write(f"stopcr_{cut}.fa", good[:at] + b"\r\n" + good[at:])]
+    seen_ok = seen_err = 0
+    for name, paths in cases.items():
+        dev = _fa_run(paths, 0)
+        host = _fa_run(paths, HOST)
+        assert _same(dev, host), (name, dev[0], host[0], dev[1:] if dev[0] == "error" else "", host[1:] if host[0] == "error" else "")
+        for block in (131072 + 12288, 1 << 20):                 # other block sizes: other places where lines and records are cut
+            assert _same(_fa_run(paths, 0, block=block), host), (name, block)
+        if dev[0] == "error":
+            seen_err += 1
+            continue
+        seen_ok += 1
+        try:
+            want = linepump.sequences(paths, fasta=True)
+        except linepump.PumpError:
+            want = None
+        if want is not None:
+            assert dev[0][0] == len(want) and dev[0][1] == sum(len(x) for x in want), name
+    assert seen_ok >= 10 and seen_err >= 5, (seen_ok, seen_err)
+    # with intervals (a flush per 2 sequences) and the default block size
+    p = cases["good"]
+    assert _same(_fa_run(p, 0, interval=2, block=0), _fa_run(p, HOST, interval=2, block=0))
+
+
+def test_device_fasta_parser_batches_and_many_records(tmp_path):
+    """The two ways a batch ends before the stream does: 64 MB of complete records (the record in progress then moves to the other
+    accumulation buffer), and record offsets running short (600 k records of 20 bases through 128 KiB blocks).  Device parser =
+    host parser = the same sequences through hulk_add_reads."""
+    from hulk_amd import _lib, synth
+    HOST = _lib.HULK_INGEST_HOST_PARSER
+    # (a) 30 records of 5 Mbases, 80 per line: 150 MB of sequence, two hand-overs before the end
+    p = str(tmp_path / "big.fa")
+    n, L = 30, 5_000_000
+    with open(p, "wb") as fh:
+        for i in range(n):
+            seq = synth.reads_numpy(1000 + i, 1, L)[0][:L].tobytes()
+            fh.write(b">chr%d\n" % i + b"\n".join(seq[j:j + 80] for j in range(0, L, 80)) + b"\n")
+    dev = _fa_run([p], 0, k=21, w=9, S=64, block=0)
+    host = _fa_run([p], HOST, k=21, w=9, S=64, block=0)
+    assert dev[0] == (n, n * L, n * (1 + (L + 79) // 80)) and _same(dev, host), (dev[0], host[0])
+    # (b) many short records
+    q = str(tmp_path / "many.fa")
+    m = 600_000
+    bases = synth.reads_numpy(7, m, 20)[0][:m * 20].reshape(m, 20)
+    rows = np.empty((m, 24), dtype=np.uint8)
+    rows[:, 0] = ord(">"); rows[:, 1] = ord("r"); rows[:, 2] = ord("\n"); rows[:, 3:23] = bases; rows[:, 23] = ord("\n")
+    open(q, "wb").write(rows.tobytes())
+    dev = _fa_run([q], 0)
+    host = _fa_run([q], HOST)
+    assert dev[0] == (m, m * 20, 2 * m) and _same(dev, host), (dev[0], host[0])

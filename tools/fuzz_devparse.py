@@ -5,6 +5,9 @@ everywhere, CR/LF mixes, stray '>' and '@' lines, missing final newlines, severa
 records straddle block borders in every phase.  What must agree with the oracle: the error text, or the number of reads,
 their total length, the number of lines, and the k-mer spectrum of everything binned (the spectrum of hulk_add_reads over
 the oracle's reads; interval 0: one spectrum for the run).  The host parser (HULK_INGEST_HOST_PARSER) runs beside it.
+FUZZ_FASTA=1: the same for --fasta (k_fa_* behind hulk_sketch_files(fasta = 1), sketch.go:102-135): sequence lines of any length, '>'
+lines anywhere (back to back, first, last), sequence lines in front of the first header, an empty line somewhere (it ends the
+parsing), CR/LF, several inputs that continue one another's record.
 usage: fuzz_devparse.py [n_cases] [seed]     (run on the GPU box)"""
 import gzip
 import os
@@ -28,6 +31,31 @@ K, W = 7, 3
 MINLEN = W + K - 1
 bad = 0
 took_over = 0
+FASTA = bool(os.environ.get("FUZZ_FASTA"))
+
+
+def fasta_soup(n_lines, kind):
+    """kind 0: clean records; 1: + junk in front, headers back to back; 2: + an empty line somewhere, short records"""
+    out = []
+    if kind >= 1 and rng.random() < 0.5:
+        out += [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.integers(1, 90)))) for _ in range(int(rng.integers(1, 4)))]
+    while len(out) < n_lines:
+        out.append(b">contig %d some text" % len(out) if rng.random() < 0.9 else b">")
+        if kind >= 1 and rng.random() < 0.02:
+            continue                                                        # (headers back to back: an empty record)
+        Lmax = int(rng.choice([MINLEN, 40, 300, 5000, 200000]))
+        short = kind == 2 and rng.random() < 0.03
+        L = int(rng.integers(1, MINLEN)) if short else int(rng.integers(MINLEN, Lmax + 1))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), size=L))
+        width = int(rng.choice([60, 70, 80, 1, 7, 1000, 65000]))
+        out += [seq[i:i + width] for i in range(0, L, width)]
+    if kind == 2 and rng.random() < 0.5 and out:
+        out.insert(int(rng.integers(0, len(out) + 1)), b"")
+    eol = [b"\n", b"\r\n"][int(rng.random() < 0.2)]
+    data = eol.join(out)
+    if rng.random() < 0.7:
+        data += eol
+    return data
 
 
 def soup(n_lines, kind):
@@ -66,7 +94,7 @@ with tempfile.TemporaryDirectory() as td:
         paths = []
         for f in range(int(rng.integers(1, 4))):
             n_lines = int(rng.choice([0, 3, 17, 200, 4000, 30000]))
-            data = soup(n_lines, kind)
+            data = fasta_soup(n_lines, kind) if FASTA else soup(n_lines, kind)
             if rng.random() < 0.03:                                  # a line of 64 KiB: "bufio.Scanner: token too long"
                 at = int(rng.integers(0, len(data) + 1))
                 data = data[:at] + b"A" * 65536 + data[at:]
@@ -81,7 +109,7 @@ with tempfile.TemporaryDirectory() as td:
         # problem of the stream up to and including the first line-level one is an acceptable message
         want, acceptable = [], set()
         try:
-            for s_ in linepump.fastq_handler(linepump.data_streamer(paths), False):
+            for s_ in linepump.fastq_handler(linepump.data_streamer(paths), FASTA):
                 s_ = s_ if s_ is not None else b""
                 if len(s_) == 0:
                     acceptable.add("sequence length must be > 0")
@@ -97,7 +125,7 @@ with tempfile.TemporaryDirectory() as td:
         for label, flags in (("device", 0), ("host", _lib.HULK_INGEST_HOST_PARSER)):
             g = hulk_amd.GpuSketcher(K, W, 8, interval=0)
             try:
-                st = g.sketch_files(paths, opts={"flags": flags, "block_bytes": block, "parser_threads": int(rng.choice([1, 3]))})
+                st = g.sketch_files(paths, fasta=FASTA, opts={"flags": flags, "block_bytes": block, "parser_threads": int(rng.choice([1, 3]))})
                 g.synchronize()
                 res[label] = (None, (st["n_seqs"], st["total_len"], st["n_lines"]), g.histogram().copy())
             except HulkError as e:
@@ -113,7 +141,11 @@ with tempfile.TemporaryDirectory() as td:
             o.synchronize()
             hist = o.histogram().copy()
             o.close()
-            n_lines = sum(1 for _ in linepump.data_streamer(paths))
+            n_lines = 0
+            for ln in linepump.data_streamer(paths):
+                n_lines += 1
+                if FASTA and ln is None:                                   # (the empty line that ends the parsing is the last one read)
+                    break
             exp = (None, (len(want), sum(len(s) for s in want), n_lines), hist)
         else:
             exp = (werr, None, None)
