@@ -828,18 +828,20 @@ def main():
                 for i in range(nfa):
                     seq = synth.reads_numpy(i, 1, Lfa)[0].tobytes()
                     fh.write(b">contig_%d\n" % i + b"\n".join(seq[j:j + 60] for j in range(0, Lfa, 60)) + b"\n")
-            runs, md5s = [], set()
-            for _ in range(3):
-                sk = hulk_amd.GpuSketcher(K, W, S, interval=0, device=dev_index)
-                state["kick"] = time.monotonic()
-                t0 = time.perf_counter()
-                st = sk.sketch_files([path], fasta=True)
-                sk.finish()
-                runs.append(time.perf_counter() - t0)
-                assert st["n_seqs"] == nfa and st["total_len"] == nfa * Lfa, st
-                mins, _ = sk.sketch()
-                md5s.add(hashlib.md5(mins.astype("<u8").tobytes()).hexdigest())
-                sk.close()
+            # the line pump on the device (hulk_fastq.hip k_fa_*: the default) and on the host's parser threads (HULK_INGEST_HOST_PARSER)
+            runs, runs_host, md5s = [], [], set()
+            for flags, into in ((0, runs), (_lib.HULK_INGEST_HOST_PARSER, runs_host)):
+                for _ in range(3):
+                    sk = hulk_amd.GpuSketcher(K, W, S, interval=0, device=dev_index)
+                    state["kick"] = time.monotonic()
+                    t0 = time.perf_counter()
+                    st = sk.sketch_files([path], fasta=True, opts={"flags": flags})
+                    sk.finish()
+                    into.append(time.perf_counter() - t0)
+                    assert st["n_seqs"] == nfa and st["total_len"] == nfa * Lfa, st
+                    mins, _ = sk.sketch()
+                    md5s.add(hashlib.md5(mins.astype("<u8").tobytes()).hexdigest())
+                    sk.close()
             assert len(md5s) == 1
             # the same contigs through the device-pointer call: the file path changes nothing but where the bytes come from
             b, off = synth.reads_torch(0, nfa, Lfa, device=device)
@@ -852,6 +854,8 @@ def main():
             md5_file = md5s.pop()
             res["fasta_file"] = {"contigs": nfa, "length": Lfa, "file_bytes": os.path.getsize(path), "seconds": min(runs), "seconds_all_runs": runs,
                                  "bases_per_s": nfa * Lfa / min(runs), "file_GB_per_s": os.path.getsize(path) / min(runs) / 1e9, "sketch_md5": md5_file,
+                                 "parser": "device (k_fa_*: the host read()s blocks into pinned memory)",
+                                 "host_parser": {"seconds": min(runs_host), "seconds_all_runs": runs_host, "bases_per_s": nfa * Lfa / min(runs_host)},
                                  "same_sketch_as_device_buffers": hashlib.md5(mins.astype("<u8").tobytes()).hexdigest() == md5_file}
         finally:
             shutil.rmtree(d_, ignore_errors=True)

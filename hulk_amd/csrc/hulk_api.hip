@@ -266,6 +266,7 @@ void hulk_destroy(hulk_ctx *c) {
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);
+    for (auto &H : c->h_long_desc) { if (H.p) hipHostFree(H.p); if (H.ev) hipEventDestroy(H.ev); }
     comm_teardown(c);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -303,7 +304,11 @@ int hulk_add_reads_device(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d
     if (n && (!d_bases || !d_offsets)) return fail(c, HULK_ERR_ARG, "NULL buffer");
     const uint64_t I = c->p.interval;
     uint64_t pos = 0;
+    const uint64_t *h_off = c->h_off_hint;                         // (ctx_hint_host_offsets: for this call only)
+    c->h_off_hint = nullptr;
+    struct Clear { hulk_ctx *c; ~Clear() { c->h_off_chunk = nullptr; } } clear_hint{c};
     while (pos < n) {
+        c->h_off_chunk = h_off ? h_off + pos : nullptr;
         // one K1 launch covers up to T complete intervals; they are then flushed with ONE pass over K
         const uint64_t fill = I ? c->seq_count % I : 0;
         uint64_t chunk = n - pos;
@@ -396,6 +401,7 @@ int hulk_add_reads(hulk_ctx *c, const uint8_t *bases, const uint64_t *offsets, u
         hulk_ctx::HostStage *hsp = nullptr;
         { const int rcs = stage_host_reads(c, bases, offsets, i0, i1, &hsp); if (rcs != HULK_OK) return rcs; }
         hulk_ctx::HostStage &hs = *hsp;
+        ctx_hint_host_offsets(c, hs.h_off);                         // (the long-sequence path reads the lengths here)
         const int rc = hulk_add_reads_device(c, hs.d_bases, hs.d_off, cn, (uint32_t)cmax, hs.cap_bases);
         if (rc != HULK_OK) return rc;
         { const int rcb = stage_mark_busy(c, hs); if (rcb != HULK_OK) return rcb; }

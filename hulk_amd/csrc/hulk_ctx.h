@@ -127,6 +127,14 @@ struct hulk_ctx {
     bool lds_order_ok = true, cms_chain = false;        // lds_order_verified(device); the count-min replay runs the chain-form kernels (HULK_FLAG_CMS_CHAIN or !lds_order_ok)
     uint64_t *d_long_xs = nullptr, *d_long_table = nullptr; uint8_t *d_long_valid = nullptr;   // long-sequence scratch
     void *d_long_desc = nullptr; uint64_t long_desc_cap = 0;
+    // the descriptors of a group of long sequences are built on the host: two pinned staging buffers in turn, each reused when the
+    // copy out of it (two groups ago) has run — the calling thread stays up to two groups ahead of the binning (bin_long_reads)
+    struct LongDescStage { void *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } h_long_desc[2];
+    int long_desc_turn = 0;
+    // A caller that holds the batch's offsets in host memory says so (ctx_hint_host_offsets): the long-sequence path then reads the
+    // lengths there instead of fetching them from the device behind everything queued on the lane.  Valid for the next
+    // hulk_add_reads_device only; h_off_chunk is that call's current piece.
+    const uint64_t *h_off_hint = nullptr, *h_off_chunk = nullptr;
     uint64_t long_cap = 0, long_table_cap = 0;   // minimizer list of the short-read kernel (grow-only)
     // host-side run state
     uint64_t seq_count = 0, flush_index = 0;

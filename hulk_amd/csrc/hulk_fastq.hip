@@ -22,6 +22,11 @@
 // reference's messages and their order.
 #include "hulk_fastq.h"
 
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "hulk_device.h"
 
 namespace hulk {
@@ -334,16 +339,17 @@ __global__ __launch_bounds__(256) void k_fa_begin(const uint8_t *__restrict__ pr
 __global__ __launch_bounds__(FQ_T) void k_fa_class(const uint8_t *__restrict__ raw, FaState *st, const uint32_t *__restrict__ line_end,
                                                    uint32_t *__restrict__ linfo) {
     const uint32_t NL = st->n_lines;
-    const uint32_t i = blockIdx.x * FQ_T + threadIdx.x;
-    if (i >= NL) return;
-    const uint32_t b = i ? line_end[i - 1] + 1u : st->start, e = line_end[i];
-    const uint32_t rawlen = e - b;
-    uint32_t L = rawlen;
-    if (L && raw[e - 1] == '\r') L--;                               // ScanLines' dropCR
-    const uint32_t first = L ? raw[b] : 0u;
-    if (rawlen >= FQ_MAX_TOKEN) atomicMin(&st->long_line, i);
-    if (L == 0) atomicMin(&st->first_empty, i);
-    linfo[i] = (L < 0xffffffu ? L : 0xffffffu) | first << 24;
+    // (the grid is sized for lines of 16 bytes; a block of shorter ones takes more trips)
+    for (uint32_t i = blockIdx.x * FQ_T + threadIdx.x; i < NL; i += gridDim.x * FQ_T) {
+        const uint32_t b = i ? line_end[i - 1] + 1u : st->start, e = line_end[i];
+        const uint32_t rawlen = e - b;
+        uint32_t L = rawlen;
+        if (L && raw[e - 1] == '\r') L--;                               // ScanLines' dropCR
+        const uint32_t first = L ? raw[b] : 0u;
+        if (rawlen >= FQ_MAX_TOKEN) atomicMin(&st->long_line, i);
+        if (L == 0) atomicMin(&st->first_empty, i);
+        linfo[i] = (L < 0xffffffu ? L : 0xffffffu) | first << 24;
+    }
 }
 
 // lines in front of the first event (empty line / line too long) count
@@ -358,41 +364,48 @@ __global__ __launch_bounds__(FQ_T) void k_fa_flags(const FaState *st, const uint
                                                    unsigned long long *__restrict__ wgbytes) {
     __shared__ uint32_t rc[FQ_T / 64]; __shared__ unsigned long long rb[FQ_T / 64];
     const uint32_t ev = fa_live_lines(st);
-    if (blockIdx.x * FQ_T >= ev) { if (threadIdx.x == 0) { wghdr[blockIdx.x] = 0; wgbytes[blockIdx.x] = 0; } return; }
-    const uint32_t i = blockIdx.x * FQ_T + threadIdx.x;
-    uint32_t c = 0; unsigned long long by = 0;
-    if (i < ev) {
-        const uint32_t info = linfo[i];
-        if ((info >> 24) == '>') c = 1; else by = info & 0xffffffu;
-    }
-    for (int off = 32; off; off >>= 1) { c += __shfl_xor(c, off); by += __shfl_xor(by, off); }
-    if ((threadIdx.x & 63) == 0) { rc[threadIdx.x >> 6] = c; rb[threadIdx.x >> 6] = by; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tc = 0; unsigned long long tb = 0;
-        for (int x = 0; x < FQ_T / 64; x++) { tc += rc[x]; tb += rb[x]; }
-        wghdr[blockIdx.x] = tc; wgbytes[blockIdx.x] = tb;
+    for (uint32_t blk = blockIdx.x; blk * FQ_T < ev; blk += gridDim.x) {      // chunk `blk` of FQ_T lines (k_fa_scan reads no chunk behind ev)
+        const uint32_t i = blk * FQ_T + threadIdx.x;
+        uint32_t c = 0; unsigned long long by = 0;
+        if (i < ev) {
+            const uint32_t info = linfo[i];
+            if ((info >> 24) == '>') c = 1; else by = info & 0xffffffu;
+        }
+        for (int off = 32; off; off >>= 1) { c += __shfl_xor(c, off); by += __shfl_xor(by, off); }
+        if ((threadIdx.x & 63) == 0) { rc[threadIdx.x >> 6] = c; rb[threadIdx.x >> 6] = by; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tc = 0; unsigned long long tb = 0;
+            for (int x = 0; x < FQ_T / 64; x++) { tc += rc[x]; tb += rb[x]; }
+            wghdr[blk] = tc; wgbytes[blk] = tb;
+        }
+        __syncthreads();
     }
 }
 
-// exclusive scans of up to 16 * FQ_T workgroup sums; the block's scalars
+// exclusive scans of the workgroup sums (16 * FQ_T of them per trip); the block's scalars
 __global__ __launch_bounds__(FQ_T) void k_fa_scan(uint32_t *__restrict__ wghdr, unsigned long long *__restrict__ wgbytes, uint32_t n,
                                                   FaState *st, const uint32_t *__restrict__ line_end) {
     __shared__ uint32_t lds[FQ_T / 64 + 1]; __shared__ unsigned long long ldb[FQ_T / 64 + 1];
-    uint32_t mc[16], sc = 0; unsigned long long mb[16], sb = 0;
+    { const uint32_t used = (fa_live_lines(st) + FQ_T - 1) / FQ_T; if (used < n) n = used; }     // (chunks behind the last live line were not written)
+    uint32_t carry_c = 0; unsigned long long carry_b = 0;
+    for (uint32_t base = 0; base < n || base == 0; base += 16u * FQ_T) {
+        uint32_t mc[16], sc = 0; unsigned long long mb[16], sb = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const uint32_t at = threadIdx.x * 16 + i;
-        mc[i] = at < n ? wghdr[at] : 0u; mb[i] = at < n ? wgbytes[at] : 0ull; sc += mc[i]; sb += mb[i];
+        for (int i = 0; i < 16; i++) {
+            const uint32_t at = base + threadIdx.x * 16 + i;
+            mc[i] = at < n ? wghdr[at] : 0u; mb[i] = at < n ? wgbytes[at] : 0ull; sc += mc[i]; sb += mb[i];
+        }
+        uint32_t tc; unsigned long long tb;
+        uint32_t rcn = carry_c + wg_excl_u32(sc, lds, tc);
+        unsigned long long rbn = carry_b + wg_excl_u64(sb, ldb, tb);
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const uint32_t at = base + threadIdx.x * 16 + i; if (at < n) { wghdr[at] = rcn; wgbytes[at] = rbn; } rcn += mc[i]; rbn += mb[i]; }
+        carry_c += tc; carry_b += tb;
     }
-    uint32_t tc; unsigned long long tb;
-    uint32_t rcn = wg_excl_u32(sc, lds, tc);
-    unsigned long long rbn = wg_excl_u64(sb, ldb, tb);
-#pragma unroll
-    for (int i = 0; i < 16; i++) { const uint32_t at = threadIdx.x * 16 + i; if (at < n) { wghdr[at] = rcn; wgbytes[at] = rbn; } rcn += mc[i]; rbn += mb[i]; }
     if (threadIdx.x == 0) {
-        st->n_hdr = tc;
-        st->seq_bytes = tb;
+        st->n_hdr = carry_c;
+        st->seq_bytes = carry_b;
         const uint32_t NL = st->n_lines;
         st->tail_start = NL ? line_end[NL - 1] + 1u : st->start;
         st->tail_len = st->end - st->tail_start;
@@ -404,19 +417,20 @@ __global__ __launch_bounds__(FQ_T) void k_fa_emit(const FaState *st, const uint3
                                                   uint64_t *__restrict__ rec_off, uint64_t out_base) {
     __shared__ uint32_t lds[FQ_T / 64 + 1]; __shared__ unsigned long long ldb[FQ_T / 64 + 1];
     const uint32_t ev = fa_live_lines(st);
-    if (blockIdx.x * FQ_T >= ev) return;
-    const uint32_t i = blockIdx.x * FQ_T + threadIdx.x;
-    uint32_t c = 0, L = 0;
-    if (i < ev) {
-        const uint32_t info = linfo[i];
-        if ((info >> 24) == '>') c = 1; else L = info & 0xffffffu;
-    }
-    uint32_t tc; unsigned long long tb;
-    const uint32_t hidx = wghdr[blockIdx.x] + wg_excl_u32(c, lds, tc);
-    const unsigned long long at = wgbytes[blockIdx.x] + wg_excl_u64((unsigned long long)L, ldb, tb);
-    if (i < ev) {
-        if (c) { rec_off[hidx] = out_base + at; ldst[i] = FA_NONE; }
-        else ldst[i] = (uint32_t)at;                                // (a block's sequence bytes are fewer than its raw bytes: 32 bits)
+    for (uint32_t blk = blockIdx.x; blk * FQ_T < ev; blk += gridDim.x) {
+        const uint32_t i = blk * FQ_T + threadIdx.x;
+        uint32_t c = 0, L = 0;
+        if (i < ev) {
+            const uint32_t info = linfo[i];
+            if ((info >> 24) == '>') c = 1; else L = info & 0xffffffu;
+        }
+        uint32_t tc; unsigned long long tb;
+        const uint32_t hidx = wghdr[blk] + wg_excl_u32(c, lds, tc);
+        const unsigned long long at = wgbytes[blk] + wg_excl_u64((unsigned long long)L, ldb, tb);
+        if (i < ev) {
+            if (c) { rec_off[hidx] = out_base + at; ldst[i] = FA_NONE; }
+            else ldst[i] = (uint32_t)at;                            // (a block's sequence bytes are fewer than its raw bytes: 32 bits)
+        }
     }
 }
 
@@ -425,18 +439,30 @@ __global__ __launch_bounds__(256) void k_fa_copy(const uint8_t *__restrict__ raw
                                                  const uint32_t *__restrict__ ldst, uint8_t *__restrict__ out) {
     const uint32_t ev = fa_live_lines(st);
     const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
-    // 64 consecutive lines per wave and round: every lane fetches one line's (source, destination, length), the wave copies them in turn
-    for (uint32_t r0 = wave * 64u; r0 < ev; r0 += nw * 64u) {
-        const uint32_t r = r0 + lane;
+    // 8 consecutive lines per wave and round: lanes 0..7 fetch a line's (source, destination, length) each; the first 128 bytes of all
+    // eight are loaded before any is stored (a line is 60-80 bytes: one dependent round trip per round, not per line), what is left
+    // of a longer line follows 64 bytes at a time
+    constexpr uint32_t R = 8;
+    for (uint32_t r0 = wave * R; r0 < ev; r0 += nw * R) {
+        const uint32_t r = r0 + (lane & (R - 1));
         uint32_t src = 0, dst = FA_NONE, L = 0;
         if (r < ev) { dst = ldst[r]; L = linfo[r] & 0xffffffu; src = r ? line_end[r - 1] + 1u : st->start; }
-        const uint32_t cnt = ev - r0 < 64u ? ev - r0 : 64u;
-        for (uint32_t x = 0; x < cnt; x++) {
-            const uint32_t d = (uint32_t)__shfl((int)dst, (int)x);
-            if (d == FA_NONE) continue;
-            const uint32_t s_ = (uint32_t)__shfl((int)src, (int)x), n = (uint32_t)__shfl((int)L, (int)x);
-            for (uint32_t y = lane; y < n; y += 64u) out[(size_t)d + y] = raw[s_ + y];
+        if (dst == FA_NONE) L = 0;                                  // (a header line, or no line)
+        uint8_t v0[R], v1[R]; uint32_t s_[R], d_[R], n_[R];
+#pragma unroll
+        for (uint32_t x = 0; x < R; x++) {
+            s_[x] = (uint32_t)__shfl((int)src, (int)x); d_[x] = (uint32_t)__shfl((int)dst, (int)x); n_[x] = (uint32_t)__shfl((int)L, (int)x);
+            v0[x] = lane < n_[x] ? raw[s_[x] + lane] : (uint8_t)0;
+            v1[x] = lane + 64u < n_[x] ? raw[s_[x] + lane + 64u] : (uint8_t)0;
         }
+#pragma unroll
+        for (uint32_t x = 0; x < R; x++) {
+            if (lane < n_[x]) out[(size_t)d_[x] + lane] = v0[x];
+            if (lane + 64u < n_[x]) out[(size_t)d_[x] + lane + 64u] = v1[x];
+        }
+#pragma unroll
+        for (uint32_t x = 0; x < R; x++)
+            for (uint32_t y = 128u + lane; y < n_[x]; y += 64u) out[(size_t)d_[x] + y] = raw[s_[x] + y];
     }
 }
 
@@ -480,18 +506,51 @@ hipError_t launch_fa_parse(hipStream_t s, const FaBuffers &B, const uint8_t *pre
     const uint32_t span = B.porch + len + 16u;
     const uint32_t nchunks = (span + FQ_CHUNK - 1) / FQ_CHUNK;
     const uint32_t nlwg = (B.line_cap + FQ_T - 1) / FQ_T;
-    if (nchunks > 8 * FQ_T || nlwg > 16 * FQ_T) return hipErrorInvalidValue;
+    if (nchunks > 8 * FQ_T) return hipErrorInvalidValue;
+#ifdef HULK_EXPERIMENTS
+    // HULK_FA_TIME=n: every kernel of the chain alone (the stream is synchronised around it), microseconds summed per kernel and
+    // printed every n blocks
+    static const int every = getenv("HULK_FA_TIME") ? atoi(getenv("HULK_FA_TIME")) : 0;
+    static const bool timing = every > 0;
+    static double acc_us[10]; static int nblk = 0; int ki = 0;
+#define FA_T(name) do { if (timing) { hipStreamSynchronize(s); const double t1_ = now_us(); acc_us[ki++] += t1_ - t0_; t0_ = t1_; } } while (0)
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    if (timing) hipStreamSynchronize(s);
+    double t0_ = now_us();
+#else
+#define FA_T(name) do { } while (0)
+#endif
     hipLaunchKernelGGL(k_fa_begin, dim3(64), dim3(256), 0, s, prev_raw, prev_state, raw, state, B.porch, len);
+    FA_T("k_fa_begin");
     hipLaunchKernelGGL(k_fq_count<FaState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt);
+    FA_T("k_fq_count");
     hipLaunchKernelGGL(k_fq_scan_u32<FaState>, dim3(1), dim3(FQ_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
+    FA_T("k_fq_scan_u32");
     hipLaunchKernelGGL(k_fq_lines<FaState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
-    // (a block of 60-byte lines has 1/30 of line_cap: the workgroups behind the last line leave at once)
-    hipLaunchKernelGGL(k_fa_class, dim3(nlwg), dim3(FQ_T), 0, s, raw, state, B.line_end, B.linfo);
-    hipLaunchKernelGGL(k_fa_flags, dim3(nlwg), dim3(FQ_T), 0, s, state, B.linfo, B.wghdr, B.wgbytes);
+    FA_T("k_fq_lines");
+    // a block of 60-byte lines has 1/30 of line_cap: the grids are sized for lines of 16 bytes, the kernels take more trips over shorter ones
+    const uint32_t glw = std::min<uint32_t>(nlwg, (span / 16u + FQ_T - 1) / FQ_T + 1u);
+    hipLaunchKernelGGL(k_fa_class, dim3(glw), dim3(FQ_T), 0, s, raw, state, B.line_end, B.linfo);
+    FA_T("k_fa_class");
+    hipLaunchKernelGGL(k_fa_flags, dim3(glw), dim3(FQ_T), 0, s, state, B.linfo, B.wghdr, B.wgbytes);
+    FA_T("k_fa_flags");
     hipLaunchKernelGGL(k_fa_scan, dim3(1), dim3(FQ_T), 0, s, B.wghdr, B.wgbytes, nlwg, state, B.line_end);
-    hipLaunchKernelGGL(k_fa_emit, dim3(nlwg), dim3(FQ_T), 0, s, state, B.linfo, B.wghdr, B.wgbytes, B.ldst, rec_off, out_base);
+    FA_T("k_fa_scan");
+    hipLaunchKernelGGL(k_fa_emit, dim3(glw), dim3(FQ_T), 0, s, state, B.linfo, B.wghdr, B.wgbytes, B.ldst, rec_off, out_base);
+    FA_T("k_fa_emit");
     hipLaunchKernelGGL(k_fa_copy, dim3(2048), dim3(256), 0, s, raw, state, B.line_end, B.linfo, B.ldst, acc + out_base);
+    FA_T("k_fa_copy");
     hipLaunchKernelGGL(k_fa_lens, dim3(64), dim3(256), 0, s, state, rec_off);
+    FA_T("k_fa_lens");
+#ifdef HULK_EXPERIMENTS
+    if (timing && ++nblk % every == 0) {
+        static const char *names[10] = {"k_fa_begin", "k_fq_count", "k_fq_scan_u32", "k_fq_lines", "k_fa_class", "k_fa_flags", "k_fa_scan", "k_fa_emit", "k_fa_copy", "k_fa_lens"};
+        fprintf(stderr, "fasta parse kernels, us per block over %d blocks:", nblk);
+        for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.0f", names[i], acc_us[i] / nblk);
+        fprintf(stderr, "\n");
+    }
+#endif
+#undef FA_T
     return hipGetLastError();
 }
 

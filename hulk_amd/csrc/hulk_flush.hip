@@ -98,10 +98,17 @@ bool pick_config(uint32_t k, uint32_t max_len, MinimizerParams &P, int &threads)
 
 // sequences with more than GENERIC_XCAP_MAX k-mer positions: grouped launches of the long-sequence kernels
 int bin_long_reads(hulk_ctx *c, hipStream_t s, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n, MinimizerParams P,
-                   uint32_t *hist) {
-    std::vector<uint64_t> off(n + 1);
-    HIPCHK(c, hipMemcpyAsync(off.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+                   uint32_t *hist, const uint64_t *h_offsets) {
+    // the lengths: from the caller's host copy of the offsets when there is one (ctx_hint_host_offsets), else fetched from the
+    // device — which waits for everything queued on the lane before
+    std::vector<uint64_t> fetched;
+    const uint64_t *off = h_offsets;
+    if (!off) {
+        fetched.resize(n + 1);
+        HIPCHK(c, hipMemcpyAsync(fetched.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        off = fetched.data();
+    }
     // groups of long sequences, one launch set per group: bounded scratch (positions) and grid.y
     constexpr uint64_t GROUP_POS = 128ull << 20;        // positions per group (8 B + 1 B scratch, <= 16 B of table each)
     constexpr uint32_t GROUP_SEQS = 32768;
@@ -129,13 +136,25 @@ int bin_long_reads(hulk_ctx *c, hipStream_t s, const uint8_t *d_bases, const uin
             HIPCHK(c, hipMalloc((void **)&c->d_long_desc, (descs.size() + 1024) * sizeof(hulk::LongSeqDesc)));
             c->long_desc_cap = descs.size() + 1024;
         }
-        // pageable source: the copy is staged before the call returns, descs may be reused afterwards
-        HIPCHK(c, hipMemcpyAsync(c->d_long_desc, descs.data(), descs.size() * sizeof(hulk::LongSeqDesc),
-                                 hipMemcpyHostToDevice, s));
+        // through one of two pinned staging buffers (the copy runs when the lane gets there: the source has to stay as it is)
+        hulk_ctx::LongDescStage &H = c->h_long_desc[c->long_desc_turn];
+        c->long_desc_turn ^= 1;
+        if (H.used) HIPCHK(c, hipEventSynchronize(H.ev));          // the copy out of it, two groups ago
+        const size_t dbytes = descs.size() * sizeof(hulk::LongSeqDesc);
+        if (dbytes > H.cap) {
+            if (H.p) HIPCHK(c, hipHostFree(H.p));
+            H.p = nullptr; H.cap = 0;
+            HIPCHK(c, hipHostMalloc(&H.p, dbytes + 1024 * sizeof(hulk::LongSeqDesc), hipHostMallocDefault));
+            H.cap = dbytes + 1024 * sizeof(hulk::LongSeqDesc);
+        }
+        if (!H.ev) HIPCHK(c, hipEventCreateWithFlags(&H.ev, hipEventDisableTiming));
+        memcpy(H.p, descs.data(), dbytes);
+        HIPCHK(c, hipMemcpyAsync(c->d_long_desc, H.p, dbytes, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipEventRecord(H.ev, s));
+        H.used = true;
         HIPCHK(c, launch_long_group(s, d_bases, (const hulk::LongSeqDesc *)c->d_long_desc, (uint32_t)descs.size(),
                                     max_npos, P, c->d_long_xs, c->d_long_valid, c->d_long_table, tab_total, hist,
                                     c->d_min_slots));
-        HIPCHK(c, hipStreamSynchronize(s));      // descs.data() is pageable memory: keep it simple and ordered
         descs.clear(); pos_total = tab_total = max_npos = 0;
         return HULK_OK;
     };
@@ -364,7 +383,7 @@ int bin_reads(hulk_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, ui
             P.skip_long = fits ? 0u : 1u;
             HIPCHK(c, launch_minimizer_bin(s, d_bases, d_offsets, n, P, threads, hist, c->d_state,
                                            c->d_min_slots, nullptr, nullptr, 0));
-            if (!fits) rc = bin_long_reads(c, s, d_bases, d_offsets, n, P, hist);
+            if (!fits) rc = bin_long_reads(c, s, d_bases, d_offsets, n, P, hist, c->h_off_chunk);
         }
     }
     if (rc != HULK_OK) return rc;
@@ -572,6 +591,7 @@ int ctx_stage_acquire(hulk_ctx *c, size_t nbytes, uint64_t n, StageSet *out) {
     return HULK_OK;
 }
 int ctx_device(const hulk_ctx *c) { return c->p.device; }
+void ctx_hint_host_offsets(hulk_ctx *c, const uint64_t *h_offsets) { c->h_off_hint = h_offsets; }
 int ctx_wait_event(hulk_ctx *c, hipEvent_t e) {
     HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
     c->copies_pending = true;                                   // (lane 1 is told through the fork in front of its next batch)

@@ -1340,6 +1340,7 @@ struct GpuSink : Sink {
         ING_HIP(hipMemcpyAsync(st.d_bases, st.h_bases, tot, hipMemcpyHostToDevice, stream));
         ING_HIP(hipMemcpyAsync(st.d_off, st.h_off, (n + 1) * 8, hipMemcpyHostToDevice, stream));
         const double tc1 = PhaseTrace::now(); g_trace.enqueue += tc1 - tc0;
+        hulk::ctx_hint_host_offsets(ctx, st.h_off);               // (long sequences: their lengths are read here, not fetched back)
         int rc = hulk_add_reads_device(ctx, st.d_bases, st.d_off, n, (uint32_t)mx, st.cap_bases);
         g_trace.add_reads += PhaseTrace::now() - tc1;
         if (rc != HULK_OK) return err.set(rc, hulk_last_error(ctx));
@@ -1780,7 +1781,12 @@ static FqDev *fq_dev_for(hulk_ctx *ctx, size_t block, IngestError &err) {
 #define FQ_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err.set(HULK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); FqDev::destroy(d); return nullptr; } } while (0)
     FQ_HIP(hipSetDevice(d->device));
     FQ_HIP(hipStreamCreateWithFlags(&d->cs, hipStreamNonBlocking));
-    FQ_HIP(hipStreamCreateWithFlags(&d->ps, hipStreamNonBlocking));
+    {   // the parse kernels are short and the calling thread waits for their scalars block by block, while the context's lanes keep
+        // the chip full with binning kernels: their workgroups go first when CUs come free
+        int lo = 0, hi = 0;
+        FQ_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        FQ_HIP(hipStreamCreateWithPriority(&d->ps, hipStreamNonBlocking, hi));
+    }
     hulk::FqBuffers &B = d->B;
     B.porch = d->porch;
     B.line_cap = (uint32_t)((d->porch + block) / 8 + 1024);
@@ -2090,6 +2096,7 @@ int run_ingest_fasta_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_
     uint64_t bmin = ~0ull, bmax = 0;             // over the complete records not handed over yet
     uint64_t n_lines = 0, dev_seqs = 0, bytes_done = 0;
     hipEvent_t last_parsed = nullptr;
+    std::vector<uint64_t> h_rec;
     // a buffer is written from acc_len on; what the context still reads of it (records handed over by the run before) lies below —
     // except in a buffer taken over EMPTY: wait for its readers first
     auto wait_readers = [&](int b) -> bool {
@@ -2127,6 +2134,11 @@ int run_ingest_fasta_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_
             if (bmin < min_len) return err.set(HULK_ERR_SHORT_SEQ, hulk_strerror(HULK_ERR_SHORT_SEQ));
             if (bmax > 0xffffffffull) return err.set(HULK_ERR_READ_TOO_LONG, hulk_strerror(HULK_ERR_READ_TOO_LONG));
             const double tc1 = PhaseTrace::now();
+            // the records' offsets, for the long-sequence path's descriptors (the parse stream has passed them: no waiting for the binning)
+            h_rec.resize(n + 1);
+            if (hipMemcpyAsync(h_rec.data(), F.rec_off[cur], (n + 1) * 8, hipMemcpyDeviceToHost, D->ps) != hipSuccess || hipStreamSynchronize(D->ps) != hipSuccess)
+                return err.set(HULK_ERR_HIP, "hipMemcpyAsync (FASTA record offsets)");
+            hulk::ctx_hint_host_offsets(ctx, h_rec.data());
             int rc = last_parsed ? hulk::ctx_wait_event(ctx, last_parsed) : HULK_OK;
             if (rc == HULK_OK) rc = hulk_add_reads_device(ctx, F.acc[cur], F.rec_off[cur], n, (uint32_t)bmax, F.acc_cap[cur] + 64);
             if (rc == HULK_OK) rc = hulk::ctx_record_busy(ctx, F.ev_busy[cur][0], F.ev_busy[cur][1], &F.busy1[cur]);

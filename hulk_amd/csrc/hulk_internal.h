@@ -211,5 +211,8 @@ int ctx_wait_event(hulk_ctx *c, hipEvent_t e);
 // record e0 on the context's stream and, if there is a second work lane, e1 on it: both passed = the kernels queued so far
 // have read their inputs.  *has1 says whether e1 was recorded.
 int ctx_record_busy(hulk_ctx *c, hipEvent_t e0, hipEvent_t e1, bool *has1);
+// offsets[0 .. n] of the NEXT hulk_add_reads_device as the caller holds them in host memory (read during that call only): the
+// long-sequence path then takes the lengths from there instead of fetching them from the device behind everything queued
+void ctx_hint_host_offsets(hulk_ctx *c, const uint64_t *h_offsets);
 
 }  // namespace hulk

@@ -213,10 +213,12 @@ int hulk_parse_files(const char *const *paths, uint32_t n_paths, int fasta, uint
 #define HULK_INGEST_GZ_ONE_THREAD 1u  /* every gzip input through the one-thread reader (no parallel member / BGZF readers) */
 #define HULK_INGEST_GZ_ZLIB 2u        /* zlib's inflate instead of the library's own decoder */
 #define HULK_INGEST_TRACE 4u          /* seconds per phase of the calling thread and of the gzip readers, on stderr */
-#define HULK_INGEST_HOST_PARSER 8u    /* hulk_sketch_files*: FASTQ lines -> reads on the host's parser threads.  Default: the raw file
-                                       * bytes go to the GPU as they are read and the line machine runs there (hulk_fastq.hip); a block
-                                       * the device will not decide — a header without '@', a line of 64 KiB, an over-long run of empty
-                                       * lines — hands the stream to the host parser, whose reads and messages are the same */
+#define HULK_INGEST_HOST_PARSER 8u    /* hulk_sketch_files*: lines -> sequences on the host's parser threads.  Default: the raw file
+                                       * bytes go to the GPU as they are read and the line machine runs there (hulk_fastq.hip).  FASTQ: a
+                                       * block the device will not decide — a header without '@', a line of 64 KiB, an over-long run of
+                                       * empty lines — hands the stream to the host parser, whose reads and messages are the same.
+                                       * --fasta: the device decides everything (the empty line that ends the parsing, the line of 64 KiB
+                                       * that is bufio.Scanner's error); sequences of any length accumulate in device memory across blocks */
 typedef struct hulk_ingest_opts {
     uint32_t parser_threads;  /* 0 = one per hardware thread, at most 16 (the measured optimum); any other figure is taken as it is (<= 256) */
     uint32_t gz_threads;      /* threads inflating the members of a bgzip'd input, or the chunks of ONE gzip member, side by side: 1..64, 0 = 16 */
@@ -349,7 +351,9 @@ int hulk_debug_read(hulk_ctx *ctx, uint32_t what, void *out, uint64_t *bytes_io)
 
 /* Process-level buffers the library keeps between calls — the device FASTQ parser's pinned and device blocks (hulk_sketch_files:
  * 64 MB pinned and about 250 MB of HBM per set at the default block size; at most two sets, and a set nobody borrowed for 10 s is
- * freed by the process's next hulk_create / hulk_destroy / hulk_sketch_files), the host parsers' large buffers (gzip, FASTA, the
+ * freed by the process's next hulk_create / hulk_destroy / hulk_sketch_files; a set that has parsed --fasta input also holds a
+ * line index for 2-byte lines and two accumulation buffers that grow with the longest sequence: about 0.7 GB of HBM more), the
+ * host parsers' large buffers (gzip, FASTA, the
  * host FASTQ parser: ordinary memory, at most 1 GiB, same 10 s rule) and hulk_smash's device arrays — are freed at once;
  * the next call that needs them allocates again.  Call it with no hulk_sketch_files / hulk_smash in flight on another thread. */
 int hulk_release_caches(void);

@@ -9,6 +9,7 @@ namespace hulk {
 int ctx_device(const hulk_ctx *) { return 0; }
 int ctx_wait_event(hulk_ctx *, hipEvent_t) { return -1; }
 int ctx_record_busy(hulk_ctx *, hipEvent_t, hipEvent_t, bool *) { return -1; }
+void ctx_hint_host_offsets(hulk_ctx *, const uint64_t *) {}
 hipError_t launch_fq_parse(hipStream_t, const FqBuffers &, const uint8_t *, const FqState *, uint8_t *, FqState *, uint32_t, uint64_t *, uint8_t *) { return hipErrorUnknown; }
 hipError_t launch_fa_parse(hipStream_t, const FaBuffers &, const uint8_t *, const FaState *, uint8_t *, FaState *, uint32_t, uint8_t *, uint64_t, uint64_t *) { return hipErrorUnknown; }
 hipStream_t ctx_stream(hulk_ctx *) { return nullptr; }
@@ -34,6 +35,8 @@ hipError_t hipMemset(void *, int, size_t) { return hipErrorUnknown; }
 hipError_t hipMemsetAsync(void *, int, size_t, hipStream_t) { return hipErrorUnknown; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *, unsigned) { return hipErrorUnknown; }
+hipError_t hipDeviceGetStreamPriorityRange(int *, int *) { return hipErrorUnknown; }
+hipError_t hipStreamCreateWithPriority(hipStream_t *, unsigned, int) { return hipErrorUnknown; }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
