@@ -267,6 +267,7 @@ void hulk_destroy(hulk_ctx *c) {
     if (c->ev_join) hipEventDestroy(c->ev_join);
     hipFree(c->d_long_xs); hipFree(c->d_long_valid); hipFree(c->d_long_table); hipFree(c->d_long_desc);
     for (auto &H : c->h_long_desc) { if (H.p) hipHostFree(H.p); if (H.ev) hipEventDestroy(H.ev); }
+    if (c->ev_long) hipEventDestroy(c->ev_long);
     comm_teardown(c);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;

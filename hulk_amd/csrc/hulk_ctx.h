@@ -131,6 +131,9 @@ struct hulk_ctx {
     // copy out of it (two groups ago) has run — the calling thread stays up to two groups ahead of the binning (bin_long_reads)
     struct LongDescStage { void *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; } h_long_desc[2];
     int long_desc_turn = 0;
+    // the descriptors and the set tables on the device are ONE set per context: a group queued on one work lane waits for the group
+    // queued before it on the other (the kernels of a group fill the chip: nothing is lost)
+    hipEvent_t ev_long = nullptr; hipStream_t long_last_stream = nullptr; bool long_pending = false;
     // A caller that holds the batch's offsets in host memory says so (ctx_hint_host_offsets): the long-sequence path then reads the
     // lengths there instead of fetching them from the device behind everything queued on the lane.  Valid for the next
     // hulk_add_reads_device only; h_off_chunk is that call's current piece.

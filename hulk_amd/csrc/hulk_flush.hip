@@ -119,6 +119,7 @@ int bin_long_reads(hulk_ctx *c, hipStream_t s, const uint8_t *d_bases, const uin
         static const bool two_pass = HULK_EXP_ENV("HULK_LONG_TWO_PASS") != nullptr;      // the round-1..5 form as comparator (9 B of scratch per position)
         if (two_pass && pos_total > c->long_cap) {
             HIPCHK(c, hipStreamSynchronize(s));
+            if (c->long_pending) HIPCHK(c, hipEventSynchronize(c->ev_long));
             hipFree(c->d_long_xs); hipFree(c->d_long_valid); c->d_long_xs = nullptr; c->d_long_valid = nullptr; c->long_cap = 0;
             HIPCHK(c, hipMalloc((void **)&c->d_long_xs, pos_total * 8));
             HIPCHK(c, hipMalloc((void **)&c->d_long_valid, pos_total));
@@ -126,16 +127,20 @@ int bin_long_reads(hulk_ctx *c, hipStream_t s, const uint8_t *d_bases, const uin
         }
         if (tab_total > c->long_table_cap) {
             HIPCHK(c, hipStreamSynchronize(s));
+            if (c->long_pending) HIPCHK(c, hipEventSynchronize(c->ev_long));
             hipFree(c->d_long_table); c->d_long_table = nullptr; c->long_table_cap = 0;
             HIPCHK(c, hipMalloc((void **)&c->d_long_table, tab_total * 8));
             c->long_table_cap = tab_total;
         }
         if (descs.size() > c->long_desc_cap) {
             HIPCHK(c, hipStreamSynchronize(s));
+            if (c->long_pending) HIPCHK(c, hipEventSynchronize(c->ev_long));
             hipFree(c->d_long_desc); c->d_long_desc = nullptr; c->long_desc_cap = 0;
             HIPCHK(c, hipMalloc((void **)&c->d_long_desc, (descs.size() + 1024) * sizeof(hulk::LongSeqDesc)));
             c->long_desc_cap = descs.size() + 1024;
         }
+        if (c->long_pending && c->long_last_stream != s && !HULK_EXP_ENV("HULK_LONG_NO_LANE_ORDER"))          // (the switch: to show that the test for it fails)
+            HIPCHK(c, hipStreamWaitEvent(s, c->ev_long, 0));                                                   // the other lane's group: same scratch
         // through one of two pinned staging buffers (the copy runs when the lane gets there: the source has to stay as it is)
         hulk_ctx::LongDescStage &H = c->h_long_desc[c->long_desc_turn];
         c->long_desc_turn ^= 1;
@@ -155,6 +160,9 @@ int bin_long_reads(hulk_ctx *c, hipStream_t s, const uint8_t *d_bases, const uin
         HIPCHK(c, launch_long_group(s, d_bases, (const hulk::LongSeqDesc *)c->d_long_desc, (uint32_t)descs.size(),
                                     max_npos, P, c->d_long_xs, c->d_long_valid, c->d_long_table, tab_total, hist,
                                     c->d_min_slots));
+        if (!c->ev_long) HIPCHK(c, hipEventCreateWithFlags(&c->ev_long, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_long, s));
+        c->long_last_stream = s; c->long_pending = true;
         descs.clear(); pos_total = tab_total = max_npos = 0;
         return HULK_OK;
     };

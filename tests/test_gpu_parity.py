@@ -1015,3 +1015,24 @@ def test_profile_table_times_every_launch_of_a_one_stream_context():
     assert tbl["k_cms_freq"][0] == tbl["k_flush_decide"][0] == 3                      # one flush per batch of 4 intervals
     assert "-" not in tbl and 0 < sum(v[1] for v in tbl.values()) < wall_ms
     assert out[0][2] == {}
+
+
+def test_long_sequences_on_two_work_lanes_share_one_scratch_in_order():
+    """The long-sequence path returns with its kernels queued (round 6; it used to wait for them), and consecutive batches run on
+    alternating work lanes — while the descriptors and the per-sequence set tables on the device are one set per context.  A group
+    queued on one lane must wait for the group queued before it on the other (tools/fuzz_parity.py found the race: seed 7, case 3).
+    Many intervals of one batch each, every read long: sketch and minimizer count against the oracle.  (With the ordering switched
+    off — HULK_LONG_NO_LANE_ORDER, profiling build — this test fails.)"""
+    rng = np.random.default_rng(99)
+    k, w, S, I = 15, 5, 32, 16
+    seqs = random_reads(rng, 400, (20_000, 40_000), b"ACGTN")      # a group of 16 such reads keeps the chip busy for ~100 us
+    o = pyorc.Sketcher(k, w, S, 0, 0.02, I)
+    g = gpu().GpuSketcher(k, w, S, I, 0.02, 0, batch=1, work_lanes=2)
+    bases, offsets = pack_reads(seqs)
+    o.add_reads(bases, offsets)
+    for a in range(0, len(seqs), 80):                              # several calls: batches keep alternating lanes across them
+        g.add_reads(bases, offsets[a:min(a + 80, len(seqs)) + 1])
+    o.finish(); g.finish()
+    assert_same_sketch(o, g)
+    assert o.counters()["n_minimizers"] == g.counters()["n_minimizers"]
+    g.close(); o.close()
