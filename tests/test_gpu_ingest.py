@@ -245,3 +245,16 @@ def test_device_fasta_parser_batches_and_many_records(tmp_path):
     dev = _fa_run([q], 0)
     host = _fa_run([q], HOST)
     assert dev[0] == (m, m * 20, 2 * m) and _same(dev, host), (dev[0], host[0])
+    # (c) one sequence longer than an accumulation buffer (192 MB): the buffer grows under the record in progress; a short one behind it
+    r = str(tmp_path / "chromosome.fa")
+    Lc = 230_000_000
+    seq = synth.reads_numpy(4242, 1, Lc)[0][:Lc]
+    rows = Lc // 100
+    body = np.full((rows, 101), ord("\n"), dtype=np.uint8)
+    body[:, :100] = seq.reshape(rows, 100)
+    with open(r, "wb") as fh:
+        fh.write(b">chr1\n"); fh.write(body.tobytes()); fh.write(b">tail\n" + b"ACGT" * 25 + b"\n")
+    del body, seq
+    dev = _fa_run([r], 0, k=21, w=9, S=64, block=0)
+    host = _fa_run([r], HOST, k=21, w=9, S=64, block=0)
+    assert dev[0] == (2, Lc + 100, rows + 3) and _same(dev, host), (dev[0], host[0])
