@@ -61,20 +61,26 @@ struct FaState {
     uint32_t n_hdr;          // '>' lines in front of the first of those two
     uint32_t tail_start, tail_len;   // the unterminated line at the block's end: the next block parses it again
     uint32_t min_len, max_len;       // over the records that begin AND end at a header of this block (n_hdr - 1 of them)
-    unsigned long long seq_bytes;    // sequence bytes appended by this block
-    unsigned long long first_hdr, last_hdr;   // positions in the accumulation buffer the block's first / last header stood at
+    uint32_t first_hdr, last_hdr;    // sequence bytes of the block in front of its first / its last header
+    unsigned long long seq_bytes;    // sequence bytes of the block (in front of the first event)
 };
+// One set of index arrays per block in flight (two: a block is indexed while the one before it is placed).
 struct FaBuffers {
     uint32_t porch = 0;
     // Lines the index holds: (64 KiB + block) / 2 + 2.  A non-empty line takes two bytes at least, so a block with more lines
     // than that has an empty one among the first line_cap — where the parsing ends anyway: clamping the index loses nothing.
     uint32_t line_cap = 0;
-    uint32_t *wgcnt = nullptr, *line_end = nullptr, *linfo = nullptr, *ldst = nullptr, *wghdr = nullptr;
+    uint32_t *wgcnt = nullptr, *line_end = nullptr, *linfo = nullptr, *ldst = nullptr, *wghdr = nullptr, *hrel = nullptr;
     unsigned long long *wgbytes = nullptr;
 };
-// Parse raw[porch - tail .. porch + len) on stream s.  Sequence bytes go to acc + out_base .., the positions of header lines
-// to rec_off[0 .. n_hdr) (the caller guarantees room for line_cap entries); scalars to *state.
-hipError_t launch_fa_parse(hipStream_t s, const FaBuffers &B, const uint8_t *prev_raw, const FaState *prev_state, uint8_t *raw,
-                           FaState *state, uint32_t len, uint8_t *acc, uint64_t out_base, uint64_t *rec_off);
+// A block in two steps, both on stream s.
+//   index : raw[porch - tail .. porch + len) -> the line index, every sequence line's place in the block's own sequence bytes
+//           (ldst), every header's (hrel), the block's scalars (*state).  Needs nothing from the blocks before but the tail.
+//   place : the sequence lines to acc + out_base .., the headers' positions (out_base + hrel) to rec_off[0 .. n_hdr) — queued
+//           once the host knows where the blocks before left the accumulation buffer (their scalars).
+hipError_t launch_fa_index(hipStream_t s, const FaBuffers &B, const uint8_t *prev_raw, const FaState *prev_state, uint8_t *raw,
+                           FaState *state, uint32_t len);
+hipError_t launch_fa_place(hipStream_t s, const FaBuffers &B, const uint8_t *raw, const FaState *state, uint8_t *acc, uint64_t out_base,
+                           uint64_t *rec_off);
 
 }  // namespace hulk

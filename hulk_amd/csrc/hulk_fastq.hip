@@ -23,9 +23,6 @@
 #include "hulk_fastq.h"
 
 #include <algorithm>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
 
 #include "hulk_device.h"
 
@@ -60,21 +57,23 @@ __device__ __forceinline__ uint32_t newline_mask(const uint8_t *raw, uint32_t ad
 constexpr int FQ_T = 1024;                     // threads per workgroup of the index kernels
 constexpr uint32_t FQ_CHUNK = FQ_T * 16;       // bytes per workgroup
 
-// workgroup-wide exclusive prefix sum of one uint32 per thread (FQ_T threads); returns the workgroup total through `total`
-__device__ __forceinline__ uint32_t wg_excl_u32(uint32_t v, uint32_t *lds /* [FQ_T / 64 + 1] */, uint32_t &total) {
+// workgroup-wide exclusive prefix sum of one uint32 per thread (T threads); returns the workgroup total through `total`
+template <int T = FQ_T>
+__device__ __forceinline__ uint32_t wg_excl_u32(uint32_t v, uint32_t *lds /* [T / 64 + 1] */, uint32_t &total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
     if (lane == 63) lds[wid] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < FQ_T / 64; i++) { const uint32_t t = lds[i]; lds[i] = run; run += t; } lds[FQ_T / 64] = run; }
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < T / 64; i++) { const uint32_t t = lds[i]; lds[i] = run; run += t; } lds[T / 64] = run; }
     __syncthreads();
-    total = lds[FQ_T / 64];
+    total = lds[T / 64];
     const uint32_t r = lds[wid] + incl - v;
     __syncthreads();
     return r;
 }
+template <int T = FQ_T>
 __device__ __forceinline__ unsigned long long wg_excl_u64(unsigned long long v, unsigned long long *lds, unsigned long long &total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     unsigned long long incl = v;
@@ -82,9 +81,9 @@ __device__ __forceinline__ unsigned long long wg_excl_u64(unsigned long long v, 
     for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(incl, d); if (lane >= d) incl += o; }
     if (lane == 63) lds[wid] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) { unsigned long long run = 0; for (int i = 0; i < FQ_T / 64; i++) { const unsigned long long t = lds[i]; lds[i] = run; run += t; } lds[FQ_T / 64] = run; }
+    if (threadIdx.x == 0) { unsigned long long run = 0; for (int i = 0; i < T / 64; i++) { const unsigned long long t = lds[i]; lds[i] = run; run += t; } lds[T / 64] = run; }
     __syncthreads();
-    total = lds[FQ_T / 64];
+    total = lds[T / 64];
     const unsigned long long r = lds[wid] + incl - v;
     __syncthreads();
     return r;
@@ -126,8 +125,7 @@ __global__ __launch_bounds__(256) void k_fq_tail_in(const uint8_t *__restrict__ 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tl; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-template <class ST>
-__global__ __launch_bounds__(FQ_T) void k_fq_count(const uint8_t *__restrict__ raw, const ST *__restrict__ st,
+__global__ __launch_bounds__(FQ_T) void k_fq_count(const uint8_t *__restrict__ raw, const FqState *__restrict__ st,
                                                    uint32_t *__restrict__ wgcnt) {
     __shared__ uint32_t red[FQ_T / 64];
     const uint32_t lo = st->start, hi = st->end, a0 = lo & ~15u;
@@ -141,8 +139,7 @@ __global__ __launch_bounds__(FQ_T) void k_fq_count(const uint8_t *__restrict__ r
 }
 
 // exclusive scan of n <= 8 * FQ_T workgroup counts in place; the total goes to *total_out (clamped to cap -> need_host)
-template <class ST>
-__global__ __launch_bounds__(FQ_T) void k_fq_scan_u32(uint32_t *__restrict__ v, uint32_t n, ST *st, uint32_t cap) {
+__global__ __launch_bounds__(FQ_T) void k_fq_scan_u32(uint32_t *__restrict__ v, uint32_t n, FqState *st, uint32_t cap) {
     __shared__ uint32_t lds[FQ_T / 64 + 1];
     uint32_t mine[8], sum = 0;
 #pragma unroll
@@ -157,8 +154,7 @@ __global__ __launch_bounds__(FQ_T) void k_fq_scan_u32(uint32_t *__restrict__ v, 
     }
 }
 
-template <class ST>
-__global__ __launch_bounds__(FQ_T) void k_fq_lines(const uint8_t *__restrict__ raw, const ST *__restrict__ st,
+__global__ __launch_bounds__(FQ_T) void k_fq_lines(const uint8_t *__restrict__ raw, const FqState *__restrict__ st,
                                                    const uint32_t *__restrict__ wgbase, uint32_t *__restrict__ line_end, uint32_t cap) {
     __shared__ uint32_t lds[FQ_T / 64 + 1];
     const uint32_t lo = st->start, hi = st->end, a0 = lo & ~15u;
@@ -310,12 +306,16 @@ __global__ __launch_bounds__(256) void k_fq_copy(const uint8_t *__restrict__ raw
 
 
 // ------------------------------------------------------------------------------------------
-// FASTA (hulk_fastq.h).  The newline index is the FASTQ parser's (k_fq_count / k_fq_scan_u32 / k_fq_lines); then
+// FASTA (hulk_fastq.h).  A block in two steps — index (everything that depends on the block's own bytes only) and place (the
+// copy into the accumulation buffer, once the host knows where the blocks before left it):
+//   k_fa_count / k_fa_scan_lines / k_fa_lines    the newline index, as the FASTQ parser's, in 256-thread workgroups
 //   k_fa_class   per line: length (CR dropped), first byte; the first empty line and the first line of 64 KiB or more (atomicMin)
 //   k_fa_flags / k_fa_scan    header lines and sequence bytes in front of the first of those, per workgroup -> prefix sums
-//   k_fa_emit    a sequence line's destination (bytes from the block's first sequence byte), a header's position -> rec_off
-//   k_fa_copy    the sequence lines to the end of the accumulation buffer, a wave per line
+//   k_fa_emit    a sequence line's destination and a header's position, both in bytes from the block's first sequence byte
 //   k_fa_lens    shortest / longest record between two headers of the block, the block's first / last header position
+//   -- place --
+//   k_fa_copy    the sequence lines to the end of the accumulation buffer, 8 lines per wave and round
+//   k_fa_recs    the headers' positions in the accumulation buffer -> the record offsets
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fa_begin(const uint8_t *__restrict__ prev_raw, const FaState *__restrict__ prev,
                                                   uint8_t *__restrict__ raw, FaState *st, uint32_t porch, uint32_t len) {
@@ -336,11 +336,65 @@ __global__ __launch_bounds__(256) void k_fa_begin(const uint8_t *__restrict__ pr
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tl; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-__global__ __launch_bounds__(FQ_T) void k_fa_class(const uint8_t *__restrict__ raw, FaState *st, const uint32_t *__restrict__ line_end,
+
+// The FASTA chain runs beside the context's binning kernels (k_long_tile fills every CU with 256-thread workgroups and leaves a few
+// wave slots free): its kernels use 256-thread workgroups, which find room at once — a 1024-thread workgroup waits until half a CU
+// happens to be free (measured: the one-workgroup scans went from 15 to 200 us).
+constexpr int FA_T = 256;
+constexpr uint32_t FA_CHUNK = FA_T * 16;
+
+__global__ __launch_bounds__(FA_T) void k_fa_count(const uint8_t *__restrict__ raw, const FaState *__restrict__ st, uint32_t *__restrict__ wgcnt) {
+    __shared__ uint32_t red[FA_T / 64];
+    const uint32_t lo = st->start, hi = st->end, a0 = lo & ~15u;
+    const uint32_t addr = a0 + blockIdx.x * FA_CHUNK + threadIdx.x * 16u;
+    if (a0 + blockIdx.x * FA_CHUNK >= hi) { if (threadIdx.x == 0) wgcnt[blockIdx.x] = 0; return; }
+    uint32_t c = (uint32_t)__popc(newline_mask(raw, addr, lo, hi));
+    for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int i = 0; i < FA_T / 64; i++) t += red[i]; wgcnt[blockIdx.x] = t; }
+}
+// exclusive scan of the n chunk counts in place (16 * FA_T per trip); the total -> n_lines (clamped to cap)
+__global__ __launch_bounds__(FA_T) void k_fa_scan_lines(uint32_t *__restrict__ v, uint32_t n, FaState *st, uint32_t cap) {
+    __shared__ uint32_t lds[FA_T / 64 + 1];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 16u * FA_T) {
+        uint32_t mine[16], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const uint32_t at = base + threadIdx.x * 16 + i; mine[i] = at < n ? v[at] : 0u; sum += mine[i]; }
+        uint32_t total;
+        uint32_t run = carry + wg_excl_u32<FA_T>(sum, lds, total);
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const uint32_t at = base + threadIdx.x * 16 + i; if (at < n) v[at] = run; run += mine[i]; }
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        if (carry > cap) { st->need_host |= FQ_NEED_LINES; carry = cap; }
+        st->n_lines = carry;
+    }
+}
+__global__ __launch_bounds__(FA_T) void k_fa_lines(const uint8_t *__restrict__ raw, const FaState *__restrict__ st, const uint32_t *__restrict__ wgbase,
+                                                   uint32_t *__restrict__ line_end, uint32_t cap) {
+    __shared__ uint32_t lds[FA_T / 64 + 1];
+    const uint32_t lo = st->start, hi = st->end, a0 = lo & ~15u;
+    if (a0 + blockIdx.x * FA_CHUNK >= hi) return;
+    const uint32_t addr = a0 + blockIdx.x * FA_CHUNK + threadIdx.x * 16u;
+    uint32_t m = newline_mask(raw, addr, lo, hi);
+    uint32_t total;
+    uint32_t at = wgbase[blockIdx.x] + wg_excl_u32<FA_T>((uint32_t)__popc(m), lds, total);
+    while (m) {
+        const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+        m &= m - 1u;
+        if (at < cap) line_end[at] = addr + b;
+        at++;
+    }
+}
+
+__global__ __launch_bounds__(FA_T) void k_fa_class(const uint8_t *__restrict__ raw, FaState *st, const uint32_t *__restrict__ line_end,
                                                    uint32_t *__restrict__ linfo) {
     const uint32_t NL = st->n_lines;
     // (the grid is sized for lines of 16 bytes; a block of shorter ones takes more trips)
-    for (uint32_t i = blockIdx.x * FQ_T + threadIdx.x; i < NL; i += gridDim.x * FQ_T) {
+    for (uint32_t i = blockIdx.x * FA_T + threadIdx.x; i < NL; i += gridDim.x * FA_T) {
         const uint32_t b = i ? line_end[i - 1] + 1u : st->start, e = line_end[i];
         const uint32_t rawlen = e - b;
         uint32_t L = rawlen;
@@ -360,12 +414,12 @@ __device__ __forceinline__ uint32_t fa_live_lines(const FaState *st) {
     return ev;
 }
 
-__global__ __launch_bounds__(FQ_T) void k_fa_flags(const FaState *st, const uint32_t *__restrict__ linfo, uint32_t *__restrict__ wghdr,
+__global__ __launch_bounds__(FA_T) void k_fa_flags(const FaState *st, const uint32_t *__restrict__ linfo, uint32_t *__restrict__ wghdr,
                                                    unsigned long long *__restrict__ wgbytes) {
-    __shared__ uint32_t rc[FQ_T / 64]; __shared__ unsigned long long rb[FQ_T / 64];
+    __shared__ uint32_t rc[FA_T / 64]; __shared__ unsigned long long rb[FA_T / 64];
     const uint32_t ev = fa_live_lines(st);
-    for (uint32_t blk = blockIdx.x; blk * FQ_T < ev; blk += gridDim.x) {      // chunk `blk` of FQ_T lines (k_fa_scan reads no chunk behind ev)
-        const uint32_t i = blk * FQ_T + threadIdx.x;
+    for (uint32_t blk = blockIdx.x; blk * FA_T < ev; blk += gridDim.x) {      // chunk `blk` of FA_T lines (k_fa_scan reads no chunk behind ev)
+        const uint32_t i = blk * FA_T + threadIdx.x;
         uint32_t c = 0; unsigned long long by = 0;
         if (i < ev) {
             const uint32_t info = linfo[i];
@@ -376,20 +430,20 @@ __global__ __launch_bounds__(FQ_T) void k_fa_flags(const FaState *st, const uint
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t tc = 0; unsigned long long tb = 0;
-            for (int x = 0; x < FQ_T / 64; x++) { tc += rc[x]; tb += rb[x]; }
+            for (int x = 0; x < FA_T / 64; x++) { tc += rc[x]; tb += rb[x]; }
             wghdr[blk] = tc; wgbytes[blk] = tb;
         }
         __syncthreads();
     }
 }
 
-// exclusive scans of the workgroup sums (16 * FQ_T of them per trip); the block's scalars
-__global__ __launch_bounds__(FQ_T) void k_fa_scan(uint32_t *__restrict__ wghdr, unsigned long long *__restrict__ wgbytes, uint32_t n,
+// exclusive scans of the workgroup sums (16 * FA_T of them per trip); the block's scalars
+__global__ __launch_bounds__(FA_T) void k_fa_scan(uint32_t *__restrict__ wghdr, unsigned long long *__restrict__ wgbytes, uint32_t n,
                                                   FaState *st, const uint32_t *__restrict__ line_end) {
-    __shared__ uint32_t lds[FQ_T / 64 + 1]; __shared__ unsigned long long ldb[FQ_T / 64 + 1];
-    { const uint32_t used = (fa_live_lines(st) + FQ_T - 1) / FQ_T; if (used < n) n = used; }     // (chunks behind the last live line were not written)
+    __shared__ uint32_t lds[FA_T / 64 + 1]; __shared__ unsigned long long ldb[FA_T / 64 + 1];
+    { const uint32_t used = (fa_live_lines(st) + FA_T - 1) / FA_T; if (used < n) n = used; }     // (chunks behind the last live line were not written)
     uint32_t carry_c = 0; unsigned long long carry_b = 0;
-    for (uint32_t base = 0; base < n || base == 0; base += 16u * FQ_T) {
+    for (uint32_t base = 0; base < n || base == 0; base += 16u * FA_T) {
         uint32_t mc[16], sc = 0; unsigned long long mb[16], sb = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -397,8 +451,8 @@ __global__ __launch_bounds__(FQ_T) void k_fa_scan(uint32_t *__restrict__ wghdr, 
             mc[i] = at < n ? wghdr[at] : 0u; mb[i] = at < n ? wgbytes[at] : 0ull; sc += mc[i]; sb += mb[i];
         }
         uint32_t tc; unsigned long long tb;
-        uint32_t rcn = carry_c + wg_excl_u32(sc, lds, tc);
-        unsigned long long rbn = carry_b + wg_excl_u64(sb, ldb, tb);
+        uint32_t rcn = carry_c + wg_excl_u32<FA_T>(sc, lds, tc);
+        unsigned long long rbn = carry_b + wg_excl_u64<FA_T>(sb, ldb, tb);
 #pragma unroll
         for (int i = 0; i < 16; i++) { const uint32_t at = base + threadIdx.x * 16 + i; if (at < n) { wghdr[at] = rcn; wgbytes[at] = rbn; } rcn += mc[i]; rbn += mb[i]; }
         carry_c += tc; carry_b += tb;
@@ -412,24 +466,24 @@ __global__ __launch_bounds__(FQ_T) void k_fa_scan(uint32_t *__restrict__ wghdr, 
     }
 }
 
-__global__ __launch_bounds__(FQ_T) void k_fa_emit(const FaState *st, const uint32_t *__restrict__ linfo, const uint32_t *__restrict__ wghdr,
+__global__ __launch_bounds__(FA_T) void k_fa_emit(const FaState *st, const uint32_t *__restrict__ linfo, const uint32_t *__restrict__ wghdr,
                                                   const unsigned long long *__restrict__ wgbytes, uint32_t *__restrict__ ldst,
-                                                  uint64_t *__restrict__ rec_off, uint64_t out_base) {
-    __shared__ uint32_t lds[FQ_T / 64 + 1]; __shared__ unsigned long long ldb[FQ_T / 64 + 1];
+                                                  uint32_t *__restrict__ hrel) {
+    __shared__ uint32_t lds[FA_T / 64 + 1]; __shared__ unsigned long long ldb[FA_T / 64 + 1];
     const uint32_t ev = fa_live_lines(st);
-    for (uint32_t blk = blockIdx.x; blk * FQ_T < ev; blk += gridDim.x) {
-        const uint32_t i = blk * FQ_T + threadIdx.x;
+    for (uint32_t blk = blockIdx.x; blk * FA_T < ev; blk += gridDim.x) {
+        const uint32_t i = blk * FA_T + threadIdx.x;
         uint32_t c = 0, L = 0;
         if (i < ev) {
             const uint32_t info = linfo[i];
             if ((info >> 24) == '>') c = 1; else L = info & 0xffffffu;
         }
         uint32_t tc; unsigned long long tb;
-        const uint32_t hidx = wghdr[blk] + wg_excl_u32(c, lds, tc);
-        const unsigned long long at = wgbytes[blk] + wg_excl_u64((unsigned long long)L, ldb, tb);
-        if (i < ev) {
-            if (c) { rec_off[hidx] = out_base + at; ldst[i] = FA_NONE; }
-            else ldst[i] = (uint32_t)at;                            // (a block's sequence bytes are fewer than its raw bytes: 32 bits)
+        const uint32_t hidx = wghdr[blk] + wg_excl_u32<FA_T>(c, lds, tc);
+        const unsigned long long at = wgbytes[blk] + wg_excl_u64<FA_T>((unsigned long long)L, ldb, tb);
+        if (i < ev) {                                               // (a block's sequence bytes are fewer than its raw bytes: 32 bits)
+            if (c) { hrel[hidx] = (uint32_t)at; ldst[i] = FA_NONE; }
+            else ldst[i] = (uint32_t)at;
         }
     }
 }
@@ -466,17 +520,23 @@ __global__ __launch_bounds__(256) void k_fa_copy(const uint8_t *__restrict__ raw
     }
 }
 
-__global__ __launch_bounds__(256) void k_fa_lens(FaState *st, const uint64_t *__restrict__ rec_off) {
+__global__ __launch_bounds__(256) void k_fa_lens(FaState *st, const uint32_t *__restrict__ hrel) {
     const uint32_t n = st->n_hdr;
     uint32_t mn = FA_NONE, mx = 0;
     for (uint32_t h = 1u + blockIdx.x * blockDim.x + threadIdx.x; h < n; h += gridDim.x * blockDim.x) {
-        const uint64_t d = rec_off[h] - rec_off[h - 1];
-        const uint32_t d32 = d < 0xfffffffeull ? (uint32_t)d : 0xfffffffeu;
-        mn = d32 < mn ? d32 : mn; mx = d32 > mx ? d32 : mx;
+        const uint32_t d = hrel[h] - hrel[h - 1];
+        mn = d < mn ? d : mn; mx = d > mx ? d : mx;
     }
     for (int off = 32; off; off >>= 1) { const uint32_t a = __shfl_xor(mn, off), b = __shfl_xor(mx, off); mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
     if ((threadIdx.x & 63) == 0) { if (mn != FA_NONE) atomicMin(&st->min_len, mn); if (mx) atomicMax(&st->max_len, mx); }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n) { st->first_hdr = rec_off[0]; st->last_hdr = rec_off[n - 1]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) { st->first_hdr = hrel[0]; st->last_hdr = hrel[n - 1]; }
+}
+
+// the block's headers -> record offsets of the accumulation buffer
+__global__ __launch_bounds__(256) void k_fa_recs(const FaState *__restrict__ st, const uint32_t *__restrict__ hrel, uint64_t *__restrict__ rec_off,
+                                                 uint64_t out_base) {
+    const uint32_t n = st->n_hdr;
+    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < n; h += gridDim.x * blockDim.x) rec_off[h] = out_base + hrel[h];
 }
 
 }  // namespace
@@ -488,9 +548,9 @@ hipError_t launch_fq_parse(hipStream_t s, const FqBuffers &B, const uint8_t *pre
     const uint32_t nlwg = (B.line_cap + FQ_T - 1) / FQ_T;
     if (nchunks > 8 * FQ_T || nlwg > 8 * FQ_T) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_fq_tail_in, dim3(64), dim3(256), 0, s, prev_raw, prev_state, raw, state, B.porch, len);
-    hipLaunchKernelGGL(k_fq_count<FqState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt);
-    hipLaunchKernelGGL(k_fq_scan_u32<FqState>, dim3(1), dim3(FQ_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
-    hipLaunchKernelGGL(k_fq_lines<FqState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
+    hipLaunchKernelGGL(k_fq_count, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt);
+    hipLaunchKernelGGL(k_fq_scan_u32, dim3(1), dim3(FQ_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
+    hipLaunchKernelGGL(k_fq_lines, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
     hipLaunchKernelGGL(k_fq_class, dim3(nlwg), dim3(FQ_T), 0, s, raw, state, B.line_end, B.linfo, B.lmap, B.wgmap);
     hipLaunchKernelGGL(k_fq_scan_maps, dim3(1), dim3(FQ_T), 0, s, B.wgmap, nlwg, B.wgstate, state);
     hipLaunchKernelGGL(k_fq_flags, dim3(nlwg), dim3(FQ_T), 0, s, state, B.linfo, B.lmap, B.wgstate, B.wgseq, B.wgbytes);
@@ -501,56 +561,29 @@ hipError_t launch_fq_parse(hipStream_t s, const FqBuffers &B, const uint8_t *pre
     return hipGetLastError();
 }
 
-hipError_t launch_fa_parse(hipStream_t s, const FaBuffers &B, const uint8_t *prev_raw, const FaState *prev_state, uint8_t *raw,
-                           FaState *state, uint32_t len, uint8_t *acc, uint64_t out_base, uint64_t *rec_off) {
+hipError_t launch_fa_index(hipStream_t s, const FaBuffers &B, const uint8_t *prev_raw, const FaState *prev_state, uint8_t *raw,
+                           FaState *state, uint32_t len) {
     const uint32_t span = B.porch + len + 16u;
-    const uint32_t nchunks = (span + FQ_CHUNK - 1) / FQ_CHUNK;
-    const uint32_t nlwg = (B.line_cap + FQ_T - 1) / FQ_T;
-    if (nchunks > 8 * FQ_T) return hipErrorInvalidValue;
-#ifdef HULK_EXPERIMENTS
-    // HULK_FA_TIME=n: every kernel of the chain alone (the stream is synchronised around it), microseconds summed per kernel and
-    // printed every n blocks
-    static const int every = getenv("HULK_FA_TIME") ? atoi(getenv("HULK_FA_TIME")) : 0;
-    static const bool timing = every > 0;
-    static double acc_us[10]; static int nblk = 0; int ki = 0;
-#define FA_T(name) do { if (timing) { hipStreamSynchronize(s); const double t1_ = now_us(); acc_us[ki++] += t1_ - t0_; t0_ = t1_; } } while (0)
-    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    if (timing) hipStreamSynchronize(s);
-    double t0_ = now_us();
-#else
-#define FA_T(name) do { } while (0)
-#endif
+    const uint32_t nchunks = (span + FA_CHUNK - 1) / FA_CHUNK;
+    const uint32_t nlwg = (B.line_cap + FA_T - 1) / FA_T;
     hipLaunchKernelGGL(k_fa_begin, dim3(64), dim3(256), 0, s, prev_raw, prev_state, raw, state, B.porch, len);
-    FA_T("k_fa_begin");
-    hipLaunchKernelGGL(k_fq_count<FaState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt);
-    FA_T("k_fq_count");
-    hipLaunchKernelGGL(k_fq_scan_u32<FaState>, dim3(1), dim3(FQ_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
-    FA_T("k_fq_scan_u32");
-    hipLaunchKernelGGL(k_fq_lines<FaState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
-    FA_T("k_fq_lines");
+    hipLaunchKernelGGL(k_fa_count, dim3(nchunks), dim3(FA_T), 0, s, raw, state, B.wgcnt);
+    hipLaunchKernelGGL(k_fa_scan_lines, dim3(1), dim3(FA_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
+    hipLaunchKernelGGL(k_fa_lines, dim3(nchunks), dim3(FA_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
     // a block of 60-byte lines has 1/30 of line_cap: the grids are sized for lines of 16 bytes, the kernels take more trips over shorter ones
-    const uint32_t glw = std::min<uint32_t>(nlwg, (span / 16u + FQ_T - 1) / FQ_T + 1u);
-    hipLaunchKernelGGL(k_fa_class, dim3(glw), dim3(FQ_T), 0, s, raw, state, B.line_end, B.linfo);
-    FA_T("k_fa_class");
-    hipLaunchKernelGGL(k_fa_flags, dim3(glw), dim3(FQ_T), 0, s, state, B.linfo, B.wghdr, B.wgbytes);
-    FA_T("k_fa_flags");
-    hipLaunchKernelGGL(k_fa_scan, dim3(1), dim3(FQ_T), 0, s, B.wghdr, B.wgbytes, nlwg, state, B.line_end);
-    FA_T("k_fa_scan");
-    hipLaunchKernelGGL(k_fa_emit, dim3(glw), dim3(FQ_T), 0, s, state, B.linfo, B.wghdr, B.wgbytes, B.ldst, rec_off, out_base);
-    FA_T("k_fa_emit");
+    const uint32_t glw = std::min<uint32_t>(nlwg, (span / 16u + FA_T - 1) / FA_T + 1u);
+    hipLaunchKernelGGL(k_fa_class, dim3(glw), dim3(FA_T), 0, s, raw, state, B.line_end, B.linfo);
+    hipLaunchKernelGGL(k_fa_flags, dim3(glw), dim3(FA_T), 0, s, state, B.linfo, B.wghdr, B.wgbytes);
+    hipLaunchKernelGGL(k_fa_scan, dim3(1), dim3(FA_T), 0, s, B.wghdr, B.wgbytes, nlwg, state, B.line_end);
+    hipLaunchKernelGGL(k_fa_emit, dim3(glw), dim3(FA_T), 0, s, state, B.linfo, B.wghdr, B.wgbytes, B.ldst, B.hrel);
+    hipLaunchKernelGGL(k_fa_lens, dim3(64), dim3(256), 0, s, state, B.hrel);
+    return hipGetLastError();
+}
+
+hipError_t launch_fa_place(hipStream_t s, const FaBuffers &B, const uint8_t *raw, const FaState *state, uint8_t *acc, uint64_t out_base,
+                           uint64_t *rec_off) {
     hipLaunchKernelGGL(k_fa_copy, dim3(2048), dim3(256), 0, s, raw, state, B.line_end, B.linfo, B.ldst, acc + out_base);
-    FA_T("k_fa_copy");
-    hipLaunchKernelGGL(k_fa_lens, dim3(64), dim3(256), 0, s, state, rec_off);
-    FA_T("k_fa_lens");
-#ifdef HULK_EXPERIMENTS
-    if (timing && ++nblk % every == 0) {
-        static const char *names[10] = {"k_fa_begin", "k_fq_count", "k_fq_scan_u32", "k_fq_lines", "k_fa_class", "k_fa_flags", "k_fa_scan", "k_fa_emit", "k_fa_copy", "k_fa_lens"};
-        fprintf(stderr, "fasta parse kernels, us per block over %d blocks:", nblk);
-        for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.0f", names[i], acc_us[i] / nblk);
-        fprintf(stderr, "\n");
-    }
-#endif
-#undef FA_T
+    hipLaunchKernelGGL(k_fa_recs, dim3(64), dim3(256), 0, s, state, B.hrel, rec_off, out_base);
     return hipGetLastError();
 }
 

@@ -1689,12 +1689,13 @@ struct FqDev {
     hipEvent_t ev_copied[NHOST] = {}, ev_parsed[NST] = {}, ev_busy[NOUT][2] = {};
     bool busy0[NOUT] = {}, busy1[NOUT] = {};
     hulk::FqBuffers B;
-    // --fasta (run_ingest_fasta_device), allocated by the first such run of the set: a line index with room for (64 KiB + block) / 2
-    // lines, two accumulation buffers (sequence bytes of complete records + the record in progress; they grow with the longest
-    // record) and their record offsets — about 110 MB + 2 x (192 MB + 70 MB) of HBM at the default block size
+    // --fasta (run_ingest_fasta_device), allocated by the first such run of the set: two line indices with room for (64 KiB + block) / 2
+    // lines each, two accumulation buffers (sequence bytes of complete records + the record in progress; they grow with the longest
+    // record) and their record offsets — about 2 x 135 MB + 2 x (192 MB + 70 MB) of HBM at the default block size
     struct Fasta {
         bool ready = false;
-        hulk::FaBuffers B;
+        hulk::FaBuffers B[2];                                      // index arrays: a block is indexed while the one before it is placed
+        hipEvent_t ev_placed[NRAW] = {};                           // the block that used raw slot r has been placed (the slot may be overwritten)
         hulk::FaState *d_state = nullptr, *h_state = nullptr;      // [NST]
         uint8_t *acc[2] = {}; size_t acc_cap[2] = {};
         uint64_t *rec_off[2] = {}; size_t rec_cap = 0;
@@ -1705,7 +1706,8 @@ struct FqDev {
     void release() {
         if (cs) hipStreamSynchronize(cs);
         if (ps) hipStreamSynchronize(ps);
-        hipFree(fa.B.wgcnt); hipFree(fa.B.line_end); hipFree(fa.B.linfo); hipFree(fa.B.ldst); hipFree(fa.B.wghdr); hipFree(fa.B.wgbytes);
+        for (auto &b : fa.B) { hipFree(b.wgcnt); hipFree(b.line_end); hipFree(b.linfo); hipFree(b.ldst); hipFree(b.wghdr); hipFree(b.hrel); hipFree(b.wgbytes); }
+        for (auto &e : fa.ev_placed) if (e) hipEventDestroy(e);
         hipFree(fa.d_state); if (fa.h_state) hipHostFree(fa.h_state);
         for (int i = 0; i < 2; i++) { hipFree(fa.acc[i]); hipFree(fa.rec_off[i]); for (auto &e : fa.ev_busy[i]) if (e) hipEventDestroy(e); }
         fa = Fasta{};
@@ -2048,24 +2050,28 @@ static bool fa_ensure(FqDev *D, IngestError &err) {
     FqDev::Fasta &F = D->fa;
     if (F.ready) return true;
 #define FA_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return err.set(HULK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
-    F.B.porch = D->porch;
-    F.B.line_cap = (uint32_t)((MAX_TOKEN + D->block) / 2 + 2);
-    const size_t nchunk = (D->raw_bytes() + 16383) / 16384 + 8, nlwg = ((size_t)F.B.line_cap + 1023) / 1024 + 8;
-    FA_HIP(hipMalloc((void **)&F.B.wgcnt, nchunk * 4));
-    FA_HIP(hipMalloc((void **)&F.B.line_end, (size_t)F.B.line_cap * 4));
-    FA_HIP(hipMalloc((void **)&F.B.linfo, (size_t)F.B.line_cap * 4));
-    FA_HIP(hipMalloc((void **)&F.B.ldst, (size_t)F.B.line_cap * 4));
-    FA_HIP(hipMalloc((void **)&F.B.wghdr, nlwg * 4));
-    FA_HIP(hipMalloc((void **)&F.B.wgbytes, nlwg * 8));
+    const uint32_t line_cap = (uint32_t)((MAX_TOKEN + D->block) / 2 + 2);
+    const size_t nchunk = (D->raw_bytes() + 4095) / 4096 + 8, nlwg = ((size_t)line_cap + 255) / 256 + 8;     // (hulk_fastq.hip FA_T = 256)
+    for (auto &B : F.B) {
+        B.porch = D->porch; B.line_cap = line_cap;
+        FA_HIP(hipMalloc((void **)&B.wgcnt, nchunk * 4));
+        FA_HIP(hipMalloc((void **)&B.line_end, (size_t)line_cap * 4));
+        FA_HIP(hipMalloc((void **)&B.linfo, (size_t)line_cap * 4));
+        FA_HIP(hipMalloc((void **)&B.ldst, (size_t)line_cap * 4));
+        FA_HIP(hipMalloc((void **)&B.hrel, (size_t)line_cap * 4));
+        FA_HIP(hipMalloc((void **)&B.wghdr, nlwg * 4));
+        FA_HIP(hipMalloc((void **)&B.wgbytes, nlwg * 8));
+    }
     FA_HIP(hipMalloc((void **)&F.d_state, FqDev::NST * sizeof(hulk::FaState)));
     FA_HIP(hipHostMalloc((void **)&F.h_state, FqDev::NST * sizeof(hulk::FaState), hipHostMallocDefault));
-    F.rec_cap = (size_t)F.B.line_cap + ((size_t)1 << 19);
+    F.rec_cap = (size_t)line_cap + ((size_t)1 << 19);
     for (int i = 0; i < 2; i++) {
         F.acc_cap[i] = (size_t)192 << 20;
         FA_HIP(hipMalloc((void **)&F.acc[i], F.acc_cap[i] + 64));
         FA_HIP(hipMalloc((void **)&F.rec_off[i], (F.rec_cap + 2) * 8));
         for (auto &e : F.ev_busy[i]) FA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    for (auto &e : F.ev_placed) FA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     FA_HIP(hipDeviceSynchronize());
 #undef FA_HIP
     F.ready = true;
@@ -2095,7 +2101,7 @@ int run_ingest_fasta_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_
     bool have_hdr = false, stopped = false, ok = true;
     uint64_t bmin = ~0ull, bmax = 0;             // over the complete records not handed over yet
     uint64_t n_lines = 0, dev_seqs = 0, bytes_done = 0;
-    hipEvent_t last_parsed = nullptr;
+    hipEvent_t last_placed = nullptr;
     std::vector<uint64_t> h_rec;
     // a buffer is written from acc_len on; what the context still reads of it (records handed over by the run before) lies below —
     // except in a buffer taken over EMPTY: wait for its readers first
@@ -2134,12 +2140,12 @@ int run_ingest_fasta_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_
             if (bmin < min_len) return err.set(HULK_ERR_SHORT_SEQ, hulk_strerror(HULK_ERR_SHORT_SEQ));
             if (bmax > 0xffffffffull) return err.set(HULK_ERR_READ_TOO_LONG, hulk_strerror(HULK_ERR_READ_TOO_LONG));
             const double tc1 = PhaseTrace::now();
-            // the records' offsets, for the long-sequence path's descriptors (the parse stream has passed them: no waiting for the binning)
+            // the records' offsets, for the long-sequence path's descriptors (the parse stream gets there long before the binning would)
             h_rec.resize(n + 1);
             if (hipMemcpyAsync(h_rec.data(), F.rec_off[cur], (n + 1) * 8, hipMemcpyDeviceToHost, D->ps) != hipSuccess || hipStreamSynchronize(D->ps) != hipSuccess)
                 return err.set(HULK_ERR_HIP, "hipMemcpyAsync (FASTA record offsets)");
             hulk::ctx_hint_host_offsets(ctx, h_rec.data());
-            int rc = last_parsed ? hulk::ctx_wait_event(ctx, last_parsed) : HULK_OK;
+            int rc = last_placed ? hulk::ctx_wait_event(ctx, last_placed) : HULK_OK;
             if (rc == HULK_OK) rc = hulk_add_reads_device(ctx, F.acc[cur], F.rec_off[cur], n, (uint32_t)bmax, F.acc_cap[cur] + 64);
             if (rc == HULK_OK) rc = hulk::ctx_record_busy(ctx, F.ev_busy[cur][0], F.ev_busy[cur][1], &F.busy1[cur]);
             g_trace.add_reads += PhaseTrace::now() - tc1;
@@ -2150,15 +2156,12 @@ int run_ingest_fasta_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_
         bmin = ~0ull; bmax = 0;
         return true;
     };
-    // the record in progress moves to the front of the other buffer; the next blocks append there
-    auto switch_buffers = [&]() -> bool {
+    // the record in progress moves to the front of the other buffer; the next blocks are placed there
+    auto switch_buffers = [&](uint64_t room) -> bool {
         const int nb = cur ^ 1;
         const uint64_t part = have_hdr ? acc_len - open_start : 0;
-        // (the context may still read records of `nb` handed over two batches ago: it is written from byte 0 now)
-        if (F.busy0[nb] || F.busy1[nb]) {
-            if (!wait_readers(nb)) return false;
-        }
-        if (!ensure_acc(nb, part + MAX_TOKEN + block + 64, 0)) return false;
+        if (!wait_readers(nb)) return false;                         // (records of `nb` handed over two batches ago: it is written from byte 0 now)
+        if (!ensure_acc(nb, part + room + 64, 0)) return false;
         if (part && hipMemcpyAsync(F.acc[nb], F.acc[cur] + open_start, part, hipMemcpyDeviceToDevice, D->ps) != hipSuccess)
             return err.set(HULK_ERR_HIP, "hipMemcpyAsync (FASTA record in progress)");
         if (hipMemsetAsync(F.rec_off[nb], 0, 8, D->ps) != hipSuccess) return err.set(HULK_ERR_HIP, "hipMemsetAsync (FASTA record offsets)");
@@ -2168,12 +2171,12 @@ int run_ingest_fasta_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_
     {
         RawReader reader(paths, n_paths, cfg, D);
         if (!wait_readers(0) || !wait_readers(1)) return err.code;
-        std::deque<RawReader::Item> held;
-        uint64_t b = 0;
-        bool eof = false;
-        // block x's scalars -> the stream's bookkeeping; false: the run fails (err)
-        auto consume = [&](uint64_t x) -> bool {
-            const int st = (int)(x % FqDev::NST);
+        std::deque<RawReader::Item> held;        // blocks indexed, not placed yet (one)
+        uint64_t b = 0;                          // blocks indexed so far
+        // Block x has been indexed: its scalars -> the stream's books, its sequence lines -> the accumulation buffer.
+        // false: the run fails (err).  Sets `stopped` at the empty line that ends the parsing.
+        auto place = [&](uint64_t x) -> bool {
+            const int st = (int)(x % FqDev::NST), r = (int)(x % FqDev::NRAW);
             const double tw0 = PhaseTrace::now();
             if (hipEventSynchronize(D->ev_parsed[st]) != hipSuccess) return err.set(HULK_ERR_HIP, "hipEventSynchronize (device FASTA parser)");
             g_trace.stage_wait += PhaseTrace::now() - tw0;
@@ -2181,17 +2184,32 @@ int run_ingest_fasta_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_
             const bool stop = S.first_empty != hulk::FA_NONE && S.first_empty < S.long_line;
             const bool too_long = S.long_line != hulk::FA_NONE && !stop;
             n_lines += stop ? (uint64_t)S.first_empty + 1 : too_long ? (uint64_t)S.long_line : (uint64_t)S.n_lines;
+            // as Parser::fasta_block: the first of the two events in stream order counts; a line too long ends the run with nothing handed over
+            if (too_long) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
+            // the offsets could not take this block's headers: a batch ends early
+            if (rec_count + S.n_hdr + 2 > F.rec_cap && (!hand_over(false) || !switch_buffers(S.seq_bytes))) return false;
+            if (!ensure_acc(cur, acc_len + S.seq_bytes + 64, acc_len)) return false;
+            const double tq0 = PhaseTrace::now();
+            if (S.seq_bytes || S.n_hdr) {
+                const hipError_t e = hulk::launch_fa_place(D->ps, F.B[x & 1], D->d_raw[r], F.d_state + st, F.acc[cur], acc_len, F.rec_off[cur] + rec_count);
+                if (e != hipSuccess) return err.set(HULK_ERR_HIP, std::string("launch_fa_place: ") + hipGetErrorString(e));
+            }
+            if (hipEventRecord(F.ev_placed[r], D->ps) != hipSuccess) return err.set(HULK_ERR_HIP, "hipEventRecord (FASTA block placed)");
+            last_placed = F.ev_placed[r];
+            g_trace.enqueue += PhaseTrace::now() - tq0;
             if (S.n_hdr) {
-                if (have_hdr) { const uint64_t L = S.first_hdr - open_start; bmin = std::min(bmin, L); bmax = std::max(bmax, L); }
-                else batch_start = S.first_hdr;                         // (sequence lines in front of the stream's first header: no record owns them)
+                const uint64_t first = acc_len + S.first_hdr, last = acc_len + S.last_hdr;
+                if (have_hdr) { const uint64_t L = first - open_start; bmin = std::min(bmin, L); bmax = std::max(bmax, L); }
+                else batch_start = first;                               // (sequence lines in front of the stream's first header: no record owns them)
                 if (S.n_hdr > 1) { bmin = std::min<uint64_t>(bmin, S.min_len); bmax = std::max<uint64_t>(bmax, S.max_len); }
-                rec_count += S.n_hdr; open_start = S.last_hdr; have_hdr = true;
+                rec_count += S.n_hdr; open_start = last; have_hdr = true;
             }
             acc_len += S.seq_bytes;
             if (!have_hdr) acc_len = 0;                                 // (l2 = nil: sequence lines before any header are dropped)
-            if (too_long) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
             if (stop) { stopped = true; return true; }
             if (S.tail_len >= MAX_TOKEN) return err.set(HULK_ERR_LINE_TOO_LONG, hulk_strerror(HULK_ERR_LINE_TOO_LONG));
+            // a batch is due (the host parser's rule)
+            if (rec_count > 1 && open_start - batch_start >= FASTA_BATCH_BYTES && (!hand_over(false) || !switch_buffers(0))) return false;
             return true;
         };
         for (;;) {
@@ -2200,41 +2218,31 @@ int run_ingest_fasta_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_
             const bool got = reader.next(it, err);
             const double tb1 = PhaseTrace::now(); g_trace.wait_block += tb1 - tb0;
             if (!got) { ok = err.code == HULK_OK; break; }
+            if (it.len == 0) { reader.recycle(it.idx); break; }        // (end of the stream right on a block border)
             const int r = (int)(b % FqDev::NRAW), st = (int)(b % FqDev::NST);
-            if (it.len) {
-                DEV_HIP(hipMemcpyAsync(D->d_raw[r] + D->porch, D->h_buf[it.idx], it.len, hipMemcpyHostToDevice, D->cs));
-                DEV_HIP(hipEventRecord(D->ev_copied[it.idx], D->cs));
-            }
-            g_trace.enqueue += PhaseTrace::now() - tb1;
-            if (!held.empty()) {                                        // block b-1: its scalars, while block b crosses the link
-                if (!consume(b - 1)) { ok = false; break; }
-                reader.recycle(held.front().idx); held.pop_front();
-                if (stopped) { reader.recycle(it.idx); break; }
-                // a batch is due (the host parser's rule), or the offsets / the buffer could not take another block
-                const bool full = rec_count > 1 && open_start - batch_start >= FASTA_BATCH_BYTES;
-                if (full || rec_count + F.B.line_cap + 2 > F.rec_cap) {
-                    if (!hand_over(false) || !switch_buffers()) { ok = false; break; }
-                }
-            }
-            if (it.len == 0) { reader.recycle(it.idx); eof = true; break; }   // (end of the stream right on a block border)
-            if (!ensure_acc(cur, acc_len + MAX_TOKEN + it.len + 64, acc_len)) { ok = false; break; }
-            const double tq0 = PhaseTrace::now();
+            // the copy, and the block's index: neither needs to know where the blocks before left the accumulation buffer
+            if (b >= (uint64_t)FqDev::NRAW) DEV_HIP(hipStreamWaitEvent(D->cs, F.ev_placed[r], 0));     // (the block that used this raw slot)
+            DEV_HIP(hipMemcpyAsync(D->d_raw[r] + D->porch, D->h_buf[it.idx], it.len, hipMemcpyHostToDevice, D->cs));
+            DEV_HIP(hipEventRecord(D->ev_copied[it.idx], D->cs));
             DEV_HIP(hipStreamWaitEvent(D->ps, D->ev_copied[it.idx], 0));
-            DEV_HIP(hulk::launch_fa_parse(D->ps, F.B, b ? D->d_raw[(b - 1) % FqDev::NRAW] : nullptr, b ? F.d_state + (b - 1) % FqDev::NST : nullptr,
-                                          D->d_raw[r], F.d_state + st, (uint32_t)it.len, F.acc[cur], acc_len, F.rec_off[cur] + rec_count));
+            DEV_HIP(hulk::launch_fa_index(D->ps, F.B[b & 1], b ? D->d_raw[(b - 1) % FqDev::NRAW] : nullptr, b ? F.d_state + (b - 1) % FqDev::NST : nullptr,
+                                          D->d_raw[r], F.d_state + st, (uint32_t)it.len));
             DEV_HIP(hipMemcpyAsync(F.h_state + st, F.d_state + st, sizeof(hulk::FaState), hipMemcpyDeviceToHost, D->ps));
             DEV_HIP(hipEventRecord(D->ev_parsed[st], D->ps));
-            last_parsed = D->ev_parsed[st];
-            g_trace.enqueue += PhaseTrace::now() - tq0;
+            g_trace.enqueue += PhaseTrace::now() - tb1;
             held.push_back(it);
             b++;
-            if (it.eof) { eof = true; break; }
+            if (held.size() > 1) {                                      // block b-2 is placed while block b-1 crosses the link and is indexed
+                if (!place(b - 2)) { ok = false; break; }
+                reader.recycle(held.front().idx); held.pop_front();
+                if (stopped) break;
+            }
+            if (it.eof) break;
         }
-        if (ok && !stopped && !held.empty()) {
-            if (!consume(b - 1)) ok = false;
+        while (ok && !stopped && !held.empty()) {
+            if (!place(b - held.size())) ok = false;
             reader.recycle(held.front().idx); held.pop_front();
         }
-        (void)eof;
         if (ok) {
             // sketch.go:126-135 flushes the final entry unconditionally; with no header line at all the reference dies on l1[0] = 64
             if (!have_hdr) ok = err.set(HULK_ERR_FASTA_HEADER, hulk_strerror(HULK_ERR_FASTA_HEADER));
@@ -2249,7 +2257,7 @@ int run_ingest_fasta_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_
     }
 #undef DEV_HIP
     if (cfg.trace)
-        fprintf(stderr, "ingest trace (device FASTA parser; calling thread, s): next block %.3f | copies + parse kernels queued %.3f, "
+        fprintf(stderr, "ingest trace (device FASTA parser; calling thread, s): next block %.3f | copies + kernels queued %.3f, "
                         "waiting for a block's scalars %.3f, hulk_add_reads_device %.3f\n",
                 g_trace.wait_block, g_trace.enqueue, g_trace.stage_wait, g_trace.add_reads);
     return ok ? HULK_OK : err.code;

@@ -11,7 +11,8 @@ int ctx_wait_event(hulk_ctx *, hipEvent_t) { return -1; }
 int ctx_record_busy(hulk_ctx *, hipEvent_t, hipEvent_t, bool *) { return -1; }
 void ctx_hint_host_offsets(hulk_ctx *, const uint64_t *) {}
 hipError_t launch_fq_parse(hipStream_t, const FqBuffers &, const uint8_t *, const FqState *, uint8_t *, FqState *, uint32_t, uint64_t *, uint8_t *) { return hipErrorUnknown; }
-hipError_t launch_fa_parse(hipStream_t, const FaBuffers &, const uint8_t *, const FaState *, uint8_t *, FaState *, uint32_t, uint8_t *, uint64_t, uint64_t *) { return hipErrorUnknown; }
+hipError_t launch_fa_index(hipStream_t, const FaBuffers &, const uint8_t *, const FaState *, uint8_t *, FaState *, uint32_t) { return hipErrorUnknown; }
+hipError_t launch_fa_place(hipStream_t, const FaBuffers &, const uint8_t *, const FaState *, uint8_t *, uint64_t, uint64_t *) { return hipErrorUnknown; }
 hipStream_t ctx_stream(hulk_ctx *) { return nullptr; }
 uint64_t ctx_min_read_len(const hulk_ctx *) { return 0; }
 int ctx_fail(hulk_ctx *, int code, const char *) { return code; }
