@@ -54,7 +54,8 @@ __device__ __forceinline__ uint32_t newline_mask(const uint8_t *raw, uint32_t ad
     return m;
 }
 
-constexpr int FQ_T = 1024;                     // threads per workgroup of the index kernels
+constexpr int FQ_T = 256;                      // threads per workgroup of the index kernels: small ones find room at once beside the binning
+                                               // kernels, which leave a few wave slots per CU free (1024-thread ones waited for half a CU)
 constexpr uint32_t FQ_CHUNK = FQ_T * 16;       // bytes per workgroup
 
 // workgroup-wide exclusive prefix sum of one uint32 per thread (T threads); returns the workgroup total through `total`
@@ -138,19 +139,23 @@ __global__ __launch_bounds__(FQ_T) void k_fq_count(const uint8_t *__restrict__ r
     if (threadIdx.x == 0) { uint32_t t = 0; for (int i = 0; i < FQ_T / 64; i++) t += red[i]; wgcnt[blockIdx.x] = t; }
 }
 
-// exclusive scan of n <= 8 * FQ_T workgroup counts in place; the total goes to *total_out (clamped to cap -> need_host)
+// exclusive scan of the n workgroup counts in place (8 * FQ_T per trip); the total goes to n_lines (clamped to cap -> need_host)
 __global__ __launch_bounds__(FQ_T) void k_fq_scan_u32(uint32_t *__restrict__ v, uint32_t n, FqState *st, uint32_t cap) {
     __shared__ uint32_t lds[FQ_T / 64 + 1];
-    uint32_t mine[8], sum = 0;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 8u * FQ_T) {
+        uint32_t mine[8], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { const uint32_t at = threadIdx.x * 8 + i; mine[i] = at < n ? v[at] : 0u; sum += mine[i]; }
-    uint32_t total;
-    uint32_t run = wg_excl_u32(sum, lds, total);
+        for (int i = 0; i < 8; i++) { const uint32_t at = base + threadIdx.x * 8 + i; mine[i] = at < n ? v[at] : 0u; sum += mine[i]; }
+        uint32_t total;
+        uint32_t run = carry + wg_excl_u32(sum, lds, total);
 #pragma unroll
-    for (int i = 0; i < 8; i++) { const uint32_t at = threadIdx.x * 8 + i; if (at < n) v[at] = run; run += mine[i]; }
+        for (int i = 0; i < 8; i++) { const uint32_t at = base + threadIdx.x * 8 + i; if (at < n) v[at] = run; run += mine[i]; }
+        carry += total;
+    }
     if (threadIdx.x == 0) {
-        if (total > cap) { st->need_host |= FQ_NEED_LINES; total = cap; }
-        st->n_lines = total;
+        if (carry > cap) { st->need_host |= FQ_NEED_LINES; carry = cap; }
+        st->n_lines = carry;
     }
 }
 
@@ -199,14 +204,18 @@ __global__ __launch_bounds__(FQ_T) void k_fq_class(const uint8_t *__restrict__ r
 __global__ __launch_bounds__(FQ_T) void k_fq_scan_maps(const uint32_t *__restrict__ wgmap, uint32_t n, uint8_t *__restrict__ wgstate,
                                                        FqState *st) {
     __shared__ uint32_t lds[FQ_T / 64 + 1];
-    uint32_t mine[8], mm = MAP_ID;
+    uint32_t carry = MAP_ID;                                        // composition of everything in front of this trip
+    for (uint32_t base = 0; base < n || base == 0; base += 8u * FQ_T) {
+        uint32_t mine[8], mm = MAP_ID;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { const uint32_t at = threadIdx.x * 8 + i; mine[i] = at < n ? wgmap[at] : MAP_ID; mm = map_then(mm, mine[i]); }
-    uint32_t total;
-    uint32_t run = wg_excl_map(mm, lds, total);
+        for (int i = 0; i < 8; i++) { const uint32_t at = base + threadIdx.x * 8 + i; mine[i] = at < n ? wgmap[at] : MAP_ID; mm = map_then(mm, mine[i]); }
+        uint32_t total;
+        uint32_t run = map_then(carry, wg_excl_map(mm, lds, total));
 #pragma unroll
-    for (int i = 0; i < 8; i++) { const uint32_t at = threadIdx.x * 8 + i; if (at < n) wgstate[at] = (uint8_t)map_apply(run, 0u); run = map_then(run, mine[i]); }
-    if (threadIdx.x == 0) st->end_state = map_apply(total, 0u);
+        for (int i = 0; i < 8; i++) { const uint32_t at = base + threadIdx.x * 8 + i; if (at < n) wgstate[at] = (uint8_t)map_apply(run, 0u); run = map_then(run, mine[i]); }
+        carry = map_then(carry, total);
+    }
+    if (threadIdx.x == 0) st->end_state = map_apply(carry, 0u);
 }
 
 // sequence lines and completing lines; per workgroup: number of sequence lines and their bytes
@@ -235,22 +244,26 @@ __global__ __launch_bounds__(FQ_T) void k_fq_flags(FqState *st, const uint32_t *
     }
 }
 
-// exclusive scans of the workgroup sums; the block's scalars
+// exclusive scans of the workgroup sums (8 * FQ_T per trip); the block's scalars
 __global__ __launch_bounds__(FQ_T) void k_fq_scan_cnt(uint32_t *__restrict__ wgseq, unsigned long long *__restrict__ wgbytes, uint32_t n,
                                                       FqState *st, const uint32_t *__restrict__ line_end, uint64_t *__restrict__ off_out,
                                                       uint32_t read_cap, uint64_t bytes_cap) {
     __shared__ uint32_t lds[FQ_T / 64 + 1]; __shared__ unsigned long long ldb[FQ_T / 64 + 1];
-    uint32_t mc[8], sc = 0; unsigned long long mb[8], sb = 0;
+    uint32_t tc = 0; unsigned long long tb = 0;                       // running totals
+    for (uint32_t base = 0; base < n || base == 0; base += 8u * FQ_T) {
+        uint32_t mc[8], sc = 0; unsigned long long mb[8], sb = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t at = threadIdx.x * 8 + i;
-        mc[i] = at < n ? wgseq[at] : 0u; mb[i] = at < n ? wgbytes[at] : 0ull; sc += mc[i]; sb += mb[i];
+        for (int i = 0; i < 8; i++) {
+            const uint32_t at = base + threadIdx.x * 8 + i;
+            mc[i] = at < n ? wgseq[at] : 0u; mb[i] = at < n ? wgbytes[at] : 0ull; sc += mc[i]; sb += mb[i];
+        }
+        uint32_t t1; unsigned long long t2;
+        uint32_t rcn = tc + wg_excl_u32(sc, lds, t1);
+        unsigned long long rbn = tb + wg_excl_u64(sb, ldb, t2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const uint32_t at = base + threadIdx.x * 8 + i; if (at < n) { wgseq[at] = rcn; wgbytes[at] = rbn; } rcn += mc[i]; rbn += mb[i]; }
+        tc += t1; tb += t2;
     }
-    uint32_t tc; unsigned long long tb;
-    uint32_t rcn = wg_excl_u32(sc, lds, tc);
-    unsigned long long rbn = wg_excl_u64(sb, ldb, tb);
-#pragma unroll
-    for (int i = 0; i < 8; i++) { const uint32_t at = threadIdx.x * 8 + i; if (at < n) { wgseq[at] = rcn; wgbytes[at] = rbn; } rcn += mc[i]; rbn += mb[i]; }
     if (threadIdx.x == 0) {
         const uint32_t lc = st->last_complete;                      // number of lines up to and including the last completing one
         st->n_seq = tc;
@@ -546,7 +559,6 @@ hipError_t launch_fq_parse(hipStream_t s, const FqBuffers &B, const uint8_t *pre
     const uint32_t span = B.porch + len + 16u;
     const uint32_t nchunks = (span + FQ_CHUNK - 1) / FQ_CHUNK;
     const uint32_t nlwg = (B.line_cap + FQ_T - 1) / FQ_T;
-    if (nchunks > 8 * FQ_T || nlwg > 8 * FQ_T) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_fq_tail_in, dim3(64), dim3(256), 0, s, prev_raw, prev_state, raw, state, B.porch, len);
     hipLaunchKernelGGL(k_fq_count, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt);
     hipLaunchKernelGGL(k_fq_scan_u32, dim3(1), dim3(FQ_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);

@@ -1800,7 +1800,7 @@ static FqDev *fq_dev_for(hulk_ctx *ctx, size_t block, IngestError &err) {
     for (auto &p : d->d_off) FQ_HIP(hipMalloc((void **)&p, ((size_t)B.read_cap + 2) * 8));
     FQ_HIP(hipMalloc((void **)&d->d_state, FqDev::NST * sizeof(hulk::FqState)));
     FQ_HIP(hipHostMalloc((void **)&d->h_state, FqDev::NST * sizeof(hulk::FqState), hipHostMallocDefault));
-    const size_t nchunk = (d->raw_bytes() + 16383) / 16384 + 8, nlwg = ((size_t)B.line_cap + 1023) / 1024 + 8;
+    const size_t nchunk = (d->raw_bytes() + 4095) / 4096 + 8, nlwg = ((size_t)B.line_cap + 255) / 256 + 8;      // (hulk_fastq.hip FQ_T = 256)
     FQ_HIP(hipMalloc((void **)&B.wgcnt, nchunk * 4));
     FQ_HIP(hipMalloc((void **)&B.line_end, (size_t)B.line_cap * 4));
     FQ_HIP(hipMalloc((void **)&B.linfo, (size_t)B.line_cap * 4));
