@@ -1670,8 +1670,8 @@ int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, const Inge
 // hulk_add_reads_device.  Streams: copies on `cs`, parse kernels on `ps`, binning on the context's lanes;
 //   copy(b) -> parse(b) [after parse(b-1): the tail; after the binning of block b-2 has read the output set] -> the block's
 //   scalars reach the host -> hulk_add_reads_device(b) while copy(b+1) / parse(b+1) are already under way.
-// Buffers: 4 pinned blocks, 3 raw device blocks (porch + block), 2 output sets (bases + offsets), one set of line-index arrays
-// — 4 x 16 MiB = 64 MB pinned and about 250 MB of HBM at the default block size.  They belong to the PROCESS, not to a context: a
+// Buffers: 6 pinned blocks, 4 raw device blocks (porch + block), 3 output sets (bases + offsets), one set of line-index arrays
+// — 6 x 16 MiB = 96 MB pinned and about 300 MB of HBM at the default block size.  They belong to the PROCESS, not to a context: a
 // run borrows an idle set for its device and block size and hands it back (a `hulk sketch` per file on fresh contexts would
 // otherwise pin and unpin 64 MB per file: tens of milliseconds each).  The pool is bounded in size (FQ_POOL_MAX sets) and in AGE:
 // a set nobody borrowed for FQ_IDLE_SECONDS is freed by the next hulk_create / hulk_destroy / hulk_sketch_files of the process
@@ -1679,7 +1679,11 @@ int run_ingest(const char *const *paths, uint32_t n_paths, int fasta, const Inge
 // hulk_release_caches() frees them at once.
 // ------------------------------------------------------------------------------------------
 struct FqDev {
-    static constexpr int NRAW = 3, NOUT = 2, NHOST = 4, NST = 4;
+    // FASTQ keeps DEPTH blocks queued behind the one whose reads it hands over (with one, the PCIe link idled a third of the time:
+    // a block's copy was queued only when the parse of the block before the previous one had been waited for): a block's raw slot is
+    // its successor's tail source and, should the host parser take over, the successor's successor's — NRAW = DEPTH + 2; an output
+    // set is written again when DEPTH blocks behind it have been queued — NOUT = DEPTH + 1
+    static constexpr int DEPTH = 2, NRAW = DEPTH + 2, NOUT = DEPTH + 1, NHOST = 6, NST = 6;
     int device = 0; size_t block = 0; uint32_t porch = 0;
     double idle_since = 0.0;                                       // when the set went back to the pool (steady clock, seconds)
     hipStream_t cs = nullptr, ps = nullptr;
@@ -1975,8 +1979,8 @@ int run_ingest_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths,
             }
             if (it.len == 0) { reader.recycle(it.idx); break; }     // (end of the stream right on a block border)
             const int r = (int)(b % FqDev::NRAW), o = (int)(b % FqDev::NOUT), st = (int)(b % FqDev::NST);
-            // raw slot r held block b-3 and served block b-2 as the source of its tail
-            if (b >= 3) DEV_HIP(hipStreamWaitEvent(D->cs, D->ev_parsed[(b - 2) % FqDev::NST], 0));
+            // raw slot r held block b - NRAW and served block b - NRAW + 1 as the source of its tail
+            if (b >= (uint64_t)FqDev::NRAW) DEV_HIP(hipStreamWaitEvent(D->cs, D->ev_parsed[(b - FqDev::NRAW + 1) % FqDev::NST], 0));
             DEV_HIP(hipMemcpyAsync(D->d_raw[r] + D->porch, D->h_buf[it.idx], it.len, hipMemcpyHostToDevice, D->cs));
             DEV_HIP(hipEventRecord(D->ev_copied[it.idx], D->cs));
             DEV_HIP(hipStreamWaitEvent(D->ps, D->ev_copied[it.idx], 0));
@@ -1988,7 +1992,7 @@ int run_ingest_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths,
             DEV_HIP(hipEventRecord(D->ev_parsed[st], D->ps));
             g_trace.enqueue += PhaseTrace::now() - tb1;
             held.push_back(it);
-            if (held.size() > 1) {                                  // block b-1, while block b is copied and parsed
+            if (held.size() > (size_t)FqDev::DEPTH) {               // block b - DEPTH, while the blocks behind it are copied and parsed
                 if (!consume(first_held)) { ok = false; break; }
                 if (on_host) break;
                 reader.recycle(held.front().idx); held.pop_front(); first_held++;
@@ -1996,9 +2000,10 @@ int run_ingest_device(hulk_ctx *ctx, const char *const *paths, uint32_t n_paths,
             b++;
             if (it.eof) break;
         }
-        if (ok && !on_host && !held.empty()) {
-            if (!consume(first_held)) ok = false;
-            else if (!on_host) { reader.recycle(held.front().idx); held.pop_front(); first_held++; }
+        while (ok && !on_host && !held.empty()) {                    // the blocks still queued at the end of the stream, in order
+            if (!consume(first_held)) { ok = false; break; }
+            if (on_host) break;
+            reader.recycle(held.front().idx); held.pop_front(); first_held++;
         }
         if (ok && on_host) {
             // the blocks the device had been given but whose reads were not handed over, in order, then the rest of the stream

@@ -350,7 +350,7 @@ int hulk_debug_read(hulk_ctx *ctx, uint32_t what, void *out, uint64_t *bytes_io)
 #endif /* HULK_EXPERIMENTS */
 
 /* Process-level buffers the library keeps between calls — the device FASTQ parser's pinned and device blocks (hulk_sketch_files:
- * 64 MB pinned and about 250 MB of HBM per set at the default block size; at most two sets, and a set nobody borrowed for 10 s is
+ * 96 MB pinned and about 300 MB of HBM per set at the default block size; at most two sets, and a set nobody borrowed for 10 s is
  * freed by the process's next hulk_create / hulk_destroy / hulk_sketch_files; a set that has parsed --fasta input also holds a
  * two line indices for 2-byte lines and two accumulation buffers that grow with the longest sequence: about 0.8 GB of HBM more), the
  * host parsers' large buffers (gzip, FASTA, the

@@ -25,7 +25,8 @@ size = os.path.getsize(path)
 print("file: %d reads, %.1f MB" % (n, size / 1e6), flush=True)
 for r in range(runs):
     sk = hulk_amd.GpuSketcher(21, 9, 512, interval=100_000)
-    t0 = time.perf_counter(); st = sk.sketch_files([path]); sk.finish(); dt = time.perf_counter() - t0
+    opts = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("FQ_OPTS", "").split(",") if kv)}
+    t0 = time.perf_counter(); st = sk.sketch_files([path], opts=opts or None); sk.finish(); dt = time.perf_counter() - t0
     m5 = hashlib.md5(sk.sketch()[0].astype("<u8").tobytes()).hexdigest()[:8]
     sk.close()
     print("run %d: %.1f ms, %.3g reads/s, %.1f GB/s of file | md5 %s" % (r, dt * 1e3, n / dt, size / dt / 1e9, m5), flush=True)
