@@ -258,3 +258,41 @@ def test_device_fasta_parser_batches_and_many_records(tmp_path):
     dev = _fa_run([r], 0, k=21, w=9, S=64, block=0)
     host = _fa_run([r], HOST, k=21, w=9, S=64, block=0)
     assert dev[0] == (2, Lc + 100, rows + 3) and _same(dev, host), (dev[0], host[0])
+
+
+@pytest.mark.parametrize("fasta", [False, True])
+def test_stdin_is_sketched_like_the_file(tmp_path, fasta):
+    """`hulk sketch` without -f reads STDIN (cmd/sketch.go:98-110; pipeline/sketch.go:45-52): the same bytes through a pipe — short
+    reads at a time, no seeking — and as a file argument give the same sketch file, FASTQ and --fasta (both on the device parsers)."""
+    import json
+    from hulk_amd import synth
+    n, L = (4000, 150) if not fasta else (12, 40_000)
+    bases, _ = synth.reads_numpy(77, n, L)
+    raw = bases[:n * L].tobytes()
+    if fasta:
+        data = b"".join(b">c%d\n" % i + b"\n".join(raw[i * L + j:i * L + min(j + 70, L)] for j in range(0, L, 70)) + b"\n" for i in range(n))
+    else:
+        data = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, raw[i * L:(i + 1) * L], b"I" * L) for i in range(n))
+    p = str(tmp_path / ("in.fa" if fasta else "in.fq"))
+    open(p, "wb").write(data)
+    common = [sys.executable, "-m", "hulk_amd", "sketch", "-k", "15", "-w", "5", "-s", "24", "-i", "500" if not fasta else "3"] + (["--fasta"] if fasta else [])
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    a = subprocess.run(common + ["-f", p, "-o", str(tmp_path / "from_file")], capture_output=True, env=env, timeout=600)
+    assert a.returncode == 0, a.stderr[-2000:]
+    with open(p, "rb") as fh:
+        b = subprocess.run(common + ["-o", str(tmp_path / "from_stdin")], stdin=fh, capture_output=True, env=env, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    # a pipe, written a little at a time
+    c = subprocess.Popen(common + ["-o", str(tmp_path / "from_pipe")], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    for at in range(0, len(data), 100_003):
+        c.stdin.write(data[at:at + 100_003]); c.stdin.flush()
+    c.stdin.close()
+    assert c.wait(timeout=600) == 0, c.stderr.read()[-2000:]
+
+    def sketch_of(name):
+        d = json.load(open(tmp_path / (name + ".json")))
+        sig = d["signatures"][0]["Sketch"]
+        return sig["mins"], sig["weights"], sig["md5sum"]
+    f0 = sketch_of("from_file")
+    assert f0 == sketch_of("from_stdin") == sketch_of("from_pipe")
+    assert len(f0[0]) == 24
