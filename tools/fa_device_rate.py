@@ -12,8 +12,19 @@ runs = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 d = tempfile.mkdtemp(dir="/dev/shm")
 path = os.path.join(d, "c.fa")
 W = 60
-with open(path, "wb") as fh:
-    for i in range(n):
+short = L <= 1000                                  # reads in FASTA clothing: one sequence line per record, written in bulk
+if short:
+    with open(path, "wb") as fh:
+        for first in range(0, n, 500_000):
+            m = min(500_000, n - first)
+            bases = synth.reads_numpy(first, m, L)[0][:m * L].reshape(m, L)
+            rec = np.empty((m, 9 + L + 1), dtype=np.uint8)
+            ids = np.char.zfill(np.arange(first, first + m).astype("U7"), 7)
+            rec[:, 0] = ord(">"); rec[:, 1:8] = np.frombuffer("".join(ids).encode(), dtype=np.uint8).reshape(m, 7); rec[:, 8] = ord("\n")
+            rec[:, 9:9 + L] = bases; rec[:, 9 + L] = ord("\n")
+            fh.write(rec.tobytes())
+with open(path, "ab" if short else "wb") as fh:
+    for i in range(0 if short else n):
         seq = synth.reads_numpy(i, 1, L)[0][:L]
         rows = (L + W - 1) // W
         buf = np.full((rows, W + 1), ord("\n"), dtype=np.uint8)
