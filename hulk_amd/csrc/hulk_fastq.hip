@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void k_fq_tail_in(const uint8_t *__restrict__ 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tl; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-__global__ __launch_bounds__(FQ_T) void k_fq_count(const uint8_t *__restrict__ raw, const FqState *__restrict__ st,
+template <class ST>                                            // FqState / FaState: start, end, n_lines, need_host
+__global__ __launch_bounds__(FQ_T) void k_fq_count(const uint8_t *__restrict__ raw, const ST *__restrict__ st,
                                                    uint32_t *__restrict__ wgcnt) {
     __shared__ uint32_t red[FQ_T / 64];
     const uint32_t lo = st->start, hi = st->end, a0 = lo & ~15u;
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(FQ_T) void k_fq_count(const uint8_t *__restrict__ r
 }
 
 // exclusive scan of the n workgroup counts in place (8 * FQ_T per trip); the total goes to n_lines (clamped to cap -> need_host)
-__global__ __launch_bounds__(FQ_T) void k_fq_scan_u32(uint32_t *__restrict__ v, uint32_t n, FqState *st, uint32_t cap) {
+template <class ST>
+__global__ __launch_bounds__(FQ_T) void k_fq_scan_u32(uint32_t *__restrict__ v, uint32_t n, ST *st, uint32_t cap) {
     __shared__ uint32_t lds[FQ_T / 64 + 1];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < n; base += 8u * FQ_T) {
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(FQ_T) void k_fq_scan_u32(uint32_t *__restrict__ v, 
     }
 }
 
-__global__ __launch_bounds__(FQ_T) void k_fq_lines(const uint8_t *__restrict__ raw, const FqState *__restrict__ st,
+template <class ST>
+__global__ __launch_bounds__(FQ_T) void k_fq_lines(const uint8_t *__restrict__ raw, const ST *__restrict__ st,
                                                    const uint32_t *__restrict__ wgbase, uint32_t *__restrict__ line_end, uint32_t cap) {
     __shared__ uint32_t lds[FQ_T / 64 + 1];
     const uint32_t lo = st->start, hi = st->end, a0 = lo & ~15u;
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void k_fq_copy(const uint8_t *__restrict__ raw
 // ------------------------------------------------------------------------------------------
 // FASTA (hulk_fastq.h).  A block in two steps — index (everything that depends on the block's own bytes only) and place (the
 // copy into the accumulation buffer, once the host knows where the blocks before left it):
-//   k_fa_count / k_fa_scan_lines / k_fa_lines    the newline index, as the FASTQ parser's, in 256-thread workgroups
+//   k_fq_count / k_fq_scan_u32 / k_fq_lines      the newline index: the FASTQ parser's kernels
 //   k_fa_class   per line: length (CR dropped), first byte; the first empty line and the first line of 64 KiB or more (atomicMin)
 //   k_fa_flags / k_fa_scan    header lines and sequence bytes in front of the first of those, per workgroup -> prefix sums
 //   k_fa_emit    a sequence line's destination and a header's position, both in bytes from the block's first sequence byte
@@ -350,58 +353,11 @@ __global__ __launch_bounds__(256) void k_fa_begin(const uint8_t *__restrict__ pr
 }
 
 
-// The FASTA chain runs beside the context's binning kernels (k_long_tile fills every CU with 256-thread workgroups and leaves a few
-// wave slots free): its kernels use 256-thread workgroups, which find room at once — a 1024-thread workgroup waits until half a CU
-// happens to be free (measured: the one-workgroup scans went from 15 to 200 us).
-constexpr int FA_T = 256;
-constexpr uint32_t FA_CHUNK = FA_T * 16;
-
-__global__ __launch_bounds__(FA_T) void k_fa_count(const uint8_t *__restrict__ raw, const FaState *__restrict__ st, uint32_t *__restrict__ wgcnt) {
-    __shared__ uint32_t red[FA_T / 64];
-    const uint32_t lo = st->start, hi = st->end, a0 = lo & ~15u;
-    const uint32_t addr = a0 + blockIdx.x * FA_CHUNK + threadIdx.x * 16u;
-    if (a0 + blockIdx.x * FA_CHUNK >= hi) { if (threadIdx.x == 0) wgcnt[blockIdx.x] = 0; return; }
-    uint32_t c = (uint32_t)__popc(newline_mask(raw, addr, lo, hi));
-    for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t t = 0; for (int i = 0; i < FA_T / 64; i++) t += red[i]; wgcnt[blockIdx.x] = t; }
-}
-// exclusive scan of the n chunk counts in place (16 * FA_T per trip); the total -> n_lines (clamped to cap)
-__global__ __launch_bounds__(FA_T) void k_fa_scan_lines(uint32_t *__restrict__ v, uint32_t n, FaState *st, uint32_t cap) {
-    __shared__ uint32_t lds[FA_T / 64 + 1];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 16u * FA_T) {
-        uint32_t mine[16], sum = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { const uint32_t at = base + threadIdx.x * 16 + i; mine[i] = at < n ? v[at] : 0u; sum += mine[i]; }
-        uint32_t total;
-        uint32_t run = carry + wg_excl_u32<FA_T>(sum, lds, total);
-#pragma unroll
-        for (int i = 0; i < 16; i++) { const uint32_t at = base + threadIdx.x * 16 + i; if (at < n) v[at] = run; run += mine[i]; }
-        carry += total;
-    }
-    if (threadIdx.x == 0) {
-        if (carry > cap) { st->need_host |= FQ_NEED_LINES; carry = cap; }
-        st->n_lines = carry;
-    }
-}
-__global__ __launch_bounds__(FA_T) void k_fa_lines(const uint8_t *__restrict__ raw, const FaState *__restrict__ st, const uint32_t *__restrict__ wgbase,
-                                                   uint32_t *__restrict__ line_end, uint32_t cap) {
-    __shared__ uint32_t lds[FA_T / 64 + 1];
-    const uint32_t lo = st->start, hi = st->end, a0 = lo & ~15u;
-    if (a0 + blockIdx.x * FA_CHUNK >= hi) return;
-    const uint32_t addr = a0 + blockIdx.x * FA_CHUNK + threadIdx.x * 16u;
-    uint32_t m = newline_mask(raw, addr, lo, hi);
-    uint32_t total;
-    uint32_t at = wgbase[blockIdx.x] + wg_excl_u32<FA_T>((uint32_t)__popc(m), lds, total);
-    while (m) {
-        const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
-        m &= m - 1u;
-        if (at < cap) line_end[at] = addr + b;
-        at++;
-    }
-}
+// The chain runs beside the context's binning kernels (k_long_tile fills every CU with 256-thread workgroups and leaves a few
+// wave slots free): 256-thread workgroups (FQ_T) find room at once — a 1024-thread workgroup waited until half a CU happened to
+// be free (measured: the one-workgroup scans went from 15 to 200 us).
+constexpr int FA_T = FQ_T;
+constexpr uint32_t FA_CHUNK = FQ_CHUNK;
 
 __global__ __launch_bounds__(FA_T) void k_fa_class(const uint8_t *__restrict__ raw, FaState *st, const uint32_t *__restrict__ line_end,
                                                    uint32_t *__restrict__ linfo) {
@@ -560,9 +516,9 @@ hipError_t launch_fq_parse(hipStream_t s, const FqBuffers &B, const uint8_t *pre
     const uint32_t nchunks = (span + FQ_CHUNK - 1) / FQ_CHUNK;
     const uint32_t nlwg = (B.line_cap + FQ_T - 1) / FQ_T;
     hipLaunchKernelGGL(k_fq_tail_in, dim3(64), dim3(256), 0, s, prev_raw, prev_state, raw, state, B.porch, len);
-    hipLaunchKernelGGL(k_fq_count, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt);
-    hipLaunchKernelGGL(k_fq_scan_u32, dim3(1), dim3(FQ_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
-    hipLaunchKernelGGL(k_fq_lines, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
+    hipLaunchKernelGGL(k_fq_count<FqState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt);
+    hipLaunchKernelGGL(k_fq_scan_u32<FqState>, dim3(1), dim3(FQ_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
+    hipLaunchKernelGGL(k_fq_lines<FqState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
     hipLaunchKernelGGL(k_fq_class, dim3(nlwg), dim3(FQ_T), 0, s, raw, state, B.line_end, B.linfo, B.lmap, B.wgmap);
     hipLaunchKernelGGL(k_fq_scan_maps, dim3(1), dim3(FQ_T), 0, s, B.wgmap, nlwg, B.wgstate, state);
     hipLaunchKernelGGL(k_fq_flags, dim3(nlwg), dim3(FQ_T), 0, s, state, B.linfo, B.lmap, B.wgstate, B.wgseq, B.wgbytes);
@@ -579,9 +535,9 @@ hipError_t launch_fa_index(hipStream_t s, const FaBuffers &B, const uint8_t *pre
     const uint32_t nchunks = (span + FA_CHUNK - 1) / FA_CHUNK;
     const uint32_t nlwg = (B.line_cap + FA_T - 1) / FA_T;
     hipLaunchKernelGGL(k_fa_begin, dim3(64), dim3(256), 0, s, prev_raw, prev_state, raw, state, B.porch, len);
-    hipLaunchKernelGGL(k_fa_count, dim3(nchunks), dim3(FA_T), 0, s, raw, state, B.wgcnt);
-    hipLaunchKernelGGL(k_fa_scan_lines, dim3(1), dim3(FA_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
-    hipLaunchKernelGGL(k_fa_lines, dim3(nchunks), dim3(FA_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
+    hipLaunchKernelGGL(k_fq_count<FaState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt);
+    hipLaunchKernelGGL(k_fq_scan_u32<FaState>, dim3(1), dim3(FQ_T), 0, s, B.wgcnt, nchunks, state, B.line_cap);
+    hipLaunchKernelGGL(k_fq_lines<FaState>, dim3(nchunks), dim3(FQ_T), 0, s, raw, state, B.wgcnt, B.line_end, B.line_cap);
     // a block of 60-byte lines has 1/30 of line_cap: the grids are sized for lines of 16 bytes, the kernels take more trips over shorter ones
     const uint32_t glw = std::min<uint32_t>(nlwg, (span / 16u + FA_T - 1) / FA_T + 1u);
     hipLaunchKernelGGL(k_fa_class, dim3(glw), dim3(FA_T), 0, s, raw, state, B.line_end, B.linfo);
