@@ -15,7 +15,10 @@
 //                   stays in the tail
 //   k_fq_copy       the sequences, back to back: the (bases, offsets) layout hulk_add_reads_device takes
 //
-// What the device does NOT decide: anything the reference turns into an error or that outgrows the fixed buffers — a header
+// --fasta (sketch.go:102-135) is the second half of this file (k_fa_*): same newline index, no slot machine — sequence lines are
+// compacted to the end of an accumulation buffer that outlives the block, header lines become the record offsets.
+//
+// What the device does NOT decide (FASTQ): anything the reference turns into an error or that outgrows the fixed buffers — a header
 // line that does not begin with '@' (seqio.go:38-40), a line of 64 KiB or more (bufio.Scanner: token too long), more lines
 // than the index holds, a tail longer than the porch.  The block is then flagged `need_host` and the host parser
 // (hulk_ingest.hip, the comparator of tools/fuzz_ingest.py) takes the stream over from the last record boundary, with the
